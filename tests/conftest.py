@@ -1,0 +1,80 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def librosa_goldens():
+    return np.load(os.path.join(GOLDEN, "librosa_goldens.npz"))
+
+
+@pytest.fixture(scope="session")
+def sox_goldens():
+    return np.load(os.path.join(GOLDEN, "sox_goldens.npz"))
+
+
+class RefRuns:
+    """Outputs of the reference implementation itself (tests/golden/make_golden.py)."""
+
+    def __init__(self):
+        self.arrays = np.load(os.path.join(GOLDEN, "reference_runs.npz"))
+        with open(os.path.join(GOLDEN, "reference_runs.json")) as f:
+            self.meta = json.load(f)
+        self.cases = self.meta["cases"]
+
+    def select(self, op):
+        return [c for c in self.cases if c["op"] == op]
+
+    def inputs(self, case):
+        return [self.arrays[k] for k in case["inputs"]]
+
+    def output(self, case):
+        return self.arrays[f"c{case['id']}_out"]
+
+
+_REF = None
+
+
+def ref_runs():
+    global _REF
+    if _REF is None:
+        _REF = RefRuns()
+    return _REF
+
+
+@pytest.fixture(scope="session", name="ref_runs")
+def ref_runs_fixture():
+    return ref_runs()
+
+
+def peak_rel_err(a, b):
+    """max|a-b| / max|b| -- the north-star parity metric."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.size == 0:
+        return 0.0
+    d = np.max(np.abs(a.astype(np.complex128) - b.astype(np.complex128)))
+    m = np.max(np.abs(b))
+    return float(d / m) if m > 0 else float(d)
+
+
+def floor_rel_err(a, b, floor=1e-6):
+    """element-wise relative error above a floor of `floor`*max|b|."""
+    a = np.asarray(a, dtype=np.complex128)
+    b = np.asarray(b, dtype=np.complex128)
+    m = np.max(np.abs(b)) if b.size else 0.0
+    den = np.maximum(np.abs(b), floor * m)
+    return float(np.max(np.abs(a - b) / den)) if b.size else 0.0
