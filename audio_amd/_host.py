@@ -1,0 +1,197 @@
+"""Host-side (init-time) constants for the HIP kernels: twiddle tables, centre-padded
+windows, banded mel filterbanks, DCT matrices, windowed-sinc resampling kernels.
+
+These are small, computed once per configuration on the CPU exactly as the reference
+computes its own ``register_buffer`` constants, then uploaded.  Nothing here is on the
+per-call data path.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+# --------------------------------------------------------------------------- #
+# FFT twiddles                                                                #
+# --------------------------------------------------------------------------- #
+
+
+def twiddle_table(n_fft: int) -> np.ndarray:
+    """float32 [n_fft, 2] = (cos, -sin)(2 pi t / n_fft), evaluated in float64."""
+    t = np.arange(n_fft, dtype=np.float64)
+    # exact quadrant symmetry: reduce the angle before cos/sin
+    ang = 2.0 * np.pi * t / n_fft
+    tw = np.stack([np.cos(ang), -np.sin(ang)], axis=1)
+    return tw.astype(np.float32)
+
+
+def frame_count(length: int, n_fft: int, hop: int, center: bool, pad: int = 0) -> int:
+    lp = length + 2 * pad + (2 * (n_fft // 2) if center else 0)
+    return 1 + (lp - n_fft) // hop
+
+
+def center_pad_window(window: torch.Tensor, n_fft: int) -> torch.Tensor:
+    """aten::stft zero-pads a short window to n_fft, centred (left = (n_fft - win_length)//2)."""
+    wl = window.shape[0]
+    if wl == n_fft:
+        return window
+    left = (n_fft - wl) // 2
+    return torch.nn.functional.pad(window, (left, n_fft - wl - left))
+
+
+# --------------------------------------------------------------------------- #
+# mel filterbank (reference: functional/functional.py:425-587)                #
+# --------------------------------------------------------------------------- #
+
+
+def _hz_to_mel(freq: float, mel_scale: str = "htk") -> float:
+    if mel_scale not in ["slaney", "htk"]:
+        raise ValueError('mel_scale should be one of "htk" or "slaney".')
+    if mel_scale == "htk":
+        return 2595.0 * math.log10(1.0 + (freq / 700.0))
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    if freq >= min_log_hz:
+        return min_log_hz / f_sp + math.log(freq / min_log_hz) / (math.log(6.4) / 27.0)
+    return freq / f_sp
+
+
+def _mel_to_hz(mels: torch.Tensor, mel_scale: str = "htk") -> torch.Tensor:
+    if mel_scale not in ["slaney", "htk"]:
+        raise ValueError('mel_scale should be one of "htk" or "slaney".')
+    if mel_scale == "htk":
+        return 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+    f_sp = 200.0 / 3
+    freqs = f_sp * mels
+    min_log_mel = 1000.0 / f_sp
+    logstep = math.log(6.4) / 27.0
+    is_log = mels >= min_log_mel
+    freqs[is_log] = 1000.0 * torch.exp(logstep * (mels[is_log] - min_log_mel))
+    return freqs
+
+
+def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int,
+                    norm: Optional[str] = None, mel_scale: str = "htk") -> torch.Tensor:
+    """Triangular mel filterbank (n_freqs, n_mels), float32 torch CPU ops in the same order as
+    the reference so the buffer is bit-identical to torchaudio's ``fb``."""
+    if norm is not None and norm != "slaney":
+        raise ValueError('norm must be one of None or "slaney"')
+    bin_hz = torch.linspace(0, sample_rate // 2, n_freqs)
+    mel_lo = _hz_to_mel(f_min, mel_scale=mel_scale)
+    mel_hi = _hz_to_mel(f_max, mel_scale=mel_scale)
+    edges_hz = _mel_to_hz(torch.linspace(mel_lo, mel_hi, n_mels + 2), mel_scale=mel_scale)
+    gaps = edges_hz[1:] - edges_hz[:-1]                         # (n_mels + 1)
+    dist = edges_hz.unsqueeze(0) - bin_hz.unsqueeze(1)          # (n_freqs, n_mels + 2)
+    falling = (-1.0 * dist[:, :-2]) / gaps[:-1]
+    rising = dist[:, 2:] / gaps[1:]
+    fb = torch.max(torch.zeros(1), torch.min(falling, rising))
+    if norm == "slaney":
+        fb *= (2.0 / (edges_hz[2:n_mels + 2] - edges_hz[:n_mels])).unsqueeze(0)
+    if (fb.max(dim=0).values == 0.0).any():
+        warnings.warn(
+            "At least one mel filterbank has all zero values. "
+            f"The value for `n_mels` ({n_mels}) may be set too high. "
+            f"Or, the value for `n_freqs` ({n_freqs}) may be set too low."
+        )
+    return fb
+
+
+def mel_band_table(fb: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray, int]:
+    """Banded view of ANY fb[n_freq, n_mels]: per column first/last non-zero row.
+    Returns (lo int32[M], width int32[M], weights float32[M, max_width], max_width)."""
+    fb = np.asarray(fb, dtype=np.float32)
+    n_freq, n_mels = fb.shape
+    nz = fb != 0
+    any_nz = nz.any(axis=0)
+    lo = np.where(any_nz, nz.argmax(axis=0), 0).astype(np.int32)
+    hi = np.where(any_nz, n_freq - 1 - nz[::-1].argmax(axis=0), -1).astype(np.int32)
+    width = np.where(any_nz, hi - lo + 1, 0).astype(np.int32)
+    max_width = max(1, int(width.max()) if n_mels else 1)
+    weights = np.zeros((n_mels, max_width), dtype=np.float32)
+    for m in range(n_mels):
+        w = int(width[m])
+        if w:
+            weights[m, :w] = fb[lo[m]:lo[m] + w, m]
+    return lo, width, weights, max_width
+
+
+# --------------------------------------------------------------------------- #
+# DCT (reference: functional/functional.py:636-667)                           #
+# --------------------------------------------------------------------------- #
+
+
+def create_dct(n_mfcc: int, n_mels: int, norm: Optional[str]) -> torch.Tensor:
+    if norm is not None and norm != "ortho":
+        raise ValueError('norm must be either "ortho" or None')
+    n = torch.arange(float(n_mels))
+    k = torch.arange(float(n_mfcc)).unsqueeze(1)
+    basis = torch.cos(math.pi / float(n_mels) * (n + 0.5) * k)   # (n_mfcc, n_mels)
+    if norm is None:
+        basis *= 2.0
+    else:
+        basis[0] *= 1.0 / math.sqrt(2.0)
+        basis *= math.sqrt(2.0 / float(n_mels))
+    return basis.t()
+
+
+# --------------------------------------------------------------------------- #
+# windowed-sinc resampling kernel (reference: functional/functional.py:1305-1402)
+# --------------------------------------------------------------------------- #
+
+_DEPRECATED_METHODS = {"sinc_interpolation": "sinc_interp_hann", "kaiser_window": "sinc_interp_kaiser"}
+
+
+def sinc_resample_kernel(orig_freq: int, new_freq: int, gcd: int, lowpass_filter_width: int = 6,
+                         rolloff: float = 0.99, resampling_method: str = "sinc_interp_hann",
+                         beta: Optional[float] = None, dtype: Optional[torch.dtype] = None):
+    """CPU evaluation with the reference's dtype rules: ``dtype=None`` (Transform) evaluates the
+    index grid in float64 and casts the result to float32; an explicit dtype (functional path)
+    evaluates everything in that dtype.  Returns (kernel[new, 1, 2*width+orig], width)."""
+    if not (int(orig_freq) == orig_freq and int(new_freq) == new_freq):
+        raise Exception(
+            "Frequencies must be of integer type to ensure quality resampling computation. "
+            "To work around this, manually convert both frequencies to integer values "
+            "that maintain their resampling rate ratio before passing them into the function. "
+            "Example: To downsample a 44100 hz waveform by a factor of 8, use "
+            "`orig_freq=8` and `new_freq=1` instead of `orig_freq=44100` and `new_freq=5512.5`. "
+            "For more information, please refer to https://github.com/pytorch/audio/issues/1487."
+        )
+    if resampling_method in _DEPRECATED_METHODS:
+        warnings.warn(
+            f'"{resampling_method}" resampling method name is being deprecated and replaced by '
+            f'"{_DEPRECATED_METHODS[resampling_method]}" in the next release. '
+            "The default behavior remains unchanged.",
+            stacklevel=3,
+        )
+    elif resampling_method not in ["sinc_interp_hann", "sinc_interp_kaiser"]:
+        raise ValueError("Invalid resampling method: {}".format(resampling_method))
+
+    orig = int(orig_freq) // gcd
+    new = int(new_freq) // gcd
+    if lowpass_filter_width <= 0:
+        raise ValueError("Low pass filter width should be positive.")
+    cutoff = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / cutoff)
+
+    grid_dtype = dtype if dtype is not None else torch.float64
+    grid = torch.arange(-width, width + orig, dtype=grid_dtype)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=dtype)[:, None, None] / new + grid
+    t *= cutoff
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    if resampling_method in ("sinc_interp_hann", "sinc_interpolation"):
+        taper = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    else:
+        if beta is None:
+            beta = 14.769656459379492
+        beta_t = torch.tensor(float(beta))
+        taper = torch.i0(beta_t * torch.sqrt(1 - (t / lowpass_filter_width) ** 2)) / torch.i0(beta_t)
+    t *= math.pi
+    gain = cutoff / orig
+    kern = torch.where(t == 0, torch.tensor(1.0).to(t), t.sin() / t)
+    kern *= taper * gain
+    if dtype is None:
+        kern = kern.to(dtype=torch.float32)
+    return kern, width

@@ -1,0 +1,98 @@
+"""ctypes binding of libaudio_amd.so (the C ABI declared in include/audio_amd.h).
+
+The shared library is built in-tree by ``python -m audio_amd._build`` (or
+``__graft_entry__.build()``) with ``hipcc --offload-arch=gfx950``.  There is NO
+fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libaudio_amd.so")
+
+AAMD_OK = 0
+PAD_MODES = {"reflect": 0, "constant": 1, "replicate": 2, "circular": 3}
+
+
+class StftDesc(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int64), ("length", C.c_int64), ("row_stride", C.c_int64),
+        ("n_fft", C.c_int32), ("hop", C.c_int32), ("pad", C.c_int32), ("center", C.c_int32),
+        ("pad_mode", C.c_int32), ("onesided", C.c_int32), ("n_frames", C.c_int32),
+        ("scale", C.c_float), ("power", C.c_float),
+    ]
+
+
+class MelBands(C.Structure):
+    _fields_ = [
+        ("n_mels", C.c_int32), ("max_width", C.c_int32),
+        ("lo", C.c_void_p), ("width", C.c_void_p), ("weights", C.c_void_p),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+_P = C.c_void_p
+_SIGS = {
+    "aamd_abi_version": (C.c_int, []),
+    "aamd_last_error": (C.c_char_p, []),
+    "aamd_device_info": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "aamd_spectrogram_f32": (C.c_int, [_P, _P, _P, _P, C.POINTER(StftDesc), _P]),
+    "aamd_melspectrogram_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), _P]),
+    "aamd_mel_scale_f32": (C.c_int, [_P, C.POINTER(MelBands), _P, C.c_int64, C.c_int32, C.c_int32, _P]),
+    "aamd_amplitude_to_db_f32": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P]),
+    "aamd_db_clamp_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_float, _P]),
+    "aamd_mfcc_dct_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64,
+                                    C.c_float, _P]),
+    "aamd_resample_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int64, _P]),
+    "aamd_lfilter_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, _P]),
+    "aamd_fftconvolve_workspace": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "aamd_fftconvolve_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, C.c_int64,
+                                       C.c_int64, _P, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"audio_amd: {LIB_PATH} not found. Build the HIP extension first "
+                    "(python -m audio_amd._build). There is no CPU fallback.")
+            h = C.CDLL(LIB_PATH)
+            for name, (res, args) in _SIGS.items():
+                fn = getattr(h, name)   # AttributeError if the ABI symbol is missing
+                fn.restype = res
+                fn.argtypes = args
+            if h.aamd_abi_version() != 1:
+                raise RuntimeError("audio_amd: ABI version mismatch between _lib.py and libaudio_amd.so")
+            _lib = h
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != AAMD_OK:
+        msg = lib().aamd_last_error()
+        raise RuntimeError((msg or b"audio_amd: unknown error").decode())
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (0-size tensors give a dummy non-null pointer)."""
+    return t.data_ptr() if t.numel() else 0
+
+
+def current_stream(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,382 @@
+// C ABI of libaudio_amd.so (see include/audio_amd.h): argument validation + kernel launches.
+// No torch dependency, no global mutable state except a thread-local error string and a
+// per-process cache of immutable device properties.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "../../include/audio_amd.h"
+#include "db_mfcc.h"
+#include "fftconv.h"
+#include "lfilter.h"
+#include "melspec400.h"
+#include "resample.h"
+#include "stft_generic.h"
+
+using namespace aamd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define AAMD_CHECK_ARG(cond, msg) \
+  do { if (!(cond)) return fail(AAMD_EINVAL, std::string("audio_amd: ") + msg); } while (0)
+
+#define AAMD_HIP(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(AAMD_EHIP, std::string("audio_amd: HIP error: ") + hipGetErrorString(e_) + \
+                                 " at " #expr);                                          \
+  } while (0)
+
+int launch_check() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(AAMD_EHIP, std::string("audio_amd: kernel launch failed: ") + hipGetErrorString(e));
+  return AAMD_OK;
+}
+
+struct DevProps {
+  int cu_count = 0;
+  size_t lds_per_block = 0;
+  bool ok = false;
+};
+
+DevProps& dev_props() {
+  static DevProps props[64];
+  static std::mutex mu;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  DevProps& p = props[dev];
+  if (!p.ok) {
+    hipDeviceProp_t dp;
+    if (hipGetDeviceProperties(&dp, dev) == hipSuccess) {
+      p.cu_count = dp.multiProcessorCount;
+      p.lds_per_block = dp.sharedMemPerBlock;
+      p.ok = true;
+    } else {
+      p.cu_count = 256;
+      p.lds_per_block = 64 * 1024;
+    }
+  }
+  return p;
+}
+
+int frames_expected(const aamd_stft_desc* d) {
+  int64_t lp = d->length + 2 * (int64_t)d->pad + (d->center ? 2 * (int64_t)(d->n_fft / 2) : 0);
+  if (lp < d->n_fft) return -1;
+  return (int)(1 + (lp - d->n_fft) / d->hop);
+}
+
+int validate_desc(const aamd_stft_desc* d, StftGeom& g) {
+  AAMD_CHECK_ARG(d != nullptr, "null stft desc");
+  AAMD_CHECK_ARG(d->rows >= 0 && d->length >= 0, "negative sizes");
+  AAMD_CHECK_ARG(d->n_fft >= 1 && d->hop >= 1 && d->pad >= 0, "n_fft, hop must be >= 1 and pad >= 0");
+  AAMD_CHECK_ARG(d->row_stride >= d->length, "row_stride < length");
+  AAMD_CHECK_ARG(d->pad_mode >= 0 && d->pad_mode <= 3, "bad pad_mode");
+  if (d->n_fft > 8192) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft > 8192 not supported");
+  const int64_t l1 = d->length + 2 * (int64_t)d->pad;
+  if (d->center && d->pad_mode == AAMD_PAD_REFLECT)
+    AAMD_CHECK_ARG(d->n_fft / 2 < l1, "reflect padding needs n_fft/2 < padded length");
+  if (d->center && d->pad_mode == AAMD_PAD_CIRCULAR)
+    AAMD_CHECK_ARG(d->n_fft / 2 <= l1, "circular padding needs n_fft/2 <= padded length");
+  if (d->center && d->pad_mode == AAMD_PAD_REPLICATE) AAMD_CHECK_ARG(l1 >= 1, "empty input");
+  const int T = frames_expected(d);
+  AAMD_CHECK_ARG(T >= 1, "input shorter than n_fft");
+  AAMD_CHECK_ARG(T == d->n_frames, "n_frames does not match 1 + (L' - n_fft)/hop");
+  g.rows = d->rows; g.length = d->length; g.row_stride = d->row_stride;
+  g.n_fft = d->n_fft; g.hop = d->hop; g.pad = d->pad; g.center = d->center;
+  g.pad_mode = d->pad_mode; g.onesided = d->onesided; g.n_frames = d->n_frames;
+  g.n_freq = d->onesided ? d->n_fft / 2 + 1 : d->n_fft;
+  g.scale = d->scale; g.power = d->power;
+  g.n_stages = plan_radices(d->n_fft, g.radix);
+  if (g.n_stages < 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft has too many prime factors");
+  return AAMD_OK;
+}
+
+int validate_bands(const aamd_mel_bands* b, int n_freq, MelBandsDev& mb) {
+  AAMD_CHECK_ARG(b != nullptr, "null mel bands");
+  AAMD_CHECK_ARG(b->n_mels >= 1 && b->max_width >= 1 && b->max_width <= n_freq, "bad mel band table");
+  AAMD_CHECK_ARG(b->lo && b->width && b->weights, "null mel band pointers");
+  mb.n_mels = b->n_mels; mb.max_width = b->max_width;
+  mb.lo = b->lo; mb.width = b->width; mb.weights = b->weights;
+  return AAMD_OK;
+}
+
+template <int EPI>
+int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
+                   const float* twiddle, float* out, hipStream_t s) {
+  if (g.rows == 0) return AAMD_OK;
+  const int fpb = 4;
+  const int bpr = (g.n_frames + fpb - 1) / fpb;
+  const int64_t blocks = g.rows * bpr;
+  AAMD_CHECK_ARG(blocks < (1ll << 31), "too many frames for one launch");
+  const size_t lds = (size_t)2 * g.n_fft * sizeof(cplx<float>) + (size_t)g.n_freq * sizeof(float);
+  auto kern = stft_generic_kernel<float, EPI>;
+  if (lds > 48 * 1024)
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, g, wav, window,
+                     reinterpret_cast<const cplx<float>*>(twiddle), mb, out, fpb, bpr);
+  return launch_check();
+}
+
+bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
+  return g.n_fft == 400 && g.hop == 160 && g.center && g.pad_mode == AAMD_PAD_REFLECT &&
+         g.onesided && g.pad == 0 && g.power == 2.0f && g.length > 400 && mb.n_mels <= 1024;
+}
+
+int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
+                  const float* twiddle, float* out, hipStream_t s) {
+  if (g.rows == 0) return AAMD_OK;
+  const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
+  const int64_t n_tiles = g.rows * tiles_per_row;
+  const size_t lds = (size_t)4 * m400::kLdsDwordsPerWave * sizeof(float);
+  static thread_local int occ_cache = 0;
+  if (occ_cache == 0) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, m400::melspec400_kernel, 256, lds) != hipSuccess || occ < 1)
+      occ = 2;
+    occ_cache = occ;
+  }
+  int64_t blocks = (int64_t)dev_props().cu_count * occ_cache;
+  const int64_t need = (n_tiles + 3) / 4;
+  if (blocks > need) blocks = need;
+  if (blocks >= 8) blocks -= blocks % 8;  // XCD remap wants a multiple of 8
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(m400::melspec400_kernel, dim3((unsigned)blocks), dim3(256), lds, s, wav, window,
+                     twiddle, mb, out, g.rows, g.length, g.row_stride, g.n_frames, g.scale,
+                     tiles_per_row, n_tiles, 0);
+  return launch_check();
+}
+
+int grid_for(int64_t n, int per_block, int max_blocks) {
+  int64_t b = (n + per_block - 1) / per_block;
+  if (b > max_blocks) b = max_blocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <int D>
+int launch_lfilter(const float* x, const float* a, const float* b, float* y, int64_t n_seq,
+                   int channels, int64_t length, int n_order, int n_rows, int n_stages, int clamp,
+                   hipStream_t s) {
+  using L = LfLds<D>;
+  const size_t lds = ((size_t)L::total + (size_t)n_stages * (L::total - L::H)) * sizeof(float);
+  if (lds > 160 * 1024) return fail(AAMD_EUNSUPPORTED, "audio_amd: lfilter cascade too long for LDS");
+  auto kern = lfilter_kernel<D>;
+  if (lds > 48 * 1024)
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int blocks = grid_for(n_seq, 1, dev_props().cu_count * 8);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(kLfThreads), lds, s, x, a, b, y, n_seq, channels,
+                     length, n_order, n_rows, n_stages, clamp);
+  return launch_check();
+}
+
+}  // namespace
+
+extern "C" {
+
+int aamd_abi_version(void) { return AAMD_ABI_VERSION; }
+
+const char* aamd_last_error(void) { return g_err.c_str(); }
+
+int aamd_device_info(char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes) {
+  int dev = 0;
+  AAMD_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t dp;
+  AAMD_HIP(hipGetDeviceProperties(&dp, dev));
+  if (name && name_len > 0) {
+    std::snprintf(name, (size_t)name_len, "%s", dp.gcnArchName);
+  }
+  if (cu_count) *cu_count = dp.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)dp.totalGlobalMem;
+  return AAMD_OK;
+}
+
+int aamd_spectrogram_f32(const float* wav, const float* window, const float* twiddle, float* out,
+                         const aamd_stft_desc* desc, void* stream) {
+  StftGeom g;
+  int rc = validate_desc(desc, g);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(wav && window && twiddle && out, "null buffer");
+  MelBandsDev mb{};
+  return launch_generic<EPI_SPEC>(g, mb, wav, window, twiddle, out, (hipStream_t)stream);
+}
+
+int aamd_melspectrogram_f32(const float* wav, const float* window, const float* twiddle,
+                            const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
+                            void* stream) {
+  StftGeom g;
+  int rc = validate_desc(desc, g);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(wav && window && twiddle && out, "null buffer");
+  AAMD_CHECK_ARG(desc->power > 0.0f, "mel spectrogram needs power > 0");
+  AAMD_CHECK_ARG(desc->onesided, "mel spectrogram needs a onesided spectrum");
+  MelBandsDev mb;
+  rc = validate_bands(bands, g.n_freq, mb);
+  if (rc != AAMD_OK) return rc;
+  if (mel400_eligible(g, mb) && std::getenv("AAMD_FORCE_GENERIC") == nullptr)
+    return launch_mel400(g, mb, wav, window, twiddle, out, (hipStream_t)stream);
+  return launch_generic<EPI_MEL>(g, mb, wav, window, twiddle, out, (hipStream_t)stream);
+}
+
+int aamd_mel_scale_f32(const float* spec, const aamd_mel_bands* bands, float* out, int64_t rows,
+                       int32_t n_frames, int32_t n_freq, void* stream) {
+  AAMD_CHECK_ARG(spec && out, "null buffer");
+  AAMD_CHECK_ARG(rows >= 0 && n_frames >= 0 && n_freq >= 1, "bad sizes");
+  MelBandsDev mb;
+  int rc = validate_bands(bands, n_freq, mb);
+  if (rc != AAMD_OK) return rc;
+  const int64_t n_vec = rows * n_frames;
+  if (n_vec == 0) return AAMD_OK;
+  const int blocks = grid_for(n_vec * mb.n_mels, 256, dev_props().cu_count * 16);
+  hipLaunchKernelGGL(mel_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, spec, mb, out,
+                     n_vec, n_freq);
+  return launch_check();
+}
+
+int aamd_amplitude_to_db_f32(const float* x, float* out, int64_t n, float multiplier, float amin,
+                             float db_multiplier, float* group_max, int64_t group_size, void* stream) {
+  AAMD_CHECK_ARG(x && out, "null buffer");
+  AAMD_CHECK_ARG(n >= 0, "negative size");
+  AAMD_CHECK_ARG(group_max == nullptr || group_size >= 1, "group_size must be >= 1");
+  if (n == 0) return AAMD_OK;
+  const int blocks = grid_for(n, 256, dev_props().cu_count * 16);
+  hipLaunchKernelGGL(amplitude_to_db_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, n,
+                     multiplier, amin, db_multiplier, group_max, group_size < 1 ? 1 : group_size);
+  return launch_check();
+}
+
+int aamd_db_clamp_f32(const float* x, float* out, int64_t n, const float* group_max,
+                      int64_t group_size, float top_db, void* stream) {
+  AAMD_CHECK_ARG(x && out && group_max, "null buffer");
+  AAMD_CHECK_ARG(n >= 0 && group_size >= 1, "bad sizes");
+  if (n == 0) return AAMD_OK;
+  const int blocks = grid_for(n, 256, dev_props().cu_count * 16);
+  hipLaunchKernelGGL(db_clamp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, n,
+                     group_max, group_size, top_db);
+  return launch_check();
+}
+
+int aamd_mfcc_dct_f32(const float* mel, const float* dct, float* out, int64_t n_vec, int32_t n_mels,
+                      int32_t n_mfcc, int32_t log_mode, const float* group_max,
+                      int64_t vec_per_group, float top_db, void* stream) {
+  AAMD_CHECK_ARG(mel && dct && out, "null buffer");
+  AAMD_CHECK_ARG(n_vec >= 0 && n_mels >= 1 && n_mfcc >= 1, "bad sizes");
+  AAMD_CHECK_ARG(log_mode >= 0 && log_mode <= 2, "bad log_mode");
+  AAMD_CHECK_ARG(vec_per_group >= 1 || group_max == nullptr, "vec_per_group must be >= 1");
+  if (n_vec == 0) return AAMD_OK;
+  const size_t lds = ((size_t)n_mels * n_mfcc + (size_t)kMfccVecPerBlock * n_mels) * sizeof(float);
+  if (lds > 160 * 1024) return fail(AAMD_EUNSUPPORTED, "audio_amd: dct matrix too large for LDS");
+  if (lds > 48 * 1024)
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_dct_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int blocks = grid_for(n_vec, kMfccVecPerBlock, dev_props().cu_count * 8);
+  hipLaunchKernelGGL(mfcc_dct_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, mel, dct, out,
+                     n_vec, n_mels, n_mfcc, log_mode, group_max, vec_per_group < 1 ? 1 : vec_per_group,
+                     top_db);
+  return launch_check();
+}
+
+int aamd_resample_f32(const float* wav, const float* kernel, float* out, int64_t rows, int64_t length,
+                      int64_t row_stride, int32_t orig, int32_t new_, int32_t width, int64_t out_len,
+                      void* stream) {
+  AAMD_CHECK_ARG(wav && kernel && out, "null buffer");
+  AAMD_CHECK_ARG(rows >= 0 && length >= 0 && orig >= 1 && new_ >= 1 && width >= 0, "bad sizes");
+  AAMD_CHECK_ARG(row_stride >= length, "row_stride < length");
+  const int64_t expect = (new_ * length + orig - 1) / orig;
+  AAMD_CHECK_ARG(out_len == expect, "out_len must be ceil(new*length/orig)");
+  if (rows == 0 || out_len == 0) return AAMD_OK;
+  ResampleGeom g;
+  g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
+  g.orig = orig; g.new_ = new_; g.width = width; g.taps = 2 * width + orig;
+  const int64_t nq = (out_len + new_ - 1) / new_;
+  // aim for ~2048 outputs per workgroup, halo within 96 KiB of LDS
+  int qt = (2048 + new_ - 1) / new_;
+  if (qt < 1) qt = 1;
+  if (qt > nq) qt = (int)nq;
+  const int64_t lds_budget = 96 * 1024 / sizeof(float);
+  while (qt > 1 && (int64_t)(qt - 1) * orig + g.taps > lds_budget) --qt;
+  g.qt = qt;
+  g.use_lds = ((int64_t)(qt - 1) * orig + g.taps <= lds_budget) ? 1 : 0;
+  g.nq_tiles = (int)((nq + qt - 1) / qt);
+  const int64_t blocks = rows * g.nq_tiles;
+  AAMD_CHECK_ARG(blocks < (1ll << 31), "too many tiles for one launch");
+  const size_t lds = g.use_lds ? ((size_t)(qt - 1) * orig + g.taps) * sizeof(float) : 0;
+  if (lds > 48 * 1024)
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g, wav,
+                     kernel, out);
+  return launch_check();
+}
+
+int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, int64_t batch,
+                     int32_t channels, int64_t length, int32_t n_order, int32_t n_coeff_rows,
+                     int32_t n_stages, int32_t clamp, void* stream) {
+  AAMD_CHECK_ARG(x && a && b && y, "null buffer");
+  AAMD_CHECK_ARG(batch >= 0 && channels >= 1 && length >= 0, "bad sizes");
+  AAMD_CHECK_ARG(n_order >= 1 && n_stages >= 1, "n_order and n_stages must be >= 1");
+  AAMD_CHECK_ARG(n_coeff_rows == 1 || n_coeff_rows == channels, "n_coeff_rows must be 1 or channels");
+  const int64_t n_seq = batch * channels;
+  if (n_seq == 0 || length == 0) return AAMD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int d = n_order - 1;
+#define AAMD_LF(D) return launch_lfilter<D>(x, a, b, y, n_seq, channels, length, n_order, n_coeff_rows, n_stages, clamp, s)
+  if (d <= 1) AAMD_LF(1);
+  if (d <= 2) AAMD_LF(2);
+  if (d <= 3) AAMD_LF(3);
+  if (d <= 4) AAMD_LF(4);
+  if (d <= 6) AAMD_LF(6);
+  if (d <= 8) AAMD_LF(8);
+  if (d <= 12) AAMD_LF(12);
+  if (d <= 16) AAMD_LF(16);
+#undef AAMD_LF
+  return fail(AAMD_EUNSUPPORTED, "audio_amd: lfilter order > 16 not supported");
+}
+
+int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t nx, int64_t ny) {
+  (void)rows; (void)nx; (void)ny;
+  return 0;
+}
+
+int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t nx,
+                         int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of, int64_t start,
+                         int64_t out_len, void* workspace, void* stream) {
+  (void)workspace;
+  AAMD_CHECK_ARG(x && y && out, "null buffer");
+  AAMD_CHECK_ARG(rows >= 0 && nx >= 1 && ny >= 1, "bad sizes");
+  AAMD_CHECK_ARG(start >= 0 && out_len >= 0 && start + out_len <= nx + ny - 1, "slice outside the full convolution");
+  if (rows == 0 || out_len == 0) return AAMD_OK;
+  FcGeom g;
+  g.rows = rows; g.start = start; g.out_len = out_len;
+  // stream the SHORTER operand as taps (convolution commutes)
+  const bool swap = ny > nx;
+  const float* xa = swap ? y : x;
+  const float* ya = swap ? x : y;
+  g.nx = swap ? ny : nx;
+  g.ny = swap ? nx : ny;
+  const int64_t* xmap = swap ? y_row_of : x_row_of;
+  const int64_t* ymap = swap ? x_row_of : y_row_of;
+  g.n_tiles = (int)((out_len + kFcTN - 1) / kFcTN);
+  const int64_t blocks = rows * g.n_tiles;
+  AAMD_CHECK_ARG(blocks < (1ll << 31), "too many tiles for one launch");
+  hipLaunchKernelGGL(fftconv_direct_kernel, dim3((unsigned)blocks), dim3(kFcThreads), 0, (hipStream_t)stream,
+                     g, xa, ya, xmap, ymap, out);
+  return launch_check();
+}
+
+}  // extern "C"

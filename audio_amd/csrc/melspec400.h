@@ -1,0 +1,272 @@
+// Headline kernel: fused MelSpectrogram for n_fft = 400, hop = 160 (the RNN-T / Whisper
+// style front-end, BASELINE.json config 2), power = 2, centre + reflect padding.
+//
+// Design (MI355X, wave64; no barriers -- every wave owns private LDS):
+//   * two REAL frames a, b are packed as one COMPLEX 400-point FFT  z = a + i b
+//     (no redundant half-spectrum work, no post-twiddle multiply);
+//   * 400 = 20 x 20 Cooley-Tukey.  A 20-lane group owns one frame pair; each lane runs a
+//     20-point DFT entirely in registers (Good-Thomas 4x5: five radix-4 + four radix-5
+//     butterflies, NO internal twiddles), multiplies by its W400^(r s) twiddles, and the
+//     20x20 transposition goes once through LDS (row stride 21 complex = conflict free for
+//     both the column write and the row read); a second in-register DFT-20 finishes the FFT;
+//   * 3 pairs (60 lanes) = 6 frames per wave per iteration;
+//   * the a/b spectra are separated with the conj-symmetry rule; the partner bin Z[400-k]
+//     lives in lane (20 - s) mod 20 of the same group and is fetched with ds_bpermute
+//     (wavefront shuffle), so only |A|^2, |B|^2 for k = 0..200 are ever written to LDS;
+//   * mel = banded reduction over the LDS power spectrum (<= 13 taps per filter for the
+//     80-mel bank), written frame-major: 6 frames x 80 mels = 480 contiguous floats per wave.
+//
+// Reference semantics: transforms/_transforms.py:612-622 (MelSpectrogram.forward),
+// functional/functional.py:112-145, torch/functional.py:675-681; framing is bit-exact
+// (index reflection i<0 -> -i, i>=L -> 2(L-1)-i).
+#pragma once
+#include "hd.h"
+#include "stft_generic.h"
+
+namespace aamd {
+namespace m400 {
+
+constexpr int kN = 400;
+constexpr int kHop = 160;
+constexpr int kPad = 200;
+constexpr int kFramesPerWave = 6;
+constexpr int kTRow = 42;                 // dwords per transposition row (20 complex + 1 pad)
+constexpr int kPStride = 202;             // dwords per power-spectrum row (201 + 1, = 10 mod 16)
+constexpr int kLdsDwordsPerWave = 60 * kTRow;  // 2520 dwords = 10080 B (P rows alias it)
+
+struct LaneConst {
+  float twr[20], twi[20];  // W400^(r*s), s = 0..19
+  float win[20];           // 0.5 * scale * window[r + 20 q]
+  int p, r;                // pair index (0..2), row/column index inside the pair (0..19)
+  int active;              // lanes 60..63 shadow pair 2 but never store
+};
+
+AAMD_HD void lane_init(int lane, const float* window, const float* tw400, float scale,
+                       LaneConst& c) {
+  c.active = lane < 60;
+  const int l = c.active ? lane : lane - 20;
+  c.p = l / 20;
+  c.r = l - 20 * c.p;
+#pragma unroll
+  for (int s = 0; s < 20; ++s) {
+    const int idx = (c.r * s) % kN;
+    c.twr[s] = tw400[2 * idx];
+    c.twi[s] = tw400[2 * idx + 1];
+  }
+#pragma unroll
+  for (int q = 0; q < 20; ++q) c.win[q] = window[c.r + 20 * q] * (0.5f * scale);
+}
+
+// ---- in-register DFT-20, forward (e^{-2 pi i nk/20}), natural order in and out -----------
+AAMD_HD void dft4(float ar, float ai, float br, float bi, float cr, float ci, float dr, float di,
+                  float* o_r, float* o_i) {
+  const float s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
+  const float s2r = br + dr, s2i = bi + di, s3r = br - dr, s3i = bi - di;
+  o_r[0] = s0r + s2r; o_i[0] = s0i + s2i;
+  o_r[1] = s1r + s3i; o_i[1] = s1i - s3r;   // s1 - i*s3
+  o_r[2] = s0r - s2r; o_i[2] = s0i - s2i;
+  o_r[3] = s1r - s3i; o_i[3] = s1i + s3r;   // s1 + i*s3
+}
+
+AAMD_HD void dft5(const float* xr, const float* xi, float* o_r, float* o_i) {
+  constexpr float C1 = 0.30901699437494742f, C2 = -0.80901699437494742f;
+  constexpr float S1 = 0.95105651629515357f, S2 = 0.58778525229247313f;
+  const float t1r = xr[1] + xr[4], t1i = xi[1] + xi[4];
+  const float t2r = xr[2] + xr[3], t2i = xi[2] + xi[3];
+  const float t3r = xr[1] - xr[4], t3i = xi[1] - xi[4];
+  const float t4r = xr[2] - xr[3], t4i = xi[2] - xi[3];
+  const float m1r = xr[0] + C1 * t1r + C2 * t2r, m1i = xi[0] + C1 * t1i + C2 * t2i;
+  const float m2r = xr[0] + C2 * t1r + C1 * t2r, m2i = xi[0] + C2 * t1i + C1 * t2i;
+  const float u1r = S1 * t3r + S2 * t4r, u1i = S1 * t3i + S2 * t4i;
+  const float u2r = S2 * t3r - S1 * t4r, u2i = S2 * t3i - S1 * t4i;
+  o_r[0] = xr[0] + t1r + t2r; o_i[0] = xi[0] + t1i + t2i;
+  o_r[1] = m1r + u1i; o_i[1] = m1i - u1r;   // m1 - i*u1
+  o_r[4] = m1r - u1i; o_i[4] = m1i + u1r;
+  o_r[2] = m2r + u2i; o_i[2] = m2i - u2r;   // m2 - i*u2
+  o_r[3] = m2r - u2i; o_i[3] = m2i + u2r;
+}
+
+// Good-Thomas: n = (5 n1 + 4 n2) mod 20, k = (5 k1 + 16 k2) mod 20.
+AAMD_HD void dft20(const float (&xr)[20], const float (&xi)[20], float (&yr)[20], float (&yi)[20]) {
+  float tr[4][5], ti[4][5];
+#pragma unroll
+  for (int n2 = 0; n2 < 5; ++n2) {
+    float o_r[4], o_i[4];
+    const int i0 = (4 * n2) % 20, i1 = (5 + 4 * n2) % 20, i2 = (10 + 4 * n2) % 20,
+              i3 = (15 + 4 * n2) % 20;
+    dft4(xr[i0], xi[i0], xr[i1], xi[i1], xr[i2], xi[i2], xr[i3], xi[i3], o_r, o_i);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) { tr[k1][n2] = o_r[k1]; ti[k1][n2] = o_i[k1]; }
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    float o_r[5], o_i[5];
+    dft5(tr[k1], ti[k1], o_r, o_i);
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) {
+      const int k = (5 * k1 + 16 * k2) % 20;
+      yr[k] = o_r[k2];
+      yi[k] = o_i[k2];
+    }
+  }
+}
+
+AAMD_HD int64_t reflect_idx(int64_t i, int64_t len) {
+  if (i < 0) i = -i;
+  if (i >= len) i = 2 * (len - 1) - i;
+  return i;
+}
+
+// ---- phase A: gather + window + DFT-20 over q + twiddle + transposed LDS write ----------
+//   lane (p, r) owns samples n = r + 20 q of frames a = t0 + 2p, b = a + 1.
+template <bool EDGE>
+AAMD_HD void phase_a(const LaneConst& c, const float* wav_row, int64_t length, int64_t t0,
+                     int n_frames, float* lds) {
+  float xr[20], xi[20], yr[20], yi[20];
+  const int64_t ta = t0 + 2 * c.p;
+  const int64_t ia0 = ta * kHop - kPad + c.r;
+#pragma unroll
+  for (int q = 0; q < 20; ++q) {
+    const int64_t ia = ia0 + 20 * q, ib = ia + kHop;
+    float xa, xb;
+    if (!EDGE) {
+      xa = wav_row[ia];
+      xb = wav_row[ib];
+    } else {
+      xa = (ta < n_frames) ? wav_row[reflect_idx(ia, length)] : 0.0f;
+      xb = (ta + 1 < n_frames) ? wav_row[reflect_idx(ib, length)] : 0.0f;
+    }
+    xr[q] = xa * c.win[q];
+    xi[q] = xb * c.win[q];
+  }
+  dft20(xr, xi, yr, yi);
+  if (c.active) {
+    float* col = lds + kTRow * (20 * c.p) + 2 * c.r;
+#pragma unroll
+    for (int s = 0; s < 20; ++s) {
+      const float vr = yr[s] * c.twr[s] - yi[s] * c.twi[s];
+      const float vi = yr[s] * c.twi[s] + yi[s] * c.twr[s];
+      col[kTRow * s] = vr;
+      col[kTRow * s + 1] = vi;
+    }
+  }
+}
+
+// ---- phase B1: read own row, DFT-20 over r  ->  Z[s + 20 u] in registers ------------------
+AAMD_HD void phase_b1(const LaneConst& c, const float* lds, float (&zr)[20], float (&zi)[20]) {
+  float vr[20], vi[20];
+  const float* row = lds + kTRow * (20 * c.p + c.r);
+#pragma unroll
+  for (int j = 0; j < 20; ++j) { vr[j] = row[2 * j]; vi[j] = row[2 * j + 1]; }
+  dft20(vr, vi, zr, zi);
+}
+
+AAMD_HD int partner_lane(const LaneConst& c) { return 20 * c.p + (20 - c.r) % 20; }
+
+// ---- phase B2: separate the two real spectra, |.|^2, write P rows ------------------------
+//   g[i] = partner's Z[10 + i].  conj(Z[400-k]) for k = s + 20u is partner idx 19-u (s != 0),
+//   or own-lane idx (20-u) mod 20 when s == 0 (partner == self).
+AAMD_HD void phase_b2(const LaneConst& c, const float (&zr)[20], const float (&zi)[20],
+                      const float (&gr)[10], const float (&gi)[10], float* lds) {
+  if (!c.active) return;
+  float* pa = lds + kPStride * (2 * c.p) + c.r;
+  float* pb = pa + kPStride;
+  const bool s0 = (c.r == 0);
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    float cr, ci;
+    if (u == 0) {
+      cr = s0 ? zr[0] : gr[9];
+      ci = s0 ? zi[0] : gi[9];
+    } else {
+      cr = s0 ? gr[10 - u] : gr[9 - u];
+      ci = s0 ? gi[10 - u] : gi[9 - u];
+    }
+    const float ar = zr[u] + cr, ai = zi[u] - ci;   // 2*A = Z[k] + conj(Z[N-k])
+    const float br = zr[u] - cr, bi = zi[u] + ci;   // |2*B|: Z[k] - conj(Z[N-k])
+    pa[20 * u] = ar * ar + ai * ai;
+    pb[20 * u] = br * br + bi * bi;
+  }
+  if (s0) {  // k = 200 (Nyquist): partner idx 10 of this same lane
+    const float ar = zr[10] + gr[0], ai = zi[10] - gi[0];
+    const float br = zr[10] - gr[0], bi = zi[10] + gi[0];
+    pa[200] = ar * ar + ai * ai;
+    pb[200] = br * br + bi * bi;
+  }
+}
+
+// ---- phase C: banded mel reduction from the 6 LDS power rows, coalesced frame-major store --
+AAMD_HD void phase_c(int lane, const MelBandsDev& mb, const float* lds, float* out_row,
+                     int64_t t0, int n_frames) {
+  const int total = kFramesPerWave * mb.n_mels;
+  for (int o = lane; o < total; o += 64) {
+    const int f = o / mb.n_mels;
+    const int m = o - f * mb.n_mels;
+    const int lo = mb.lo[m], w = mb.width[m];
+    const float* wt = mb.weights + m * mb.max_width;
+    const float* P = lds + kPStride * f + lo;
+    float acc = 0.0f;
+    for (int i = 0; i < w; ++i) acc += wt[i] * P[i];
+    if (t0 + f < n_frames) out_row[(t0 + f) * (int64_t)mb.n_mels + m] = acc;
+  }
+}
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS ops of one wave execute in order; this only stops the compiler from moving
+  // LDS accesses across the hand-off between lanes.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ void __launch_bounds__(256)
+melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ window,
+                  const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
+                  int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
+                  int tiles_per_row, int64_t n_tiles, int n_blocks_log) {
+  extern __shared__ __attribute__((aligned(16))) float smem400[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* lds = smem400 + wave * kLdsDwordsPerWave;
+
+  LaneConst c;
+  lane_init(lane, window, tw400, scale, c);
+
+  // XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
+  // range of tiles so the frame-overlap re-reads stay inside one L2.
+  const int nb = gridDim.x;
+  const int per_xcd = nb >> 3;
+  int lb = blockIdx.x;
+  if ((nb & 7) == 0) lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int64_t waves_total = (int64_t)nb * 4;
+  const int partner = partner_lane(c);
+
+  for (int64_t tile = (int64_t)lb * 4 + wave; tile < n_tiles; tile += waves_total) {
+    const int64_t row = tile / tiles_per_row;
+    const int64_t t0 = (tile - row * tiles_per_row) * kFramesPerWave;
+    const float* wav_row = wav + row * row_stride;
+    const bool interior = (t0 * kHop - kPad >= 0) &&
+                          ((t0 + kFramesPerWave - 1) * kHop + (kN - kPad) <= length) &&
+                          (t0 + kFramesPerWave <= n_frames);
+    if (interior) phase_a<false>(c, wav_row, length, t0, n_frames, lds);
+    else          phase_a<true>(c, wav_row, length, t0, n_frames, lds);
+    wave_lds_fence();
+    float zr[20], zi[20], gr[10], gi[10];
+    phase_b1(c, lds, zr, zi);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      gr[i] = __shfl(zr[10 + i], partner, 64);
+      gi[i] = __shfl(zi[10 + i], partner, 64);
+    }
+    wave_lds_fence();
+    phase_b2(c, zr, zi, gr, gi, lds);
+    wave_lds_fence();
+    phase_c(lane, mb, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
+    wave_lds_fence();
+  }
+}
+#endif  // __HIPCC__
+
+}  // namespace m400
+}  // namespace aamd

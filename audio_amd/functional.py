@@ -1,0 +1,604 @@
+"""Drop-in replacements for the hot-path functions of ``torchaudio.functional``.
+
+Same names, argument meaning, shapes, strides, warnings and error messages as the reference
+(src/torchaudio/functional/functional.py and filtering.py); the arithmetic runs in hand-written
+HIP kernels for MI355X behind the C ABI of ``libaudio_amd.so``.  Inputs must live on a ROCm
+device (``tensor.is_cuda``) and be float32; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import warnings
+from typing import Optional, Union
+
+import torch
+from torch import Tensor
+
+from . import _host
+from . import _lib
+from ._host import create_dct, melscale_fbanks  # noqa: F401  (re-exported, host-side constants)
+
+__all__ = [
+    "spectrogram", "amplitude_to_DB", "melscale_fbanks", "create_dct", "resample",
+    "lfilter", "biquad", "fftconvolve", "mel_scale", "filtfilt",
+    "lowpass_biquad", "highpass_biquad", "allpass_biquad", "bandpass_biquad",
+    "bandreject_biquad", "equalizer_biquad", "band_biquad", "treble_biquad", "bass_biquad",
+]
+
+# --------------------------------------------------------------------------- #
+# helpers                                                                     #
+# --------------------------------------------------------------------------- #
+
+
+def _require_device(t: Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"audio_amd: {what} must be on an MI355X (ROCm) device, got {t.device}. "
+            "The HIP kernels have no CPU fallback.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"audio_amd: {what} must be float32 (got {t.dtype}); kernels compute in fp32.")
+    if t.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("audio_amd: forward-only kernels; wrap the call in torch.no_grad().")
+
+
+def _rows2d(t: Tensor) -> Tensor:
+    """(..., L) -> contiguous (rows, L) view/copy."""
+    x = t.reshape(-1, t.shape[-1])
+    if x.stride(-1) != 1 or (x.shape[0] > 1 and x.stride(0) < x.shape[1]):
+        x = x.contiguous()
+    return x
+
+
+_CACHE: dict = {}
+
+
+def _cached(key, make):
+    v = _CACHE.get(key)
+    if v is None:
+        if len(_CACHE) > 256:
+            _CACHE.clear()
+        v = make()
+        _CACHE[key] = v
+    return v
+
+
+def _twiddles(n_fft: int, device) -> Tensor:
+    return _cached(("tw", n_fft, str(device)),
+                   lambda: torch.from_numpy(_host.twiddle_table(n_fft)).to(device).contiguous())
+
+
+def _padded_window(window: Tensor, n_fft: int) -> Tensor:
+    key = ("win", window.data_ptr(), window._version, tuple(window.shape), n_fft, str(window.device))
+    return _cached(key, lambda: _host.center_pad_window(window.detach(), n_fft).contiguous())
+
+
+class MelBandsOnDevice:
+    """Device copy of the banded filterbank + the ctypes struct that points at it."""
+
+    def __init__(self, fb: Tensor, device):
+        lo, width, weights, max_width = _host.mel_band_table(fb.detach().cpu().numpy())
+        self.n_freq, self.n_mels = fb.shape
+        self.lo = torch.from_numpy(lo).to(device)
+        self.width = torch.from_numpy(width).to(device)
+        self.weights = torch.from_numpy(weights).to(device).contiguous()
+        self.max_width = max_width
+        self.struct = _lib.MelBands(self.n_mels, max_width, self.lo.data_ptr(), self.width.data_ptr(),
+                                    self.weights.data_ptr())
+
+
+def _mel_bands(fb: Tensor, device) -> MelBandsOnDevice:
+    key = ("fb", fb.data_ptr(), fb._version, tuple(fb.shape), str(device))
+    return _cached(key, lambda: MelBandsOnDevice(fb, device))
+
+
+def _get_spec_norms(normalized: Union[str, bool]):
+    frame_length_norm, window_norm = False, False
+    if isinstance(normalized, str):
+        if normalized not in ["frame_length", "window"]:
+            raise ValueError("Invalid normalized parameter: {}".format(normalized))
+        if normalized == "frame_length":
+            frame_length_norm = True
+        elif normalized == "window":
+            window_norm = True
+    elif isinstance(normalized, bool):
+        if normalized:
+            window_norm = True
+    else:
+        raise TypeError("Input type not supported")
+    return frame_length_norm, window_norm
+
+
+def _stft_desc(x2: Tensor, pad: int, window: Tensor, n_fft: int, hop_length: int, power, normalized,
+               center: bool, pad_mode: str, onesided: bool) -> _lib.StftDesc:
+    rows, length = x2.shape
+    if pad_mode not in _lib.PAD_MODES:
+        raise NotImplementedError(f"audio_amd: pad_mode {pad_mode!r} is not supported")
+    l1 = length + 2 * pad
+    if center:
+        half = n_fft // 2
+        if pad_mode == "reflect" and not half < l1:
+            raise RuntimeError(
+                f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                f"but got: padding ({half}, {half}) at dimension 2 of input {[1, rows, l1]}")
+        if pad_mode == "circular" and half > l1:
+            raise RuntimeError("Padding value causes wrapping around more than once.")
+        l1 += 2 * half
+    if not (0 < n_fft <= l1):
+        raise RuntimeError(f"stft: expected 0 < n_fft <= {l1}, but got n_fft={n_fft}")
+    if hop_length <= 0:
+        raise RuntimeError(f"stft: expected hop_length > 0, but got hop_length={hop_length}")
+    n_frames = 1 + (l1 - n_fft) // hop_length
+    frame_norm, window_norm = _get_spec_norms(normalized)
+    scale = 1.0
+    if frame_norm:
+        scale = 1.0 / math.sqrt(n_fft)
+    if window_norm:
+        key = ("wnorm", window.data_ptr(), window._version, tuple(window.shape), str(window.device))
+        scale = scale / _cached(key, lambda: float(window.pow(2.0).sum().sqrt()))
+    return _lib.StftDesc(rows, length, x2.stride(0) if rows > 1 else max(length, 1), n_fft, hop_length, pad,
+                         int(center), _lib.PAD_MODES[pad_mode], int(onesided), n_frames, scale,
+                         0.0 if power is None else float(power))
+
+
+# --------------------------------------------------------------------------- #
+# spectrogram                                                                 #
+# --------------------------------------------------------------------------- #
+
+
+def spectrogram(
+    waveform: Tensor,
+    pad: int,
+    window: Tensor,
+    n_fft: int,
+    hop_length: int,
+    win_length: int,
+    power: Optional[float],
+    normalized: Union[bool, str],
+    center: bool = True,
+    pad_mode: str = "reflect",
+    onesided: bool = True,
+    return_complex: Optional[bool] = None,
+) -> Tensor:
+    r"""Spectrogram of ``(..., time)`` audio -> ``(..., freq, time)``; reference:
+    torchaudio/functional/functional.py:54-145.  One fused HIP kernel does padding-by-index,
+    windowing, the FFT and ``|X|^power``; the result is stored frame-major and returned as the
+    same transposed view (same strides) ``torch.stft`` produces."""
+    if return_complex is not None:
+        warnings.warn(
+            "`return_complex` argument is now deprecated and is not effective."
+            "`torchaudio.functional.spectrogram(power=None)` always returns a tensor with "
+            "complex dtype. Please remove the argument in the function call."
+        )
+    _require_device(waveform, "waveform")
+    if window.shape[0] != win_length:
+        raise RuntimeError(
+            f"stft: expected a 1D window tensor of size equal to win_length={win_length}, "
+            f"but got window with size {list(window.shape)}")
+    if not 0 < win_length <= n_fft:
+        raise RuntimeError(f"stft: expected 0 < win_length <= n_fft, but got win_length={win_length}")
+    window = window.to(device=waveform.device, dtype=torch.float32)
+    shape = waveform.size()
+    x2 = _rows2d(waveform)
+    desc = _stft_desc(x2, pad, window, n_fft, hop_length, power, normalized, center, pad_mode, onesided)
+    n_freq = n_fft // 2 + 1 if onesided else n_fft
+    lead = tuple(shape[:-1])
+    T = desc.n_frames
+    comp = 2 if power is None else 1
+    out = torch.empty((desc.rows, T, n_freq * comp), dtype=torch.float32, device=waveform.device)
+    if out.numel():
+        L = _lib.lib()
+        _lib.check(L.aamd_spectrogram_f32(
+            x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, waveform.device).data_ptr(),
+            out.data_ptr(), C.byref(desc), _lib.current_stream(waveform.device)))
+    if power is None:
+        out = torch.view_as_complex(out.view(desc.rows, T, n_freq, 2))
+    return out.view(lead + (T, n_freq)).transpose(-1, -2)
+
+
+def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_fft: int, hop_length: int,
+                    win_length: int, power: float, normalized, center: bool, pad_mode: str,
+                    bands: Optional[MelBandsOnDevice] = None) -> Tensor:
+    """Fused Spectrogram + MelScale (transforms/_transforms.py:612-622). Returns frame-major
+    (rows, T, n_mels) plus the leading shape; callers build the (..., n_mels, T) view."""
+    _require_device(waveform, "waveform")
+    if power is None:
+        raise ValueError("audio_amd: MelSpectrogram needs a real power (got None)")
+    window = window.to(device=waveform.device, dtype=torch.float32)
+    x2 = _rows2d(waveform)
+    desc = _stft_desc(x2, pad, window, n_fft, hop_length, power, normalized, center, pad_mode, True)
+    if bands is None:
+        bands = _mel_bands(fb, waveform.device)
+    if bands.n_freq != n_fft // 2 + 1:
+        raise RuntimeError(
+            f"mat1 and mat2 shapes cannot be multiplied ({desc.n_frames}x{n_fft // 2 + 1} and "
+            f"{bands.n_freq}x{bands.n_mels})")
+    out = torch.empty((desc.rows, desc.n_frames, bands.n_mels), dtype=torch.float32, device=waveform.device)
+    if out.numel():
+        L = _lib.lib()
+        _lib.check(L.aamd_melspectrogram_f32(
+            x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, waveform.device).data_ptr(),
+            C.byref(bands.struct), out.data_ptr(), C.byref(desc), _lib.current_stream(waveform.device)))
+    return out
+
+
+def mel_scale(specgram: Tensor, fb: Tensor) -> Tensor:
+    """MelScale.forward (transforms/_transforms.py:403-415): (..., freq, time) -> (..., n_mels, time)."""
+    _require_device(specgram, "specgram")
+    shape = specgram.shape
+    n_freq, T = shape[-2], shape[-1]
+    if n_freq != fb.shape[0]:
+        raise RuntimeError(
+            f"mat1 and mat2 shapes cannot be multiplied ({T}x{n_freq} and {fb.shape[0]}x{fb.shape[1]})")
+    fm = specgram.transpose(-1, -2).reshape(-1, T, n_freq)
+    if not fm.is_contiguous():
+        fm = fm.contiguous()
+    bands = _mel_bands(fb, specgram.device)
+    out = torch.empty((fm.shape[0], T, bands.n_mels), dtype=torch.float32, device=specgram.device)
+    if out.numel():
+        L = _lib.lib()
+        _lib.check(L.aamd_mel_scale_f32(fm.data_ptr(), C.byref(bands.struct), out.data_ptr(), fm.shape[0], T,
+                                        n_freq, _lib.current_stream(specgram.device)))
+    return out.view(tuple(shape[:-2]) + (T, bands.n_mels)).transpose(-1, -2)
+
+
+# --------------------------------------------------------------------------- #
+# dB                                                                          #
+# --------------------------------------------------------------------------- #
+
+
+def amplitude_to_DB(x: Tensor, multiplier: float, amin: float, db_multiplier: float,
+                    top_db: Optional[float] = None) -> Tensor:
+    r"""Power/amplitude -> decibel (functional/functional.py:356-404).  With ``top_db`` the cut-off
+    is per leading item of the ``(-1, C, F, T)`` view, ``C = shape[-3]`` if ``x.dim() > 2`` else 1."""
+    _require_device(x, "x")
+    xc = x if x.is_contiguous() else x.contiguous()
+    n = xc.numel()
+    out = torch.empty_like(xc)
+    L = _lib.lib()
+    stream = _lib.current_stream(x.device)
+    if n == 0:
+        return out.view(x.shape)
+    if top_db is None:
+        _lib.check(L.aamd_amplitude_to_db_f32(xc.data_ptr(), out.data_ptr(), n, multiplier, amin, db_multiplier,
+                                              None, 1, stream))
+        return out.view(x.shape)
+    shape = x.shape
+    packed = shape[-3] if x.dim() > 2 else 1
+    group = packed * shape[-2] * shape[-1]
+    n_groups = n // group
+    gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=x.device)
+    _lib.check(L.aamd_amplitude_to_db_f32(xc.data_ptr(), out.data_ptr(), n, multiplier, amin, db_multiplier,
+                                          gmax.data_ptr(), group, stream))
+    _lib.check(L.aamd_db_clamp_f32(out.data_ptr(), out.data_ptr(), n, gmax.data_ptr(), group, float(top_db), stream))
+    return out.view(shape)
+
+
+# --------------------------------------------------------------------------- #
+# resample                                                                    #
+# --------------------------------------------------------------------------- #
+
+
+def _apply_sinc_resample_kernel(waveform: Tensor, orig_freq: int, new_freq: int, gcd: int, kernel: Tensor,
+                                width: int) -> Tensor:
+    """functional/functional.py:1405-1432 as one polyphase HIP kernel."""
+    if not waveform.is_floating_point():
+        raise TypeError(f"Expected floating point type for waveform tensor, but received {waveform.dtype}.")
+    _require_device(waveform, "waveform")
+    orig = int(orig_freq) // gcd
+    new = int(new_freq) // gcd
+    shape = waveform.size()
+    x2 = _rows2d(waveform)
+    rows, length = x2.shape
+    out_len = int(math.ceil(new * length / orig))
+    kern = kernel.to(device=waveform.device, dtype=torch.float32).reshape(new, -1).contiguous()
+    if kern.shape[1] != 2 * width + orig:
+        raise RuntimeError("audio_amd: resample kernel shape does not match (new, 2*width+orig)")
+    out = torch.empty((rows, out_len), dtype=torch.float32, device=waveform.device)
+    if out.numel():
+        L = _lib.lib()
+        _lib.check(L.aamd_resample_f32(x2.data_ptr(), kern.data_ptr(), out.data_ptr(), rows, length,
+                                       x2.stride(0) if rows > 1 else max(length, 1), orig, new, width, out_len,
+                                       _lib.current_stream(waveform.device)))
+    return out.view(tuple(shape[:-1]) + (out_len,))
+
+
+def resample(
+    waveform: Tensor,
+    orig_freq: int,
+    new_freq: int,
+    lowpass_filter_width: int = 6,
+    rolloff: float = 0.99,
+    resampling_method: str = "sinc_interp_hann",
+    beta: Optional[float] = None,
+) -> Tensor:
+    r"""Band-limited sinc-interpolation resampling (functional/functional.py:1435-1490).  The tap
+    table is evaluated on the host in the waveform's dtype exactly as the reference's CPU path
+    does per call (cached here per parameter set) and applied by the polyphase HIP kernel."""
+    if orig_freq <= 0.0 or new_freq <= 0.0:
+        raise ValueError("Original frequency and desired frequecy should be positive")
+    if orig_freq == new_freq:
+        return waveform
+    gcd = math.gcd(int(orig_freq), int(new_freq))
+    key = ("sinc", int(orig_freq), int(new_freq), lowpass_filter_width, rolloff, resampling_method, beta,
+           str(waveform.dtype), str(waveform.device))
+    if key in _CACHE:
+        kernel, width = _CACHE[key]
+    else:
+        kernel, width = _host.sinc_resample_kernel(orig_freq, new_freq, gcd, lowpass_filter_width, rolloff,
+                                                   resampling_method, beta, dtype=waveform.dtype)
+        kernel = kernel.to(waveform.device)
+        _CACHE[key] = (kernel, width)
+    return _apply_sinc_resample_kernel(waveform, orig_freq, new_freq, gcd, kernel, width)
+
+
+# --------------------------------------------------------------------------- #
+# lfilter / biquad                                                            #
+# --------------------------------------------------------------------------- #
+
+
+def _lfilter_launch(x3: Tensor, a: Tensor, b: Tensor, clamp: bool, n_stages: int = 1) -> Tensor:
+    """x3: (batch, channels, L) contiguous; a, b: (n_stages, rows, n_order)."""
+    batch, channels, length = x3.shape
+    y = torch.empty_like(x3)
+    if y.numel():
+        L = _lib.lib()
+        _lib.check(L.aamd_lfilter_f32(x3.data_ptr(), a.data_ptr(), b.data_ptr(), y.data_ptr(), batch, channels,
+                                      length, a.shape[-1], a.shape[-2], n_stages, int(clamp),
+                                      _lib.current_stream(x3.device)))
+    return y
+
+
+def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = True, batching: bool = True) -> Tensor:
+    r"""IIR filter by the difference equation (functional/filtering.py:1032-1099): FIR + recursion
+    + clamp in one HIP kernel (chunked linear-recurrence scan, see csrc/lfilter.h)."""
+    if a_coeffs.size() != b_coeffs.size():
+        raise ValueError(
+            "Expected coeffs to be the same size."
+            f"Found: a_coeffs size: {a_coeffs.size()}, b_coeffs size: {b_coeffs.size()}"
+        )
+    if a_coeffs.ndim > 2:
+        raise ValueError(f"Expected coeffs to have greater than 1 dimension. Found: {a_coeffs.ndim}")
+    if a_coeffs.ndim > 1:
+        if batching:
+            if waveform.ndim <= 0:
+                raise ValueError("Expected waveform to have a positive number of dimensions." f"Found: {waveform.ndim}")
+            if waveform.shape[-2] != a_coeffs.shape[0]:
+                raise ValueError(
+                    "Expected number of batches in waveform and coeffs to be the same."
+                    f"Found: coeffs batches: {a_coeffs.shape[0]}, waveform batches: {waveform.shape[-2]}"
+                )
+        else:
+            waveform = torch.stack([waveform] * a_coeffs.shape[0], -2)
+    else:
+        a_coeffs = a_coeffs.unsqueeze(0)
+        b_coeffs = b_coeffs.unsqueeze(0)
+    _require_device(waveform, "waveform")
+    shape = waveform.size()
+    n_filt = a_coeffs.shape[0]
+    x3 = waveform.reshape(-1, n_filt, shape[-1]).contiguous()
+    a = a_coeffs.to(device=waveform.device, dtype=torch.float32).contiguous()
+    b = b_coeffs.to(device=waveform.device, dtype=torch.float32).contiguous()
+    y = _lfilter_launch(x3, a, b, clamp)
+    return y.reshape(shape[:-1] + y.shape[-1:])
+
+
+def biquad_cascade(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = True) -> Tensor:
+    """``n_stages`` sequential ``lfilter`` calls (each clamped like the reference's default) fused in
+    ONE pass over the audio.  a_coeffs, b_coeffs: (n_stages, n_order) shared across channels or
+    (n_stages, channels, n_order).  Extension of the reference API (BASELINE config 5a)."""
+    _require_device(waveform, "waveform")
+    if a_coeffs.shape != b_coeffs.shape or a_coeffs.ndim not in (2, 3):
+        raise ValueError("biquad_cascade: a_coeffs and b_coeffs must both be (stages, order+1) or (stages, channels, order+1)")
+    shape = waveform.size()
+    a = a_coeffs.to(device=waveform.device, dtype=torch.float32)
+    b = b_coeffs.to(device=waveform.device, dtype=torch.float32)
+    if a.ndim == 2:
+        a, b = a.unsqueeze(1), b.unsqueeze(1)
+        x3 = waveform.reshape(-1, 1, shape[-1]).contiguous()
+    else:
+        if waveform.ndim < 2 or waveform.shape[-2] != a.shape[1]:
+            raise ValueError("biquad_cascade: waveform channel dim does not match coefficient rows")
+        x3 = waveform.reshape(-1, a.shape[1], shape[-1]).contiguous()
+    y = _lfilter_launch(x3, a.contiguous(), b.contiguous(), clamp, n_stages=a.shape[0])
+    return y.reshape(shape)
+
+
+def _cpu_scalar(v, dtype) -> Tensor:
+    """0-dim CPU tensor of the waveform dtype (the reference builds its coefficients with
+    ``torch.as_tensor(v, dtype=waveform.dtype)`` scalars; doing it on the host avoids launches)."""
+    if isinstance(v, Tensor):
+        return v.detach().to(device="cpu", dtype=dtype).reshape(())
+    return torch.as_tensor(v, dtype=dtype)
+
+
+def biquad(waveform: Tensor, b0: float, b1: float, b2: float, a0: float, a1: float, a2: float) -> Tensor:
+    r"""Biquad filter (functional/filtering.py:295-333): ``lfilter`` with 3-tap a, b."""
+    dtype = waveform.dtype
+    coef = torch.stack([_cpu_scalar(v, dtype) for v in (a0, a1, a2, b0, b1, b2)]).to(waveform.device)
+    return lfilter(waveform, coef[:3], coef[3:])
+
+
+def filtfilt(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = True) -> Tensor:
+    r"""Forward-backward IIR filtering (functional/filtering.py:672-711)."""
+    fwd = lfilter(waveform, a_coeffs, b_coeffs, clamp=False, batching=True)
+    bwd = lfilter(fwd.flip(-1), a_coeffs, b_coeffs, clamp=clamp, batching=True).flip(-1)
+    return bwd
+
+
+# ---- biquad designers: RBJ-cookbook coefficient formulas evaluated with 0-dim tensors of the
+# ---- waveform dtype (as the reference does), then one call to biquad --------------------- #
+
+
+def _w0(freq, sample_rate: int, dtype) -> Tensor:
+    return 2 * math.pi * _cpu_scalar(freq, dtype) / sample_rate
+
+
+def lowpass_biquad(waveform: Tensor, sample_rate: int, cutoff_freq: float, Q: float = 0.707) -> Tensor:
+    r"""functional/filtering.py:1102-1133."""
+    dt = waveform.dtype
+    w0 = _w0(cutoff_freq, sample_rate, dt)
+    alpha = torch.sin(w0) / 2 / _cpu_scalar(Q, dt)
+    b0 = (1 - torch.cos(w0)) / 2
+    return biquad(waveform, b0, 1 - torch.cos(w0), b0, 1 + alpha, -2 * torch.cos(w0), 1 - alpha)
+
+
+def highpass_biquad(waveform: Tensor, sample_rate: int, cutoff_freq: float, Q: float = 0.707) -> Tensor:
+    r"""functional/filtering.py:893-923."""
+    dt = waveform.dtype
+    w0 = _w0(cutoff_freq, sample_rate, dt)
+    alpha = torch.sin(w0) / 2.0 / _cpu_scalar(Q, dt)
+    b0 = (1 + torch.cos(w0)) / 2
+    return biquad(waveform, b0, -1 - torch.cos(w0), b0, 1 + alpha, -2 * torch.cos(w0), 1 - alpha)
+
+
+def allpass_biquad(waveform: Tensor, sample_rate: int, central_freq: float, Q: float = 0.707) -> Tensor:
+    r"""functional/filtering.py:70-101."""
+    dt = waveform.dtype
+    w0 = _w0(central_freq, sample_rate, dt)
+    alpha = torch.sin(w0) / 2 / _cpu_scalar(Q, dt)
+    return biquad(waveform, 1 - alpha, -2 * torch.cos(w0), 1 + alpha, 1 + alpha, -2 * torch.cos(w0), 1 - alpha)
+
+
+def bandpass_biquad(waveform: Tensor, sample_rate: int, central_freq: float, Q: float = 0.707,
+                    const_skirt_gain: bool = False) -> Tensor:
+    r"""functional/filtering.py:104-142."""
+    dt = waveform.dtype
+    w0 = _w0(central_freq, sample_rate, dt)
+    alpha = torch.sin(w0) / 2 / _cpu_scalar(Q, dt)
+    peak = torch.sin(w0) / 2 if const_skirt_gain else alpha
+    return biquad(waveform, peak, 0.0, -peak, 1 + alpha, -2 * torch.cos(w0), 1 - alpha)
+
+
+def bandreject_biquad(waveform: Tensor, sample_rate: int, central_freq: float, Q: float = 0.707) -> Tensor:
+    r"""functional/filtering.py:145-177."""
+    dt = waveform.dtype
+    w0 = _w0(central_freq, sample_rate, dt)
+    alpha = torch.sin(w0) / 2 / _cpu_scalar(Q, dt)
+    return biquad(waveform, 1.0, -2 * torch.cos(w0), 1.0, 1 + alpha, -2 * torch.cos(w0), 1 - alpha)
+
+
+def equalizer_biquad(waveform: Tensor, sample_rate: int, center_freq: float, gain: float, Q: float = 0.707) -> Tensor:
+    r"""functional/filtering.py:851-890."""
+    dt = waveform.dtype
+    w0 = _w0(center_freq, sample_rate, dt)
+    A = torch.exp(_cpu_scalar(gain, dt) / 40.0 * math.log(10))
+    alpha = torch.sin(w0) / 2 / _cpu_scalar(Q, dt)
+    return biquad(waveform, 1 + alpha * A, -2 * torch.cos(w0), 1 - alpha * A, 1 + alpha / A, -2 * torch.cos(w0),
+                  1 - alpha / A)
+
+
+def band_biquad(waveform: Tensor, sample_rate: int, central_freq: float, Q: float = 0.707, noise: bool = False) -> Tensor:
+    r"""functional/filtering.py:180-229."""
+    dt = waveform.dtype
+    fc = _cpu_scalar(central_freq, dt)
+    w0 = 2 * math.pi * fc / sample_rate
+    bw_hz = fc / _cpu_scalar(Q, dt)
+    a2 = torch.exp(-2 * math.pi * bw_hz / sample_rate)
+    a1 = -4 * a2 / (1 + a2) * torch.cos(w0)
+    b0 = torch.sqrt(1 - a1 * a1 / (4 * a2)) * (1 - a2)
+    if noise:
+        mult = torch.sqrt(((1 + a2) * (1 + a2) - a1 * a1) * (1 - a2) / (1 + a2)) / b0
+        b0 = mult * b0
+    return biquad(waveform, b0, 0.0, 0.0, 1.0, a1, a2)
+
+
+def _shelf_terms(sample_rate: int, gain, central_freq, Q, dt):
+    w0 = _w0(central_freq, sample_rate, dt)
+    alpha = torch.sin(w0) / 2 / _cpu_scalar(Q, dt)
+    A = torch.exp(_cpu_scalar(gain, dt) / 40 * math.log(10))
+    return A, 2 * torch.sqrt(A) * alpha, (A - 1) * torch.cos(w0), (A + 1) * torch.cos(w0)
+
+
+def treble_biquad(waveform: Tensor, sample_rate: int, gain: float, central_freq: float = 3000, Q: float = 0.707) -> Tensor:
+    r"""functional/filtering.py:1363-1411 (high shelf)."""
+    A, t1, t2, t3 = _shelf_terms(sample_rate, gain, central_freq, Q, waveform.dtype)
+    b0 = A * ((A + 1) + t2 + t1)
+    b1 = -2 * A * ((A - 1) + t3)
+    b2 = A * ((A + 1) + t2 - t1)
+    a0 = (A + 1) - t2 + t1
+    a1 = 2 * ((A - 1) - t3)
+    a2 = (A + 1) - t2 - t1
+    return biquad(waveform, b0, b1, b2, a0, a1, a2)
+
+
+def bass_biquad(waveform: Tensor, sample_rate: int, gain: float, central_freq: float = 100, Q: float = 0.707) -> Tensor:
+    r"""functional/filtering.py:232-280 (low shelf; coefficients pre-divided by a0 as there)."""
+    A, t1, t2, t3 = _shelf_terms(sample_rate, gain, central_freq, Q, waveform.dtype)
+    b0 = A * ((A + 1) - t2 + t1)
+    b1 = 2 * A * ((A - 1) - t3)
+    b2 = A * ((A + 1) - t2 - t1)
+    a0 = (A + 1) + t2 + t1
+    a1 = -2 * ((A - 1) + t3)
+    a2 = (A + 1) + t2 - t1
+    return biquad(waveform, b0 / a0, b1 / a0, b2 / a0, a0 / a0, a1 / a0, a2 / a0)
+
+
+# --------------------------------------------------------------------------- #
+# fftconvolve                                                                 #
+# --------------------------------------------------------------------------- #
+
+
+def _check_shape_compatible(x: Tensor, y: Tensor) -> None:
+    if x.ndim != y.ndim:
+        raise ValueError(f"The operands must be the same dimension (got {x.ndim} and {y.ndim}).")
+    for i in range(x.ndim - 1):
+        xi, yi = x.size(i), y.size(i)
+        if xi == yi or xi == 1 or yi == 1:
+            continue
+        raise ValueError(f"Leading dimensions of x and y are not broadcastable (got {x.shape} and {y.shape}).")
+
+
+_CONV_MODES = ["full", "valid", "same"]
+
+
+def _check_convolve_mode(mode: str) -> None:
+    if mode not in _CONV_MODES:
+        raise ValueError(f"Unrecognized mode value '{mode}'. Please specify one of {_CONV_MODES}.")
+
+
+def fftconvolve(x: Tensor, y: Tensor, mode: str = "full") -> Tensor:
+    r"""Linear convolution along the last dim with broadcast leading dims and the reference's
+    full / valid / same crops (functional/functional.py:2222-2258)."""
+    _check_shape_compatible(x, y)
+    _check_convolve_mode(mode)
+    if not x.is_floating_point():
+        x = x.float()
+    if not y.is_floating_point():
+        y = y.float()
+    _require_device(x, "x")
+    _require_device(y, "y")
+    nx, ny = x.size(-1), y.size(-1)
+    n_full = nx + ny - 1
+    if mode == "full":
+        start, out_len = 0, n_full
+    elif mode == "valid":
+        out_len = max(nx, ny) - min(nx, ny) + 1
+        start = (n_full - out_len) // 2
+    else:
+        out_len = nx
+        start = (n_full - nx) // 2
+    lead = torch.broadcast_shapes(tuple(x.shape[:-1]), tuple(y.shape[:-1]))
+    rows = 1
+    for d in lead:
+        rows *= d
+    xr = x.reshape(-1, nx).contiguous()
+    yr = y.reshape(-1, ny).contiguous()
+
+    def row_map(t: Tensor):
+        if tuple(t.shape[:-1]) == tuple(lead):
+            return None
+        idx = torch.arange(xr.shape[0] if t is x else yr.shape[0], device=x.device).view(tuple(t.shape[:-1]))
+        return idx.expand(lead).reshape(-1).contiguous()
+
+    xmap, ymap = row_map(x), row_map(y)
+    out = torch.empty((rows, out_len), dtype=torch.float32, device=x.device)
+    if out.numel():
+        L = _lib.lib()
+        ws_bytes = L.aamd_fftconvolve_workspace(rows, nx, ny)
+        ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=x.device) if ws_bytes else None
+        _lib.check(L.aamd_fftconvolve_f32(
+            xr.data_ptr(), yr.data_ptr(), out.data_ptr(), rows, nx, ny,
+            xmap.data_ptr() if xmap is not None else None, ymap.data_ptr() if ymap is not None else None,
+            start, out_len, ws.data_ptr() if ws is not None else None, _lib.current_stream(x.device)))
+    return out.view(tuple(lead) + (out_len,))

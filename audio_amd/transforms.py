@@ -1,0 +1,291 @@
+"""Drop-in replacements for the hot-path modules of ``torchaudio.transforms``:
+Spectrogram, MelScale, MelSpectrogram, AmplitudeToDB, MFCC, Resample, FFTConvolve.
+
+Constructor / forward signatures, registered buffer names (``window``, ``fb``, ``dct_mat``,
+``kernel``), shapes, strides, warnings and error messages follow
+src/torchaudio/transforms/_transforms.py; ``forward`` calls the HIP kernels through
+``audio_amd.functional``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import warnings
+from typing import Callable, Optional, Union
+
+import torch
+from torch import Tensor
+
+from . import _host, _lib
+from . import functional as F
+
+__all__ = ["Spectrogram", "MelScale", "MelSpectrogram", "AmplitudeToDB", "MFCC", "Resample", "FFTConvolve"]
+
+
+class Spectrogram(torch.nn.Module):
+    r"""Spectrogram of ``(..., time)`` audio (reference: _transforms.py:25-123)."""
+    __constants__ = ["n_fft", "win_length", "hop_length", "pad", "power", "normalized"]
+
+    def __init__(
+        self,
+        n_fft: int = 400,
+        win_length: Optional[int] = None,
+        hop_length: Optional[int] = None,
+        pad: int = 0,
+        window_fn: Callable[..., Tensor] = torch.hann_window,
+        power: Optional[float] = 2.0,
+        normalized: Union[bool, str] = False,
+        wkwargs: Optional[dict] = None,
+        center: bool = True,
+        pad_mode: str = "reflect",
+        onesided: bool = True,
+        return_complex: Optional[bool] = None,
+    ) -> None:
+        super().__init__()
+        torch._C._log_api_usage_once("torchaudio.transforms.Spectrogram")
+        self.n_fft = n_fft
+        self.win_length = win_length if win_length is not None else n_fft
+        self.hop_length = hop_length if hop_length is not None else self.win_length // 2
+        window = window_fn(self.win_length) if wkwargs is None else window_fn(self.win_length, **wkwargs)
+        self.register_buffer("window", window)
+        self.pad = pad
+        self.power = power
+        self.normalized = normalized
+        self.center = center
+        self.pad_mode = pad_mode
+        self.onesided = onesided
+        if return_complex is not None:
+            warnings.warn(
+                "`return_complex` argument is now deprecated and is not effective."
+                "`torchaudio.transforms.Spectrogram(power=None)` always returns a tensor with "
+                "complex dtype. Please remove the argument in the function call."
+            )
+
+    def forward(self, waveform: Tensor) -> Tensor:
+        return F.spectrogram(waveform, self.pad, self.window, self.n_fft, self.hop_length, self.win_length,
+                             self.power, self.normalized, self.center, self.pad_mode, self.onesided)
+
+
+class AmplitudeToDB(torch.nn.Module):
+    r"""Power/amplitude -> dB (reference: _transforms.py:300-346)."""
+    __constants__ = ["multiplier", "amin", "ref_value", "db_multiplier"]
+
+    def __init__(self, stype: str = "power", top_db: Optional[float] = None) -> None:
+        super().__init__()
+        self.stype = stype
+        if top_db is not None and top_db < 0:
+            raise ValueError("top_db must be positive value")
+        self.top_db = top_db
+        self.multiplier = 10.0 if stype == "power" else 20.0
+        self.amin = 1e-10
+        self.ref_value = 1.0
+        self.db_multiplier = math.log10(max(self.amin, self.ref_value))
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F.amplitude_to_DB(x, self.multiplier, self.amin, self.db_multiplier, self.top_db)
+
+
+class MelScale(torch.nn.Module):
+    r"""STFT bins -> mel bins with triangular filters (reference: _transforms.py:349-415)."""
+    __constants__ = ["n_mels", "sample_rate", "f_min", "f_max"]
+
+    def __init__(
+        self,
+        n_mels: int = 128,
+        sample_rate: int = 16000,
+        f_min: float = 0.0,
+        f_max: Optional[float] = None,
+        n_stft: int = 201,
+        norm: Optional[str] = None,
+        mel_scale: str = "htk",
+    ) -> None:
+        super().__init__()
+        self.n_mels = n_mels
+        self.sample_rate = sample_rate
+        self.f_max = f_max if f_max is not None else float(sample_rate // 2)
+        self.f_min = f_min
+        self.norm = norm
+        self.mel_scale = mel_scale
+        if f_min > self.f_max:
+            raise ValueError("Require f_min: {} <= f_max: {}".format(f_min, self.f_max))
+        fb = F.melscale_fbanks(n_stft, self.f_min, self.f_max, self.n_mels, self.sample_rate, self.norm, self.mel_scale)
+        self.register_buffer("fb", fb)
+
+    def forward(self, specgram: Tensor) -> Tensor:
+        return F.mel_scale(specgram, self.fb)
+
+
+class MelSpectrogram(torch.nn.Module):
+    r"""MelSpectrogram (reference: _transforms.py:506-622).  ``forward`` is ONE fused kernel:
+    framing -> window -> FFT -> |X|^power -> banded mel; the (rows, T, freq) spectrogram the
+    reference materialises between its two sub-modules never touches HBM."""
+    __constants__ = ["sample_rate", "n_fft", "win_length", "hop_length", "pad", "n_mels", "f_min"]
+
+    def __init__(
+        self,
+        sample_rate: int = 16000,
+        n_fft: int = 400,
+        win_length: Optional[int] = None,
+        hop_length: Optional[int] = None,
+        f_min: float = 0.0,
+        f_max: Optional[float] = None,
+        pad: int = 0,
+        n_mels: int = 128,
+        window_fn: Callable[..., Tensor] = torch.hann_window,
+        power: float = 2.0,
+        normalized: bool = False,
+        wkwargs: Optional[dict] = None,
+        center: bool = True,
+        pad_mode: str = "reflect",
+        onesided: Optional[bool] = None,
+        norm: Optional[str] = None,
+        mel_scale: str = "htk",
+    ) -> None:
+        super().__init__()
+        torch._C._log_api_usage_once("torchaudio.transforms.MelSpectrogram")
+        if onesided is not None:
+            warnings.warn(
+                "Argument 'onesided' has been deprecated and has no influence on the behavior of this module."
+            )
+        self.sample_rate = sample_rate
+        self.n_fft = n_fft
+        self.win_length = win_length if win_length is not None else n_fft
+        self.hop_length = hop_length if hop_length is not None else self.win_length // 2
+        self.pad = pad
+        self.power = power
+        self.normalized = normalized
+        self.n_mels = n_mels
+        self.f_max = f_max
+        self.f_min = f_min
+        self.spectrogram = Spectrogram(
+            n_fft=self.n_fft, win_length=self.win_length, hop_length=self.hop_length, pad=self.pad,
+            window_fn=window_fn, power=self.power, normalized=self.normalized, wkwargs=wkwargs,
+            center=center, pad_mode=pad_mode, onesided=True,
+        )
+        self.mel_scale = MelScale(self.n_mels, self.sample_rate, self.f_min, self.f_max, self.n_fft // 2 + 1,
+                                  norm, mel_scale)
+
+    def _frame_major(self, waveform: Tensor) -> Tensor:
+        sp = self.spectrogram
+        return F._melspectrogram(waveform, sp.pad, sp.window, self.mel_scale.fb, sp.n_fft, sp.hop_length,
+                                 sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode)
+
+    def forward(self, waveform: Tensor) -> Tensor:
+        out = self._frame_major(waveform)                       # (rows, T, n_mels)
+        lead = tuple(waveform.shape[:-1])
+        return out.view(lead + out.shape[-2:]).transpose(-1, -2)
+
+
+class MFCC(torch.nn.Module):
+    r"""MFCC (reference: _transforms.py:625-709): fused mel kernel, then dB (+ top_db = 80 with the
+    reference's grouping of the cut-off) or log, then the DCT-II as one kernel."""
+    __constants__ = ["sample_rate", "n_mfcc", "dct_type", "top_db", "log_mels"]
+
+    def __init__(
+        self,
+        sample_rate: int = 16000,
+        n_mfcc: int = 40,
+        dct_type: int = 2,
+        norm: str = "ortho",
+        log_mels: bool = False,
+        melkwargs: Optional[dict] = None,
+    ) -> None:
+        super().__init__()
+        supported_dct_types = [2]
+        if dct_type not in supported_dct_types:
+            raise ValueError("DCT type not supported: {}".format(dct_type))
+        self.sample_rate = sample_rate
+        self.n_mfcc = n_mfcc
+        self.dct_type = dct_type
+        self.norm = norm
+        self.top_db = 80.0
+        self.amplitude_to_DB = AmplitudeToDB("power", self.top_db)
+        melkwargs = melkwargs or {}
+        self.MelSpectrogram = MelSpectrogram(sample_rate=self.sample_rate, **melkwargs)
+        if self.n_mfcc > self.MelSpectrogram.n_mels:
+            raise ValueError("Cannot select more MFCC coefficients than # mel bins")
+        dct_mat = F.create_dct(self.n_mfcc, self.MelSpectrogram.n_mels, self.norm)
+        self.register_buffer("dct_mat", dct_mat)
+        self.log_mels = log_mels
+        #: optional hook ``fn(group_max: Tensor) -> None`` run between the dB pass and the clamp;
+        #: audio_amd.distributed installs an all-reduce(MAX) here when a batch is sharded.
+        self.group_max_hook: Optional[Callable[[Tensor], None]] = None
+
+    def forward(self, waveform: Tensor) -> Tensor:
+        mel = self.MelSpectrogram._frame_major(waveform)        # (rows, T, n_mels) frame-major
+        rows, T, n_mels = mel.shape
+        lead = tuple(waveform.shape[:-1])
+        dev = waveform.device
+        out = torch.empty((rows, T, self.n_mfcc), dtype=torch.float32, device=dev)
+        dct = self.dct_mat.to(device=dev, dtype=torch.float32).contiguous()
+        if out.numel():
+            L = _lib.lib()
+            stream = _lib.current_stream(dev)
+            n_vec = rows * T
+            if self.log_mels:
+                _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), n_vec, n_mels,
+                                               self.n_mfcc, 1, None, 1, -1.0, stream))
+            else:
+                # amplitude_to_DB's cut-off groups: the mel tensor is (..., C?, n_mels, T); one cut-off
+                # per leading item of its (-1, C, n_mels, T) view (functional.py:393-402)
+                packed = waveform.shape[-2] if waveform.dim() > 1 else 1
+                n_groups = rows // packed
+                gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
+                a2db = self.amplitude_to_DB
+                _lib.check(L.aamd_amplitude_to_db_f32(mel.data_ptr(), mel.data_ptr(), mel.numel(), a2db.multiplier,
+                                                      a2db.amin, a2db.db_multiplier, gmax.data_ptr(),
+                                                      packed * T * n_mels, stream))
+                if self.group_max_hook is not None:
+                    self.group_max_hook(gmax)
+                _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), n_vec, n_mels,
+                                               self.n_mfcc, 2, gmax.data_ptr(), packed * T, float(self.top_db),
+                                               stream))
+        return out.view(lead + (T, self.n_mfcc)).transpose(-1, -2)
+
+
+class Resample(torch.nn.Module):
+    r"""Resample (reference: _transforms.py:899-980): the tap table is computed once in float64
+    and cached as the float32 buffer ``kernel``; forward is the polyphase HIP kernel."""
+
+    def __init__(
+        self,
+        orig_freq: int = 16000,
+        new_freq: int = 16000,
+        resampling_method: str = "sinc_interp_hann",
+        lowpass_filter_width: int = 6,
+        rolloff: float = 0.99,
+        beta: Optional[float] = None,
+        *,
+        dtype: Optional[torch.dtype] = None,
+    ) -> None:
+        super().__init__()
+        self.orig_freq = orig_freq
+        self.new_freq = new_freq
+        self.gcd = math.gcd(int(self.orig_freq), int(self.new_freq))
+        self.resampling_method = resampling_method
+        self.lowpass_filter_width = lowpass_filter_width
+        self.rolloff = rolloff
+        self.beta = beta
+        if self.orig_freq != self.new_freq:
+            kernel, self.width = _host.sinc_resample_kernel(
+                self.orig_freq, self.new_freq, self.gcd, self.lowpass_filter_width, self.rolloff,
+                self.resampling_method, beta, dtype=dtype)
+            self.register_buffer("kernel", kernel)
+
+    def forward(self, waveform: Tensor) -> Tensor:
+        if self.orig_freq == self.new_freq:
+            return waveform
+        return F._apply_sinc_resample_kernel(waveform, self.orig_freq, self.new_freq, self.gcd, self.kernel,
+                                             self.width)
+
+
+class FFTConvolve(torch.nn.Module):
+    r"""Convolution along the last dim (reference: _transforms.py:1906-1948)."""
+
+    def __init__(self, mode: str = "full") -> None:
+        super().__init__()
+        F._check_convolve_mode(mode)
+        self.mode = mode
+
+    def forward(self, x: Tensor, y: Tensor) -> Tensor:
+        return F.fftconvolve(x, y, mode=self.mode)

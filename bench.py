@@ -1,0 +1,124 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): audio-sec/sec of MelSpectrogram
+(n_fft=400, hop=160, n_mels=80) on batch = 256 x 10 s @ 16 kHz fp32 PER GPU (weak scaling).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; batches are born sharded --
+   the path is embarrassingly parallel over clips, so there is no data-path collective; the
+   only communication is the barrier + MAX-reduce of the timing.)
+
+Prints ONE JSON line on rank 0 with the driver's fields plus `roofline` (dominant kernel vs the
+HBM roofline, timed live with HIP events on the launch stream) and `cpu_baseline` (the
+reference's CPU composition timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BATCH, SECONDS, SR, N_FFT, HOP, N_MELS = 256, 10.0, 16000, 400, 160, 80
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import audio_amd.transforms as T
+    mel = T.MelSpectrogram(sample_rate=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS).to(dev)
+    L = int(SECONDS * SR)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = (0.5 * torch.randn(BATCH, L, device=dev, generator=g)).clamp_(-1, 1)   # resident in HBM
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = mel(x)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()                      # the kernels are launched on torch's current stream
+        for _ in range(args.steps):
+            y = mel(x)
+        e1.record()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / args.steps
+
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    n_frames = y.shape[-1]
+    assert tuple(y.shape) == (BATCH, N_MELS, n_frames) and n_frames == 1001
+
+    if rank == 0:
+        audio_s = world * BATCH * SECONDS * args.steps
+        algo_bytes = BATCH * L * 4 + BATCH * n_frames * N_MELS * 4          # 245 821 440 B
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "audio-sec/sec MelSpectrogram (b=256, 16kHz, n_fft=400, n_mels=80)",
+            "value": audio_s / wall,
+            "unit": "audio-sec/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "MelSpectrogram n_fft=400 hop=160 n_mels=80, batch=256 x 10 s @16 kHz fp32 per GPU "
+                                   "(BASELINE configs[1])", "per_gpu_batch": BATCH, "clip_seconds": SECONDS,
+                       "sharding": "clips born sharded across ranks, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "melspec400_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
+                         "read_only_frac": (BATCH * L * 4) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import torch_cpu_ref
+            n_clips = 32
+            v, cores, calls = torch_cpu_ref.time_mel_baseline(n_clips, SECONDS, SR, N_FFT, HOP, N_MELS)
+            out["cpu_baseline"] = {"value": v, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+                                   "sample": f"{n_clips} of the 256 clips x 10 s, best of {calls} calls; same ATen "
+                                             "ops as torchaudio's CPU path (torch.stft + abs().pow(2) + matmul)"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

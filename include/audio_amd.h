@@ -1,0 +1,171 @@
+/*
+ * audio_amd.h -- C ABI of libaudio_amd.so: MI355X (gfx950) native kernels for the
+ * torchaudio DSP hot path (Spectrogram / MelSpectrogram / MFCC / Resample / lfilter /
+ * fftconvolve).
+ *
+ * Boundary contract
+ *   - plain C, no torch types: device pointers + sizes + a HIP stream handle (void* =
+ *     hipStream_t; NULL = the legacy default stream).  The caller owns every buffer; the
+ *     library allocates nothing, keeps no global mutable state and is re-entrant per
+ *     (device, stream).  Kernels are enqueued asynchronously on `stream`.
+ *   - every entry point returns AAMD_OK (0) or a negative AAMD_E* code;
+ *     aamd_last_error() returns a thread-local message for the last failure.
+ *   - all tensors are dense row-major fp32 unless stated; "rows" = the flattened leading
+ *     dims of the reference's (..., time) tensors.
+ *
+ * What each entry point replaces in the reference (pytorch/audio, paths relative to
+ * src/torchaudio/):
+ *   aamd_spectrogram_f32      functional/functional.py:54-145 (F.spectrogram = pad +
+ *                             torch.stft + normalisation + abs/pow), called by
+ *                             transforms/_transforms.py:101-123 (Spectrogram.forward)
+ *   aamd_melspectrogram_f32   transforms/_transforms.py:612-622 (MelSpectrogram.forward =
+ *                             Spectrogram.forward + MelScale.forward :403-415)
+ *   aamd_mel_scale_f32        transforms/_transforms.py:403-415 (MelScale.forward on a
+ *                             caller-supplied spectrogram)
+ *   aamd_amplitude_to_db_f32  functional/functional.py:356-404 (F.amplitude_to_DB)
+ *   aamd_mfcc_dct_f32         transforms/_transforms.py:692-709 (MFCC.forward after the
+ *                             mel step: dB/log + top_db clamp + DCT-II matmul)
+ *   aamd_resample_f32         functional/functional.py:1405-1432 (_apply_sinc_resample_kernel:
+ *                             pad + strided conv1d + phase interleave + crop)
+ *   aamd_lfilter_f32          functional/filtering.py:1027-1099 (_lfilter + clamp), i.e.
+ *                             DifferentiableFIR.forward :943-951 and the native IIR loop
+ *                             libtorchaudio/lfilter.cpp:17-48 / iir_cuda.cu:10-35
+ *                             (op torchaudio::_lfilter_core_loop, lfilter.cpp:118-124)
+ *   aamd_fftconvolve_f32      functional/functional.py:2222-2258 (F.fftconvolve)
+ *
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef AUDIO_AMD_H
+#define AUDIO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AAMD_ABI_VERSION 1
+
+enum {
+  AAMD_OK = 0,
+  AAMD_EINVAL = -1,      /* bad argument (message in aamd_last_error) */
+  AAMD_EUNSUPPORTED = -2,/* valid request this build cannot serve (e.g. n_fft too large) */
+  AAMD_EHIP = -3         /* a HIP runtime call / kernel launch failed */
+};
+
+/* pad modes of torch.stft(center=True) (torch/functional.py:675-680) */
+enum { AAMD_PAD_REFLECT = 0, AAMD_PAD_CONSTANT = 1, AAMD_PAD_REPLICATE = 2, AAMD_PAD_CIRCULAR = 3 };
+
+/* Framing + FFT description shared by the STFT-family entry points. */
+typedef struct aamd_stft_desc {
+  int64_t rows;        /* number of waveforms (flattened leading dims) */
+  int64_t length;      /* samples per waveform BEFORE `pad` */
+  int64_t row_stride;  /* elements between consecutive waveforms (>= length) */
+  int32_t n_fft;
+  int32_t hop;
+  int32_t pad;         /* F.spectrogram's two-sided constant zero padding (functional.py:112-114) */
+  int32_t center;      /* 0/1 */
+  int32_t pad_mode;    /* AAMD_PAD_* (used when center) */
+  int32_t onesided;    /* 0/1 */
+  int32_t n_frames;    /* must equal 1 + (L' - n_fft)/hop, L' = length + 2*pad (+ 2*(n_fft/2) if center) */
+  float   scale;       /* multiplies the complex spectrum: 1, n_fft^-1/2 ("frame_length") or 1/||w||_2 ("window") */
+  float   power;       /* <= 0: complex output;  1: |X|;  2: |X|^2;  else |X|^power */
+} aamd_stft_desc;
+
+/* Banded view of a mel filterbank fb[n_freq][n_mels] (built by the host from the SAME fb
+ * tensor the reference multiplies with): column m is non-zero only on rows
+ * [lo[m], lo[m]+width[m]); weights[m*max_width + i] = fb[lo[m]+i][m], zero padded. */
+typedef struct aamd_mel_bands {
+  int32_t n_mels;
+  int32_t max_width;
+  const int32_t* lo;       /* device, n_mels */
+  const int32_t* width;    /* device, n_mels */
+  const float*   weights;  /* device, n_mels * max_width */
+} aamd_mel_bands;
+
+int         aamd_abi_version(void);
+const char* aamd_last_error(void);
+/* "gfx950" when the current device is an MI355X-class part; fills name (<=63 chars). */
+int         aamd_device_info(char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
+
+/* ---- STFT family --------------------------------------------------------------------- */
+
+/* window: device float[n_fft] (already centre zero-padded from win_length, as aten::stft does).
+ * twiddle: device float[2*n_fft], twiddle[2t],[2t+1] = cos, -sin(2*pi*t/n_fft), fp64-computed.
+ * out: frame-major.  power > 0: float[rows][n_frames][n_freq];  power <= 0: interleaved complex
+ *      float[rows][n_frames][n_freq][2].  n_freq = onesided ? n_fft/2+1 : n_fft.
+ * The reference's logical (..., freq, time) tensor is the transposed VIEW of this buffer, with
+ * exactly the strides torch.stft returns. */
+int aamd_spectrogram_f32(const float* wav, const float* window, const float* twiddle,
+                         float* out, const aamd_stft_desc* desc, void* stream);
+
+/* Fused STFT -> |X|^power -> banded mel.  out: float[rows][n_frames][n_mels].
+ * Uses the register/LDS radix-20x20 kernel when (n_fft, hop) = (400, 160), center/reflect,
+ * onesided; every other shape takes the generic LDS Stockham kernel -- same results. */
+int aamd_melspectrogram_f32(const float* wav, const float* window, const float* twiddle,
+                            const aamd_mel_bands* bands, float* out,
+                            const aamd_stft_desc* desc, void* stream);
+
+/* MelScale.forward on an existing spectrogram given frame-major: spec float[rows][n_frames][n_freq]
+ * -> out float[rows][n_frames][n_mels]. */
+int aamd_mel_scale_f32(const float* spec, const aamd_mel_bands* bands, float* out,
+                       int64_t rows, int32_t n_frames, int32_t n_freq, void* stream);
+
+/* ---- dB / MFCC ------------------------------------------------------------------------- */
+
+/* x_db = multiplier*log10(max(x, amin)) - multiplier*db_multiplier (functional.py:390-391).
+ * If group_max != NULL, also atomically max-reduces x_db of group g = i / group_size into
+ * group_max[g] (float bit pattern; caller pre-fills with -inf).  out may alias x. */
+int aamd_amplitude_to_db_f32(const float* x, float* out, int64_t n, float multiplier, float amin,
+                             float db_multiplier, float* group_max, int64_t group_size, void* stream);
+
+/* out[i] = max(x[i], group_max[i / group_size] - top_db)  (functional.py:393-402). */
+int aamd_db_clamp_f32(const float* x, float* out, int64_t n, const float* group_max,
+                      int64_t group_size, float top_db, void* stream);
+
+/* MFCC tail on frame-major mel features mel float[n_vec][n_mels]:
+ *   log_mode 0: y = 10*log10(max(mel,1e-10)) clamped at group_max[g]-top_db (top_db<0: no clamp)
+ *   log_mode 1: y = log(mel + 1e-6)
+ *   log_mode 2: mel already holds y (dB), only clamp
+ * then out[v][k] = sum_m y[v][m] * dct[m][k]   (dct: device float[n_mels][n_mfcc]).
+ * g = v / vec_per_group. */
+int aamd_mfcc_dct_f32(const float* mel, const float* dct, float* out, int64_t n_vec,
+                      int32_t n_mels, int32_t n_mfcc, int32_t log_mode, const float* group_max,
+                      int64_t vec_per_group, float top_db, void* stream);
+
+/* ---- Resample --------------------------------------------------------------------------- */
+
+/* y[row][q*new + p] = sum_k kernel[p][k] * xpad[row][q*orig + k],  xpad = [0]*width ++ x ++ [0]*(width+orig),
+ * for the first out_len = ceil(new*length/orig) outputs.  kernel: device float[new][taps],
+ * taps = 2*width + orig.  out: float[rows][out_len]. */
+int aamd_resample_f32(const float* wav, const float* kernel, float* out, int64_t rows,
+                      int64_t length, int64_t row_stride, int32_t orig, int32_t new_, int32_t width,
+                      int64_t out_len, void* stream);
+
+/* ---- lfilter ---------------------------------------------------------------------------- */
+
+/* x, y: float[batch][channels][length]; a, b: device float[n_coeff_rows][n_order] with
+ * n_coeff_rows = 1 (shared) or channels (per channel), lower delays first, NOT yet normalised
+ * by a0 (the kernel divides, like filtering.py:1028-1029).  clamp: 0/1 -> clamp(y,-1,1) after
+ * the recursion.  n_stages > 1 applies a cascade: a, b are float[n_stages][n_coeff_rows][n_order]
+ * and each stage's (clamped) output feeds the next -- equal to n_stages sequential F.lfilter calls. */
+int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, int64_t batch,
+                     int32_t channels, int64_t length, int32_t n_order, int32_t n_coeff_rows,
+                     int32_t n_stages, int32_t clamp, void* stream);
+
+/* ---- fftconvolve ------------------------------------------------------------------------ */
+
+/* Linear convolution along the last dim: out[row][n] = sum_m x[rx][m] * y[ry][n-m], full length
+ * nx+ny-1, then the slice [start, start+out_len) is stored (mode crop, functional.py:2207-2219).
+ * x_row_of / y_row_of are device int64[rows] maps from output row to input row (broadcasting);
+ * NULL means identity.  Direct (time-domain) tiling for short y, overlap-save on the LDS FFT
+ * for long y; `workspace` must hold aamd_fftconvolve_workspace() bytes (may be NULL if that is 0). */
+int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t nx, int64_t ny);
+int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t nx,
+                         int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of,
+                         int64_t start, int64_t out_len, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUDIO_AMD_H */

@@ -1,0 +1,208 @@
+// CPU replay of the HIP kernels' per-thread phase functions (audio_amd/csrc/*.h compiled with
+// g++, no GPU).  Each driver below mirrors the corresponding __global__ kernel's control flow,
+// replacing "all threads run phase X, then __syncthreads()" by a loop over thread ids.
+// TEST INFRASTRUCTURE ONLY: lets the build container check index math / algorithms of the
+// exact device source before a GPU is available.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/audio_amd.h"
+#include "../../audio_amd/csrc/db_mfcc.h"
+#include "../../audio_amd/csrc/fftconv.h"
+#include "../../audio_amd/csrc/lfilter.h"
+#include "../../audio_amd/csrc/melspec400.h"
+#include "../../audio_amd/csrc/resample.h"
+#include "../../audio_amd/csrc/stft_generic.h"
+
+using namespace aamd;
+
+static void fill_geom(const aamd_stft_desc* d, StftGeom& g) {
+  g.rows = d->rows; g.length = d->length; g.row_stride = d->row_stride;
+  g.n_fft = d->n_fft; g.hop = d->hop; g.pad = d->pad; g.center = d->center;
+  g.pad_mode = d->pad_mode; g.onesided = d->onesided; g.n_frames = d->n_frames;
+  g.n_freq = d->onesided ? d->n_fft / 2 + 1 : d->n_fft;
+  g.scale = d->scale; g.power = d->power;
+  g.n_stages = plan_radices(d->n_fft, g.radix);
+}
+
+extern "C" {
+
+int sim_stft_generic(const float* wav, const float* window, const float* tw, const aamd_mel_bands* bands,
+                     float* out, const aamd_stft_desc* d, int epi_mel) {
+  StftGeom g; fill_geom(d, g);
+  if (g.n_stages < 0) return -1;
+  MelBandsDev mb{};
+  if (epi_mel) { mb.n_mels = bands->n_mels; mb.max_width = bands->max_width; mb.lo = bands->lo; mb.width = bands->width; mb.weights = bands->weights; }
+  const int nthr = 256;
+  std::vector<cplx<float>> A(g.n_fft), B(g.n_fft);
+  std::vector<float> P(g.n_freq);
+  const cplx<float>* twc = reinterpret_cast<const cplx<float>*>(tw);
+  const int opf = epi_mel ? mb.n_mels : (g.power <= 0.f ? 2 * g.n_freq : g.n_freq);
+  for (int64_t row = 0; row < g.rows; ++row)
+    for (int64_t t = 0; t < g.n_frames; ++t) {
+      const float* wr = wav + row * g.row_stride;
+      for (int tid = 0; tid < nthr; ++tid) stft_load_frame<float>(tid, nthr, g, wr, window, t, A.data());
+      cplx<float>* x = A.data(); cplx<float>* y = B.data();
+      int s = 1;
+      for (int st = 0; st < g.n_stages; ++st) {
+        for (int tid = 0; tid < nthr; ++tid) stockham_stage<float>(tid, nthr, g.n_fft, g.radix[st], s, x, y, twc);
+        s *= g.radix[st];
+        std::swap(x, y);
+      }
+      float* of = out + (row * g.n_frames + t) * (int64_t)opf;
+      if (!epi_mel) {
+        for (int tid = 0; tid < nthr; ++tid) stft_store_spec<float>(tid, nthr, g, x, of);
+      } else {
+        for (int tid = 0; tid < nthr; ++tid) stft_power_to_lds<float>(tid, nthr, g, x, P.data());
+        for (int tid = 0; tid < nthr; ++tid) mel_from_lds<float>(tid, nthr, mb, P.data(), of);
+      }
+    }
+  return 0;
+}
+
+int sim_melspec400(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
+                   float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale) {
+  MelBandsDev mb{bands->n_mels, bands->max_width, bands->lo, bands->width, bands->weights};
+  std::vector<float> lds(m400::kLdsDwordsPerWave, 0.f);
+  m400::LaneConst c[64];
+  for (int l = 0; l < 64; ++l) m400::lane_init(l, window, tw400, scale, c[l]);
+  const int tiles_per_row = (n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
+  static float zr[64][20], zi[64][20], gr[64][10], gi[64][10];
+  for (int64_t row = 0; row < rows; ++row)
+    for (int tl = 0; tl < tiles_per_row; ++tl) {
+      const int64_t t0 = (int64_t)tl * m400::kFramesPerWave;
+      const float* wr = wav + row * row_stride;
+      const bool interior = (t0 * m400::kHop - m400::kPad >= 0) &&
+                            ((t0 + m400::kFramesPerWave - 1) * m400::kHop + (m400::kN - m400::kPad) <= length) &&
+                            (t0 + m400::kFramesPerWave <= n_frames);
+      for (int l = 0; l < 64; ++l) {
+        if (interior) m400::phase_a<false>(c[l], wr, length, t0, n_frames, lds.data());
+        else m400::phase_a<true>(c[l], wr, length, t0, n_frames, lds.data());
+      }
+      for (int l = 0; l < 64; ++l) m400::phase_b1(c[l], lds.data(), zr[l], zi[l]);
+      for (int l = 0; l < 64; ++l) {
+        const int pl = m400::partner_lane(c[l]);
+        for (int i = 0; i < 10; ++i) { gr[l][i] = zr[pl][10 + i]; gi[l][i] = zi[pl][10 + i]; }
+      }
+      for (int l = 0; l < 64; ++l) m400::phase_b2(c[l], zr[l], zi[l], gr[l], gi[l], lds.data());
+      for (int l = 0; l < 64; ++l) m400::phase_c(l, mb, lds.data(), out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
+    }
+  return 0;
+}
+
+int sim_resample(const float* wav, const float* kern, float* out, int64_t rows, int64_t length, int64_t row_stride,
+                 int orig, int new_, int width, int64_t out_len, int qt, int use_lds) {
+  ResampleGeom g;
+  g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
+  g.orig = orig; g.new_ = new_; g.width = width; g.taps = 2 * width + orig; g.qt = qt; g.use_lds = use_lds;
+  const int64_t nq = (out_len + new_ - 1) / new_;
+  g.nq_tiles = (int)((nq + qt - 1) / qt);
+  std::vector<float> xs((size_t)(qt - 1) * orig + g.taps + 1);
+  for (int64_t row = 0; row < rows; ++row)
+    for (int tile = 0; tile < g.nq_tiles; ++tile) {
+      const int64_t q0 = (int64_t)tile * qt;
+      const float* wr = wav + row * row_stride;
+      if (use_lds) for (int tid = 0; tid < 256; ++tid) resample_stage(tid, 256, g, wr, q0, xs.data());
+      for (int tid = 0; tid < 256; ++tid) resample_compute(tid, 256, g, kern, wr, xs.data(), q0, out + row * out_len);
+    }
+  return 0;
+}
+
+}  // extern C (pause)
+template <int D>
+static int sim_lfilter_d(const float* x, const float* a, const float* b, float* y, int64_t n_seq, int channels,
+                         int64_t length, int n_order, int n_rows, int n_stages, int clamp) {
+  using L = LfLds<D>;
+  const int stage_floats = L::total - L::H;
+  std::vector<float> ldsv((size_t)L::total + (size_t)n_stages * stage_floats, 0.f);
+  float* lds = ldsv.data();
+  float* stage_store = lds + L::total;
+  std::vector<LfThread<D>> th(kLfThreads);
+  for (int64_t seq = 0; seq < n_seq; ++seq) {
+    const int ch = (int)(seq % channels);
+    const int crow = (n_rows == 1) ? 0 : ch;
+    for (int st = 0; st < n_stages; ++st) {
+      const int64_t coff = ((int64_t)st * n_rows + crow) * n_order;
+      lf_build_tables<D>(a + coff, b + coff, n_order, lds);
+      for (int e = 0; e < D; ++e) { lds[L::cx + e] = 0.f; lds[L::cy + e] = 0.f; }
+      for (int i = 0; i < stage_floats; ++i) stage_store[st * stage_floats + i] = lds[L::H + i];
+    }
+    const float* xs = x + seq * length;
+    float* ys = y + seq * length;
+    for (int64_t n0 = 0; n0 < length; n0 += kLfBlock) {
+      for (int i = 0; i < kLfBlock; ++i) {
+        const int64_t n = n0 + i;
+        lds[L::blk + (i / kLfChunk) * kLfChunkStride + (i % kLfChunk)] = (n < length) ? xs[n] : 0.f;
+      }
+      for (int st = 0; st < n_stages; ++st) {
+        for (int i = 0; i < stage_floats; ++i) lds[L::H + i] = stage_store[st * stage_floats + i];
+        for (int tid = 0; tid < kLfThreads; ++tid) lf_chunk_pass<D>(tid, lds, th[tid]);
+        lf_save_input_carry<D>(lds);
+        bool src_is_a = true;
+        for (int k = 0; k < kLfScanSteps; ++k) {
+          for (int tid = 0; tid < kLfThreads; ++tid) lf_scan_step<D>(tid, k, lds, th[tid], src_is_a);
+          src_is_a = !src_is_a;
+        }
+        for (int tid = 0; tid < kLfThreads; ++tid) lf_correct_store<D>(tid, lds, th[tid], src_is_a, clamp);
+        lf_save_output_carry<D>(lds, src_is_a);
+        for (int i = 0; i < 2 * D; ++i) stage_store[st * stage_floats + (L::cx - L::H) + i] = lds[L::cx + i];
+      }
+      for (int i = 0; i < kLfBlock; ++i) {
+        const int64_t n = n0 + i;
+        if (n < length) ys[n] = lds[L::blk + (i / kLfChunk) * kLfChunkStride + (i % kLfChunk)];
+      }
+    }
+  }
+  return 0;
+}
+
+extern "C" {
+int sim_lfilter(const float* x, const float* a, const float* b, float* y, int64_t batch, int channels, int64_t length,
+                int n_order, int n_rows, int n_stages, int clamp) {
+  const int d = n_order - 1;
+  const int64_t n_seq = batch * channels;
+#define SIM_LF(D) return sim_lfilter_d<D>(x, a, b, y, n_seq, channels, length, n_order, n_rows, n_stages, clamp)
+  if (d <= 1) SIM_LF(1);
+  if (d <= 2) SIM_LF(2);
+  if (d <= 3) SIM_LF(3);
+  if (d <= 4) SIM_LF(4);
+  if (d <= 6) SIM_LF(6);
+  if (d <= 8) SIM_LF(8);
+  if (d <= 12) SIM_LF(12);
+  if (d <= 16) SIM_LF(16);
+  return -1;
+}
+
+int sim_fftconv(const float* x, const float* y, float* out, int64_t rows, int64_t nx, int64_t ny,
+                const int64_t* x_row_of, const int64_t* y_row_of, int64_t start, int64_t out_len) {
+  FcGeom g; g.rows = rows; g.start = start; g.out_len = out_len;
+  const bool swap = ny > nx;
+  const float* xa = swap ? y : x; const float* ya = swap ? x : y;
+  g.nx = swap ? ny : nx; g.ny = swap ? nx : ny;
+  const int64_t* xmap = swap ? y_row_of : x_row_of; const int64_t* ymap = swap ? x_row_of : y_row_of;
+  g.n_tiles = (int)((out_len + kFcTN - 1) / kFcTN);
+  std::vector<float> xs(kFcTN + kFcTY), ys(kFcTY);
+  for (int64_t row = 0; row < rows; ++row)
+    for (int tile = 0; tile < g.n_tiles; ++tile) {
+      const int64_t rx = xmap ? xmap[row] : row, ry = ymap ? ymap[row] : row;
+      const float* xr = xa + rx * g.nx; const float* yr = ya + ry * g.ny;
+      const int64_t n0 = start + (int64_t)tile * kFcTN;
+      static float acc[kFcThreads][kFcOutPerThread];
+      std::memset(acc, 0, sizeof(acc));
+      for (int64_t j0 = 0; j0 < g.ny; j0 += kFcTY) {
+        const int64_t xbase = n0 - j0 - (kFcTY - 1);
+        if (xbase >= g.nx || xbase + kFcTN + kFcTY - 1 <= 0) continue;
+        for (int tid = 0; tid < kFcThreads; ++tid) fc_stage(tid, kFcThreads, g, xr, yr, j0, xbase, xs.data(), ys.data());
+        for (int tid = 0; tid < kFcThreads; ++tid) fc_accumulate(tid, xs.data(), ys.data(), acc[tid]);
+      }
+      for (int tid = 0; tid < kFcThreads; ++tid)
+        for (int i = 0; i < kFcOutPerThread; ++i) {
+          const int64_t n = (int64_t)tile * kFcTN + tid + i * kFcThreads;
+          if (n < out_len) out[row * out_len + n] = acc[tid][i];
+        }
+    }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+"""Build + load the CPU replay of the HIP kernels' phase functions (tests/cpu_sim/sim.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from audio_amd import _host, _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "cpu_sim", "sim.cpp")
+OUT = os.path.join(HERE, "cpu_sim", "_build", "libaamd_sim.so")
+CSRC = os.path.join(os.path.dirname(HERE), "audio_amd", "csrc")
+
+_sim = None
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def sim():
+    global _sim
+    if _sim is None:
+        if _stale():
+            os.makedirs(os.path.dirname(OUT), exist_ok=True)
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT])
+        _sim = C.CDLL(OUT)
+    return _sim
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HostBands:
+    def __init__(self, fb):
+        self.lo, self.width, self.weights, self.max_width = _host.mel_band_table(np.asarray(fb))
+        self.lo = np.ascontiguousarray(self.lo)
+        self.width = np.ascontiguousarray(self.width)
+        self.weights = np.ascontiguousarray(self.weights)
+        self.n_mels = self.lo.shape[0]
+        self.struct = _lib.MelBands(self.n_mels, self.max_width, self.lo.ctypes.data, self.width.ctypes.data,
+                                    self.weights.ctypes.data)
+
+
+def make_desc(rows, length, n_fft, hop, pad=0, center=True, pad_mode="reflect", onesided=True, scale=1.0,
+              power=2.0):
+    T = _host.frame_count(length, n_fft, hop, center, pad)
+    return _lib.StftDesc(rows, length, length, n_fft, hop, pad, int(center), _lib.PAD_MODES[pad_mode],
+                         int(onesided), T, scale, 0.0 if power is None else float(power))
+
+
+def sim_spectrogram(x, window_padded, desc):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(window_padded, dtype=np.float32)
+    tw = np.ascontiguousarray(_host.twiddle_table(desc.n_fft))
+    n_freq = desc.n_fft // 2 + 1 if desc.onesided else desc.n_fft
+    comp = 2 if desc.power <= 0 else 1
+    out = np.zeros((desc.rows, desc.n_frames, n_freq * comp), dtype=np.float32)
+    rc = sim().sim_stft_generic(fptr(x), fptr(w), fptr(tw), None, fptr(out), C.byref(desc), 0)
+    assert rc == 0
+    if comp == 2:
+        out = out.reshape(desc.rows, desc.n_frames, n_freq, 2)
+        out = out[..., 0] + 1j * out[..., 1]
+    return np.swapaxes(out, -1, -2)
+
+
+def sim_mel_generic(x, window_padded, bands, desc):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(window_padded, dtype=np.float32)
+    tw = np.ascontiguousarray(_host.twiddle_table(desc.n_fft))
+    out = np.zeros((desc.rows, desc.n_frames, bands.n_mels), dtype=np.float32)
+    rc = sim().sim_stft_generic(fptr(x), fptr(w), fptr(tw), C.byref(bands.struct), fptr(out), C.byref(desc), 1)
+    assert rc == 0
+    return np.swapaxes(out, -1, -2)
+
+
+def sim_mel400(x, window, bands, scale=1.0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, length = x.shape
+    w = np.ascontiguousarray(window, dtype=np.float32)
+    tw = np.ascontiguousarray(_host.twiddle_table(400))
+    T = _host.frame_count(length, 400, 160, True)
+    out = np.zeros((rows, T, bands.n_mels), dtype=np.float32)
+    f = sim().sim_melspec400
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                  C.c_int, C.c_float]
+    rc = f(fptr(x), fptr(w), fptr(tw), C.cast(C.byref(bands.struct), C.c_void_p), fptr(out), rows, length, length,
+           T, scale)
+    assert rc == 0
+    return np.swapaxes(out, -1, -2)
+
+
+def sim_resample(x, kernel, orig, new, width, qt=None, use_lds=1):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, length = x.shape
+    k = np.ascontiguousarray(kernel, dtype=np.float32).reshape(new, -1)
+    out_len = -(-new * length // orig)
+    out = np.zeros((rows, out_len), dtype=np.float32)
+    if qt is None:
+        qt = max(1, -(-2048 // new))
+    f = sim().sim_resample
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_int] * 3 + [C.c_int64, C.c_int, C.c_int]
+    assert f(fptr(x), fptr(k), fptr(out), rows, length, length, orig, new, width, out_len, qt, use_lds) == 0
+    return out
+
+
+def sim_lfilter(x, a, b, clamp=True):
+    """x: (batch, channels, L); a, b: (stages, rows, order+1)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    batch, ch, L = x.shape
+    y = np.zeros_like(x)
+    f = sim().sim_lfilter
+    f.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+    assert f(fptr(x), fptr(a), fptr(b), fptr(y), batch, ch, L, a.shape[-1], a.shape[-2], a.shape[0], int(clamp)) == 0
+    return y
+
+
+def sim_fftconv(x, y, start, out_len, xmap=None, ymap=None, rows=None):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    nx, ny = x.shape[-1], y.shape[-1]
+    rows = rows if rows is not None else x.shape[0]
+    out = np.zeros((rows, out_len), dtype=np.float32)
+    f = sim().sim_fftconv
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_void_p] * 2 + [C.c_int64] * 2
+    xm = None if xmap is None else fptr(np.ascontiguousarray(xmap, dtype=np.int64))
+    ym = None if ymap is None else fptr(np.ascontiguousarray(ymap, dtype=np.int64))
+    assert f(fptr(x), fptr(y), fptr(out), rows, nx, ny, xm, ym, start, out_len) == 0
+    return out

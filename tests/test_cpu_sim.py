@@ -1,0 +1,195 @@
+"""CPU replay of the HIP kernels' phase functions (same device source, compiled with g++)
+against the float64 oracle and the reference-run fixtures.  No GPU needed."""
+import numpy as np
+import pytest
+import torch
+
+from audio_amd import _host
+from conftest import peak_rel_err, ref_runs
+from oracle import dsp_oracle as O
+import oracle_dispatch as OD
+import sim_util as S
+
+TOL = 1e-4   # north-star: <= 1e-4 peak-relative on FFT / mel magnitudes (fp32)
+
+
+def _win(kw, wl):
+    if kw.get("window") == "hamming":
+        return torch.hamming_window(wl).numpy()
+    return torch.hann_window(wl).numpy()
+
+
+@pytest.mark.parametrize("case", ref_runs().select("Spectrogram"), ids=lambda c: f"{c['id']}")
+def test_sim_spectrogram_generic(case):
+    rr = ref_runs()
+    kw = case["kwargs"]
+    x = rr.inputs(case)[0]
+    n_fft = kw.get("n_fft", 400)
+    if n_fft > 1024:
+        pytest.skip("slow on the CPU replay; covered on the GPU")
+    wl = kw.get("win_length") or n_fft
+    hop = kw.get("hop_length") or wl // 2
+    w = _win(kw, wl)
+    wp = _host.center_pad_window(torch.from_numpy(w), n_fft).numpy()
+    norm = kw.get("normalized", False)
+    scale = 1.0
+    if norm == "frame_length":
+        scale = 1.0 / np.sqrt(n_fft)
+    elif norm is True or norm == "window":
+        scale = 1.0 / float(np.sqrt((w.astype(np.float64) ** 2).sum()))
+    x2 = x.reshape(-1, x.shape[-1])
+    d = S.make_desc(x2.shape[0], x2.shape[1], n_fft, hop, kw.get("pad", 0), kw.get("center", True),
+                    kw.get("pad_mode", "reflect"), kw.get("onesided", True), scale, kw.get("power", 2.0))
+    got = S.sim_spectrogram(x2, wp, d).reshape(rr.output(case).shape)
+    exp_ref = rr.output(case)
+    exp_orc = OD.evaluate(case, [x])
+    assert peak_rel_err(got, exp_ref) <= TOL
+    assert peak_rel_err(got, exp_orc) <= TOL
+
+
+def _mel_setup(kw):
+    sr = kw.get("sample_rate", 16000)
+    n_fft = kw.get("n_fft", 400)
+    wl = kw.get("win_length") or n_fft
+    hop = kw.get("hop_length") or wl // 2
+    f_max = kw.get("f_max")
+    f_max = float(sr // 2) if f_max is None else f_max
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fb = _host.melscale_fbanks(n_fft // 2 + 1, kw.get("f_min", 0.0), f_max, kw.get("n_mels", 128), sr,
+                                   kw.get("norm"), kw.get("mel_scale", "htk")).numpy()
+    return n_fft, wl, hop, fb
+
+
+@pytest.mark.parametrize("case", ref_runs().select("MelSpectrogram"), ids=lambda c: f"{c['id']}-{c.get('tag')}")
+def test_sim_melspectrogram(case):
+    rr = ref_runs()
+    kw = case["kwargs"]
+    x = rr.inputs(case)[0]
+    n_fft, wl, hop, fb = _mel_setup(kw)
+    if n_fft > 600:
+        pytest.skip("slow on the CPU replay; covered on the GPU")
+    w = torch.hann_window(wl).numpy()
+    wp = _host.center_pad_window(torch.from_numpy(w), n_fft).numpy()
+    scale = 1.0 / float(np.sqrt((w.astype(np.float64) ** 2).sum())) if kw.get("normalized") else 1.0
+    x2 = x.reshape(-1, x.shape[-1])
+    bands = S.HostBands(fb)
+    d = S.make_desc(x2.shape[0], x2.shape[1], n_fft, hop, kw.get("pad", 0), kw.get("center", True),
+                    "reflect", True, scale, kw.get("power", 2.0))
+    exp = rr.output(case)
+    got = S.sim_mel_generic(x2, wp, bands, d).reshape(exp.shape)
+    assert peak_rel_err(got, exp) <= TOL
+    assert peak_rel_err(got, OD.evaluate(case, [x])) <= TOL
+    # headline kernel (radix 20x20 register FFT) on the shapes it serves
+    if n_fft == 400 and hop == 160 and kw.get("power", 2.0) == 2.0 and x2.shape[1] > 400:
+        got4 = S.sim_mel400(x2, wp, bands, scale).reshape(exp.shape)
+        assert peak_rel_err(got4, exp) <= TOL
+        assert peak_rel_err(got4, OD.evaluate(case, [x])) <= TOL
+
+
+def test_sim_mel400_framing_exact():
+    """Framing / reflect indexing is integer-exact: a waveform of sample INDICES (as floats) run
+    through a rectangular 'window' reproduces the oracle's frame sums exactly at DC."""
+    L = 1723
+    x = np.arange(L, dtype=np.float32)[None] / 1024.0
+    fb = np.zeros((201, 1), dtype=np.float32)
+    fb[0, 0] = 1.0          # mel = |X[0]|^2 = (sum of frame)^2
+    bands = S.HostBands(fb)
+    w = np.ones(400, dtype=np.float32)
+    got = S.sim_mel400(x, w, bands)[0, 0]
+    fr = O.frames(x.astype(np.float64), 400, 160)[0]
+    exp = fr.sum(-1) ** 2
+    np.testing.assert_allclose(got, exp, rtol=2e-6)
+
+
+@pytest.mark.parametrize("case", [c for c in ref_runs().select("T.Resample") if c["kwargs"]["orig_freq"] != c["kwargs"]["new_freq"]],
+                         ids=lambda c: f"{c['id']}")
+def test_sim_resample(case):
+    import math
+    rr = ref_runs()
+    kw = dict(case["kwargs"])
+    x = rr.inputs(case)[0]
+    o, n = kw.pop("orig_freq"), kw.pop("new_freq")
+    g = math.gcd(o, n)
+    k, width = _host.sinc_resample_kernel(o, n, g, **kw)
+    x2 = x.reshape(-1, x.shape[-1])
+    exp = rr.output(case)
+    got = S.sim_resample(x2, k.numpy(), o // g, n // g, width).reshape(exp.shape)
+    assert peak_rel_err(got, exp) <= 1e-5
+    got2 = S.sim_resample(x2, k.numpy(), o // g, n // g, width, qt=3, use_lds=0).reshape(exp.shape)
+    assert peak_rel_err(got2, exp) <= 1e-5
+
+
+@pytest.mark.parametrize("case", ref_runs().select("lfilter"), ids=lambda c: f"{c['id']}-{c.get('tag')}")
+def test_sim_lfilter(case):
+    rr = ref_runs()
+    kw = case["kwargs"]
+    x, a, b = rr.inputs(case)
+    a2, b2 = np.atleast_2d(a), np.atleast_2d(b)
+    if kw.get("batching") is False:
+        x = np.stack([x] * a2.shape[0], -2)
+    C_ = a2.shape[0]
+    x3 = x.reshape(-1, C_, x.shape[-1])
+    exp = rr.output(case)
+    got = S.sim_lfilter(x3, a2[None], b2[None], kw.get("clamp", True)).reshape(exp.shape)
+    tol = 2e-4 if case.get("tag") in ("order4", "order8") else 2e-5
+    assert peak_rel_err(got, exp) <= tol
+    assert peak_rel_err(got, OD.evaluate(case, rr.inputs(case))) <= tol
+
+
+def test_sim_lfilter_long_and_cascade():
+    """> one 8192-sample block (carried state across blocks) and a fused 4-stage cascade."""
+    rng = np.random.default_rng(5)
+    x = (0.3 * rng.standard_normal((1, 2, 20000))).astype(np.float32)
+    a = np.array([[1.0, -1.8, 0.85]], dtype=np.float32)
+    b = np.array([[0.02, 0.04, 0.02]], dtype=np.float32)
+    got = S.sim_lfilter(x, a[None], b[None], True)
+    exp = O.lfilter(x, a[0], b[0], True)
+    assert peak_rel_err(got, exp) <= 2e-5
+    rr = ref_runs()
+    case = rr.select("lowpass_cascade")[0]
+    xin = rr.inputs(case)[0]
+    import audio_amd.functional as F
+    sr, Q = case["kwargs"]["sample_rate"], case["kwargs"]["Q"]
+    A, B = [], []
+    for fc in case["kwargs"]["cutoffs"]:
+        w0 = 2 * np.pi * np.float32(fc) / sr
+        w0 = torch.tensor(2 * np.pi) * 0 + 2 * torch.pi * torch.tensor(fc, dtype=torch.float32) / sr
+        alpha = torch.sin(w0) / 2 / torch.tensor(Q, dtype=torch.float32)
+        b0 = (1 - torch.cos(w0)) / 2
+        B.append([float(b0), float(1 - torch.cos(w0)), float(b0)])
+        A.append([float(1 + alpha), float(-2 * torch.cos(w0)), float(1 - alpha)])
+    a4 = np.array(A, dtype=np.float32)[:, None, :]
+    b4 = np.array(B, dtype=np.float32)[:, None, :]
+    x3 = xin.reshape(-1, 1, xin.shape[-1])
+    got = S.sim_lfilter(x3, a4, b4, True).reshape(xin.shape)
+    assert peak_rel_err(got, rr.output(case)) <= 2e-5
+
+
+@pytest.mark.parametrize("case", ref_runs().select("fftconvolve"), ids=lambda c: f"{c['id']}-{c['kwargs']['mode']}")
+def test_sim_fftconvolve(case):
+    rr = ref_runs()
+    x, y = rr.inputs(case)
+    mode = case["kwargs"]["mode"]
+    nx, ny = x.shape[-1], y.shape[-1]
+    n_full = nx + ny - 1
+    if mode == "full":
+        start, out_len = 0, n_full
+    elif mode == "valid":
+        out_len = max(nx, ny) - min(nx, ny) + 1
+        start = (n_full - out_len) // 2
+    else:
+        out_len, start = nx, (n_full - nx) // 2
+    lead = np.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    rows = int(np.prod(lead)) if lead else 1
+
+    def rmap(t):
+        if tuple(t.shape[:-1]) == tuple(lead):
+            return None
+        n = int(np.prod(t.shape[:-1])) if t.ndim > 1 else 1
+        return np.broadcast_to(np.arange(n).reshape(t.shape[:-1]), lead).reshape(-1)
+
+    got = S.sim_fftconv(x.reshape(-1, nx), y.reshape(-1, ny), start, out_len, rmap(x), rmap(y), rows)
+    exp = rr.output(case)
+    assert peak_rel_err(got.reshape(exp.shape), exp) <= 1e-5

@@ -1,0 +1,173 @@
+"""Parity tests proper: the HIP path (through the C ABI) on a real MI355X against
+ (a) the outputs of the reference implementation itself (committed fixtures), and
+ (b) the float64 CPU oracle on the same inputs.
+Tolerances: integer work (shapes, strides, frame indexing) exact; floating point
+<= 1e-4 peak-relative (north-star), tighter where the reference's own tests are tighter."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import floor_rel_err, peak_rel_err, ref_runs
+import oracle_dispatch as OD
+import product_dispatch as PD
+
+pytestmark = pytest.mark.gpu
+
+TOL = {
+    "Spectrogram": 1e-4, "MelSpectrogram": 1e-4, "MFCC": 1e-4, "AmplitudeToDB": 1e-4, "MelScale": 1e-4,
+    "F.resample": 1e-4, "T.Resample": 1e-4, "lfilter": 1e-4, "biquad": 1e-4, "filtfilt": 1e-4,
+    "lowpass_cascade": 1e-4, "fftconvolve": 1e-4, "T.FFTConvolve": 1e-4,
+    "lowpass_biquad": 1e-4, "highpass_biquad": 1e-4, "allpass_biquad": 1e-4, "bandpass_biquad": 1e-4,
+    "bandreject_biquad": 1e-4, "equalizer_biquad": 1e-4, "bass_biquad": 1e-4, "treble_biquad": 1e-4,
+    "band_biquad": 1e-4,
+}
+CASES = [c for c in ref_runs().cases if c["op"] in TOL]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X (run through gpurun)"
+    from audio_amd import _lib
+    _lib.lib()
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['id']}-{c['op']}-{c.get('tag')}")
+def test_against_reference_and_oracle(case):
+    rr = ref_runs()
+    inputs = rr.inputs(case)
+    got_t = PD.run(case, inputs)
+    assert got_t is not None
+    exp = rr.output(case)
+    assert tuple(got_t.shape) == tuple(exp.shape)          # integer work: exact
+    got = got_t.cpu().numpy()
+    tol = TOL[case["op"]]
+    if case.get("tag") in ("order4", "order8"):
+        tol = 5e-4    # reference's own fp32 recursion drifts at high order (see test_oracle_golden)
+    e_ref = peak_rel_err(got, exp)
+    assert e_ref <= tol, f"vs reference: {e_ref}"
+    orc = OD.evaluate(case, inputs)
+    if orc is not None:
+        e_orc = peak_rel_err(got, orc)
+        assert e_orc <= tol, f"vs oracle: {e_orc}"
+
+
+def test_output_strides_match_reference():
+    """The reference returns (..., F, T) views of frame-major memory."""
+    import audio_amd.transforms as T
+    x = torch.randn(4, 16000, device="cuda")
+    s = T.Spectrogram(n_fft=400, hop_length=160).cuda()(x)
+    assert s.shape == (4, 201, 101) and s.stride() == (20301, 1, 201)
+    m = T.MelSpectrogram(n_fft=400, hop_length=160, n_mels=80).cuda()(x)
+    assert m.shape == (4, 80, 101) and m.stride() == (8080, 1, 80)
+    c = T.MFCC(n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()(x)
+    assert c.shape == (4, 40, 101) and c.stride() == (4040, 1, 40)
+    z = T.Spectrogram(n_fft=400, hop_length=160, power=None).cuda()(x)
+    assert z.dtype == torch.complex64 and z.shape == (4, 201, 101)
+
+
+def test_librosa_goldens_on_gpu(librosa_goldens):
+    """The reference's own librosa golden vectors, through the HIP path (fp32 vs f64 goldens)."""
+    import audio_amd.transforms as T
+    xw = torch.from_numpy(librosa_goldens["whitenoise_16k"]).cuda()
+    xs = torch.from_numpy(librosa_goldens["sinusoid_16k"]).cuda()
+    for i, (n_fft, hop, power) in enumerate([(400, 200, 2.0), (600, 100, 2.0), (400, 200, 3.0), (200, 50, 2.0)]):
+        got = T.Spectrogram(n_fft=n_fft, hop_length=hop, power=power).cuda()(xw)[0].cpu().numpy()
+        assert peak_rel_err(got, librosa_goldens[f"spectrogram_{i}"]) <= 1e-4
+    sizes = [(400, 200, 64), (600, 100, 128), (200, 50, 32)]
+    for i in range(12):
+        n_fft, hop, n_mels = sizes[i // 4]
+        norm = [None, "slaney"][(i // 2) % 2]
+        scale = ["htk", "slaney"][i % 2]
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t = T.MelSpectrogram(sample_rate=16000, n_fft=n_fft, hop_length=hop, n_mels=n_mels, norm=norm,
+                                 mel_scale=scale).cuda()
+        got = t(xs)[0].cpu().numpy()
+        assert peak_rel_err(got, librosa_goldens[f"melspectrogram_{i:02d}"]) <= 1e-4
+    for i, (n_fft, hop, n_mels, n_mfcc) in enumerate([(400, 200, 64, 40), (600, 100, 128, 20), (200, 50, 32, 25)]):
+        t = T.MFCC(sample_rate=16000, n_mfcc=n_mfcc, norm="ortho",
+                   melkwargs={"hop_length": hop, "n_fft": n_fft, "n_mels": n_mels}).cuda()
+        got = t(xw)[0].cpu().numpy()
+        np.testing.assert_allclose(got, librosa_goldens[f"mfcc_{i}"], atol=5e-3, rtol=1e-4)
+
+
+def test_sox_golden_biquad_on_gpu(sox_goldens):
+    import audio_amd.functional as F
+    x = torch.from_numpy(sox_goldens["noise_8k"]).cuda()
+    got = F.lfilter(x, torch.tensor([0.7, 0.2, 0.6]).cuda(), torch.tensor([0.4, 0.2, 0.9]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(got, sox_goldens["perf_biquad_filtering"], atol=1e-4, rtol=1e-5)
+    for name, fn, kw, atol in [
+        ("lowpass", F.lowpass_biquad, dict(sample_rate=8000, cutoff_freq=3000), 1.5e-4),
+        ("highpass", F.highpass_biquad, dict(sample_rate=8000, cutoff_freq=2000), 1.5e-4),
+        ("allpass", F.allpass_biquad, dict(sample_rate=8000, central_freq=1000, Q=0.707), 1e-4),
+        ("bandreject", F.bandreject_biquad, dict(sample_rate=8000, central_freq=1000, Q=0.707), 1e-4),
+        ("equalizer", F.equalizer_biquad, dict(sample_rate=8000, center_freq=300, gain=1, Q=0.707), 1e-4),
+    ]:
+        got = fn(x, **kw).cpu().numpy()
+        np.testing.assert_allclose(got, sox_goldens[name], atol=atol, rtol=1e-5)
+
+
+def test_mel400_fast_path_equals_generic(monkeypatch):
+    """Headline register-FFT kernel vs the generic LDS Stockham kernel on ragged / edge inputs."""
+    import os
+    import audio_amd.transforms as T
+    t = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).cuda()
+    for L in (401, 560, 961, 1600, 16000, 16001, 48017):
+        x = torch.randn(3, L, device="cuda").clamp_(-1, 1)
+        fast = t(x)
+        os.environ["AAMD_FORCE_GENERIC"] = "1"
+        try:
+            gen = t(x)
+        finally:
+            del os.environ["AAMD_FORCE_GENERIC"]
+        assert fast.shape == gen.shape
+        e = (fast - gen).abs().max() / gen.abs().max()
+        assert float(e) <= 2e-6, (L, float(e))
+
+
+def test_headline_shape_properties():
+    """BASELINE config 2 (256 x 10 s): size-independent checks at full size --
+    batch consistency (item-wise == batched, batch_consistency_test.py:102-107),
+    linearity of the power spectrum under scaling, and Parseval on the |X|^2 frames."""
+    import audio_amd.transforms as T
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = (0.5 * torch.randn(256, 160000, device="cuda", generator=g)).clamp_(-1, 1)
+    mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).cuda()
+    y = mel(x)
+    assert y.shape == (256, 80, 1001) and y.stride() == (80080, 1, 80)
+    assert torch.isfinite(y).all()
+    for b in (0, 17, 255):
+        yb = mel(x[b:b + 1])
+        assert torch.equal(yb[0], y[b])                      # bit-identical item-wise
+    y2 = mel(2.0 * x[:8])
+    assert float(((y2 - 4.0 * y[:8]).abs().max() / y2.abs().max())) < 1e-6
+    # Parseval per frame: sum_k' |X_k|^2 (two-sided) = N * sum_n (w x)^2 -- use a Spectrogram
+    spec = T.Spectrogram(n_fft=400, hop_length=160).cuda()(x[:4])          # (4, 201, 1001)
+    two_sided = spec[:, 0] + spec[:, 200] + 2 * spec[:, 1:200].sum(1)
+    w = torch.hann_window(400, device="cuda")
+    xp = torch.nn.functional.pad(x[:4, None], (200, 200), mode="reflect")[:, 0]
+    fr = xp.unfold(-1, 400, 160) * w
+    assert float(((two_sided - 400 * (fr ** 2).sum(-1)).abs().max() / two_sided.abs().max())) < 1e-5
+
+
+def test_empty_and_error_behaviour():
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    with pytest.raises(RuntimeError):
+        T.Spectrogram(n_fft=400)(torch.randn(2, 100, device="cuda"))      # reflect pad >= length
+    with pytest.raises(ValueError, match="same dimension"):
+        F.fftconvolve(torch.randn(2, 5, device="cuda"), torch.randn(5, device="cuda"))
+    with pytest.raises(ValueError, match="Unrecognized mode"):
+        F.fftconvolve(torch.randn(5, device="cuda"), torch.randn(5, device="cuda"), "bogus")
+    with pytest.raises(ValueError, match="same size"):
+        F.lfilter(torch.randn(5, device="cuda"), torch.ones(3).cuda(), torch.ones(2).cuda())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        T.MelSpectrogram()(torch.randn(1, 16000))
+    out = T.MelSpectrogram(n_fft=400, hop_length=160, n_mels=80).cuda()(torch.zeros(0, 16000, device="cuda"))
+    assert out.shape == (0, 80, 101)
+    y = F.resample(torch.randn(2, 1000, device="cuda"), 16000, 16000)
+    assert y.shape == (2, 1000)
+    assert F.resample(torch.randn(2, 1001, device="cuda"), 16000, 8000).shape == (2, 501)
