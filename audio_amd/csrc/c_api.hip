@@ -134,7 +134,8 @@ int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, c
 
 bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
   return g.n_fft == 400 && g.hop == 160 && g.center && g.pad_mode == AAMD_PAD_REFLECT &&
-         g.onesided && g.pad == 0 && g.power == 2.0f && g.length > 400 && mb.n_mels <= 1024;
+         g.onesided && g.pad == 0 && g.power == 2.0f && g.length > 400 &&
+         m400::mel_tab_dwords(mb.n_mels, mb.max_width) <= 16 * 1024;
 }
 
 int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
@@ -142,7 +143,7 @@ int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, co
   if (g.rows == 0) return AAMD_OK;
   const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
   const int64_t n_tiles = g.rows * tiles_per_row;
-  const size_t lds = (size_t)4 * m400::kLdsDwordsPerWave * sizeof(float);
+  const size_t lds = ((size_t)4 * m400::kLdsDwordsPerWave + m400::mel_tab_dwords(mb.n_mels, mb.max_width)) * sizeof(float);
   static thread_local int occ_cache = 0;
   if (occ_cache == 0) {
     int occ = 0;
@@ -150,6 +151,9 @@ int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, co
       occ = 2;
     occ_cache = occ;
   }
+  if (lds > 48 * 1024)
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(m400::melspec400_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int64_t blocks = (int64_t)dev_props().cu_count * occ_cache;
   const int64_t need = (n_tiles + 3) / 4;
   if (blocks > need) blocks = need;

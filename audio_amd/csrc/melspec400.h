@@ -13,8 +13,8 @@
 //   * the a/b spectra are separated with the conj-symmetry rule; the partner bin Z[400-k]
 //     lives in lane (20 - s) mod 20 of the same group and is fetched with ds_bpermute
 //     (wavefront shuffle), so only |A|^2, |B|^2 for k = 0..200 are ever written to LDS;
-//   * mel = banded reduction over the LDS power spectrum (<= 13 taps per filter for the
-//     80-mel bank), written frame-major: 6 frames x 80 mels = 480 contiguous floats per wave.
+//   * mel = banded reduction over the LDS power spectrum: the filterbank's band table lives
+//     in LDS; rounds of 10 mels x 6 frames with a wave-uniform tap count per round.
 //
 // Reference semantics: transforms/_transforms.py:612-622 (MelSpectrogram.forward),
 // functional/functional.py:112-145, torch/functional.py:675-681; framing is bit-exact
@@ -31,8 +31,45 @@ constexpr int kHop = 160;
 constexpr int kPad = 200;
 constexpr int kFramesPerWave = 6;
 constexpr int kTRow = 42;                 // dwords per transposition row (20 complex + 1 pad)
-constexpr int kPStride = 202;             // dwords per power-spectrum row (201 + 1, = 10 mod 16)
-constexpr int kLdsDwordsPerWave = 60 * kTRow;  // 2520 dwords = 10080 B (P rows alias it)
+constexpr int kPStride = 218;             // dwords per power-spectrum row: 201 bins + 17 zeros, = 10 mod 16
+constexpr int kLdsDwordsPerWave = 60 * kTRow;  // 2520 dwords = 10080 B (the 6 P rows alias it)
+constexpr int kMelsPerRound = 10;         // phase C: 6 frames x 10 mels = 60 lanes per round
+constexpr int kMelChunk = 8;              // taps fetched per batch of LDS reads
+
+// Per-workgroup LDS copy of the banded filterbank (built once per launch by every workgroup).
+struct MelTab {
+  const float* w;    // [n_mels][wpad], zero padded
+  const int* lo;     // [n_mels]
+  const int* rw;     // [n_rounds]: widest band among the round's mels (wave-uniform trip count)
+  int n_mels, wpad, n_rounds;
+};
+
+AAMD_HD int mel_wpad(int max_width) { return max_width | 1; }   // odd stride: conflict-free rows
+AAMD_HD int mel_rounds(int n_mels) { return (n_mels + kMelsPerRound - 1) / kMelsPerRound; }
+AAMD_HD int mel_tab_dwords(int n_mels, int max_width) {
+  return n_mels * mel_wpad(max_width) + n_mels + mel_rounds(n_mels);
+}
+
+AAMD_HD void mel_tab_build(int tid, int nthr, const MelBandsDev& mb, float* base, MelTab& mt) {
+  mt.n_mels = mb.n_mels;
+  mt.wpad = mel_wpad(mb.max_width);
+  mt.n_rounds = mel_rounds(mb.n_mels);
+  float* w = base;
+  int* lo = reinterpret_cast<int*>(base + mb.n_mels * mt.wpad);
+  int* rw = lo + mb.n_mels;
+  for (int i = tid; i < mb.n_mels * mt.wpad; i += nthr) {
+    const int m = i / mt.wpad, j = i - m * mt.wpad;
+    w[i] = (j < mb.width[m]) ? mb.weights[m * mb.max_width + j] : 0.0f;
+  }
+  for (int m = tid; m < mb.n_mels; m += nthr) lo[m] = mb.lo[m];
+  for (int r = tid; r < mt.n_rounds; r += nthr) {
+    int mx = 0;
+    for (int m = r * kMelsPerRound; m < (r + 1) * kMelsPerRound && m < mb.n_mels; ++m)
+      mx = mb.width[m] > mx ? mb.width[m] : mx;
+    rw[r] = mx;
+  }
+  mt.w = w; mt.lo = lo; mt.rw = rw;
+}
 
 struct LaneConst {
   float twr[20], twi[20];  // W400^(r*s), s = 0..19
@@ -195,19 +232,46 @@ AAMD_HD void phase_b2(const LaneConst& c, const float (&zr)[20], const float (&z
   }
 }
 
-// ---- phase C: banded mel reduction from the 6 LDS power rows, coalesced frame-major store --
-AAMD_HD void phase_c(int lane, const MelBandsDev& mb, const float* lds, float* out_row,
-                     int64_t t0, int n_frames) {
-  const int total = kFramesPerWave * mb.n_mels;
-  for (int o = lane; o < total; o += 64) {
-    const int f = o / mb.n_mels;
-    const int m = o - f * mb.n_mels;
-    const int lo = mb.lo[m], w = mb.width[m];
-    const float* wt = mb.weights + m * mb.max_width;
-    const float* P = lds + kPStride * f + lo;
+// zero the 17-float tail of each P row so that band reads past bin 200 (weight 0) never touch
+// stale transposition data of another frame
+AAMD_HD void phase_b2_pad(int lane, float* lds) {
+  constexpr int kTail = kPStride - 201;
+  for (int i = lane; i < kFramesPerWave * kTail; i += 64) {
+    const int f = i / kTail, j = i - f * kTail;
+    lds[kPStride * f + 201 + j] = 0.0f;
+  }
+}
+
+// ---- phase C: banded mel reduction from the 6 LDS power rows ----------------------------------
+//   round r: lane (f, mi) -> frame f, mel m = 10 r + mi; mel widths grow with m, so the
+//   wave-uniform trip count rw[r] tracks each lane's own band width closely (46 tap slots per
+//   lane for the 80-mel bank vs 37 ideal).  Weights and taps are fetched in batches of 8 LDS
+//   reads to keep them in flight together.
+AAMD_HD void phase_c(int lane, const MelTab& mt, const float* lds, float* out_row, int64_t t0,
+                     int n_frames) {
+  const bool lane_ok = lane < 60;
+  const int f = lane_ok ? lane / kMelsPerRound : 0;
+  const int mi = lane_ok ? lane - kMelsPerRound * f : 0;
+  for (int r = 0; r < mt.n_rounds; ++r) {
+    const int m = r * kMelsPerRound + mi;
+    const bool ok = lane_ok && m < mt.n_mels;
+    const int mm = ok ? m : 0;
+    const float* wt = mt.w + mm * mt.wpad;
+    const float* P = lds + kPStride * f + mt.lo[mm];
+    const int rw = mt.rw[r];
     float acc = 0.0f;
-    for (int i = 0; i < w; ++i) acc += wt[i] * P[i];
-    if (t0 + f < n_frames) out_row[(t0 + f) * (int64_t)mb.n_mels + m] = acc;
+    for (int i0 = 0; i0 < rw; i0 += kMelChunk) {
+      float wv[kMelChunk], pv[kMelChunk];
+#pragma unroll
+      for (int j = 0; j < kMelChunk; ++j) {
+        const bool in = i0 + j < rw;          // wave-uniform
+        wv[j] = in ? wt[i0 + j] : 0.0f;
+        pv[j] = in ? P[i0 + j] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < kMelChunk; ++j) acc += wv[j] * pv[j];
+    }
+    if (ok && t0 + f < n_frames) out_row[(t0 + f) * (int64_t)mt.n_mels + m] = acc;
   }
 }
 
@@ -229,6 +293,10 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   float* lds = smem400 + wave * kLdsDwordsPerWave;
+
+  MelTab mt;
+  mel_tab_build(threadIdx.x, blockDim.x, mb, smem400 + 4 * kLdsDwordsPerWave, mt);
+  __syncthreads();
 
   LaneConst c;
   lane_init(lane, window, tw400, scale, c);
@@ -261,8 +329,9 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     }
     wave_lds_fence();
     phase_b2(c, zr, zi, gr, gi, lds);
+    phase_b2_pad(lane, lds);
     wave_lds_fence();
-    phase_c(lane, mb, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
+    phase_c(lane, mt, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
     wave_lds_fence();
   }
 }

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import warnings
+import weakref
 from typing import Optional, Union
 
 import torch
@@ -50,7 +51,8 @@ def _rows2d(t: Tensor) -> Tensor:
     return x
 
 
-_CACHE: dict = {}
+_CACHE: dict = {}        # value-keyed constants (twiddles, sinc kernels): key holds every parameter
+_TENSOR_CACHE: dict = {}  # id(tensor) -> {key: value}; entry dropped when the tensor dies
 
 
 def _cached(key, make):
@@ -63,14 +65,32 @@ def _cached(key, make):
     return v
 
 
+def _tensor_cached(t: Tensor, key, make):
+    """Cache a constant derived from tensor `t` (window / fb buffers).  Keyed by object identity
+    + in-place version counter; a weakref finalizer evicts the entry when `t` is freed, so a new
+    tensor that happens to reuse the same id / data_ptr can never hit a stale entry."""
+    tid = id(t)
+    slot = _TENSOR_CACHE.get(tid)
+    if slot is None:
+        slot = {}
+        _TENSOR_CACHE[tid] = slot
+        weakref.finalize(t, _TENSOR_CACHE.pop, tid, None)
+    k = (key, t._version, str(t.device), t.dtype)
+    v = slot.get(k)
+    if v is None:
+        v = make()
+        slot[k] = v
+    return v
+
+
 def _twiddles(n_fft: int, device) -> Tensor:
     return _cached(("tw", n_fft, str(device)),
                    lambda: torch.from_numpy(_host.twiddle_table(n_fft)).to(device).contiguous())
 
 
 def _padded_window(window: Tensor, n_fft: int) -> Tensor:
-    key = ("win", window.data_ptr(), window._version, tuple(window.shape), n_fft, str(window.device))
-    return _cached(key, lambda: _host.center_pad_window(window.detach(), n_fft).contiguous())
+    return _tensor_cached(window, ("win", n_fft),
+                          lambda: _host.center_pad_window(window.detach(), n_fft).contiguous())
 
 
 class MelBandsOnDevice:
@@ -88,8 +108,7 @@ class MelBandsOnDevice:
 
 
 def _mel_bands(fb: Tensor, device) -> MelBandsOnDevice:
-    key = ("fb", fb.data_ptr(), fb._version, tuple(fb.shape), str(device))
-    return _cached(key, lambda: MelBandsOnDevice(fb, device))
+    return _tensor_cached(fb, ("bands", str(device)), lambda: MelBandsOnDevice(fb, device))
 
 
 def _get_spec_norms(normalized: Union[str, bool]):
@@ -134,8 +153,7 @@ def _stft_desc(x2: Tensor, pad: int, window: Tensor, n_fft: int, hop_length: int
     if frame_norm:
         scale = 1.0 / math.sqrt(n_fft)
     if window_norm:
-        key = ("wnorm", window.data_ptr(), window._version, tuple(window.shape), str(window.device))
-        scale = scale / _cached(key, lambda: float(window.pow(2.0).sum().sqrt()))
+        scale = scale / _tensor_cached(window, "l2norm", lambda: float(window.pow(2.0).sum().sqrt()))
     return _lib.StftDesc(rows, length, x2.stride(0) if rows > 1 else max(length, 1), n_fft, hop_length, pad,
                          int(center), _lib.PAD_MODES[pad_mode], int(onesided), n_frames, scale,
                          0.0 if power is None else float(power))

@@ -65,6 +65,9 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
                    float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale) {
   MelBandsDev mb{bands->n_mels, bands->max_width, bands->lo, bands->width, bands->weights};
   std::vector<float> lds(m400::kLdsDwordsPerWave, 0.f);
+  std::vector<float> tab(m400::mel_tab_dwords(mb.n_mels, mb.max_width));
+  m400::MelTab mt;
+  for (int tid = 0; tid < 256; ++tid) m400::mel_tab_build(tid, 256, mb, tab.data(), mt);
   m400::LaneConst c[64];
   for (int l = 0; l < 64; ++l) m400::lane_init(l, window, tw400, scale, c[l]);
   const int tiles_per_row = (n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
@@ -86,7 +89,8 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
         for (int i = 0; i < 10; ++i) { gr[l][i] = zr[pl][10 + i]; gi[l][i] = zi[pl][10 + i]; }
       }
       for (int l = 0; l < 64; ++l) m400::phase_b2(c[l], zr[l], zi[l], gr[l], gi[l], lds.data());
-      for (int l = 0; l < 64; ++l) m400::phase_c(l, mb, lds.data(), out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
+      for (int l = 0; l < 64; ++l) m400::phase_b2_pad(l, lds.data());
+      for (int l = 0; l < 64; ++l) m400::phase_c(l, mt, lds.data(), out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
     }
   return 0;
 }

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Micro-benchmarks on one MI355X (run through gpurun): per-op kernel time with HIP events.
+  python tools/gpu_microbench.py [mel] [spec] [mfcc] [resample] [lfilter] [fftconv]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import audio_amd.functional as F
+import audio_amd.transforms as T
+
+
+def timeit(fn, warm=5, iters=30):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+def main():
+    what = sys.argv[1:] or ["mel"]
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    with torch.no_grad():
+        if "mel" in what:
+            x = (0.5 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
+            mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).to(dev)
+            us = timeit(lambda: mel(x), 10, 100)
+            by = 256 * 160000 * 4 + 256 * 1001 * 80 * 4
+            print(f"mel400 fast : {us:9.1f} us  {by / us / 1e3:8.1f} GB/s  frac {by / us / 1e3 / 8000:.3f}", flush=True)
+            for v in os.environ.get("AAMD_VARIANTS", "").split(","):
+                if v:
+                    os.environ["AAMD_MEL400_VARIANT"] = v
+                    us = timeit(lambda: mel(x), 10, 100)
+                    print(f"mel400 var {v}: {us:9.1f} us  frac {by / us / 1e3 / 8000:.3f}", flush=True)
+            os.environ["AAMD_FORCE_GENERIC"] = "1"
+            us = timeit(lambda: mel(x), 2, 5)
+            del os.environ["AAMD_FORCE_GENERIC"]
+            print(f"mel generic : {us:9.1f} us")
+        if "spec" in what:
+            x = (0.5 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
+            sp = T.Spectrogram(n_fft=400, hop_length=160).to(dev)
+            print(f"spectrogram generic 400/160: {timeit(lambda: sp(x), 2, 5):9.1f} us")
+        if "mfcc" in what:
+            x = (0.5 * torch.randn(512, 160000, device=dev)).clamp_(-1, 1)
+            m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).to(dev)
+            print(f"mfcc b=512: {timeit(lambda: m(x), 3, 20):9.1f} us")
+        if "resample" in what:
+            x = (0.5 * torch.randn(16, 2, 1323000, device=dev)).clamp_(-1, 1)
+            r = T.Resample(44100, 16000, resampling_method="sinc_interp_kaiser", lowpass_filter_width=64,
+                           rolloff=0.9475937167399596, beta=14.769656459379492).to(dev)
+            us = timeit(lambda: r(x), 1, 3)
+            print(f"resample kaiser_best 16x2x30s: {us:9.1f} us  ({16 * 30 / (us * 1e-6):.0f} clip-s/s)")
+        if "lfilter" in what:
+            x = (torch.rand(32, 8, 480000, device=dev) - 0.5)
+            a = torch.tensor([1.0, -1.2, 0.5], device=dev)
+            b = torch.tensor([0.1, 0.2, 0.1], device=dev)
+            us = timeit(lambda: F.lfilter(x, a, b), 1, 5)
+            print(f"lfilter biquad 32x8x10s@48k: {us:9.1f} us  {2 * x.numel() * 4 / us / 1e3:.1f} GB/s")
+        if "fftconv" in what:
+            x = torch.randn(4, 8, 48000, device=dev)
+            y = torch.randn(1, 1, 2400, device=dev)
+            print(f"fftconvolve 4x8x1s * 2400 taps: {timeit(lambda: F.fftconvolve(x, y), 1, 3):9.1f} us")
+
+
+if __name__ == "__main__":
+    main()
