@@ -135,7 +135,8 @@ int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, c
 bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
   return g.n_fft == 400 && g.hop == 160 && g.center && g.pad_mode == AAMD_PAD_REFLECT &&
          g.onesided && g.pad == 0 && g.power == 2.0f && g.length > 400 &&
-         m400::mel_tab_dwords(mb.n_mels, mb.max_width) <= 16 * 1024;
+         m400::mel_tab_dwords(mb.n_mels, mb.max_width) <= 16 * 1024 &&
+         m400::mel_rounds(mb.n_mels) <= m400::kMelMaxRounds;
 }
 
 int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
@@ -159,9 +160,11 @@ int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, co
   if (blocks > need) blocks = need;
   if (blocks >= 8) blocks -= blocks % 8;  // XCD remap wants a multiple of 8
   if (blocks < 1) blocks = 1;
+  int ablate = 0;
+  if (const char* e = std::getenv("AAMD_MEL400_VARIANT")) ablate = std::atoi(e);   // profiling aid
   hipLaunchKernelGGL(m400::melspec400_kernel, dim3((unsigned)blocks), dim3(256), lds, s, wav, window,
                      twiddle, mb, out, g.rows, g.length, g.row_stride, g.n_frames, g.scale,
-                     tiles_per_row, n_tiles, 0);
+                     tiles_per_row, n_tiles, ablate);
   return launch_check();
 }
 

@@ -72,7 +72,9 @@ AAMD_HD void mel_tab_build(int tid, int nthr, const MelBandsDev& mb, float* base
 }
 
 struct LaneConst {
-  float twr[20], twi[20];  // W400^(r*s), s = 0..19
+  // W400^(r*s) = ta[s & 3] * tb[s >> 2] with ta[b] = w^b (b = 1..3), tb[a] = w^(4a) (a = 1..4),
+  // w = W400^r: 14 registers instead of 40; 12 of the 20 twiddles cost one extra complex multiply.
+  float tar[3], tai[3], tbr[4], tbi[4];
   float win[20];           // 0.5 * scale * window[r + 20 q]
   int p, r;                // pair index (0..2), row/column index inside the pair (0..19)
   int active;              // lanes 60..63 shadow pair 2 but never store
@@ -85,10 +87,16 @@ AAMD_HD void lane_init(int lane, const float* window, const float* tw400, float 
   c.p = l / 20;
   c.r = l - 20 * c.p;
 #pragma unroll
-  for (int s = 0; s < 20; ++s) {
-    const int idx = (c.r * s) % kN;
-    c.twr[s] = tw400[2 * idx];
-    c.twi[s] = tw400[2 * idx + 1];
+  for (int b = 1; b < 4; ++b) {
+    const int idx = (c.r * b) % kN;
+    c.tar[b - 1] = tw400[2 * idx];
+    c.tai[b - 1] = tw400[2 * idx + 1];
+  }
+#pragma unroll
+  for (int a = 1; a < 5; ++a) {
+    const int idx = (c.r * 4 * a) % kN;
+    c.tbr[a - 1] = tw400[2 * idx];
+    c.tbi[a - 1] = tw400[2 * idx + 1];
   }
 #pragma unroll
   for (int q = 0; q < 20; ++q) c.win[q] = window[c.r + 20 * q] * (0.5f * scale);
@@ -181,8 +189,18 @@ AAMD_HD void phase_a(const LaneConst& c, const float* wav_row, int64_t length, i
     float* col = lds + kTRow * (20 * c.p) + 2 * c.r;
 #pragma unroll
     for (int s = 0; s < 20; ++s) {
-      const float vr = yr[s] * c.twr[s] - yi[s] * c.twi[s];
-      const float vi = yr[s] * c.twi[s] + yi[s] * c.twr[s];
+      float vr = yr[s], vi = yi[s];
+      const int b = s & 3, a = s >> 2;
+      if (b != 0) {
+        const float tr_ = vr * c.tar[b - 1] - vi * c.tai[b - 1];
+        vi = vr * c.tai[b - 1] + vi * c.tar[b - 1];
+        vr = tr_;
+      }
+      if (a != 0) {
+        const float tr_ = vr * c.tbr[a - 1] - vi * c.tbi[a - 1];
+        vi = vr * c.tbi[a - 1] + vi * c.tbr[a - 1];
+        vr = tr_;
+      }
       col[kTRow * s] = vr;
       col[kTRow * s + 1] = vi;
     }
@@ -244,34 +262,77 @@ AAMD_HD void phase_b2_pad(int lane, float* lds) {
 
 // ---- phase C: banded mel reduction from the 6 LDS power rows ----------------------------------
 //   round r: lane (f, mi) -> frame f, mel m = 10 r + mi; mel widths grow with m, so the
-//   wave-uniform trip count rw[r] tracks each lane's own band width closely (46 tap slots per
-//   lane for the 80-mel bank vs 37 ideal).  Weights and taps are fetched in batches of 8 LDS
-//   reads to keep them in flight together.
+//   wave-uniform tap count rw[r] tracks each lane's own band width closely (46 tap slots per
+//   lane for the 80-mel bank vs 37 ideal).  Each round is a straight-line body selected by the
+//   uniform tap count: all 2*W LDS reads are issued back to back, then W FMAs.
+constexpr int kMelMaxTaps = 16;   // bands wider than this use the chunked loop
+constexpr int kMelMaxRounds = 16;
+
+template <int W>
+AAMD_HD float mel_dot(const float* wt, const float* P) {
+  float wv[W], pv[W];
+#pragma unroll
+  for (int j = 0; j < W; ++j) { wv[j] = wt[j]; pv[j] = P[j]; }
+  float acc = 0.0f;
+#pragma unroll
+  for (int j = 0; j < W; ++j) acc += wv[j] * pv[j];
+  return acc;
+}
+
+AAMD_HD float mel_dot_n(int rw, const float* wt, const float* P) {
+  switch (rw) {
+    case 0: return 0.0f;
+    case 1: return mel_dot<1>(wt, P);
+    case 2: return mel_dot<2>(wt, P);
+    case 3: return mel_dot<3>(wt, P);
+    case 4: return mel_dot<4>(wt, P);
+    case 5: return mel_dot<5>(wt, P);
+    case 6: return mel_dot<6>(wt, P);
+    case 7: return mel_dot<7>(wt, P);
+    case 8: return mel_dot<8>(wt, P);
+    case 9: return mel_dot<9>(wt, P);
+    case 10: return mel_dot<10>(wt, P);
+    case 11: return mel_dot<11>(wt, P);
+    case 12: return mel_dot<12>(wt, P);
+    case 13: return mel_dot<13>(wt, P);
+    case 14: return mel_dot<14>(wt, P);
+    case 15: return mel_dot<15>(wt, P);
+    case 16: return mel_dot<16>(wt, P);
+    default: break;
+  }
+  float acc = 0.0f;
+  for (int i0 = 0; i0 < rw; i0 += kMelMaxTaps) {
+    float part = 0.0f;
+    for (int j = 0; j < kMelMaxTaps && i0 + j < rw; ++j) part += wt[i0 + j] * P[i0 + j];
+    acc += part;
+  }
+  return acc;
+}
+
 AAMD_HD void phase_c(int lane, const MelTab& mt, const float* lds, float* out_row, int64_t t0,
                      int n_frames) {
   const bool lane_ok = lane < 60;
   const int f = lane_ok ? lane / kMelsPerRound : 0;
   const int mi = lane_ok ? lane - kMelsPerRound * f : 0;
-  for (int r = 0; r < mt.n_rounds; ++r) {
+  const float* Prow = lds + kPStride * f;
+  const bool frame_ok = lane_ok && (t0 + f < n_frames);
+  float* orow = out_row + (t0 + f) * (int64_t)mt.n_mels;
+  // band starts of this lane's mel in every round, fetched together
+  int lo[kMelMaxRounds];
+#pragma unroll
+  for (int r = 0; r < kMelMaxRounds; ++r) {
     const int m = r * kMelsPerRound + mi;
-    const bool ok = lane_ok && m < mt.n_mels;
-    const int mm = ok ? m : 0;
-    const float* wt = mt.w + mm * mt.wpad;
-    const float* P = lds + kPStride * f + mt.lo[mm];
-    const int rw = mt.rw[r];
-    float acc = 0.0f;
-    for (int i0 = 0; i0 < rw; i0 += kMelChunk) {
-      float wv[kMelChunk], pv[kMelChunk];
+    lo[r] = (r < mt.n_rounds && m < mt.n_mels) ? mt.lo[m] : 0;
+  }
 #pragma unroll
-      for (int j = 0; j < kMelChunk; ++j) {
-        const bool in = i0 + j < rw;          // wave-uniform
-        wv[j] = in ? wt[i0 + j] : 0.0f;
-        pv[j] = in ? P[i0 + j] : 0.0f;
-      }
-#pragma unroll
-      for (int j = 0; j < kMelChunk; ++j) acc += wv[j] * pv[j];
+  for (int r = 0; r < kMelMaxRounds; ++r) {
+    if (r < mt.n_rounds) {
+      const int m = r * kMelsPerRound + mi;
+      const bool ok = m < mt.n_mels;
+      const float* wt = mt.w + (ok ? m : 0) * mt.wpad;
+      const float acc = mel_dot_n(mt.rw[r], wt, Prow + lo[r]);
+      if (ok && frame_ok) orow[m] = acc;
     }
-    if (ok && t0 + f < n_frames) out_row[(t0 + f) * (int64_t)mt.n_mels + m] = acc;
   }
 }
 
@@ -288,7 +349,7 @@ __global__ void __launch_bounds__(256)
 melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ window,
                   const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
                   int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
-                  int tiles_per_row, int64_t n_tiles, int n_blocks_log) {
+                  int tiles_per_row, int64_t n_tiles, int ablate) {
   extern __shared__ __attribute__((aligned(16))) float smem400[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -317,6 +378,8 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     const bool interior = (t0 * kHop - kPad >= 0) &&
                           ((t0 + kFramesPerWave - 1) * kHop + (kN - kPad) <= length) &&
                           (t0 + kFramesPerWave <= n_frames);
+    // `ablate` bits are a profiling aid only (tools/gpu_microbench.py); 0 in production
+    if (ablate & 1) wav_row = wav;           // every tile re-reads row 0 (cache-resident input)
     if (interior) phase_a<false>(c, wav_row, length, t0, n_frames, lds);
     else          phase_a<true>(c, wav_row, length, t0, n_frames, lds);
     wave_lds_fence();
@@ -331,7 +394,8 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     phase_b2(c, zr, zi, gr, gi, lds);
     phase_b2_pad(lane, lds);
     wave_lds_fence();
-    phase_c(lane, mt, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
+    if (!(ablate & 2)) phase_c(lane, mt, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
+    else if (lane == 0) out[tile] = lds[lane];
     wave_lds_fence();
   }
 }

@@ -52,7 +52,7 @@ def _rows2d(t: Tensor) -> Tensor:
 
 
 _CACHE: dict = {}        # value-keyed constants (twiddles, sinc kernels): key holds every parameter
-_TENSOR_CACHE: dict = {}  # id(tensor) -> {key: value}; entry dropped when the tensor dies
+_TENSOR_CACHE: dict = {}  # id(tensor) -> (weakref(tensor), {key: value})
 
 
 def _cached(key, make):
@@ -66,20 +66,23 @@ def _cached(key, make):
 
 
 def _tensor_cached(t: Tensor, key, make):
-    """Cache a constant derived from tensor `t` (window / fb buffers).  Keyed by object identity
-    + in-place version counter; a weakref finalizer evicts the entry when `t` is freed, so a new
-    tensor that happens to reuse the same id / data_ptr can never hit a stale entry."""
+    """Cache a constant derived from tensor `t` (window / fb buffers).  The slot is found by
+    object id but is only trusted while its weak reference still resolves to `t` itself, so a
+    new tensor that reuses a dead tensor's id can never hit a stale entry (finalizers of tensor
+    wrappers may run late); the in-place version counter invalidates on mutation."""
     tid = id(t)
     slot = _TENSOR_CACHE.get(tid)
-    if slot is None:
-        slot = {}
+    if slot is None or slot[0]() is not t:
+        if len(_TENSOR_CACHE) > 512:
+            for k in [k for k, s in _TENSOR_CACHE.items() if s[0]() is None]:
+                del _TENSOR_CACHE[k]
+        slot = (weakref.ref(t), {})
         _TENSOR_CACHE[tid] = slot
-        weakref.finalize(t, _TENSOR_CACHE.pop, tid, None)
     k = (key, t._version, str(t.device), t.dtype)
-    v = slot.get(k)
+    v = slot[1].get(k)
     if v is None:
         v = make()
-        slot[k] = v
+        slot[1][k] = v
     return v
 
 
