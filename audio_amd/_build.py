@@ -10,7 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "libaudio_amd.so")
 SOURCES = ["c_api.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
+         # packed fp32 VALU ops run at half rate on gfx950 (no gain) and cost v_mov shuffles
+         "-fno-slp-vectorize"]
 
 
 def hipcc() -> str:

@@ -135,7 +135,7 @@ int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, c
 bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
   return g.n_fft == 400 && g.hop == 160 && g.center && g.pad_mode == AAMD_PAD_REFLECT &&
          g.onesided && g.pad == 0 && g.power == 2.0f && g.length > 400 &&
-         m400::mel_tab_dwords(mb.n_mels, mb.max_width) <= 16 * 1024 &&
+         mb.max_width + 2 <= m400::kMelMaxTaps &&
          m400::mel_rounds(mb.n_mels) <= m400::kMelMaxRounds;
 }
 
@@ -145,26 +145,22 @@ int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, co
   const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
   const int64_t n_tiles = g.rows * tiles_per_row;
   const size_t lds = ((size_t)4 * m400::kLdsDwordsPerWave + m400::mel_tab_dwords(mb.n_mels, mb.max_width)) * sizeof(float);
-  static thread_local int occ_cache = 0;
-  if (occ_cache == 0) {
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, m400::melspec400_kernel, 256, lds) != hipSuccess || occ < 1)
-      occ = 2;
-    occ_cache = occ;
-  }
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(m400::melspec400_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int64_t blocks = (int64_t)dev_props().cu_count * occ_cache;
+  int occ = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, m400::melspec400_kernel, 256, lds) != hipSuccess || occ < 1)
+    occ = 1;
+  // persistent grid: every wave walks a contiguous run of tiles (6 frames each)
+  int64_t blocks = (int64_t)dev_props().cu_count * occ;
   const int64_t need = (n_tiles + 3) / 4;
   if (blocks > need) blocks = need;
   if (blocks >= 8) blocks -= blocks % 8;  // XCD remap wants a multiple of 8
   if (blocks < 1) blocks = 1;
-  int ablate = 0;
-  if (const char* e = std::getenv("AAMD_MEL400_VARIANT")) ablate = std::atoi(e);   // profiling aid
+  const int tiles_per_wave = (int)((n_tiles + blocks * 4 - 1) / (blocks * 4));
   hipLaunchKernelGGL(m400::melspec400_kernel, dim3((unsigned)blocks), dim3(256), lds, s, wav, window,
                      twiddle, mb, out, g.rows, g.length, g.row_stride, g.n_frames, g.scale,
-                     tiles_per_row, n_tiles, ablate);
+                     tiles_per_row, n_tiles, tiles_per_wave);
   return launch_check();
 }
 

@@ -22,6 +22,15 @@ using std::fmin;
 
 namespace aamd {
 
+// 8- / 16-byte LDS accesses (ds_read_b64 / ds_read_b128 need their natural alignment)
+#if defined(__HIPCC__)
+using F2 = float2;
+using F4 = float4;
+#else
+struct alignas(8) F2 { float x, y; };
+struct alignas(16) F4 { float x, y, z, w; };
+#endif
+
 template <typename T>
 struct cplx {
   T x, y;

@@ -1,20 +1,24 @@
 // Headline kernel: fused MelSpectrogram for n_fft = 400, hop = 160 (the RNN-T / Whisper
 // style front-end, BASELINE.json config 2), power = 2, centre + reflect padding.
 //
-// Design (MI355X, wave64; no barriers -- every wave owns private LDS):
-//   * two REAL frames a, b are packed as one COMPLEX 400-point FFT  z = a + i b
+// Design (MI355X, wave64; no workgroup barriers in the tile loop -- every wave owns private LDS):
+//   * two REAL frames a, b = a + 1 are packed as one COMPLEX 400-point FFT  z = a + i b
 //     (no redundant half-spectrum work, no post-twiddle multiply);
 //   * 400 = 20 x 20 Cooley-Tukey.  A 20-lane group owns one frame pair; each lane runs a
 //     20-point DFT entirely in registers (Good-Thomas 4x5: five radix-4 + four radix-5
-//     butterflies, NO internal twiddles), multiplies by its W400^(r s) twiddles, and the
-//     20x20 transposition goes once through LDS (row stride 21 complex = conflict free for
+//     butterflies, NO internal twiddles), multiplies by its W400^(b c) twiddles, and the
+//     20x20 transposition goes once through LDS (row stride 22 complex: conflict free for
 //     both the column write and the row read); a second in-register DFT-20 finishes the FFT;
-//   * 3 pairs (60 lanes) = 6 frames per wave per iteration;
-//   * the a/b spectra are separated with the conj-symmetry rule; the partner bin Z[400-k]
-//     lives in lane (20 - s) mod 20 of the same group and is fetched with ds_bpermute
-//     (wavefront shuffle), so only |A|^2, |B|^2 for k = 0..200 are ever written to LDS;
-//   * mel = banded reduction over the LDS power spectrum: the filterbank's band table lives
-//     in LDS; rounds of 10 mels x 6 frames with a wave-uniform tap count per round.
+//   * 3 pairs (60 lanes) = 6 frames per wave per tile; frame b starts 160 = 8*20 samples after
+//     frame a, so a lane fetches 28 (not 40) strided samples per pair;
+//   * the a/b spectra are separated with the conj-symmetry rule.  Lanes are laid out so that the
+//     lane holding column 20-c sits next to the lane holding column c: the partner bin
+//     Z[400-k] arrives through a DPP quad_perm [1,0,3,2] swap (wavefront shuffle on the VALU,
+//     no LDS traffic); the two self-paired columns (0 and 10) are patched with selects;
+//   * |A|^2, |B|^2 for k = 0..200 go to LDS interleaved as float2 (a, b) per bin;
+//   * mel = banded reduction over that LDS power spectrum: lane (pair, slot) owns mels
+//     slot + 20 r for BOTH frames of the pair; the band table (even-aligned band starts, zero
+//     padded weights) lives in LDS, read as b64 (2 weights) + b128 (2 bins x 2 frames).
 //
 // Reference semantics: transforms/_transforms.py:612-622 (MelSpectrogram.forward),
 // functional/functional.py:112-145, torch/functional.py:675-681; framing is bit-exact
@@ -30,54 +34,79 @@ constexpr int kN = 400;
 constexpr int kHop = 160;
 constexpr int kPad = 200;
 constexpr int kFramesPerWave = 6;
-constexpr int kTRow = 42;                 // dwords per transposition row (20 complex + 1 pad)
-constexpr int kPStride = 218;             // dwords per power-spectrum row: 201 bins + 17 zeros, = 10 mod 16
-constexpr int kLdsDwordsPerWave = 60 * kTRow;  // 2520 dwords = 10080 B (the 6 P rows alias it)
-constexpr int kMelsPerRound = 10;         // phase C: 6 frames x 10 mels = 60 lanes per round
-constexpr int kMelChunk = 8;              // taps fetched per batch of LDS reads
+// LDS strides picked with tools/lds_conflicts.py (bank model of MI355X_MICROARCH.md):
+constexpr int kTRow = 44;                      // dwords per transposition row: 20 complex + pad, 16-B aligned
+                                               // rows -> conflict-free ds_read_b128; column writes 6 array
+                                               // cycles = the ds_write_b64 issue cost
+constexpr int kTPair = 20 * kTRow;             // 880 dwords per pair
+constexpr int kLdsDwordsPerWave = 3 * kTPair;  // 2640 dwords = 10560 B (the P rows alias it)
+constexpr int kPK = 212;                       // readable bins per P row: 201 + zeroed tail, even
+constexpr int kPPair = 448;                    // dwords per pair of P rows (>= 2 * kPK)
+constexpr int kMelSlots = 20;                  // mels per round
+constexpr int kMelMaxRounds = 8;               // n_mels <= 160
+constexpr int kMelMaxTaps = 64;                // widest padded band
 
-// Per-workgroup LDS copy of the banded filterbank (built once per launch by every workgroup).
+static_assert(3 * kPPair <= kLdsDwordsPerWave && 2 * kPK <= kPPair, "P rows must fit in the transposition buffer");
+static_assert(3 * (kPK - 201) <= 64, "one lane per tail bin");
+
+// column held by the lane at position pi of a 20-lane group (pass 2), and its inverse:
+// positions (0,1) = columns (0,10), then (2j, 2j+1) = (j, 20-j): lane ^ 1 holds column 20 - c.
+AAMD_HD constexpr int col_of_pos(int pi) {
+  return pi == 0 ? 0 : pi == 1 ? 10 : (pi & 1) ? 20 - (pi >> 1) : (pi >> 1);
+}
+AAMD_HD constexpr int pos_of_col(int c) {
+  return c == 0 ? 0 : c == 10 ? 1 : c < 10 ? 2 * c : 2 * (20 - c) + 1;
+}
+
+// ---- banded filterbank in LDS (built once per launch by every workgroup) ------------------
 struct MelTab {
-  const float* w;    // [n_mels][wpad], zero padded
-  const int* lo;     // [n_mels]
-  const int* rw;     // [n_rounds]: widest band among the round's mels (wave-uniform trip count)
-  int n_mels, wpad, n_rounds;
+  const float* w;    // [n_mels][ws]: weight of bin lo2[m] + j, zero outside the band
+  const int* lo2;    // [n_mels]: even band start (<= first non-zero bin)
+  const int* rw2;    // [n_rounds]: even tap count of the round (wave-uniform trip count)
+  int n_mels, ws, n_rounds;
 };
 
-AAMD_HD int mel_wpad(int max_width) { return max_width | 1; }   // odd stride: conflict-free rows
-AAMD_HD int mel_rounds(int n_mels) { return (n_mels + kMelsPerRound - 1) / kMelsPerRound; }
+AAMD_HD int mel_rounds(int n_mels) { return (n_mels + kMelSlots - 1) / kMelSlots; }
+// row stride: covers the widest even-aligned band, = 2 mod 4 (b64 rows of 20 mels hit distinct banks)
+AAMD_HD int mel_ws(int max_width) {
+  const int w2 = (max_width + 2) & ~1;
+  return (w2 & 3) == 0 ? w2 + 2 : w2;
+}
 AAMD_HD int mel_tab_dwords(int n_mels, int max_width) {
-  return n_mels * mel_wpad(max_width) + n_mels + mel_rounds(n_mels);
+  return n_mels * mel_ws(max_width) + n_mels + kMelMaxRounds;
 }
 
 AAMD_HD void mel_tab_build(int tid, int nthr, const MelBandsDev& mb, float* base, MelTab& mt) {
   mt.n_mels = mb.n_mels;
-  mt.wpad = mel_wpad(mb.max_width);
+  mt.ws = mel_ws(mb.max_width);
   mt.n_rounds = mel_rounds(mb.n_mels);
   float* w = base;
-  int* lo = reinterpret_cast<int*>(base + mb.n_mels * mt.wpad);
-  int* rw = lo + mb.n_mels;
-  for (int i = tid; i < mb.n_mels * mt.wpad; i += nthr) {
-    const int m = i / mt.wpad, j = i - m * mt.wpad;
-    w[i] = (j < mb.width[m]) ? mb.weights[m * mb.max_width + j] : 0.0f;
+  int* lo2 = reinterpret_cast<int*>(base + mb.n_mels * mt.ws);
+  int* rw2 = lo2 + mb.n_mels;
+  // every thread derives the per-round tap counts it needs (n_mels is small)
+  for (int i = tid; i < mb.n_mels * mt.ws; i += nthr) {
+    const int m = i / mt.ws, j = i - m * mt.ws;
+    const int r = m / kMelSlots;
+    int rw = 0;
+    for (int q = r * kMelSlots; q < (r + 1) * kMelSlots && q < mb.n_mels; ++q) {
+      const int e = (mb.width[q] + (mb.lo[q] & 1) + 1) & ~1;
+      rw = e > rw ? e : rw;
+    }
+    int l2 = mb.lo[m] & ~1;
+    if (l2 + rw > kPK) l2 = kPK - rw;
+    const int off = mb.lo[m] - l2;
+    w[i] = (j >= off && j - off < mb.width[m]) ? mb.weights[m * mb.max_width + (j - off)] : 0.0f;
+    if (j == 0) lo2[m] = l2;
+    if (j == 0 && m == r * kMelSlots) rw2[r] = rw;
   }
-  for (int m = tid; m < mb.n_mels; m += nthr) lo[m] = mb.lo[m];
-  for (int r = tid; r < mt.n_rounds; r += nthr) {
-    int mx = 0;
-    for (int m = r * kMelsPerRound; m < (r + 1) * kMelsPerRound && m < mb.n_mels; ++m)
-      mx = mb.width[m] > mx ? mb.width[m] : mx;
-    rw[r] = mx;
-  }
-  mt.w = w; mt.lo = lo; mt.rw = rw;
+  mt.w = w; mt.lo2 = lo2; mt.rw2 = rw2;
 }
 
 struct LaneConst {
-  // W400^(r*s) = ta[s & 3] * tb[s >> 2] with ta[b] = w^b (b = 1..3), tb[a] = w^(4a) (a = 1..4),
-  // w = W400^r: 14 registers instead of 40; 12 of the 20 twiddles cost one extra complex multiply.
-  float tar[3], tai[3], tbr[4], tbi[4];
-  float win[20];           // 0.5 * scale * window[r + 20 q]
-  int p, r;                // pair index (0..2), row/column index inside the pair (0..19)
-  int active;              // lanes 60..63 shadow pair 2 but never store
+  float twr[19], twi[19];  // W400^(b*c), c = 1..19 (pass-1 role b = pi)
+  float win[20];           // 0.5 * scale * window[b + 20 q]
+  int p, pi, col;          // pair 0..2, position in the 20-lane group, pass-2 column
+  int active;              // lanes 60..63 shadow lanes 40..43 but never store
 };
 
 AAMD_HD void lane_init(int lane, const float* window, const float* tw400, float scale,
@@ -85,21 +114,16 @@ AAMD_HD void lane_init(int lane, const float* window, const float* tw400, float 
   c.active = lane < 60;
   const int l = c.active ? lane : lane - 20;
   c.p = l / 20;
-  c.r = l - 20 * c.p;
+  c.pi = l - 20 * c.p;
+  c.col = col_of_pos(c.pi);
 #pragma unroll
-  for (int b = 1; b < 4; ++b) {
-    const int idx = (c.r * b) % kN;
-    c.tar[b - 1] = tw400[2 * idx];
-    c.tai[b - 1] = tw400[2 * idx + 1];
+  for (int s = 1; s < 20; ++s) {
+    const int idx = (c.pi * s) % kN;
+    c.twr[s - 1] = tw400[2 * idx];
+    c.twi[s - 1] = tw400[2 * idx + 1];
   }
 #pragma unroll
-  for (int a = 1; a < 5; ++a) {
-    const int idx = (c.r * 4 * a) % kN;
-    c.tbr[a - 1] = tw400[2 * idx];
-    c.tbi[a - 1] = tw400[2 * idx + 1];
-  }
-#pragma unroll
-  for (int q = 0; q < 20; ++q) c.win[q] = window[c.r + 20 * q] * (0.5f * scale);
+  for (int q = 0; q < 20; ++q) c.win[q] = window[c.pi + 20 * q] * (0.5f * scale);
 }
 
 // ---- in-register DFT-20, forward (e^{-2 pi i nk/20}), natural order in and out -----------
@@ -163,176 +187,143 @@ AAMD_HD int64_t reflect_idx(int64_t i, int64_t len) {
 }
 
 // ---- phase A: gather + window + DFT-20 over q + twiddle + transposed LDS write ----------
-//   lane (p, r) owns samples n = r + 20 q of frames a = t0 + 2p, b = a + 1.
+//   lane (p, b) owns samples n = b + 20 q of frames a = t0 + 2p and a + 1; the 28 fetched
+//   samples X[q] sit at signal index a*160 - 200 + b + 20 q: frame a uses X[0..19], frame
+//   a + 1 uses X[8..27].
 template <bool EDGE>
 AAMD_HD void phase_a(const LaneConst& c, const float* wav_row, int64_t length, int64_t t0,
                      int n_frames, float* lds) {
-  float xr[20], xi[20], yr[20], yi[20];
+  float X[28];
   const int64_t ta = t0 + 2 * c.p;
-  const int64_t ia0 = ta * kHop - kPad + c.r;
+  const int64_t i0 = ta * kHop - kPad + c.pi;
+  if (!EDGE) {
+    const float* src = wav_row + i0;
+#pragma unroll
+    for (int q = 0; q < 28; ++q) X[q] = src[20 * q];
+  } else {
+#pragma unroll
+    for (int q = 0; q < 28; ++q) {
+      const int64_t i = i0 + 20 * q;
+      // q < 20 belongs to frame a (and to a + 1 when q >= 8); q >= 20 only to frame a + 1
+      const bool need = (q < 20) ? (ta < n_frames) : (ta + 1 < n_frames);
+      X[q] = need ? wav_row[reflect_idx(i, length)] : 0.0f;
+    }
+  }
+  float xr[20], xi[20], yr[20], yi[20];
+  const bool vb = !EDGE || (ta + 1 < n_frames);
 #pragma unroll
   for (int q = 0; q < 20; ++q) {
-    const int64_t ia = ia0 + 20 * q, ib = ia + kHop;
-    float xa, xb;
-    if (!EDGE) {
-      xa = wav_row[ia];
-      xb = wav_row[ib];
-    } else {
-      xa = (ta < n_frames) ? wav_row[reflect_idx(ia, length)] : 0.0f;
-      xb = (ta + 1 < n_frames) ? wav_row[reflect_idx(ib, length)] : 0.0f;
-    }
-    xr[q] = xa * c.win[q];
-    xi[q] = xb * c.win[q];
+    xr[q] = X[q] * c.win[q];
+    xi[q] = vb ? X[q + 8] * c.win[q] : 0.0f;
   }
   dft20(xr, xi, yr, yi);
   if (c.active) {
-    float* col = lds + kTRow * (20 * c.p) + 2 * c.r;
+    float* colp = lds + kTPair * c.p + 2 * c.pi;
 #pragma unroll
     for (int s = 0; s < 20; ++s) {
       float vr = yr[s], vi = yi[s];
-      const int b = s & 3, a = s >> 2;
-      if (b != 0) {
-        const float tr_ = vr * c.tar[b - 1] - vi * c.tai[b - 1];
-        vi = vr * c.tai[b - 1] + vi * c.tar[b - 1];
-        vr = tr_;
+      if (s != 0) {
+        const float wr = c.twr[s - 1], wi = c.twi[s - 1];
+        vr = yr[s] * wr - yi[s] * wi;
+        vi = yr[s] * wi + yi[s] * wr;
       }
-      if (a != 0) {
-        const float tr_ = vr * c.tbr[a - 1] - vi * c.tbi[a - 1];
-        vi = vr * c.tbi[a - 1] + vi * c.tbr[a - 1];
-        vr = tr_;
-      }
-      col[kTRow * s] = vr;
-      col[kTRow * s + 1] = vi;
+      *reinterpret_cast<F2*>(colp + kTRow * pos_of_col(s)) = F2{vr, vi};
     }
   }
 }
 
-// ---- phase B1: read own row, DFT-20 over r  ->  Z[s + 20 u] in registers ------------------
+// ---- phase B1: read own row, DFT-20 over b  ->  Z[col + 20 d] in registers ----------------
 AAMD_HD void phase_b1(const LaneConst& c, const float* lds, float (&zr)[20], float (&zi)[20]) {
   float vr[20], vi[20];
-  const float* row = lds + kTRow * (20 * c.p + c.r);
+  const float* row = lds + kTPair * c.p + kTRow * c.pi;
 #pragma unroll
-  for (int j = 0; j < 20; ++j) { vr[j] = row[2 * j]; vi[j] = row[2 * j + 1]; }
+  for (int j = 0; j < 10; ++j) {
+    const F4 v = *reinterpret_cast<const F4*>(row + 4 * j);
+    vr[2 * j] = v.x;
+    vi[2 * j] = v.y;
+    vr[2 * j + 1] = v.z;
+    vi[2 * j + 1] = v.w;
+  }
   dft20(vr, vi, zr, zi);
 }
 
-AAMD_HD int partner_lane(const LaneConst& c) { return 20 * c.p + (20 - c.r) % 20; }
+// ---- phase B2a: the values the neighbour lane (lane ^ 1) needs: q[i] = Z-register 10 + i,
+//   except on the column-0 lane, whose conjugate partner of bin 20 u is its OWN register
+//   (20 - u) % 20 = (19 - u) + 1: rotate by one so every lane can use index 19 - u.
+AAMD_HD void phase_b2_send(const LaneConst& c, const float (&zr)[20], const float (&zi)[20],
+                           float (&qr)[10], float (&qi)[10]) {
+  const bool c0 = (c.col == 0);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const int j = 10 + i;
+    // load both candidates first: a select between array ELEMENTS, never between indices
+    const float nr = zr[j], ni = zi[j], rr = zr[(j + 1) % 20], ri = zi[(j + 1) % 20];
+    qr[i] = c0 ? rr : nr;
+    qi[i] = c0 ? ri : ni;
+  }
+}
 
-// ---- phase B2: separate the two real spectra, |.|^2, write P rows ------------------------
-//   g[i] = partner's Z[10 + i].  conj(Z[400-k]) for k = s + 20u is partner idx 19-u (s != 0),
-//   or own-lane idx (20-u) mod 20 when s == 0 (partner == self).
+// ---- phase B2b: separate the two real spectra, |.|^2, write interleaved P rows ------------
+//   g = q of lane ^ 1 (DPP swap).  conj(Z[400-k]) for k = col + 20u is g[9 - u]; the self-paired
+//   columns 0 and 10 take their own q instead.
 AAMD_HD void phase_b2(const LaneConst& c, const float (&zr)[20], const float (&zi)[20],
-                      const float (&gr)[10], const float (&gi)[10], float* lds) {
+                      const float (&qr)[10], const float (&qi)[10], const float (&gr)[10],
+                      const float (&gi)[10], float* lds) {
   if (!c.active) return;
-  float* pa = lds + kPStride * (2 * c.p) + c.r;
-  float* pb = pa + kPStride;
-  const bool s0 = (c.r == 0);
+  float* P = lds + kPPair * c.p + 2 * c.col;
+  const bool self = (c.col == 0) || (c.col == 10);
 #pragma unroll
   for (int u = 0; u < 10; ++u) {
-    float cr, ci;
-    if (u == 0) {
-      cr = s0 ? zr[0] : gr[9];
-      ci = s0 ? zi[0] : gi[9];
-    } else {
-      cr = s0 ? gr[10 - u] : gr[9 - u];
-      ci = s0 ? gi[10 - u] : gi[9 - u];
-    }
+    const float sr = qr[9 - u], si = qi[9 - u], pr = gr[9 - u], pi_ = gi[9 - u];
+    const float cr = self ? sr : pr;
+    const float ci = self ? si : pi_;
     const float ar = zr[u] + cr, ai = zi[u] - ci;   // 2*A = Z[k] + conj(Z[N-k])
     const float br = zr[u] - cr, bi = zi[u] + ci;   // |2*B|: Z[k] - conj(Z[N-k])
-    pa[20 * u] = ar * ar + ai * ai;
-    pb[20 * u] = br * br + bi * bi;
+    *reinterpret_cast<F2*>(P + 40 * u) = F2{ar * ar + ai * ai, br * br + bi * bi};
   }
-  if (s0) {  // k = 200 (Nyquist): partner idx 10 of this same lane
-    const float ar = zr[10] + gr[0], ai = zi[10] - gi[0];
-    const float br = zr[10] - gr[0], bi = zi[10] + gi[0];
-    pa[200] = ar * ar + ai * ai;
-    pb[200] = br * br + bi * bi;
+  if (c.col == 0) {  // k = 200 (Nyquist) is its own conjugate partner: A = Re, B = Im
+    const float ar = zr[10] + zr[10], bi = zi[10] + zi[10];
+    *reinterpret_cast<F2*>(P + 400) = F2{ar * ar, bi * bi};
   }
 }
 
-// zero the 17-float tail of each P row so that band reads past bin 200 (weight 0) never touch
-// stale transposition data of another frame
+// zero bins 201..211 of each P row so that band reads past bin 200 (weight 0) never touch
+// stale transposition data
 AAMD_HD void phase_b2_pad(int lane, float* lds) {
-  constexpr int kTail = kPStride - 201;
-  for (int i = lane; i < kFramesPerWave * kTail; i += 64) {
-    const int f = i / kTail, j = i - f * kTail;
-    lds[kPStride * f + 201 + j] = 0.0f;
+  constexpr int kTail = kPK - 201;
+  if (lane < 3 * kTail) {
+    const int p = lane / kTail, j = lane - p * kTail;
+    *reinterpret_cast<F2*>(lds + kPPair * p + 2 * (201 + j)) = F2{0.0f, 0.0f};
   }
 }
 
-// ---- phase C: banded mel reduction from the 6 LDS power rows ----------------------------------
-//   round r: lane (f, mi) -> frame f, mel m = 10 r + mi; mel widths grow with m, so the
-//   wave-uniform tap count rw[r] tracks each lane's own band width closely (46 tap slots per
-//   lane for the 80-mel bank vs 37 ideal).  Each round is a straight-line body selected by the
-//   uniform tap count: all 2*W LDS reads are issued back to back, then W FMAs.
-constexpr int kMelMaxTaps = 16;   // bands wider than this use the chunked loop
-constexpr int kMelMaxRounds = 16;
-
-template <int W>
-AAMD_HD float mel_dot(const float* wt, const float* P) {
-  float wv[W], pv[W];
-#pragma unroll
-  for (int j = 0; j < W; ++j) { wv[j] = wt[j]; pv[j] = P[j]; }
-  float acc = 0.0f;
-#pragma unroll
-  for (int j = 0; j < W; ++j) acc += wv[j] * pv[j];
-  return acc;
-}
-
-AAMD_HD float mel_dot_n(int rw, const float* wt, const float* P) {
-  switch (rw) {
-    case 0: return 0.0f;
-    case 1: return mel_dot<1>(wt, P);
-    case 2: return mel_dot<2>(wt, P);
-    case 3: return mel_dot<3>(wt, P);
-    case 4: return mel_dot<4>(wt, P);
-    case 5: return mel_dot<5>(wt, P);
-    case 6: return mel_dot<6>(wt, P);
-    case 7: return mel_dot<7>(wt, P);
-    case 8: return mel_dot<8>(wt, P);
-    case 9: return mel_dot<9>(wt, P);
-    case 10: return mel_dot<10>(wt, P);
-    case 11: return mel_dot<11>(wt, P);
-    case 12: return mel_dot<12>(wt, P);
-    case 13: return mel_dot<13>(wt, P);
-    case 14: return mel_dot<14>(wt, P);
-    case 15: return mel_dot<15>(wt, P);
-    case 16: return mel_dot<16>(wt, P);
-    default: break;
-  }
-  float acc = 0.0f;
-  for (int i0 = 0; i0 < rw; i0 += kMelMaxTaps) {
-    float part = 0.0f;
-    for (int j = 0; j < kMelMaxTaps && i0 + j < rw; ++j) part += wt[i0 + j] * P[i0 + j];
-    acc += part;
-  }
-  return acc;
-}
-
-AAMD_HD void phase_c(int lane, const MelTab& mt, const float* lds, float* out_row, int64_t t0,
-                     int n_frames) {
-  const bool lane_ok = lane < 60;
-  const int f = lane_ok ? lane / kMelsPerRound : 0;
-  const int mi = lane_ok ? lane - kMelsPerRound * f : 0;
-  const float* Prow = lds + kPStride * f;
-  const bool frame_ok = lane_ok && (t0 + f < n_frames);
-  float* orow = out_row + (t0 + f) * (int64_t)mt.n_mels;
-  // band starts of this lane's mel in every round, fetched together
-  int lo[kMelMaxRounds];
-#pragma unroll
-  for (int r = 0; r < kMelMaxRounds; ++r) {
-    const int m = r * kMelsPerRound + mi;
-    lo[r] = (r < mt.n_rounds && m < mt.n_mels) ? mt.lo[m] : 0;
-  }
-#pragma unroll
-  for (int r = 0; r < kMelMaxRounds; ++r) {
-    if (r < mt.n_rounds) {
-      const int m = r * kMelsPerRound + mi;
-      const bool ok = m < mt.n_mels;
-      const float* wt = mt.w + (ok ? m : 0) * mt.wpad;
-      const float acc = mel_dot_n(mt.rw[r], wt, Prow + lo[r]);
-      if (ok && frame_ok) orow[m] = acc;
+// ---- phase C: banded mel reduction from the LDS power rows --------------------------------
+//   lane (p, slot) computes mel m = slot + 20 r of frames 2p and 2p + 1 in round r; the tap
+//   count rw2[r] is wave-uniform.
+AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds, float* out_row,
+                     int64_t t0, int n_frames) {
+  const int64_t ta = t0 + 2 * c.p;
+  const bool va = c.active && ta < n_frames, vb = c.active && ta + 1 < n_frames;
+  const float* Pp = lds + kPPair * c.p;
+  float* oa = out_row + ta * (int64_t)mt.n_mels;
+  for (int r = 0; r < mt.n_rounds; ++r) {
+    const int m = r * kMelSlots + c.pi;
+    const bool ok = m < mt.n_mels;
+    const int mm = ok ? m : 0;
+    const float* wt = mt.w + mm * mt.ws;
+    const float* P = Pp + 2 * mt.lo2[mm];
+    const int n2 = mt.rw2[r];
+    float acc_a = 0.0f, acc_b = 0.0f;
+    for (int j = 0; j < n2; j += 2) {
+      const F2 w = *reinterpret_cast<const F2*>(wt + j);
+      const F4 q = *reinterpret_cast<const F4*>(P + 2 * j);   // (a, b) of bins j, j + 1
+      acc_a += w.x * q.x;
+      acc_b += w.x * q.y;
+      acc_a += w.y * q.z;
+      acc_b += w.y * q.w;
     }
+    if (ok && va) oa[m] = acc_a;
+    if (ok && vb) oa[mt.n_mels + m] = acc_b;
   }
 }
 
@@ -345,11 +336,17 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-__global__ void __launch_bounds__(256)
+// value of lane ^ 1 (DPP quad_perm [1,0,3,2]): a VALU move, no LDS traffic
+__device__ __forceinline__ float swap_adjacent(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+__global__ void __launch_bounds__(256, 2)
 melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ window,
                   const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
                   int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
-                  int tiles_per_row, int64_t n_tiles, int ablate) {
+                  int tiles_per_row, int64_t n_tiles, int tiles_per_wave) {
   extern __shared__ __attribute__((aligned(16))) float smem400[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -365,37 +362,38 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
   // XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
   // range of tiles so the frame-overlap re-reads stay inside one L2.
   const int nb = gridDim.x;
-  const int per_xcd = nb >> 3;
   int lb = blockIdx.x;
-  if ((nb & 7) == 0) lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const int64_t waves_total = (int64_t)nb * 4;
-  const int partner = partner_lane(c);
+  if ((nb & 7) == 0) lb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+  const int64_t first = ((int64_t)lb * 4 + wave) * tiles_per_wave;
+  int64_t last = first + tiles_per_wave;
+  if (last > n_tiles) last = n_tiles;
 
-  for (int64_t tile = (int64_t)lb * 4 + wave; tile < n_tiles; tile += waves_total) {
-    const int64_t row = tile / tiles_per_row;
-    const int64_t t0 = (tile - row * tiles_per_row) * kFramesPerWave;
+  // (row, tile-in-row) advance incrementally: one division per wave, none per tile
+  int64_t row = first / tiles_per_row;
+  int tir = (int)(first - row * tiles_per_row);
+  for (int64_t tile = first; tile < last; ++tile, ++tir) {
+    if (tir == tiles_per_row) { tir = 0; ++row; }
+    const int64_t t0 = (int64_t)tir * kFramesPerWave;
     const float* wav_row = wav + row * row_stride;
     const bool interior = (t0 * kHop - kPad >= 0) &&
                           ((t0 + kFramesPerWave - 1) * kHop + (kN - kPad) <= length) &&
                           (t0 + kFramesPerWave <= n_frames);
-    // `ablate` bits are a profiling aid only (tools/gpu_microbench.py); 0 in production
-    if (ablate & 1) wav_row = wav;           // every tile re-reads row 0 (cache-resident input)
     if (interior) phase_a<false>(c, wav_row, length, t0, n_frames, lds);
     else          phase_a<true>(c, wav_row, length, t0, n_frames, lds);
     wave_lds_fence();
-    float zr[20], zi[20], gr[10], gi[10];
+    float zr[20], zi[20], qr[10], qi[10], gr[10], gi[10];
     phase_b1(c, lds, zr, zi);
+    phase_b2_send(c, zr, zi, qr, qi);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-      gr[i] = __shfl(zr[10 + i], partner, 64);
-      gi[i] = __shfl(zi[10 + i], partner, 64);
+      gr[i] = swap_adjacent(qr[i]);
+      gi[i] = swap_adjacent(qi[i]);
     }
     wave_lds_fence();
-    phase_b2(c, zr, zi, gr, gi, lds);
+    phase_b2(c, zr, zi, qr, qi, gr, gi, lds);
     phase_b2_pad(lane, lds);
     wave_lds_fence();
-    if (!(ablate & 2)) phase_c(lane, mt, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
-    else if (lane == 0) out[tile] = lds[lane];
+    phase_c(c, mt, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
     wave_lds_fence();
   }
 }

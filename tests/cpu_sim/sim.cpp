@@ -64,14 +64,15 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
 int sim_melspec400(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
                    float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale) {
   MelBandsDev mb{bands->n_mels, bands->max_width, bands->lo, bands->width, bands->weights};
-  std::vector<float> lds(m400::kLdsDwordsPerWave, 0.f);
-  std::vector<float> tab(m400::mel_tab_dwords(mb.n_mels, mb.max_width));
+  if (mb.max_width + 2 > m400::kMelMaxTaps || m400::mel_rounds(mb.n_mels) > m400::kMelMaxRounds) return -2;
+  alignas(16) static float lds[m400::kLdsDwordsPerWave];
+  alignas(16) static float tab[m400::kMelMaxRounds * m400::kMelSlots * (m400::kMelMaxTaps + 2) + 256];
   m400::MelTab mt;
-  for (int tid = 0; tid < 256; ++tid) m400::mel_tab_build(tid, 256, mb, tab.data(), mt);
+  for (int tid = 0; tid < 256; ++tid) m400::mel_tab_build(tid, 256, mb, tab, mt);
   m400::LaneConst c[64];
   for (int l = 0; l < 64; ++l) m400::lane_init(l, window, tw400, scale, c[l]);
   const int tiles_per_row = (n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
-  static float zr[64][20], zi[64][20], gr[64][10], gi[64][10];
+  static float zr[64][20], zi[64][20], qr[64][10], qi[64][10];
   for (int64_t row = 0; row < rows; ++row)
     for (int tl = 0; tl < tiles_per_row; ++tl) {
       const int64_t t0 = (int64_t)tl * m400::kFramesPerWave;
@@ -80,17 +81,15 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
                             ((t0 + m400::kFramesPerWave - 1) * m400::kHop + (m400::kN - m400::kPad) <= length) &&
                             (t0 + m400::kFramesPerWave <= n_frames);
       for (int l = 0; l < 64; ++l) {
-        if (interior) m400::phase_a<false>(c[l], wr, length, t0, n_frames, lds.data());
-        else m400::phase_a<true>(c[l], wr, length, t0, n_frames, lds.data());
+        if (interior) m400::phase_a<false>(c[l], wr, length, t0, n_frames, lds);
+        else m400::phase_a<true>(c[l], wr, length, t0, n_frames, lds);
       }
-      for (int l = 0; l < 64; ++l) m400::phase_b1(c[l], lds.data(), zr[l], zi[l]);
-      for (int l = 0; l < 64; ++l) {
-        const int pl = m400::partner_lane(c[l]);
-        for (int i = 0; i < 10; ++i) { gr[l][i] = zr[pl][10 + i]; gi[l][i] = zi[pl][10 + i]; }
-      }
-      for (int l = 0; l < 64; ++l) m400::phase_b2(c[l], zr[l], zi[l], gr[l], gi[l], lds.data());
-      for (int l = 0; l < 64; ++l) m400::phase_b2_pad(l, lds.data());
-      for (int l = 0; l < 64; ++l) m400::phase_c(l, mt, lds.data(), out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
+      for (int l = 0; l < 64; ++l) m400::phase_b1(c[l], lds, zr[l], zi[l]);
+      for (int l = 0; l < 64; ++l) m400::phase_b2_send(c[l], zr[l], zi[l], qr[l], qi[l]);
+      // the DPP quad_perm [1,0,3,2] swap: lane l receives lane l ^ 1's q
+      for (int l = 0; l < 64; ++l) m400::phase_b2(c[l], zr[l], zi[l], qr[l], qi[l], qr[l ^ 1], qi[l ^ 1], lds);
+      for (int l = 0; l < 64; ++l) m400::phase_b2_pad(l, lds);
+      for (int l = 0; l < 64; ++l) m400::phase_c(c[l], mt, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
     }
   return 0;
 }
