@@ -48,6 +48,7 @@ int launch_check() {
 struct DevProps {
   int cu_count = 0;
   size_t lds_per_block = 0;
+  size_t lds_per_block_optin = 0;
   bool ok = false;
 };
 
@@ -64,10 +65,12 @@ DevProps& dev_props() {
     if (hipGetDeviceProperties(&dp, dev) == hipSuccess) {
       p.cu_count = dp.multiProcessorCount;
       p.lds_per_block = dp.sharedMemPerBlock;
+      p.lds_per_block_optin = dp.sharedMemPerBlockOptin ? dp.sharedMemPerBlockOptin : dp.sharedMemPerBlock;
       p.ok = true;
     } else {
       p.cu_count = 256;
       p.lds_per_block = 64 * 1024;
+      p.lds_per_block_optin = 160 * 1024;
     }
   }
   return p;
@@ -135,7 +138,7 @@ int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, c
 bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
   return g.n_fft == 400 && g.hop == 160 && g.center && g.pad_mode == AAMD_PAD_REFLECT &&
          g.onesided && g.pad == 0 && g.power == 2.0f && g.length > 400 &&
-         mb.max_width + 2 <= m400::kMelMaxTaps &&
+         m400::mel_ws(mb.max_width) <= m400::kMelMaxTaps + 4 &&
          m400::mel_rounds(mb.n_mels) <= m400::kMelMaxRounds;
 }
 
@@ -144,23 +147,28 @@ int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, co
   if (g.rows == 0) return AAMD_OK;
   const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
   const int64_t n_tiles = g.rows * tiles_per_row;
-  const size_t lds = ((size_t)4 * m400::kLdsDwordsPerWave + m400::mel_tab_dwords(mb.n_mels, mb.max_width)) * sizeof(float);
+  AAMD_CHECK_ARG(n_tiles < (1ll << 31), "too many frames for one launch");
+  const int wpb = m400::kWavesPerBlock;
+  const size_t lds = m400::lds_bytes(mb.n_mels, mb.max_width);
+  if (lds > dev_props().lds_per_block_optin)
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: mel filterbank too large for the LDS of this device");
   if (lds > 48 * 1024)
-    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(m400::melspec400_kernel),
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(m400::melspec400_kernel<0>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int occ = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, m400::melspec400_kernel, 256, lds) != hipSuccess || occ < 1)
-    occ = 1;
-  // persistent grid: every wave walks a contiguous run of tiles (6 frames each)
-  int64_t blocks = (int64_t)dev_props().cu_count * occ;
-  const int64_t need = (n_tiles + 3) / 4;
+  // persistent grid: ONE 12-wave workgroup per CU; each owns a contiguous run of tiles (6 frames
+  // each) that its waves claim dynamically
+  int64_t blocks = dev_props().cu_count;
+  const int64_t need = (n_tiles + wpb - 1) / wpb;
   if (blocks > need) blocks = need;
   if (blocks >= 8) blocks -= blocks % 8;  // XCD remap wants a multiple of 8
   if (blocks < 1) blocks = 1;
-  const int tiles_per_wave = (int)((n_tiles + blocks * 4 - 1) / (blocks * 4));
-  hipLaunchKernelGGL(m400::melspec400_kernel, dim3((unsigned)blocks), dim3(256), lds, s, wav, window,
+  const int tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
+  // 16-B paths: LDS-DMA staging of the waveform, dwordx4 stores of the mel rows
+  const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (g.row_stride % 4 == 0);
+  const int out_wide = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (mb.n_mels % 4 == 0);
+  hipLaunchKernelGGL(m400::melspec400_kernel<0>, dim3((unsigned)blocks), dim3(64 * wpb), lds, s, wav, window,
                      twiddle, mb, out, g.rows, g.length, g.row_stride, g.n_frames, g.scale,
-                     tiles_per_row, n_tiles, tiles_per_wave);
+                     tiles_per_row, n_tiles, tiles_per_block, in_aligned, out_wide);
   return launch_check();
 }
 

@@ -18,7 +18,11 @@
 //   * |A|^2, |B|^2 for k = 0..200 go to LDS interleaved as float2 (a, b) per bin;
 //   * mel = banded reduction over that LDS power spectrum: lane (pair, slot) owns mels
 //     slot + 20 r for BOTH frames of the pair; the band table (even-aligned band starts, zero
-//     padded weights) lives in LDS, read as b64 (2 weights) + b128 (2 bins x 2 frames).
+//     padded weights) lives in LDS, read as b64 (2 weights) + b128 (2 bins x 2 frames);
+//   * HBM traffic is all 16 B per lane: the waveform tile (1200 contiguous samples) is copied
+//     global -> LDS by LDS-DMA one tile ahead (no VGPR round trip, overlaps the second half of
+//     the previous tile), and the tile's 6 x n_mels outputs (contiguous in memory) leave through
+//     an LDS transposition as dwordx4 stores.
 //
 // Reference semantics: transforms/_transforms.py:612-622 (MelSpectrogram.forward),
 // functional/functional.py:112-145, torch/functional.py:675-681; framing is bit-exact
@@ -34,6 +38,8 @@ constexpr int kN = 400;
 constexpr int kHop = 160;
 constexpr int kPad = 200;
 constexpr int kFramesPerWave = 6;
+constexpr int kWavesPerBlock = 12;              // 768 threads = 3 waves per SIMD: ONE block per CU (a second block of a
+                                               // smaller size is not admitted: its waves land on the same SIMDs)
 // LDS strides picked with tools/lds_conflicts.py (bank model of MI355X_MICROARCH.md):
 constexpr int kTRow = 44;                      // dwords per transposition row: 20 complex + pad, 16-B aligned
                                                // rows -> conflict-free ds_read_b128; column writes 6 array
@@ -42,12 +48,16 @@ constexpr int kTPair = 20 * kTRow;             // 880 dwords per pair
 constexpr int kLdsDwordsPerWave = 3 * kTPair;  // 2640 dwords = 10560 B (the P rows alias it)
 constexpr int kPK = 212;                       // readable bins per P row: 201 + zeroed tail, even
 constexpr int kPPair = 448;                    // dwords per pair of P rows (>= 2 * kPK)
+constexpr int kSOff = 3 * kPPair;              // 1344: staging area for the NEXT tile's samples (LDS-DMA)
+constexpr int kSPieces = 320;                  // 16-B pieces: 1200 samples + 20 pad dwords per 320 samples
+constexpr int kTileSamples = (kFramesPerWave - 1) * kHop + kN;   // 1200
 constexpr int kMelSlots = 20;                  // mels per round
 constexpr int kMelMaxRounds = 8;               // n_mels <= 160
-constexpr int kMelMaxTaps = 64;                // widest padded band
+constexpr int kMelMaxTaps = 64;                // widest padded band (taps)
 
 static_assert(3 * kPPair <= kLdsDwordsPerWave && 2 * kPK <= kPPair, "P rows must fit in the transposition buffer");
 static_assert(3 * (kPK - 201) <= 64, "one lane per tail bin");
+static_assert(kSOff + 4 * kSPieces <= kLdsDwordsPerWave, "staging area must fit beside the P rows");
 
 // column held by the lane at position pi of a 20-lane group (pass 2), and its inverse:
 // positions (0,1) = columns (0,10), then (2j, 2j+1) = (j, 20-j): lane ^ 1 holds column 20 - c.
@@ -59,71 +69,100 @@ AAMD_HD constexpr int pos_of_col(int c) {
 }
 
 // ---- banded filterbank in LDS (built once per launch by every workgroup) ------------------
+//   Bands are processed in chunks of 4 taps = one b128 of weights + two b128 of P (2 bins x 2
+//   frames each), so band starts are floored to even bins and rows are zero padded.
 struct MelTab {
   const float* w;    // [n_mels][ws]: weight of bin lo2[m] + j, zero outside the band
   const int* lo2;    // [n_mels]: even band start (<= first non-zero bin)
-  const int* rw2;    // [n_rounds]: even tap count of the round (wave-uniform trip count)
+  const int* rc;     // [n_rounds]: 4-tap chunks of the round (wave-uniform trip count)
   int n_mels, ws, n_rounds;
 };
 
 AAMD_HD int mel_rounds(int n_mels) { return (n_mels + kMelSlots - 1) / kMelSlots; }
-// row stride: covers the widest even-aligned band, = 2 mod 4 (b64 rows of 20 mels hit distinct banks)
+// row stride: covers the widest even-aligned band rounded up to 4 taps; ws / 4 odd so that the
+// b128 reads of 16 different rows hit 16 different 4-bank slots
 AAMD_HD int mel_ws(int max_width) {
-  const int w2 = (max_width + 2) & ~1;
-  return (w2 & 3) == 0 ? w2 + 2 : w2;
+  const int w4 = (max_width + 1 + 3) & ~3;
+  return ((w4 >> 2) & 1) ? w4 : w4 + 4;
 }
 AAMD_HD int mel_tab_dwords(int n_mels, int max_width) {
   return n_mels * mel_ws(max_width) + n_mels + kMelMaxRounds;
 }
 
-AAMD_HD void mel_tab_build(int tid, int nthr, const MelBandsDev& mb, float* base, MelTab& mt) {
+// phase 1 (then a workgroup barrier): per-round chunk counts; phase 2: weights and band starts
+AAMD_HD void mel_tab_rounds(int tid, int nthr, const MelBandsDev& mb, float* base, MelTab& mt) {
   mt.n_mels = mb.n_mels;
   mt.ws = mel_ws(mb.max_width);
   mt.n_rounds = mel_rounds(mb.n_mels);
-  float* w = base;
+  mt.w = base;
   int* lo2 = reinterpret_cast<int*>(base + mb.n_mels * mt.ws);
-  int* rw2 = lo2 + mb.n_mels;
-  // every thread derives the per-round tap counts it needs (n_mels is small)
-  for (int i = tid; i < mb.n_mels * mt.ws; i += nthr) {
-    const int m = i / mt.ws, j = i - m * mt.ws;
-    const int r = m / kMelSlots;
-    int rw = 0;
+  int* rc = lo2 + mb.n_mels;
+  mt.lo2 = lo2;
+  mt.rc = rc;
+  for (int r = tid; r < mt.n_rounds; r += nthr) {
+    int rw = 4;
     for (int q = r * kMelSlots; q < (r + 1) * kMelSlots && q < mb.n_mels; ++q) {
-      const int e = (mb.width[q] + (mb.lo[q] & 1) + 1) & ~1;
+      const int e = (mb.width[q] + (mb.lo[q] & 1) + 3) & ~3;
       rw = e > rw ? e : rw;
     }
-    int l2 = mb.lo[m] & ~1;
-    if (l2 + rw > kPK) l2 = kPK - rw;
-    const int off = mb.lo[m] - l2;
-    w[i] = (j >= off && j - off < mb.width[m]) ? mb.weights[m * mb.max_width + (j - off)] : 0.0f;
-    if (j == 0) lo2[m] = l2;
-    if (j == 0 && m == r * kMelSlots) rw2[r] = rw;
+    rc[r] = rw >> 2;
   }
-  mt.w = w; mt.lo2 = lo2; mt.rw2 = rw2;
+}
+
+AAMD_HD void mel_tab_fill(int tid, int nthr, const MelBandsDev& mb, float* base, const MelTab& mt) {
+  float* w = base;
+  int* lo2 = reinterpret_cast<int*>(base + mb.n_mels * mt.ws);
+  for (int i = tid; i < mb.n_mels * mt.ws; i += nthr) {
+    const int m = i / mt.ws, j = i - m * mt.ws;
+    const int rw = 4 * mt.rc[m / kMelSlots];
+    const int lo = mb.lo[m], wd = mb.width[m];
+    int l2 = lo & ~1;
+    if (l2 + rw > kPK) l2 = kPK - rw;
+    const int off = lo - l2;
+    w[i] = (j >= off && j - off < wd) ? mb.weights[m * mb.max_width + (j - off)] : 0.0f;
+    if (j == 0) lo2[m] = l2;
+  }
+}
+
+// Per-workgroup constant tables in LDS (re-read every tile: 15 b128 reads per lane instead of
+// 58 live registers -> one more wave per SIMD):
+//   twiddles  [20 b][44]: W400^(b c) as (re, im) pairs, c = 0..19, row padded to 44 dwords
+//   window    [20 b][20]: 0.5 * scale * window[b + 20 q]
+constexpr int kTwRow = 44;
+constexpr int kConstDwords = 20 * kTwRow + 20 * 20;   // 1280
+
+AAMD_HD void const_tab_build(int tid, int nthr, const float* window, const float* tw400, float scale,
+                             float* base) {
+  for (int i = tid; i < 20 * 20; i += nthr) {
+    const int b = i / 20, s = i - 20 * b;
+    const int idx = (b * s) % kN;
+    base[kTwRow * b + 2 * s] = tw400[2 * idx];
+    base[kTwRow * b + 2 * s + 1] = tw400[2 * idx + 1];
+    base[20 * kTwRow + i] = window[b + 20 * s] * (0.5f * scale);   // (b, q = s)
+  }
+}
+
+// dynamic LDS of one workgroup: per-wave regions, constant tables, mel table, tile queue
+AAMD_HD size_t lds_bytes(int n_mels, int max_width) {
+  return ((size_t)kWavesPerBlock * kLdsDwordsPerWave + kConstDwords + mel_tab_dwords(n_mels, max_width) + 4) *
+         sizeof(float);
 }
 
 struct LaneConst {
-  float twr[19], twi[19];  // W400^(b*c), c = 1..19 (pass-1 role b = pi)
-  float win[20];           // 0.5 * scale * window[b + 20 q]
+  const float* tw;         // this lane's twiddle row (pass-1 role b = pi)
+  const float* win;        // this lane's window row
   int p, pi, col;          // pair 0..2, position in the 20-lane group, pass-2 column
   int active;              // lanes 60..63 shadow lanes 40..43 but never store
 };
 
-AAMD_HD void lane_init(int lane, const float* window, const float* tw400, float scale,
-                       LaneConst& c) {
+AAMD_HD void lane_init(int lane, const float* const_tab, LaneConst& c) {
   c.active = lane < 60;
   const int l = c.active ? lane : lane - 20;
   c.p = l / 20;
   c.pi = l - 20 * c.p;
   c.col = col_of_pos(c.pi);
-#pragma unroll
-  for (int s = 1; s < 20; ++s) {
-    const int idx = (c.pi * s) % kN;
-    c.twr[s - 1] = tw400[2 * idx];
-    c.twi[s - 1] = tw400[2 * idx + 1];
-  }
-#pragma unroll
-  for (int q = 0; q < 20; ++q) c.win[q] = window[c.pi + 20 * q] * (0.5f * scale);
+  c.tw = const_tab + kTwRow * c.pi;
+  c.win = const_tab + 20 * kTwRow + 20 * c.pi;
 }
 
 // ---- in-register DFT-20, forward (e^{-2 pi i nk/20}), natural order in and out -----------
@@ -187,54 +226,75 @@ AAMD_HD int64_t reflect_idx(int64_t i, int64_t len) {
 }
 
 // ---- phase A: gather + window + DFT-20 over q + twiddle + transposed LDS write ----------
-//   lane (p, b) owns samples n = b + 20 q of frames a = t0 + 2p and a + 1; the 28 fetched
+//   lane (p, b) owns samples n = b + 20 q of frames a = t0 + 2p and a + 1; the 28 gathered
 //   samples X[q] sit at signal index a*160 - 200 + b + 20 q: frame a uses X[0..19], frame
 //   a + 1 uses X[8..27].
-template <bool EDGE>
-AAMD_HD void phase_a(const LaneConst& c, const float* wav_row, int64_t length, int64_t t0,
-                     int n_frames, float* lds) {
-  float X[28];
+//
+// Staged tiles: the tile's 1200 contiguous samples were copied global -> LDS by LDS-DMA
+// (coalesced 16-B pieces, issued one tile ahead); sample i of the tile lives at staging dword
+// i + 20 * (i / 320): the 20-dword pad per 320 samples moves the three pairs' rows onto disjoint
+// banks, so the strided gather below is conflict free.
+AAMD_HD int stage_src_piece(int u) {   // staging piece u (16 B) <- tile piece (4 samples)
+  const int blk = u / 85, r = u - 85 * blk;
+  const int s = 80 * blk + (r < 80 ? r : 79);
+  return s < kTileSamples / 4 ? s : kTileSamples / 4 - 1;
+}
+
+AAMD_HD void gather_lds(const LaneConst& c, const float* S, float (&X)[28]) {
+  const float* src = S + 340 * c.p + c.pi;
+#pragma unroll
+  for (int q = 0; q < 28; ++q) X[q] = src[20 * q + (q >= 16 ? 20 : 0)];
+}
+
+// Unstaged tiles (clip edges: reflect padding; or inputs that are not 16-B aligned): direct loads.
+AAMD_HD void gather_global(const LaneConst& c, const float* wav_row, int64_t length, int64_t t0,
+                           int n_frames, float (&X)[28]) {
   const int64_t ta = t0 + 2 * c.p;
   const int64_t i0 = ta * kHop - kPad + c.pi;
-  if (!EDGE) {
-    const float* src = wav_row + i0;
 #pragma unroll
-    for (int q = 0; q < 28; ++q) X[q] = src[20 * q];
-  } else {
+  for (int q = 0; q < 28; ++q) {
+    const int64_t i = i0 + 20 * q;
+    // q < 20 belongs to frame a (and to a + 1 when q >= 8); q >= 20 only to frame a + 1
+    const bool need = (q < 20) ? (ta < n_frames) : (ta + 1 < n_frames);
+    X[q] = need ? wav_row[reflect_idx(i, length)] : 0.0f;
+  }
+}
+
+AAMD_HD void phase_a(const LaneConst& c, const float (&X)[28], bool vb, float* lds) {
+  float xr[20], xi[20], yr[20], yi[20];
 #pragma unroll
-    for (int q = 0; q < 28; ++q) {
-      const int64_t i = i0 + 20 * q;
-      // q < 20 belongs to frame a (and to a + 1 when q >= 8); q >= 20 only to frame a + 1
-      const bool need = (q < 20) ? (ta < n_frames) : (ta + 1 < n_frames);
-      X[q] = need ? wav_row[reflect_idx(i, length)] : 0.0f;
+  for (int q4 = 0; q4 < 5; ++q4) {
+    const F4 w = *reinterpret_cast<const F4*>(c.win + 4 * q4);
+    const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = 4 * q4 + e;
+      xr[q] = X[q] * wv[e];
+      xi[q] = vb ? X[q + 8] * wv[e] : 0.0f;
     }
   }
-  float xr[20], xi[20], yr[20], yi[20];
-  const bool vb = !EDGE || (ta + 1 < n_frames);
-#pragma unroll
-  for (int q = 0; q < 20; ++q) {
-    xr[q] = X[q] * c.win[q];
-    xi[q] = vb ? X[q + 8] * c.win[q] : 0.0f;
-  }
   dft20(xr, xi, yr, yi);
-  if (c.active) {
-    float* colp = lds + kTPair * c.p + 2 * c.pi;
+  float* colp = lds + kTPair * c.p + 2 * c.pi;
 #pragma unroll
-    for (int s = 0; s < 20; ++s) {
-      float vr = yr[s], vi = yi[s];
-      if (s != 0) {
-        const float wr = c.twr[s - 1], wi = c.twi[s - 1];
-        vr = yr[s] * wr - yi[s] * wi;
-        vi = yr[s] * wi + yi[s] * wr;
-      }
-      *reinterpret_cast<F2*>(colp + kTRow * pos_of_col(s)) = F2{vr, vi};
+  for (int s2 = 0; s2 < 10; ++s2) {
+    const F4 t = *reinterpret_cast<const F4*>(c.tw + 4 * s2);   // W^(b * 2 s2), W^(b * (2 s2 + 1))
+    const int s = 2 * s2;
+    float v0r = yr[s], v0i = yi[s];
+    if (s != 0) {
+      v0r = yr[s] * t.x - yi[s] * t.y;
+      v0i = yr[s] * t.y + yi[s] * t.x;
+    }
+    const float v1r = yr[s + 1] * t.z - yi[s + 1] * t.w;
+    const float v1i = yr[s + 1] * t.w + yi[s + 1] * t.z;
+    if (c.active) {
+      *reinterpret_cast<F2*>(colp + kTRow * pos_of_col(s)) = F2{v0r, v0i};
+      *reinterpret_cast<F2*>(colp + kTRow * pos_of_col(s + 1)) = F2{v1r, v1i};
     }
   }
 }
 
-// ---- phase B1: read own row, DFT-20 over b  ->  Z[col + 20 d] in registers ----------------
-AAMD_HD void phase_b1(const LaneConst& c, const float* lds, float (&zr)[20], float (&zi)[20]) {
-  float vr[20], vi[20];
+// ---- phase B1: read own row (then DFT-20 over b  ->  Z[col + 20 d] in registers) ----------
+AAMD_HD void phase_b1_load(const LaneConst& c, const float* lds, float (&vr)[20], float (&vi)[20]) {
   const float* row = lds + kTPair * c.p + kTRow * c.pi;
 #pragma unroll
   for (int j = 0; j < 10; ++j) {
@@ -244,7 +304,6 @@ AAMD_HD void phase_b1(const LaneConst& c, const float* lds, float (&zr)[20], flo
     vr[2 * j + 1] = v.z;
     vi[2 * j + 1] = v.w;
   }
-  dft20(vr, vi, zr, zi);
 }
 
 // ---- phase B2a: the values the neighbour lane (lane ^ 1) needs: q[i] = Z-register 10 + i,
@@ -298,42 +357,105 @@ AAMD_HD void phase_b2_pad(int lane, float* lds) {
 }
 
 // ---- phase C: banded mel reduction from the LDS power rows --------------------------------
-//   lane (p, slot) computes mel m = slot + 20 r of frames 2p and 2p + 1 in round r; the tap
-//   count rw2[r] is wave-uniform.
-AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds, float* out_row,
-                     int64_t t0, int n_frames) {
+//   lane (p, slot) computes mel m = slot + 20 r of frames 2p and 2p + 1 in round r; the chunk
+//   count rc[r] is wave-uniform.  All LDS reads of a round are issued before its FMAs.
+template <int NC>
+AAMD_HD void mel_chunks(const float* wt, const float* P, float& sa, float& sb) {
+  F4 w[NC], q0[NC], q1[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    w[k] = *reinterpret_cast<const F4*>(wt + 4 * k);
+    q0[k] = *reinterpret_cast<const F4*>(P + 8 * k);       // (a, b) of bins 4k, 4k + 1
+    q1[k] = *reinterpret_cast<const F4*>(P + 8 * k + 4);   // (a, b) of bins 4k + 2, 4k + 3
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    sa += w[k].x * q0[k].x;
+    sb += w[k].x * q0[k].y;
+    sa += w[k].y * q0[k].z;
+    sb += w[k].y * q0[k].w;
+    sa += w[k].z * q1[k].x;
+    sb += w[k].z * q1[k].y;
+    sa += w[k].w * q1[k].z;
+    sb += w[k].w * q1[k].w;
+  }
+}
+
+AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
+                     float (&acc_a)[kMelMaxRounds], float (&acc_b)[kMelMaxRounds]) {
+  const float* Pp = lds + kPPair * c.p;
+#pragma unroll
+  for (int r = 0; r < kMelMaxRounds; ++r) {
+    float sa = 0.0f, sb = 0.0f;
+    if (r < mt.n_rounds) {
+      const int m = r * kMelSlots + c.pi;
+      const int mm = m < mt.n_mels ? m : 0;
+      const float* wt = mt.w + mm * mt.ws;
+      const float* P = Pp + 2 * mt.lo2[mm];
+      const int nc = mt.rc[r];
+      switch (nc) {
+        case 1: mel_chunks<1>(wt, P, sa, sb); break;
+        case 2: mel_chunks<2>(wt, P, sa, sb); break;
+        case 3: mel_chunks<3>(wt, P, sa, sb); break;
+        case 4: mel_chunks<4>(wt, P, sa, sb); break;
+        default:
+          for (int k = 0; k < nc; ++k) mel_chunks<1>(wt + 4 * k, P + 8 * k, sa, sb);
+      }
+    }
+    acc_a[r] = sa;
+    acc_b[r] = sb;
+  }
+}
+
+// narrow store path (any n_mels / alignment): 4-byte stores straight from the accumulators
+AAMD_HD void store_direct(const LaneConst& c, const MelTab& mt, const float (&acc_a)[kMelMaxRounds],
+                          const float (&acc_b)[kMelMaxRounds], float* out_row, int64_t t0, int n_frames) {
   const int64_t ta = t0 + 2 * c.p;
   const bool va = c.active && ta < n_frames, vb = c.active && ta + 1 < n_frames;
-  const float* Pp = lds + kPPair * c.p;
   float* oa = out_row + ta * (int64_t)mt.n_mels;
-  for (int r = 0; r < mt.n_rounds; ++r) {
+#pragma unroll
+  for (int r = 0; r < kMelMaxRounds; ++r) {
     const int m = r * kMelSlots + c.pi;
-    const bool ok = m < mt.n_mels;
-    const int mm = ok ? m : 0;
-    const float* wt = mt.w + mm * mt.ws;
-    const float* P = Pp + 2 * mt.lo2[mm];
-    const int n2 = mt.rw2[r];
-    float acc_a = 0.0f, acc_b = 0.0f;
-    for (int j = 0; j < n2; j += 2) {
-      const F2 w = *reinterpret_cast<const F2*>(wt + j);
-      const F4 q = *reinterpret_cast<const F4*>(P + 2 * j);   // (a, b) of bins j, j + 1
-      acc_a += w.x * q.x;
-      acc_b += w.x * q.y;
-      acc_a += w.y * q.z;
-      acc_b += w.y * q.w;
+    if (r < mt.n_rounds && m < mt.n_mels) {
+      if (va) oa[m] = acc_a[r];
+      if (vb) oa[mt.n_mels + m] = acc_b[r];
     }
-    if (ok && va) oa[m] = acc_a;
-    if (ok && vb) oa[mt.n_mels + m] = acc_b;
   }
+}
+
+// wide store path (n_mels % 4 == 0, 16-B aligned output): the tile's 6 x n_mels outputs are
+// contiguous in memory; stage them in LDS (over the dead P rows) and write 16 B per lane.
+AAMD_HD void store_stage(const LaneConst& c, const MelTab& mt, const float (&acc_a)[kMelMaxRounds],
+                         const float (&acc_b)[kMelMaxRounds], float* lds) {
+  if (!c.active) return;
+  float* oa = lds + 2 * c.p * mt.n_mels;
+#pragma unroll
+  for (int r = 0; r < kMelMaxRounds; ++r) {
+    const int m = r * kMelSlots + c.pi;
+    if (r < mt.n_rounds && m < mt.n_mels) {
+      oa[m] = acc_a[r];
+      oa[mt.n_mels + m] = acc_b[r];
+    }
+  }
+}
+
+AAMD_HD void store_wide(int lane, const MelTab& mt, const float* lds, float* out_row, int64_t t0,
+                        int n_frames) {
+  const int64_t left = n_frames - t0;
+  const int n_valid = left < kFramesPerWave ? (int)left : kFramesPerWave;
+  const int pieces = n_valid * mt.n_mels / 4;
+  float* dst = out_row + t0 * (int64_t)mt.n_mels;
+  for (int j = lane; j < pieces; j += 64)
+    *reinterpret_cast<F4*>(dst + 4 * j) = *reinterpret_cast<const F4*>(lds + 4 * j);
 }
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ void wave_lds_fence() {
-  // LDS ops of one wave execute in order; this only stops the compiler from moving
-  // LDS accesses across the hand-off between lanes.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // Hand-off between lanes of ONE wave through LDS.  The hardware executes a wave's LDS
+  // instructions in order, so no s_waitcnt is needed between the writes and the dependent
+  // reads; this only stops the COMPILER from moving LDS accesses across the hand-off
+  // (a release/acquire fence would also drain vmcnt/lgkmcnt and stall the wave 6x per tile).
+  asm volatile("" ::: "memory");
 }
 
 // value of lane ^ 1 (DPP quad_perm [1,0,3,2]): a VALU move, no LDS traffic
@@ -342,47 +464,130 @@ __device__ __forceinline__ float swap_adjacent(float v) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-__global__ void __launch_bounds__(256, 2)
+// LDS-DMA of one 16-B piece per lane: 64 lanes fill 1 KiB at LDS byte address `lds_dst`
+// (wave-uniform).  hipcc does not count this load: the consumer waits with stage_wait().
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+__device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+struct TileInfo {
+  int64_t row, t0;
+  bool staged;   // fully inside the clip and 16-B aligned: gathered through the LDS staging area
+};
+
+// LAB != 0 builds profiling variants for tools/ubench/mel400_lab.hip (wrong results by design):
+//   bit 0: no wait for the staged tile   bit 1: no global stores   bit 2: no phase C
+//   bit 3: no LDS-DMA issue              bit 4: no phase B (second DFT, separation, P rows)
+template <int LAB>
+__global__ void __launch_bounds__(64 * kWavesPerBlock, 3)
 melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ window,
                   const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
                   int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
-                  int tiles_per_row, int64_t n_tiles, int tiles_per_wave) {
+                  int tiles_per_row, int64_t n_tiles, int tiles_per_block, int in_aligned,
+                  int out_wide) {
   extern __shared__ __attribute__((aligned(16))) float smem400[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  long long lab_t0 = 0;
+  if (LAB & 1024) lab_t0 = wall_clock64();
   float* lds = smem400 + wave * kLdsDwordsPerWave;
+  const unsigned s_addr = (unsigned)(uintptr_t)(lds + kSOff);   // LDS byte address of the staging area
 
+  float* const_tab = smem400 + kWavesPerBlock * kLdsDwordsPerWave;
+  const_tab_build(threadIdx.x, blockDim.x, window, tw400, scale, const_tab);
   MelTab mt;
-  mel_tab_build(threadIdx.x, blockDim.x, mb, smem400 + 4 * kLdsDwordsPerWave, mt);
+  mel_tab_rounds(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
+  // tile queue of this workgroup: the next unclaimed tile (waves start on tiles 0 .. W-1)
+  int* queue = reinterpret_cast<int*>(const_tab + kConstDwords + mel_tab_dwords(mb.n_mels, mb.max_width));
+  if (threadIdx.x == 0) *queue = kWavesPerBlock;
+  __syncthreads();
+  mel_tab_fill(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
   __syncthreads();
 
+  long long lab_t1 = 0;
+  if (LAB & 1024) lab_t1 = wall_clock64();
   LaneConst c;
-  lane_init(lane, window, tw400, scale, c);
+  lane_init(lane, const_tab, c);
+  int spiece[5];   // tile piece fetched by this lane in DMA instruction k
+#pragma unroll
+  for (int k = 0; k < 5; ++k) spiece[k] = 4 * stage_src_piece(64 * k + lane);
 
   // XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
   // range of tiles so the frame-overlap re-reads stay inside one L2.
   const int nb = gridDim.x;
   int lb = blockIdx.x;
   if ((nb & 7) == 0) lb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
-  const int64_t first = ((int64_t)lb * 4 + wave) * tiles_per_wave;
-  int64_t last = first + tiles_per_wave;
-  if (last > n_tiles) last = n_tiles;
+  // this workgroup's run of tiles; its waves claim them one at a time from the LDS queue, so a
+  // wave that the scheduler favours simply takes more tiles (static shares left 40 % idle tails)
+  const unsigned blk_first = (unsigned)lb * (unsigned)tiles_per_block;
+  unsigned blk_count = 0;
+  if (blk_first < (unsigned)n_tiles) {
+    blk_count = (unsigned)n_tiles - blk_first;
+    if (blk_count > (unsigned)tiles_per_block) blk_count = (unsigned)tiles_per_block;
+  }
+  auto claim = [&]() {   // wave-uniform
+    int v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (unsigned)__builtin_amdgcn_readfirstlane(v);
+  };
 
-  // (row, tile-in-row) advance incrementally: one division per wave, none per tile
-  int64_t row = first / tiles_per_row;
-  int tir = (int)(first - row * tiles_per_row);
-  for (int64_t tile = first; tile < last; ++tile, ++tir) {
-    if (tir == tiles_per_row) { tir = 0; ++row; }
-    const int64_t t0 = (int64_t)tir * kFramesPerWave;
-    const float* wav_row = wav + row * row_stride;
-    const bool interior = (t0 * kHop - kPad >= 0) &&
-                          ((t0 + kFramesPerWave - 1) * kHop + (kN - kPad) <= length) &&
-                          (t0 + kFramesPerWave <= n_frames);
-    if (interior) phase_a<false>(c, wav_row, length, t0, n_frames, lds);
-    else          phase_a<true>(c, wav_row, length, t0, n_frames, lds);
+  auto tile_info = [&](unsigned idx) {
+    TileInfo ti;
+    const unsigned t = blk_first + idx;
+    const unsigned row = t / (unsigned)tiles_per_row;
+    ti.row = row;
+    ti.t0 = (int64_t)(t - row * (unsigned)tiles_per_row) * kFramesPerWave;
+    ti.staged = idx < blk_count && in_aligned && (ti.t0 * kHop - kPad >= 0) &&
+                ((ti.t0 + kFramesPerWave - 1) * kHop + (kN - kPad) <= length) &&
+                (ti.t0 + kFramesPerWave <= n_frames);
+    return ti;
+  };
+  auto stage_issue = [&](const TileInfo& ti) {
+    const float* src = wav + ti.row * row_stride + (ti.t0 * kHop - kPad);
+    if (LAB & 32) src = wav + 6 * kHop;                 // lab: always the same (cache-resident) tile
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+      if (!(LAB & 64) || k == 0) glds16(src + spiece[k], s_addr + 1024 * k);   // lab bit 6: one piece only
+  };
+
+  unsigned cur_idx = (unsigned)wave;
+  TileInfo cur = tile_info(cur_idx);
+  if (LAB & 128) {   // lab: stagger the waves of a SIMD by thirds of a tile time
+    const int k = (wave + 6 * lb) % 3;
+    for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(112);
+  }
+  if (cur.staged && !(LAB & 8)) stage_issue(cur);
+
+  while (cur_idx < blk_count) {
+    // claim the tile after this one now: it is prefetched while this one is in its second half
+    const unsigned nxt_idx = claim();
+    TileInfo nxt = tile_info(nxt_idx);
+
+    float X[28];
+    if (cur.staged) {
+      if (!(LAB & 1)) stage_wait();
+      if (LAB & 256) {   // lab: no gather (samples from a register expression)
+#pragma unroll
+        for (int q = 0; q < 28; ++q) X[q] = (float)(q + lane) * scale;
+      } else {
+        gather_lds(c, lds + kSOff, X);
+      }
+    } else {
+      gather_global(c, wav + cur.row * row_stride, length, cur.t0, n_frames, X);
+    }
+    phase_a(c, X, cur.staged || (cur.t0 + 2 * c.p + 1 < n_frames), lds);
     wave_lds_fence();
-    float zr[20], zi[20], qr[10], qi[10], gr[10], gi[10];
-    phase_b1(c, lds, zr, zi);
+    float vr[20], vi[20], zr[20], zi[20], qr[10], qi[10], gr[10], gi[10];
+    phase_b1_load(c, lds, vr, vi);
+    // every transposition row has been read: the staging area (it aliases rows) is free again
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (nxt.staged && !(LAB & 8)) stage_issue(nxt);
+    if (LAB & 16) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
+    dft20(vr, vi, zr, zi);
     phase_b2_send(c, zr, zi, qr, qi);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
@@ -393,8 +598,28 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     phase_b2(c, zr, zi, qr, qi, gr, gi, lds);
     phase_b2_pad(lane, lds);
     wave_lds_fence();
-    phase_c(c, mt, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
+    float acc_a[kMelMaxRounds], acc_b[kMelMaxRounds];
+    if (LAB & 4) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
+    phase_c(c, mt, lds, acc_a, acc_b);
+    float* out_row = out + cur.row * n_frames * (int64_t)mb.n_mels;
+    if (out_wide) {
+      wave_lds_fence();
+      store_stage(c, mt, acc_a, acc_b, lds);
+      wave_lds_fence();
+      if (!(LAB & 2)) store_wide(lane, mt, lds, out_row, cur.t0, n_frames);
+    } else {
+      if (!(LAB & 2)) store_direct(c, mt, acc_a, acc_b, out_row, cur.t0, n_frames);
+    }
     wave_lds_fence();
+    cur = nxt;
+    cur_idx = nxt_idx;
+  }
+  if ((LAB & 1024) && lane == 0) {   // lab census: per-wave entry / tables ready / done (100 MHz clock)
+    long long* rec = reinterpret_cast<long long*>(const_cast<float*>(tw400) + 1024);
+    const int w = blockIdx.x * kWavesPerBlock + wave;
+    rec[3 * w] = lab_t0;
+    rec[3 * w + 1] = lab_t1;
+    rec[3 * w + 2] = wall_clock64();
   }
 }
 #endif  // __HIPCC__

@@ -63,34 +63,65 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
 
 int sim_melspec400(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
                    float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale) {
+  using namespace m400;
   MelBandsDev mb{bands->n_mels, bands->max_width, bands->lo, bands->width, bands->weights};
-  if (mb.max_width + 2 > m400::kMelMaxTaps || m400::mel_rounds(mb.n_mels) > m400::kMelMaxRounds) return -2;
-  alignas(16) static float lds[m400::kLdsDwordsPerWave];
-  alignas(16) static float tab[m400::kMelMaxRounds * m400::kMelSlots * (m400::kMelMaxTaps + 2) + 256];
-  m400::MelTab mt;
-  for (int tid = 0; tid < 256; ++tid) m400::mel_tab_build(tid, 256, mb, tab, mt);
-  m400::LaneConst c[64];
-  for (int l = 0; l < 64; ++l) m400::lane_init(l, window, tw400, scale, c[l]);
-  const int tiles_per_row = (n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
-  static float zr[64][20], zi[64][20], qr[64][10], qi[64][10];
-  for (int64_t row = 0; row < rows; ++row)
-    for (int tl = 0; tl < tiles_per_row; ++tl) {
-      const int64_t t0 = (int64_t)tl * m400::kFramesPerWave;
-      const float* wr = wav + row * row_stride;
-      const bool interior = (t0 * m400::kHop - m400::kPad >= 0) &&
-                            ((t0 + m400::kFramesPerWave - 1) * m400::kHop + (m400::kN - m400::kPad) <= length) &&
-                            (t0 + m400::kFramesPerWave <= n_frames);
-      for (int l = 0; l < 64; ++l) {
-        if (interior) m400::phase_a<false>(c[l], wr, length, t0, n_frames, lds);
-        else m400::phase_a<true>(c[l], wr, length, t0, n_frames, lds);
-      }
-      for (int l = 0; l < 64; ++l) m400::phase_b1(c[l], lds, zr[l], zi[l]);
-      for (int l = 0; l < 64; ++l) m400::phase_b2_send(c[l], zr[l], zi[l], qr[l], qi[l]);
-      // the DPP quad_perm [1,0,3,2] swap: lane l receives lane l ^ 1's q
-      for (int l = 0; l < 64; ++l) m400::phase_b2(c[l], zr[l], zi[l], qr[l], qi[l], qr[l ^ 1], qi[l ^ 1], lds);
-      for (int l = 0; l < 64; ++l) m400::phase_b2_pad(l, lds);
-      for (int l = 0; l < 64; ++l) m400::phase_c(c[l], mt, lds, out + row * n_frames * (int64_t)mb.n_mels, t0, n_frames);
+  if (mel_ws(mb.max_width) > kMelMaxTaps + 4 || mel_rounds(mb.n_mels) > kMelMaxRounds) return -2;
+  alignas(16) static float lds[kLdsDwordsPerWave];
+  alignas(16) static float tab[kMelMaxRounds * kMelSlots * (kMelMaxTaps + 4) + 256];
+  alignas(16) static float ctab[kConstDwords];
+  for (int tid = 0; tid < 256; ++tid) const_tab_build(tid, 256, window, tw400, scale, ctab);
+  MelTab mt;
+  for (int tid = 0; tid < 256; ++tid) mel_tab_rounds(tid, 256, mb, tab, mt);
+  for (int tid = 0; tid < 256; ++tid) mel_tab_fill(tid, 256, mb, tab, mt);
+  LaneConst c[64];
+  for (int l = 0; l < 64; ++l) lane_init(l, ctab, c[l]);
+  const int tiles_per_row = (n_frames + kFramesPerWave - 1) / kFramesPerWave;
+  // same launch-time switches as launch_mel400() in c_api.hip
+  const bool in_aligned = (row_stride % 4 == 0);
+  const bool out_wide = (mb.n_mels % 4 == 0);
+  static float X[64][28], vr[64][20], vi[64][20], zr[64][20], zi[64][20], qr[64][10], qi[64][10];
+  static float acc_a[64][kMelMaxRounds], acc_b[64][kMelMaxRounds];
+  auto staged = [&](int64_t t0) {
+    return in_aligned && (t0 * kHop - kPad >= 0) && ((t0 + kFramesPerWave - 1) * kHop + (kN - kPad) <= length) &&
+           (t0 + kFramesPerWave <= n_frames);
+  };
+  // what the 5 LDS-DMA instructions of stage_issue() do: staging piece u <- tile piece stage_src_piece(u)
+  auto stage = [&](int64_t row, int64_t t0) {
+    const float* src = wav + row * row_stride + (t0 * kHop - kPad);
+    for (int u = 0; u < kSPieces; ++u)
+      for (int e = 0; e < 4; ++e) lds[kSOff + 4 * u + e] = src[4 * stage_src_piece(u) + e];
+  };
+  // one wave walks all tiles in order, exactly like the kernel's tile loop
+  const int64_t n_tiles = rows * tiles_per_row;
+  bool cur_staged = n_tiles > 0 && staged(0);
+  if (cur_staged) stage(0, 0);
+  for (int64_t tile = 0; tile < n_tiles; ++tile) {
+    const int64_t row = tile / tiles_per_row, t0 = (tile % tiles_per_row) * kFramesPerWave;
+    const int64_t nrow = (tile + 1) / tiles_per_row, nt0 = ((tile + 1) % tiles_per_row) * kFramesPerWave;
+    const bool nxt_staged = (tile + 1 < n_tiles) && staged(nt0);
+    const float* wr = wav + row * row_stride;
+    for (int l = 0; l < 64; ++l) {
+      if (cur_staged) gather_lds(c[l], lds + kSOff, X[l]);
+      else gather_global(c[l], wr, length, t0, n_frames, X[l]);
     }
+    for (int l = 0; l < 64; ++l) phase_a(c[l], X[l], cur_staged || (t0 + 2 * c[l].p + 1 < n_frames), lds);
+    for (int l = 0; l < 64; ++l) phase_b1_load(c[l], lds, vr[l], vi[l]);
+    if (nxt_staged) stage(nrow, nt0);
+    for (int l = 0; l < 64; ++l) dft20(vr[l], vi[l], zr[l], zi[l]);
+    for (int l = 0; l < 64; ++l) phase_b2_send(c[l], zr[l], zi[l], qr[l], qi[l]);
+    // the DPP quad_perm [1,0,3,2] swap: lane l receives lane l ^ 1's q
+    for (int l = 0; l < 64; ++l) phase_b2(c[l], zr[l], zi[l], qr[l], qi[l], qr[l ^ 1], qi[l ^ 1], lds);
+    for (int l = 0; l < 64; ++l) phase_b2_pad(l, lds);
+    for (int l = 0; l < 64; ++l) phase_c(c[l], mt, lds, acc_a[l], acc_b[l]);
+    float* out_row = out + row * n_frames * (int64_t)mb.n_mels;
+    if (out_wide) {
+      for (int l = 0; l < 64; ++l) store_stage(c[l], mt, acc_a[l], acc_b[l], lds);
+      for (int l = 0; l < 64; ++l) store_wide(l, mt, lds, out_row, t0, n_frames);
+    } else {
+      for (int l = 0; l < 64; ++l) store_direct(c[l], mt, acc_a[l], acc_b[l], out_row, t0, n_frames);
+    }
+    cur_staged = nxt_staged;
+  }
   return 0;
 }
 

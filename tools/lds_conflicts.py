@@ -75,3 +75,40 @@ if __name__ == "__main__":
     print("b128 row reads, best (total, S, TP, W1, R1):", best[:8])
     bw = sorted((report(44, 880, PP)[2], PP) for PP in range(404, 480, 4))
     print("P pair stride, best (W2, PP):", bw[:8])
+
+
+def phase_c_report(PP, n_mels=80, verbose=False):
+    """P reads (b128) + weight reads (b64) of phase C for the HTK filterbank of the headline config."""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import warnings
+    from audio_amd import _host
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fb = _host.melscale_fbanks(201, 0.0, 8000.0, n_mels, 16000).numpy()
+    lo, width, _, maxw = _host.mel_band_table(fb)
+    ws = (maxw + 2) & ~1
+    ws = ws + 2 if ws % 4 == 0 else ws
+    nr = (n_mels + 19) // 20
+    tot_p = tot_w = ideal = 0
+    for r in range(nr):
+        ms = range(20 * r, min(20 * r + 20, n_mels))
+        rw = max(((width[m] + (lo[m] & 1) + 1) & ~1) for m in ms)
+        for j in range(0, rw, 2):
+            pa, wa = [], []
+            for _, act, p, pi in lanes():
+                m = 20 * r + pi
+                m = m if m < n_mels else 0
+                l2 = lo[m] & ~1
+                pa.append(PP * p + 2 * (l2 + j))
+                wa.append(10000 * 0 + m * ws + j)
+            tot_p += cycles("read_b128", pa)
+            tot_w += cycles("read_b64", wa)
+            ideal += 6
+    return tot_p, tot_w, ideal
+
+
+if __name__ == "__main__":
+    for PP in (424, 448, 432, 440, 456, 464, 472, 480, 488, 496):
+        w2 = report(44, 880, PP)[2]
+        print("PP", PP, "W2", w2, "phaseC (P b128, W b64, ideal P+W)", phase_c_report(PP))
