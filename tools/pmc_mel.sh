@@ -4,7 +4,7 @@
 #   bash tools/pmc_mel.sh <outdir> [groups-file, one counter group per line]
 R=$PWD
 OUT=${1:-gpurun_out/pmc}
-GROUPS_FILE=${2:-tools/pmc_groups_default.txt}
+GROUPS_FILE=$(realpath ${2:-tools/pmc_groups_default.txt})
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -12,6 +12,6 @@ while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $R/$OUT/p$i -o pmc -- python $R/tools/run_mel_once.py 4 > $R/$OUT/p$i.log 2>&1 || echo "pass $i failed: $grp"
-done < $R/$GROUPS_FILE
+done < $GROUPS_FILE
 cd $R
 python tools/pmc_summary.py $OUT melspec400
