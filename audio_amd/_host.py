@@ -195,3 +195,23 @@ def sinc_resample_kernel(orig_freq: int, new_freq: int, gcd: int, lowpass_filter
     if dtype is None:
         kern = kern.to(dtype=torch.float32)
     return kern, width
+
+
+def resample_band_table(kernel: np.ndarray, rel_threshold: float = 2.0 ** -40):
+    """Per tile of 16 consecutive phases: first tap and common span of the non-negligible taps of
+    the polyphase table ``kernel`` (new, taps).  A tap is negligible when ``|h| <= rel_threshold *
+    max|h|``; with 2^-40 the dropped taps of one output sum to < 1e-9 of a full-scale sample
+    (the kaiser/hann windows of functional.py:1378-1397 leave ~1e-20-sized tails outside
+    +-lowpass_filter_width zero crossings).  Returns (tap_lo int32[n_tiles], tap_span)."""
+    k = np.abs(np.asarray(kernel, dtype=np.float64))
+    new, taps = k.shape
+    thr = rel_threshold * (k.max() if k.size else 0.0)
+    n_tiles = (new + 15) // 16
+    lo = np.zeros(n_tiles, dtype=np.int32)
+    span = 1
+    for t in range(n_tiles):
+        cols = np.nonzero((k[16 * t: 16 * t + 16] > thr).any(axis=0))[0]
+        if cols.size:
+            lo[t] = cols[0]
+            span = max(span, int(cols[-1] - cols[0] + 1))
+    return lo, span

@@ -33,6 +33,10 @@ class MelBands(C.Structure):
     ]
 
 
+class ResampleBands(C.Structure):
+    _fields_ = [("n_tiles", C.c_int32), ("tap_span", C.c_int32), ("tap_lo", C.POINTER(C.c_int32))]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -43,6 +47,8 @@ _SIGS = {
     "aamd_device_info": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "aamd_spectrogram_f32": (C.c_int, [_P, _P, _P, _P, C.POINTER(StftDesc), _P]),
     "aamd_melspectrogram_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), _P]),
+    "aamd_melspectrogram_db_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.c_float,
+                                             C.c_float, C.c_float, _P, C.c_int64, _P]),
     "aamd_mel_scale_f32": (C.c_int, [_P, C.POINTER(MelBands), _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "aamd_amplitude_to_db_f32": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P]),
     "aamd_db_clamp_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_float, _P]),
@@ -50,6 +56,8 @@ _SIGS = {
                                     C.c_float, _P]),
     "aamd_resample_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int64, _P]),
+    "aamd_resample_banded_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_int64, C.POINTER(ResampleBands), _P]),
     "aamd_lfilter_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, _P]),
     "aamd_fftconvolve_workspace": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
@@ -76,7 +84,7 @@ def lib():
                 fn = getattr(h, name)   # AttributeError if the ABI symbol is missing
                 fn.restype = res
                 fn.argtypes = args
-            if h.aamd_abi_version() != 1:
+            if h.aamd_abi_version() != 2:
                 raise RuntimeError("audio_amd: ABI version mismatch between _lib.py and libaudio_amd.so")
             _lib = h
     return _lib

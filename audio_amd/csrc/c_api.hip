@@ -15,6 +15,7 @@
 #include "lfilter.h"
 #include "melspec400.h"
 #include "resample.h"
+#include "resample_mfma.h"
 #include "stft_generic.h"
 
 using namespace aamd;
@@ -135,25 +136,31 @@ int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, c
   return launch_check();
 }
 
-bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
+bool fft400_eligible(const StftGeom& g) {
   return g.n_fft == 400 && g.hop == 160 && g.center && g.pad_mode == AAMD_PAD_REFLECT &&
-         g.onesided && g.pad == 0 && g.power == 2.0f && g.length > 400 &&
+         g.onesided && g.pad == 0 && g.length > 400 && std::getenv("AAMD_FORCE_GENERIC") == nullptr;
+}
+
+bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
+  return fft400_eligible(g) && g.power == 2.0f &&
          m400::mel_ws(mb.max_width) <= m400::kMelMaxTaps + 4 &&
          m400::mel_rounds(mb.n_mels) <= m400::kMelMaxRounds;
 }
 
-int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
-                  const float* twiddle, float* out, hipStream_t s) {
+template <int EPI>
+int launch_fft400(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
+                  const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
   const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
   const int64_t n_tiles = g.rows * tiles_per_row;
   AAMD_CHECK_ARG(n_tiles < (1ll << 31), "too many frames for one launch");
   const int wpb = m400::kWavesPerBlock;
-  const size_t lds = m400::lds_bytes(mb.n_mels, mb.max_width);
+  const size_t lds = (EPI == m400::EPI400_SPEC) ? m400::lds_bytes(0, 1) : m400::lds_bytes(mb.n_mels, mb.max_width);
   if (lds > dev_props().lds_per_block_optin)
     return fail(AAMD_EUNSUPPORTED, "audio_amd: mel filterbank too large for the LDS of this device");
+  auto kern = m400::melspec400_kernel<0, EPI>;
   if (lds > 48 * 1024)
-    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(m400::melspec400_kernel<0>),
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // persistent grid: ONE 12-wave workgroup per CU; each owns a contiguous run of tiles (6 frames
   // each) that its waves claim dynamically
@@ -163,12 +170,15 @@ int launch_mel400(const StftGeom& g, const MelBandsDev& mb, const float* wav, co
   if (blocks >= 8) blocks -= blocks % 8;  // XCD remap wants a multiple of 8
   if (blocks < 1) blocks = 1;
   const int tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
-  // 16-B paths: LDS-DMA staging of the waveform, dwordx4 stores of the mel rows
+  // 16-B paths: LDS-DMA staging of the waveform, dwordx4 stores of the output rows
   const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (g.row_stride % 4 == 0);
-  const int out_wide = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (mb.n_mels % 4 == 0);
-  hipLaunchKernelGGL(m400::melspec400_kernel<0>, dim3((unsigned)blocks), dim3(64 * wpb), lds, s, wav, window,
+  const int out_wide = (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
+                       (EPI == m400::EPI400_SPEC || mb.n_mels % 4 == 0);
+  if (EPI == m400::EPI400_SPEC && !out_wide)
+    return fail(AAMD_EINVAL, "audio_amd: spectrogram output buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, s, wav, window,
                      twiddle, mb, out, g.rows, g.length, g.row_stride, g.n_frames, g.scale,
-                     tiles_per_row, n_tiles, tiles_per_block, in_aligned, out_wide);
+                     tiles_per_row, n_tiles, tiles_per_block, in_aligned, out_wide, epi);
   return launch_check();
 }
 
@@ -224,6 +234,11 @@ int aamd_spectrogram_f32(const float* wav, const float* window, const float* twi
   if (rc != AAMD_OK) return rc;
   AAMD_CHECK_ARG(wav && window && twiddle && out, "null buffer");
   MelBandsDev mb{};
+  if (fft400_eligible(g) && g.power > 0.0f && reinterpret_cast<uintptr_t>(out) % 16 == 0) {
+    m400::Epi400 epi{};
+    epi.power = g.power;
+    return launch_fft400<m400::EPI400_SPEC>(g, mb, wav, window, twiddle, out, epi, (hipStream_t)stream);
+  }
   return launch_generic<EPI_SPEC>(g, mb, wav, window, twiddle, out, (hipStream_t)stream);
 }
 
@@ -239,9 +254,37 @@ int aamd_melspectrogram_f32(const float* wav, const float* window, const float* 
   MelBandsDev mb;
   rc = validate_bands(bands, g.n_freq, mb);
   if (rc != AAMD_OK) return rc;
-  if (mel400_eligible(g, mb) && std::getenv("AAMD_FORCE_GENERIC") == nullptr)
-    return launch_mel400(g, mb, wav, window, twiddle, out, (hipStream_t)stream);
+  if (mel400_eligible(g, mb))
+    return launch_fft400<m400::EPI400_MEL>(g, mb, wav, window, twiddle, out, m400::Epi400{}, (hipStream_t)stream);
   return launch_generic<EPI_MEL>(g, mb, wav, window, twiddle, out, (hipStream_t)stream);
+}
+
+int aamd_melspectrogram_db_f32(const float* wav, const float* window, const float* twiddle,
+                               const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
+                               float multiplier, float amin, float db_multiplier, float* group_max,
+                               int64_t rows_per_group, void* stream) {
+  StftGeom g;
+  int rc = validate_desc(desc, g);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(wav && window && twiddle && out, "null buffer");
+  AAMD_CHECK_ARG(desc->power > 0.0f, "mel spectrogram needs power > 0");
+  AAMD_CHECK_ARG(desc->onesided, "mel spectrogram needs a onesided spectrum");
+  AAMD_CHECK_ARG(group_max == nullptr || rows_per_group >= 1, "rows_per_group must be >= 1");
+  MelBandsDev mb;
+  rc = validate_bands(bands, g.n_freq, mb);
+  if (rc != AAMD_OK) return rc;
+  if (mel400_eligible(g, mb)) {
+    m400::Epi400 epi{};
+    epi.multiplier = multiplier; epi.amin = amin; epi.db_sub = multiplier * db_multiplier;
+    epi.group_max = group_max; epi.rows_per_group = rows_per_group < 1 ? 1 : rows_per_group;
+    return launch_fft400<m400::EPI400_MEL_DB>(g, mb, wav, window, twiddle, out, epi, (hipStream_t)stream);
+  }
+  rc = launch_generic<EPI_MEL>(g, mb, wav, window, twiddle, out, (hipStream_t)stream);
+  if (rc != AAMD_OK) return rc;
+  return aamd_amplitude_to_db_f32(out, out, g.rows * g.n_frames * (int64_t)mb.n_mels, multiplier, amin,
+                                  db_multiplier, group_max,
+                                  (rows_per_group < 1 ? 1 : rows_per_group) * g.n_frames * (int64_t)mb.n_mels,
+                                  stream);
 }
 
 int aamd_mel_scale_f32(const float* spec, const aamd_mel_bands* bands, float* out, int64_t rows,
@@ -290,6 +333,32 @@ int aamd_mfcc_dct_f32(const float* mel, const float* dct, float* out, int64_t n_
   AAMD_CHECK_ARG(log_mode >= 0 && log_mode <= 2, "bad log_mode");
   AAMD_CHECK_ARG(vec_per_group >= 1 || group_max == nullptr, "vec_per_group must be >= 1");
   if (n_vec == 0) return AAMD_OK;
+  const int nt = (n_mfcc + 15) / 16;
+  if (n_mels % 4 == 0 && nt <= 4 && reinterpret_cast<uintptr_t>(mel) % 16 == 0 &&
+      reinterpret_cast<uintptr_t>(out) % 16 == 0 && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+    const size_t flds = (size_t)dct_frag_floats(n_mels, n_mfcc) * sizeof(float);
+    if (flds <= 64 * 1024) {
+      const int64_t tiles = (n_vec + kDctFramesPerTile - 1) / kDctFramesPerTile;
+      const int blocks = grid_for(tiles, 4, dev_props().cu_count * 8);
+      const int64_t vpg = vec_per_group < 1 ? 1 : vec_per_group;
+#define AAMD_DCT(NT)                                                                                   \
+  do {                                                                                                 \
+    if (flds > 48 * 1024)                                                                              \
+      AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mfcc_dct_mfma_kernel<NT>),            \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));            \
+    hipLaunchKernelGGL(mfcc_dct_mfma_kernel<NT>, dim3(blocks), dim3(256), flds, (hipStream_t)stream,   \
+                       mel, dct, out, n_vec, n_mels, n_mfcc, log_mode, group_max, vpg, top_db);        \
+    return launch_check();                                                                             \
+  } while (0)
+      switch (nt) {
+        case 1: AAMD_DCT(1);
+        case 2: AAMD_DCT(2);
+        case 3: AAMD_DCT(3);
+        default: AAMD_DCT(4);
+      }
+#undef AAMD_DCT
+    }
+  }
   const size_t lds = ((size_t)n_mels * n_mfcc + (size_t)kMfccVecPerBlock * n_mels) * sizeof(float);
   if (lds > 160 * 1024) return fail(AAMD_EUNSUPPORTED, "audio_amd: dct matrix too large for LDS");
   if (lds > 48 * 1024)
@@ -333,6 +402,79 @@ int aamd_resample_f32(const float* wav, const float* kernel, float* out, int64_t
   hipLaunchKernelGGL(resample_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, g, wav,
                      kernel, out);
   return launch_check();
+}
+
+int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, int64_t rows,
+                             int64_t length, int64_t row_stride, int32_t orig, int32_t new_, int32_t width,
+                             int64_t out_len, const aamd_resample_bands* bands, void* stream) {
+  const int n_tiles = (new_ + 15) / 16;
+  const int ks = bands ? rsm::pick_ks(bands->tap_span) : 0;
+  if (bands == nullptr || ks == 0 || std::getenv("AAMD_FORCE_GENERIC") != nullptr)
+    return aamd_resample_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, stream);
+  AAMD_CHECK_ARG(wav && kernel && out, "null buffer");
+  AAMD_CHECK_ARG(rows >= 0 && length >= 0 && orig >= 1 && new_ >= 1 && width >= 0, "bad sizes");
+  AAMD_CHECK_ARG(row_stride >= length, "row_stride < length");
+  AAMD_CHECK_ARG(out_len == (new_ * length + orig - 1) / orig, "out_len must be ceil(new*length/orig)");
+  AAMD_CHECK_ARG(bands->n_tiles == n_tiles && bands->tap_lo != nullptr && bands->tap_span >= 1,
+                 "band table must have ceil(new/16) tiles");
+  if (rows == 0 || out_len == 0) return AAMD_OK;
+  const int taps = 2 * width + orig;
+  for (int t = 0; t < n_tiles; ++t)
+    AAMD_CHECK_ARG(bands->tap_lo[t] >= 0 && bands->tap_lo[t] < taps, "tap_lo outside the tap table");
+  rsm::Geom g{};
+  g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
+  g.orig = orig; g.new_ = new_; g.width = width; g.taps = taps;
+  g.vec_in = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (row_stride % 4 == 0);
+  g.vec_out = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (out_len % 4 == 0) && (new_ % 4 == 0);
+  const int64_t nq = (out_len + new_ - 1) / new_;
+  const int max_cw = rsm::max_compute_waves(ks);
+  const size_t lds_cap = dev_props().lds_per_block_optin ? dev_props().lds_per_block_optin : 64 * 1024;
+  for (int pt0 = 0; pt0 < n_tiles; pt0 += max_cw) {
+    g.pt0 = pt0;
+    g.n_pt = n_tiles - pt0 < max_cw ? n_tiles - pt0 : max_cw;
+    int max_lo = 0;
+    for (int t = 0; t < g.n_pt; ++t) {
+      g.tap_lo[t] = bands->tap_lo[pt0 + t];
+      if (g.tap_lo[t] > max_lo) max_lo = g.tap_lo[t];
+    }
+    // q-groups: fill the workgroup with compute waves, bounded by the LDS double buffer and the row
+    int qg = max_cw / g.n_pt;
+    while (qg > 1 && ((int64_t)rsm::kQPerGroup * (qg - 1) >= nq ||
+                      2 * (size_t)rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) * sizeof(float) > lds_cap))
+      --qg;
+    g.qg = qg;
+    const int qc = rsm::kQPerGroup * qg;
+    g.buf_floats = rsm::buf_floats_needed(qc, orig, taps, max_lo, ks);
+    const size_t lds = 2 * (size_t)g.buf_floats * sizeof(float);
+    if (lds > lds_cap)   // a single q-group does not fit (huge orig): scalar kernel
+      return aamd_resample_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, stream);
+    g.chunks_per_row = (int)((nq + qc - 1) / qc);
+    g.n_chunks = rows * g.chunks_per_row;
+    int64_t blocks = dev_props().cu_count;
+    if (blocks > g.n_chunks) blocks = g.n_chunks;
+    g.chunks_per_block = (int)((g.n_chunks + blocks - 1) / blocks);
+    blocks = (g.n_chunks + g.chunks_per_block - 1) / g.chunks_per_block;
+    const int threads = 64 * (g.n_pt * qg + rsm::kLoaderWaves);
+#define AAMD_RSM(KS)                                                                                  \
+  do {                                                                                                \
+    auto kern = rsm::resample_mfma_kernel<KS>;                                                        \
+    if (lds > 48 * 1024)                                                                              \
+      AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds, (hipStream_t)stream, g, wav, \
+                       kernel, out);                                                                  \
+  } while (0)
+    switch (ks) {
+      case 16: AAMD_RSM(16); break;
+      case 48: AAMD_RSM(48); break;
+      case 80: AAMD_RSM(80); break;
+      default: AAMD_RSM(112); break;
+    }
+#undef AAMD_RSM
+    int rc = launch_check();
+    if (rc != AAMD_OK) return rc;
+  }
+  return AAMD_OK;
 }
 
 int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, int64_t batch,

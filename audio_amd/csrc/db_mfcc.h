@@ -18,6 +18,20 @@ AAMD_HD float mfcc_log(float v, int log_mode, float cut) {
   return fmax(y, cut);
 }
 
+// fragment geometry of the matrix-core DCT kernel below (shared with tests/cpu_sim)
+constexpr int kDctFramesPerTile = 16;
+
+AAMD_HD int dct_frag_floats(int n_mels, int n_mfcc) {
+  const int kc = (n_mels + 15) / 16, nt = (n_mfcc + 15) / 16;
+  return nt * kc * 4 * 64;
+}
+
+// fragment table value for (tile nt, chunk c, slot j, lane l): dct[16c + 4(l/16) + j][16nt + l%16]
+AAMD_HD float dct_frag_value(const float* dct, int n_mels, int n_mfcc, int nt, int c, int j, int lane) {
+  const int mel = 16 * c + 4 * (lane >> 4) + j, k = 16 * nt + (lane & 15);
+  return (mel < n_mels && k < n_mfcc) ? dct[mel * n_mfcc + k] : 0.0f;
+}
+
 #if defined(__HIPCC__)
 
 // float max via integer atomics; target must be initialised to -inf (or any float).
@@ -37,25 +51,31 @@ amplitude_to_db_kernel(const float* __restrict__ x, float* __restrict__ out, int
                        float multiplier, float amin, float db_multiplier,
                        float* __restrict__ group_max, int64_t group_size) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += stride) {
-    const int64_t i = base + threadIdx.x;
-    const bool ok = i < n;
-    float v = -INFINITY;
-    if (ok) {
-      v = to_db(x[i], multiplier, amin, db_multiplier);
-      out[i] = v;
-    }
+  // each thread keeps the running maximum of its current group and only touches memory when
+  // the group changes; the final flush is one atomic per wave when the wave agrees on the group
+  float run = -INFINITY;
+  int64_t run_g = -1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = to_db(x[i], multiplier, amin, db_multiplier);
+    out[i] = v;
     if (group_max != nullptr) {
-      // one atomic per wave when the whole wave sits in one group, else per lane
-      const int64_t g = ok ? i / group_size : -1;
-      const int64_t g0 = __shfl(g, 0, 64);
-      const bool uniform = __all(g == g0 || !ok) && g0 >= 0;
-      if (uniform) {
-        const float m = wave_max(v);
-        if ((threadIdx.x & 63) == 0) atomic_max_float(group_max + g0, m);
-      } else if (ok) {
-        atomic_max_float(group_max + g, v);
+      const int64_t g = i / group_size;
+      if (g != run_g) {
+        if (run_g >= 0) atomic_max_float(group_max + run_g, run);
+        run_g = g;
+        run = v;
+      } else {
+        run = fmaxf(run, v);
       }
+    }
+  }
+  if (group_max != nullptr) {
+    const int64_t g0 = __shfl(run_g, 0, 64);
+    if (__all(run_g == g0 || run_g < 0)) {
+      const float m = wave_max(run);
+      if ((threadIdx.x & 63) == 0 && g0 >= 0) atomic_max_float(group_max + g0, m);
+    } else if (run_g >= 0) {
+      atomic_max_float(group_max + run_g, run);
     }
   }
 }
@@ -120,6 +140,79 @@ mfcc_dct_kernel(const float* __restrict__ mel, const float* __restrict__ dct,
       float acc = 0.0f;
       for (int m = 0; m < n_mels; ++m) acc += y[m] * sd[m * n_mfcc + k];
       out[(v0 + vl) * n_mfcc + k] = acc;
+    }
+  }
+}
+
+
+// ---- MFCC tail on the matrix cores --------------------------------------------------------
+//   out[v][k] = sum_m y[v][m] * dct[m][k] is a (n_vec x n_mels) x (n_mels x n_mfcc) product with
+//   n_vec in the hundreds of thousands: HBM-bound if the contraction is cheap.  It runs on
+//   v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, same rate as the vector ALU, which stays free
+//   for the log/clamp prologue):  D^T tile (16 coefficients x 4 mels) x Y^T tile (4 mels x 16
+//   frames), so a lane ends up with 4 CONSECUTIVE coefficients of one frame = one 16-B store.
+//   The contraction order inside a chunk of 16 mels is permuted (k-slot (j, g) <-> mel
+//   16 c + 4 g + j) so that every lane loads one contiguous float4 of its frame's mel row.
+//   Needs n_mels % 4 == 0; the scalar kernel above covers the rest.
+template <int NT>
+__global__ void __launch_bounds__(256)
+mfcc_dct_mfma_kernel(const float* __restrict__ mel, const float* __restrict__ dct,
+                     float* __restrict__ out, int64_t n_vec, int n_mels, int n_mfcc, int log_mode,
+                     const float* __restrict__ group_max, int64_t vec_per_group, float top_db) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  extern __shared__ __attribute__((aligned(16))) float smem_dct[];
+  const int kc = (n_mels + 15) / 16;
+  for (int i = threadIdx.x; i < NT * kc * 4 * 64; i += blockDim.x) {
+    const int lane = i & 63, slot = i >> 6;
+    const int j = slot & 3, c = (slot >> 2) % kc, nt = (slot >> 2) / kc;
+    smem_dct[i] = dct_frag_value(dct, n_mels, n_mfcc, nt, c, j, lane);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int f = lane & 15, g = lane >> 4;
+  const int64_t n_tiles = (n_vec + kDctFramesPerTile - 1) / kDctFramesPerTile;
+  const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  const bool clampy = log_mode != 1 && top_db >= 0.0f && group_max != nullptr;
+  for (int64_t tile = wave0; tile < n_tiles; tile += n_waves) {
+    const int64_t v = tile * kDctFramesPerTile + f;
+    const bool vok = v < n_vec;
+    float cut = -INFINITY;
+    if (clampy && vok) cut = group_max[v / vec_per_group] - top_db;
+    const float* row = mel + (vok ? v : 0) * (int64_t)n_mels + 4 * g;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c = 0; c < kc; ++c) {
+      float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (vok && 16 * c + 4 * g < n_mels) {
+        const F4 m4 = *reinterpret_cast<const F4*>(row + 16 * c);
+        y[0] = mfcc_log(m4.x, log_mode, cut);
+        y[1] = mfcc_log(m4.y, log_mode, cut);
+        y[2] = mfcc_log(m4.z, log_mode, cut);
+        y[3] = mfcc_log(m4.w, log_mode, cut);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float* af = smem_dct + ((nt * kc + c) * 4) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[64 * j], y[j], acc[nt], 0, 0, 0);
+      }
+    }
+    if (vok) {
+      float* orow = out + v * (int64_t)n_mfcc;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int k0 = 16 * nt + 4 * g;
+        if (k0 + 4 <= n_mfcc && (n_mfcc & 3) == 0) {
+          *reinterpret_cast<F4*>(orow + k0) = F4{acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k0 + i < n_mfcc) orow[k0 + i] = acc[nt][i];
+        }
+      }
     }
   }
 }

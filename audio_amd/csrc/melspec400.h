@@ -46,9 +46,10 @@ constexpr int kTRow = 44;                      // dwords per transposition row: 
                                                // cycles = the ds_write_b64 issue cost
 constexpr int kTPair = 20 * kTRow;             // 880 dwords per pair
 constexpr int kLdsDwordsPerWave = 3 * kTPair;  // 2640 dwords = 10560 B (the P rows alias it)
-constexpr int kPK = 212;                       // readable bins per P row: 201 + zeroed tail, even
-constexpr int kPPair = 448;                    // dwords per pair of P rows (>= 2 * kPK)
-constexpr int kSOff = 3 * kPPair;              // 1344: staging area for the NEXT tile's samples (LDS-DMA)
+constexpr int kPK = 208;                       // readable bins per P row: 201 + zeroed tail, even
+constexpr int kPPair = 416;                    // dwords per pair of P rows (>= 2 * kPK); = 32 mod 64, so the b128
+                                               // band reads of neighbouring pairs land on opposite bank halves
+constexpr int kSOff = 1344;                    // staging area for the NEXT tile's samples (LDS-DMA)
 constexpr int kSPieces = 320;                  // 16-B pieces: 1200 samples + 20 pad dwords per 320 samples
 constexpr int kTileSamples = (kFramesPerWave - 1) * kHop + kN;   // 1200
 constexpr int kMelSlots = 20;                  // mels per round
@@ -58,6 +59,21 @@ constexpr int kMelMaxTaps = 64;                // widest padded band (taps)
 static_assert(3 * kPPair <= kLdsDwordsPerWave && 2 * kPK <= kPPair, "P rows must fit in the transposition buffer");
 static_assert(3 * (kPK - 201) <= 64, "one lane per tail bin");
 static_assert(kSOff + 4 * kSPieces <= kLdsDwordsPerWave, "staging area must fit beside the P rows");
+
+// Epilogues of the tile loop (compile-time variants of the same kernel):
+//   EPI400_MEL     banded mel of |X|^2                       -> out[rows][T][n_mels]
+//   EPI400_MEL_DB  ... then amplitude_to_DB (functional.py:390-391) fused, plus the running
+//                  maximum per cut-off group (the top_db reduction of :393-402)
+//   EPI400_SPEC    no mel: |X|^power for the 201 one-sided bins -> out[rows][T][201]
+enum { EPI400_MEL = 0, EPI400_MEL_DB = 1, EPI400_SPEC = 2 };
+struct Epi400 {
+  float multiplier, amin, db_sub;   // MEL_DB: y = multiplier * log10(max(x, amin)) - db_sub
+  float* group_max;                 // MEL_DB: [n_groups] running max of y (float bit pattern), may be null
+  int64_t rows_per_group;           // MEL_DB: waveform rows per cut-off group
+  float power;                      // SPEC: 2 -> |X|^2, 1 -> |X|, else |X|^power
+};
+constexpr int kSpecBins = 201;
+static_assert(kFramesPerWave * kSpecBins + 3 <= kSOff, "SPEC rows must fit below the staging area");
 
 // column held by the lane at position pi of a 20-lane group (pass 2), and its inverse:
 // positions (0,1) = columns (0,10), then (2j, 2j+1) = (j, 20-j): lane ^ 1 holds column 20 - c.
@@ -346,6 +362,71 @@ AAMD_HD void phase_b2(const LaneConst& c, const float (&zr)[20], const float (&z
   }
 }
 
+// ---- SPEC epilogue: |A|^power, |B|^power as frame-contiguous rows -------------------------
+//   The tile's 6 x 201 outputs are contiguous in memory (frame-major spectrogram).  They are
+//   staged at LDS float index `phase + 201 * frame + k`, phase = (global float offset of the
+//   tile) mod 4, so that 16-B LDS pieces line up with 16-B global pieces.
+AAMD_HD float spec_pow(float m2, float power) {
+  if (power == 2.0f) return m2;
+  const float m = sqrt(m2);
+  if (power == 1.0f) return m;
+  return pow(m, power);
+}
+
+AAMD_HD void phase_b2_spec(const LaneConst& c, const float (&zr)[20], const float (&zi)[20],
+                           const float (&qr)[10], const float (&qi)[10], const float (&gr)[10],
+                           const float (&gi)[10], float power, int phase, float* lds) {
+  if (!c.active) return;
+  float* Ra = lds + phase + kSpecBins * 2 * c.p + c.col;
+  float* Rb = Ra + kSpecBins;
+  const bool self = (c.col == 0) || (c.col == 10);
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    const float sr = qr[9 - u], si = qi[9 - u], pr = gr[9 - u], pi_ = gi[9 - u];
+    const float cr = self ? sr : pr;
+    const float ci = self ? si : pi_;
+    const float ar = zr[u] + cr, ai = zi[u] - ci;
+    const float br = zr[u] - cr, bi = zi[u] + ci;
+    Ra[20 * u] = spec_pow(ar * ar + ai * ai, power);
+    Rb[20 * u] = spec_pow(br * br + bi * bi, power);
+  }
+  if (c.col == 0) {
+    const float ar = zr[10] + zr[10], bi = zi[10] + zi[10];
+    Ra[200] = spec_pow(ar * ar, power);
+    Rb[200] = spec_pow(bi * bi, power);
+  }
+}
+
+// coalesced copy of the staged rows: 16-B pieces where a piece lies fully inside the run,
+// single floats at the ragged ends
+AAMD_HD void store_spec(int lane, const float* lds, float* out, int64_t a0, int n_floats) {
+  const int phase = (int)(a0 & 3);
+  float* base = out + (a0 - phase);   // 16-B aligned when `out` is
+  const int n_pieces = (phase + n_floats + 3) >> 2;
+  for (int j = lane; j < n_pieces; j += 64) {
+    const int i0 = 4 * j;
+    if (i0 >= phase && i0 + 4 <= phase + n_floats) {
+      *reinterpret_cast<F4*>(base + i0) = *reinterpret_cast<const F4*>(lds + i0);
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (i0 + e >= phase && i0 + e < phase + n_floats) base[i0 + e] = lds[i0 + e];
+    }
+  }
+}
+
+// amplitude_to_DB of one value (functional.py:390-391); log10 through the hardware log2
+// (v_log_f32, ~1 ulp of log2 x => < 2e-5 dB absolute)
+AAMD_HD float fast_log10(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __log2f(x) * 0.30102999566398120f;
+#else
+  return log10(x);
+#endif
+}
+AAMD_HD float epi_db(float x, const Epi400& e) {
+  return e.multiplier * fast_log10(fmax(x, e.amin)) - e.db_sub;
+}
+
 // zero bins 201..211 of each P row so that band reads past bin 200 (weight 0) never touch
 // stale transposition data
 AAMD_HD void phase_b2_pad(int lane, float* lds) {
@@ -482,13 +563,19 @@ struct TileInfo {
 // LAB != 0 builds profiling variants for tools/ubench/mel400_lab.hip (wrong results by design):
 //   bit 0: no wait for the staged tile   bit 1: no global stores   bit 2: no phase C
 //   bit 3: no LDS-DMA issue              bit 4: no phase B (second DFT, separation, P rows)
-template <int LAB>
+// float max through integer atomics (target initialised to -inf or any float)
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+template <int LAB, int EPI>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, 3)
 melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ window,
                   const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
                   int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
                   int tiles_per_row, int64_t n_tiles, int tiles_per_block, int in_aligned,
-                  int out_wide) {
+                  int out_wide, Epi400 epi) {
   extern __shared__ __attribute__((aligned(16))) float smem400[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -499,13 +586,14 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
 
   float* const_tab = smem400 + kWavesPerBlock * kLdsDwordsPerWave;
   const_tab_build(threadIdx.x, blockDim.x, window, tw400, scale, const_tab);
-  MelTab mt;
-  mel_tab_rounds(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
+  MelTab mt{};
+  if (EPI != EPI400_SPEC) mel_tab_rounds(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
   // tile queue of this workgroup: the next unclaimed tile (waves start on tiles 0 .. W-1)
-  int* queue = reinterpret_cast<int*>(const_tab + kConstDwords + mel_tab_dwords(mb.n_mels, mb.max_width));
+  const int tab_dwords = (EPI != EPI400_SPEC) ? mel_tab_dwords(mb.n_mels, mb.max_width) : 0;
+  int* queue = reinterpret_cast<int*>(const_tab + kConstDwords + tab_dwords);
   if (threadIdx.x == 0) *queue = kWavesPerBlock;
   __syncthreads();
-  mel_tab_fill(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
+  if (EPI != EPI400_SPEC) mel_tab_fill(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
   __syncthreads();
 
   long long lab_t1 = 0;
@@ -554,6 +642,19 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
       if (!(LAB & 64) || k == 0) glds16(src + spiece[k], s_addr + 1024 * k);   // lab bit 6: one piece only
   };
 
+  // MEL_DB: running maximum of this wave's dB values, flushed whenever the cut-off group changes
+  float wmax = -INFINITY;
+  int64_t wgroup = -1;
+  auto flush_max = [&]() {
+    if (EPI == EPI400_MEL_DB && epi.group_max != nullptr && wgroup >= 0) {
+      float m = wmax;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      if (lane == 0) atomic_max_f32(epi.group_max + wgroup, m);
+    }
+    wmax = -INFINITY;
+  };
+
   unsigned cur_idx = (unsigned)wave;
   TileInfo cur = tile_info(cur_idx);
   if (LAB & 128) {   // lab: stagger the waves of a SIMD by thirds of a tile time
@@ -595,12 +696,39 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
       gi[i] = swap_adjacent(qi[i]);
     }
     wave_lds_fence();
+    if (EPI == EPI400_SPEC) {
+      const int64_t a0 = (cur.row * n_frames + cur.t0) * (int64_t)kSpecBins;
+      phase_b2_spec(c, zr, zi, qr, qi, gr, gi, epi.power, (int)(a0 & 3), lds);
+      wave_lds_fence();
+      const int64_t left = n_frames - cur.t0;
+      const int n_valid = left < kFramesPerWave ? (int)left : kFramesPerWave;
+      if (!(LAB & 2)) store_spec(lane, lds, out, a0, n_valid * kSpecBins);
+      wave_lds_fence();
+      cur = nxt;
+      cur_idx = nxt_idx;
+      continue;
+    }
     phase_b2(c, zr, zi, qr, qi, gr, gi, lds);
     phase_b2_pad(lane, lds);
     wave_lds_fence();
     float acc_a[kMelMaxRounds], acc_b[kMelMaxRounds];
     if (LAB & 4) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
     phase_c(c, mt, lds, acc_a, acc_b);
+    if (EPI == EPI400_MEL_DB) {
+      const int64_t g = cur.row / epi.rows_per_group;   // wave-uniform
+      if (g != wgroup) {
+        flush_max();
+        wgroup = g;
+      }
+#pragma unroll
+      for (int r = 0; r < kMelMaxRounds; ++r) {
+        if (r < mt.n_rounds) {
+          acc_a[r] = epi_db(acc_a[r], epi);
+          acc_b[r] = epi_db(acc_b[r], epi);
+          wmax = fmaxf(wmax, fmaxf(acc_a[r], acc_b[r]));
+        }
+      }
+    }
     float* out_row = out + cur.row * n_frames * (int64_t)mb.n_mels;
     if (out_wide) {
       wave_lds_fence();
@@ -613,6 +741,34 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     wave_lds_fence();
     cur = nxt;
     cur_idx = nxt_idx;
+  }
+  if (EPI == EPI400_MEL_DB && epi.group_max != nullptr) {
+    // final flush through LDS: one atomic per workgroup and group instead of one per wave
+    // (thousands of same-address atomics from every XCD serialise at one L2 channel)
+    float m = wmax;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) {
+      reinterpret_cast<int*>(lds)[0] = (int)wgroup;
+      lds[1] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int g_run = -1;
+      float m_run = -INFINITY;
+      for (int w = 0; w < kWavesPerBlock; ++w) {
+        const int gw = reinterpret_cast<const int*>(smem400 + w * kLdsDwordsPerWave)[0];
+        const float mw = smem400[w * kLdsDwordsPerWave + 1];
+        if (gw != g_run) {
+          if (g_run >= 0) atomic_max_f32(epi.group_max + g_run, m_run);
+          g_run = gw;
+          m_run = mw;
+        } else {
+          m_run = fmaxf(m_run, mw);
+        }
+      }
+      if (g_run >= 0) atomic_max_f32(epi.group_max + g_run, m_run);
+    }
   }
   if ((LAB & 1024) && lane == 0) {   // lab census: per-wave entry / tables ready / done (100 MHz clock)
     long long* rec = reinterpret_cast<long long*>(const_cast<float*>(tw400) + 1024);

@@ -219,9 +219,13 @@ def spectrogram(
 
 def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_fft: int, hop_length: int,
                     win_length: int, power: float, normalized, center: bool, pad_mode: str,
-                    bands: Optional[MelBandsOnDevice] = None) -> Tensor:
+                    bands: Optional[MelBandsOnDevice] = None, db=None) -> Tensor:
     """Fused Spectrogram + MelScale (transforms/_transforms.py:612-622). Returns frame-major
-    (rows, T, n_mels) plus the leading shape; callers build the (..., n_mels, T) view."""
+    (rows, T, n_mels); callers build the (..., n_mels, T) view.
+
+    ``db = (multiplier, amin, db_multiplier, group_max, rows_per_group)`` additionally fuses
+    F.amplitude_to_DB (functional.py:390-391) into the kernel epilogue and max-reduces the dB
+    values of each cut-off group into ``group_max`` (the top_db reduction, :393-402)."""
     _require_device(waveform, "waveform")
     if power is None:
         raise ValueError("audio_amd: MelSpectrogram needs a real power (got None)")
@@ -237,9 +241,15 @@ def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_ff
     out = torch.empty((desc.rows, desc.n_frames, bands.n_mels), dtype=torch.float32, device=waveform.device)
     if out.numel():
         L = _lib.lib()
-        _lib.check(L.aamd_melspectrogram_f32(
-            x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, waveform.device).data_ptr(),
-            C.byref(bands.struct), out.data_ptr(), C.byref(desc), _lib.current_stream(waveform.device)))
+        args = (x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, waveform.device).data_ptr(),
+                C.byref(bands.struct), out.data_ptr(), C.byref(desc))
+        if db is None:
+            _lib.check(L.aamd_melspectrogram_f32(*args, _lib.current_stream(waveform.device)))
+        else:
+            multiplier, amin, db_multiplier, group_max, rows_per_group = db
+            _lib.check(L.aamd_melspectrogram_db_f32(
+                *args, multiplier, amin, db_multiplier, None if group_max is None else group_max.data_ptr(),
+                rows_per_group, _lib.current_stream(waveform.device)))
     return out
 
 
@@ -318,9 +328,14 @@ def _apply_sinc_resample_kernel(waveform: Tensor, orig_freq: int, new_freq: int,
     out = torch.empty((rows, out_len), dtype=torch.float32, device=waveform.device)
     if out.numel():
         L = _lib.lib()
-        _lib.check(L.aamd_resample_f32(x2.data_ptr(), kern.data_ptr(), out.data_ptr(), rows, length,
-                                       x2.stride(0) if rows > 1 else max(length, 1), orig, new, width, out_len,
-                                       _lib.current_stream(waveform.device)))
+        # band table of the taps (host, once per kernel tensor): the matrix-core kernel skips the
+        # ~1e-20-sized window tails outside each phase tile's band
+        tap_lo, span = _tensor_cached(kernel, ("rs_bands", new),
+                                      lambda: _host.resample_band_table(kern.cpu().numpy()))
+        bands = _lib.ResampleBands(tap_lo.shape[0], span, tap_lo.ctypes.data_as(C.POINTER(C.c_int32)))
+        _lib.check(L.aamd_resample_banded_f32(x2.data_ptr(), kern.data_ptr(), out.data_ptr(), rows, length,
+                                              x2.stride(0) if rows > 1 else max(length, 1), orig, new, width,
+                                              out_len, C.byref(bands), _lib.current_stream(waveform.device)))
     return out.view(tuple(shape[:-1]) + (out_len,))
 
 

@@ -165,10 +165,10 @@ class MelSpectrogram(torch.nn.Module):
         self.mel_scale = MelScale(self.n_mels, self.sample_rate, self.f_min, self.f_max, self.n_fft // 2 + 1,
                                   norm, mel_scale)
 
-    def _frame_major(self, waveform: Tensor) -> Tensor:
+    def _frame_major(self, waveform: Tensor, db=None) -> Tensor:
         sp = self.spectrogram
         return F._melspectrogram(waveform, sp.pad, sp.window, self.mel_scale.fb, sp.n_fft, sp.hop_length,
-                                 sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode)
+                                 sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode, db=db)
 
     def forward(self, waveform: Tensor) -> Tensor:
         out = self._frame_major(waveform)                       # (rows, T, n_mels)
@@ -212,34 +212,38 @@ class MFCC(torch.nn.Module):
         self.group_max_hook: Optional[Callable[[Tensor], None]] = None
 
     def forward(self, waveform: Tensor) -> Tensor:
-        mel = self.MelSpectrogram._frame_major(waveform)        # (rows, T, n_mels) frame-major
-        rows, T, n_mels = mel.shape
         lead = tuple(waveform.shape[:-1])
         dev = waveform.device
-        out = torch.empty((rows, T, self.n_mfcc), dtype=torch.float32, device=dev)
         dct = self.dct_mat.to(device=dev, dtype=torch.float32).contiguous()
-        if out.numel():
-            L = _lib.lib()
-            stream = _lib.current_stream(dev)
-            n_vec = rows * T
-            if self.log_mels:
-                _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), n_vec, n_mels,
-                                               self.n_mfcc, 1, None, 1, -1.0, stream))
-            else:
-                # amplitude_to_DB's cut-off groups: the mel tensor is (..., C?, n_mels, T); one cut-off
-                # per leading item of its (-1, C, n_mels, T) view (functional.py:393-402)
-                packed = waveform.shape[-2] if waveform.dim() > 1 else 1
-                n_groups = rows // packed
-                gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
-                a2db = self.amplitude_to_DB
-                _lib.check(L.aamd_amplitude_to_db_f32(mel.data_ptr(), mel.data_ptr(), mel.numel(), a2db.multiplier,
-                                                      a2db.amin, a2db.db_multiplier, gmax.data_ptr(),
-                                                      packed * T * n_mels, stream))
-                if self.group_max_hook is not None:
-                    self.group_max_hook(gmax)
-                _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), n_vec, n_mels,
+        L = _lib.lib()
+        if self.log_mels:
+            mel = self.MelSpectrogram._frame_major(waveform)    # (rows, T, n_mels) frame-major
+            rows, T, n_mels = mel.shape
+            out = torch.empty((rows, T, self.n_mfcc), dtype=torch.float32, device=dev)
+            if out.numel():
+                _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), rows * T, n_mels,
+                                               self.n_mfcc, 1, None, 1, -1.0, _lib.current_stream(dev)))
+        else:
+            # amplitude_to_DB's cut-off groups: the mel tensor is (..., C?, n_mels, T); one cut-off
+            # per leading item of its (-1, C, n_mels, T) view (functional.py:393-402).  The dB
+            # conversion and the per-group maximum are fused into the mel kernel's epilogue.
+            packed = waveform.shape[-2] if waveform.dim() > 1 else 1
+            n_rows = 1
+            for d in lead:
+                n_rows *= d
+            n_groups = max(n_rows // max(packed, 1), 1)
+            gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
+            a2db = self.amplitude_to_DB
+            mel = self.MelSpectrogram._frame_major(
+                waveform, db=(a2db.multiplier, a2db.amin, a2db.db_multiplier, gmax, packed))
+            rows, T, n_mels = mel.shape
+            out = torch.empty((rows, T, self.n_mfcc), dtype=torch.float32, device=dev)
+            if self.group_max_hook is not None:
+                self.group_max_hook(gmax)
+            if out.numel():
+                _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), rows * T, n_mels,
                                                self.n_mfcc, 2, gmax.data_ptr(), packed * T, float(self.top_db),
-                                               stream))
+                                               _lib.current_stream(dev)))
         return out.view(lead + (T, self.n_mfcc)).transpose(-1, -2)
 
 

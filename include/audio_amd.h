@@ -20,6 +20,8 @@
  *                             transforms/_transforms.py:101-123 (Spectrogram.forward)
  *   aamd_melspectrogram_f32   transforms/_transforms.py:612-622 (MelSpectrogram.forward =
  *                             Spectrogram.forward + MelScale.forward :403-415)
+ *   aamd_melspectrogram_db_f32  ... + F.amplitude_to_DB and its top_db group maximum fused
+ *                             (first half of MFCC.forward, _transforms.py:692-706)
  *   aamd_mel_scale_f32        transforms/_transforms.py:403-415 (MelScale.forward on a
  *                             caller-supplied spectrogram)
  *   aamd_amplitude_to_db_f32  functional/functional.py:356-404 (F.amplitude_to_DB)
@@ -27,6 +29,7 @@
  *                             mel step: dB/log + top_db clamp + DCT-II matmul)
  *   aamd_resample_f32         functional/functional.py:1405-1432 (_apply_sinc_resample_kernel:
  *                             pad + strided conv1d + phase interleave + crop)
+ *   aamd_resample_banded_f32  the same, banded evaluation on the matrix cores
  *   aamd_lfilter_f32          functional/filtering.py:1027-1099 (_lfilter + clamp), i.e.
  *                             DifferentiableFIR.forward :943-951 and the native IIR loop
  *                             libtorchaudio/lfilter.cpp:17-48 / iir_cuda.cu:10-35
@@ -44,7 +47,7 @@
 extern "C" {
 #endif
 
-#define AAMD_ABI_VERSION 1
+#define AAMD_ABI_VERSION 2
 
 enum {
   AAMD_OK = 0,
@@ -101,10 +104,23 @@ int aamd_spectrogram_f32(const float* wav, const float* window, const float* twi
 
 /* Fused STFT -> |X|^power -> banded mel.  out: float[rows][n_frames][n_mels].
  * Uses the register/LDS radix-20x20 kernel when (n_fft, hop) = (400, 160), center/reflect,
- * onesided; every other shape takes the generic LDS Stockham kernel -- same results. */
+ * onesided; every other shape takes the generic LDS Stockham kernel -- same results.
+ * (aamd_spectrogram_f32 takes the same fast kernel for that shape when power > 0.) */
 int aamd_melspectrogram_f32(const float* wav, const float* window, const float* twiddle,
                             const aamd_mel_bands* bands, float* out,
                             const aamd_stft_desc* desc, void* stream);
+
+/* The same with F.amplitude_to_DB (functional.py:390-391) fused into the epilogue:
+ *   out = multiplier*log10(max(mel, amin)) - multiplier*db_multiplier,
+ * and, if group_max != NULL, the running maximum of `out` over each cut-off group of
+ * rows_per_group consecutive waveforms max-reduced into group_max[row / rows_per_group]
+ * (float; caller pre-fills with -inf) -- the reduction top_db needs (functional.py:393-402).
+ * This is the first half of MFCC.forward (transforms/_transforms.py:692-706); aamd_mfcc_dct_f32
+ * with log_mode 2 is the second half. */
+int aamd_melspectrogram_db_f32(const float* wav, const float* window, const float* twiddle,
+                               const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
+                               float multiplier, float amin, float db_multiplier, float* group_max,
+                               int64_t rows_per_group, void* stream);
 
 /* MelScale.forward on an existing spectrogram given frame-major: spec float[rows][n_frames][n_freq]
  * -> out float[rows][n_frames][n_mels]. */
@@ -141,6 +157,24 @@ int aamd_mfcc_dct_f32(const float* mel, const float* dct, float* out, int64_t n_
 int aamd_resample_f32(const float* wav, const float* kernel, float* out, int64_t rows,
                       int64_t length, int64_t row_stride, int32_t orig, int32_t new_, int32_t width,
                       int64_t out_len, void* stream);
+
+/* Band description of the tap table per tile of 16 consecutive phases (HOST memory): every
+ * non-negligible tap of phases [16t, 16t+16) lies in [tap_lo[t], tap_lo[t] + tap_span).
+ * Taps outside the band are treated as zero (the caller decides what is negligible; the Python
+ * host drops |h| <= 2^-40 max|h|, < 1e-9 of a full-scale output). */
+typedef struct aamd_resample_bands {
+  int32_t n_tiles;         /* ceil(new / 16) */
+  int32_t tap_span;
+  const int32_t* tap_lo;   /* host, n_tiles */
+} aamd_resample_bands;
+
+/* Same result as aamd_resample_f32, evaluated on the matrix cores over the banded tap table
+ * (v_mfma_f32_16x16x4_f32, exact fp32 FMA chains).  bands == NULL, a band wider than 448 taps
+ * or an `orig` whose double-buffered chunk exceeds the LDS fall back to aamd_resample_f32. */
+int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, int64_t rows,
+                             int64_t length, int64_t row_stride, int32_t orig, int32_t new_,
+                             int32_t width, int64_t out_len, const aamd_resample_bands* bands,
+                             void* stream);
 
 /* ---- lfilter ---------------------------------------------------------------------------- */
 

@@ -13,6 +13,7 @@
 #include "../../audio_amd/csrc/lfilter.h"
 #include "../../audio_amd/csrc/melspec400.h"
 #include "../../audio_amd/csrc/resample.h"
+#include "../../audio_amd/csrc/resample_mfma.h"
 #include "../../audio_amd/csrc/stft_generic.h"
 
 using namespace aamd;
@@ -61,24 +62,35 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
   return 0;
 }
 
+// epi: 0 mel, 1 mel + dB (db = {multiplier, amin, db_sub}; gmax[rows / rows_per_group] max-reduced),
+//      2 spectrogram |X|^power (bands unused)
 int sim_melspec400(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
-                   float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale) {
+                   float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
+                   int epi_mode, const float* db, float* gmax, int64_t rows_per_group, float power) {
   using namespace m400;
-  MelBandsDev mb{bands->n_mels, bands->max_width, bands->lo, bands->width, bands->weights};
-  if (mel_ws(mb.max_width) > kMelMaxTaps + 4 || mel_rounds(mb.n_mels) > kMelMaxRounds) return -2;
+  MelBandsDev mb{};
+  if (epi_mode != EPI400_SPEC) {
+    mb = MelBandsDev{bands->n_mels, bands->max_width, bands->lo, bands->width, bands->weights};
+    if (mel_ws(mb.max_width) > kMelMaxTaps + 4 || mel_rounds(mb.n_mels) > kMelMaxRounds) return -2;
+  }
+  Epi400 epi{};
+  if (epi_mode == EPI400_MEL_DB) { epi.multiplier = db[0]; epi.amin = db[1]; epi.db_sub = db[2]; }
+  epi.power = power;
   alignas(16) static float lds[kLdsDwordsPerWave];
   alignas(16) static float tab[kMelMaxRounds * kMelSlots * (kMelMaxTaps + 4) + 256];
   alignas(16) static float ctab[kConstDwords];
   for (int tid = 0; tid < 256; ++tid) const_tab_build(tid, 256, window, tw400, scale, ctab);
-  MelTab mt;
-  for (int tid = 0; tid < 256; ++tid) mel_tab_rounds(tid, 256, mb, tab, mt);
-  for (int tid = 0; tid < 256; ++tid) mel_tab_fill(tid, 256, mb, tab, mt);
+  MelTab mt{};
+  if (epi_mode != EPI400_SPEC) {
+    for (int tid = 0; tid < 256; ++tid) mel_tab_rounds(tid, 256, mb, tab, mt);
+    for (int tid = 0; tid < 256; ++tid) mel_tab_fill(tid, 256, mb, tab, mt);
+  }
   LaneConst c[64];
   for (int l = 0; l < 64; ++l) lane_init(l, ctab, c[l]);
   const int tiles_per_row = (n_frames + kFramesPerWave - 1) / kFramesPerWave;
   // same launch-time switches as launch_mel400() in c_api.hip
   const bool in_aligned = (row_stride % 4 == 0);
-  const bool out_wide = (mb.n_mels % 4 == 0);
+  const bool out_wide = (epi_mode == EPI400_SPEC) || (mb.n_mels % 4 == 0);
   static float X[64][28], vr[64][20], vi[64][20], zr[64][20], zi[64][20], qr[64][10], qi[64][10];
   static float acc_a[64][kMelMaxRounds], acc_b[64][kMelMaxRounds];
   auto staged = [&](int64_t t0) {
@@ -110,9 +122,29 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
     for (int l = 0; l < 64; ++l) dft20(vr[l], vi[l], zr[l], zi[l]);
     for (int l = 0; l < 64; ++l) phase_b2_send(c[l], zr[l], zi[l], qr[l], qi[l]);
     // the DPP quad_perm [1,0,3,2] swap: lane l receives lane l ^ 1's q
+    if (epi_mode == EPI400_SPEC) {
+      const int64_t a0 = (row * n_frames + t0) * (int64_t)kSpecBins;
+      for (int l = 0; l < 64; ++l)
+        phase_b2_spec(c[l], zr[l], zi[l], qr[l], qi[l], qr[l ^ 1], qi[l ^ 1], epi.power, (int)(a0 & 3), lds);
+      const int64_t left = n_frames - t0;
+      const int n_valid = left < kFramesPerWave ? (int)left : kFramesPerWave;
+      for (int l = 0; l < 64; ++l) store_spec(l, lds, out, a0, n_valid * kSpecBins);
+      cur_staged = nxt_staged;
+      continue;
+    }
     for (int l = 0; l < 64; ++l) phase_b2(c[l], zr[l], zi[l], qr[l], qi[l], qr[l ^ 1], qi[l ^ 1], lds);
     for (int l = 0; l < 64; ++l) phase_b2_pad(l, lds);
     for (int l = 0; l < 64; ++l) phase_c(c[l], mt, lds, acc_a[l], acc_b[l]);
+    if (epi_mode == EPI400_MEL_DB) {
+      float m = -INFINITY;
+      for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < mt.n_rounds; ++r) {
+          acc_a[l][r] = epi_db(acc_a[l][r], epi);
+          acc_b[l][r] = epi_db(acc_b[l][r], epi);
+          m = std::fmax(m, std::fmax(acc_a[l][r], acc_b[l][r]));
+        }
+      if (gmax) { float& g = gmax[row / rows_per_group]; g = std::fmax(g, m); }
+    }
     float* out_row = out + row * n_frames * (int64_t)mb.n_mels;
     if (out_wide) {
       for (int l = 0; l < 64; ++l) store_stage(c[l], mt, acc_a[l], acc_b[l], lds);
@@ -121,6 +153,57 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
       for (int l = 0; l < 64; ++l) store_direct(c[l], mt, acc_a[l], acc_b[l], out_row, t0, n_frames);
     }
     cur_staged = nxt_staged;
+  }
+  return 0;
+}
+
+// Replay of mfcc_dct_mfma_kernel: the A/B/C fragment maps of v_mfma_f32_16x16x4_f32
+// (A[l&15][l>>4], B[l>>4][l&15], C row = 4*(l>>4)+i, col = l&15) applied to the same index math.
+int sim_mfcc_dct_mfma(const float* mel, const float* dct, float* out, int64_t n_vec, int n_mels, int n_mfcc,
+                      int log_mode, const float* group_max, int64_t vec_per_group, float top_db) {
+  const int kc = (n_mels + 15) / 16, NT = (n_mfcc + 15) / 16;
+  std::vector<float> frag((size_t)NT * kc * 4 * 64);
+  for (size_t i = 0; i < frag.size(); ++i) {
+    const int lane = (int)(i & 63), slot = (int)(i >> 6);
+    const int j = slot & 3, c = (slot >> 2) % kc, nt = (slot >> 2) / kc;
+    frag[i] = dct_frag_value(dct, n_mels, n_mfcc, nt, c, j, lane);
+  }
+  const bool clampy = log_mode != 1 && top_db >= 0.0f && group_max != nullptr;
+  const int64_t n_tiles = (n_vec + kDctFramesPerTile - 1) / kDctFramesPerTile;
+  for (int64_t tile = 0; tile < n_tiles; ++tile) {
+    std::vector<float> C(NT * 16 * 16, 0.f);   // [nt][row][col]
+    for (int c = 0; c < kc; ++c) {
+      float y[64][4];
+      for (int lane = 0; lane < 64; ++lane) {
+        const int f = lane & 15, g = lane >> 4;
+        const int64_t v = tile * kDctFramesPerTile + f;
+        for (int j = 0; j < 4; ++j) y[lane][j] = 0.f;
+        if (v < n_vec && 16 * c + 4 * g < n_mels) {
+          float cut = -INFINITY;
+          if (clampy) cut = group_max[v / vec_per_group] - top_db;
+          for (int j = 0; j < 4; ++j) y[lane][j] = mfcc_log(mel[v * n_mels + 16 * c + 4 * g + j], log_mode, cut);
+        }
+      }
+      for (int nt = 0; nt < NT; ++nt)
+        for (int j = 0; j < 4; ++j)
+          for (int row = 0; row < 16; ++row)
+            for (int col = 0; col < 16; ++col)
+              for (int k = 0; k < 4; ++k) {
+                const float a = frag[(size_t)(((nt * kc + c) * 4 + j) * 64) + (row + 16 * k)];   // lane = row + 16 k
+                const float b = y[col + 16 * k][j];                                               // lane = col + 16 k
+                C[(nt * 16 + row) * 16 + col] += a * b;
+              }
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+      const int f = lane & 15, g = lane >> 4;
+      const int64_t v = tile * kDctFramesPerTile + f;
+      if (v >= n_vec) continue;
+      for (int nt = 0; nt < NT; ++nt)
+        for (int i = 0; i < 4; ++i) {
+          const int k0 = 16 * nt + 4 * g;
+          if (k0 + i < n_mfcc) out[v * n_mfcc + k0 + i] = C[(nt * 16 + 4 * g + i) * 16 + f];
+        }
+    }
   }
   return 0;
 }
@@ -140,6 +223,72 @@ int sim_resample(const float* wav, const float* kern, float* out, int64_t rows, 
       if (use_lds) for (int tid = 0; tid < 256; ++tid) resample_stage(tid, 256, g, wr, q0, xs.data());
       for (int tid = 0; tid < 256; ++tid) resample_compute(tid, 256, g, kern, wr, xs.data(), q0, out + row * out_len);
     }
+  return 0;
+}
+
+// Replay of rsm::resample_mfma_kernel: same Geom set-up as aamd_resample_banded_f32, the loader's
+// piece copies into a chunk buffer, and the MFMA fragment maps (A: lane m + 16 k, B: lane n + 16 k,
+// C: lane n + 16 (m / 4), element m % 4) applied to a_frag / b_base / store_c.
+int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t rows, int64_t length,
+                      int64_t row_stride, int orig, int new_, int width, int64_t out_len,
+                      const int32_t* tap_lo, int tap_span, int vec_ok) {
+  using namespace rsm;
+  const int n_tiles = (new_ + 15) / 16;
+  const int ks = pick_ks(tap_span);
+  if (ks == 0) return -2;
+  Geom g{};
+  g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
+  g.orig = orig; g.new_ = new_; g.width = width; g.taps = 2 * width + orig;
+  g.vec_in = vec_ok && (row_stride % 4 == 0);
+  g.vec_out = vec_ok && (out_len % 4 == 0) && (new_ % 4 == 0);
+  const int64_t nq = (out_len + new_ - 1) / new_;
+  const int max_cw = max_compute_waves(ks);
+  for (int pt0 = 0; pt0 < n_tiles; pt0 += max_cw) {
+    g.pt0 = pt0;
+    g.n_pt = n_tiles - pt0 < max_cw ? n_tiles - pt0 : max_cw;
+    int max_lo = 0;
+    for (int t = 0; t < g.n_pt; ++t) { g.tap_lo[t] = tap_lo[pt0 + t]; if (g.tap_lo[t] > max_lo) max_lo = g.tap_lo[t]; }
+    int qg = max_cw / g.n_pt;
+    while (qg > 1 && ((int64_t)kQPerGroup * (qg - 1) >= nq ||
+                      2 * (size_t)buf_floats_needed(kQPerGroup * qg, orig, g.taps, max_lo, ks) * 4 > 160 * 1024)) --qg;
+    g.qg = qg;
+    const int qc = kQPerGroup * qg;
+    g.buf_floats = buf_floats_needed(qc, orig, g.taps, max_lo, ks);
+    g.chunks_per_row = (int)((nq + qc - 1) / qc);
+    g.n_chunks = rows * g.chunks_per_row;
+    std::vector<float> buf(g.buf_floats);
+    for (int64_t cid = 0; cid < g.n_chunks; ++cid) {
+      const int64_t row = cid / g.chunks_per_row;
+      const int64_t qc0 = (cid - row * g.chunks_per_row) * qc;
+      const float* wrow = wav + row * row_stride;
+      const int64_t a0 = chunk_a0(g, qc0);
+      for (int j = 0; j < g.buf_floats / 4; ++j) {
+        const F4 v = load_piece(g, wrow, a0, j);
+        buf[4 * j] = v.x; buf[4 * j + 1] = v.y; buf[4 * j + 2] = v.z; buf[4 * j + 3] = v.w;
+      }
+      const int shift = (int)((qc0 * orig - width) - a0);
+      for (int w = 0; w < g.n_pt * qg; ++w) {
+        const int pt_l = w % g.n_pt, qgi = w / g.n_pt, pt = pt0 + pt_l, lo = g.tap_lo[pt_l];
+        for (int half = 0; half < 2; ++half) {
+          const int qt = 2 * qgi + half;
+          float Cm[16][16] = {};
+          for (int kk = 0; kk < ks; ++kk)
+            for (int m = 0; m < 16; ++m)
+              for (int n = 0; n < 16; ++n)
+                for (int k = 0; k < 4; ++k) {
+                  const int bidx = b_base(g, qt, lo, ks, shift, n + 16 * k) + kk;
+                  if (bidx < 0 || bidx >= g.buf_floats) return -3;   // read outside the chunk buffer
+                  Cm[m][n] += a_frag(g, kern, pt, lo, ks, kk, m + 16 * k) * buf[bidx];
+                }
+          for (int lane = 0; lane < 64; ++lane) {
+            const int n = lane & 15, gq = lane >> 4;
+            store_c(g, out + row * out_len, qc0, qt, pt, lane, Cm[4 * gq][n], Cm[4 * gq + 1][n], Cm[4 * gq + 2][n],
+                    Cm[4 * gq + 3][n]);
+          }
+        }
+      }
+    }
+  }
   return 0;
 }
 

@@ -80,20 +80,50 @@ def sim_mel_generic(x, window_padded, bands, desc):
     return np.swapaxes(out, -1, -2)
 
 
-def sim_mel400(x, window, bands, scale=1.0):
+def _sim_fft400(x, window, bands, scale, epi, db=None, gmax=None, rows_per_group=1, power=2.0, out_width=None):
     x = np.ascontiguousarray(x, dtype=np.float32)
     rows, length = x.shape
     w = np.ascontiguousarray(window, dtype=np.float32)
     tw = np.ascontiguousarray(_host.twiddle_table(400))
     T = _host.frame_count(length, 400, 160, True)
-    out = np.zeros((rows, T, bands.n_mels), dtype=np.float32)
+    out = np.zeros((rows, T, out_width), dtype=np.float32)
     f = sim().sim_melspec400
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                  C.c_int, C.c_float]
-    rc = f(fptr(x), fptr(w), fptr(tw), C.cast(C.byref(bands.struct), C.c_void_p), fptr(out), rows, length, length,
-           T, scale)
+                  C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
+    dbv = None if db is None else fptr(np.ascontiguousarray(db, dtype=np.float32))
+    rc = f(fptr(x), fptr(w), fptr(tw), None if bands is None else C.cast(C.byref(bands.struct), C.c_void_p),
+           fptr(out), rows, length, length, T, scale, epi, dbv, None if gmax is None else fptr(gmax),
+           rows_per_group, power)
     assert rc == 0
     return np.swapaxes(out, -1, -2)
+
+
+def sim_mel400(x, window, bands, scale=1.0):
+    return _sim_fft400(x, window, bands, scale, 0, out_width=bands.n_mels)
+
+
+def sim_mel400_db(x, window, bands, multiplier, amin, db_multiplier, gmax, rows_per_group, scale=1.0):
+    """gmax: float32 array pre-filled with -inf, max-reduced in place."""
+    return _sim_fft400(x, window, bands, scale, 1, db=[multiplier, amin, multiplier * db_multiplier], gmax=gmax,
+                       rows_per_group=rows_per_group, out_width=bands.n_mels)
+
+
+def sim_spec400(x, window, power, scale=1.0):
+    return _sim_fft400(x, window, None, scale, 2, power=power, out_width=201)
+
+
+def sim_mfcc_dct_mfma(mel_fm, dct, log_mode, group_max=None, vec_per_group=1, top_db=-1.0):
+    """mel_fm: (n_vec, n_mels) frame-major; dct: (n_mels, n_mfcc)."""
+    mel_fm = np.ascontiguousarray(mel_fm, dtype=np.float32)
+    dct = np.ascontiguousarray(dct, dtype=np.float32)
+    n_vec, n_mels = mel_fm.shape
+    n_mfcc = dct.shape[1]
+    out = np.zeros((n_vec, n_mfcc), dtype=np.float32)
+    f = sim().sim_mfcc_dct_mfma
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_float]
+    gm = None if group_max is None else fptr(np.ascontiguousarray(group_max, dtype=np.float32))
+    assert f(fptr(mel_fm), fptr(dct), fptr(out), n_vec, n_mels, n_mfcc, log_mode, gm, vec_per_group, top_db) == 0
+    return out
 
 
 def sim_resample(x, kernel, orig, new, width, qt=None, use_lds=1):
@@ -108,6 +138,20 @@ def sim_resample(x, kernel, orig, new, width, qt=None, use_lds=1):
     f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_int] * 3 + [C.c_int64, C.c_int, C.c_int]
     assert f(fptr(x), fptr(k), fptr(out), rows, length, length, orig, new, width, out_len, qt, use_lds) == 0
     return out
+
+
+def sim_resample_mfma(x, kernel, orig, new, width, vec_ok=1):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, length = x.shape
+    k = np.ascontiguousarray(kernel, dtype=np.float32).reshape(new, -1)
+    out_len = -(-new * length // orig)
+    out = np.full((rows, out_len), np.nan, dtype=np.float32)
+    lo, span = _host.resample_band_table(k)
+    lo = np.ascontiguousarray(lo, dtype=np.int32)
+    f = sim().sim_resample_mfma
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_int] * 3 + [C.c_int64, C.c_void_p, C.c_int, C.c_int]
+    rc = f(fptr(x), fptr(k), fptr(out), rows, length, length, orig, new, width, out_len, fptr(lo), span, vec_ok)
+    return rc, out
 
 
 def sim_lfilter(x, a, b, clamp=True):

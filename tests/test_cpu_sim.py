@@ -119,6 +119,14 @@ def test_sim_resample(case):
     assert peak_rel_err(got, exp) <= 1e-5
     got2 = S.sim_resample(x2, k.numpy(), o // g, n // g, width, qt=3, use_lds=0).reshape(exp.shape)
     assert peak_rel_err(got2, exp) <= 1e-5
+    # matrix-core kernel (banded taps, permuted contraction order, double-buffered chunks)
+    for vec_ok in (1, 0):
+        rc, got3 = S.sim_resample_mfma(x2, k.numpy(), o // g, n // g, width, vec_ok)
+        if rc == -2:
+            continue          # band wider than 448 taps: the scalar kernel serves it
+        assert rc == 0
+        assert not np.isnan(got3).any()          # every output written exactly by some lane
+        assert peak_rel_err(got3.reshape(exp.shape), exp) <= 1e-5
 
 
 @pytest.mark.parametrize("case", ref_runs().select("lfilter"), ids=lambda c: f"{c['id']}-{c.get('tag')}")
@@ -193,3 +201,73 @@ def test_sim_fftconvolve(case):
     got = S.sim_fftconv(x.reshape(-1, nx), y.reshape(-1, ny), start, out_len, rmap(x), rmap(y), rows)
     exp = rr.output(case)
     assert peak_rel_err(got.reshape(exp.shape), exp) <= 1e-5
+
+
+def _headline_setup(rows=3, L=2537, seed=5):
+    rng = np.random.default_rng(seed)
+    x = np.clip(0.5 * rng.standard_normal((rows, L)), -1, 1).astype(np.float32)
+    w = O.hann_window(400).astype(np.float32)
+    fb = O.melscale_fbanks(201, 0.0, 8000.0, 80, 16000).astype(np.float32)
+    return x, w, fb
+
+
+@pytest.mark.parametrize("power", [2.0, 1.0, 3.0])
+@pytest.mark.parametrize("L", [2537, 1600, 1283])   # ragged tails: 16, 11, 9 frames (6 per tile)
+def test_sim_spec400_epilogue(power, L):
+    """Spectrogram epilogue of the radix-20x20 kernel (EPI400_SPEC): frame-contiguous rows staged
+    with the global 16-B phase, ragged head/tail stores."""
+    x, w, _ = _headline_setup(rows=3, L=L)
+    got = S.sim_spec400(x, w, power)
+    exp = O.spectrogram(x.astype(np.float64), 0, w.astype(np.float64), 400, 160, 400, power, False)
+    assert got.shape == exp.shape
+    assert peak_rel_err(got, exp) <= TOL
+
+
+def test_sim_mel400_db_epilogue_and_group_max():
+    x, w, fb = _headline_setup(rows=4, L=2100)
+    x[1] *= 1e-3                      # different dynamic range per cut-off group
+    bands = S.HostBands(fb)
+    gmax = np.full((2,), -np.inf, dtype=np.float32)
+    got = S.sim_mel400_db(x, w, bands, 10.0, 1e-10, 0.0, gmax, rows_per_group=2)
+    mel = O.mel_spectrogram(x.astype(np.float64), w.astype(np.float64), fb.astype(np.float64), 400, 160)
+    exp = O.amplitude_to_db(mel, 10.0, 1e-10, 0.0)
+    assert np.abs(got - exp).max() <= 2e-4          # dB absolute
+    np.testing.assert_allclose(gmax, exp.reshape(2, -1).max(-1), atol=2e-4)
+
+
+@pytest.mark.parametrize("n_mels,n_mfcc,log_mode", [(80, 40, 2), (80, 40, 0), (64, 13, 1), (128, 64, 2), (40, 40, 2), (36, 20, 0)])
+def test_sim_mfcc_dct_mfma_fragments(n_mels, n_mfcc, log_mode):
+    """Index math of the matrix-core DCT (fragment tables, permuted contraction order, C layout)."""
+    rng = np.random.default_rng(n_mels + n_mfcc)
+    n_vec = 37                                  # ragged last tile of 16 frames
+    dct = O.create_dct(n_mfcc, n_mels, "ortho").astype(np.float32)
+    if log_mode == 2:
+        y = (20 * rng.standard_normal((n_vec, n_mels)) - 30).astype(np.float32)
+        gmax = np.array([y[:20].max(), y[20:].max()], dtype=np.float32)
+        got = S.sim_mfcc_dct_mfma(y, dct, 2, gmax, 20, 30.0)
+        yc = y.astype(np.float64).copy()
+        yc[:20] = np.maximum(yc[:20], gmax[0] - 30.0)
+        yc[20:] = np.maximum(yc[20:], gmax[1] - 30.0)
+        exp = yc @ dct.astype(np.float64)
+    else:
+        p = (rng.standard_normal((n_vec, n_mels)) ** 2).astype(np.float32)
+        got = S.sim_mfcc_dct_mfma(p, dct, log_mode)
+        yy = 10 * np.log10(np.maximum(p.astype(np.float64), 1e-10)) if log_mode == 0 else np.log(p.astype(np.float64) + 1e-6)
+        exp = yy @ dct.astype(np.float64)
+    assert peak_rel_err(got, exp) <= 1e-5
+
+
+def test_sim_resample_mfma_kaiser_best_headline():
+    """BASELINE config 3 parameters (44.1k -> 16k kaiser_best: 160 phases x 815 taps, band 417):
+    10 phase tiles, KS = 112, one q-group; ragged length so the last chunk / q-tile are partial."""
+    o, n, g = 44100, 16000, 100
+    k, width = _host.sinc_resample_kernel(o, n, g, 64, 0.9475937167399596, "sinc_interp_kaiser", 14.769656459379492)
+    lo, span = _host.resample_band_table(k.numpy().reshape(n // g, -1))
+    assert width == 187 and k.shape[-1] == 815 and span <= 448 and lo.shape == (10,)
+    rng = np.random.default_rng(3)
+    x = np.clip(0.5 * rng.standard_normal((2, 20011)), -1, 1).astype(np.float32)
+    rc, got = S.sim_resample_mfma(x, k.numpy(), o // g, n // g, width)
+    assert rc == 0 and not np.isnan(got).any()
+    exp = O.apply_sinc_resample_kernel(x.astype(np.float64), o, n, g, k.numpy().astype(np.float64).reshape(n // g, -1), width)
+    assert got.shape == exp.shape
+    assert peak_rel_err(got, exp) <= 5e-6

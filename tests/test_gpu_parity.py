@@ -171,3 +171,110 @@ def test_empty_and_error_behaviour():
     y = F.resample(torch.randn(2, 1000, device="cuda"), 16000, 16000)
     assert y.shape == (2, 1000)
     assert F.resample(torch.randn(2, 1001, device="cuda"), 16000, 8000).shape == (2, 501)
+
+
+def _force_generic(fn):
+    import os
+    os.environ["AAMD_FORCE_GENERIC"] = "1"
+    try:
+        return fn()
+    finally:
+        del os.environ["AAMD_FORCE_GENERIC"]
+
+
+@pytest.mark.parametrize("power", [2.0, 1.0, 0.5])
+def test_spec400_fast_path_equals_generic_and_oracle(power):
+    """Spectrogram epilogue of the radix-20x20 kernel vs the generic Stockham kernel and the oracle."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    t = T.Spectrogram(n_fft=400, hop_length=160, power=power).cuda()
+    for L in (401, 560, 961, 1283, 1600, 16000, 16001, 48017):
+        x = torch.randn(3, L, device="cuda").clamp_(-1, 1)
+        fast = t(x)
+        gen = _force_generic(lambda: t(x))
+        assert fast.shape == gen.shape and fast.stride() == gen.stride()
+        e = (fast - gen).abs().max() / gen.abs().max()
+        assert float(e) <= 3e-6, (L, float(e))
+        if L <= 16001:
+            exp = O.spectrogram(x.cpu().numpy().astype(np.float64), 0, O.hann_window(400), 400, 160, 400, power, False)
+            assert peak_rel_err(fast.cpu().numpy(), exp) <= 1e-4, L
+
+
+@pytest.mark.parametrize("shape", [(6, 4000), (3, 2, 4000), (2, 2, 2, 2400), (4000,)])
+def test_mfcc_fused_db_path_equals_generic_and_oracle(shape):
+    """MFCC = mel kernel with fused dB + per-group max, then the matrix-core DCT: compared with
+    the unfused generic kernels and the float64 oracle, with silence so that top_db clamps."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(7)
+    x = (0.5 * torch.randn(*shape, generator=g)).clamp_(-1, 1)
+    x[..., 1000:1700] = 0.0                          # digital silence -> -100 dB -> clamped
+    if x.dim() > 1:
+        x[0] *= 1e-3
+    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
+    fast = m(x.cuda())
+    gen = _force_generic(lambda: m(x.cuda()))
+    assert fast.shape == gen.shape and fast.stride() == gen.stride()
+    assert float((fast - gen).abs().max() / gen.abs().max()) <= 2e-5
+    fb = O.melscale_fbanks(201, 0.0, 8000.0, 80, 16000)
+    exp = O.mfcc(x.numpy().astype(np.float64), O.hann_window(400), fb, O.create_dct(40, 80, "ortho"), 400, 160)
+    assert peak_rel_err(fast.cpu().numpy(), exp) <= 1e-4
+
+
+def test_mfcc_headline_shape_properties():
+    """BASELINE config 4 (512 x 10 s) at full size: per-item cut-offs ((B,1,L) input) make the
+    batched result equal the item-wise one; the (B,L) input shares ONE cut-off."""
+    import audio_amd.transforms as T
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = (0.5 * torch.randn(512, 160000, device="cuda", generator=g)).clamp_(-1, 1)
+    x[5] *= 1e-4
+    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
+    y3 = m(x[:, None, :])
+    assert y3.shape == (512, 1, 40, 1001) and torch.isfinite(y3).all()
+    for b in (0, 5, 511):
+        yb = m(x[b:b + 1, None, :])
+        assert float((yb[0] - y3[b]).abs().max()) <= 1e-4 * float(y3[b].abs().max())
+    y2 = m(x)
+    assert y2.shape == (512, 40, 1001) and y2.stride() == (40040, 1, 40)
+    # one global cut-off: the quiet item is clamped in the 2-D call but not in the 3-D call
+    assert float((y2[5] - y3[5, 0]).abs().max()) > 1.0
+    assert float((y2[0] - y3[0, 0]).abs().max()) <= 1e-4 * float(y2[0].abs().max())
+
+
+@pytest.mark.parametrize("rates", [(44100, 16000, "kaiser_best"), (44100, 16000, "default"), (48000, 44100, "kaiser_best"),
+                                   (16000, 44100, "default"), (8000, 16000, "default"), (48000, 16000, "kaiser_best")])
+def test_resample_matrix_core_path_equals_scalar_and_oracle(rates):
+    """Banded MFMA resampler vs the scalar polyphase kernel and the float64 oracle, ragged lengths."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    o, n, kind = rates
+    kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=64, rolloff=0.9475937167399596,
+              beta=14.769656459379492) if kind == "kaiser_best" else {}
+    r = T.Resample(o, n, **kw).cuda()
+    g = torch.Generator().manual_seed(11)
+    for shape in [(3, 20011), (2, 2, 7001), (1, 501)]:
+        x = (0.5 * torch.randn(*shape, generator=g)).clamp_(-1, 1)
+        fast = r(x.cuda())
+        gen = _force_generic(lambda: r(x.cuda()))
+        assert fast.shape == gen.shape
+        assert float((fast - gen).abs().max()) <= 2e-6 * max(float(gen.abs().max()), 1e-3)
+        exp = O.resample(x.numpy().astype(np.float64), o, n, **kw)
+        assert fast.shape == exp.shape
+        assert peak_rel_err(fast.cpu().numpy(), exp) <= 1e-5
+
+
+def test_resample_headline_shape_properties():
+    """BASELINE config 3 shape at 1/64 of the batch (16 x stereo x 30 s, 44.1k -> 16k kaiser_best):
+    output length, batch consistency, linearity and DC gain 1 (each phase of the table sums to 1)."""
+    import audio_amd.transforms as T
+    r = T.Resample(44100, 16000, resampling_method="sinc_interp_kaiser", lowpass_filter_width=64,
+                   rolloff=0.9475937167399596, beta=14.769656459379492).cuda()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (0.5 * torch.randn(16, 2, 1323000, device="cuda", generator=g)).clamp_(-1, 1)
+    y = r(x)
+    assert y.shape == (16, 2, 480000) and torch.isfinite(y).all()
+    assert torch.equal(r(x[3:4])[0], y[3])
+    y2 = r(0.5 * x[:2])
+    assert float((y2 - 0.5 * y[:2]).abs().max()) <= 1e-6
+    dc = r(torch.ones(1, 100000, device="cuda"))
+    assert float((dc[0, 200:-200] - 1.0).abs().max()) <= 1e-5

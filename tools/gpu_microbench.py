@@ -48,17 +48,35 @@ def main():
         if "spec" in what:
             x = (0.5 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
             sp = T.Spectrogram(n_fft=400, hop_length=160).to(dev)
+            us = timeit(lambda: sp(x), 5, 50)
+            by = 256 * 160000 * 4 + 256 * 1001 * 201 * 4
+            print(f"spectrogram400 fast: {us:9.1f} us  {by / us / 1e3:8.1f} GB/s  frac {by / us / 1e3 / 8000:.3f}")
+            os.environ["AAMD_FORCE_GENERIC"] = "1"
             print(f"spectrogram generic 400/160: {timeit(lambda: sp(x), 2, 5):9.1f} us")
+            del os.environ["AAMD_FORCE_GENERIC"]
         if "mfcc" in what:
             x = (0.5 * torch.randn(512, 160000, device=dev)).clamp_(-1, 1)
             m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).to(dev)
-            print(f"mfcc b=512: {timeit(lambda: m(x), 3, 20):9.1f} us")
+            us = timeit(lambda: m(x), 3, 20)
+            by = 512 * 160000 * 4 + 512 * 1001 * 40 * 4
+            print(f"mfcc b=512 (2-D, one cut-off): {us:9.1f} us  algorithmic {by / us / 1e3:8.1f} GB/s  frac {by / us / 1e3 / 8000:.3f}")
+            x3 = x[:, None, :]
+            us = timeit(lambda: m(x3), 3, 20)
+            print(f"mfcc b=512 (3-D, per-item cut-off): {us:9.1f} us")
         if "resample" in what:
             x = (0.5 * torch.randn(16, 2, 1323000, device=dev)).clamp_(-1, 1)
             r = T.Resample(44100, 16000, resampling_method="sinc_interp_kaiser", lowpass_filter_width=64,
                            rolloff=0.9475937167399596, beta=14.769656459379492).to(dev)
-            us = timeit(lambda: r(x), 1, 3)
-            print(f"resample kaiser_best 16x2x30s: {us:9.1f} us  ({16 * 30 / (us * 1e-6):.0f} clip-s/s)")
+            x = (0.5 * torch.randn(128, 2, 1323000, device=dev)).clamp_(-1, 1)     # cfg3 per-GPU shard (1/8)
+            us = timeit(lambda: r(x), 2, 10)
+            fl = 128 * 2 * 480000 * 373 * 2
+            by = x.numel() * 4 + 128 * 2 * 480000 * 4
+            print(f"resample kaiser_best 128x2x30s (MFMA): {us:9.1f} us  ({128 * 30 / (us * 1e-6):.0f} clip-s/s) "
+                  f"{fl / us / 1e6:.1f} algorithmic TFLOP/s (frac {fl / us / 1e6 / 157.3:.3f})  {by / us / 1e3:.0f} GB/s")
+            os.environ["AAMD_FORCE_GENERIC"] = "1"
+            us = timeit(lambda: r(x[:16]), 1, 3)
+            del os.environ["AAMD_FORCE_GENERIC"]
+            print(f"resample kaiser_best 16x2x30s scalar kernel: {us:9.1f} us")
         if "lfilter" in what:
             x = (torch.rand(32, 8, 480000, device=dev) - 0.5)
             a = torch.tensor([1.0, -1.2, 0.5], device=dev)
