@@ -334,7 +334,7 @@ int aamd_mfcc_dct_f32(const float* mel, const float* dct, float* out, int64_t n_
   AAMD_CHECK_ARG(vec_per_group >= 1 || group_max == nullptr, "vec_per_group must be >= 1");
   if (n_vec == 0) return AAMD_OK;
   const int nt = (n_mfcc + 15) / 16;
-  if (n_mels % 4 == 0 && nt <= 4 && reinterpret_cast<uintptr_t>(mel) % 16 == 0 &&
+  if (n_mels % 4 == 0 && n_mels <= 16 * kDctMaxChunks && nt <= 4 && reinterpret_cast<uintptr_t>(mel) % 16 == 0 &&
       reinterpret_cast<uintptr_t>(out) % 16 == 0 && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
     const size_t flds = (size_t)dct_frag_floats(n_mels, n_mfcc) * sizeof(float);
     if (flds <= 64 * 1024) {

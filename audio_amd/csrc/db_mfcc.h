@@ -20,6 +20,7 @@ AAMD_HD float mfcc_log(float v, int log_mode, float cut) {
 
 // fragment geometry of the matrix-core DCT kernel below (shared with tests/cpu_sim)
 constexpr int kDctFramesPerTile = 16;
+constexpr int kDctMaxChunks = 8;        // n_mels <= 128 on the matrix-core path
 
 AAMD_HD int dct_frag_floats(int n_mels, int n_mfcc) {
   const int kc = (n_mels + 15) / 16, nt = (n_mfcc + 15) / 16;
@@ -183,21 +184,30 @@ mfcc_dct_mfma_kernel(const float* __restrict__ mel, const float* __restrict__ dc
     f32x4 acc[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    for (int c = 0; c < kc; ++c) {
-      float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (vok && 16 * c + 4 * g < n_mels) {
-        const F4 m4 = *reinterpret_cast<const F4*>(row + 16 * c);
-        y[0] = mfcc_log(m4.x, log_mode, cut);
-        y[1] = mfcc_log(m4.y, log_mode, cut);
-        y[2] = mfcc_log(m4.z, log_mode, cut);
-        y[3] = mfcc_log(m4.w, log_mode, cut);
-      }
+    // all of the frame's mel row first (kc <= kDctMaxChunks loads in flight per lane), then the math
+    F4 m4[kDctMaxChunks];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float* af = smem_dct + ((nt * kc + c) * 4) * 64 + lane;
+    for (int c = 0; c < kDctMaxChunks; ++c) {
+      m4[c] = F4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (c < kc && vok && 16 * c + 4 * g < n_mels) m4[c] = *reinterpret_cast<const F4*>(row + 16 * c);
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[64 * j], y[j], acc[nt], 0, 0, 0);
+    for (int c = 0; c < kDctMaxChunks; ++c) {
+      if (c < kc) {
+        float y[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (vok && 16 * c + 4 * g < n_mels) {
+          y[0] = mfcc_log(m4[c].x, log_mode, cut);
+          y[1] = mfcc_log(m4[c].y, log_mode, cut);
+          y[2] = mfcc_log(m4[c].z, log_mode, cut);
+          y[3] = mfcc_log(m4[c].w, log_mode, cut);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float* af = smem_dct + ((nt * kc + c) * 4) * 64 + lane;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[64 * j], y[j], acc[nt], 0, 0, 0);
+        }
       }
     }
     if (vok) {

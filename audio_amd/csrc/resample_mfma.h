@@ -138,13 +138,26 @@ resample_mfma_kernel(Geom g, const float* __restrict__ wav, const float* __restr
       const int64_t qc0 = (cid - row * g.chunks_per_row) * qc;
       const float* wrow = wav + row * g.row_stride;
       const int64_t a0 = chunk_a0(g, qc0);
-      constexpr int U = 8;
+      // half a chunk in flight at once (U x 16 B per lane; the loader branch owns its registers):
+      // with 8 the two loader waves were latency-bound and the compute waves idled at the barrier
+      constexpr int U = 16;
+      // interior chunk (every sample exists, 16-B aligned): branch-free batches of U loads per lane
+      const bool interior = g.vec_in && a0 >= 0 && a0 + g.buf_floats <= g.length;
       for (int j0 = lt; j0 < pieces; j0 += 64 * kLoaderWaves * U) {
         F4 v[U];
+        if (interior) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = j0 + 64 * kLoaderWaves * u;
-          if (j < pieces) v[u] = load_piece(g, wrow, a0, j);
+          for (int u = 0; u < U; ++u) {
+            int j = j0 + 64 * kLoaderWaves * u;
+            if (j >= pieces) j = pieces - 1;
+            v[u] = *reinterpret_cast<const F4*>(wrow + a0 + 4 * j);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int j = j0 + 64 * kLoaderWaves * u;
+            if (j < pieces) v[u] = load_piece(g, wrow, a0, j);
+          }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
