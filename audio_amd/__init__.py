@@ -7,5 +7,6 @@ Arithmetic runs in hand-written HIP kernels loaded from ``audio_amd/lib/libaudio
 (C ABI: include/audio_amd.h).  No CPU fallback exists.
 """
 from . import functional, transforms  # noqa: F401
+from . import _ops  # noqa: F401  (registers torch.ops.audio_amd.*)
 
 __version__ = "0.1.0"

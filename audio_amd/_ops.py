@@ -1,0 +1,127 @@
+"""``torch.ops.audio_amd.*`` -- the hot path registered as PyTorch custom ops.
+
+The reference reaches native code through operator registration: ``torch.ops.load_library`` runs
+``STABLE_TORCH_LIBRARY_FRAGMENT(torchaudio, m){ m.def(schema) }`` / ``..._IMPL(torchaudio, CUDA, m)``
+(src/libtorchaudio/lfilter.cpp:118-138, src/torchaudio/_extension/utils.py:50-56).  This module is the
+same mechanism from the Python side (``torch.library``): schemas in a new namespace, implementations
+under the CUDA dispatch key (ROCm tensors dispatch there) that call libaudio_amd.so's C ABI, and
+Meta ("fake") implementations so the ops trace / export.  There is deliberately NO CPU-key
+implementation: a CPU tensor fails in the dispatcher ("no kernel for CPU"), loudly.
+
+Schemas follow SURVEY.md 8(b).  ``norm_mode``: 0 none, 1 "frame_length", 2 "window".
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import _host
+from . import functional as F
+
+_NORM = {0: False, 1: "frame_length", 2: "window"}
+
+_DEF = torch.library.Library("audio_amd", "DEF")
+_DEF.define("spectrogram(Tensor waveform, Tensor window, int pad, int n_fft, int hop_length, int win_length, "
+            "float? power, int norm_mode, bool center, str pad_mode, bool onesided) -> Tensor")
+_DEF.define("mel_spectrogram(Tensor waveform, Tensor window, Tensor fb, int pad, int n_fft, int hop_length, "
+            "int win_length, float power, int norm_mode, bool center, str pad_mode) -> Tensor")
+_DEF.define("mfcc(Tensor waveform, Tensor window, Tensor fb, Tensor dct_mat, int pad, int n_fft, int hop_length, "
+            "int win_length, float power, int norm_mode, bool center, str pad_mode, bool log_mels, float top_db) -> Tensor")
+_DEF.define("amplitude_to_DB(Tensor x, float multiplier, float amin, float db_multiplier, float? top_db) -> Tensor")
+_DEF.define("resample_apply(Tensor waveform, Tensor kernel, int orig_freq, int new_freq, int gcd, int width) -> Tensor")
+_DEF.define("lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, bool clamp, bool batching) -> Tensor")
+_DEF.define("lfilter_cascade(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, bool clamp) -> Tensor")
+_DEF.define("fftconvolve(Tensor x, Tensor y, str mode) -> Tensor")
+
+_CUDA = torch.library.Library("audio_amd", "IMPL", "CUDA")
+_META = torch.library.Library("audio_amd", "IMPL", "Meta")
+
+
+def _spectrogram(waveform, window, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode, onesided):
+    return F.spectrogram(waveform, pad, window, n_fft, hop_length, win_length, power, _NORM[norm_mode], center,
+                         pad_mode, onesided)
+
+
+def _mel_spectrogram(waveform, window, fb, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode):
+    out = F._melspectrogram(waveform, pad, window, fb, n_fft, hop_length, win_length, power, _NORM[norm_mode], center,
+                            pad_mode)
+    return out.view(tuple(waveform.shape[:-1]) + out.shape[-2:]).transpose(-1, -2)
+
+
+def _mfcc(waveform, window, fb, dct_mat, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode,
+          log_mels, top_db):
+    return F._mfcc(waveform, pad, window, fb, dct_mat, n_fft, hop_length, win_length, power, _NORM[norm_mode], center,
+                   pad_mode, log_mels, top_db)
+
+
+_CUDA.impl("spectrogram", _spectrogram)
+_CUDA.impl("mel_spectrogram", _mel_spectrogram)
+_CUDA.impl("mfcc", _mfcc)
+_CUDA.impl("amplitude_to_DB", F.amplitude_to_DB)
+_CUDA.impl("resample_apply", F._apply_sinc_resample_kernel)
+_CUDA.impl("lfilter", F.lfilter)
+_CUDA.impl("lfilter_cascade", F.biquad_cascade)
+_CUDA.impl("fftconvolve", F.fftconvolve)
+
+
+# ---- Meta implementations: shapes / strides only ---------------------------------------------
+
+def _stft_frames(length, pad, n_fft, hop, center):
+    return _host.frame_count(length, n_fft, hop, center, pad)
+
+
+def _frame_major_view(waveform, n_out, T, dtype=None):
+    lead = tuple(waveform.shape[:-1])
+    rows = 1
+    for d in lead:
+        rows *= d
+    out = waveform.new_empty((rows, T, n_out), dtype=dtype or waveform.dtype)
+    return out.view(lead + (T, n_out)).transpose(-1, -2)
+
+
+def _spectrogram_meta(waveform, window, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode, onesided):
+    T = _stft_frames(waveform.shape[-1], pad, n_fft, hop_length, center)
+    n_freq = n_fft // 2 + 1 if onesided else n_fft
+    return _frame_major_view(waveform, n_freq, T, torch.complex64 if power is None else None)
+
+
+def _mel_meta(waveform, window, fb, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode):
+    return _frame_major_view(waveform, fb.shape[1], _stft_frames(waveform.shape[-1], pad, n_fft, hop_length, center))
+
+
+def _mfcc_meta(waveform, window, fb, dct_mat, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode,
+               log_mels, top_db):
+    return _frame_major_view(waveform, dct_mat.shape[1], _stft_frames(waveform.shape[-1], pad, n_fft, hop_length, center))
+
+
+def _resample_meta(waveform, kernel, orig_freq, new_freq, gcd, width):
+    orig, new = int(orig_freq) // gcd, int(new_freq) // gcd
+    return waveform.new_empty(tuple(waveform.shape[:-1]) + (int(math.ceil(new * waveform.shape[-1] / orig)),))
+
+
+def _lfilter_meta(waveform, a_coeffs, b_coeffs, clamp, batching):
+    if a_coeffs.ndim > 1 and not batching:
+        return waveform.new_empty(tuple(waveform.shape[:-1]) + (a_coeffs.shape[0], waveform.shape[-1]))
+    return torch.empty_like(waveform)
+
+
+def _fftconvolve_meta(x, y, mode):
+    F._check_shape_compatible(x, y)
+    F._check_convolve_mode(mode)
+    nx, ny = x.shape[-1], y.shape[-1]
+    n = {"full": nx + ny - 1, "same": nx, "valid": max(nx, ny) - min(nx, ny) + 1}[mode]
+    lead = tuple(max(a, b) for a, b in zip(x.shape[:-1], y.shape[:-1]))
+    return x.new_empty(lead + (n,))
+
+
+_META.impl("spectrogram", _spectrogram_meta)
+_META.impl("mel_spectrogram", _mel_meta)
+_META.impl("mfcc", _mfcc_meta)
+_META.impl("amplitude_to_DB", lambda x, multiplier, amin, db_multiplier, top_db: torch.empty_like(x))
+_META.impl("resample_apply", _resample_meta)
+_META.impl("lfilter", _lfilter_meta)
+_META.impl("lfilter_cascade", lambda waveform, a_coeffs, b_coeffs, clamp: torch.empty_like(waveform))
+_META.impl("fftconvolve", _fftconvolve_meta)

@@ -1,0 +1,166 @@
+"""Batch sharding of the DSP hot path across the GPUs of one node: one process per GPU,
+``torch.distributed`` over RCCL (backend ``"nccl"`` on ROCm) / xGMI.
+
+Every op on the path is independent per (clip, channel) sequence (the reference only
+*reshapes* the batch: functional.py:119-120, :1421, filtering.py:1089-1090), so a batch shards by
+contiguous row ranges with constants (window, fb, dct, sinc table, coefficients, RIR) replicated.
+There is NO data-path collective except:
+
+  * ``scatter_batch`` / ``gather_batch`` -- moving a batch that was born on one rank (point-to-point
+    sends under the hood: xGMI is a link mesh, not a switch, so the root's 7 links work in parallel);
+  * MFCC on a ``(batch, time)`` input: ``amplitude_to_DB(top_db=80)`` takes its cut-off from the
+    maximum over the WHOLE batch (functional.py:393-402), i.e. one fp32 ``all_reduce(MAX)`` between
+    the mel/dB kernel and the clamp + DCT kernel.  ``ShardedTransform`` installs it through
+    ``MFCC.group_max_hook``.
+
+The same code runs on the ``gloo`` backend with CPU tensors (tests/test_distributed.py, world size 2).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+__all__ = ["init_from_env", "shard_range", "scatter_batch", "gather_batch", "all_gather_batch",
+           "allreduce_group_max", "ShardedTransform"]
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, torch.device]:
+    """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (as set by
+    ``python -m torch.distributed.run``); returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+        backend = backend or ("nccl" if use_gpu else "gloo")
+        kw = {"device_id": device} if backend == "nccl" else {}
+        dist.init_process_group(backend, **kw)
+    return rank, world, device
+
+
+def _world(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_range(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous split of ``n_rows`` rows: the first ``n_rows % world`` ranks get one extra row."""
+    base, extra = divmod(n_rows, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def scatter_batch(batch: Optional[Tensor], shape: Tuple[int, ...], device, root: int = 0, group=None,
+                  dtype=torch.float32) -> Tensor:
+    """Rank ``root`` holds ``batch`` of ``shape`` (leading dim = rows to shard); every rank returns its
+    contiguous shard.  Ragged splits are sent as point-to-point messages (no padding traffic)."""
+    rank, world = _world(group)
+    lo, hi = shard_range(shape[0], world, rank)
+    if world == 1:
+        return batch.to(device)
+    local = torch.empty((hi - lo,) + tuple(shape[1:]), dtype=dtype, device=device)
+    if rank == root:
+        reqs = []
+        for r in range(world):
+            a, b = shard_range(shape[0], world, r)
+            if r == root:
+                local.copy_(batch[a:b])
+            elif b > a:
+                reqs.append(dist.isend(batch[a:b].contiguous(), dst=r, group=group))
+        for q in reqs:
+            q.wait()
+    elif hi > lo:
+        dist.recv(local, src=root, group=group)
+    return local
+
+
+def gather_batch(local: Tensor, n_rows: int, root: int = 0, group=None) -> Optional[Tensor]:
+    """Inverse of ``scatter_batch``: rank ``root`` returns the (n_rows, ...) concatenation."""
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    local = local.contiguous()
+    if rank == root:
+        out = torch.empty((n_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        reqs = []
+        for r in range(world):
+            a, b = shard_range(n_rows, world, r)
+            if r == root:
+                out[a:b].copy_(local)
+            elif b > a:
+                reqs.append(dist.irecv(out[a:b], src=r, group=group))
+        for q in reqs:
+            q.wait()
+        return out
+    lo, hi = shard_range(n_rows, world, rank)
+    if hi > lo:
+        dist.send(local, dst=root, group=group)
+    return None
+
+
+def all_gather_batch(local: Tensor, n_rows: int, group=None) -> Tensor:
+    """Every rank ends up with the full (n_rows, ...) result (equal or ragged shards)."""
+    rank, world = _world(group)
+    if world == 1:
+        return local
+    parts = []
+    for r in range(world):
+        a, b = shard_range(n_rows, world, r)
+        parts.append(torch.empty((b - a,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device))
+    dist.all_gather(parts, local.contiguous(), group=group) if len({p.shape for p in parts}) == 1 else \
+        _ragged_all_gather(parts, local.contiguous(), rank, world, group)
+    return torch.cat(parts, 0)
+
+
+def _ragged_all_gather(parts, local, rank, world, group):
+    parts[rank].copy_(local)
+    for r in range(world):
+        if parts[r].numel():
+            dist.broadcast(parts[r], src=r, group=group)
+
+
+def allreduce_group_max(group_max: Tensor, group=None) -> None:
+    """In-place MAX over ranks of the per-group dB maxima (the batch-global top_db cut-off)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(group_max, op=dist.ReduceOp.MAX, group=group)
+
+
+class ShardedTransform:
+    """Apply ``transform`` to this rank's shard of a batch.
+
+    ``transform`` is any of the drop-in modules.  If it exposes ``group_max_hook`` (MFCC) and the
+    input is 2-D ``(batch, time)`` -- the reference then uses ONE cut-off for the whole batch -- the
+    hook is set to the MAX all-reduce so the sharded result equals the unsharded one bit for bit in
+    the clamp decision.  Inputs with a channel dim have per-item cut-offs and need no exchange.
+    """
+
+    def __init__(self, transform: Callable[[Tensor], Tensor], group=None):
+        self.transform = transform
+        self.group = group
+
+    def __call__(self, local: Tensor) -> Tensor:
+        hooked = hasattr(self.transform, "group_max_hook") and local.dim() == 2
+        if hooked:
+            prev = self.transform.group_max_hook
+            self.transform.group_max_hook = lambda gmax: allreduce_group_max(gmax, self.group)
+        try:
+            return self.transform(local)
+        finally:
+            if hooked:
+                self.transform.group_max_hook = prev
+
+    def run_from_root(self, batch: Optional[Tensor], shape: Tuple[int, ...], device, root: int = 0) -> Optional[Tensor]:
+        """scatter -> transform -> gather; returns the full result on ``root`` (None elsewhere)."""
+        local = scatter_batch(batch, shape, device, root, self.group)
+        out = self(local)
+        return gather_batch(out, shape[0], root, self.group)

@@ -253,6 +253,48 @@ def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_ff
     return out
 
 
+def _mfcc(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, dct_mat: Tensor, n_fft: int, hop_length: int,
+          win_length: int, power: float, normalized, center: bool, pad_mode: str, log_mels: bool, top_db: float,
+          db=(10.0, 1e-10, 0.0), group_max_hook=None) -> Tensor:
+    """MFCC.forward (transforms/_transforms.py:692-709) in two kernels: the mel kernel with
+    amplitude_to_DB and the per-cut-off-group maximum fused into its epilogue, then clamp + DCT-II
+    on the matrix cores.  ``group_max_hook(gmax)`` runs between them (audio_amd.distributed installs
+    the all-reduce(MAX) a batch-global cut-off needs when the batch is sharded)."""
+    lead = tuple(waveform.shape[:-1])
+    dev = waveform.device
+    dct = dct_mat.to(device=dev, dtype=torch.float32).contiguous()
+    n_mfcc = dct.shape[1]
+    L = _lib.lib()
+    if log_mels:
+        mel = _melspectrogram(waveform, pad, window, fb, n_fft, hop_length, win_length, power, normalized, center,
+                              pad_mode)                                  # (rows, T, n_mels) frame-major
+        rows, T, n_mels = mel.shape
+        out = torch.empty((rows, T, n_mfcc), dtype=torch.float32, device=dev)
+        if out.numel():
+            _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), rows * T, n_mels, n_mfcc,
+                                           1, None, 1, -1.0, _lib.current_stream(dev)))
+    else:
+        # amplitude_to_DB's cut-off groups: the mel tensor is (..., C?, n_mels, T); one cut-off per
+        # leading item of its (-1, C, n_mels, T) view (functional.py:393-402)
+        packed = waveform.shape[-2] if waveform.dim() > 1 else 1
+        n_rows = 1
+        for d in lead:
+            n_rows *= d
+        n_groups = max(n_rows // max(packed, 1), 1)
+        gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
+        mel = _melspectrogram(waveform, pad, window, fb, n_fft, hop_length, win_length, power, normalized, center,
+                              pad_mode, db=(db[0], db[1], db[2], gmax, max(packed, 1)))
+        rows, T, n_mels = mel.shape
+        out = torch.empty((rows, T, n_mfcc), dtype=torch.float32, device=dev)
+        if group_max_hook is not None:
+            group_max_hook(gmax)
+        if out.numel():
+            _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), rows * T, n_mels, n_mfcc,
+                                           2, gmax.data_ptr(), max(packed, 1) * T, float(top_db),
+                                           _lib.current_stream(dev)))
+    return out.view(lead + (T, n_mfcc)).transpose(-1, -2)
+
+
 def mel_scale(specgram: Tensor, fb: Tensor) -> Tensor:
     """MelScale.forward (transforms/_transforms.py:403-415): (..., freq, time) -> (..., n_mels, time)."""
     _require_device(specgram, "specgram")

@@ -212,39 +212,12 @@ class MFCC(torch.nn.Module):
         self.group_max_hook: Optional[Callable[[Tensor], None]] = None
 
     def forward(self, waveform: Tensor) -> Tensor:
-        lead = tuple(waveform.shape[:-1])
-        dev = waveform.device
-        dct = self.dct_mat.to(device=dev, dtype=torch.float32).contiguous()
-        L = _lib.lib()
-        if self.log_mels:
-            mel = self.MelSpectrogram._frame_major(waveform)    # (rows, T, n_mels) frame-major
-            rows, T, n_mels = mel.shape
-            out = torch.empty((rows, T, self.n_mfcc), dtype=torch.float32, device=dev)
-            if out.numel():
-                _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), rows * T, n_mels,
-                                               self.n_mfcc, 1, None, 1, -1.0, _lib.current_stream(dev)))
-        else:
-            # amplitude_to_DB's cut-off groups: the mel tensor is (..., C?, n_mels, T); one cut-off
-            # per leading item of its (-1, C, n_mels, T) view (functional.py:393-402).  The dB
-            # conversion and the per-group maximum are fused into the mel kernel's epilogue.
-            packed = waveform.shape[-2] if waveform.dim() > 1 else 1
-            n_rows = 1
-            for d in lead:
-                n_rows *= d
-            n_groups = max(n_rows // max(packed, 1), 1)
-            gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
-            a2db = self.amplitude_to_DB
-            mel = self.MelSpectrogram._frame_major(
-                waveform, db=(a2db.multiplier, a2db.amin, a2db.db_multiplier, gmax, packed))
-            rows, T, n_mels = mel.shape
-            out = torch.empty((rows, T, self.n_mfcc), dtype=torch.float32, device=dev)
-            if self.group_max_hook is not None:
-                self.group_max_hook(gmax)
-            if out.numel():
-                _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), rows * T, n_mels,
-                                               self.n_mfcc, 2, gmax.data_ptr(), packed * T, float(self.top_db),
-                                               _lib.current_stream(dev)))
-        return out.view(lead + (T, self.n_mfcc)).transpose(-1, -2)
+        sp = self.MelSpectrogram.spectrogram
+        a2db = self.amplitude_to_DB
+        return F._mfcc(waveform, sp.pad, sp.window, self.MelSpectrogram.mel_scale.fb, self.dct_mat, sp.n_fft,
+                       sp.hop_length, sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode, self.log_mels,
+                       self.top_db, db=(a2db.multiplier, a2db.amin, a2db.db_multiplier),
+                       group_max_hook=self.group_max_hook)
 
 
 class Resample(torch.nn.Module):

@@ -26,6 +26,16 @@ BATCH, SECONDS, SR, N_FFT, HOP, N_MELS = 256, 10.0, 16000, 400, 160, 80
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the headline kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; see profiles/pmc_traffic_melspec400.json); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_melspec400.json")) as f:
+            return float(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,7 +114,7 @@ def main():
                                    "(BASELINE configs[1])", "per_gpu_batch": BATCH, "clip_seconds": SECONDS,
                        "sharding": "clips born sharded across ranks, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "melspec400_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
                          "read_only_frac": (BATCH * L * 4) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }

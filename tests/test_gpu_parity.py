@@ -278,3 +278,23 @@ def test_resample_headline_shape_properties():
     assert float((y2 - 0.5 * y[:2]).abs().max()) <= 1e-6
     dc = r(torch.ones(1, 100000, device="cuda"))
     assert float((dc[0, 200:-200] - 1.0).abs().max()) <= 1e-5
+
+
+def test_registered_ops_equal_modules():
+    """torch.ops.audio_amd.* (the dispatcher-registered surface) == the drop-in modules."""
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    x = torch.randn(2, 2, 8000, device="cuda").clamp_(-1, 1)
+    mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).cuda()
+    got = torch.ops.audio_amd.mel_spectrogram(x, mel.spectrogram.window, mel.mel_scale.fb, 0, 400, 160, 400, 2.0, 0,
+                                              True, "reflect")
+    assert torch.equal(got, mel(x)) and got.stride() == mel(x).stride()
+    mf = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
+    got = torch.ops.audio_amd.mfcc(x, mel.spectrogram.window, mel.mel_scale.fb, mf.dct_mat, 0, 400, 160, 400, 2.0, 0,
+                                   True, "reflect", False, 80.0)
+    assert torch.equal(got, mf(x))
+    a = torch.tensor([1.0, -1.2, 0.5], device="cuda")
+    b = torch.tensor([0.1, 0.2, 0.1], device="cuda")
+    assert torch.equal(torch.ops.audio_amd.lfilter(x, a, b, True, True), F.lfilter(x, a, b))
+    y = torch.randn(1, 1, 300, device="cuda")
+    assert torch.equal(torch.ops.audio_amd.fftconvolve(x, y, "same"), F.fftconvolve(x, y, "same"))

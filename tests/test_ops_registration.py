@@ -1,0 +1,42 @@
+"""torch.ops.audio_amd.*: schemas registered, Meta kernels give the reference's shapes/strides,
+and a CPU tensor fails loudly in the dispatcher (there is no CPU kernel)."""
+import pytest
+import torch
+
+import audio_amd  # noqa: F401  (registers the ops)
+
+OPS = ["spectrogram", "mel_spectrogram", "mfcc", "amplitude_to_DB", "resample_apply", "lfilter", "lfilter_cascade",
+       "fftconvolve"]
+
+
+def test_ops_are_registered():
+    for name in OPS:
+        assert hasattr(torch.ops.audio_amd, name)
+        assert "Tensor" in str(getattr(torch.ops.audio_amd, name).default._schema)
+
+
+def test_meta_shapes_and_strides_match_reference_layout():
+    x = torch.empty(3, 2, 16000, device="meta")
+    w = torch.empty(400, device="meta")
+    fb = torch.empty(201, 80, device="meta")
+    dct = torch.empty(80, 40, device="meta")
+    s = torch.ops.audio_amd.spectrogram(x, w, 0, 400, 160, 400, 2.0, 0, True, "reflect", True)
+    assert s.shape == (3, 2, 201, 101) and s.stride()[-2:] == (1, 201)       # frame-major storage
+    c = torch.ops.audio_amd.spectrogram(x, w, 0, 400, 160, 400, None, 0, True, "reflect", True)
+    assert c.dtype == torch.complex64
+    m = torch.ops.audio_amd.mel_spectrogram(x, w, fb, 0, 400, 160, 400, 2.0, 0, True, "reflect")
+    assert m.shape == (3, 2, 80, 101) and m.stride()[-2:] == (1, 80)
+    k = torch.ops.audio_amd.mfcc(x, w, fb, dct, 0, 400, 160, 400, 2.0, 0, True, "reflect", False, 80.0)
+    assert k.shape == (3, 2, 40, 101)
+    r = torch.ops.audio_amd.resample_apply(torch.empty(4, 44100, device="meta"), torch.empty(160, 1, 815, device="meta"),
+                                           44100, 16000, 100, 187)
+    assert r.shape == (4, 16000)
+    f = torch.ops.audio_amd.fftconvolve(torch.empty(4, 1, 100, device="meta"), torch.empty(1, 3, 7, device="meta"), "full")
+    assert f.shape == (4, 3, 106)
+
+
+def test_cpu_tensor_has_no_kernel():
+    with pytest.raises(NotImplementedError, match="CPU"):
+        torch.ops.audio_amd.fftconvolve(torch.randn(5), torch.randn(3), "full")
+    with pytest.raises(NotImplementedError, match="CPU"):
+        torch.ops.audio_amd.lfilter(torch.randn(2, 50), torch.ones(3), torch.ones(3), True, True)
