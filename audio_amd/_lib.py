@@ -60,9 +60,9 @@ _SIGS = {
                                            C.c_int32, C.c_int64, C.POINTER(ResampleBands), _P]),
     "aamd_lfilter_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, _P]),
-    "aamd_fftconvolve_workspace": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
-    "aamd_fftconvolve_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, C.c_int64,
-                                       C.c_int64, _P, _P]),
+    "aamd_fftconvolve_workspace": (C.c_int64, [C.c_int64] * 5),
+    "aamd_fftconvolve_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
+                                       C.c_int64, C.c_int64, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -12,6 +12,7 @@
 #include "../../include/audio_amd.h"
 #include "db_mfcc.h"
 #include "fftconv.h"
+#include "fftconv_os.h"
 #include "lfilter.h"
 #include "melspec400.h"
 #include "resample.h"
@@ -501,33 +502,74 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
   return fail(AAMD_EUNSUPPORTED, "audio_amd: lfilter order > 16 not supported");
 }
 
-int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t nx, int64_t ny) {
-  (void)rows; (void)nx; (void)ny;
-  return 0;
+// taps above this use overlap-save on the LDS FFT; below, the tiled time-domain kernel is cheaper
+static const int64_t kFftConvMinTaps = 192;
+
+static bool fftconv_use_fft(int64_t n_taps) {
+  return n_taps > kFftConvMinTaps && std::getenv("AAMD_FORCE_GENERIC") == nullptr;
 }
 
-int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t nx,
-                         int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of, int64_t start,
-                         int64_t out_len, void* workspace, void* stream) {
-  (void)workspace;
+int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_rows, int64_t nx, int64_t ny) {
+  (void)rows;
+  const bool swap = ny > nx;
+  const int64_t taps = swap ? nx : ny;
+  const int64_t tap_rows = swap ? n_x_rows : n_y_rows;
+  if (!fftconv_use_fft(taps)) return 0;
+  fco::Geom g{};
+  fco::plan(taps, 1, g);
+  return (int64_t)sizeof(fco::C32) * fco::kN * (1 + tap_rows * g.n_part);
+}
+
+int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows,
+                         int64_t n_y_rows, int64_t nx, int64_t ny, const int64_t* x_row_of,
+                         const int64_t* y_row_of, int64_t start, int64_t out_len, void* workspace,
+                         void* stream) {
   AAMD_CHECK_ARG(x && y && out, "null buffer");
-  AAMD_CHECK_ARG(rows >= 0 && nx >= 1 && ny >= 1, "bad sizes");
+  AAMD_CHECK_ARG(rows >= 0 && nx >= 1 && ny >= 1 && n_x_rows >= 1 && n_y_rows >= 1, "bad sizes");
   AAMD_CHECK_ARG(start >= 0 && out_len >= 0 && start + out_len <= nx + ny - 1, "slice outside the full convolution");
   if (rows == 0 || out_len == 0) return AAMD_OK;
-  FcGeom g;
-  g.rows = rows; g.start = start; g.out_len = out_len;
   // stream the SHORTER operand as taps (convolution commutes)
   const bool swap = ny > nx;
   const float* xa = swap ? y : x;
   const float* ya = swap ? x : y;
-  g.nx = swap ? ny : nx;
-  g.ny = swap ? nx : ny;
+  const int64_t nxa = swap ? ny : nx, nya = swap ? nx : ny;
+  const int64_t tap_rows = swap ? n_x_rows : n_y_rows;
   const int64_t* xmap = swap ? y_row_of : x_row_of;
   const int64_t* ymap = swap ? x_row_of : y_row_of;
+  hipStream_t s = (hipStream_t)stream;
+  if (fftconv_use_fft(nya)) {
+    AAMD_CHECK_ARG(workspace != nullptr, "fftconvolve needs the workspace of aamd_fftconvolve_workspace()");
+    AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(workspace) % 8 == 0, "workspace must be 8-byte aligned");
+    fco::Geom g{};
+    g.rows = rows; g.nx = nxa; g.ny = nya; g.start = start; g.out_len = out_len;
+    fco::plan(nya, out_len, g);
+    fco::C32* tw = reinterpret_cast<fco::C32*>(workspace);
+    fco::C32* H = tw + fco::kN;
+    const size_t lds = (size_t)fco::kLdsComplex * sizeof(fco::C32);
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fco::spectrum_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fco::overlap_save_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fco::twiddle_kernel, dim3(fco::kN / 256), dim3(256), 0, s, tw);
+    AAMD_CHECK_ARG(tap_rows * g.n_part < (1ll << 31), "too many tap rows");
+    hipLaunchKernelGGL(fco::spectrum_kernel, dim3((unsigned)(tap_rows * g.n_part)), dim3(fco::kThreads), lds, s, g,
+                       ya, tw, H);
+    const int64_t items = rows * g.n_pairs;
+    int64_t blocks = dev_props().cu_count;
+    if (blocks > items) blocks = items;
+    for (int p = 0; p < g.n_part; ++p)
+      hipLaunchKernelGGL(fco::overlap_save_kernel, dim3((unsigned)blocks), dim3(fco::kThreads), lds, s, g, p, xa, tw,
+                         H, xmap, ymap, out);
+    return launch_check();
+  }
+  FcGeom g;
+  g.rows = rows; g.start = start; g.out_len = out_len;
+  g.nx = nxa;
+  g.ny = nya;
   g.n_tiles = (int)((out_len + kFcTN - 1) / kFcTN);
   const int64_t blocks = rows * g.n_tiles;
   AAMD_CHECK_ARG(blocks < (1ll << 31), "too many tiles for one launch");
-  hipLaunchKernelGGL(fftconv_direct_kernel, dim3((unsigned)blocks), dim3(kFcThreads), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(fftconv_direct_kernel, dim3((unsigned)blocks), dim3(kFcThreads), 0, s,
                      g, xa, ya, xmap, ymap, out);
   return launch_check();
 }

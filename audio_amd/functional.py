@@ -673,10 +673,10 @@ def fftconvolve(x: Tensor, y: Tensor, mode: str = "full") -> Tensor:
     out = torch.empty((rows, out_len), dtype=torch.float32, device=x.device)
     if out.numel():
         L = _lib.lib()
-        ws_bytes = L.aamd_fftconvolve_workspace(rows, nx, ny)
-        ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=x.device) if ws_bytes else None
+        ws_bytes = L.aamd_fftconvolve_workspace(rows, xr.shape[0], yr.shape[0], nx, ny)
+        ws = torch.empty((ws_bytes // 8,), dtype=torch.float64, device=x.device) if ws_bytes else None
         _lib.check(L.aamd_fftconvolve_f32(
-            xr.data_ptr(), yr.data_ptr(), out.data_ptr(), rows, nx, ny,
+            xr.data_ptr(), yr.data_ptr(), out.data_ptr(), rows, xr.shape[0], yr.shape[0], nx, ny,
             xmap.data_ptr() if xmap is not None else None, ymap.data_ptr() if ymap is not None else None,
             start, out_len, ws.data_ptr() if ws is not None else None, _lib.current_stream(x.device)))
     return out.view(tuple(lead) + (out_len,))

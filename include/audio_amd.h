@@ -191,13 +191,17 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
 
 /* Linear convolution along the last dim: out[row][n] = sum_m x[rx][m] * y[ry][n-m], full length
  * nx+ny-1, then the slice [start, start+out_len) is stored (mode crop, functional.py:2207-2219).
- * x_row_of / y_row_of are device int64[rows] maps from output row to input row (broadcasting);
- * NULL means identity.  Direct (time-domain) tiling for short y, overlap-save on the LDS FFT
- * for long y; `workspace` must hold aamd_fftconvolve_workspace() bytes (may be NULL if that is 0). */
-int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t nx, int64_t ny);
-int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t nx,
-                         int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of,
-                         int64_t start, int64_t out_len, void* workspace, void* stream);
+ * x: float[n_x_rows][nx], y: float[n_y_rows][ny]; x_row_of / y_row_of are device int64[rows] maps
+ * from output row to input row (broadcasting); NULL means identity.
+ * The shorter operand is treated as the taps.  <= 192 taps: tiled time-domain evaluation.  More:
+ * overlap-save on a 16384-point complex FFT held in LDS (two real blocks per complex FFT, taps
+ * in partitions of <= 8192; tap spectra and the twiddle table live in `workspace`, which must hold
+ * aamd_fftconvolve_workspace() bytes, 8-byte aligned; it may be NULL when that is 0). */
+int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_rows, int64_t nx, int64_t ny);
+int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows,
+                         int64_t n_y_rows, int64_t nx, int64_t ny, const int64_t* x_row_of,
+                         const int64_t* y_row_of, int64_t start, int64_t out_len, void* workspace,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,7 @@
 // replacing "all threads run phase X, then __syncthreads()" by a loop over thread ids.
 // TEST INFRASTRUCTURE ONLY: lets the build container check index math / algorithms of the
 // exact device source before a GPU is available.
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -10,6 +11,7 @@
 #include "../../include/audio_amd.h"
 #include "../../audio_amd/csrc/db_mfcc.h"
 #include "../../audio_amd/csrc/fftconv.h"
+#include "../../audio_amd/csrc/fftconv_os.h"
 #include "../../audio_amd/csrc/lfilter.h"
 #include "../../audio_amd/csrc/melspec400.h"
 #include "../../audio_amd/csrc/resample.h"
@@ -355,6 +357,52 @@ int sim_lfilter(const float* x, const float* a, const float* b, float* y, int64_
   if (d <= 12) SIM_LF(12);
   if (d <= 16) SIM_LF(16);
   return -1;
+}
+
+// Replay of the overlap-save path (fco::spectrum_kernel + fco::overlap_save_kernel): the same
+// launcher logic as aamd_fftconvolve_f32, 1024 "threads" per phase, phases separated where the
+// kernel has barriers.  Twiddles as the device twiddle_kernel computes them (fp64 -> fp32).
+int sim_fftconv_os(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows, int64_t n_y_rows,
+                   int64_t nx, int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of, int64_t start,
+                   int64_t out_len) {
+  using namespace fco;
+  const bool swap = ny > nx;
+  const float* xa = swap ? y : x; const float* ya = swap ? x : y;
+  const int64_t nxa = swap ? ny : nx, nya = swap ? nx : ny;
+  const int64_t tap_rows = swap ? n_x_rows : n_y_rows;
+  const int64_t* xmap = swap ? y_row_of : x_row_of; const int64_t* ymap = swap ? x_row_of : y_row_of;
+  Geom g{};
+  g.rows = rows; g.nx = nxa; g.ny = nya; g.start = start; g.out_len = out_len;
+  plan(nya, out_len, g);
+  std::vector<C32> tw(kN), lds(kLdsComplex), H((size_t)tap_rows * g.n_part * kN);
+  for (int m = 0; m < kN; ++m) {
+    const double a = -2.0 * M_PI * (double)m / (double)kN;
+    tw[m] = C32{(float)std::cos(a), (float)std::sin(a)};
+  }
+  auto fwd = [&]() {
+    for (int t = 0; t < kThreads; ++t) pass16<16384, false>(t, lds.data(), tw.data());
+    for (int t = 0; t < kThreads; ++t) pass16<1024, false>(t, lds.data(), tw.data());
+    for (int t = 0; t < kThreads; ++t) pass16<64, false>(t, lds.data(), tw.data());
+  };
+  for (int64_t b = 0; b < tap_rows * g.n_part; ++b) {
+    const int64_t yrow = b / g.n_part; const int p = (int)(b - yrow * g.n_part);
+    for (int t = 0; t < kThreads; ++t) load_taps(t, g, ya + yrow * g.ny, p, lds.data());
+    fwd();
+    for (int t = 0; t < kThreads; ++t) middle_spectrum(t, lds.data(), H.data() + b * kN, 1.0f / (float)kN);
+  }
+  for (int p = 0; p < g.n_part; ++p)
+    for (int64_t item = 0; item < rows * g.n_pairs; ++item) {
+      const int64_t row = item / g.n_pairs, j0 = 2 * (item - row * g.n_pairs);
+      const int64_t rx = xmap ? xmap[row] : row, ry = ymap ? ymap[row] : row;
+      for (int t = 0; t < kThreads; ++t) load_pair(t, g, xa + rx * g.nx, p, j0, lds.data());
+      fwd();
+      for (int t = 0; t < kThreads; ++t) middle(t, lds.data(), H.data() + (ry * g.n_part + p) * (int64_t)kN);
+      for (int t = 0; t < kThreads; ++t) pass16<64, true>(t, lds.data(), tw.data());
+      for (int t = 0; t < kThreads; ++t) pass16<1024, true>(t, lds.data(), tw.data());
+      for (int t = 0; t < kThreads; ++t) pass16<16384, true>(t, lds.data(), tw.data());
+      for (int t = 0; t < kThreads; ++t) store_pair(t, g, lds.data(), p, j0, out + row * out_len);
+    }
+  return 0;
 }
 
 int sim_fftconv(const float* x, const float* y, float* out, int64_t rows, int64_t nx, int64_t ny,

@@ -179,3 +179,18 @@ def sim_fftconv(x, y, start, out_len, xmap=None, ymap=None, rows=None):
     ym = None if ymap is None else fptr(np.ascontiguousarray(ymap, dtype=np.int64))
     assert f(fptr(x), fptr(y), fptr(out), rows, nx, ny, xm, ym, start, out_len) == 0
     return out
+
+
+def sim_fftconv_os(x, y, start, out_len, xmap=None, ymap=None, rows=None):
+    """Overlap-save path (16384-point LDS FFT).  x: (n_x_rows, nx), y: (n_y_rows, ny)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    nx, ny = x.shape[-1], y.shape[-1]
+    rows = rows if rows is not None else x.shape[0]
+    out = np.full((rows, out_len), np.nan, dtype=np.float32)
+    f = sim().sim_fftconv_os
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 5 + [C.c_void_p] * 2 + [C.c_int64] * 2
+    xm = None if xmap is None else fptr(np.ascontiguousarray(xmap, dtype=np.int64))
+    ym = None if ymap is None else fptr(np.ascontiguousarray(ymap, dtype=np.int64))
+    assert f(fptr(x), fptr(y), fptr(out), rows, x.shape[0], y.shape[0], nx, ny, xm, ym, start, out_len) == 0
+    return out

@@ -271,3 +271,20 @@ def test_sim_resample_mfma_kaiser_best_headline():
     exp = O.apply_sinc_resample_kernel(x.astype(np.float64), o, n, g, k.numpy().astype(np.float64).reshape(n // g, -1), width)
     assert got.shape == exp.shape
     assert peak_rel_err(got, exp) <= 5e-6
+
+
+@pytest.mark.parametrize("nx,ny,mode", [(40000, 9000, "full"), (20000, 700, "same"), (30000, 17000, "valid"),
+                                        (500, 20000, "full")])
+def test_sim_fftconvolve_overlap_save(nx, ny, mode):
+    """Overlap-save on the 16384-point LDS FFT (DIF radix-16 passes, digit-reversed product, DIT inverse,
+    two real blocks per complex FFT, tap partitions accumulating) vs the float64 oracle; broadcast taps."""
+    rng = np.random.default_rng(nx + ny)
+    x = rng.standard_normal((2, nx)).astype(np.float32)
+    y = (rng.standard_normal((1, ny)) * np.exp(-np.arange(ny) / (0.3 * ny))).astype(np.float32)
+    exp = O.fftconvolve(x.astype(np.float64), np.broadcast_to(y, (2, ny)).astype(np.float64), mode)
+    n_full = nx + ny - 1
+    out_len = exp.shape[-1]
+    start = 0 if mode == "full" else (n_full - out_len) // 2
+    got = S.sim_fftconv_os(x, y, start, out_len, ymap=np.zeros(2, dtype=np.int64), rows=2)
+    assert not np.isnan(got).any()
+    assert peak_rel_err(got, exp) <= 2e-6

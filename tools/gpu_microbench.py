@@ -84,9 +84,17 @@ def main():
             us = timeit(lambda: F.lfilter(x, a, b), 1, 5)
             print(f"lfilter biquad 32x8x10s@48k: {us:9.1f} us  {2 * x.numel() * 4 / us / 1e3:.1f} GB/s")
         if "fftconv" in what:
-            x = torch.randn(4, 8, 48000, device=dev)
-            y = torch.randn(1, 1, 2400, device=dev)
-            print(f"fftconvolve 4x8x1s * 2400 taps: {timeit(lambda: F.fftconvolve(x, y), 1, 3):9.1f} us")
+            x = torch.rand(32, 8, 480000, device=dev) - 0.5                       # cfg5b per-GPU shard (1/8)
+            y = torch.randn(1, 1, 24000, device=dev) * 0.05
+            us = timeit(lambda: F.fftconvolve(x, y), 2, 10)
+            by = x.numel() * 4 + 32 * 8 * 503999 * 4
+            print(f"fftconvolve 32x8x10s@48k * 24000-tap RIR (overlap-save LDS FFT): {us:9.1f} us  "
+                  f"algorithmic {by / us / 1e3:.0f} GB/s (frac {by / us / 1e3 / 8000:.3f})")
+            x1, y1 = torch.randn(4, 8, 48000, device=dev), torch.randn(1, 1, 2400, device=dev)
+            print(f"fftconvolve 4x8x1s * 2400 taps: {timeit(lambda: F.fftconvolve(x1, y1), 1, 3):9.1f} us")
+            os.environ["AAMD_FORCE_GENERIC"] = "1"
+            print(f"  same, time-domain kernel: {timeit(lambda: F.fftconvolve(x1, y1), 1, 3):9.1f} us")
+            del os.environ["AAMD_FORCE_GENERIC"]
 
 
 if __name__ == "__main__":
