@@ -14,6 +14,7 @@
 #include "fftconv.h"
 #include "fftconv_os.h"
 #include "lfilter.h"
+#include "lfilter_wave.h"
 #include "melspec400.h"
 #include "resample.h"
 #include "resample_mfma.h"
@@ -489,6 +490,24 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
   if (n_seq == 0 || length == 0) return AAMD_OK;
   hipStream_t s = (hipStream_t)stream;
   const int d = n_order - 1;
+  // biquad-class filters: W waves per sequence with shuffle scans (lfilter_wave.h); W fills the chip
+  if (n_order <= 3 && n_stages <= lfw::kMaxCascade && length < (1ll << 30) && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+    int W = 1;
+    while (W < lfw::kMaxWaves && n_seq * (2 * W) <= 8192 && (int64_t)W * lfw::kWaveBlock < length) W *= 2;
+    const size_t cap = dev_props().lds_per_block_optin ? dev_props().lds_per_block_optin : 64 * 1024;
+    while (W > 1 && lfw::lds_bytes(W, n_stages) > cap) W /= 2;
+    const size_t lds = lfw::lds_bytes(W, n_stages);
+    if (lds <= cap) {
+      AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lfw::lfilter_wave_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const int blocks = grid_for(n_seq, 1, dev_props().cu_count * 8);
+      const int vec_ok = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0) &&
+                         (length % 4 == 0);
+      hipLaunchKernelGGL(lfw::lfilter_wave_kernel, dim3(blocks), dim3(64 * W), lds, s, x, a, b, y, n_seq, channels,
+                         length, n_order, n_coeff_rows, n_stages, clamp, vec_ok);
+      return launch_check();
+    }
+  }
 #define AAMD_LF(D) return launch_lfilter<D>(x, a, b, y, n_seq, channels, length, n_order, n_coeff_rows, n_stages, clamp, s)
   if (d <= 1) AAMD_LF(1);
   if (d <= 2) AAMD_LF(2);

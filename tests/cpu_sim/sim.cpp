@@ -13,6 +13,7 @@
 #include "../../audio_amd/csrc/fftconv.h"
 #include "../../audio_amd/csrc/fftconv_os.h"
 #include "../../audio_amd/csrc/lfilter.h"
+#include "../../audio_amd/csrc/lfilter_wave.h"
 #include "../../audio_amd/csrc/melspec400.h"
 #include "../../audio_amd/csrc/resample.h"
 #include "../../audio_amd/csrc/resample_mfma.h"
@@ -336,6 +337,100 @@ static int sim_lfilter_d(const float* x, const float* a, const float* b, float* 
       for (int i = 0; i < kLfBlock; ++i) {
         const int64_t n = n0 + i;
         if (n < length) ys[n] = lds[L::blk + (i / kLfChunk) * kLfChunkStride + (i % kLfChunk)];
+      }
+    }
+  }
+  return 0;
+}
+
+// Replay of lfw::lfilter_wave_kernel: W waves x 64 lanes per sequence, shuffles as array reads,
+// phases cut where the kernel has workgroup barriers.
+extern "C" int sim_lfilter_wave(const float* x, const float* a, const float* b, float* y, int64_t batch, int channels,
+                                int64_t length, int n_order, int n_rows, int n_stages, int clamp, int W) {
+  using namespace lfw;
+  if (n_order > 3 || n_stages > kMaxCascade || W > kMaxWaves) return -1;
+  const int64_t n_seq = batch * channels;
+  const int64_t block_len = (int64_t)W * kWaveBlock;
+  std::vector<float> tiles((size_t)W * kTile), tabs((size_t)n_stages * kTabFloats), xch(xch_floats(W, n_stages));
+  std::vector<std::vector<float>> v(W * 64, std::vector<float>(kCh)), z(W * 64, std::vector<float>(kCh));
+  std::vector<float> s0(W * 64), s1(W * 64), t0(W * 64), t1(W * 64);
+  auto arr = [](std::vector<float>& r) -> float(&)[kCh] { return *reinterpret_cast<float(*)[kCh]>(r.data()); };
+  for (int64_t seq = 0; seq < n_seq; ++seq) {
+    const int crow = (n_rows == 1) ? 0 : (int)(seq % channels);
+    for (int st = 0; st < n_stages; ++st) {
+      const int64_t coff = ((int64_t)st * n_rows + crow) * n_order;
+      build_stage(a + coff, b + coff, n_order, tabs.data() + st * kTabFloats);
+    }
+    std::fill(xch.begin(), xch.end(), 0.0f);
+    const float* xs = x + seq * length;
+    float* ys = y + seq * length;
+    int parity = 0;
+    for (int64_t n0 = 0; n0 < length; n0 += block_len, parity ^= 1) {
+      for (int w = 0; w < W; ++w) {
+        float* tile = tiles.data() + (size_t)w * kTile;
+        const int64_t nw = n0 + (int64_t)w * kWaveBlock;
+        for (int sidx = 0; sidx < kWaveBlock; ++sidx) tile[tile_idx(sidx)] = (nw + sidx < length) ? xs[nw + sidx] : 0.0f;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < kCh; ++j) v[w * 64 + lane][j] = tile[lane * kRow + j];
+        xch[xch_tail(W, n_stages, parity, 0, w)] = v[w * 64 + 63][kCh - 1];
+        xch[xch_tail(W, n_stages, parity, 0, w) + 1] = v[w * 64 + 63][kCh - 2];
+      }
+      for (int st = 0; st < n_stages; ++st) {
+        const float* tab = tabs.data() + st * kTabFloats;
+        for (int w = 0; w < W; ++w) {
+          for (int lane = 0; lane < 64; ++lane) {
+            float hu0, hu1;
+            if (lane > 0) { hu0 = v[w * 64 + lane - 1][kCh - 1]; hu1 = v[w * 64 + lane - 1][kCh - 2]; }
+            else {
+              const int src = (w > 0) ? xch_tail(W, n_stages, parity, st, w - 1) : xch_tail(W, n_stages, parity ^ 1, st, W - 1);
+              hu0 = xch[src]; hu1 = xch[src + 1];
+            }
+            z[w * 64 + lane] = v[w * 64 + lane];   // the kernel filters in place; keep v for the neighbour's history
+            chunk_pass(tab, arr(z[w * 64 + lane]), hu0, hu1, s0[w * 64 + lane], s1[w * 64 + lane]);
+          }
+          for (int k = 0; k < kScanSteps; ++k) {
+            for (int lane = 0; lane < 64; ++lane) {
+              const int src = lane >= (1 << k) ? lane - (1 << k) : lane;
+              t0[w * 64 + lane] = s0[w * 64 + src]; t1[w * 64 + lane] = s1[w * 64 + src];
+            }
+            for (int lane = 0; lane < 64; ++lane)
+              scan_step(tab, k, lane >= (1 << k), t0[w * 64 + lane], t1[w * 64 + lane], s0[w * 64 + lane], s1[w * 64 + lane]);
+          }
+          xch[xch_S(w)] = s0[w * 64 + 63];
+          xch[xch_S(w) + 1] = s1[w * 64 + 63];
+        }
+        // barrier 1
+        const int cin = xch_carry(W, n_stages, parity, st);
+        for (int w = 0; w < W; ++w) {
+          float e0, e1;
+          fold_entering(tab, xch.data(), w, xch[cin], xch[cin + 1], e0, e1);
+          for (int lane = 0; lane < 64; ++lane) {
+            float p0, p1;
+            mat_apply(tab + kTabPow + 4 * lane, e0, e1, p0, p1);
+            s0[w * 64 + lane] += p0; s1[w * 64 + lane] += p1;
+          }
+          for (int lane = 0; lane < 64; ++lane) {
+            const float tt0 = lane ? s0[w * 64 + lane - 1] : e0, tt1 = lane ? s1[w * 64 + lane - 1] : e1;
+            correct_clamp(tab, tt0, tt1, clamp, arr(z[w * 64 + lane]));
+          }
+        }
+        for (int w = 0; w < W; ++w) {   // writes that the kernel does before barrier 2
+          if (w == W - 1) {
+            const int cout = xch_carry(W, n_stages, parity ^ 1, st);
+            xch[cout] = s0[w * 64 + 63]; xch[cout + 1] = s1[w * 64 + 63];
+          }
+          xch[xch_tail(W, n_stages, parity, st + 1, w)] = z[w * 64 + 63][kCh - 1];
+          xch[xch_tail(W, n_stages, parity, st + 1, w) + 1] = z[w * 64 + 63][kCh - 2];
+          for (int lane = 0; lane < 64; ++lane) v[w * 64 + lane] = z[w * 64 + lane];
+        }
+      }
+      for (int w = 0; w < W; ++w) {
+        float* tile = tiles.data() + (size_t)w * kTile;
+        const int64_t nw = n0 + (int64_t)w * kWaveBlock;
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < kCh; ++j) tile[lane * kRow + j] = v[w * 64 + lane][j];
+        for (int sidx = 0; sidx < kWaveBlock; ++sidx)
+          if (nw + sidx < length) ys[nw + sidx] = tile[tile_idx(sidx)];
       }
     }
   }

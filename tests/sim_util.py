@@ -167,6 +167,19 @@ def sim_lfilter(x, a, b, clamp=True):
     return y
 
 
+def sim_lfilter_wave(x, a, b, clamp=True, waves=1):
+    """Wave-per-sequence biquad kernel.  x: (batch, channels, L); a, b: (stages, rows, order+1), order <= 2."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    batch, ch, L = x.shape
+    y = np.full_like(x, np.nan)
+    f = sim().sim_lfilter_wave
+    f.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    rc = f(fptr(x), fptr(a), fptr(b), fptr(y), batch, ch, L, a.shape[-1], a.shape[-2], a.shape[0], int(clamp), waves)
+    return rc, y
+
+
 def sim_fftconv(x, y, start, out_len, xmap=None, ymap=None, rows=None):
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.ascontiguousarray(y, dtype=np.float32)

@@ -141,6 +141,11 @@ def test_sim_lfilter(case):
     x3 = x.reshape(-1, C_, x.shape[-1])
     exp = rr.output(case)
     got = S.sim_lfilter(x3, a2[None], b2[None], kw.get("clamp", True)).reshape(exp.shape)
+    if a2.shape[-1] <= 3:       # biquad class: also the wave-per-sequence kernel
+        for waves in (1, 4):
+            rc, gw = S.sim_lfilter_wave(x3, a2[None], b2[None], kw.get("clamp", True), waves)
+            assert rc == 0 and not np.isnan(gw).any()
+            assert peak_rel_err(gw.reshape(exp.shape), exp) <= 2e-5
     tol = 2e-4 if case.get("tag") in ("order4", "order8") else 2e-5
     assert peak_rel_err(got, exp) <= tol
     assert peak_rel_err(got, OD.evaluate(case, rr.inputs(case))) <= tol
@@ -173,6 +178,24 @@ def test_sim_lfilter_long_and_cascade():
     x3 = xin.reshape(-1, 1, xin.shape[-1])
     got = S.sim_lfilter(x3, a4, b4, True).reshape(xin.shape)
     assert peak_rel_err(got, rr.output(case)) <= 2e-5
+    rc, gw = S.sim_lfilter_wave(x3, a4, b4, True)
+    assert rc == 0 and peak_rel_err(gw.reshape(xin.shape), rr.output(case)) <= 2e-5
+    # long ragged sequence (several 2048-sample blocks, carried state) + per-channel coefficients
+    xl = (0.3 * rng.standard_normal((2, 2, 7013))).astype(np.float32)
+    a2c = np.array([[1.0, -1.8, 0.85], [1.0, -1.2, 0.5]], dtype=np.float32)
+    b2c = np.array([[0.02, 0.04, 0.02], [0.3, -0.1, 0.2]], dtype=np.float32)
+    for waves in (1, 2, 16):
+        rc, gw = S.sim_lfilter_wave(xl, a2c[None], b2c[None], True, waves)
+        assert rc == 0 and not np.isnan(gw).any()
+        for c in range(2):
+            assert peak_rel_err(gw[:, c], O.lfilter(xl[:, c], a2c[c], b2c[c], True)) <= 2e-5
+    # several multi-wave blocks with carried state, fused 4-stage cascade
+    xl = (0.3 * rng.standard_normal((1, 1, 4 * 2048 * 2 + 777))).astype(np.float32)
+    rc, gw = S.sim_lfilter_wave(xl, a4, b4, True, 4)
+    ref = xl[0, 0].astype(np.float64)
+    for st in range(4):
+        ref = O.lfilter(ref, a4[st, 0], b4[st, 0], True)
+    assert rc == 0 and peak_rel_err(gw[0, 0], ref) <= 2e-5
 
 
 @pytest.mark.parametrize("case", ref_runs().select("fftconvolve"), ids=lambda c: f"{c['id']}-{c['kwargs']['mode']}")

@@ -188,16 +188,20 @@ def test_spec400_fast_path_equals_generic_and_oracle(power):
     import audio_amd.transforms as T
     from oracle import dsp_oracle as O
     t = T.Spectrogram(n_fft=400, hop_length=160, power=power).cuda()
+    g = torch.Generator().manual_seed(17)
+    # powers < 1 amplify the rounding of near-zero bins without bound (d|X|^p ~ |X|^(p-1) d|X|), in the
+    # reference too: compare in the power-spectrum domain, where the 1e-4 bar of the north star is defined
+    back = 2.0 / power
     for L in (401, 560, 961, 1283, 1600, 16000, 16001, 48017):
-        x = torch.randn(3, L, device="cuda").clamp_(-1, 1)
+        x = torch.randn(3, L, generator=g).clamp_(-1, 1).cuda()
         fast = t(x)
         gen = _force_generic(lambda: t(x))
         assert fast.shape == gen.shape and fast.stride() == gen.stride()
-        e = (fast - gen).abs().max() / gen.abs().max()
+        e = (fast.pow(back) - gen.pow(back)).abs().max() / gen.pow(back).abs().max()
         assert float(e) <= 3e-6, (L, float(e))
         if L <= 16001:
             exp = O.spectrogram(x.cpu().numpy().astype(np.float64), 0, O.hann_window(400), 400, 160, 400, power, False)
-            assert peak_rel_err(fast.cpu().numpy(), exp) <= 1e-4, L
+            assert peak_rel_err(fast.double().pow(back).cpu().numpy(), exp ** back) <= 1e-4, L
 
 
 @pytest.mark.parametrize("shape", [(6, 4000), (3, 2, 4000), (2, 2, 2, 2400), (4000,)])
@@ -346,3 +350,56 @@ def test_fftconvolve_headline_shape_properties():
         lo, hi = max(0, n - 23999), min(n, 479999)
         ref = float(np.dot(xr[lo:hi + 1], h[n - np.arange(lo, hi + 1)]))
         assert abs(float(y[3, 5, n]) - ref) <= 2e-5 * float(y.abs().max())
+
+
+def test_lfilter_wave_kernel_equals_workgroup_kernel_and_oracle():
+    """Big-batch biquad path (one wave per sequence, shuffle scan) vs the workgroup-scan kernel and the
+    sequential float64 oracle: shared and per-channel coefficients, ragged length, no clamp, 1st order."""
+    import audio_amd.functional as F
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(3)
+    x = (0.3 * torch.randn(40, 2, 9001, generator=g))
+    cases = [
+        (torch.tensor([1.0, -1.8, 0.85]), torch.tensor([0.02, 0.04, 0.02]), True),
+        (torch.tensor([[1.0, -1.8, 0.85], [0.9, -0.7, 0.2]]), torch.tensor([[0.02, 0.04, 0.02], [0.3, -0.1, 0.2]]), True),
+        (torch.tensor([1.0, -0.6]), torch.tensor([0.5, 0.4]), False),
+    ]
+    for a, b, clamp in cases:
+        fast = F.lfilter(x.cuda(), a.cuda(), b.cuda(), clamp=clamp)
+        gen = _force_generic(lambda: F.lfilter(x.cuda(), a.cuda(), b.cuda(), clamp=clamp))
+        assert float((fast - gen).abs().max()) <= 2e-5 * max(float(gen.abs().max()), 1e-3)
+        if a.ndim == 1:
+            exp = O.lfilter(x.numpy().astype(np.float64), a.numpy(), b.numpy(), clamp)
+        else:
+            exp = np.stack([O.lfilter(x[:, c].numpy().astype(np.float64), a[c].numpy(), b[c].numpy(), clamp) for c in range(2)], 1)
+        assert peak_rel_err(fast.cpu().numpy(), exp) <= 1e-4
+
+
+def test_lfilter_cascade_headline_shape_properties():
+    """BASELINE config 5a at 1/8 of the batch (32 x 8 ch x 10 s @48 kHz): the fused 4-biquad cascade
+    equals four sequential F.lfilter calls (each clamped), and filtering is causal + time invariant."""
+    import audio_amd.functional as F
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = torch.rand(32, 8, 480000, device="cuda", generator=g) - 0.5
+    sr = 48000
+    A, B = [], []
+    for fc in (8000.0, 6000.0, 4000.0, 3000.0):
+        w0 = 2 * math.pi * fc / sr
+        alpha = math.sin(w0) / 2 / 0.707
+        A.append([1 + alpha, -2 * math.cos(w0), 1 - alpha])
+        B.append([(1 - math.cos(w0)) / 2, 1 - math.cos(w0), (1 - math.cos(w0)) / 2])
+    a = torch.tensor(A, device="cuda")
+    b = torch.tensor(B, device="cuda")
+    y = F.biquad_cascade(x, a, b)
+    assert y.shape == x.shape and torch.isfinite(y).all()
+    ref = x[:2]
+    for s in range(4):
+        ref = F.lfilter(ref, a[s], b[s])
+    assert float((y[:2] - ref).abs().max()) <= 1e-5
+    # causality / time invariance: delaying the input by d samples delays the output by d
+    d = 777
+    xd = torch.zeros_like(x[:1])
+    xd[..., d:] = x[:1, :, :-d]
+    yd = F.biquad_cascade(xd, a, b)
+    assert float((yd[..., d:] - y[:1, :, :-d]).abs().max()) <= 1e-5
+    assert float(yd[..., :d].abs().max()) == 0.0

@@ -81,8 +81,17 @@ def main():
             x = (torch.rand(32, 8, 480000, device=dev) - 0.5)
             a = torch.tensor([1.0, -1.2, 0.5], device=dev)
             b = torch.tensor([0.1, 0.2, 0.1], device=dev)
-            us = timeit(lambda: F.lfilter(x, a, b), 1, 5)
-            print(f"lfilter biquad 32x8x10s@48k: {us:9.1f} us  {2 * x.numel() * 4 / us / 1e3:.1f} GB/s")
+            us = timeit(lambda: F.lfilter(x, a, b), 2, 10)
+            print(f"lfilter biquad 32x8x10s@48k (wave kernel): {us:9.1f} us  {2 * x.numel() * 4 / us / 1e3:.1f} GB/s")
+            a4 = torch.tensor([[1.0, -1.2, 0.5], [1.0, -0.9, 0.3], [1.0, -0.5, 0.2], [1.0, -0.2, 0.1]], device=dev)
+            b4 = torch.tensor([[0.1, 0.2, 0.1], [0.2, 0.3, 0.2], [0.3, 0.2, 0.1], [0.2, 0.1, 0.05]], device=dev)
+            us = timeit(lambda: F.biquad_cascade(x, a4, b4), 2, 10)
+            print(f"4-biquad cascade fused 32x8x10s@48k (cfg5a shard): {us:9.1f} us  {2 * x.numel() * 4 / us / 1e3:.1f} GB/s "
+                  f"(frac {2 * x.numel() * 4 / us / 1e3 / 8000:.3f})")
+            os.environ["AAMD_FORCE_GENERIC"] = "1"
+            us = timeit(lambda: F.biquad_cascade(x, a4, b4), 1, 3)
+            del os.environ["AAMD_FORCE_GENERIC"]
+            print(f"  same, workgroup-scan kernel: {us:9.1f} us")
         if "fftconv" in what:
             x = torch.rand(32, 8, 480000, device=dev) - 0.5                       # cfg5b per-GPU shard (1/8)
             y = torch.randn(1, 1, 24000, device=dev) * 0.05

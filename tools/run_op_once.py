@@ -40,6 +40,15 @@ elif op == "lfilter":
     a = torch.tensor([1.0, -1.2, 0.5], device=dev)
     b = torch.tensor([0.1, 0.2, 0.1], device=dev)
     fn = lambda: F.lfilter(x, a, b)
+elif op == "fftconv":
+    x = torch.rand(32, 8, 480000, device=dev, generator=g) - 0.5
+    rir = torch.randn(1, 1, 24000, device=dev, generator=g) * 0.05
+    fn = lambda: F.fftconvolve(x, rir)
+elif op == "cascade":
+    x = torch.rand(32, 8, 480000, device=dev, generator=g) - 0.5
+    a = torch.tensor([[1.0, -1.2, 0.5], [1.0, -0.9, 0.3], [1.0, -0.5, 0.2], [1.0, -0.2, 0.1]], device=dev)
+    b = torch.tensor([[0.1, 0.2, 0.1], [0.2, 0.3, 0.2], [0.3, 0.2, 0.1], [0.2, 0.1, 0.05]], device=dev)
+    fn = lambda: F.biquad_cascade(x, a, b)
 else:
     raise SystemExit("unknown op")
 with torch.no_grad():
