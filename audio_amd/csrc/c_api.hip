@@ -116,7 +116,7 @@ int validate_bands(const aamd_mel_bands* b, int n_freq, MelBandsDev& mb) {
   AAMD_CHECK_ARG(b->n_mels >= 1 && b->max_width >= 1 && b->max_width <= n_freq, "bad mel band table");
   AAMD_CHECK_ARG(b->lo && b->width && b->weights, "null mel band pointers");
   mb.n_mels = b->n_mels; mb.max_width = b->max_width;
-  mb.lo = b->lo; mb.width = b->width; mb.weights = b->weights;
+  mb.lo = b->lo; mb.width = b->width; mb.weights = b->weights; mb.order = b->lane_order;
   return AAMD_OK;
 }
 
@@ -174,7 +174,10 @@ int launch_fft400(const StftGeom& g, const MelBandsDev& mb, const float* wav, co
   const int tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
   // 16-B paths: LDS-DMA staging of the waveform, dwordx4 stores of the output rows
   const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (g.row_stride % 4 == 0);
-  const int out_wide = (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
+  // mel rows leave as 4-byte stores straight from the accumulators: the LDS pipe is this kernel's
+  // bottleneck and the LDS-staged dwordx4 path measured 3-4 us slower (AAMD_MEL400_WIDE=1 selects it)
+  const bool want_wide = (EPI == m400::EPI400_SPEC) || std::getenv("AAMD_MEL400_WIDE") != nullptr;
+  const int out_wide = want_wide && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
                        (EPI == m400::EPI400_SPEC || mb.n_mels % 4 == 0);
   if (EPI == m400::EPI400_SPEC && !out_wide)
     return fail(AAMD_EINVAL, "audio_amd: spectrogram output buffer must be 16-byte aligned");

@@ -38,7 +38,11 @@ constexpr int kN = 400;
 constexpr int kHop = 160;
 constexpr int kPad = 200;
 constexpr int kFramesPerWave = 6;
-constexpr int kWavesPerBlock = 12;              // 768 threads = 3 waves per SIMD: ONE block per CU (a second block of a
+#ifndef AAMD_M400_WAVES
+#define AAMD_M400_WAVES 12
+#define AAMD_M400_MINWAVES 3
+#endif
+constexpr int kWavesPerBlock = AAMD_M400_WAVES;              // 768 threads = 3 waves per SIMD: ONE block per CU (a second block of a
                                                // smaller size is not admitted: its waves land on the same SIMDs)
 // LDS strides picked with tools/lds_conflicts.py (bank model of MI355X_MICROARCH.md):
 constexpr int kTRow = 44;                      // dwords per transposition row: 20 complex + pad, 16-B aligned
@@ -87,10 +91,14 @@ AAMD_HD constexpr int pos_of_col(int c) {
 // ---- banded filterbank in LDS (built once per launch by every workgroup) ------------------
 //   Bands are processed in chunks of 4 taps = one b128 of weights + two b128 of P (2 bins x 2
 //   frames each), so band starts are floored to even bins and rows are zero padded.
+//   Table ROWS are lane assignments: row 20 r + pi is evaluated by the lane at position pi in round r.
+//   Which mel a row holds is free (MelBandsDev::order, chosen on the host so that the b128 band reads of
+//   each 16-lane group fall on distinct 4-bank slots); row_mel[] maps a row back to its mel for the store.
 struct MelTab {
-  const float* w;    // [n_mels][ws]: weight of bin lo2[m] + j, zero outside the band
-  const int* lo2;    // [n_mels]: even band start (<= first non-zero bin)
-  const int* rc;     // [n_rounds]: 4-tap chunks of the round (wave-uniform trip count)
+  const float* w;     // [rows][ws]: weight of bin lo2[row] + j, zero outside the band
+  const int* lo2;     // [rows]: even band start (<= first non-zero bin)
+  const int* rc;      // [n_rounds]: 4-tap chunks of the round (wave-uniform trip count)
+  const int* row_mel; // [rows]: mel evaluated by the row, -1 = none
   int n_mels, ws, n_rounds;
 };
 
@@ -101,8 +109,13 @@ AAMD_HD int mel_ws(int max_width) {
   const int w4 = (max_width + 1 + 3) & ~3;
   return ((w4 >> 2) & 1) ? w4 : w4 + 4;
 }
+AAMD_HD int mel_rows(int n_mels) { return mel_rounds(n_mels) * kMelSlots; }
 AAMD_HD int mel_tab_dwords(int n_mels, int max_width) {
-  return n_mels * mel_ws(max_width) + n_mels + kMelMaxRounds;
+  return mel_rows(n_mels) * (mel_ws(max_width) + 2) + kMelMaxRounds;
+}
+AAMD_HD int row_to_mel(const MelBandsDev& mb, int row) {
+  const int m = mb.order ? mb.order[row] : row;
+  return (m >= 0 && m < mb.n_mels) ? m : -1;
 }
 
 // phase 1 (then a workgroup barrier): per-round chunk counts; phase 2: weights and band starts
@@ -110,14 +123,19 @@ AAMD_HD void mel_tab_rounds(int tid, int nthr, const MelBandsDev& mb, float* bas
   mt.n_mels = mb.n_mels;
   mt.ws = mel_ws(mb.max_width);
   mt.n_rounds = mel_rounds(mb.n_mels);
+  const int rows = mel_rows(mb.n_mels);
   mt.w = base;
-  int* lo2 = reinterpret_cast<int*>(base + mb.n_mels * mt.ws);
-  int* rc = lo2 + mb.n_mels;
+  int* lo2 = reinterpret_cast<int*>(base + rows * mt.ws);
+  int* row_mel = lo2 + rows;
+  int* rc = row_mel + rows;
   mt.lo2 = lo2;
+  mt.row_mel = row_mel;
   mt.rc = rc;
   for (int r = tid; r < mt.n_rounds; r += nthr) {
     int rw = 4;
-    for (int q = r * kMelSlots; q < (r + 1) * kMelSlots && q < mb.n_mels; ++q) {
+    for (int row = r * kMelSlots; row < (r + 1) * kMelSlots; ++row) {
+      const int q = row_to_mel(mb, row);
+      if (q < 0) continue;
       const int e = (mb.width[q] + (mb.lo[q] & 1) + 3) & ~3;
       rw = e > rw ? e : rw;
     }
@@ -127,16 +145,22 @@ AAMD_HD void mel_tab_rounds(int tid, int nthr, const MelBandsDev& mb, float* bas
 
 AAMD_HD void mel_tab_fill(int tid, int nthr, const MelBandsDev& mb, float* base, const MelTab& mt) {
   float* w = base;
-  int* lo2 = reinterpret_cast<int*>(base + mb.n_mels * mt.ws);
-  for (int i = tid; i < mb.n_mels * mt.ws; i += nthr) {
-    const int m = i / mt.ws, j = i - m * mt.ws;
-    const int rw = 4 * mt.rc[m / kMelSlots];
-    const int lo = mb.lo[m], wd = mb.width[m];
+  const int rows = mel_rows(mb.n_mels);
+  int* lo2 = reinterpret_cast<int*>(base + rows * mt.ws);
+  int* row_mel = lo2 + rows;
+  for (int i = tid; i < rows * mt.ws; i += nthr) {
+    const int row = i / mt.ws, j = i - row * mt.ws;
+    const int m = row_to_mel(mb, row);
+    const int rw = 4 * mt.rc[row / kMelSlots];
+    const int lo = m >= 0 ? mb.lo[m] : 0, wd = m >= 0 ? mb.width[m] : 0;
     int l2 = lo & ~1;
     if (l2 + rw > kPK) l2 = kPK - rw;
     const int off = lo - l2;
     w[i] = (j >= off && j - off < wd) ? mb.weights[m * mb.max_width + (j - off)] : 0.0f;
-    if (j == 0) lo2[m] = l2;
+    if (j == 0) {
+      lo2[row] = l2;
+      row_mel[row] = m;
+    }
   }
 }
 
@@ -469,10 +493,9 @@ AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
   for (int r = 0; r < kMelMaxRounds; ++r) {
     float sa = 0.0f, sb = 0.0f;
     if (r < mt.n_rounds) {
-      const int m = r * kMelSlots + c.pi;
-      const int mm = m < mt.n_mels ? m : 0;
-      const float* wt = mt.w + mm * mt.ws;
-      const float* P = Pp + 2 * mt.lo2[mm];
+      const int row = r * kMelSlots + c.pi;
+      const float* wt = mt.w + row * mt.ws;
+      const float* P = Pp + 2 * mt.lo2[row];
       const int nc = mt.rc[r];
       switch (nc) {
         case 1: mel_chunks<1>(wt, P, sa, sb); break;
@@ -496,10 +519,12 @@ AAMD_HD void store_direct(const LaneConst& c, const MelTab& mt, const float (&ac
   float* oa = out_row + ta * (int64_t)mt.n_mels;
 #pragma unroll
   for (int r = 0; r < kMelMaxRounds; ++r) {
-    const int m = r * kMelSlots + c.pi;
-    if (r < mt.n_rounds && m < mt.n_mels) {
-      if (va) oa[m] = acc_a[r];
-      if (vb) oa[mt.n_mels + m] = acc_b[r];
+    if (r < mt.n_rounds) {
+      const int m = mt.row_mel[r * kMelSlots + c.pi];
+      if (m >= 0) {
+        if (va) oa[m] = acc_a[r];
+        if (vb) oa[mt.n_mels + m] = acc_b[r];
+      }
     }
   }
 }
@@ -512,10 +537,12 @@ AAMD_HD void store_stage(const LaneConst& c, const MelTab& mt, const float (&acc
   float* oa = lds + 2 * c.p * mt.n_mels;
 #pragma unroll
   for (int r = 0; r < kMelMaxRounds; ++r) {
-    const int m = r * kMelSlots + c.pi;
-    if (r < mt.n_rounds && m < mt.n_mels) {
-      oa[m] = acc_a[r];
-      oa[mt.n_mels + m] = acc_b[r];
+    if (r < mt.n_rounds) {
+      const int m = mt.row_mel[r * kMelSlots + c.pi];
+      if (m >= 0) {
+        oa[m] = acc_a[r];
+        oa[mt.n_mels + m] = acc_b[r];
+      }
     }
   }
 }
@@ -570,7 +597,7 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
 }
 
 template <int LAB, int EPI>
-__global__ void __launch_bounds__(64 * kWavesPerBlock, 3)
+__global__ void __launch_bounds__(64 * kWavesPerBlock, AAMD_M400_MINWAVES)
 melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ window,
                   const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
                   int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
@@ -657,9 +684,18 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
 
   unsigned cur_idx = (unsigned)wave;
   TileInfo cur = tile_info(cur_idx);
-  if (LAB & 128) {   // lab: stagger the waves of a SIMD by thirds of a tile time
+  if (LAB & 128) {   // lab: stagger the waves of a SIMD by thirds of a tile time.  Interleaved A/B runs
+    // (tools/ubench/mel400_lab) put it within noise of the lock-step start (74-78 us either way): off.
     const int k = (wave + 6 * lb) % 3;
     for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(112);
+  }
+  if (LAB & 2048) {  // lab: 12 distinct phase offsets, 1/12 of a tile time apart
+    const int k = 4 * (wave & 3) + (wave >> 2) % 3;   // waves w, w+4, w+8 share a SIMD: a third apart
+    for (int i = 0; i < (k % 12); ++i) __builtin_amdgcn_s_sleep(17);
+  }
+  if (LAB & 4096) {  // lab: thirds within a SIMD + a twelfth between SIMDs
+    const int k = 4 * ((wave >> 2) % 3) + (wave & 3);
+    for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(17);
   }
   if (cur.staged && !(LAB & 8)) stage_issue(cur);
 

@@ -30,6 +30,7 @@ struct MelBandsDev {
   const int32_t* lo;
   const int32_t* width;
   const float* weights;
+  const int32_t* order;   // mel400 only: table row -> mel (lane assignment), -1 = unused row; null = identity
 };
 
 // ---- phase 1: gather one frame, multiply by the window, write complex (v, 0) ------------

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import warnings
 import weakref
 from typing import Optional, Union
@@ -106,8 +107,12 @@ class MelBandsOnDevice:
         self.width = torch.from_numpy(width).to(device)
         self.weights = torch.from_numpy(weights).to(device).contiguous()
         self.max_width = max_width
+        # lane assignment of the radix-20x20 kernel (bank-conflict optimised, results independent of it)
+        use_order = self.n_freq == 201 and os.environ.get("AAMD_MEL400_NO_LANE_ORDER") is None   # env: A/B experiments
+        self.lane_order = torch.from_numpy(_host.mel_lane_order(lo, width)).to(device) if use_order else None
         self.struct = _lib.MelBands(self.n_mels, max_width, self.lo.data_ptr(), self.width.data_ptr(),
-                                    self.weights.data_ptr())
+                                    self.weights.data_ptr(),
+                                    self.lane_order.data_ptr() if self.lane_order is not None else None)
 
 
 def _mel_bands(fb: Tensor, device) -> MelBandsOnDevice:

@@ -39,8 +39,8 @@ def pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -68,8 +68,10 @@ def main():
             dist.barrier()
 
     with torch.no_grad():
+        y = None
         for _ in range(args.warmup):
-            y = mel(x)
+            y = None                     # the consumer released the previous features: torch's caching
+            y = mel(x)                   # allocator hands the same 82 MB block back, as in a pipeline
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -78,6 +80,7 @@ def main():
         t0 = time.perf_counter()
         e0.record()                      # the kernels are launched on torch's current stream
         for _ in range(args.steps):
+            y = None
             y = mel(x)
         e1.record()
         torch.cuda.synchronize()

@@ -84,6 +84,11 @@ typedef struct aamd_mel_bands {
   const int32_t* lo;       /* device, n_mels */
   const int32_t* width;    /* device, n_mels */
   const float*   weights;  /* device, n_mels * max_width */
+  /* Optional (may be NULL = identity): lane assignment for the radix-20x20 kernel, device
+   * int32[ceil(n_mels/20)*20]; entry 20 r + i = the mel evaluated at lane position i in round r
+   * (every mel exactly once, -1 = unused).  Results do not depend on it; it only decides which
+   * LDS banks the band reads of a wavefront hit (audio_amd/_host.py: mel_lane_order). */
+  const int32_t* lane_order;
 } aamd_mel_bands;
 
 int         aamd_abi_version(void);

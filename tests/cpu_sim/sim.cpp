@@ -69,18 +69,18 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
 //      2 spectrogram |X|^power (bands unused)
 int sim_melspec400(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
                    float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
-                   int epi_mode, const float* db, float* gmax, int64_t rows_per_group, float power) {
+                   int epi_mode, const float* db, float* gmax, int64_t rows_per_group, float power, int want_wide) {
   using namespace m400;
   MelBandsDev mb{};
   if (epi_mode != EPI400_SPEC) {
-    mb = MelBandsDev{bands->n_mels, bands->max_width, bands->lo, bands->width, bands->weights};
+    mb = MelBandsDev{bands->n_mels, bands->max_width, bands->lo, bands->width, bands->weights, bands->lane_order};
     if (mel_ws(mb.max_width) > kMelMaxTaps + 4 || mel_rounds(mb.n_mels) > kMelMaxRounds) return -2;
   }
   Epi400 epi{};
   if (epi_mode == EPI400_MEL_DB) { epi.multiplier = db[0]; epi.amin = db[1]; epi.db_sub = db[2]; }
   epi.power = power;
   alignas(16) static float lds[kLdsDwordsPerWave];
-  alignas(16) static float tab[kMelMaxRounds * kMelSlots * (kMelMaxTaps + 4) + 256];
+  alignas(16) static float tab[kMelMaxRounds * kMelSlots * (kMelMaxTaps + 4 + 2) + 256];
   alignas(16) static float ctab[kConstDwords];
   for (int tid = 0; tid < 256; ++tid) const_tab_build(tid, 256, window, tw400, scale, ctab);
   MelTab mt{};
@@ -93,7 +93,7 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
   const int tiles_per_row = (n_frames + kFramesPerWave - 1) / kFramesPerWave;
   // same launch-time switches as launch_mel400() in c_api.hip
   const bool in_aligned = (row_stride % 4 == 0);
-  const bool out_wide = (epi_mode == EPI400_SPEC) || (mb.n_mels % 4 == 0);
+  const bool out_wide = (epi_mode == EPI400_SPEC) || (want_wide && mb.n_mels % 4 == 0);
   static float X[64][28], vr[64][20], vi[64][20], zr[64][20], zi[64][20], qr[64][10], qi[64][10];
   static float acc_a[64][kMelMaxRounds], acc_b[64][kMelMaxRounds];
   auto staged = [&](int64_t t0) {

@@ -38,14 +38,16 @@ def fptr(a):
 
 
 class HostBands:
-    def __init__(self, fb):
+    def __init__(self, fb, permute=False):
         self.lo, self.width, self.weights, self.max_width = _host.mel_band_table(np.asarray(fb))
         self.lo = np.ascontiguousarray(self.lo)
         self.width = np.ascontiguousarray(self.width)
         self.weights = np.ascontiguousarray(self.weights)
         self.n_mels = self.lo.shape[0]
+        self.lane_order = np.ascontiguousarray(_host.mel_lane_order(self.lo, self.width)) if permute else None
         self.struct = _lib.MelBands(self.n_mels, self.max_width, self.lo.ctypes.data, self.width.ctypes.data,
-                                    self.weights.ctypes.data)
+                                    self.weights.ctypes.data,
+                                    self.lane_order.ctypes.data if self.lane_order is not None else None)
 
 
 def make_desc(rows, length, n_fft, hop, pad=0, center=True, pad_mode="reflect", onesided=True, scale=1.0,
@@ -80,7 +82,8 @@ def sim_mel_generic(x, window_padded, bands, desc):
     return np.swapaxes(out, -1, -2)
 
 
-def _sim_fft400(x, window, bands, scale, epi, db=None, gmax=None, rows_per_group=1, power=2.0, out_width=None):
+def _sim_fft400(x, window, bands, scale, epi, db=None, gmax=None, rows_per_group=1, power=2.0, out_width=None,
+                wide=0):
     x = np.ascontiguousarray(x, dtype=np.float32)
     rows, length = x.shape
     w = np.ascontiguousarray(window, dtype=np.float32)
@@ -89,17 +92,17 @@ def _sim_fft400(x, window, bands, scale, epi, db=None, gmax=None, rows_per_group
     out = np.zeros((rows, T, out_width), dtype=np.float32)
     f = sim().sim_melspec400
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                  C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
+                  C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int]
     dbv = None if db is None else fptr(np.ascontiguousarray(db, dtype=np.float32))
     rc = f(fptr(x), fptr(w), fptr(tw), None if bands is None else C.cast(C.byref(bands.struct), C.c_void_p),
            fptr(out), rows, length, length, T, scale, epi, dbv, None if gmax is None else fptr(gmax),
-           rows_per_group, power)
+           rows_per_group, power, wide)
     assert rc == 0
     return np.swapaxes(out, -1, -2)
 
 
-def sim_mel400(x, window, bands, scale=1.0):
-    return _sim_fft400(x, window, bands, scale, 0, out_width=bands.n_mels)
+def sim_mel400(x, window, bands, scale=1.0, wide=0):
+    return _sim_fft400(x, window, bands, scale, 0, out_width=bands.n_mels, wide=wide)
 
 
 def sim_mel400_db(x, window, bands, multiplier, amin, db_multiplier, gmax, rows_per_group, scale=1.0):

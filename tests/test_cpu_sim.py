@@ -86,6 +86,14 @@ def test_sim_melspectrogram(case):
         got4 = S.sim_mel400(x2, wp, bands, scale).reshape(exp.shape)
         assert peak_rel_err(got4, exp) <= TOL
         assert peak_rel_err(got4, OD.evaluate(case, [x])) <= TOL
+        # LDS-staged store path and the bank-conflict-optimised lane assignment: identical results
+        got4w = S.sim_mel400(x2, wp, bands, scale, wide=1).reshape(exp.shape)
+        assert np.array_equal(got4w, got4)
+        perm = S.HostBands(fb, permute=True)
+        assert sorted(m for m in perm.lane_order if m >= 0) == list(range(perm.n_mels))
+        for wide in (0, 1):
+            got4p = S.sim_mel400(x2, wp, perm, scale, wide=wide).reshape(exp.shape)
+            assert np.array_equal(got4p, got4)
 
 
 def test_sim_mel400_framing_exact():
@@ -311,3 +319,28 @@ def test_sim_fftconvolve_overlap_save(nx, ny, mode):
     got = S.sim_fftconv_os(x, y, start, out_len, ymap=np.zeros(2, dtype=np.int64), rows=2)
     assert not np.isnan(got).any()
     assert peak_rel_err(got, exp) <= 2e-6
+
+
+def test_mel_lane_order_reduces_modelled_bank_conflicts():
+    """Host optimiser of the lane assignment: a permutation inside each round, cheaper than identity under
+    the b128 bank model of MI355X_MICROARCH.md for the headline filterbank; ragged n_mels keep -1 rows."""
+    fb = O.melscale_fbanks(201, 0.0, 8000.0, 80, 16000).astype(np.float32)
+    lo, width, _, _ = _host.mel_band_table(fb)
+    order = _host.mel_lane_order(lo, width)
+    assert order.shape == (80,) and sorted(order) == list(range(80))
+    for r in range(4):
+        assert sorted(order[20 * r: 20 * r + 20]) == list(range(20 * r, 20 * r + 20))
+
+    def total(ordr):
+        c = 0
+        for r in range(4):
+            ms = ordr[20 * r: 20 * r + 20]
+            rw = max(int((width[m] + (lo[m] & 1) + 3) & ~3) for m in ms)
+            c += _host._m400_round_cost(np.array([min(int(lo[m]) & ~1, 208 - rw) for m in ms]))
+        return c
+
+    assert total(order) < total(np.arange(80))
+    fb64 = O.melscale_fbanks(201, 0.0, 8000.0, 64, 16000).astype(np.float32)
+    lo, width, _, _ = _host.mel_band_table(fb64)
+    o64 = _host.mel_lane_order(lo, width)
+    assert o64.shape == (80,) and sorted(m for m in o64 if m >= 0) == list(range(64)) and (o64 == -1).sum() == 16 and (o64[:60] >= 0).all()

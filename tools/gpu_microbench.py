@@ -36,6 +36,35 @@ def main():
             us = timeit(lambda: mel(x), 10, 100)
             by = 256 * 160000 * 4 + 256 * 1001 * 80 * 4
             print(f"mel400 fast : {us:9.1f} us  {by / us / 1e3:8.1f} GB/s  frac {by / us / 1e3 / 8000:.3f}", flush=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                mel(x)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            print(f"  host issue {1e6 * (t1 - t0) / 200:.1f} us/call, issue+drain {1e6 * (t2 - t0) / 200:.1f} us/call", flush=True)
+            out = torch.empty(256, 1001, 80, device=dev)
+            import ctypes as C
+            from audio_amd import _lib
+            sp = mel.spectrogram
+            x2 = x
+            desc = F._stft_desc(x2, 0, sp.window, 400, 160, 2.0, False, True, "reflect", True)
+            bands = F._mel_bands(mel.mel_scale.fb, dev)
+            L = _lib.lib()
+            args = (x2.data_ptr(), F._padded_window(sp.window, 400).data_ptr(), F._twiddles(400, dev).data_ptr(),
+                    C.byref(bands.struct), out.data_ptr(), C.byref(desc), _lib.current_stream(dev))
+            us = timeit(lambda: L.aamd_melspectrogram_f32(*args), 10, 200)
+            print(f"  raw C-ABI launches into ONE output buffer: {us:9.1f} us  frac {by / us / 1e3 / 8000:.3f}", flush=True)
+            # A/B in one process: lane order on/off, interleaved (box-to-box variation is +-8 %)
+            os.environ["AAMD_MEL400_NO_LANE_ORDER"] = "1"
+            mel_b = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).to(dev)
+            mel_b(x)
+            del os.environ["AAMD_MEL400_NO_LANE_ORDER"]
+            for rep in range(3):
+                ua = timeit(lambda: mel(x), 5, 100)
+                ub = timeit(lambda: mel_b(x), 5, 100)
+                print(f"  A/B lane order on {ua:7.1f} us | off {ub:7.1f} us", flush=True)
             for v in os.environ.get("AAMD_VARIANTS", "").split(","):
                 if v:
                     os.environ["AAMD_MEL400_VARIANT"] = v

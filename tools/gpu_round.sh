@@ -5,7 +5,7 @@ timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r1a/pytest.log 2>&1
 timeout 300 python bench.py > gpurun_out/r1a/bench.json 2> gpurun_out/r1a/bench.err
 timeout 300 python tools/gpu_microbench.py mel spec mfcc resample lfilter fftconv > gpurun_out/r1a/micro.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r1a/prof -o mel -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r1a/prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r1a/prof -o mel -- python $R/bench.py --steps 1000 --warmup 500 --no-cpu-baseline > $R/gpurun_out/r1a/prof.log 2>&1
 cd $R
 python tools/prof_summary.py gpurun_out/r1a/prof > gpurun_out/r1a/prof_summary.txt
 printf 'FETCH_SIZE\nWRITE_SIZE\nGRBM_GUI_ACTIVE GRBM_COUNT\nSQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR\nSQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA\n' > /tmp/grp.txt

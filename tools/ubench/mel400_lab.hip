@@ -1,4 +1,4 @@
-// Design lab for the headline kernel (NOT product): ablation variants of melspec400_kernel<LAB> built
+// Design lab for the headline kernel (NOT product): ablation variants of melspec400_kernel<LAB, 0> built
 // from the same phase functions, timed with HIP events on one MI355X, plus a float64 host check.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize mel400_lab.hip -o mel400_lab
 #include <hip/hip_runtime.h>
@@ -64,17 +64,17 @@ static float run(const char* name, int blocks, size_t lds, const float* wav, con
   const int tiles_per_row = (T + kFramesPerWave - 1) / kFramesPerWave;
   const int64_t n_tiles = rows * tiles_per_row;
   const int tpw = (int)((n_tiles + blocks - 1) / blocks);   // tiles per block
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(melspec400_kernel<LAB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(melspec400_kernel<LAB, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 10; ++i)
-    hipLaunchKernelGGL(melspec400_kernel<LAB>, dim3(blocks), dim3(64 * kWavesPerBlock), lds, 0, wav, win, tw, mb, out, rows, L, L, T, 1.0f, tiles_per_row, n_tiles, tpw, in_aligned, out_wide);
+  for (int i = 0; i < (name[0] ? 10 : 3); ++i)
+    hipLaunchKernelGGL((melspec400_kernel<LAB, 0>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, 0, wav, win, tw, mb, out, rows, L, L, T, 1.0f, tiles_per_row, n_tiles, tpw, in_aligned, out_wide, Epi400{});
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL(melspec400_kernel<LAB>, dim3(blocks), dim3(64 * kWavesPerBlock), lds, 0, wav, win, tw, mb, out, rows, L, L, T, 1.0f, tiles_per_row, n_tiles, tpw, in_aligned, out_wide);
+    hipLaunchKernelGGL((melspec400_kernel<LAB, 0>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, 0, wav, win, tw, mb, out, rows, L, L, T, 1.0f, tiles_per_row, n_tiles, tpw, in_aligned, out_wide, Epi400{});
   CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-  printf("%-44s %8.1f us\n", name, ms * 1e3f / iters);
+  if (name[0]) printf("%-44s %8.1f us\n", name, ms * 1e3f / iters);
   return ms * 1e3f / iters;
 }
 
@@ -101,8 +101,8 @@ int main(int argc, char** argv) {
   const size_t lds = lds_bytes(M, maxw) + lds_pad;
   const int blocks = 256 * occ_blocks;
   int occ = 0;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(melspec400_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, melspec400_kernel<0>, 64 * kWavesPerBlock, lds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(melspec400_kernel<0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, melspec400_kernel<0, 0>, 64 * kWavesPerBlock, lds));
   printf("blocks/CU %d (occupancy API: %d), LDS/block %zu B, max band width %d\n", occ_blocks, occ, lds, maxw);
   const int it = 50;
   run<0>("product: staged in + wide out", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
@@ -130,12 +130,34 @@ int main(int argc, char** argv) {
     printf("float64 check: peak-rel err %.3e\n", worst / peak);
   }
   run<0>("product: staged in + narrow out", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 0);
+  {  // interleaved A/B (medians of 7 x 30 launches each): stagger on/off x lane order on/off, narrow stores
+    MelBandsDev mbo = mb;
+    std::vector<int> ord;
+    if (FILE* f = fopen("tools/ubench/order80.txt", "r")) { int v; while (fscanf(f, "%d", &v) == 1) ord.push_back(v); fclose(f); }
+    int* dord = nullptr;
+    if ((int)ord.size() == 80) { CK(hipMalloc(&dord, 320)); CK(hipMemcpy(dord, ord.data(), 320, hipMemcpyHostToDevice)); mbo.order = dord; }
+    std::vector<float> t[4];
+    for (int rep = 0; rep < 7; ++rep) {
+      t[0].push_back(run<0>("", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, 30, 1, 0));
+      t[1].push_back(run<128>("", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, 30, 1, 0));
+      if (dord) {
+        t[2].push_back(run<0>("", blocks, lds, dx, dwin, dtw, mbo, dout, rows, L, T, 30, 1, 0));
+        t[3].push_back(run<128>("", blocks, lds, dx, dwin, dtw, mbo, dout, rows, L, T, 30, 1, 0));
+      }
+    }
+    const char* nm[4] = {"no stagger, identity order", "stagger, identity order", "no stagger, lane order", "stagger, lane order"};
+    for (int i = 0; i < 4; ++i) if (!t[i].empty()) { std::sort(t[i].begin(), t[i].end()); printf("A/B median %-28s %7.1f us (min %.1f max %.1f)\n", nm[i], t[i][t[i].size() / 2], t[i].front(), t[i].back()); }
+  }
   run<1>("LAB1 no stage wait", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
   run<2>("LAB2 no global stores", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
   run<3>("LAB3 no wait, no stores", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
   run<3+32>("LAB35 no wait/stores, DMA same tile", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
   run<3+64>("LAB67 no wait/stores, DMA 1 of 5", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
-  run<128>("LAB128 product, staggered start", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
+  run<2048>("LAB2048 product, 12-phase stagger (SIMD-major)", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
+  run<4096>("LAB4096 product, thirds per SIMD + twelfths", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
+  run<4096>("LAB4096 + narrow out", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 0);
+  run<128>("LAB128 stagger + narrow out", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 0);
+  run<128>("LAB128 product with the wave stagger", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
   run<8>("LAB8 no DMA issue", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
   run<11>("LAB11 no DMA, no wait, no stores", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
   run<15>("LAB15 ... and no phase C", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);

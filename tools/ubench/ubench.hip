@@ -100,6 +100,16 @@ int main() {
     double cyc = ms * 1e-3 * 2.4e9 / (instr_per_wave * waves_per_simd);
     printf("%-34s %8.3f ms  %6.2f cycles/wave-instr/SIMD (at 2.4 GHz)\n", name, ms, cyc);
   };
+  for (int wps : {1, 2, 3, 4, 8}) {   // VALU issue rate vs waves per SIMD (256-thread WGs: 1 wave per SIMD each)
+    const int nb = 256 * wps;
+    auto rep = [&](const char* name, float ms) {
+      printf("  %d waves/SIMD %-14s %6.2f cycles/wave-instr/SIMD (at 2.4 GHz nominal)\n", wps, name,
+             ms * 1e-3 * 2.4e9 / (8.0 * ITERS * wps));
+    };
+    rep("v_fma_f32", run([&] { k_fma<<<nb, threads>>>(out, 1.0001f, 0.5f); }));
+    rep("v_add_f32", run([&] { k_add<<<nb, threads>>>(out, 1.0001f, 0.5f); }));
+    rep("v_pk_fma_f32", run([&] { k_pkfma<<<nb, threads>>>(out, 1.0001f, 0.5f); }));
+  }
   report("v_fma_f32", run([&] { k_fma<<<blocks, threads>>>(out, 1.0001f, 0.5f); }), 8.0 * ITERS);
   report("v_pk_fma_f32", run([&] { k_pkfma<<<blocks, threads>>>(out, 1.0001f, 0.5f); }), 8.0 * ITERS);
   report("v_add_f32", run([&] { k_add<<<blocks, threads>>>(out, 1.0001f, 0.5f); }), 8.0 * ITERS);
