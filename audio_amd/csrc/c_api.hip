@@ -124,17 +124,20 @@ template <int EPI>
 int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
                    const float* twiddle, float* out, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
-  const int fpb = 4;
-  const int bpr = (g.n_frames + fpb - 1) / fpb;
+  int pb = gen_pairs_per_block(g.n_fft);
+  const int pairs_per_row = (g.n_frames + 1) / 2;
+  if (pb > pairs_per_row) pb = pairs_per_row;
+  const int bpr = (pairs_per_row + pb - 1) / pb;
   const int64_t blocks = g.rows * bpr;
   AAMD_CHECK_ARG(blocks < (1ll << 31), "too many frames for one launch");
-  const size_t lds = (size_t)2 * g.n_fft * sizeof(cplx<float>) + (size_t)g.n_freq * sizeof(float);
+  const size_t lds = gen_lds_floats(g.n_fft, g.n_freq, pb) * sizeof(float);
+  if (lds > dev_props().lds_per_block_optin) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft too large for the LDS");
   auto kern = stft_generic_kernel<float, EPI>;
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, g, wav, window,
-                     reinterpret_cast<const cplx<float>*>(twiddle), mb, out, fpb, bpr);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGenThreads), lds, s, g, wav, window,
+                     reinterpret_cast<const cplx<float>*>(twiddle), mb, out, pb, bpr);
   return launch_check();
 }
 

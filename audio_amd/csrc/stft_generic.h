@@ -1,10 +1,12 @@
 // Generic STFT path: any n_fft (mixed radix, arbitrary prime factors), any hop / padding /
 // window / normalisation / power, with optional fused banded-mel epilogue.
 //
-// One workgroup owns a run of consecutive frames of one waveform.  Per frame:
+// One workgroup owns 2 PB consecutive frames of one waveform (PB frame PAIRS, each pair one complex FFT):
 //   load+window (reflect/replicate/circular/constant index math, exact integers)
-//   -> Stockham autosort FFT, ping-pong between two LDS buffers, one barrier per stage
-//   -> epilogue straight from LDS (|X|^p or complex, or banded mel reduction).
+//   -> Stockham autosort FFT, ping-pong between two LDS buffers, one barrier per stage, ONE radix-r
+//      butterfly per work item (radix 2/3/4/5 in registers, any other prime by its r-point DFT),
+//      twiddles from an LDS copy of the W_N table
+//   -> epilogue straight from LDS: separate the two real spectra, |X|^p or complex, or banded mel.
 // This is the correctness workhorse for every shape that is not the (400,160) headline
 // kernel in melspec400.h; both are checked against the same oracle.
 //
@@ -33,50 +35,136 @@ struct MelBandsDev {
   const int32_t* order;   // mel400 only: table row -> mel (lane assignment), -1 = unused row; null = identity
 };
 
-// ---- phase 1: gather one frame, multiply by the window, write complex (v, 0) ------------
+// ---- geometry of one workgroup: PB frame PAIRS (2 PB consecutive frames of one waveform) ------------
+// Two real frames a, b = a + 1 are transformed as ONE complex sequence z = a + i b and separated in
+// the epilogue with X_a[k] = (Z[k] + conj Z[N-k]) / 2,  X_b[k] = (Z[k] - conj Z[N-k]) / (2i).
+constexpr int kGenThreads = 256;
+AAMD_HD int gen_pairs_per_block(int n_fft) {
+  int p = 1024 / n_fft;
+  return p < 1 ? 1 : (p > 8 ? 8 : p);
+}
+// LDS floats: twiddle table N complex | two ping-pong buffers of PB x N complex | PB x 2 power rows
+AAMD_HD size_t gen_lds_floats(int n_fft, int n_freq, int pb) {
+  return (size_t)2 * n_fft + (size_t)4 * pb * n_fft + (size_t)2 * pb * n_freq;
+}
+
 template <typename T>
-AAMD_HD void stft_load_frame(int tid, int nthr, const StftGeom& g, const T* wav_row,
-                             const T* window, int64_t t, cplx<T>* buf) {
+AAMD_HD T stft_sample(const StftGeom& g, const T* wav_row, int64_t t, int n) {
   const int64_t L1 = g.length + 2 * (int64_t)g.pad;  // after F.spectrogram's zero pad
-  const int64_t base = t * (int64_t)g.hop - (g.center ? g.n_fft / 2 : 0);
-  for (int n = tid; n < g.n_fft; n += nthr) {
-    int64_t i1 = base + n;
-    int64_t s1 = g.center ? pad_source_index(i1, L1, g.pad_mode) : i1;
-    T v = 0;
-    if (s1 >= 0) {
-      int64_t s0 = s1 - g.pad;
-      if (s0 >= 0 && s0 < g.length) v = wav_row[s0];
-    }
-    buf[n] = {v * window[n], (T)0};
+  const int64_t i1 = t * (int64_t)g.hop - (g.center ? g.n_fft / 2 : 0) + n;
+  const int64_t s1 = g.center ? pad_source_index(i1, L1, g.pad_mode) : i1;
+  if (s1 < 0) return (T)0;
+  const int64_t s0 = s1 - g.pad;
+  return (s0 >= 0 && s0 < g.length) ? wav_row[s0] : (T)0;
+}
+
+// ---- phase 1: gather PB frame pairs, multiply by the window, write z = a + i b ----------------------
+template <typename T>
+AAMD_HD void gen_load(int tid, int nthr, const StftGeom& g, const T* wav_row, const T* window, int64_t t0,
+                      int pb, cplx<T>* buf) {
+  const int N = g.n_fft;
+  for (int idx = tid; idx < pb * N; idx += nthr) {
+    const int pair = idx / N, n = idx - pair * N;
+    const int64_t ta = t0 + 2 * pair, tb = ta + 1;
+    const T w = window[n];
+    const T a = (ta < g.n_frames) ? stft_sample<T>(g, wav_row, ta, n) * w : (T)0;
+    const T b = (tb < g.n_frames) ? stft_sample<T>(g, wav_row, tb, n) * w : (T)0;
+    buf[idx] = {a, b};
   }
 }
 
-// ---- phase 2: one Stockham (DIF, autosort) stage of radix r, sub-length n = N/s ---------
-//   y[q + s(r p + k)] = W_n^{pk} * sum_j x[q + s(p + m j)] W_r^{jk},  m = n/r,
-//   p in [0,m), q in [0,s), k in [0,r).   One work item per output element.
+// ---- radix butterflies (forward, e^{-2 pi i jk/r}), in place on v[0..r) ------------------------------
 template <typename T>
-AAMD_HD void stockham_stage(int tid, int nthr, int N, int r, int s, const cplx<T>* x,
-                            cplx<T>* y, const cplx<T>* tw) {
-  const int n = N / s;
-  const int m = n / r;
-  const int nb = N / r;  // butterflies
-  for (int u = tid; u < N; u += nthr) {
-    const int k = u / nb;
-    const int i = u - k * nb;
-    const int p = i / s;
-    const int q = i - p * s;
-    cplx<T> acc = {0, 0};
-    const int wstep = (int)(((int64_t)nb * k) % N);  // W_r^{k} as a power of W_N
-    int widx = 0;
-    for (int j = 0; j < r; ++j) {
-      cplx<T> a = x[q + s * (p + m * j)];
-      acc = cadd(acc, cmul(a, tw[widx]));
-      widx += wstep;
-      if (widx >= N) widx -= N;
+AAMD_HD void bfly2(cplx<T>* v) {
+  const cplx<T> a = v[0], b = v[1];
+  v[0] = cadd(a, b);
+  v[1] = csub(a, b);
+}
+template <typename T>
+AAMD_HD void bfly4(cplx<T>* v) {
+  const cplx<T> s0 = cadd(v[0], v[2]), s1 = csub(v[0], v[2]), s2 = cadd(v[1], v[3]), s3 = csub(v[1], v[3]);
+  const cplx<T> m = {s3.y, -s3.x};   // -i * s3
+  v[0] = cadd(s0, s2);
+  v[1] = cadd(s1, m);
+  v[2] = csub(s0, s2);
+  v[3] = csub(s1, m);
+}
+template <typename T>
+AAMD_HD void bfly3(cplx<T>* v) {
+  const T h = (T)0.86602540378443864676;   // sin(2 pi / 3)
+  const cplx<T> t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+  const cplx<T> c = {v[0].x - (T)0.5 * t.x, v[0].y - (T)0.5 * t.y};
+  const cplx<T> e = {h * d.y, -h * d.x};   // -i * h * d
+  v[0] = cadd(v[0], t);
+  v[1] = cadd(c, e);
+  v[2] = csub(c, e);
+}
+template <typename T>
+AAMD_HD void bfly5(cplx<T>* v) {
+  const T C1 = (T)0.30901699437494742, C2 = (T)-0.80901699437494742;
+  const T S1 = (T)0.95105651629515357, S2 = (T)0.58778525229247313;
+  const cplx<T> t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+  const cplx<T> m1 = {v[0].x + C1 * t1.x + C2 * t2.x, v[0].y + C1 * t1.y + C2 * t2.y};
+  const cplx<T> m2 = {v[0].x + C2 * t1.x + C1 * t2.x, v[0].y + C2 * t1.y + C1 * t2.y};
+  const cplx<T> u1 = {S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y};
+  const cplx<T> u2 = {S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y};
+  v[0] = {v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y};
+  v[1] = {m1.x + u1.y, m1.y - u1.x};   // m1 - i u1
+  v[4] = {m1.x - u1.y, m1.y + u1.x};
+  v[2] = {m2.x + u2.y, m2.y - u2.x};   // m2 - i u2
+  v[3] = {m2.x - u2.y, m2.y + u2.x};
+}
+
+// load R inputs (stride `in_stride`), butterfly in registers, twiddle, store R outputs (stride `out_stride`)
+template <typename T, int R>
+AAMD_HD void gen_bfly_static(const cplx<T>* xs, cplx<T>* ys, int in_stride, int out_stride, int step,
+                             const cplx<T>* tw) {
+  cplx<T> v[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) v[j] = xs[in_stride * j];
+  if (R == 4) bfly4<T>(v);
+  else if (R == 5) bfly5<T>(v);
+  else if (R == 2) bfly2<T>(v);
+  else bfly3<T>(v);
+  ys[0] = v[0];
+#pragma unroll
+  for (int k = 1; k < R; ++k) ys[out_stride * k] = cmul(v[k], tw[step * k]);
+}
+
+// ---- phase 2: one Stockham (autosort) stage of radix r on PB sequences: one BUTTERFLY per work item --
+//   y[q + s(r p + k)] = W_N^{s p k} * sum_j x[q + s(p + m j)] W_r^{jk},  m = N / (s r),
+//   p in [0,m), q in [0,s), k in [0,r);  s p k < N, so the twiddle index needs no reduction.
+template <typename T>
+AAMD_HD void gen_stage(int tid, int nthr, int N, int r, int s, int pb, const cplx<T>* x, cplx<T>* y,
+                       const cplx<T>* tw) {
+  const int nb = N / r;          // butterflies per sequence
+  const int m = nb / s;
+  for (int it = tid; it < pb * nb; it += nthr) {
+    const int pair = it / nb, i = it - pair * nb;
+    const int p = i / s, q = i - p * s;
+    const cplx<T>* xs = x + pair * N + q + s * p;
+    cplx<T>* ys = y + pair * N + q + s * r * p;
+    const int step = s * p;      // W_N^{s p k}
+    if (r == 4) {
+      gen_bfly_static<T, 4>(xs, ys, s * m, s, step, tw);
+    } else if (r == 5) {
+      gen_bfly_static<T, 5>(xs, ys, s * m, s, step, tw);
+    } else if (r == 2) {
+      gen_bfly_static<T, 2>(xs, ys, s * m, s, step, tw);
+    } else if (r == 3) {
+      gen_bfly_static<T, 3>(xs, ys, s * m, s, step, tw);
+    } else {   // any other prime radix: direct r-point DFT, W_r^{jk} = W_N^{(N/r) (jk mod r)}
+      for (int k = 0; k < r; ++k) {
+        cplx<T> acc = xs[0];
+        int e = 0;
+        for (int j = 1; j < r; ++j) {
+          e += k;
+          if (e >= r) e -= r;
+          acc = cadd(acc, cmul(xs[s * m * j], tw[nb * e]));
+        }
+        ys[s * k] = (k == 0) ? acc : cmul(acc, tw[step * k]);
+      }
     }
-    const int tidx = (int)(((int64_t)s * p * k) % N);  // W_n^{pk}
-    acc = cmul(acc, tw[tidx]);
-    y[q + s * (r * p + k)] = acc;
   }
 }
 
@@ -89,38 +177,64 @@ AAMD_HD T mag_pow(T re, T im, float power) {
   return pow(m, (T)power);
 }
 
-// ---- phase 3a: spectrogram epilogue ----------------------------------------------------
+// the two real spectra of pair `pair` at bin k (scaled)
 template <typename T>
-AAMD_HD void stft_store_spec(int tid, int nthr, const StftGeom& g, const cplx<T>* X,
-                             T* out_frame) {
-  for (int k = tid; k < g.n_freq; k += nthr) {
-    T re = X[k].x * (T)g.scale, im = X[k].y * (T)g.scale;
+AAMD_HD void gen_separate(const StftGeom& g, const cplx<T>* X, int pair, int k, cplx<T>& A, cplx<T>& B) {
+  const int N = g.n_fft;
+  const cplx<T> zk = X[pair * N + k];
+  const cplx<T> zm = X[pair * N + (k == 0 ? 0 : N - k)];
+  const T h = (T)0.5 * (T)g.scale;
+  A = {h * (zk.x + zm.x), h * (zk.y - zm.y)};       // (Z[k] + conj Z[N-k]) / 2
+  B = {h * (zk.y + zm.y), h * (zm.x - zk.x)};       // (Z[k] - conj Z[N-k]) / (2i)
+}
+
+// ---- phase 3a: spectrogram epilogue (2 PB frames x n_freq bins, frame-major output) --------------------
+template <typename T>
+AAMD_HD void gen_store_spec(int tid, int nthr, const StftGeom& g, const cplx<T>* X, int pb, int64_t t0,
+                            T* out_row /* frame 0 of this waveform */) {
+  const int opf = g.power <= 0.0f ? 2 * g.n_freq : g.n_freq;
+  for (int idx = tid; idx < 2 * pb * g.n_freq; idx += nthr) {
+    const int f = idx / g.n_freq, k = idx - f * g.n_freq;
+    const int64_t t = t0 + f;
+    if (t >= g.n_frames) continue;
+    cplx<T> A, B;
+    gen_separate<T>(g, X, f >> 1, k, A, B);
+    const cplx<T> v = (f & 1) ? B : A;
+    T* o = out_row + t * (int64_t)opf;
     if (g.power <= 0.0f) {
-      out_frame[2 * k] = re;
-      out_frame[2 * k + 1] = im;
+      o[2 * k] = v.x;
+      o[2 * k + 1] = v.y;
     } else {
-      out_frame[k] = mag_pow(re, im, g.power);
+      o[k] = mag_pow(v.x, v.y, g.power);
     }
   }
 }
 
-// ---- phase 3b/3c: power spectrum to LDS, then banded mel reduction ------------------------
+// ---- phase 3b/3c: power rows to LDS, then banded mel reduction ---------------------------------------
 template <typename T>
-AAMD_HD void stft_power_to_lds(int tid, int nthr, const StftGeom& g, const cplx<T>* X, T* P) {
-  for (int k = tid; k < g.n_freq; k += nthr) {
-    T re = X[k].x * (T)g.scale, im = X[k].y * (T)g.scale;
-    P[k] = mag_pow(re, im, g.power);
+AAMD_HD void gen_power_rows(int tid, int nthr, const StftGeom& g, const cplx<T>* X, int pb, T* P) {
+  for (int idx = tid; idx < pb * g.n_freq; idx += nthr) {
+    const int pair = idx / g.n_freq, k = idx - pair * g.n_freq;
+    cplx<T> A, B;
+    gen_separate<T>(g, X, pair, k, A, B);
+    P[(2 * pair) * g.n_freq + k] = mag_pow(A.x, A.y, g.power);
+    P[(2 * pair + 1) * g.n_freq + k] = mag_pow(B.x, B.y, g.power);
   }
 }
 
 template <typename T>
-AAMD_HD void mel_from_lds(int tid, int nthr, const MelBandsDev& mb, const T* P, T* out_frame) {
-  for (int m = tid; m < mb.n_mels; m += nthr) {
+AAMD_HD void gen_mel(int tid, int nthr, const StftGeom& g, const MelBandsDev& mb, const T* P, int pb, int64_t t0,
+                     T* out_row) {
+  for (int idx = tid; idx < 2 * pb * mb.n_mels; idx += nthr) {
+    const int f = idx / mb.n_mels, m = idx - f * mb.n_mels;
+    const int64_t t = t0 + f;
+    if (t >= g.n_frames) continue;
     const int lo = mb.lo[m], w = mb.width[m];
     const float* wt = mb.weights + (int64_t)m * mb.max_width;
+    const T* Pf = P + f * g.n_freq + lo;
     T acc = 0;
-    for (int i = 0; i < w; ++i) acc += (T)wt[i] * P[lo + i];
-    out_frame[m] = acc;
+    for (int i = 0; i < w; ++i) acc += (T)wt[i] * Pf[i];
+    out_row[t * (int64_t)mb.n_mels + m] = acc;
   }
 }
 
@@ -128,46 +242,42 @@ AAMD_HD void mel_from_lds(int tid, int nthr, const MelBandsDev& mb, const T* P, 
 enum { EPI_SPEC = 0, EPI_MEL = 1 };
 
 template <typename T, int EPI>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kGenThreads)
 stft_generic_kernel(StftGeom g, const T* __restrict__ wav, const T* __restrict__ window,
                     const cplx<T>* __restrict__ tw, MelBandsDev mb, T* __restrict__ out,
-                    int frames_per_block, int blocks_per_row) {
+                    int pairs_per_block, int blocks_per_row) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  cplx<T>* bufA = reinterpret_cast<cplx<T>*>(smem);
-  cplx<T>* bufB = bufA + g.n_fft;
-  T* P = reinterpret_cast<T*>(bufB + g.n_fft);
+  const int N = g.n_fft, pb = pairs_per_block;
+  cplx<T>* twl = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* bufA = twl + N;
+  cplx<T>* bufB = bufA + pb * N;
+  T* P = reinterpret_cast<T*>(bufB + pb * N);
 
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int64_t row = blockIdx.x / blocks_per_row;
   const int chunk = blockIdx.x - (int)row * blocks_per_row;
+  const int64_t t0 = (int64_t)chunk * 2 * pb;
   const T* wav_row = wav + row * g.row_stride;
-  const int out_per_frame =
-      EPI == EPI_MEL ? mb.n_mels : (g.power <= 0.0f ? 2 * g.n_freq : g.n_freq);
-
-  for (int f = 0; f < frames_per_block; ++f) {
-    const int64_t t = (int64_t)chunk * frames_per_block + f;
-    if (t >= g.n_frames) break;
-    stft_load_frame<T>(tid, nthr, g, wav_row, window, t, bufA);
+  for (int i = tid; i < N; i += nthr) twl[i] = tw[i];
+  gen_load<T>(tid, nthr, g, wav_row, window, t0, pb, bufA);
+  __syncthreads();
+  cplx<T>* x = bufA;
+  cplx<T>* y = bufB;
+  int s = 1;
+  for (int st = 0; st < g.n_stages; ++st) {
+    const int r = g.radix[st];
+    gen_stage<T>(tid, nthr, N, r, s, pb, x, y, twl);
     __syncthreads();
-    cplx<T>* x = bufA;
-    cplx<T>* y = bufB;
-    int s = 1;
-    for (int st = 0; st < g.n_stages; ++st) {
-      const int r = g.radix[st];
-      stockham_stage<T>(tid, nthr, g.n_fft, r, s, x, y, tw);
-      __syncthreads();
-      s *= r;
-      cplx<T>* tmp = x; x = y; y = tmp;
-    }
-    T* out_frame = out + (row * g.n_frames + t) * (int64_t)out_per_frame;
-    if (EPI == EPI_SPEC) {
-      stft_store_spec<T>(tid, nthr, g, x, out_frame);
-    } else {
-      stft_power_to_lds<T>(tid, nthr, g, x, P);
-      __syncthreads();
-      mel_from_lds<T>(tid, nthr, mb, P, out_frame);
-    }
+    s *= r;
+    cplx<T>* tmp = x; x = y; y = tmp;
+  }
+  if (EPI == EPI_SPEC) {
+    const int opf = g.power <= 0.0f ? 2 * g.n_freq : g.n_freq;
+    gen_store_spec<T>(tid, nthr, g, x, pb, t0, out + row * g.n_frames * (int64_t)opf);
+  } else {
+    gen_power_rows<T>(tid, nthr, g, x, pb, P);
     __syncthreads();
+    gen_mel<T>(tid, nthr, g, mb, P, pb, t0, out + row * g.n_frames * (int64_t)mb.n_mels);
   }
 }
 #endif  // __HIPCC__

@@ -38,28 +38,33 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
   if (g.n_stages < 0) return -1;
   MelBandsDev mb{};
   if (epi_mel) { mb.n_mels = bands->n_mels; mb.max_width = bands->max_width; mb.lo = bands->lo; mb.width = bands->width; mb.weights = bands->weights; }
-  const int nthr = 256;
-  std::vector<cplx<float>> A(g.n_fft), B(g.n_fft);
-  std::vector<float> P(g.n_freq);
+  const int nthr = kGenThreads, N = g.n_fft;
+  int pb = gen_pairs_per_block(N);
+  const int pairs_per_row = (g.n_frames + 1) / 2;
+  if (pb > pairs_per_row) pb = pairs_per_row;
+  const int bpr = (pairs_per_row + pb - 1) / pb;
+  std::vector<cplx<float>> A((size_t)pb * N), B((size_t)pb * N);
+  std::vector<float> P((size_t)2 * pb * g.n_freq);
   const cplx<float>* twc = reinterpret_cast<const cplx<float>*>(tw);
   const int opf = epi_mel ? mb.n_mels : (g.power <= 0.f ? 2 * g.n_freq : g.n_freq);
   for (int64_t row = 0; row < g.rows; ++row)
-    for (int64_t t = 0; t < g.n_frames; ++t) {
+    for (int chunk = 0; chunk < bpr; ++chunk) {
+      const int64_t t0 = (int64_t)chunk * 2 * pb;
       const float* wr = wav + row * g.row_stride;
-      for (int tid = 0; tid < nthr; ++tid) stft_load_frame<float>(tid, nthr, g, wr, window, t, A.data());
+      for (int tid = 0; tid < nthr; ++tid) gen_load<float>(tid, nthr, g, wr, window, t0, pb, A.data());
       cplx<float>* x = A.data(); cplx<float>* y = B.data();
       int s = 1;
       for (int st = 0; st < g.n_stages; ++st) {
-        for (int tid = 0; tid < nthr; ++tid) stockham_stage<float>(tid, nthr, g.n_fft, g.radix[st], s, x, y, twc);
+        for (int tid = 0; tid < nthr; ++tid) gen_stage<float>(tid, nthr, N, g.radix[st], s, pb, x, y, twc);
         s *= g.radix[st];
         std::swap(x, y);
       }
-      float* of = out + (row * g.n_frames + t) * (int64_t)opf;
+      float* out_row = out + row * g.n_frames * (int64_t)opf;
       if (!epi_mel) {
-        for (int tid = 0; tid < nthr; ++tid) stft_store_spec<float>(tid, nthr, g, x, of);
+        for (int tid = 0; tid < nthr; ++tid) gen_store_spec<float>(tid, nthr, g, x, pb, t0, out_row);
       } else {
-        for (int tid = 0; tid < nthr; ++tid) stft_power_to_lds<float>(tid, nthr, g, x, P.data());
-        for (int tid = 0; tid < nthr; ++tid) mel_from_lds<float>(tid, nthr, mb, P.data(), of);
+        for (int tid = 0; tid < nthr; ++tid) gen_power_rows<float>(tid, nthr, g, x, pb, P.data());
+        for (int tid = 0; tid < nthr; ++tid) gen_mel<float>(tid, nthr, g, mb, P.data(), pb, t0, out_row);
       }
     }
   return 0;
