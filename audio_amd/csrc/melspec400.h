@@ -300,7 +300,10 @@ AAMD_HD void gather_global(const LaneConst& c, const float* wav_row, int64_t len
   }
 }
 
-AAMD_HD void phase_a(const LaneConst& c, const float (&X)[28], bool vb, float* lds) {
+//   A frame b beyond the end of the clip is NOT zeroed here (that cost 20 selects per tile): its
+//   spectrum is garbage that no store path writes (store_direct / store_wide / store_spec mask by
+//   frame) and that the dB epilogue excludes from the running maximum.
+AAMD_HD void phase_a(const LaneConst& c, const float (&X)[28], float* lds) {
   float xr[20], xi[20], yr[20], yi[20];
 #pragma unroll
   for (int q4 = 0; q4 < 5; ++q4) {
@@ -310,7 +313,7 @@ AAMD_HD void phase_a(const LaneConst& c, const float (&X)[28], bool vb, float* l
     for (int e = 0; e < 4; ++e) {
       const int q = 4 * q4 + e;
       xr[q] = X[q] * wv[e];
-      xi[q] = vb ? X[q + 8] * wv[e] : 0.0f;
+      xi[q] = X[q + 8] * wv[e];
     }
   }
   dft20(xr, xi, yr, yi);
@@ -363,19 +366,15 @@ AAMD_HD void phase_b2_send(const LaneConst& c, const float (&zr)[20], const floa
 }
 
 // ---- phase B2b: separate the two real spectra, |.|^2, write interleaved P rows ------------
-//   g = q of lane ^ 1 (DPP swap).  conj(Z[400-k]) for k = col + 20u is g[9 - u]; the self-paired
-//   columns 0 and 10 take their own q instead.
+//   x = the exchanged values: q of lane ^ 1 (DPP swap), except on the self-paired columns 0 and 10,
+//   which keep their own q (exchange_partner below).  conj(Z[400-k]) for k = col + 20u is x[9 - u].
 AAMD_HD void phase_b2(const LaneConst& c, const float (&zr)[20], const float (&zi)[20],
-                      const float (&qr)[10], const float (&qi)[10], const float (&gr)[10],
-                      const float (&gi)[10], float* lds) {
+                      const float (&xr)[10], const float (&xi)[10], float* lds) {
   if (!c.active) return;
   float* P = lds + kPPair * c.p + 2 * c.col;
-  const bool self = (c.col == 0) || (c.col == 10);
 #pragma unroll
   for (int u = 0; u < 10; ++u) {
-    const float sr = qr[9 - u], si = qi[9 - u], pr = gr[9 - u], pi_ = gi[9 - u];
-    const float cr = self ? sr : pr;
-    const float ci = self ? si : pi_;
+    const float cr = xr[9 - u], ci = xi[9 - u];
     const float ar = zr[u] + cr, ai = zi[u] - ci;   // 2*A = Z[k] + conj(Z[N-k])
     const float br = zr[u] - cr, bi = zi[u] + ci;   // |2*B|: Z[k] - conj(Z[N-k])
     *reinterpret_cast<F2*>(P + 40 * u) = F2{ar * ar + ai * ai, br * br + bi * bi};
@@ -398,17 +397,13 @@ AAMD_HD float spec_pow(float m2, float power) {
 }
 
 AAMD_HD void phase_b2_spec(const LaneConst& c, const float (&zr)[20], const float (&zi)[20],
-                           const float (&qr)[10], const float (&qi)[10], const float (&gr)[10],
-                           const float (&gi)[10], float power, int phase, float* lds) {
+                           const float (&xr)[10], const float (&xi)[10], float power, int phase, float* lds) {
   if (!c.active) return;
   float* Ra = lds + phase + kSpecBins * 2 * c.p + c.col;
   float* Rb = Ra + kSpecBins;
-  const bool self = (c.col == 0) || (c.col == 10);
 #pragma unroll
   for (int u = 0; u < 10; ++u) {
-    const float sr = qr[9 - u], si = qi[9 - u], pr = gr[9 - u], pi_ = gi[9 - u];
-    const float cr = self ? sr : pr;
-    const float ci = self ? si : pi_;
+    const float cr = xr[9 - u], ci = xi[9 - u];
     const float ar = zr[u] + cr, ai = zi[u] - ci;
     const float br = zr[u] - cr, bi = zi[u] + ci;
     Ra[20 * u] = spec_pow(ar * ar + ai * ai, power);
@@ -566,10 +561,42 @@ __device__ __forceinline__ void wave_lds_fence() {
   asm volatile("" ::: "memory");
 }
 
-// value of lane ^ 1 (DPP quad_perm [1,0,3,2]): a VALU move, no LDS traffic
-__device__ __forceinline__ float swap_adjacent(float v) {
-  return __builtin_bit_cast(
-      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+// In-place exchange with lane ^ 1 (DPP quad_perm [1,0,3,2], a VALU move) of 20 registers, with the
+// self-paired lanes (columns 0 and 10: wave-uniform mask `self_mask`) switched off in EXEC so that
+// they keep their own values: replaces 20 v_mov_dpp + 20 v_cndmask by 20 v_mov_dpp.  Lanes 0/1 of a
+// quad are each other's partners, so no enabled lane reads a disabled one.  s_nop: VALU write ->
+// DPP read of the same VGPR needs 2 wait states, an EXEC write before a DPP op 5.
+__device__ __forceinline__ void exchange_partner(float (&qr)[10], float (&qi)[10], unsigned long long self_mask) {
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      "s_andn2_b64 exec, exec, %[m]\n\t"
+      "s_nop 4\n\t"
+      "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %4, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %5, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %6, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %8, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %9, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %10, %10 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %11, %11 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %12, %12 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %13, %13 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %14, %14 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %16, %16 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %17, %17 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %18, %18 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b32_dpp %19, %19 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : "+v"(qr[0]), "+v"(qr[1]), "+v"(qr[2]), "+v"(qr[3]), "+v"(qr[4]), "+v"(qr[5]), "+v"(qr[6]), "+v"(qr[7]),
+        "+v"(qr[8]), "+v"(qr[9]), "+v"(qi[0]), "+v"(qi[1]), "+v"(qi[2]), "+v"(qi[3]), "+v"(qi[4]), "+v"(qi[5]),
+        "+v"(qi[6]), "+v"(qi[7]), "+v"(qi[8]), "+v"(qi[9]), [sv] "=&s"(saved)
+      : [m] "s"(self_mask));
 }
 
 // LDS-DMA of one 16-B piece per lane: 64 lanes fill 1 KiB at LDS byte address `lds_dst`
@@ -627,6 +654,7 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
   if (LAB & 1024) lab_t1 = wall_clock64();
   LaneConst c;
   lane_init(lane, const_tab, c);
+  const unsigned long long self_mask = __ballot((c.col == 0) || (c.col == 10));   // wave-uniform (SGPR pair)
   int spiece[5];   // tile piece fetched by this lane in DMA instruction k
 #pragma unroll
   for (int k = 0; k < 5; ++k) spiece[k] = 4 * stage_src_piece(64 * k + lane);
@@ -716,9 +744,9 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     } else {
       gather_global(c, wav + cur.row * row_stride, length, cur.t0, n_frames, X);
     }
-    phase_a(c, X, cur.staged || (cur.t0 + 2 * c.p + 1 < n_frames), lds);
+    phase_a(c, X, lds);
     wave_lds_fence();
-    float vr[20], vi[20], zr[20], zi[20], qr[10], qi[10], gr[10], gi[10];
+    float vr[20], vi[20], zr[20], zi[20], qr[10], qi[10];
     phase_b1_load(c, lds, vr, vi);
     // every transposition row has been read: the staging area (it aliases rows) is free again
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -726,15 +754,11 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     if (LAB & 16) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
     dft20(vr, vi, zr, zi);
     phase_b2_send(c, zr, zi, qr, qi);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      gr[i] = swap_adjacent(qr[i]);
-      gi[i] = swap_adjacent(qi[i]);
-    }
+    exchange_partner(qr, qi, self_mask);
     wave_lds_fence();
     if (EPI == EPI400_SPEC) {
       const int64_t a0 = (cur.row * n_frames + cur.t0) * (int64_t)kSpecBins;
-      phase_b2_spec(c, zr, zi, qr, qi, gr, gi, epi.power, (int)(a0 & 3), lds);
+      phase_b2_spec(c, zr, zi, qr, qi, epi.power, (int)(a0 & 3), lds);
       wave_lds_fence();
       const int64_t left = n_frames - cur.t0;
       const int n_valid = left < kFramesPerWave ? (int)left : kFramesPerWave;
@@ -744,7 +768,7 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
       cur_idx = nxt_idx;
       continue;
     }
-    phase_b2(c, zr, zi, qr, qi, gr, gi, lds);
+    phase_b2(c, zr, zi, qr, qi, lds);
     phase_b2_pad(lane, lds);
     wave_lds_fence();
     float acc_a[kMelMaxRounds], acc_b[kMelMaxRounds];
@@ -756,12 +780,14 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
         flush_max();
         wgroup = g;
       }
+      // frames past the end of the clip hold garbage (phase_a): keep them out of the maximum
+      const bool va_ok = cur.t0 + 2 * c.p < n_frames, vb_ok = cur.t0 + 2 * c.p + 1 < n_frames;
 #pragma unroll
       for (int r = 0; r < kMelMaxRounds; ++r) {
         if (r < mt.n_rounds) {
           acc_a[r] = epi_db(acc_a[r], epi);
           acc_b[r] = epi_db(acc_b[r], epi);
-          wmax = fmaxf(wmax, fmaxf(acc_a[r], acc_b[r]));
+          wmax = fmaxf(wmax, fmaxf(va_ok ? acc_a[r] : -INFINITY, vb_ok ? acc_b[r] : -INFINITY));
         }
       }
     }

@@ -124,23 +124,29 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
       if (cur_staged) gather_lds(c[l], lds + kSOff, X[l]);
       else gather_global(c[l], wr, length, t0, n_frames, X[l]);
     }
-    for (int l = 0; l < 64; ++l) phase_a(c[l], X[l], cur_staged || (t0 + 2 * c[l].p + 1 < n_frames), lds);
+    for (int l = 0; l < 64; ++l) phase_a(c[l], X[l], lds);
     for (int l = 0; l < 64; ++l) phase_b1_load(c[l], lds, vr[l], vi[l]);
     if (nxt_staged) stage(nrow, nt0);
     for (int l = 0; l < 64; ++l) dft20(vr[l], vi[l], zr[l], zi[l]);
     for (int l = 0; l < 64; ++l) phase_b2_send(c[l], zr[l], zi[l], qr[l], qi[l]);
+    // exchange_partner(): in-place DPP swap with lane ^ 1, self-paired columns (0 and 10) keep their own
+    static float xr[64][10], xi[64][10];
+    for (int l = 0; l < 64; ++l) {
+      const bool self = (c[l].col == 0) || (c[l].col == 10);
+      for (int i = 0; i < 10; ++i) { xr[l][i] = self ? qr[l][i] : qr[l ^ 1][i]; xi[l][i] = self ? qi[l][i] : qi[l ^ 1][i]; }
+    }
     // the DPP quad_perm [1,0,3,2] swap: lane l receives lane l ^ 1's q
     if (epi_mode == EPI400_SPEC) {
       const int64_t a0 = (row * n_frames + t0) * (int64_t)kSpecBins;
       for (int l = 0; l < 64; ++l)
-        phase_b2_spec(c[l], zr[l], zi[l], qr[l], qi[l], qr[l ^ 1], qi[l ^ 1], epi.power, (int)(a0 & 3), lds);
+        phase_b2_spec(c[l], zr[l], zi[l], xr[l], xi[l], epi.power, (int)(a0 & 3), lds);
       const int64_t left = n_frames - t0;
       const int n_valid = left < kFramesPerWave ? (int)left : kFramesPerWave;
       for (int l = 0; l < 64; ++l) store_spec(l, lds, out, a0, n_valid * kSpecBins);
       cur_staged = nxt_staged;
       continue;
     }
-    for (int l = 0; l < 64; ++l) phase_b2(c[l], zr[l], zi[l], qr[l], qi[l], qr[l ^ 1], qi[l ^ 1], lds);
+    for (int l = 0; l < 64; ++l) phase_b2(c[l], zr[l], zi[l], xr[l], xi[l], lds);
     for (int l = 0; l < 64; ++l) phase_b2_pad(l, lds);
     for (int l = 0; l < 64; ++l) phase_c(c[l], mt, lds, acc_a[l], acc_b[l]);
     if (epi_mode == EPI400_MEL_DB) {
@@ -149,7 +155,8 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
         for (int r = 0; r < mt.n_rounds; ++r) {
           acc_a[l][r] = epi_db(acc_a[l][r], epi);
           acc_b[l][r] = epi_db(acc_b[l][r], epi);
-          m = std::fmax(m, std::fmax(acc_a[l][r], acc_b[l][r]));
+          if (t0 + 2 * c[l].p < n_frames) m = std::fmax(m, acc_a[l][r]);
+          if (t0 + 2 * c[l].p + 1 < n_frames) m = std::fmax(m, acc_b[l][r]);
         }
       if (gmax) { float& g = gmax[row / rows_per_group]; g = std::fmax(g, m); }
     }
