@@ -507,18 +507,21 @@ AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
 }
 
 // narrow store path (any n_mels / alignment): 4-byte stores straight from the accumulators
+//   Addressing: ONE wave-uniform tile pointer (SGPRs) + a small per-lane 32-bit offset, so every
+//   store is `global_store_dword voffset, data, s[base]` with one v_add -- no per-lane 64-bit pointers.
 AAMD_HD void store_direct(const LaneConst& c, const MelTab& mt, const float (&acc_a)[kMelMaxRounds],
                           const float (&acc_b)[kMelMaxRounds], float* out_row, int64_t t0, int n_frames) {
-  const int64_t ta = t0 + 2 * c.p;
-  const bool va = c.active && ta < n_frames, vb = c.active && ta + 1 < n_frames;
-  float* oa = out_row + ta * (int64_t)mt.n_mels;
+  const int left = (int)(n_frames - t0);               // frames of this tile inside the clip (wave-uniform)
+  const bool va = c.active && 2 * c.p < left, vb = c.active && 2 * c.p + 1 < left;
+  float* out_tile = out_row + t0 * (int64_t)mt.n_mels;   // wave-uniform
+  const unsigned oa = 2u * (unsigned)c.p * (unsigned)mt.n_mels;
 #pragma unroll
   for (int r = 0; r < kMelMaxRounds; ++r) {
     if (r < mt.n_rounds) {
       const int m = mt.row_mel[r * kMelSlots + c.pi];
       if (m >= 0) {
-        if (va) oa[m] = acc_a[r];
-        if (vb) oa[mt.n_mels + m] = acc_b[r];
+        if (va) out_tile[oa + (unsigned)m] = acc_a[r];
+        if (vb) out_tile[oa + (unsigned)mt.n_mels + (unsigned)m] = acc_b[r];
       }
     }
   }

@@ -136,8 +136,10 @@ int main(int argc, char** argv) {
     if (FILE* f = fopen("tools/ubench/order80.txt", "r")) { int v; while (fscanf(f, "%d", &v) == 1) ord.push_back(v); fclose(f); }
     int* dord = nullptr;
     if ((int)ord.size() == 80) { CK(hipMalloc(&dord, 320)); CK(hipMemcpy(dord, ord.data(), 320, hipMemcpyHostToDevice)); mbo.order = dord; }
-    std::vector<float> t[4];
+    std::vector<float> t[4], tw2[2];
     for (int rep = 0; rep < 7; ++rep) {
+      tw2[0].push_back(run<0>("", blocks, lds, dx, dwin, dtw, mbo, dout, rows, L, T, 30, 1, 1));   // wide stores
+      tw2[1].push_back(run<2>("", blocks, lds, dx, dwin, dtw, mbo, dout, rows, L, T, 30, 1, 0));   // no stores at all
       t[0].push_back(run<0>("", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, 30, 1, 0));
       t[1].push_back(run<128>("", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, 30, 1, 0));
       if (dord) {
@@ -146,6 +148,8 @@ int main(int argc, char** argv) {
       }
     }
     const char* nm[4] = {"no stagger, identity order", "stagger, identity order", "no stagger, lane order", "stagger, lane order"};
+    const char* nw[2] = {"lane order, WIDE (LDS-staged) stores", "lane order, NO global stores"};
+    for (int i = 0; i < 2; ++i) { std::sort(tw2[i].begin(), tw2[i].end()); printf("A/B median %-36s %7.1f us (min %.1f max %.1f)\n", nw[i], tw2[i][3], tw2[i].front(), tw2[i].back()); }
     for (int i = 0; i < 4; ++i) if (!t[i].empty()) { std::sort(t[i].begin(), t[i].end()); printf("A/B median %-28s %7.1f us (min %.1f max %.1f)\n", nm[i], t[i][t[i].size() / 2], t[i].front(), t[i].back()); }
   }
   run<1>("LAB1 no stage wait", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 1);
