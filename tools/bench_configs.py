@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""One JSON line per BASELINE.json config (per-GPU shard of the 8-GPU configs), same timing protocol as
+bench.py (inputs resident, warm-up to steady clocks, events on the launch stream).  Not the driver's
+contract -- that is bench.py (config 2) -- but the same fields, so the other rows of SURVEY.md 8(d) can be
+reproduced:   python tools/bench_configs.py [--steps K --warmup W] > profiles/rNN_configs.jsonl"""
+import argparse
+import json
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import audio_amd.functional as F
+import audio_amd.transforms as T
+
+HBM, FP32 = 8000.0, 157.3   # GB/s, TFLOP/s (MI355X_MICROARCH.md)
+
+
+def timed(fn, warmup, steps):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps   # ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
+    args = ap.parse_args()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(1234)
+
+    def noise(*shape):
+        return (0.5 * torch.randn(*shape, device=dev, generator=g)).clamp_(-1, 1)
+
+    def emit(name, ms, clip_seconds, algo_bytes, flops=None, note=""):
+        rec = {"config": name, "ms_per_launch": ms, "clip_seconds_per_launch": clip_seconds,
+               "value": clip_seconds / (ms * 1e-3), "unit": "audio-sec/sec (per GPU)",
+               "roofline_hbm": {"algorithmic_bytes": algo_bytes, "achieved_GBs": algo_bytes / ms / 1e6,
+                                "frac": algo_bytes / ms / 1e6 / HBM}}
+        if flops:
+            rec["roofline_fp32"] = {"algorithmic_flops": flops, "achieved_TFLOPs": flops / ms / 1e9,
+                                    "frac": flops / ms / 1e9 / FP32}
+        if note:
+            rec["note"] = note
+        print(json.dumps(rec), flush=True)
+
+    with torch.no_grad():
+        x = noise(256, 160000)
+        mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).to(dev)
+        emit("cfg2 MelSpectrogram n_fft=400 hop=160 n_mels=80, 256 x 10 s @16 kHz",
+             timed(lambda: mel(x), 5 * args.warmup, 5 * args.steps), 2560.0, 256 * 160000 * 4 + 256 * 1001 * 80 * 4)
+        sp = T.Spectrogram(n_fft=400, hop_length=160).to(dev)
+        emit("cfg1-shaped Spectrogram n_fft=400 hop=160 (power 2), 256 x 10 s @16 kHz",
+             timed(lambda: sp(x), 5 * args.warmup, 5 * args.steps), 2560.0, 256 * 160000 * 4 + 256 * 1001 * 201 * 4)
+        del x
+        x = noise(512, 160000)
+        mf = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).to(dev)
+        emit("cfg4 MFCC n_mfcc=40, 512 x 10 s @16 kHz, (B, L) input = one batch-global top_db cut-off",
+             timed(lambda: mf(x), args.warmup, args.steps), 5120.0, 512 * 160000 * 4 + 512 * 1001 * 40 * 4,
+             note="two kernels (mel+dB+max, clamp+DCT on MFMA); exact path moves 737.6 MB")
+        x3 = x[:, None, :]
+        emit("cfg4 variant: (B, 1, L) input = per-item cut-offs", timed(lambda: mf(x3), args.warmup, args.steps),
+             5120.0, 512 * 160000 * 4 + 512 * 1001 * 40 * 4)
+        del x, x3
+        x = noise(128, 2, 1323000)
+        rs = T.Resample(44100, 16000, resampling_method="sinc_interp_kaiser", lowpass_filter_width=64,
+                        rolloff=0.9475937167399596, beta=14.769656459379492).to(dev)
+        emit("cfg3 Resample 44.1k->16k kaiser_best, per-GPU shard 128 x stereo x 30 s",
+             timed(lambda: rs(x), 10, 30), 128 * 30.0, x.numel() * 4 + 128 * 2 * 480000 * 4,
+             flops=128 * 2 * 480000 * 373 * 2, note="FMA-bound; 373 effective taps per output")
+        del x
+        x = torch.rand(32, 8, 480000, device=dev, generator=g) - 0.5
+        A, B = [], []
+        for fc in (8000.0, 6000.0, 4000.0, 3000.0):
+            w0 = 2 * math.pi * fc / 48000
+            alpha = math.sin(w0) / 2 / 0.707
+            A.append([1 + alpha, -2 * math.cos(w0), 1 - alpha])
+            B.append([(1 - math.cos(w0)) / 2, 1 - math.cos(w0), (1 - math.cos(w0)) / 2])
+        a4, b4 = torch.tensor(A, device=dev), torch.tensor(B, device=dev)
+        emit("cfg5a 4-biquad lowpass cascade (8/6/4/3 kHz, Q=0.707) fused, per-GPU shard 32 x 8 ch x 10 s @48 kHz",
+             timed(lambda: F.biquad_cascade(x, a4, b4), 10, 50), 32 * 10.0, 2 * x.numel() * 4)
+        t = torch.arange(24000, device=dev) / 48000.0
+        rir = torch.randn(1, 1, 24000, device=dev, generator=g) * torch.exp(-t / 0.1) * 0.05
+        emit("cfg5b fftconvolve with a 0.5 s RIR (24000 taps), per-GPU shard 32 x 8 ch x 10 s @48 kHz",
+             timed(lambda: F.fftconvolve(x, rir), 5, 20), 32 * 10.0, x.numel() * 4 + 32 * 8 * 503999 * 4)
+
+
+if __name__ == "__main__":
+    main()
