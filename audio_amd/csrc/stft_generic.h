@@ -40,12 +40,19 @@ struct MelBandsDev {
 // the epilogue with X_a[k] = (Z[k] + conj Z[N-k]) / 2,  X_b[k] = (Z[k] - conj Z[N-k]) / (2i).
 constexpr int kGenThreads = 256;
 AAMD_HD int gen_pairs_per_block(int n_fft) {
+  // Small workgroups win here: the kernel is latency-bound (one barrier per stage), so more resident
+  // workgroups per CU beat fuller workgroups (measured: 2 pairs per block at n_fft = 512 is 1.45x faster
+  // than 4, and one wave per pair without barriers is slower still).
   int p = 1024 / n_fft;
   return p < 1 ? 1 : (p > 8 ? 8 : p);
 }
-// LDS floats: twiddle table N complex | two ping-pong buffers of PB x N complex | PB x 2 power rows
+// Sequence buffers are index-padded (one complex every 32) so that the power-of-two strides of the
+// Stockham output pattern (r p + k) do not pile onto a few LDS banks.
+AAMD_HD int gen_pad(int i) { return i + (i >> 5); }
+AAMD_HD int gen_seq_len(int n_fft) { return gen_pad(n_fft - 1) + 1; }
+// LDS floats: twiddle table N complex | two ping-pong buffers of PB padded sequences | PB x 2 power rows
 AAMD_HD size_t gen_lds_floats(int n_fft, int n_freq, int pb) {
-  return (size_t)2 * n_fft + (size_t)4 * pb * n_fft + (size_t)2 * pb * n_freq;
+  return (size_t)2 * n_fft + (size_t)4 * pb * gen_seq_len(n_fft) + (size_t)2 * pb * n_freq;
 }
 
 template <typename T>
@@ -59,17 +66,25 @@ AAMD_HD T stft_sample(const StftGeom& g, const T* wav_row, int64_t t, int n) {
 }
 
 // ---- phase 1: gather PB frame pairs, multiply by the window, write z = a + i b ----------------------
+//   Frames that lie entirely inside the waveform (all but the first / last few) take plain coalesced
+//   loads; only the edge frames pay for the padding index math.
 template <typename T>
 AAMD_HD void gen_load(int tid, int nthr, const StftGeom& g, const T* wav_row, const T* window, int64_t t0,
                       int pb, cplx<T>* buf) {
-  const int N = g.n_fft;
-  for (int idx = tid; idx < pb * N; idx += nthr) {
-    const int pair = idx / N, n = idx - pair * N;
+  const int N = g.n_fft, SL = gen_seq_len(N);
+  const int64_t cpad = g.center ? g.n_fft / 2 : 0;
+  for (int pair = 0; pair < pb; ++pair) {        // per-pair invariants hoisted out of the sample loop
     const int64_t ta = t0 + 2 * pair, tb = ta + 1;
-    const T w = window[n];
-    const T a = (ta < g.n_frames) ? stft_sample<T>(g, wav_row, ta, n) * w : (T)0;
-    const T b = (tb < g.n_frames) ? stft_sample<T>(g, wav_row, tb, n) * w : (T)0;
-    buf[idx] = {a, b};
+    const int64_t ba = ta * (int64_t)g.hop - cpad - g.pad, bb = ba + g.hop;   // source index of sample 0
+    const bool va = ta < g.n_frames, vb = tb < g.n_frames;
+    const bool ia = va && ba >= 0 && ba + N <= g.length, ib = vb && bb >= 0 && bb + N <= g.length;
+    cplx<T>* dst = buf + pair * SL;
+    for (int n = tid; n < N; n += nthr) {
+      const T w = window[n];
+      const T a = ia ? wav_row[ba + n] : (va ? stft_sample<T>(g, wav_row, ta, n) : (T)0);
+      const T b = ib ? wav_row[bb + n] : (vb ? stft_sample<T>(g, wav_row, tb, n) : (T)0);
+      dst[gen_pad(n)] = {a * w, b * w};
+    }
   }
 }
 
@@ -88,6 +103,20 @@ AAMD_HD void bfly4(cplx<T>* v) {
   v[1] = cadd(s1, m);
   v[2] = csub(s0, s2);
   v[3] = csub(s1, m);
+}
+template <typename T>
+AAMD_HD void bfly8(cplx<T>* v) {   // 2 x radix-4 on even / odd inputs, W8 twiddles, radix-2 combine
+  const T h = (T)0.70710678118654752440;
+  cplx<T> e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+  bfly4<T>(e);
+  bfly4<T>(o);
+  const cplx<T> o1 = {h * (o[1].x + o[1].y), h * (o[1].y - o[1].x)};    // o1 * W8^1 = o1 * (1 - i)/sqrt2
+  const cplx<T> o2 = {o[2].y, -o[2].x};                                 // o2 * W8^2 = -i o2
+  const cplx<T> o3 = {h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y)};   // o3 * W8^3 = o3 * (-1 - i)/sqrt2
+  v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+  v[1] = cadd(e[1], o1);   v[5] = csub(e[1], o1);
+  v[2] = cadd(e[2], o2);   v[6] = csub(e[2], o2);
+  v[3] = cadd(e[3], o3);   v[7] = csub(e[3], o3);
 }
 template <typename T>
 AAMD_HD void bfly3(cplx<T>* v) {
@@ -117,18 +146,19 @@ AAMD_HD void bfly5(cplx<T>* v) {
 
 // load R inputs (stride `in_stride`), butterfly in registers, twiddle, store R outputs (stride `out_stride`)
 template <typename T, int R>
-AAMD_HD void gen_bfly_static(const cplx<T>* xs, cplx<T>* ys, int in_stride, int out_stride, int step,
-                             const cplx<T>* tw) {
+AAMD_HD void gen_bfly_static(const cplx<T>* x, cplx<T>* y, int xi, int yi, int in_stride, int out_stride,
+                             int step, const cplx<T>* tw) {
   cplx<T> v[R];
 #pragma unroll
-  for (int j = 0; j < R; ++j) v[j] = xs[in_stride * j];
-  if (R == 4) bfly4<T>(v);
+  for (int j = 0; j < R; ++j) v[j] = x[gen_pad(xi + in_stride * j)];
+  if (R == 8) bfly8<T>(v);
+  else if (R == 4) bfly4<T>(v);
   else if (R == 5) bfly5<T>(v);
   else if (R == 2) bfly2<T>(v);
   else bfly3<T>(v);
-  ys[0] = v[0];
+  y[gen_pad(yi)] = v[0];
 #pragma unroll
-  for (int k = 1; k < R; ++k) ys[out_stride * k] = cmul(v[k], tw[step * k]);
+  for (int k = 1; k < R; ++k) y[gen_pad(yi + out_stride * k)] = cmul(v[k], tw[step * k]);
 }
 
 // ---- phase 2: one Stockham (autosort) stage of radix r on PB sequences: one BUTTERFLY per work item --
@@ -139,30 +169,34 @@ AAMD_HD void gen_stage(int tid, int nthr, int N, int r, int s, int pb, const cpl
                        const cplx<T>* tw) {
   const int nb = N / r;          // butterflies per sequence
   const int m = nb / s;
+  const int SL = gen_seq_len(N);
   for (int it = tid; it < pb * nb; it += nthr) {
     const int pair = it / nb, i = it - pair * nb;
     const int p = i / s, q = i - p * s;
-    const cplx<T>* xs = x + pair * N + q + s * p;
-    cplx<T>* ys = y + pair * N + q + s * r * p;
+    const cplx<T>* xq = x + pair * SL;
+    cplx<T>* yq = y + pair * SL;
+    const int xi = q + s * p, yi = q + s * r * p;      // un-padded indices inside the sequence
     const int step = s * p;      // W_N^{s p k}
-    if (r == 4) {
-      gen_bfly_static<T, 4>(xs, ys, s * m, s, step, tw);
+    if (r == 8) {
+      gen_bfly_static<T, 8>(xq, yq, xi, yi, s * m, s, step, tw);
+    } else if (r == 4) {
+      gen_bfly_static<T, 4>(xq, yq, xi, yi, s * m, s, step, tw);
     } else if (r == 5) {
-      gen_bfly_static<T, 5>(xs, ys, s * m, s, step, tw);
+      gen_bfly_static<T, 5>(xq, yq, xi, yi, s * m, s, step, tw);
     } else if (r == 2) {
-      gen_bfly_static<T, 2>(xs, ys, s * m, s, step, tw);
+      gen_bfly_static<T, 2>(xq, yq, xi, yi, s * m, s, step, tw);
     } else if (r == 3) {
-      gen_bfly_static<T, 3>(xs, ys, s * m, s, step, tw);
+      gen_bfly_static<T, 3>(xq, yq, xi, yi, s * m, s, step, tw);
     } else {   // any other prime radix: direct r-point DFT, W_r^{jk} = W_N^{(N/r) (jk mod r)}
       for (int k = 0; k < r; ++k) {
-        cplx<T> acc = xs[0];
+        cplx<T> acc = xq[gen_pad(xi)];
         int e = 0;
         for (int j = 1; j < r; ++j) {
           e += k;
           if (e >= r) e -= r;
-          acc = cadd(acc, cmul(xs[s * m * j], tw[nb * e]));
+          acc = cadd(acc, cmul(xq[gen_pad(xi + s * m * j)], tw[nb * e]));
         }
-        ys[s * k] = (k == 0) ? acc : cmul(acc, tw[step * k]);
+        yq[gen_pad(yi + s * k)] = (k == 0) ? acc : cmul(acc, tw[step * k]);
       }
     }
   }
@@ -180,9 +214,9 @@ AAMD_HD T mag_pow(T re, T im, float power) {
 // the two real spectra of pair `pair` at bin k (scaled)
 template <typename T>
 AAMD_HD void gen_separate(const StftGeom& g, const cplx<T>* X, int pair, int k, cplx<T>& A, cplx<T>& B) {
-  const int N = g.n_fft;
-  const cplx<T> zk = X[pair * N + k];
-  const cplx<T> zm = X[pair * N + (k == 0 ? 0 : N - k)];
+  const int N = g.n_fft, SL = gen_seq_len(N);
+  const cplx<T> zk = X[pair * SL + gen_pad(k)];
+  const cplx<T> zm = X[pair * SL + gen_pad(k == 0 ? 0 : N - k)];
   const T h = (T)0.5 * (T)g.scale;
   A = {h * (zk.x + zm.x), h * (zk.y - zm.y)};       // (Z[k] + conj Z[N-k]) / 2
   B = {h * (zk.y + zm.y), h * (zm.x - zk.x)};       // (Z[k] - conj Z[N-k]) / (2i)
@@ -247,11 +281,11 @@ stft_generic_kernel(StftGeom g, const T* __restrict__ wav, const T* __restrict__
                     const cplx<T>* __restrict__ tw, MelBandsDev mb, T* __restrict__ out,
                     int pairs_per_block, int blocks_per_row) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int N = g.n_fft, pb = pairs_per_block;
+  const int N = g.n_fft, pb = pairs_per_block, SL = gen_seq_len(N);
   cplx<T>* twl = reinterpret_cast<cplx<T>*>(smem);
   cplx<T>* bufA = twl + N;
-  cplx<T>* bufB = bufA + pb * N;
-  T* P = reinterpret_cast<T*>(bufB + pb * N);
+  cplx<T>* bufB = bufA + pb * SL;
+  T* P = reinterpret_cast<T*>(bufB + pb * SL);
 
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int64_t row = blockIdx.x / blocks_per_row;
@@ -282,13 +316,20 @@ stft_generic_kernel(StftGeom g, const T* __restrict__ wav, const T* __restrict__
 }
 #endif  // __HIPCC__
 
-// Host helper: factor n into radices (4s first, then 2, 3, 5, remaining primes).
+// Host helper: factor n into radices.  Powers of two become 8s with the remainder as 4s (never a lone
+// radix-2 stage when 4 x 4 is possible: 2^4 -> 4,4; 2^10 -> 8,8,4,4), then 3, 5, remaining primes.
 inline int plan_radices(int n, int* radix) {
-  int ns = 0;
-  while (n % 4 == 0 && ns < kMaxStages) { radix[ns++] = 4; n /= 4; }
-  for (int p = 2; n > 1 && ns < kMaxStages; ) {
+  int ns = 0, e = 0;
+  while (n % 2 == 0) { n /= 2; ++e; }
+  int n4 = (e % 3 == 1 && e >= 4) ? 2 : (e % 3 == 2 ? 1 : 0);
+  int n2 = (e == 1) ? 1 : 0;
+  int n8 = (e - 2 * n4 - n2) / 3;
+  for (int i = 0; i < n8 && ns < kMaxStages; ++i) radix[ns++] = 8;
+  for (int i = 0; i < n4 && ns < kMaxStages; ++i) radix[ns++] = 4;
+  for (int i = 0; i < n2 && ns < kMaxStages; ++i) radix[ns++] = 2;
+  for (int p = 3; n > 1 && ns < kMaxStages; ) {
     if (n % p == 0) { radix[ns++] = p; n /= p; }
-    else { p += (p == 2) ? 1 : 2; if ((int64_t)p * p > n && n > 1) { radix[ns++] = n; n = 1; } }
+    else { p += 2; if ((int64_t)p * p > n && n > 1) { radix[ns++] = n; n = 1; } }
   }
   return n == 1 ? ns : -1;
 }

@@ -38,12 +38,12 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
   if (g.n_stages < 0) return -1;
   MelBandsDev mb{};
   if (epi_mel) { mb.n_mels = bands->n_mels; mb.max_width = bands->max_width; mb.lo = bands->lo; mb.width = bands->width; mb.weights = bands->weights; }
-  const int nthr = kGenThreads, N = g.n_fft;
+  const int nthr = kGenThreads, N = g.n_fft, SL = gen_seq_len(N);
   int pb = gen_pairs_per_block(N);
   const int pairs_per_row = (g.n_frames + 1) / 2;
   if (pb > pairs_per_row) pb = pairs_per_row;
   const int bpr = (pairs_per_row + pb - 1) / pb;
-  std::vector<cplx<float>> A((size_t)pb * N), B((size_t)pb * N);
+  std::vector<cplx<float>> A((size_t)pb * SL), B((size_t)pb * SL);
   std::vector<float> P((size_t)2 * pb * g.n_freq);
   const cplx<float>* twc = reinterpret_cast<const cplx<float>*>(tw);
   const int opf = epi_mel ? mb.n_mels : (g.power <= 0.f ? 2 * g.n_freq : g.n_freq);
