@@ -403,3 +403,95 @@ def test_lfilter_cascade_headline_shape_properties():
     yd = F.biquad_cascade(xd, a, b)
     assert float((yd[..., d:] - y[:1, :, :-d]).abs().max()) <= 1e-5
     assert float(yd[..., :d].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n_mels,mel_scale,norm,f_min,f_max", [
+    (40, "htk", None, 0.0, None), (64, "slaney", "slaney", 20.0, 7600.0), (128, "htk", None, 0.0, None),
+    (160, "slaney", None, 50.0, None), (23, "htk", "slaney", 0.0, 4000.0), (80, "htk", None, 0.0, None)])
+def test_mel400_fast_path_filterbank_matrix(n_mels, mel_scale, norm, f_min, f_max):
+    """The radix-20x20 kernel with other filterbanks than the headline one (band tables, lane order,
+    rounds with unused rows, n_mels not a multiple of 4 / 20) vs the float64 oracle, ragged length."""
+    import warnings
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(n_mels)
+    x = (0.5 * torch.randn(3, 5003, generator=g)).clamp_(-1, 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=n_mels, mel_scale=mel_scale,
+                             norm=norm, f_min=f_min, f_max=f_max).cuda()
+        fb = O.melscale_fbanks(201, f_min, f_max if f_max is not None else 8000.0, n_mels, 16000, norm, mel_scale)
+    got = t(x.cuda())
+    exp = O.mel_spectrogram(x.numpy().astype(np.float64), O.hann_window(400), fb, 400, 160)
+    assert got.shape == exp.shape
+    assert peak_rel_err(got.cpu().numpy(), exp) <= 1e-4
+    gen = _force_generic(lambda: t(x.cuda()))
+    assert float((got - gen).abs().max() / gen.abs().max()) <= 3e-6
+
+
+def test_mel400_fast_path_layout_edge_cases():
+    """Inputs the LDS-DMA staging cannot take as-is: unaligned row starts (sliced views), padded row
+    strides, a window shorter than n_fft, normalized spectra, hamming window; and a long clip."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(9)
+    base = (0.5 * torch.randn(4, 9000, generator=g)).clamp_(-1, 1).cuda()
+    t = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).cuda()
+    fb = O.melscale_fbanks(201, 0.0, 8000.0, 80, 16000)
+    for view in (base[:, 1:], base[:, 3:8004], base[:, ::1][:, 2:-1], base[1:3, 5:]):
+        got = t(view)
+        exp = O.mel_spectrogram(view.cpu().numpy().astype(np.float64), O.hann_window(400), fb, 400, 160)
+        assert got.shape == exp.shape and peak_rel_err(got.cpu().numpy(), exp) <= 1e-4
+    # win_length < n_fft (centre-padded window), hamming, normalized="window"
+    t2 = T.MelSpectrogram(sample_rate=16000, n_fft=400, win_length=320, hop_length=160, n_mels=80,
+                          window_fn=torch.hamming_window, normalized=True).cuda()
+    got = t2(base)
+    w = torch.hamming_window(320).numpy().astype(np.float64)
+    exp = O.mel_spectrogram(base.cpu().numpy().astype(np.float64), w, fb, 400, 160, win_length=320, normalized=True)
+    assert peak_rel_err(got.cpu().numpy(), exp) <= 1e-4
+    fastgen = _force_generic(lambda: t2(base))
+    assert float((got - fastgen).abs().max() / fastgen.abs().max()) <= 3e-6
+    # one long clip (20 minutes at 16 kHz): many tiles per row, fast == generic on the tail frames
+    long = (0.5 * torch.randn(1, 19_200_000, generator=g)).clamp_(-1, 1).cuda()
+    y = t(long)
+    assert y.shape == (1, 80, 120001) and torch.isfinite(y).all()
+    tail = t(long[:, -48000:])
+    assert float((y[..., -200:] - tail[..., -200:]).abs().max() / tail.abs().max()) <= 3e-6
+
+
+def test_lfilter_wave_kernel_shape_edges():
+    """Workgroup-width selection of the biquad kernel: one long sequence (16 waves), thousands of short
+    ones (1 wave each, shorter than a block), gain-only 'filter', unaligned views."""
+    import audio_amd.functional as F
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(13)
+    a = torch.tensor([1.0, -1.5, 0.7])
+    b = torch.tensor([0.2, 0.1, 0.05])
+    for shape in [(1, 70001), (3000, 100), (7, 2048), (2, 3, 2049)]:
+        x = 0.3 * torch.randn(*shape, generator=g)
+        got = F.lfilter(x.cuda(), a.cuda(), b.cuda())
+        exp = O.lfilter(x.numpy().astype(np.float64), a.numpy(), b.numpy(), True)
+        assert got.shape == exp.shape and peak_rel_err(got.cpu().numpy(), exp) <= 1e-4, shape
+    x = 0.3 * torch.randn(4, 5000, generator=g)
+    got = F.lfilter(x.cuda(), torch.tensor([2.0]).cuda(), torch.tensor([0.5]).cuda())          # order 0
+    assert float((got.cpu() - (0.25 * x).clamp(-1, 1)).abs().max()) <= 1e-6
+    xv = (0.3 * torch.randn(4, 9001, generator=g)).cuda()[:, 1:]                                 # unaligned rows
+    got = F.lfilter(xv, a.cuda(), b.cuda(), clamp=False)
+    exp = O.lfilter(xv.cpu().numpy().astype(np.float64), a.numpy(), b.numpy(), False)
+    assert peak_rel_err(got.cpu().numpy(), exp) <= 1e-4
+
+
+def test_resample_matrix_core_layout_edges():
+    """Unaligned / strided inputs (scalar loader path) and a length shorter than one chunk."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    r = T.Resample(44100, 16000, resampling_method="sinc_interp_kaiser", lowpass_filter_width=64,
+                   rolloff=0.9475937167399596, beta=14.769656459379492).cuda()
+    kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=64, rolloff=0.9475937167399596,
+              beta=14.769656459379492)
+    g = torch.Generator().manual_seed(19)
+    base = (0.5 * torch.randn(3, 30011, generator=g)).clamp_(-1, 1).cuda()
+    for view in (base[:, 1:], base[:, 2:20001], base[:, :300], base[1:, 7:]):
+        got = r(view)
+        exp = O.resample(view.cpu().numpy().astype(np.float64), 44100, 16000, **kw)
+        assert got.shape == exp.shape and peak_rel_err(got.cpu().numpy(), exp) <= 1e-5
