@@ -142,9 +142,13 @@ int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, c
 }
 
 bool fft400_eligible(const StftGeom& g) {
-  return g.n_fft == 400 && g.hop == 160 && g.center && g.pad_mode == AAMD_PAD_REFLECT &&
+  return g.n_fft == 400 && (g.hop == 160 || g.hop == 200 || g.hop == 100) && g.center && g.pad_mode == AAMD_PAD_REFLECT &&
          g.onesided && g.pad == 0 && g.length > 400 && std::getenv("AAMD_FORCE_GENERIC") == nullptr;
 }
+
+template <int EPI>
+int launch_fft400(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
+                  const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s);
 
 bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
   return fft400_eligible(g) && g.power == 2.0f &&
@@ -152,18 +156,19 @@ bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
          m400::mel_rounds(mb.n_mels) <= m400::kMelMaxRounds;
 }
 
-template <int EPI>
-int launch_fft400(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
-                  const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s) {
+template <int EPI, int H>
+int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
+                    const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
   const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
   const int64_t n_tiles = g.rows * tiles_per_row;
   AAMD_CHECK_ARG(n_tiles < (1ll << 31), "too many frames for one launch");
   const int wpb = m400::kWavesPerBlock;
-  const size_t lds = (EPI == m400::EPI400_SPEC) ? m400::lds_bytes(0, 1) : m400::lds_bytes(mb.n_mels, mb.max_width);
+  const int wdw = m400::Hop<H>::lds_dwords;
+  const size_t lds = (EPI == m400::EPI400_SPEC) ? m400::lds_bytes(0, 1, wdw) : m400::lds_bytes(mb.n_mels, mb.max_width, wdw);
   if (lds > dev_props().lds_per_block_optin)
     return fail(AAMD_EUNSUPPORTED, "audio_amd: mel filterbank too large for the LDS of this device");
-  auto kern = m400::melspec400_kernel<0, EPI>;
+  auto kern = m400::melspec400_kernel<0, EPI, H>;
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -188,6 +193,16 @@ int launch_fft400(const StftGeom& g, const MelBandsDev& mb, const float* wav, co
                      twiddle, mb, out, g.rows, g.length, g.row_stride, g.n_frames, g.scale,
                      tiles_per_row, n_tiles, tiles_per_block, in_aligned, out_wide, epi);
   return launch_check();
+}
+
+template <int EPI>
+int launch_fft400(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
+                  const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s) {
+  switch (g.hop) {   // hop = 20 H
+    case 100: return launch_fft400_h<EPI, 5>(g, mb, wav, window, twiddle, out, epi, s);
+    case 200: return launch_fft400_h<EPI, 10>(g, mb, wav, window, twiddle, out, epi, s);
+    default: return launch_fft400_h<EPI, 8>(g, mb, wav, window, twiddle, out, epi, s);
+  }
 }
 
 int grid_for(int64_t n, int per_block, int max_blocks) {

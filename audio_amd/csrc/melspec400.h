@@ -1,5 +1,7 @@
 // Headline kernel: fused MelSpectrogram for n_fft = 400, hop = 160 (the RNN-T / Whisper
-// style front-end, BASELINE.json config 2), power = 2, centre + reflect padding.
+// style front-end, BASELINE.json config 2), power = 2, centre + reflect padding.  The same kernel is
+// instantiated for hop = 100 and 200 (template parameter H = hop / 20, struct Hop<H>); the text below
+// describes H = 8.
 //
 // Design (MI355X, wave64; no workgroup barriers in the tile loop -- every wave owns private LDS):
 //   * two REAL frames a, b = a + 1 are packed as one COMPLEX 400-point FFT  z = a + i b
@@ -35,7 +37,6 @@ namespace aamd {
 namespace m400 {
 
 constexpr int kN = 400;
-constexpr int kHop = 160;
 constexpr int kPad = 200;
 constexpr int kFramesPerWave = 6;
 #ifndef AAMD_M400_WAVES
@@ -54,15 +55,33 @@ constexpr int kPK = 208;                       // readable bins per P row: 201 +
 constexpr int kPPair = 416;                    // dwords per pair of P rows (>= 2 * kPK); = 32 mod 64, so the b128
                                                // band reads of neighbouring pairs land on opposite bank halves
 constexpr int kSOff = 1344;                    // staging area for the NEXT tile's samples (LDS-DMA)
-constexpr int kSPieces = 320;                  // 16-B pieces: 1200 samples + 20 pad dwords per 320 samples
-constexpr int kTileSamples = (kFramesPerWave - 1) * kHop + kN;   // 1200
+
+// Everything that depends on the hop.  The kernel serves hop = 20 H for H = 5, 8, 10 (hop 100 = n_fft/4,
+// 160 = the 10 ms ASR hop of the headline config, 200 = torchaudio's default n_fft/2): frame b of a pair
+// starts H x 20 samples after frame a, so a lane gathers 20 + H strided samples for the pair.
+template <int H>
+struct Hop {
+  static constexpr int hop = 20 * H;
+  static constexpr int nx = 20 + H;                             // samples gathered per lane and pair
+  static constexpr int tile_samples = (kFramesPerWave - 1) * hop + kN;   // 900 / 1200 / 1400
+  static constexpr int pair_stride = 2 * hop;                   // samples between the pairs of a tile
+  // staging layout: `pad` dwords after every pair_stride samples put the three pairs' strided rows on
+  // disjoint banks: (pair_stride + pad) = 20 (mod 32); always a multiple of 4 = whole 16-B pieces
+  static constexpr int pad = ((20 - pair_stride % 32) + 32) % 32;
+  static constexpr int blk_data = pair_stride / 4, blk_pieces = blk_data + pad / 4;
+  static constexpr int data_pieces = tile_samples / 4;
+  static constexpr int pieces = data_pieces + (pad / 4) * ((tile_samples - 1) / pair_stride);
+  static constexpr int ndma = (pieces + 63) / 64;               // LDS-DMA instructions per tile: 4 / 5 / 6
+  static constexpr int lds_dwords = (kSOff + 256 * ndma > kLdsDwordsPerWave) ? kSOff + 256 * ndma : kLdsDwordsPerWave;
+  static_assert(pad % 4 == 0 && (pair_stride + pad) % 32 == 20, "staging pad");
+};
 constexpr int kMelSlots = 20;                  // mels per round
 constexpr int kMelMaxRounds = 8;               // n_mels <= 160
 constexpr int kMelMaxTaps = 64;                // widest padded band (taps)
 
 static_assert(3 * kPPair <= kLdsDwordsPerWave && 2 * kPK <= kPPair, "P rows must fit in the transposition buffer");
 static_assert(3 * (kPK - 201) <= 64, "one lane per tail bin");
-static_assert(kSOff + 4 * kSPieces <= kLdsDwordsPerWave, "staging area must fit beside the P rows");
+static_assert(Hop<8>::lds_dwords == kLdsDwordsPerWave && Hop<8>::ndma == 5 && Hop<8>::pad == 20, "headline geometry");
 
 // Epilogues of the tile loop (compile-time variants of the same kernel):
 //   EPI400_MEL     banded mel of |X|^2                       -> out[rows][T][n_mels]
@@ -183,8 +202,8 @@ AAMD_HD void const_tab_build(int tid, int nthr, const float* window, const float
 }
 
 // dynamic LDS of one workgroup: per-wave regions, constant tables, mel table, tile queue
-AAMD_HD size_t lds_bytes(int n_mels, int max_width) {
-  return ((size_t)kWavesPerBlock * kLdsDwordsPerWave + kConstDwords + mel_tab_dwords(n_mels, max_width) + 4) *
+AAMD_HD size_t lds_bytes(int n_mels, int max_width, int wave_dwords = kLdsDwordsPerWave) {
+  return ((size_t)kWavesPerBlock * wave_dwords + kConstDwords + mel_tab_dwords(n_mels, max_width) + 4) *
          sizeof(float);
 }
 
@@ -274,27 +293,32 @@ AAMD_HD int64_t reflect_idx(int64_t i, int64_t len) {
 // (coalesced 16-B pieces, issued one tile ahead); sample i of the tile lives at staging dword
 // i + 20 * (i / 320): the 20-dword pad per 320 samples moves the three pairs' rows onto disjoint
 // banks, so the strided gather below is conflict free.
+template <int H>
 AAMD_HD int stage_src_piece(int u) {   // staging piece u (16 B) <- tile piece (4 samples)
-  const int blk = u / 85, r = u - 85 * blk;
-  const int s = 80 * blk + (r < 80 ? r : 79);
-  return s < kTileSamples / 4 ? s : kTileSamples / 4 - 1;
+  using HC = Hop<H>;
+  const int blk = u / HC::blk_pieces, r = u - HC::blk_pieces * blk;
+  const int s = HC::blk_data * blk + (r < HC::blk_data ? r : HC::blk_data - 1);
+  return s < HC::data_pieces ? s : HC::data_pieces - 1;
 }
 
-AAMD_HD void gather_lds(const LaneConst& c, const float* S, float (&X)[28]) {
-  const float* src = S + 340 * c.p + c.pi;
+template <int H>
+AAMD_HD void gather_lds(const LaneConst& c, const float* S, float (&X)[Hop<H>::nx]) {
+  using HC = Hop<H>;
+  const float* src = S + (HC::pair_stride + HC::pad) * c.p + c.pi;
 #pragma unroll
-  for (int q = 0; q < 28; ++q) X[q] = src[20 * q + (q >= 16 ? 20 : 0)];
+  for (int q = 0; q < HC::nx; ++q) X[q] = src[20 * q + HC::pad * (q / (2 * H))];
 }
 
 // Unstaged tiles (clip edges: reflect padding; or inputs that are not 16-B aligned): direct loads.
+template <int H>
 AAMD_HD void gather_global(const LaneConst& c, const float* wav_row, int64_t length, int64_t t0,
-                           int n_frames, float (&X)[28]) {
+                           int n_frames, float (&X)[Hop<H>::nx]) {
   const int64_t ta = t0 + 2 * c.p;
-  const int64_t i0 = ta * kHop - kPad + c.pi;
+  const int64_t i0 = ta * Hop<H>::hop - kPad + c.pi;
 #pragma unroll
-  for (int q = 0; q < 28; ++q) {
+  for (int q = 0; q < Hop<H>::nx; ++q) {
     const int64_t i = i0 + 20 * q;
-    // q < 20 belongs to frame a (and to a + 1 when q >= 8); q >= 20 only to frame a + 1
+    // q < 20 belongs to frame a (and to a + 1 when q >= H); q >= 20 only to frame a + 1
     const bool need = (q < 20) ? (ta < n_frames) : (ta + 1 < n_frames);
     X[q] = need ? wav_row[reflect_idx(i, length)] : 0.0f;
   }
@@ -303,7 +327,8 @@ AAMD_HD void gather_global(const LaneConst& c, const float* wav_row, int64_t len
 //   A frame b beyond the end of the clip is NOT zeroed here (that cost 20 selects per tile): its
 //   spectrum is garbage that no store path writes (store_direct / store_wide / store_spec mask by
 //   frame) and that the dB epilogue excludes from the running maximum.
-AAMD_HD void phase_a(const LaneConst& c, const float (&X)[28], float* lds) {
+template <int H>
+AAMD_HD void phase_a(const LaneConst& c, const float (&X)[Hop<H>::nx], float* lds) {
   float xr[20], xi[20], yr[20], yi[20];
 #pragma unroll
   for (int q4 = 0; q4 < 5; ++q4) {
@@ -313,7 +338,7 @@ AAMD_HD void phase_a(const LaneConst& c, const float (&X)[28], float* lds) {
     for (int e = 0; e < 4; ++e) {
       const int q = 4 * q4 + e;
       xr[q] = X[q] * wv[e];
-      xi[q] = X[q + 8] * wv[e];
+      xi[q] = X[q + H] * wv[e];
     }
   }
   dft20(xr, xi, yr, yi);
@@ -626,7 +651,7 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
-template <int LAB, int EPI>
+template <int LAB, int EPI, int H = 8>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, AAMD_M400_MINWAVES)
 melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ window,
                   const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
@@ -638,10 +663,12 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   long long lab_t0 = 0;
   if (LAB & 1024) lab_t0 = wall_clock64();
-  float* lds = smem400 + wave * kLdsDwordsPerWave;
+  using HC = Hop<H>;
+  constexpr int kHop = HC::hop;
+  float* lds = smem400 + wave * HC::lds_dwords;
   const unsigned s_addr = (unsigned)(uintptr_t)(lds + kSOff);   // LDS byte address of the staging area
 
-  float* const_tab = smem400 + kWavesPerBlock * kLdsDwordsPerWave;
+  float* const_tab = smem400 + kWavesPerBlock * HC::lds_dwords;
   const_tab_build(threadIdx.x, blockDim.x, window, tw400, scale, const_tab);
   MelTab mt{};
   if (EPI != EPI400_SPEC) mel_tab_rounds(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
@@ -658,9 +685,9 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
   LaneConst c;
   lane_init(lane, const_tab, c);
   const unsigned long long self_mask = __ballot((c.col == 0) || (c.col == 10));   // wave-uniform (SGPR pair)
-  int spiece[5];   // tile piece fetched by this lane in DMA instruction k
+  int spiece[HC::ndma];   // tile piece fetched by this lane in DMA instruction k
 #pragma unroll
-  for (int k = 0; k < 5; ++k) spiece[k] = 4 * stage_src_piece(64 * k + lane);
+  for (int k = 0; k < HC::ndma; ++k) spiece[k] = 4 * stage_src_piece<H>(64 * k + lane);
 
   // XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
   // range of tiles so the frame-overlap re-reads stay inside one L2.
@@ -696,7 +723,7 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     const float* src = wav + ti.row * row_stride + (ti.t0 * kHop - kPad);
     if (LAB & 32) src = wav + 6 * kHop;                 // lab: always the same (cache-resident) tile
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < HC::ndma; ++k)
       if (!(LAB & 64) || k == 0) glds16(src + spiece[k], s_addr + 1024 * k);   // lab bit 6: one piece only
   };
 
@@ -735,19 +762,19 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     const unsigned nxt_idx = claim();
     TileInfo nxt = tile_info(nxt_idx);
 
-    float X[28];
+    float X[HC::nx];
     if (cur.staged) {
       if (!(LAB & 1)) stage_wait();
       if (LAB & 256) {   // lab: no gather (samples from a register expression)
 #pragma unroll
-        for (int q = 0; q < 28; ++q) X[q] = (float)(q + lane) * scale;
+        for (int q = 0; q < HC::nx; ++q) X[q] = (float)(q + lane) * scale;
       } else {
-        gather_lds(c, lds + kSOff, X);
+        gather_lds<H>(c, lds + kSOff, X);
       }
     } else {
-      gather_global(c, wav + cur.row * row_stride, length, cur.t0, n_frames, X);
+      gather_global<H>(c, wav + cur.row * row_stride, length, cur.t0, n_frames, X);
     }
-    phase_a(c, X, lds);
+    phase_a<H>(c, X, lds);
     wave_lds_fence();
     float vr[20], vi[20], zr[20], zi[20], qr[10], qi[10];
     phase_b1_load(c, lds, vr, vi);
@@ -822,8 +849,8 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
       int g_run = -1;
       float m_run = -INFINITY;
       for (int w = 0; w < kWavesPerBlock; ++w) {
-        const int gw = reinterpret_cast<const int*>(smem400 + w * kLdsDwordsPerWave)[0];
-        const float mw = smem400[w * kLdsDwordsPerWave + 1];
+        const int gw = reinterpret_cast<const int*>(smem400 + w * HC::lds_dwords)[0];
+        const float mw = smem400[w * HC::lds_dwords + 1];
         if (gw != g_run) {
           if (g_run >= 0) atomic_max_f32(epi.group_max + g_run, m_run);
           g_run = gw;

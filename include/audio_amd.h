@@ -108,8 +108,8 @@ int aamd_spectrogram_f32(const float* wav, const float* window, const float* twi
                          float* out, const aamd_stft_desc* desc, void* stream);
 
 /* Fused STFT -> |X|^power -> banded mel.  out: float[rows][n_frames][n_mels].
- * Uses the register/LDS radix-20x20 kernel when (n_fft, hop) = (400, 160), center/reflect,
- * onesided; every other shape takes the generic LDS Stockham kernel -- same results.
+ * Uses the register/LDS radix-20x20 kernel when n_fft = 400 and hop = 100, 160 or 200, center/reflect,
+ * onesided, power 2; every other shape takes the generic LDS Stockham kernel -- same results.
  * (aamd_spectrogram_f32 takes the same fast kernel for that shape when power > 0.) */
 int aamd_melspectrogram_f32(const float* wav, const float* window, const float* twiddle,
                             const aamd_mel_bands* bands, float* out,

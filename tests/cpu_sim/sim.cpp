@@ -72,10 +72,15 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
 
 // epi: 0 mel, 1 mel + dB (db = {multiplier, amin, db_sub}; gmax[rows / rows_per_group] max-reduced),
 //      2 spectrogram |X|^power (bands unused)
-int sim_melspec400(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
-                   float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
-                   int epi_mode, const float* db, float* gmax, int64_t rows_per_group, float power, int want_wide) {
+}  // extern "C" (pause: template)
+template <int H>
+static int sim_melspec400_h(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
+                            float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
+                            int epi_mode, const float* db, float* gmax, int64_t rows_per_group, float power,
+                            int want_wide) {
   using namespace m400;
+  using HC = Hop<H>;
+  constexpr int kHop = HC::hop;
   MelBandsDev mb{};
   if (epi_mode != EPI400_SPEC) {
     mb = MelBandsDev{bands->n_mels, bands->max_width, bands->lo, bands->width, bands->weights, bands->lane_order};
@@ -84,7 +89,7 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
   Epi400 epi{};
   if (epi_mode == EPI400_MEL_DB) { epi.multiplier = db[0]; epi.amin = db[1]; epi.db_sub = db[2]; }
   epi.power = power;
-  alignas(16) static float lds[kLdsDwordsPerWave];
+  alignas(16) static float lds[HC::lds_dwords];
   alignas(16) static float tab[kMelMaxRounds * kMelSlots * (kMelMaxTaps + 4 + 2) + 256];
   alignas(16) static float ctab[kConstDwords];
   for (int tid = 0; tid < 256; ++tid) const_tab_build(tid, 256, window, tw400, scale, ctab);
@@ -99,7 +104,7 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
   // same launch-time switches as launch_mel400() in c_api.hip
   const bool in_aligned = (row_stride % 4 == 0);
   const bool out_wide = (epi_mode == EPI400_SPEC) || (want_wide && mb.n_mels % 4 == 0);
-  static float X[64][28], vr[64][20], vi[64][20], zr[64][20], zi[64][20], qr[64][10], qi[64][10];
+  static float X[64][HC::nx], vr[64][20], vi[64][20], zr[64][20], zi[64][20], qr[64][10], qi[64][10];
   static float acc_a[64][kMelMaxRounds], acc_b[64][kMelMaxRounds];
   auto staged = [&](int64_t t0) {
     return in_aligned && (t0 * kHop - kPad >= 0) && ((t0 + kFramesPerWave - 1) * kHop + (kN - kPad) <= length) &&
@@ -108,8 +113,8 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
   // what the 5 LDS-DMA instructions of stage_issue() do: staging piece u <- tile piece stage_src_piece(u)
   auto stage = [&](int64_t row, int64_t t0) {
     const float* src = wav + row * row_stride + (t0 * kHop - kPad);
-    for (int u = 0; u < kSPieces; ++u)
-      for (int e = 0; e < 4; ++e) lds[kSOff + 4 * u + e] = src[4 * stage_src_piece(u) + e];
+    for (int u = 0; u < 64 * HC::ndma; ++u)
+      for (int e = 0; e < 4; ++e) lds[kSOff + 4 * u + e] = src[4 * stage_src_piece<H>(u) + e];
   };
   // one wave walks all tiles in order, exactly like the kernel's tile loop
   const int64_t n_tiles = rows * tiles_per_row;
@@ -121,10 +126,10 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
     const bool nxt_staged = (tile + 1 < n_tiles) && staged(nt0);
     const float* wr = wav + row * row_stride;
     for (int l = 0; l < 64; ++l) {
-      if (cur_staged) gather_lds(c[l], lds + kSOff, X[l]);
-      else gather_global(c[l], wr, length, t0, n_frames, X[l]);
+      if (cur_staged) gather_lds<H>(c[l], lds + kSOff, X[l]);
+      else gather_global<H>(c[l], wr, length, t0, n_frames, X[l]);
     }
-    for (int l = 0; l < 64; ++l) phase_a(c[l], X[l], lds);
+    for (int l = 0; l < 64; ++l) phase_a<H>(c[l], X[l], lds);
     for (int l = 0; l < 64; ++l) phase_b1_load(c[l], lds, vr[l], vi[l]);
     if (nxt_staged) stage(nrow, nt0);
     for (int l = 0; l < 64; ++l) dft20(vr[l], vi[l], zr[l], zi[l]);
@@ -171,6 +176,21 @@ int sim_melspec400(const float* wav, const float* window, const float* tw400, co
   }
   return 0;
 }
+
+extern "C" {
+int sim_melspec400(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
+                   float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
+                   int epi_mode, const float* db, float* gmax, int64_t rows_per_group, float power, int want_wide,
+                   int hop) {
+#define SIM_M400(H) return sim_melspec400_h<H>(wav, window, tw400, bands, out, rows, length, row_stride, n_frames, scale, \
+                                               epi_mode, db, gmax, rows_per_group, power, want_wide)
+  if (hop == 100) SIM_M400(5);
+  if (hop == 200) SIM_M400(10);
+  if (hop == 160) SIM_M400(8);
+#undef SIM_M400
+  return -3;
+}
+
 
 // Replay of mfcc_dct_mfma_kernel: the A/B/C fragment maps of v_mfma_f32_16x16x4_f32
 // (A[l&15][l>>4], B[l>>4][l&15], C row = 4*(l>>4)+i, col = l&15) applied to the same index math.

@@ -83,26 +83,26 @@ def sim_mel_generic(x, window_padded, bands, desc):
 
 
 def _sim_fft400(x, window, bands, scale, epi, db=None, gmax=None, rows_per_group=1, power=2.0, out_width=None,
-                wide=0):
+                wide=0, hop=160):
     x = np.ascontiguousarray(x, dtype=np.float32)
     rows, length = x.shape
     w = np.ascontiguousarray(window, dtype=np.float32)
     tw = np.ascontiguousarray(_host.twiddle_table(400))
-    T = _host.frame_count(length, 400, 160, True)
+    T = _host.frame_count(length, 400, hop, True)
     out = np.zeros((rows, T, out_width), dtype=np.float32)
     f = sim().sim_melspec400
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                  C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int]
+                  C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_int]
     dbv = None if db is None else fptr(np.ascontiguousarray(db, dtype=np.float32))
     rc = f(fptr(x), fptr(w), fptr(tw), None if bands is None else C.cast(C.byref(bands.struct), C.c_void_p),
            fptr(out), rows, length, length, T, scale, epi, dbv, None if gmax is None else fptr(gmax),
-           rows_per_group, power, wide)
+           rows_per_group, power, wide, hop)
     assert rc == 0
     return np.swapaxes(out, -1, -2)
 
 
-def sim_mel400(x, window, bands, scale=1.0, wide=0):
-    return _sim_fft400(x, window, bands, scale, 0, out_width=bands.n_mels, wide=wide)
+def sim_mel400(x, window, bands, scale=1.0, wide=0, hop=160):
+    return _sim_fft400(x, window, bands, scale, 0, out_width=bands.n_mels, wide=wide, hop=hop)
 
 
 def sim_mel400_db(x, window, bands, multiplier, amin, db_multiplier, gmax, rows_per_group, scale=1.0):
@@ -111,8 +111,8 @@ def sim_mel400_db(x, window, bands, multiplier, amin, db_multiplier, gmax, rows_
                        rows_per_group=rows_per_group, out_width=bands.n_mels)
 
 
-def sim_spec400(x, window, power, scale=1.0):
-    return _sim_fft400(x, window, None, scale, 2, power=power, out_width=201)
+def sim_spec400(x, window, power, scale=1.0, hop=160):
+    return _sim_fft400(x, window, None, scale, 2, power=power, out_width=201, hop=hop)
 
 
 def sim_mfcc_dct_mfma(mel_fm, dct, log_mode, group_max=None, vec_per_group=1, top_db=-1.0):

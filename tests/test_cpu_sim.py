@@ -344,3 +344,18 @@ def test_mel_lane_order_reduces_modelled_bank_conflicts():
     lo, width, _, _ = _host.mel_band_table(fb64)
     o64 = _host.mel_lane_order(lo, width)
     assert o64.shape == (80,) and sorted(m for m in o64 if m >= 0) == list(range(64)) and (o64 == -1).sum() == 16 and (o64[:60] >= 0).all()
+
+
+@pytest.mark.parametrize("hop", [100, 200])
+@pytest.mark.parametrize("L", [2537, 1409])
+def test_sim_mel400_other_hops(hop, L):
+    """hop = 100 / 200 instantiations of the radix-20x20 kernel (Hop<5>, Hop<10>: other gather widths,
+    staging pads and DMA piece maps) vs the float64 oracle: mel and spectrogram epilogues, ragged tails."""
+    x, w, fb = _headline_setup(rows=2, L=L)
+    bands = S.HostBands(fb, permute=True)
+    got = S.sim_mel400(x, w, bands, hop=hop)
+    exp = O.mel_spectrogram(x.astype(np.float64), w.astype(np.float64), fb.astype(np.float64), 400, hop)
+    assert got.shape == exp.shape and peak_rel_err(got, exp) <= TOL
+    gs = S.sim_spec400(x, w, 2.0, hop=hop)
+    es = O.spectrogram(x.astype(np.float64), 0, w.astype(np.float64), 400, hop, 400, 2.0, False)
+    assert gs.shape == es.shape and peak_rel_err(gs, es) <= TOL

@@ -495,3 +495,25 @@ def test_resample_matrix_core_layout_edges():
         got = r(view)
         exp = O.resample(view.cpu().numpy().astype(np.float64), 44100, 16000, **kw)
         assert got.shape == exp.shape and peak_rel_err(got.cpu().numpy(), exp) <= 1e-5
+
+
+@pytest.mark.parametrize("hop", [100, 200])
+def test_fft400_other_hops_fast_path(hop):
+    """hop = 100 and 200 (torchaudio's default n_fft // 2) also take the radix-20x20 kernel: mel, MFCC and
+    spectrogram vs the generic kernel and the float64 oracle, ragged lengths."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(hop)
+    fb = O.melscale_fbanks(201, 0.0, 8000.0, 80, 16000)
+    mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=hop, n_mels=80).cuda()
+    spec = T.Spectrogram(n_fft=400, hop_length=hop, power=1.0).cuda()
+    mfcc = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=hop, n_mels=80)).cuda()
+    for L in (401, 1009, 16000, 48017):
+        x = (0.5 * torch.randn(3, L, generator=g)).clamp_(-1, 1)
+        for t in (mel, spec, mfcc):
+            fast = t(x.cuda())
+            gen = _force_generic(lambda: t(x.cuda()))
+            assert fast.shape == gen.shape and fast.stride() == gen.stride()
+            assert float((fast - gen).abs().max() / gen.abs().max()) <= 2e-5, (hop, L, type(t).__name__)
+        exp = O.mel_spectrogram(x.numpy().astype(np.float64), O.hann_window(400), fb, 400, hop)
+        assert peak_rel_err(mel(x.cuda()).cpu().numpy(), exp) <= 1e-4
