@@ -257,7 +257,7 @@ int aamd_spectrogram_f32(const float* wav, const float* window, const float* twi
   if (rc != AAMD_OK) return rc;
   AAMD_CHECK_ARG(wav && window && twiddle && out, "null buffer");
   MelBandsDev mb{};
-  if (fft400_eligible(g) && g.power > 0.0f && reinterpret_cast<uintptr_t>(out) % 16 == 0) {
+  if (fft400_eligible(g) && reinterpret_cast<uintptr_t>(out) % 16 == 0) {   // power <= 0: complex rows
     m400::Epi400 epi{};
     epi.power = g.power;
     return launch_fft400<m400::EPI400_SPEC>(g, mb, wav, window, twiddle, out, epi, (hipStream_t)stream);

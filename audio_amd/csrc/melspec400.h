@@ -96,7 +96,7 @@ struct Epi400 {
   float power;                      // SPEC: 2 -> |X|^2, 1 -> |X|, else |X|^power
 };
 constexpr int kSpecBins = 201;
-static_assert(kFramesPerWave * kSpecBins + 3 <= kSOff, "SPEC rows must fit below the staging area");
+static_assert(kFramesPerWave * kSpecBins + 3 <= kSOff && 3 * 2 * kSpecBins + 3 <= kSOff, "SPEC rows must fit below the staging area");
 
 // column held by the lane at position pi of a 20-lane group (pass 2), and its inverse:
 // positions (0,1) = columns (0,10), then (2j, 2j+1) = (j, 20-j): lane ^ 1 holds column 20 - c.
@@ -438,6 +438,29 @@ AAMD_HD void phase_b2_spec(const LaneConst& c, const float (&zr)[20], const floa
     const float ar = zr[10] + zr[10], bi = zi[10] + zi[10];
     Ra[200] = spec_pow(ar * ar, power);
     Rb[200] = spec_pow(bi * bi, power);
+  }
+}
+
+// Complex spectrogram (power = None): interleaved (re, im) rows of 402 floats.  Six of them do not fit
+// below the staging area, so the tile is written in two halves of 3 frames (frames 3 h .. 3 h + 2):
+//   A = (Z[k] + conj Z[N-k]) / 2 = (ar, ai) / 2,   B = (Z[k] - conj Z[N-k]) / (2i) = (bi, -br) / 2
+// (the 1/2 is folded into the window table).
+AAMD_HD void phase_b2_spec_complex(const LaneConst& c, const float (&zr)[20], const float (&zi)[20],
+                                   const float (&xr)[10], const float (&xi)[10], int half, int phase, float* lds) {
+  if (!c.active) return;
+  const int fa = 2 * c.p - 3 * half, fb = fa + 1;          // row of frame a / b inside this half, or outside [0, 3)
+  const bool wa = fa >= 0 && fa < 3, wb = fb >= 0 && fb < 3;
+  float* Ra = lds + phase + 2 * kSpecBins * fa + 2 * c.col;
+  float* Rb = lds + phase + 2 * kSpecBins * fb + 2 * c.col;
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    const float cr = xr[9 - u], ci = xi[9 - u];
+    if (wa) { Ra[40 * u] = zr[u] + cr; Ra[40 * u + 1] = zi[u] - ci; }
+    if (wb) { Rb[40 * u] = zi[u] + ci; Rb[40 * u + 1] = cr - zr[u]; }
+  }
+  if (c.col == 0) {   // Nyquist bin: real for both frames
+    if (wa) { Ra[400] = zr[10] + zr[10]; Ra[401] = 0.0f; }
+    if (wb) { Rb[400] = zi[10] + zi[10]; Rb[401] = 0.0f; }
   }
 }
 
@@ -787,13 +810,25 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     exchange_partner(qr, qi, self_mask);
     wave_lds_fence();
     if (EPI == EPI400_SPEC) {
-      const int64_t a0 = (cur.row * n_frames + cur.t0) * (int64_t)kSpecBins;
-      phase_b2_spec(c, zr, zi, qr, qi, epi.power, (int)(a0 & 3), lds);
-      wave_lds_fence();
       const int64_t left = n_frames - cur.t0;
       const int n_valid = left < kFramesPerWave ? (int)left : kFramesPerWave;
-      if (!(LAB & 2)) store_spec(lane, lds, out, a0, n_valid * kSpecBins);
-      wave_lds_fence();
+      if (epi.power > 0.0f) {
+        const int64_t a0 = (cur.row * n_frames + cur.t0) * (int64_t)kSpecBins;
+        phase_b2_spec(c, zr, zi, qr, qi, epi.power, (int)(a0 & 3), lds);
+        wave_lds_fence();
+        if (!(LAB & 2)) store_spec(lane, lds, out, a0, n_valid * kSpecBins);
+        wave_lds_fence();
+      } else {   // complex output, two halves of 3 frames
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int64_t a0 = (cur.row * n_frames + cur.t0 + 3 * half) * (int64_t)(2 * kSpecBins);
+          const int nv = n_valid - 3 * half < 3 ? n_valid - 3 * half : 3;
+          phase_b2_spec_complex(c, zr, zi, qr, qi, half, (int)(a0 & 3), lds);
+          wave_lds_fence();
+          if (!(LAB & 2) && nv > 0) store_spec(lane, lds, out, a0, nv * 2 * kSpecBins);
+          wave_lds_fence();
+        }
+      }
       cur = nxt;
       cur_idx = nxt_idx;
       continue;

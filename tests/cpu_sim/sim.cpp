@@ -142,12 +142,21 @@ static int sim_melspec400_h(const float* wav, const float* window, const float* 
     }
     // the DPP quad_perm [1,0,3,2] swap: lane l receives lane l ^ 1's q
     if (epi_mode == EPI400_SPEC) {
-      const int64_t a0 = (row * n_frames + t0) * (int64_t)kSpecBins;
-      for (int l = 0; l < 64; ++l)
-        phase_b2_spec(c[l], zr[l], zi[l], xr[l], xi[l], epi.power, (int)(a0 & 3), lds);
       const int64_t left = n_frames - t0;
       const int n_valid = left < kFramesPerWave ? (int)left : kFramesPerWave;
-      for (int l = 0; l < 64; ++l) store_spec(l, lds, out, a0, n_valid * kSpecBins);
+      if (epi.power > 0.0f) {
+        const int64_t a0 = (row * n_frames + t0) * (int64_t)kSpecBins;
+        for (int l = 0; l < 64; ++l)
+          phase_b2_spec(c[l], zr[l], zi[l], xr[l], xi[l], epi.power, (int)(a0 & 3), lds);
+        for (int l = 0; l < 64; ++l) store_spec(l, lds, out, a0, n_valid * kSpecBins);
+      } else {
+        for (int half = 0; half < 2; ++half) {
+          const int64_t a0 = (row * n_frames + t0 + 3 * half) * (int64_t)(2 * kSpecBins);
+          const int nv = n_valid - 3 * half < 3 ? n_valid - 3 * half : 3;
+          for (int l = 0; l < 64; ++l) phase_b2_spec_complex(c[l], zr[l], zi[l], xr[l], xi[l], half, (int)(a0 & 3), lds);
+          if (nv > 0) for (int l = 0; l < 64; ++l) store_spec(l, lds, out, a0, nv * 2 * kSpecBins);
+        }
+      }
       cur_staged = nxt_staged;
       continue;
     }

@@ -112,6 +112,10 @@ def sim_mel400_db(x, window, bands, multiplier, amin, db_multiplier, gmax, rows_
 
 
 def sim_spec400(x, window, power, scale=1.0, hop=160):
+    if power is None:      # complex: interleaved (re, im) rows
+        o = _sim_fft400(x, window, None, scale, 2, power=0.0, out_width=402, hop=hop)     # (rows, 402, T)
+        o = np.swapaxes(o, -1, -2)
+        return np.swapaxes(o[..., 0::2] + 1j * o[..., 1::2], -1, -2)
     return _sim_fft400(x, window, None, scale, 2, power=power, out_width=201, hop=hop)
 
 

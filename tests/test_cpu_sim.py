@@ -359,3 +359,13 @@ def test_sim_mel400_other_hops(hop, L):
     gs = S.sim_spec400(x, w, 2.0, hop=hop)
     es = O.spectrogram(x.astype(np.float64), 0, w.astype(np.float64), 400, hop, 400, 2.0, False)
     assert gs.shape == es.shape and peak_rel_err(gs, es) <= TOL
+
+
+@pytest.mark.parametrize("hop,L", [(160, 2537), (160, 1283), (200, 1601), (100, 1409)])
+def test_sim_spec400_complex_epilogue(hop, L):
+    """power=None on the radix-20x20 kernel: complex rows written in two half-tiles."""
+    x, w, _ = _headline_setup(rows=2, L=L)
+    got = S.sim_spec400(x, w, None, hop=hop)
+    exp = O.spectrogram(x.astype(np.float64), 0, w.astype(np.float64), 400, hop, 400, None, False)
+    assert got.shape == exp.shape
+    assert np.abs(got - exp).max() / np.abs(exp).max() <= TOL

@@ -517,3 +517,21 @@ def test_fft400_other_hops_fast_path(hop):
             assert float((fast - gen).abs().max() / gen.abs().max()) <= 2e-5, (hop, L, type(t).__name__)
         exp = O.mel_spectrogram(x.numpy().astype(np.float64), O.hann_window(400), fb, 400, hop)
         assert peak_rel_err(mel(x.cuda()).cpu().numpy(), exp) <= 1e-4
+
+
+@pytest.mark.parametrize("hop", [100, 160, 200])
+def test_spec400_complex_fast_path(hop):
+    """power=None (complex STFT) on the radix-20x20 kernel vs the generic kernel and the oracle."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(hop + 1)
+    t = T.Spectrogram(n_fft=400, hop_length=hop, power=None).cuda()
+    for L in (401, 1283, 16000, 48017):
+        x = (0.5 * torch.randn(3, L, generator=g)).clamp_(-1, 1)
+        fast = t(x.cuda())
+        gen = _force_generic(lambda: t(x.cuda()))
+        assert fast.dtype == torch.complex64 and fast.shape == gen.shape and fast.stride() == gen.stride()
+        assert float((fast - gen).abs().max() / gen.abs().max()) <= 3e-6
+        if L <= 16000:
+            exp = O.spectrogram(x.numpy().astype(np.float64), 0, O.hann_window(400), 400, hop, 400, None, False)
+            assert np.abs(fast.cpu().numpy() - exp).max() / np.abs(exp).max() <= 1e-4
