@@ -33,15 +33,16 @@ __all__ = [
 # --------------------------------------------------------------------------- #
 
 
-def _require_device(t: Tensor, what: str) -> None:
+def _require_device(t: Tensor, what: str, allow_grad: bool = False) -> None:
     if not t.is_cuda:
         raise RuntimeError(
             f"audio_amd: {what} must be on an MI355X (ROCm) device, got {t.device}. "
             "The HIP kernels have no CPU fallback.")
     if t.dtype != torch.float32:
         raise TypeError(f"audio_amd: {what} must be float32 (got {t.dtype}); kernels compute in fp32.")
-    if t.requires_grad and torch.is_grad_enabled():
-        raise RuntimeError("audio_amd: forward-only kernels; wrap the call in torch.no_grad().")
+    if t.requires_grad and torch.is_grad_enabled() and not allow_grad:
+        raise RuntimeError("audio_amd: this op is forward-only (autograd exists for lfilter / biquad); "
+                           "wrap the call in torch.no_grad().")
 
 
 def _rows2d(t: Tensor) -> Tensor:
@@ -432,6 +433,47 @@ def _lfilter_launch(x3: Tensor, a: Tensor, b: Tensor, clamp: bool, n_stages: int
     return y
 
 
+class _LFilterFunction(torch.autograd.Function):
+    """Autograd of lfilter on the HIP kernels (reference: DifferentiableFIR / DifferentiableIIR,
+    functional/filtering.py:941-1024).  With w = FIR(x; b^) and y = IIR(w; a^), both LTI:
+      dL/dx   = time-reversed lfilter(a^, b^) of the time-reversed dL/dy      (one kernel launch)
+      dL/dw   = time-reversed all-pole filter 1/A of the time-reversed dL/dy  (one kernel launch)
+      dL/db^k = sum_n dL/dw[n] x[n-k],   dL/da^k = -sum_n dL/dw[n] y[n-k]  (k >= 1; a^0 = 1 is not a parameter)
+    clamp(-1, 1) passes gradient where the unclamped output lies inside [-1, 1] (torch.clamp's rule)."""
+
+    @staticmethod
+    def forward(ctx, x3, a_n, b_n, clamp):
+        a_n = a_n.contiguous()
+        b_n = b_n.contiguous()
+        y_raw = _lfilter_launch(x3, a_n.unsqueeze(0), b_n.unsqueeze(0), False)
+        ctx.save_for_backward(x3, a_n, b_n, y_raw)
+        ctx.clamp = clamp
+        return y_raw.clamp(-1.0, 1.0) if clamp else y_raw
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, a_n, b_n, y = ctx.saved_tensors
+        g = dy
+        if ctx.clamp:
+            g = g * ((y >= -1.0) & (y <= 1.0)).to(g.dtype)
+        gf = g.flip(-1).contiguous()
+        dx = da = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _lfilter_launch(gf, a_n.unsqueeze(0), b_n.unsqueeze(0), False).flip(-1)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            one = torch.zeros_like(b_n)
+            one[:, 0] = 1.0
+            dw = _lfilter_launch(gf, a_n.unsqueeze(0), one.unsqueeze(0), False).flip(-1)
+            n_order, L = a_n.shape[1], x3.shape[-1]
+            if ctx.needs_input_grad[2]:
+                db = torch.stack([(dw[..., k:] * x3[..., :L - k]).sum((0, 2)) for k in range(n_order)], 1)
+            if ctx.needs_input_grad[1]:
+                cols = [torch.zeros(a_n.shape[0], dtype=a_n.dtype, device=a_n.device)]
+                cols += [-(dw[..., k:] * y[..., :L - k]).sum((0, 2)) for k in range(1, n_order)]
+                da = torch.stack(cols, 1)
+        return dx, da, db, None
+
+
 def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = True, batching: bool = True) -> Tensor:
     r"""IIR filter by the difference equation (functional/filtering.py:1032-1099): FIR + recursion
     + clamp in one HIP kernel (chunked linear-recurrence scan, see csrc/lfilter.h)."""
@@ -456,13 +498,19 @@ def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = 
     else:
         a_coeffs = a_coeffs.unsqueeze(0)
         b_coeffs = b_coeffs.unsqueeze(0)
-    _require_device(waveform, "waveform")
+    needs_grad = torch.is_grad_enabled() and (waveform.requires_grad or a_coeffs.requires_grad or b_coeffs.requires_grad)
+    _require_device(waveform, "waveform", allow_grad=True)
     shape = waveform.size()
     n_filt = a_coeffs.shape[0]
     x3 = waveform.reshape(-1, n_filt, shape[-1]).contiguous()
     a = a_coeffs.to(device=waveform.device, dtype=torch.float32).contiguous()
     b = b_coeffs.to(device=waveform.device, dtype=torch.float32).contiguous()
-    y = _lfilter_launch(x3, a, b, clamp)
+    if needs_grad:
+        # differentiable path (functional/filtering.py:941-1029): normalise by a0 with torch ops so that
+        # autograd sees the division, the recursion and its adjoint run in the HIP kernel
+        y = _LFilterFunction.apply(x3, a / a[:, 0:1], b / a[:, 0:1], clamp)
+    else:
+        y = _lfilter_launch(x3, a, b, clamp)
     return y.reshape(shape[:-1] + y.shape[-1:])
 
 
