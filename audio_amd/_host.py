@@ -279,3 +279,27 @@ def mel_lane_order(lo: np.ndarray, width: np.ndarray, iters: int = 4000, seed: i
                 cur, c = cand, cc
         order[20 * r: 20 * r + 20] = cur
     return order
+
+
+def resample_adjoint_table(kernel: np.ndarray, orig: int, new: int, width: int):
+    """Tap table of the ADJOINT of `y[q new + p] = sum_k h[p][k] xpad[q orig + k]` written as the same kind of
+    polyphase operator with the rates swapped (orig' = new, new' = orig):
+        dx[q' orig + r] = sum_{k'} h'[r][k'] dypad[q' new + k'],   dypad = [0]*W' ++ dy ++ [0]*(W' + new),
+        W' = A new,  A = ceil(width / orig),  k' = (A - d) new + p  <->  h[p][d orig + r + width]
+    (d = q' - q is the block offset between the input sample and the output block it contributed to).
+    Returns (h' float32[orig][2 W' + new], W')."""
+    h = np.asarray(kernel, dtype=np.float32).reshape(new, -1)
+    taps = h.shape[1]
+    assert taps == 2 * width + orig
+    A = -(-width // orig)
+    Wp = A * new
+    tp = 2 * Wp + new
+    out = np.zeros((orig, tp), dtype=np.float32)
+    r = np.arange(orig)[:, None]
+    kp = np.arange(tp)[None, :]
+    d = A - kp // new
+    p = kp % new
+    k = d * orig + r + width
+    ok = (k >= 0) & (k < taps)
+    out[ok] = h[np.broadcast_to(p, k.shape)[ok], k[ok]]
+    return out, Wp

@@ -14,6 +14,7 @@ import warnings
 import weakref
 from typing import Optional, Union
 
+import numpy as np
 import torch
 from torch import Tensor
 
@@ -41,7 +42,7 @@ def _require_device(t: Tensor, what: str, allow_grad: bool = False) -> None:
     if t.dtype != torch.float32:
         raise TypeError(f"audio_amd: {what} must be float32 (got {t.dtype}); kernels compute in fp32.")
     if t.requires_grad and torch.is_grad_enabled() and not allow_grad:
-        raise RuntimeError("audio_amd: this op is forward-only (autograd exists for lfilter / biquad); "
+        raise RuntimeError("audio_amd: this op is forward-only (autograd exists for lfilter / biquad / fftconvolve / resample); "
                            "wrap the call in torch.no_grad().")
 
 
@@ -358,33 +359,64 @@ def amplitude_to_DB(x: Tensor, multiplier: float, amin: float, db_multiplier: fl
 # --------------------------------------------------------------------------- #
 
 
-def _apply_sinc_resample_kernel(waveform: Tensor, orig_freq: int, new_freq: int, gcd: int, kernel: Tensor,
-                                width: int) -> Tensor:
-    """functional/functional.py:1405-1432 as one polyphase HIP kernel."""
-    if not waveform.is_floating_point():
-        raise TypeError(f"Expected floating point type for waveform tensor, but received {waveform.dtype}.")
-    _require_device(waveform, "waveform")
-    orig = int(orig_freq) // gcd
-    new = int(new_freq) // gcd
-    shape = waveform.size()
-    x2 = _rows2d(waveform)
+def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new: int, width: int) -> Tensor:
+    """(rows, L) -> (rows, ceil(new L / orig)) through aamd_resample_banded_f32; band table cached per tensor."""
     rows, length = x2.shape
     out_len = int(math.ceil(new * length / orig))
-    kern = kernel.to(device=waveform.device, dtype=torch.float32).reshape(new, -1).contiguous()
-    if kern.shape[1] != 2 * width + orig:
-        raise RuntimeError("audio_amd: resample kernel shape does not match (new, 2*width+orig)")
-    out = torch.empty((rows, out_len), dtype=torch.float32, device=waveform.device)
+    out = torch.empty((rows, out_len), dtype=torch.float32, device=x2.device)
     if out.numel():
         L = _lib.lib()
         # band table of the taps (host, once per kernel tensor): the matrix-core kernel skips the
         # ~1e-20-sized window tails outside each phase tile's band
-        tap_lo, span = _tensor_cached(kernel, ("rs_bands", new),
+        tap_lo, span = _tensor_cached(key_tensor, ("rs_bands", key, new),
                                       lambda: _host.resample_band_table(kern.cpu().numpy()))
         bands = _lib.ResampleBands(tap_lo.shape[0], span, tap_lo.ctypes.data_as(C.POINTER(C.c_int32)))
         _lib.check(L.aamd_resample_banded_f32(x2.data_ptr(), kern.data_ptr(), out.data_ptr(), rows, length,
                                               x2.stride(0) if rows > 1 else max(length, 1), orig, new, width,
-                                              out_len, C.byref(bands), _lib.current_stream(waveform.device)))
-    return out.view(tuple(shape[:-1]) + (out_len,))
+                                              out_len, C.byref(bands), _lib.current_stream(x2.device)))
+    return out
+
+
+class _ResampleFunction(torch.autograd.Function):
+    """Resampling is linear in the waveform; its adjoint is again a polyphase filter with the two rates
+    swapped and the tap table re-indexed (`_host.resample_adjoint_table`), so the backward pass is one
+    more launch of the same matrix-core kernel.  The tap table is a constant (no gradient), as in the
+    reference's gradcheck (test/torchaudio_unittest/functional/autograd_impl.py)."""
+
+    @staticmethod
+    def forward(ctx, x2, kern, kernel_key, orig, new, width):
+        ctx.kern, ctx.kernel_key, ctx.geom, ctx.length = kern, kernel_key, (orig, new, width), x2.shape[1]
+        return _polyphase(x2, kern, kernel_key, "fwd", orig, new, width)
+
+    @staticmethod
+    def backward(ctx, dy):
+        orig, new, width = ctx.geom
+        adj = _tensor_cached(ctx.kernel_key, ("rs_adjoint", orig, new, width), lambda: tuple(
+            (torch.from_numpy(t).to(dy.device) if isinstance(t, np.ndarray) else t)
+            for t in _host.resample_adjoint_table(ctx.kern.cpu().numpy(), orig, new, width)))
+        kern_adj, width_adj = adj
+        dx = _polyphase(dy.contiguous(), kern_adj, kern_adj, "adj", new, orig, int(width_adj))
+        return dx[:, :ctx.length], None, None, None, None, None
+
+
+def _apply_sinc_resample_kernel(waveform: Tensor, orig_freq: int, new_freq: int, gcd: int, kernel: Tensor,
+                                width: int) -> Tensor:
+    """functional/functional.py:1405-1432 as one polyphase HIP kernel (differentiable in the waveform)."""
+    if not waveform.is_floating_point():
+        raise TypeError(f"Expected floating point type for waveform tensor, but received {waveform.dtype}.")
+    _require_device(waveform, "waveform", allow_grad=True)
+    orig = int(orig_freq) // gcd
+    new = int(new_freq) // gcd
+    shape = waveform.size()
+    x2 = _rows2d(waveform)
+    kern = kernel.to(device=waveform.device, dtype=torch.float32).reshape(new, -1).contiguous()
+    if kern.shape[1] != 2 * width + orig:
+        raise RuntimeError("audio_amd: resample kernel shape does not match (new, 2*width+orig)")
+    if torch.is_grad_enabled() and waveform.requires_grad:
+        out = _ResampleFunction.apply(x2, kern, kernel, orig, new, width)
+    else:
+        out = _polyphase(x2, kern, kernel, "fwd", orig, new, width)
+    return out.view(tuple(shape[:-1]) + (out.shape[-1],))
 
 
 def resample(
@@ -688,27 +720,10 @@ def _check_convolve_mode(mode: str) -> None:
         raise ValueError(f"Unrecognized mode value '{mode}'. Please specify one of {_CONV_MODES}.")
 
 
-def fftconvolve(x: Tensor, y: Tensor, mode: str = "full") -> Tensor:
-    r"""Linear convolution along the last dim with broadcast leading dims and the reference's
-    full / valid / same crops (functional/functional.py:2222-2258)."""
-    _check_shape_compatible(x, y)
-    _check_convolve_mode(mode)
-    if not x.is_floating_point():
-        x = x.float()
-    if not y.is_floating_point():
-        y = y.float()
-    _require_device(x, "x")
-    _require_device(y, "y")
+def _conv_slice(x: Tensor, y: Tensor, start: int, out_len: int) -> Tensor:
+    """out[..., i] = (x * y)[start + i], i in [0, out_len): a slice of the full linear convolution of the
+    last dims, leading dims broadcast (forward-only launcher of aamd_fftconvolve_f32)."""
     nx, ny = x.size(-1), y.size(-1)
-    n_full = nx + ny - 1
-    if mode == "full":
-        start, out_len = 0, n_full
-    elif mode == "valid":
-        out_len = max(nx, ny) - min(nx, ny) + 1
-        start = (n_full - out_len) // 2
-    else:
-        out_len = nx
-        start = (n_full - nx) // 2
     lead = torch.broadcast_shapes(tuple(x.shape[:-1]), tuple(y.shape[:-1]))
     rows = 1
     for d in lead:
@@ -716,13 +731,13 @@ def fftconvolve(x: Tensor, y: Tensor, mode: str = "full") -> Tensor:
     xr = x.reshape(-1, nx).contiguous()
     yr = y.reshape(-1, ny).contiguous()
 
-    def row_map(t: Tensor):
+    def row_map(t: Tensor, n_rows: int):
         if tuple(t.shape[:-1]) == tuple(lead):
             return None
-        idx = torch.arange(xr.shape[0] if t is x else yr.shape[0], device=x.device).view(tuple(t.shape[:-1]))
+        idx = torch.arange(n_rows, device=x.device).view(tuple(t.shape[:-1]))
         return idx.expand(lead).reshape(-1).contiguous()
 
-    xmap, ymap = row_map(x), row_map(y)
+    xmap, ymap = row_map(x, xr.shape[0]), row_map(y, yr.shape[0])
     out = torch.empty((rows, out_len), dtype=torch.float32, device=x.device)
     if out.numel():
         L = _lib.lib()
@@ -733,3 +748,56 @@ def fftconvolve(x: Tensor, y: Tensor, mode: str = "full") -> Tensor:
             xmap.data_ptr() if xmap is not None else None, ymap.data_ptr() if ymap is not None else None,
             start, out_len, ws.data_ptr() if ws is not None else None, _lib.current_stream(x.device)))
     return out.view(tuple(lead) + (out_len,))
+
+
+class _FFTConvolveFunction(torch.autograd.Function):
+    """z = (x * y)[start : start + out_len].  Both adjoints are correlations, i.e. convolutions with a
+    time-reversed operand, evaluated by the same kernels:
+        dL/dx[m] = sum_n dz[n] y[n - m] = (dz_full * flip(y))[m + ny - 1]
+        dL/dy[j] = sum_n dz[n] x[n - j] = (dz_full * flip(x))[j + nx - 1]
+    (dz_full = dz placed at offset `start` of the full length), summed over broadcast leading dims."""
+
+    @staticmethod
+    def forward(ctx, x, y, start, out_len):
+        ctx.save_for_backward(x, y)
+        ctx.start, ctx.out_len = start, out_len
+        return _conv_slice(x, y, start, out_len)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, y = ctx.saved_tensors
+        nx, ny = x.size(-1), y.size(-1)
+        full = torch.zeros(tuple(dz.shape[:-1]) + (nx + ny - 1,), dtype=dz.dtype, device=dz.device)
+        full[..., ctx.start:ctx.start + ctx.out_len] = dz
+        dx = dy = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_slice(full, y.flip(-1), ny - 1, nx).sum_to_size(x.shape)
+        if ctx.needs_input_grad[1]:
+            dy = _conv_slice(full, x.flip(-1), nx - 1, ny).sum_to_size(y.shape)
+        return dx, dy, None, None
+
+
+def fftconvolve(x: Tensor, y: Tensor, mode: str = "full") -> Tensor:
+    r"""Linear convolution along the last dim with broadcast leading dims and the reference's
+    full / valid / same crops (functional/functional.py:2222-2258).  Differentiable in both operands."""
+    _check_shape_compatible(x, y)
+    _check_convolve_mode(mode)
+    if not x.is_floating_point():
+        x = x.float()
+    if not y.is_floating_point():
+        y = y.float()
+    _require_device(x, "x", allow_grad=True)
+    _require_device(y, "y", allow_grad=True)
+    nx, ny = x.size(-1), y.size(-1)
+    n_full = nx + ny - 1
+    if mode == "full":
+        start, out_len = 0, n_full
+    elif mode == "valid":
+        out_len = max(nx, ny) - min(nx, ny) + 1
+        start = (n_full - out_len) // 2
+    else:
+        out_len = nx
+        start = (n_full - nx) // 2
+    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+        return _FFTConvolveFunction.apply(x, y, start, out_len)
+    return _conv_slice(x, y, start, out_len)

@@ -559,3 +559,57 @@ def test_lfilter_autograd_vs_reference_gradients(name):
     import audio_amd.transforms as T
     with pytest.raises(RuntimeError, match="forward-only"):
         T.Spectrogram(n_fft=64)(x.reshape(-1, x.shape[-1]))
+
+
+@pytest.mark.parametrize("shapes,mode", [(((3, 700), (3, 90)), "full"), (((2, 2, 5000), (1, 1, 400)), "same"),
+                                         (((4, 3000), (1, 1200)), "valid"), (((1, 300), (2, 9000)), "full")])
+def test_fftconvolve_autograd(shapes, mode):
+    """Gradients of F.fftconvolve in both operands (adjoint = convolution with the time-reversed operand on the
+    same kernels, broadcast dims summed) vs autograd through the float64 FFT composition on the CPU."""
+    import audio_amd.functional as F
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(*shapes[0], generator=g, dtype=torch.float64)
+    y = torch.randn(*shapes[1], generator=g, dtype=torch.float64) * 0.3
+    xr, yr = x.clone().requires_grad_(), y.clone().requires_grad_()
+    n = x.shape[-1] + y.shape[-1] - 1
+    full = torch.fft.irfft(torch.fft.rfft(xr, n=n) * torch.fft.rfft(yr, n=n), n=n)
+    if mode == "full":
+        ref = full
+    else:
+        m = x.shape[-1] if mode == "same" else max(x.shape[-1], y.shape[-1]) - min(x.shape[-1], y.shape[-1]) + 1
+        s0 = (n - m) // 2
+        ref = full[..., s0:s0 + m]
+    r = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (ref * r).sum().backward()
+    xg = x.float().cuda().requires_grad_()
+    yg = y.float().cuda().requires_grad_()
+    z = F.fftconvolve(xg, yg, mode)
+    assert peak_rel_err(z.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
+    (z * r.float().cuda()).sum().backward()
+    assert peak_rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) <= 2e-5
+    assert peak_rel_err(yg.grad.cpu().numpy(), yr.grad.numpy()) <= 2e-5
+
+
+@pytest.mark.parametrize("rates", [(44100, 16000, True), (16000, 44100, False), (48000, 16000, False), (8000, 12000, False)])
+def test_resample_autograd(rates):
+    """dL/dx of Resample: one more launch of the polyphase kernel with the adjoint tap table, vs autograd
+    through the reference's pad + conv1d composition (float64, CPU)."""
+    import audio_amd.transforms as T
+    from oracle import torch_cpu_ref as R
+    o, n, best = rates
+    kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=64, rolloff=0.9475937167399596,
+              beta=14.769656459379492) if best else {}
+    t = T.Resample(o, n, **kw).cuda()
+    g = torch.Generator().manual_seed(5)
+    x = (0.5 * torch.randn(2, 3, 2011, generator=g, dtype=torch.float64))
+    xr = x.clone().requires_grad_()
+    gcd = math.gcd(o, n)
+    ref = R.resample(xr, t.kernel.cpu().double(), o // gcd, n // gcd, t.width)
+    r = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (ref * r).sum().backward()
+    xg = x.float().cuda().requires_grad_()
+    y = t(xg)
+    assert y.shape == ref.shape and peak_rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
+    (y * r.float().cuda()).sum().backward()
+    assert xg.grad.shape == x.shape
+    assert peak_rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) <= 2e-5
