@@ -30,6 +30,8 @@ _DEF.define("mel_spectrogram(Tensor waveform, Tensor window, Tensor fb, int pad,
             "int win_length, float power, int norm_mode, bool center, str pad_mode) -> Tensor")
 _DEF.define("mfcc(Tensor waveform, Tensor window, Tensor fb, Tensor dct_mat, int pad, int n_fft, int hop_length, "
             "int win_length, float power, int norm_mode, bool center, str pad_mode, bool log_mels, float top_db) -> Tensor")
+_DEF.define("inverse_spectrogram(Tensor spectrogram, int? length, Tensor window, int pad, int n_fft, int hop_length, "
+            "int win_length, int norm_mode, bool center, str pad_mode, bool onesided) -> Tensor")
 _DEF.define("amplitude_to_DB(Tensor x, float multiplier, float amin, float db_multiplier, float? top_db) -> Tensor")
 _DEF.define("resample_apply(Tensor waveform, Tensor kernel, int orig_freq, int new_freq, int gcd, int width) -> Tensor")
 _DEF.define("lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, bool clamp, bool batching) -> Tensor")
@@ -57,7 +59,14 @@ def _mfcc(waveform, window, fb, dct_mat, pad, n_fft, hop_length, win_length, pow
                    pad_mode, log_mels, top_db)
 
 
+def _inverse_spectrogram(spectrogram, length, window, pad, n_fft, hop_length, win_length, norm_mode, center, pad_mode,
+                         onesided):
+    return F.inverse_spectrogram(spectrogram, length, pad, window, n_fft, hop_length, win_length, _NORM[norm_mode],
+                                 center, pad_mode, onesided)
+
+
 _CUDA.impl("spectrogram", _spectrogram)
+_CUDA.impl("inverse_spectrogram", _inverse_spectrogram)
 _CUDA.impl("mel_spectrogram", _mel_spectrogram)
 _CUDA.impl("mfcc", _mfcc)
 _CUDA.impl("amplitude_to_DB", F.amplitude_to_DB)

@@ -13,6 +13,7 @@
 #include "db_mfcc.h"
 #include "fftconv.h"
 #include "fftconv_os.h"
+#include "istft.h"
 #include "lfilter.h"
 #include "lfilter_wave.h"
 #include "melspec400.h"
@@ -308,6 +309,42 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
                                   db_multiplier, group_max,
                                   (rows_per_group < 1 ? 1 : rows_per_group) * g.n_frames * (int64_t)mb.n_mels,
                                   stream);
+}
+
+int aamd_istft_f32(const float* spec, const float* window, const float* twiddle, const float* inv_envelope,
+                   float* out, const aamd_stft_desc* desc, int32_t adjoint, void* stream) {
+  AAMD_CHECK_ARG(desc != nullptr && spec && window && twiddle && out, "null buffer");
+  AAMD_CHECK_ARG(desc->rows >= 0 && desc->length >= 0 && desc->n_frames >= 0, "negative sizes");
+  AAMD_CHECK_ARG(desc->n_fft >= 2 && desc->hop >= 1 && desc->pad >= 0, "n_fft must be >= 2, hop >= 1, pad >= 0");
+  AAMD_CHECK_ARG(desc->pad_mode >= 0 && desc->pad_mode <= 3, "bad pad_mode");
+  if (!desc->onesided) return fail(AAMD_EUNSUPPORTED, "audio_amd: inverse STFT needs a onesided spectrum");
+  if (desc->rows == 0 || desc->length == 0 || desc->n_frames == 0) return AAMD_OK;
+  OlaGeom og{};
+  StftGeom& g = og.g;
+  g.rows = desc->rows; g.length = desc->length; g.row_stride = desc->length;
+  g.n_fft = desc->n_fft; g.hop = desc->hop; g.pad = desc->pad; g.center = desc->center;
+  g.pad_mode = desc->pad_mode; g.onesided = 1; g.n_frames = desc->n_frames;
+  g.n_freq = desc->n_fft / 2 + 1;
+  g.scale = 1.0f; g.power = 0.0f;
+  g.n_stages = plan_radices(desc->n_fft, g.radix);
+  if (g.n_stages < 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft has too many prime factors");
+  og.interior = adjoint ? 0.5f : 1.0f;
+  og.scale = desc->scale * (adjoint ? 1.0f : 1.0f / (float)desc->n_fft);
+  int pb = gen_pairs_per_block(g.n_fft);
+  const int pairs_per_row = (g.n_frames + 1) / 2;
+  if (pb > pairs_per_row) pb = pairs_per_row;
+  const int bpr = (pairs_per_row + pb - 1) / pb;
+  const int64_t blocks = g.rows * bpr;
+  AAMD_CHECK_ARG(blocks < (1ll << 31), "too many frames for one launch");
+  const size_t lds = ((size_t)2 * g.n_fft + (size_t)4 * pb * gen_seq_len(g.n_fft)) * sizeof(float);
+  if (lds > dev_props().lds_per_block_optin) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft too large for the LDS");
+  auto kern = ola_kernel<float>;
+  if (lds > 48 * 1024)
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGenThreads), lds, (hipStream_t)stream, og, spec, window,
+                     reinterpret_cast<const cplx<float>*>(twiddle), inv_envelope, out, pb, bpr);
+  return launch_check();
 }
 
 int aamd_mel_scale_f32(const float* spec, const aamd_mel_bands* bands, float* out, int64_t rows,

@@ -23,7 +23,7 @@ from . import _lib
 from ._host import create_dct, melscale_fbanks  # noqa: F401  (re-exported, host-side constants)
 
 __all__ = [
-    "spectrogram", "amplitude_to_DB", "melscale_fbanks", "create_dct", "resample",
+    "spectrogram", "inverse_spectrogram", "amplitude_to_DB", "melscale_fbanks", "create_dct", "resample",
     "lfilter", "biquad", "fftconvolve", "mel_scale", "filtfilt",
     "lowpass_biquad", "highpass_biquad", "allpass_biquad", "bandpass_biquad",
     "bandreject_biquad", "equalizer_biquad", "band_biquad", "treble_biquad", "bass_biquad",
@@ -42,7 +42,7 @@ def _require_device(t: Tensor, what: str, allow_grad: bool = False) -> None:
     if t.dtype != torch.float32:
         raise TypeError(f"audio_amd: {what} must be float32 (got {t.dtype}); kernels compute in fp32.")
     if t.requires_grad and torch.is_grad_enabled() and not allow_grad:
-        raise RuntimeError("audio_amd: this op is forward-only (autograd exists for lfilter / biquad / fftconvolve / resample); "
+        raise RuntimeError("audio_amd: this op is forward-only (autograd: spectrogram family, lfilter / biquad, fftconvolve, resample); "
                            "wrap the call in torch.no_grad().")
 
 
@@ -198,7 +198,7 @@ def spectrogram(
             "`torchaudio.functional.spectrogram(power=None)` always returns a tensor with "
             "complex dtype. Please remove the argument in the function call."
         )
-    _require_device(waveform, "waveform")
+    _require_device(waveform, "waveform", allow_grad=True)
     if window.shape[0] != win_length:
         raise RuntimeError(
             f"stft: expected a 1D window tensor of size equal to win_length={win_length}, "
@@ -212,16 +212,156 @@ def spectrogram(
     n_freq = n_fft // 2 + 1 if onesided else n_fft
     lead = tuple(shape[:-1])
     T = desc.n_frames
-    comp = 2 if power is None else 1
-    out = torch.empty((desc.rows, T, n_freq * comp), dtype=torch.float32, device=waveform.device)
-    if out.numel():
-        L = _lib.lib()
-        _lib.check(L.aamd_spectrogram_f32(
-            x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, waveform.device).data_ptr(),
-            out.data_ptr(), C.byref(desc), _lib.current_stream(waveform.device)))
+    if torch.is_grad_enabled() and waveform.requires_grad:
+        if not onesided:
+            raise RuntimeError("audio_amd: autograd of the spectrogram needs onesided=True")
+        out = _SpectrogramFunction.apply(x2, _padded_window(window, n_fft), desc, power)
+    else:
+        out = _spectrogram_launch(x2, _padded_window(window, n_fft), desc, power)
     if power is None:
         out = torch.view_as_complex(out.view(desc.rows, T, n_freq, 2))
     return out.view(lead + (T, n_freq)).transpose(-1, -2)
+
+
+def _spectrogram_launch(x2: Tensor, window_padded: Tensor, desc, power) -> Tensor:
+    """Frame-major (rows, T, n_freq [* 2 for complex]) float32 through aamd_spectrogram_f32."""
+    n_freq = desc.n_fft // 2 + 1 if desc.onesided else desc.n_fft
+    comp = 2 if power is None else 1
+    out = torch.empty((desc.rows, desc.n_frames, n_freq * comp), dtype=torch.float32, device=x2.device)
+    if out.numel():
+        L = _lib.lib()
+        _lib.check(L.aamd_spectrogram_f32(
+            x2.data_ptr(), window_padded.data_ptr(), _twiddles(desc.n_fft, x2.device).data_ptr(),
+            out.data_ptr(), C.byref(desc), _lib.current_stream(x2.device)))
+    return out
+
+
+def _copy_desc(desc, **changes):
+    d = _lib.StftDesc()
+    C.memmove(C.byref(d), C.byref(desc), C.sizeof(_lib.StftDesc))
+    for k, v in changes.items():
+        setattr(d, k, v)
+    return d
+
+
+def _istft_launch(spec_fm: Tensor, window_padded: Tensor, desc, adjoint: bool, inv_env: Optional[Tensor]) -> Tensor:
+    """spec_fm: float32 (rows, T, n_freq * 2) interleaved complex -> (rows, desc.length) via aamd_istft_f32."""
+    out = torch.zeros((desc.rows, desc.length), dtype=torch.float32, device=spec_fm.device)
+    if out.numel() and desc.n_frames:
+        L = _lib.lib()
+        _lib.check(L.aamd_istft_f32(
+            spec_fm.data_ptr(), window_padded.data_ptr(), _twiddles(desc.n_fft, spec_fm.device).data_ptr(),
+            None if inv_env is None else inv_env.data_ptr(), out.data_ptr(), C.byref(desc), int(adjoint),
+            _lib.current_stream(spec_fm.device)))
+    return out
+
+
+class _SpectrogramFunction(torch.autograd.Function):
+    """d/d waveform of the (onesided) spectrogram on the HIP kernels.  Backward recomputes the complex STFT
+    X (fast kernel), forms G = dL/dRe Y + i dL/dIm Y for complex output or G = dY p |X|^(p-2) X for
+    |X|^p, and runs the ADJOINT of the STFT (aamd_istft_f32, adjoint = 1): inverse FFT of every frame,
+    window, overlap-add with the forward's padding map reversed.  The window is a constant (as in the
+    reference's autograd tests, test/torchaudio_unittest/transforms/autograd_test_impl.py)."""
+
+    @staticmethod
+    def forward(ctx, x2, window_padded, desc, power):
+        ctx.save_for_backward(x2, window_padded)
+        ctx.desc, ctx.power = desc, power
+        return _spectrogram_launch(x2, window_padded, desc, power)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, window_padded = ctx.saved_tensors
+        desc, power = ctx.desc, ctx.power
+        n_freq = desc.n_fft // 2 + 1
+        dy = dy.contiguous()
+        if power is None:
+            G = dy                                             # (rows, T, n_freq * 2): dL/dRe, dL/dIm interleaved
+        else:
+            dX = _copy_desc(desc, power=0.0)
+            Xc = torch.view_as_complex(_spectrogram_launch(x2, window_padded, dX, None).view(desc.rows, -1, n_freq, 2))
+            if power == 2.0:
+                Gc = (2.0 * dy) * Xc
+            else:
+                mag = Xc.abs()
+                fac = torch.where(mag > 0, float(power) * mag.pow(power - 2.0), torch.zeros_like(mag))
+                Gc = (dy * fac) * Xc
+            G = torch.view_as_real(Gc.contiguous()).view(desc.rows, -1, 2 * n_freq)
+        dA = _copy_desc(desc)                                  # same geometry, scale and padding map
+        dx = _istft_launch(G.contiguous(), window_padded, dA, True, None)
+        return dx, None, None, None
+
+
+def inverse_spectrogram(
+    spectrogram: Tensor,
+    length: Optional[int],
+    pad: int,
+    window: Tensor,
+    n_fft: int,
+    hop_length: int,
+    win_length: int,
+    normalized: Union[bool, str],
+    center: bool = True,
+    pad_mode: str = "reflect",
+    onesided: bool = True,
+) -> Tensor:
+    r"""Least-squares inverse of the spectrogram (reference: functional/functional.py:148-225 ->
+    ``torch.istft``): inverse FFT of every frame, window, overlap-add, divided by the window envelope
+    ``sum_t w^2``, trimmed to the centre -- one HIP kernel (csrc/istft.h) plus the cached envelope."""
+    frame_length_norm, window_norm = _get_spec_norms(normalized)
+    if not spectrogram.is_complex():
+        raise ValueError("Expected `spectrogram` to be complex dtype.")
+    if not spectrogram.is_cuda:
+        raise RuntimeError(f"audio_amd: spectrogram must be on an MI355X (ROCm) device, got {spectrogram.device}. "
+                           "The HIP kernels have no CPU fallback.")
+    if spectrogram.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("audio_amd: inverse_spectrogram is forward-only; wrap the call in torch.no_grad().")
+    if not onesided:
+        raise NotImplementedError("audio_amd: inverse_spectrogram needs onesided=True")
+    dev = spectrogram.device
+    window = window.to(device=dev, dtype=torch.float32)
+    wp = _padded_window(window, n_fft)
+    shape = spectrogram.size()
+    n_freq, T = shape[-2], shape[-1]
+    if n_freq != n_fft // 2 + 1:
+        raise RuntimeError(f"istft: expected the frequency dimension of the input to be n_fft / 2 + 1 = "
+                           f"{n_fft // 2 + 1}, but got {n_freq}")
+    fm = spectrogram.to(torch.complex64).transpose(-1, -2).reshape(-1, T, n_freq)
+    if not fm.is_contiguous():
+        fm = fm.contiguous()
+    rows = fm.shape[0]
+    expected = n_fft + hop_length * (T - 1)
+    start = n_fft // 2 if center else 0
+    if length is not None:
+        out_len = length + 2 * pad
+    else:
+        out_len = expected - 2 * start
+    scale = 1.0
+    if window_norm:
+        scale *= _tensor_cached(window, "l2norm", lambda: float(window.pow(2.0).sum().sqrt()))
+    if frame_length_norm:
+        scale *= math.sqrt(n_fft)
+
+    def make_env():
+        w2 = wp.double().pow(2).view(1, 1, n_fft)
+        env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, T, dtype=torch.float64, device=dev), w2,
+                                                   stride=hop_length).view(-1)
+        env = env[start:start + out_len]
+        if env.numel() < out_len:
+            env = torch.nn.functional.pad(env, (0, out_len - env.numel()), value=1.0)
+        # torch.istft checks the envelope over the span the frames cover (NOLA)
+        covered = env[: max(min(out_len, expected - start), 0)]
+        if covered.numel() and float(covered.abs().min()) < 1e-11:
+            raise RuntimeError("istft(...) window overlap add min: 1")
+        return (1.0 / env).to(torch.float32).contiguous()
+
+    inv_env = _tensor_cached(window, ("istft_env", n_fft, hop_length, T, out_len, center), make_env)
+    desc = _lib.StftDesc(rows, out_len, out_len, n_fft, hop_length, 0, int(center), _lib.PAD_MODES["constant"], 1, T,
+                         scale, 0.0)
+    out = _istft_launch(torch.view_as_real(fm).view(rows, T, 2 * n_freq), wp, desc, False, inv_env)
+    if length is not None and pad > 0:
+        out = out[:, pad:-pad]
+    return out.reshape(tuple(shape[:-2]) + out.shape[-1:])
 
 
 def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_fft: int, hop_length: int,

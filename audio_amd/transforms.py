@@ -66,6 +66,40 @@ class Spectrogram(torch.nn.Module):
                              self.power, self.normalized, self.center, self.pad_mode, self.onesided)
 
 
+class InverseSpectrogram(torch.nn.Module):
+    r"""Least-squares inverse of a complex spectrogram (reference: _transforms.py:126-208)."""
+    __constants__ = ["n_fft", "win_length", "hop_length", "pad", "power", "normalized"]
+
+    def __init__(
+        self,
+        n_fft: int = 400,
+        win_length: Optional[int] = None,
+        hop_length: Optional[int] = None,
+        pad: int = 0,
+        window_fn: Callable[..., Tensor] = torch.hann_window,
+        normalized: Union[bool, str] = False,
+        wkwargs: Optional[dict] = None,
+        center: bool = True,
+        pad_mode: str = "reflect",
+        onesided: bool = True,
+    ) -> None:
+        super().__init__()
+        self.n_fft = n_fft
+        self.win_length = win_length if win_length is not None else n_fft
+        self.hop_length = hop_length if hop_length is not None else self.win_length // 2
+        window = window_fn(self.win_length) if wkwargs is None else window_fn(self.win_length, **wkwargs)
+        self.register_buffer("window", window)
+        self.pad = pad
+        self.normalized = normalized
+        self.center = center
+        self.pad_mode = pad_mode
+        self.onesided = onesided
+
+    def forward(self, spectrogram: Tensor, length: Optional[int] = None) -> Tensor:
+        return F.inverse_spectrogram(spectrogram, length, self.pad, self.window, self.n_fft, self.hop_length,
+                                     self.win_length, self.normalized, self.center, self.pad_mode, self.onesided)
+
+
 class AmplitudeToDB(torch.nn.Module):
     r"""Power/amplitude -> dB (reference: _transforms.py:300-346)."""
     __constants__ = ["multiplier", "amin", "ref_value", "db_multiplier"]
@@ -171,6 +205,12 @@ class MelSpectrogram(torch.nn.Module):
                                  sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode, db=db)
 
     def forward(self, waveform: Tensor) -> Tensor:
+        if torch.is_grad_enabled() and waveform.requires_grad:
+            # differentiable path: spectrogram with its HIP adjoint, then the reference's own filterbank
+            # product (transforms/_transforms.py:403-415) so that autograd sees it
+            spec = self.spectrogram(waveform)
+            fb = self.mel_scale.fb.to(spec.device)
+            return torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
         out = self._frame_major(waveform)                       # (rows, T, n_mels)
         lead = tuple(waveform.shape[:-1])
         return out.view(lead + out.shape[-2:]).transpose(-1, -2)
@@ -212,6 +252,22 @@ class MFCC(torch.nn.Module):
         self.group_max_hook: Optional[Callable[[Tensor], None]] = None
 
     def forward(self, waveform: Tensor) -> Tensor:
+        if torch.is_grad_enabled() and waveform.requires_grad:
+            # differentiable path (reference composition, _transforms.py:692-709, on top of the
+            # differentiable mel spectrogram): the dB / top_db / DCT tail is cheap and torch's autograd
+            # reproduces the reference's sub-gradients (clamp, amax) exactly
+            mel = self.MelSpectrogram(waveform)
+            if self.log_mels:
+                mel = torch.log(mel + 1e-6)
+            else:
+                a = self.amplitude_to_DB
+                x_db = a.multiplier * torch.log10(torch.clamp(mel, min=a.amin)) - a.multiplier * a.db_multiplier
+                shp = x_db.size()
+                packed = shp[-3] if x_db.dim() > 2 else 1
+                x_db = x_db.reshape(-1, packed, shp[-2], shp[-1])
+                x_db = torch.max(x_db, (x_db.amax(dim=(-3, -2, -1)) - self.top_db).view(-1, 1, 1, 1))
+                mel = x_db.reshape(shp)
+            return torch.matmul(mel.transpose(-1, -2), self.dct_mat.to(mel.device)).transpose(-1, -2)
         sp = self.MelSpectrogram.spectrogram
         a2db = self.amplitude_to_DB
         return F._mfcc(waveform, sp.pad, sp.window, self.MelSpectrogram.mel_scale.fb, self.dct_mat, sp.n_fft,

@@ -22,6 +22,8 @@
  *                             Spectrogram.forward + MelScale.forward :403-415)
  *   aamd_melspectrogram_db_f32  ... + F.amplitude_to_DB and its top_db group maximum fused
  *                             (first half of MFCC.forward, _transforms.py:692-706)
+ *   aamd_istft_f32            functional/functional.py:148-225 (F.inverse_spectrogram -> torch.istft) and the
+ *                             adjoint of the STFT for autograd of the STFT family
  *   aamd_mel_scale_f32        transforms/_transforms.py:403-415 (MelScale.forward on a
  *                             caller-supplied spectrogram)
  *   aamd_amplitude_to_db_f32  functional/functional.py:356-404 (F.amplitude_to_DB)
@@ -126,6 +128,20 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
                                const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
                                float multiplier, float amin, float db_multiplier, float* group_max,
                                int64_t rows_per_group, void* stream);
+
+/* Frames -> waveform (overlap-add).  spec: interleaved complex float[rows][n_frames][n_fft/2+1][2] (frame-major,
+ * onesided); window / twiddle as for aamd_spectrogram_f32; out: float[rows][length], MUST be zero-filled by the
+ * caller (contributions are accumulated with atomic adds).  desc->length = output samples per row; frame t
+ * covers padded-axis samples t*hop .. t*hop+n_fft-1, which map to output samples exactly as the forward's
+ * padding does (centre offset n_fft/2, pad_mode, desc->pad); samples that map nowhere are dropped.
+ *   adjoint == 0: torch.istft's numerator (functional/functional.py:205-216): out += scale/n_fft * w[n] * irfft-sum;
+ *                 pass pad_mode = AAMD_PAD_CONSTANT (centre trimming) and inv_envelope[length] = 1 / sum_t w^2
+ *                 to get the least-squares inverse, or NULL for the bare overlap-add.
+ *   adjoint != 0: the adjoint of the onesided STFT (autograd of Spectrogram & co.):
+ *                 out[i] += scale * w[n] * Re sum_{k=0}^{n_fft/2} spec[t][k] e^{+2 pi i n k / n_fft}
+ *                 with the forward's pad_mode, so reflected / replicated edges fold back onto the samples they copied. */
+int aamd_istft_f32(const float* spec, const float* window, const float* twiddle, const float* inv_envelope,
+                   float* out, const aamd_stft_desc* desc, int32_t adjoint, void* stream);
 
 /* MelScale.forward on an existing spectrogram given frame-major: spec float[rows][n_frames][n_freq]
  * -> out float[rows][n_frames][n_mels]. */

@@ -12,6 +12,7 @@
 #include "../../audio_amd/csrc/db_mfcc.h"
 #include "../../audio_amd/csrc/fftconv.h"
 #include "../../audio_amd/csrc/fftconv_os.h"
+#include "../../audio_amd/csrc/istft.h"
 #include "../../audio_amd/csrc/lfilter.h"
 #include "../../audio_amd/csrc/lfilter_wave.h"
 #include "../../audio_amd/csrc/melspec400.h"
@@ -65,6 +66,48 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
       } else {
         for (int tid = 0; tid < nthr; ++tid) gen_power_rows<float>(tid, nthr, g, x, pb, P.data());
         for (int tid = 0; tid < nthr; ++tid) gen_mel<float>(tid, nthr, g, mb, P.data(), pb, t0, out_row);
+      }
+    }
+  return 0;
+}
+
+// Replay of ola_kernel (inverse STFT / STFT adjoint): same launcher logic as aamd_istft_f32.
+int sim_istft(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,
+              const aamd_stft_desc* d, int adjoint) {
+  OlaGeom og{};
+  fill_geom(d, og.g);
+  StftGeom& g = og.g;
+  g.onesided = 1; g.n_freq = g.n_fft / 2 + 1; g.row_stride = g.length;
+  if (g.n_stages < 0) return -1;
+  og.interior = adjoint ? 0.5f : 1.0f;
+  og.scale = d->scale * (adjoint ? 1.0f : 1.0f / (float)d->n_fft);
+  const int nthr = kGenThreads, N = g.n_fft, SL = gen_seq_len(N);
+  int pb = gen_pairs_per_block(N);
+  const int pairs_per_row = (g.n_frames + 1) / 2;
+  if (pb > pairs_per_row) pb = pairs_per_row;
+  const int bpr = (pairs_per_row + pb - 1) / pb;
+  std::vector<cplx<float>> A((size_t)pb * SL), B((size_t)pb * SL);
+  const cplx<float>* twc = reinterpret_cast<const cplx<float>*>(tw);
+  for (int64_t row = 0; row < g.rows; ++row)
+    for (int chunk = 0; chunk < bpr; ++chunk) {
+      const int64_t t0 = (int64_t)chunk * 2 * pb;
+      for (int tid = 0; tid < nthr; ++tid)
+        ola_load<float>(tid, nthr, og, spec + row * g.n_frames * 2 * (int64_t)g.n_freq, t0, pb, A.data());
+      cplx<float>* x = A.data(); cplx<float>* y = B.data();
+      int s = 1;
+      for (int st = 0; st < g.n_stages; ++st) {
+        for (int tid = 0; tid < nthr; ++tid) gen_stage<float>(tid, nthr, N, g.radix[st], s, pb, x, y, twc);
+        s *= g.radix[st];
+        std::swap(x, y);
+      }
+      int64_t nf = g.n_frames - t0; if (nf > 2 * pb) nf = 2 * pb;
+      const int span = (int)(nf - 1) * g.hop + N;
+      for (int j = 0; j < span; ++j) {
+        const int64_t i = ola_target(g, t0 * g.hop + j);
+        if (i < 0) continue;
+        float v = ola_gather<float>(og, x, window, pb, j);
+        if (inv_env) v *= inv_env[i];
+        out[row * g.length + i] += v;
       }
     }
   return 0;

@@ -369,3 +369,26 @@ def test_sim_spec400_complex_epilogue(hop, L):
     exp = O.spectrogram(x.astype(np.float64), 0, w.astype(np.float64), 400, hop, 400, None, False)
     assert got.shape == exp.shape
     assert np.abs(got - exp).max() / np.abs(exp).max() <= TOL
+
+
+@pytest.mark.parametrize("n_fft,hop,L", [(400, 160, 3000), (512, 128, 2500), (200, 50, 1111), (96, 33, 700)])
+def test_sim_istft_roundtrip_and_adjoint(n_fft, hop, L):
+    """ola_kernel: (1) STFT -> inverse STFT with the window envelope reproduces the waveform (torch.istft's
+    least-squares inverse); (2) adjoint mode satisfies <STFT x, G> = <x, STFT^T G> with reflect padding."""
+    rng = np.random.default_rng(n_fft + hop)
+    x = rng.standard_normal((2, L))
+    w = O.hann_window(n_fft)
+    X = O.stft(x, w, n_fft, hop)                                   # (2, n_freq, T) complex128
+    Xfm = np.swapaxes(X, -1, -2)
+    T = Xfm.shape[1]
+    env = np.zeros(L + n_fft)
+    for t in range(T):
+        env[t * hop: t * hop + n_fft] += w ** 2
+    env = env[n_fft // 2: n_fft // 2 + L]
+    got = S.sim_istft(Xfm, w, L, n_fft, hop, inv_env=1.0 / env)
+    assert np.abs(got - x).max() <= 2e-5 * np.abs(x).max() * 10
+    G = rng.standard_normal(Xfm.shape) + 1j * rng.standard_normal(Xfm.shape)
+    dx = S.sim_istft(G, w, L, n_fft, hop, pad_mode="reflect", adjoint=True)
+    lhs = np.real(np.sum(Xfm * np.conj(G)))                         # <STFT x, G> as a real inner product
+    rhs = np.sum(x * dx)
+    assert abs(lhs - rhs) <= 2e-5 * abs(lhs)

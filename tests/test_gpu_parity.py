@@ -558,7 +558,7 @@ def test_lfilter_autograd_vs_reference_gradients(name):
     # forward-only ops still refuse tensors that require grad
     import audio_amd.transforms as T
     with pytest.raises(RuntimeError, match="forward-only"):
-        T.Spectrogram(n_fft=64)(x.reshape(-1, x.shape[-1]))
+        T.AmplitudeToDB()(x.reshape(-1, x.shape[-1]).abs())
 
 
 @pytest.mark.parametrize("shapes,mode", [(((3, 700), (3, 90)), "full"), (((2, 2, 5000), (1, 1, 400)), "same"),
@@ -613,3 +613,152 @@ def test_resample_autograd(rates):
     (y * r.float().cuda()).sum().backward()
     assert xg.grad.shape == x.shape
     assert peak_rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) <= 2e-5
+
+
+def _ref_spectrogram(x, window, n_fft, hop, pad, power, normalized, center, pad_mode):
+    """The reference composition (functional/functional.py:123-145) in float64 on the CPU, differentiable."""
+    if pad > 0:
+        x = torch.nn.functional.pad(x, (pad, pad), "constant")
+    shape = x.shape
+    X = torch.stft(x.reshape(-1, shape[-1]), n_fft, hop, window.shape[0], window, center, pad_mode, False, True,
+                   return_complex=True)
+    X = X.reshape(shape[:-1] + X.shape[-2:])
+    if normalized == "window" or normalized is True:
+        X = X / window.pow(2.0).sum().sqrt()
+    elif normalized == "frame_length":
+        X = X / math.sqrt(n_fft)
+    if power is None:
+        return X
+    return X.abs().pow(2.0) if power == 2.0 else X.abs().pow(power)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_fft=400, hop=160, L=4000, power=2.0),                                    # radix-20x20 fast path
+    dict(n_fft=400, hop=160, L=4000, power=1.0),
+    dict(n_fft=400, hop=200, L=3001, power=None),
+    dict(n_fft=512, hop=128, L=3000, power=2.0, pad_mode="constant"),
+    dict(n_fft=256, hop=64, L=2000, power=2.0, center=False, normalized="window"),
+    dict(n_fft=200, hop=50, L=1777, power=1.0, pad=37, normalized="frame_length"),
+    dict(n_fft=97, hop=31, L=1500, power=2.0, pad_mode="replicate"),
+    dict(n_fft=128, hop=32, win_length=100, L=1500, power=3.0, pad_mode="circular"),
+    dict(n_fft=2048, hop=512, L=9000, power=None),
+    dict(n_fft=64, hop=16, L=700, power=2.0, lead=(2, 3)),
+])
+def test_spectrogram_autograd(cfg):
+    """dL/dwaveform of Spectrogram: backward = complex STFT recompute + the adjoint overlap-add kernel
+    (csrc/istft.h, adjoint = 1), vs torch autograd through torch.stft in float64 on the CPU."""
+    import audio_amd.transforms as T
+    n_fft, hop, L, power = cfg["n_fft"], cfg["hop"], cfg["L"], cfg["power"]
+    win_length = cfg.get("win_length", n_fft)
+    kw = dict(pad=cfg.get("pad", 0), normalized=cfg.get("normalized", False), center=cfg.get("center", True),
+              pad_mode=cfg.get("pad_mode", "reflect"))
+    g = torch.Generator().manual_seed(n_fft * 7 + hop)
+    lead = cfg.get("lead", (3,))
+    x = 0.5 * torch.randn(*lead, L, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_()
+    w = torch.hann_window(win_length, dtype=torch.float64)
+    ref = _ref_spectrogram(xr, w, n_fft, hop, kw["pad"], power, kw["normalized"], kw["center"], kw["pad_mode"])
+    r = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    if power is None:
+        r = torch.complex(r, torch.randn(ref.shape, generator=g, dtype=torch.float64))
+        (ref * r.conj()).real.sum().backward()
+    else:
+        (ref * r).sum().backward()
+    t = T.Spectrogram(n_fft=n_fft, hop_length=hop, win_length=win_length, power=power, **kw).cuda()
+    xg = x.float().cuda().requires_grad_()
+    y = t(xg)
+    assert y.shape == ref.shape and y.stride() == t(xg.detach()).stride()
+    if power is None:
+        assert peak_rel_err(torch.view_as_real(y.detach()).cpu().numpy(), torch.view_as_real(ref.detach()).numpy()) <= 1e-5
+        (y * r.to(torch.complex64).cuda().conj()).real.sum().backward()
+    else:
+        assert peak_rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-5
+        (y * r.float().cuda()).sum().backward()
+    assert xg.grad.shape == x.shape
+    assert peak_rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) <= 2e-5
+
+
+@pytest.mark.parametrize("which", ["mel", "mfcc", "mfcc_log", "mel_generic"])
+def test_mel_and_mfcc_autograd(which):
+    """Gradients of MelSpectrogram / MFCC w.r.t. the waveform (HIP spectrogram + adjoint, torch tail) vs torch
+    autograd through the reference composition in float64 on the CPU."""
+    import audio_amd.transforms as T
+    from oracle import torch_cpu_ref as R
+    g = torch.Generator().manual_seed(77)
+    x = 0.5 * torch.randn(2, 2, 4800, generator=g, dtype=torch.float64)
+    xr = x.clone().requires_grad_()
+    n_fft, hop = (400, 160) if which != "mel_generic" else (512, 200)
+    if which.startswith("mel"):
+        t = T.MelSpectrogram(sample_rate=16000, n_fft=n_fft, hop_length=hop, n_mels=80).cuda()
+        ref = R.mel_spectrogram(xr, torch.hann_window(n_fft, dtype=torch.float64), t.mel_scale.fb.cpu().double(), n_fft, hop)
+    else:
+        t = T.MFCC(sample_rate=16000, n_mfcc=40, log_mels=(which == "mfcc_log"),
+                   melkwargs=dict(n_fft=n_fft, hop_length=hop, n_mels=80)).cuda()
+        fb, dct = t.MelSpectrogram.mel_scale.fb.cpu().double(), t.dct_mat.cpu().double()
+        if which == "mfcc_log":
+            mel = R.mel_spectrogram(xr, torch.hann_window(n_fft, dtype=torch.float64), fb, n_fft, hop)
+            ref = torch.matmul(torch.log(mel + 1e-6).transpose(-1, -2), dct).transpose(-1, -2)
+        else:
+            ref = R.mfcc(xr, torch.hann_window(n_fft, dtype=torch.float64), fb, dct, n_fft, hop)
+    r = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (ref * r).sum().backward()
+    xg = x.float().cuda().requires_grad_()
+    y = t(xg)
+    assert y.shape == ref.shape
+    assert peak_rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-4
+    with torch.no_grad():
+        assert peak_rel_err(y.detach().cpu().numpy(), t(xg.detach()).cpu().numpy()) <= 1e-5     # fused path agrees
+    (y * r.float().cuda()).sum().backward()
+    assert peak_rel_err(xg.grad.cpu().numpy(), xr.grad.numpy()) <= 1e-4
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_fft=400, hop=160, L=4000),
+    dict(n_fft=400, hop=160, L=4000, length=3900),
+    dict(n_fft=512, hop=128, L=5000, normalized="window"),
+    dict(n_fft=256, hop=64, L=3000, normalized="frame_length", length=3000, pad=20),
+    dict(n_fft=200, hop=50, win_length=160, L=2222, lead=(2, 2)),
+    dict(n_fft=97, hop=24, L=1500),
+    dict(n_fft=2048, hop=512, L=20000, length=20000),
+    dict(n_fft=128, hop=32, L=1000, center=False),
+])
+def test_inverse_spectrogram_vs_torch_istft(cfg):
+    """InverseSpectrogram (inverse FFT + window + overlap-add + envelope division in one HIP kernel) against
+    torch.istft in float64 on the CPU (what functional/functional.py:148-225 calls), and the round trip."""
+    import audio_amd.transforms as T
+    n_fft, hop, L = cfg["n_fft"], cfg["hop"], cfg["L"]
+    win_length = cfg.get("win_length", n_fft)
+    normalized, center = cfg.get("normalized", False), cfg.get("center", True)
+    length, pad = cfg.get("length"), cfg.get("pad", 0)
+    g = torch.Generator().manual_seed(n_fft + hop)
+    x = 0.5 * torch.randn(*cfg.get("lead", (3,)), L, generator=g, dtype=torch.float64)
+    w = torch.hann_window(win_length, dtype=torch.float64)
+    if not center:
+        w = w + 0.1                                   # torch.istft needs a nonzero envelope at the edges
+    X = _ref_spectrogram(x, w, n_fft, hop, pad, None, normalized, center, "reflect")
+    Xs = X
+    if normalized == "window":
+        Xs = X * w.pow(2.0).sum().sqrt()
+    elif normalized == "frame_length":
+        Xs = X * math.sqrt(n_fft)
+    shape = Xs.shape
+    ref = torch.istft(Xs.reshape(-1, shape[-2], shape[-1]), n_fft, hop, win_length, w, center, False, True,
+                      length + 2 * pad if length is not None else None, False)
+    if length is not None and pad > 0:
+        ref = ref[:, pad:-pad]
+    ref = ref.reshape(shape[:-2] + ref.shape[-1:])
+    wfn = (lambda n: torch.hann_window(n)) if center else (lambda n: torch.hann_window(n) + 0.1)
+    t = T.InverseSpectrogram(n_fft=n_fft, hop_length=hop, win_length=win_length, normalized=normalized, center=center,
+                             pad=pad, window_fn=wfn).cuda()
+    got = t(X.to(torch.complex64).cuda(), length)
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    assert peak_rel_err(got.cpu().numpy(), ref.numpy()) <= 1e-5
+    # round trip through this repo's own Spectrogram (power=None)
+    s = T.Spectrogram(n_fft=n_fft, hop_length=hop, win_length=win_length, power=None, normalized=normalized,
+                      center=center, pad=pad, window_fn=wfn).cuda()
+    xb = x.float().cuda()
+    back = t(s(xb), L)
+    frames = X.shape[-1]
+    covered = n_fft + hop * (frames - 1) - (2 * (n_fft // 2) if center else 0) - 2 * pad
+    n = min(back.shape[-1], L, covered)
+    assert peak_rel_err(back[..., :n].cpu().numpy(), x[..., :n].numpy()) <= 1e-5

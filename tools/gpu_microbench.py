@@ -133,6 +133,47 @@ def main():
             os.environ["AAMD_FORCE_GENERIC"] = "1"
             print(f"  same, time-domain kernel: {timeit(lambda: F.fftconvolve(x1, y1), 1, 3):9.1f} us")
             del os.environ["AAMD_FORCE_GENERIC"]
+    if "istft" in what:
+        x = (0.5 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
+        with torch.no_grad():
+            sp = T.Spectrogram(n_fft=400, hop_length=160, power=None).to(dev)
+            inv = T.InverseSpectrogram(n_fft=400, hop_length=160).to(dev)
+            X = sp(x)
+            us = timeit(lambda: inv(X, 160000), 3, 20)
+            by = X.numel() * 8 + x.numel() * 4
+            print(f"InverseSpectrogram 256x10s n_fft=400 hop=160: {us:9.1f} us  algorithmic {by / us / 1e3:.0f} GB/s "
+                  f"(frac {by / us / 1e3 / 8000:.3f})")
+            sp2 = T.Spectrogram(n_fft=1024, hop_length=256, power=None).to(dev)
+            inv2 = T.InverseSpectrogram(n_fft=1024, hop_length=256).to(dev)
+            X2 = sp2(x)
+            us = timeit(lambda: inv2(X2, 160000), 3, 20)
+            by = X2.numel() * 8 + x.numel() * 4
+            print(f"InverseSpectrogram 256x10s n_fft=1024 hop=256: {us:9.1f} us  algorithmic {by / us / 1e3:.0f} GB/s")
+        mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).to(dev)
+        xg = x.clone().requires_grad_()
+        r = torch.randn(256, 80, 1001, device=dev)
+
+        def fwd_bwd():
+            xg.grad = None
+            (mel(xg) * r).sum().backward()
+        us = timeit(fwd_bwd, 3, 20)
+        print(f"MelSpectrogram fwd+bwd 256x10s (HIP spectrogram + adjoint, torch tail): {us:9.1f} us")
+        mt = mel_torch_composition(mel)
+
+        def fwd_bwd_t():
+            xg.grad = None
+            (mt(xg) * r).sum().backward()
+        us = timeit(fwd_bwd_t, 3, 20)
+        print(f"  same through torch.stft (ATen/rocFFT) autograd:                    {us:9.1f} us")
+
+
+def mel_torch_composition(mel):
+    w, fb = mel.spectrogram.window, mel.mel_scale.fb
+
+    def f(x):
+        X = torch.stft(x, 400, 160, 400, w, True, "reflect", False, True, return_complex=True)
+        return torch.matmul(X.abs().pow(2.0).transpose(-1, -2), fb).transpose(-1, -2)
+    return f
 
 
 if __name__ == "__main__":
