@@ -634,9 +634,8 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
     const int64_t items = rows * g.n_pairs;
     int64_t blocks = dev_props().cu_count;
     if (blocks > items) blocks = items;
-    for (int p = 0; p < g.n_part; ++p)
-      hipLaunchKernelGGL(fco::overlap_save_kernel, dim3((unsigned)blocks), dim3(fco::kThreads), lds, s, g, p, xa, tw,
-                         H, xmap, ymap, out);
+    hipLaunchKernelGGL(fco::overlap_save_kernel, dim3((unsigned)blocks), dim3(fco::kPhys), lds, s, g, xa, tw, H,
+                       xmap, ymap, out);
     return launch_check();
   }
   FcGeom g;

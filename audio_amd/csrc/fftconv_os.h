@@ -14,10 +14,19 @@
 //     output natural): no reordering pass at all; the last forward radix-4 pass, the product and the first
 //     inverse pass are fused in registers;
 //   * a block of N = V + Pt - 1 inputs yields V valid outputs (first Pt - 1 wrap around and are dropped);
-//     partitions p > 0 accumulate into the output in stream order;
+//     the partitions of one output block pair are accumulated IN THE FREQUENCY DOMAIN, in registers
+//     (16 complex per thread, at the positions the fused middle step owns): n_part forward FFTs, one
+//     inverse FFT and one plain store per output pair -- no read-modify-write of the output;
+//   * the first forward pass takes its 16 inputs per thread straight from global memory and the last
+//     inverse pass stores its 16 outputs straight to global memory (thread tid owns elements
+//     tid + 1024 t in both), so neither the input nor the output is staged through LDS; the loads of the
+//     next partition are issued before the middle step of the current one;
 //   * LDS index padding (4 complex per 64) keeps every pass' b64 accesses on distinct banks.
-// Twiddles: W_N^m table (fp64-computed on device by a tiny kernel) at the head of the workspace; a
-// butterfly loads w^1, w^2, w^4, w^8 and forms the other powers with <= 2 chained products.
+// Twiddles: W_N^m table (fp64-computed on device by a tiny kernel) at the head of the workspace.  Gathering
+// W^e per lane from that 128 KB table costs one cache line per lane (it was the bottleneck of every pass), so
+// each workgroup keeps a two-level copy in LDS -- W^(128 a), a < 128 and W^b, b < 128 (2 KB) -- and forms
+// W^e = W^(128 (e >> 7)) W^(e & 127); a butterfly looks up w^1, w^2, w^4, w^8 that way and forms the other
+// powers with <= 2 chained products.
 #pragma once
 #include "hd.h"
 
@@ -27,7 +36,10 @@ namespace fco {
 constexpr int kN = 16384;                 // complex FFT length = real samples per block
 constexpr int kThreads = 1024;
 constexpr int kPerThread = kN / kThreads; // 16
-constexpr int kLdsComplex = kN + (kN >> 6) * 4;   // padded: 17408 complex = 139 264 B
+constexpr int kLdsData = kN + (kN >> 6) * 4;      // padded: 17408 complex = 139 264 B
+constexpr int kTwB = 256;                         // tl + kTwB: W_1024^(j k) table of pass B, [k - 1][j], j < 64
+constexpr int kTwC = kTwB + 15 * 64;              // tl + kTwC: W_64^(j k) table of pass C, [k - 1][j], j < 4
+constexpr int kLdsComplex = kLdsData + kTwC + 15 * 4;   // data + twiddle tables = 149 632 B
 constexpr int kMaxPartTaps = 8192;
 
 using C32 = cplx<float>;
@@ -105,12 +117,28 @@ AAMD_HD int opaque(int v) {
   return v;
 }
 
-// powers w^1..w^15 of w = W_N^e from the table (e * 15 < N): 4 loads + 11 products of depth <= 2
-AAMD_HD void twiddle_powers(const C32* tw, int e, C32 (&p)[16]) {
-  p[1] = tw[e]; p[2] = tw[2 * e]; p[4] = tw[4 * e]; p[8] = tw[8 * e];
+// two-level twiddle tables in LDS: tl[a] = W^(128 a), tl[128 + b] = W^b
+// ... and the complete twiddles of the two inner passes: tl[kTwB + (k-1) 64 + j] = W_1024^(j k) = W_N^(16 j k),
+// tl[kTwC + (k-1) 4 + j] = W_64^(j k) = W_N^(256 j k)   (call with tid = 0 .. 1023 once per workgroup)
+AAMD_HD void twiddle_tables(int tid, const C32* tw, C32* tl) {
+  if (tid < 128) tl[tid] = tw[128 * tid];
+  else if (tid < 256) tl[tid] = tw[tid - 128];
+  if (tid < 15 * 64) { const int k = tid / 64 + 1, j = tid % 64; tl[kTwB + tid] = tw[16 * j * k]; }
+  else if (tid < 15 * 64 + 60) { const int u = tid - 15 * 64, k = u / 4 + 1, j = u % 4; tl[kTwC + u] = tw[256 * j * k]; }
+}
+AAMD_HD C32 tw_at(const C32* tl, int e) { return cmul(tl[e >> 7], tl[128 + (e & 127)]); }
+
+// v[k] *= w^k (or conj) for k = 1..15, w = W_N^e (8 e < N): 4 look-ups, 11 products of depth <= 2.  Written
+// low-to-high so that only w^1..w^8 are ever live next to v.
+template <bool conj_w>
+AAMD_HD void mul_twiddles(C32 (&v)[16], const C32* tl, int e) {
+  C32 p[9];
+  p[1] = tw_at(tl, e); p[2] = tw_at(tl, 2 * e); p[4] = tw_at(tl, 4 * e); p[8] = tw_at(tl, 8 * e);
   p[3] = cmul(p[1], p[2]); p[5] = cmul(p[4], p[1]); p[6] = cmul(p[4], p[2]); p[7] = cmul(p[4], p[3]);
-  p[9] = cmul(p[8], p[1]); p[10] = cmul(p[8], p[2]); p[11] = cmul(p[8], p[3]); p[12] = cmul(p[8], p[4]);
-  p[13] = cmul(p[8], p[5]); p[14] = cmul(p[8], p[6]); p[15] = cmul(p[8], p[7]);
+#pragma unroll
+  for (int k = 1; k <= 8; ++k) v[k] = cmulc<conj_w>(v[k], p[k]);
+#pragma unroll
+  for (int k = 1; k <= 7; ++k) v[8 + k] = cmulc<conj_w>(v[8 + k], cmul(p[8], p[k]));
 }
 
 // One radix-16 pass on sub-transforms of length LC (LC = 16384, 1024, 64), thread `tid` owns
@@ -125,45 +153,45 @@ AAMD_HD void pass16(int tid, C32* lds, const C32* tw) {
   C32 v[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t) v[t] = lds[pad_idx(base + t * m)];
-  C32 p[16];
-  if (m > 1) twiddle_powers(tw, opaque(j * (kN / LC)), p);
-  if (inv && m > 1) {
+  // inner passes read their 15 twiddles from the LDS tables (no products to form the powers)
+  const C32* tab = tw + (LC == 1024 ? kTwB : kTwC) + opaque(j);
+  if (inv && (LC == 1024 || LC == 64)) {
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[k] = cmulc<true>(v[k], p[k]);
+    for (int k = 1; k < 16; ++k) v[k] = cmulc<true>(v[k], tab[(k - 1) * m]);
+  } else if (inv && m > 1) {
+    mul_twiddles<true>(v, tw, opaque(j * (kN / LC)));
   }
   dft16<inv>(v);
-  if (!inv && m > 1) {
+  if (!inv && (LC == 1024 || LC == 64)) {
 #pragma unroll
-    for (int k = 1; k < 16; ++k) v[k] = cmulc<false>(v[k], p[k]);
+    for (int k = 1; k < 16; ++k) v[k] = cmulc<false>(v[k], tab[(k - 1) * m]);
+  } else if (!inv && m > 1) {
+    mul_twiddles<false>(v, tw, opaque(j * (kN / LC)));
   }
 #pragma unroll
   for (int t = 0; t < 16; ++t) lds[pad_idx(base + t * m)] = v[t];
 }
 
-// Middle step: last forward pass (radix 4 on sub-transforms of length 4: no twiddles), product with the
-// tap spectrum (same digit-reversed positions), first inverse pass -- all in registers.  Thread `tid`
-// owns butterflies tid + 1024 q (q = 0..3), i.e. elements 4 (tid + 1024 q) + t.
-AAMD_HD void middle(int tid, C32* lds, const C32* H) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int e0 = 4 * (tid + kThreads * q);
-    C32 v[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0 + t)];
-    dft4<false>(v[0], v[1], v[2], v[3]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = cmul(v[t], H[e0 + t]);
-    dft4<true>(v[0], v[1], v[2], v[3]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) lds[pad_idx(e0 + t)] = v[t];
-  }
+// Middle step = last forward pass (radix 4 on sub-transforms of length 4: no twiddles), product with the
+// tap spectrum (same digit-reversed positions), first inverse pass -- all in registers.  Thread `tid` owns, for
+// q = 0..3, the 4 elements from middle_e0(tid, q): they lie inside the 1024-element sub-transform of the
+// thread's own wave, like everything passes B and C touch, so B -> C -> middle (and back) need no workgroup
+// barrier, only program order within the wave.
+AAMD_HD int middle_e0(int tid, int q) { return 1024 * (tid >> 6) + 4 * ((tid & 63) + 64 * q); }
+
+AAMD_HD void wave_sync() {     // orders this wave's LDS writes before its later LDS reads (LDS is in-order per wave)
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 // spectrum variant of the middle step (tap FFT): forward radix-4 only, result scaled and stored
 AAMD_HD void middle_spectrum(int tid, const C32* lds, C32* H, float scale) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    const int e0 = 4 * (tid + kThreads * q);
+    const int e0 = middle_e0(tid, q);
     C32 v[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0 + t)];
@@ -180,31 +208,93 @@ AAMD_HD int64_t block_s0(const Geom& g, int p, int64_t j) {
   return g.start - (int64_t)p * g.part_taps + j * g.v - (g.part_taps - 1);
 }
 
-AAMD_HD void load_pair(int tid, const Geom& g, const float* xr, int p, int64_t j0, C32* lds) {
+// ---- register-resident first / last pass ---------------------------------------------------------
+// pass16<16384, .> has m = 1024: thread tid owns elements tid + 1024 t -- the same elements a coalesced
+// global load / store of the block gives it.
+AAMD_HD void first_pass_from_regs(int tid, C32 (&v)[16], C32* lds, const C32* tw) {
+  dft16<false>(v);
+  mul_twiddles<false>(v, tw, opaque(tid));
+#pragma unroll
+  for (int t = 0; t < 16; ++t) lds[pad_idx(tid + t * 1024)] = v[t];
+}
+
+AAMD_HD void last_pass_to_regs(int tid, const C32* lds, const C32* tw, C32 (&v)[16]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) v[t] = lds[pad_idx(tid + t * 1024)];
+  mul_twiddles<true>(v, tw, opaque(tid));
+  dft16<true>(v);
+}
+
+// inputs of the block pair (j0, j0 + 1) of partition p, element tid + 1024 t -> v[t] = a + i b
+AAMD_HD void load_pair_regs(int tid, const Geom& g, const float* xr, int p, int64_t j0, C32 (&v)[16]) {
   const int64_t sa = block_s0(g, p, j0), sb = block_s0(g, p, j0 + 1);
   const bool has_b = j0 + 1 < g.n_blocks;
-#pragma unroll 4
-  for (int t = 0; t < kPerThread; ++t) {
-    const int i = tid + kThreads * t;
-    const int64_t ia = sa + i, ib = sb + i;
-    C32 z;
-    z.x = (ia >= 0 && ia < g.nx) ? xr[ia] : 0.0f;
-    z.y = (has_b && ib >= 0 && ib < g.nx) ? xr[ib] : 0.0f;
-    lds[pad_idx(i)] = z;
+  // uniform block bases + one 32-bit lane offset (opaque: keeps the address arithmetic out of the prologue)
+  const float* pa = xr + sa;
+  const float* pb = xr + sb;
+  const unsigned lane = (unsigned)opaque(tid);
+  if (has_b && sa >= 0 && sb + kN <= g.nx) {            // interior pair (uniform branch): no bounds checks
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = C32{(pa + 1024 * t)[lane], (pb + 1024 * t)[lane]};
+    return;
+  }
+  // edge pair: valid element ranges [lo, hi) of the two blocks as 32-bit block-local indices
+  const int lo_a = (int)(sa < 0 ? (-sa < kN ? -sa : kN) : 0);
+  const int hi_a = (int)(g.nx - sa < kN ? (g.nx - sa > 0 ? g.nx - sa : 0) : kN);
+  const int lo_b = (int)(sb < 0 ? (-sb < kN ? -sb : kN) : 0);
+  const int hi_b = !has_b ? 0 : (int)(g.nx - sb < kN ? (g.nx - sb > 0 ? g.nx - sb : 0) : kN);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = (int)lane + 1024 * t;
+    v[t].x = (i >= lo_a && i < hi_a) ? (pa + 1024 * t)[lane] : 0.0f;
+    v[t].y = (i >= lo_b && i < hi_b) ? (pb + 1024 * t)[lane] : 0.0f;
   }
 }
 
-AAMD_HD void store_pair(int tid, const Geom& g, const C32* lds, int p, int64_t j0, float* out_row) {
+AAMD_HD void store_pair_regs(int tid, const Geom& g, const C32 (&v)[16], int64_t j0, float* out_row) {
   const bool has_b = j0 + 1 < g.n_blocks;
-#pragma unroll 4
-  for (int t = 0; t < kPerThread; ++t) {
-    const int i = tid + kThreads * t;
-    if (i < g.part_taps - 1) continue;                    // wrapped-around samples
-    const C32 z = lds[pad_idx(i)];
-    const int64_t oa = j0 * g.v + (i - (g.part_taps - 1));
-    const int64_t ob = oa + g.v;
-    if (oa < g.out_len) out_row[oa] = (p == 0) ? z.x : out_row[oa] + z.x;
-    if (has_b && ob < g.out_len) out_row[ob] = (p == 0) ? z.y : out_row[ob] + z.y;
+  const int skip = g.part_taps - 1;                       // wrapped-around samples
+  float* oa = out_row + (j0 * g.v - skip);                // uniform bases; element i of block a -> oa[i]
+  float* ob = oa + g.v;
+  const unsigned lane = (unsigned)opaque(tid);
+  // valid i: skip <= i < hi (32-bit, uniform limits)
+  const int64_t left_a = g.out_len - (j0 * g.v - skip), left_b = left_a - g.v;
+  const int hi_a = (int)(left_a < kN ? (left_a > 0 ? left_a : 0) : kN);
+  const int hi_b = !has_b ? 0 : (int)(left_b < kN ? (left_b > 0 ? left_b : 0) : kN);
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int i = (int)lane + 1024 * t;
+    if (i >= skip && i < hi_a) (oa + 1024 * t)[lane] = v[t].x;
+    if (i >= skip && i < hi_b) (ob + 1024 * t)[lane] = v[t].y;
+  }
+}
+
+// middle step with the partitions accumulated in registers: acc[4 q + t] += DFT4(lds[4 (tid + 1024 q) + .])[t] * H
+AAMD_HD void middle_accumulate(int tid, const C32* lds, const C32* H, C32 (&acc)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e0 = middle_e0(tid, q);
+    C32 v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0 + t)];
+    dft4<false>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const C32 h = H[e0 + t];
+      acc[4 * q + t].x += v[t].x * h.x - v[t].y * h.y;
+      acc[4 * q + t].y += v[t].x * h.y + v[t].y * h.x;
+    }
+  }
+}
+
+// ... and the first inverse pass on the accumulated spectrum
+AAMD_HD void middle_finish(int tid, C32 (&acc)[16], C32* lds) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e0 = middle_e0(tid, q);
+    dft4<true>(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) lds[pad_idx(e0 + t)] = acc[4 * q + t];
   }
 }
 
@@ -237,49 +327,89 @@ spectrum_kernel(Geom g, const float* __restrict__ y, const C32* __restrict__ tw,
   const int tid = threadIdx.x;
   const int64_t yrow = blockIdx.x / g.n_part;
   const int p = blockIdx.x - (int)yrow * g.n_part;
+  C32* tl = lds + kLdsData;
+  twiddle_tables(tid, tw, tl);
   load_taps(tid, g, y + yrow * g.ny, p, lds);
   __syncthreads();
-  pass16<16384, false>(tid, lds, tw);
+  pass16<16384, false>(tid, lds, tl);
   __syncthreads();
-  pass16<1024, false>(tid, lds, tw);
+  pass16<1024, false>(tid, lds, tl);
   __syncthreads();
-  pass16<64, false>(tid, lds, tw);
+  pass16<64, false>(tid, lds, tl);
   __syncthreads();
   middle_spectrum(tid, lds, H + (int64_t)blockIdx.x * kN, 1.0f / (float)kN);
 }
 
-// one partition of the taps: out (+)= conv(x, y_p) on the slice
-__global__ void __launch_bounds__(kThreads)
-overlap_save_kernel(Geom g, int p, const float* __restrict__ x, const C32* __restrict__ tw,
+// out = conv(x, y) on the slice: one item = one pair of output blocks, all tap partitions.  512 threads, each
+// playing TWO of the 1024 logical butterfly owners (tid and tid + 512, i.e. logical waves w and w + 8): 2 waves
+// per SIMD with a 256-register budget, so the frequency-domain accumulators (64 registers) and the
+// prefetched inputs of the next partition (64) stay in registers next to a pass' working set.
+// Barriers: only around the first / last pass (which exchange data between waves); passes B, C and the
+// middle step of a logical wave stay inside its own 1024-element sub-transform.
+constexpr int kPhys = 512;
+__global__ void __launch_bounds__(kPhys)
+overlap_save_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ tw,
                     const C32* __restrict__ H, const int64_t* __restrict__ x_row_of,
                     const int64_t* __restrict__ y_row_of, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_fco[];
   C32* lds = reinterpret_cast<C32*>(smem_fco);
-  const int tid = threadIdx.x;
+  const int t0 = threadIdx.x, t1 = threadIdx.x + kPhys;
   const int64_t n_items = g.rows * g.n_pairs;
+  C32* tl = lds + kLdsData;
+  twiddle_tables(t0, tw, tl);
+  twiddle_tables(t1, tw, tl);
+  __syncthreads();
 #pragma unroll 1
   for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int64_t row = item / g.n_pairs;
     const int64_t j0 = 2 * (item - row * g.n_pairs);
     const int64_t rx = x_row_of ? x_row_of[row] : row;
     const int64_t ry = y_row_of ? y_row_of[row] : row;
-    load_pair(tid, g, x + rx * g.nx, p, j0, lds);
+    const float* xr = x + rx * g.nx;
+    const C32* Hr = H + ry * g.n_part * (int64_t)kN;
+    C32 acc0[16], acc1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc0[t] = acc1[t] = C32{0.0f, 0.0f};
+    C32 v0[16], v1[16];
+    load_pair_regs(t0, g, xr, 0, j0, v0);
+    load_pair_regs(t1, g, xr, 0, j0, v1);
+#pragma unroll 1
+    for (int p = 0; p < g.n_part; ++p) {
+      first_pass_from_regs(t0, v0, lds, tl);
+      first_pass_from_regs(t1, v1, lds, tl);
+      __syncthreads();
+      if (p + 1 < g.n_part) {                                  // in flight during the remaining passes
+        load_pair_regs(t0, g, xr, p + 1, j0, v0);
+        load_pair_regs(t1, g, xr, p + 1, j0, v1);
+      }
+      const C32* Hp = Hr + (int64_t)p * kN;
+      pass16<1024, false>(t0, lds, tl);
+      wave_sync();
+      pass16<64, false>(t0, lds, tl);
+      wave_sync();
+      middle_accumulate(t0, lds, Hp, acc0);
+      pass16<1024, false>(t1, lds, tl);
+      wave_sync();
+      pass16<64, false>(t1, lds, tl);
+      wave_sync();
+      middle_accumulate(t1, lds, Hp, acc1);
+      __syncthreads();                                          // the next first pass overwrites everything
+    }
+    middle_finish(t0, acc0, lds);
+    wave_sync();
+    pass16<64, true>(t0, lds, tl);
+    wave_sync();
+    pass16<1024, true>(t0, lds, tl);
+    middle_finish(t1, acc1, lds);
+    wave_sync();
+    pass16<64, true>(t1, lds, tl);
+    wave_sync();
+    pass16<1024, true>(t1, lds, tl);
     __syncthreads();
-    pass16<16384, false>(tid, lds, tw);
-    __syncthreads();
-    pass16<1024, false>(tid, lds, tw);
-    __syncthreads();
-    pass16<64, false>(tid, lds, tw);
-    __syncthreads();
-    middle(tid, lds, H + (ry * g.n_part + p) * (int64_t)kN);
-    __syncthreads();
-    pass16<64, true>(tid, lds, tw);
-    __syncthreads();
-    pass16<1024, true>(tid, lds, tw);
-    __syncthreads();
-    pass16<16384, true>(tid, lds, tw);
-    __syncthreads();
-    store_pair(tid, g, lds, p, j0, out + row * g.out_len);
+    last_pass_to_regs(t0, lds, tl, v0);
+    store_pair_regs(t0, g, v0, j0, out + row * g.out_len);
+    last_pass_to_regs(t1, lds, tl, v1);
+    store_pair_regs(t1, g, v1, j0, out + row * g.out_len);
     __syncthreads();
   }
 }

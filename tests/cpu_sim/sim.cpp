@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <array>
 #include <vector>
 
 #include "../../include/audio_amd.h"
@@ -558,10 +559,12 @@ int sim_fftconv_os(const float* x, const float* y, float* out, int64_t rows, int
     const double a = -2.0 * M_PI * (double)m / (double)kN;
     tw[m] = C32{(float)std::cos(a), (float)std::sin(a)};
   }
+  C32* tl = lds.data() + kLdsData;
+  for (int t = 0; t < kThreads; ++t) twiddle_tables(t, tw.data(), tl);
   auto fwd = [&]() {
-    for (int t = 0; t < kThreads; ++t) pass16<16384, false>(t, lds.data(), tw.data());
-    for (int t = 0; t < kThreads; ++t) pass16<1024, false>(t, lds.data(), tw.data());
-    for (int t = 0; t < kThreads; ++t) pass16<64, false>(t, lds.data(), tw.data());
+    for (int t = 0; t < kThreads; ++t) pass16<16384, false>(t, lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) pass16<1024, false>(t, lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) pass16<64, false>(t, lds.data(), tl);
   };
   for (int64_t b = 0; b < tap_rows * g.n_part; ++b) {
     const int64_t yrow = b / g.n_part; const int p = (int)(b - yrow * g.n_part);
@@ -569,18 +572,33 @@ int sim_fftconv_os(const float* x, const float* y, float* out, int64_t rows, int
     fwd();
     for (int t = 0; t < kThreads; ++t) middle_spectrum(t, lds.data(), H.data() + b * kN, 1.0f / (float)kN);
   }
-  for (int p = 0; p < g.n_part; ++p)
-    for (int64_t item = 0; item < rows * g.n_pairs; ++item) {
-      const int64_t row = item / g.n_pairs, j0 = 2 * (item - row * g.n_pairs);
-      const int64_t rx = xmap ? xmap[row] : row, ry = ymap ? ymap[row] : row;
-      for (int t = 0; t < kThreads; ++t) load_pair(t, g, xa + rx * g.nx, p, j0, lds.data());
-      fwd();
-      for (int t = 0; t < kThreads; ++t) middle(t, lds.data(), H.data() + (ry * g.n_part + p) * (int64_t)kN);
-      for (int t = 0; t < kThreads; ++t) pass16<64, true>(t, lds.data(), tw.data());
-      for (int t = 0; t < kThreads; ++t) pass16<1024, true>(t, lds.data(), tw.data());
-      for (int t = 0; t < kThreads; ++t) pass16<16384, true>(t, lds.data(), tw.data());
-      for (int t = 0; t < kThreads; ++t) store_pair(t, g, lds.data(), p, j0, out + row * out_len);
+  std::vector<std::array<C32, 16>> v(kThreads), acc(kThreads);
+  auto arr = [](std::array<C32, 16>& a) -> C32 (&)[16] { return *reinterpret_cast<C32 (*)[16]>(a.data()); };
+  for (int64_t item = 0; item < rows * g.n_pairs; ++item) {
+    const int64_t row = item / g.n_pairs, j0 = 2 * (item - row * g.n_pairs);
+    const int64_t rx = xmap ? xmap[row] : row, ry = ymap ? ymap[row] : row;
+    const float* xr = xa + rx * g.nx;
+    for (int t = 0; t < kThreads; ++t) {
+      for (int k = 0; k < 16; ++k) acc[t][k] = C32{0.0f, 0.0f};
+      load_pair_regs(t, g, xr, 0, j0, arr(v[t]));
     }
+    for (int p = 0; p < g.n_part; ++p) {
+      for (int t = 0; t < kThreads; ++t) first_pass_from_regs(t, arr(v[t]), lds.data(), tl);
+      for (int t = 0; t < kThreads; ++t) pass16<1024, false>(t, lds.data(), tl);
+      for (int t = 0; t < kThreads; ++t) pass16<64, false>(t, lds.data(), tl);
+      for (int t = 0; t < kThreads; ++t) {
+        if (p + 1 < g.n_part) load_pair_regs(t, g, xr, p + 1, j0, arr(v[t]));
+        middle_accumulate(t, lds.data(), H.data() + (ry * g.n_part + p) * (int64_t)kN, arr(acc[t]));
+      }
+    }
+    for (int t = 0; t < kThreads; ++t) middle_finish(t, arr(acc[t]), lds.data());
+    for (int t = 0; t < kThreads; ++t) pass16<64, true>(t, lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) pass16<1024, true>(t, lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) {
+      last_pass_to_regs(t, lds.data(), tl, arr(v[t]));
+      store_pair_regs(t, g, arr(v[t]), j0, out + row * out_len);
+    }
+  }
   return 0;
 }
 
