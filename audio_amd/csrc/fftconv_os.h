@@ -359,6 +359,13 @@ overlap_save_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__
   twiddle_tables(t0, tw, tl);
   twiddle_tables(t1, tw, tl);
   __syncthreads();
+  C32 v0[16], v1[16];
+  if ((int64_t)blockIdx.x < n_items) {
+    const int64_t row = blockIdx.x / g.n_pairs;
+    const float* xr = x + (x_row_of ? x_row_of[row] : row) * g.nx;
+    load_pair_regs(t0, g, xr, 0, 2 * (blockIdx.x - row * g.n_pairs), v0);
+    load_pair_regs(t1, g, xr, 0, 2 * (blockIdx.x - row * g.n_pairs), v1);
+  }
 #pragma unroll 1
   for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int64_t row = item / g.n_pairs;
@@ -370,9 +377,6 @@ overlap_save_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__
     C32 acc0[16], acc1[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc0[t] = acc1[t] = C32{0.0f, 0.0f};
-    C32 v0[16], v1[16];
-    load_pair_regs(t0, g, xr, 0, j0, v0);
-    load_pair_regs(t1, g, xr, 0, j0, v1);
 #pragma unroll 1
     for (int p = 0; p < g.n_part; ++p) {
       first_pass_from_regs(t0, v0, lds, tl);
@@ -406,10 +410,16 @@ overlap_save_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__
     wave_sync();
     pass16<1024, true>(t1, lds, tl);
     __syncthreads();
-    last_pass_to_regs(t0, lds, tl, v0);
-    store_pair_regs(t0, g, v0, j0, out + row * g.out_len);
-    last_pass_to_regs(t1, lds, tl, v1);
-    store_pair_regs(t1, g, v1, j0, out + row * g.out_len);
+    C32 w[16];
+    last_pass_to_regs(t0, lds, tl, w);
+    store_pair_regs(t0, g, w, j0, out + row * g.out_len);
+    const int64_t nitem = item + gridDim.x;                   // next item's first inputs: in flight during the stores
+    const int64_t nrow = nitem / g.n_pairs;
+    const float* nxr = x + (x_row_of && nitem < n_items ? x_row_of[nrow] : nrow) * g.nx;
+    if (nitem < n_items) load_pair_regs(t0, g, nxr, 0, 2 * (nitem - nrow * g.n_pairs), v0);
+    last_pass_to_regs(t1, lds, tl, w);
+    store_pair_regs(t1, g, w, j0, out + row * g.out_len);
+    if (nitem < n_items) load_pair_regs(t1, g, nxr, 0, 2 * (nitem - nrow * g.n_pairs), v1);
     __syncthreads();
   }
 }
