@@ -41,6 +41,14 @@ _lib = None
 _lock = threading.Lock()
 
 _P = C.c_void_p
+class VocoderDesc(C.Structure):
+    """aamd_vocoder_desc (include/audio_amd.h)."""
+    _fields_ = [("rows", C.c_int64), ("n_freq", C.c_int32), ("n_frames_in", C.c_int32), ("n_frames_out", C.c_int32),
+                ("in_stride_row", C.c_int64), ("in_stride_freq", C.c_int64), ("in_stride_frame", C.c_int64),
+                ("out_stride_row", C.c_int64), ("out_stride_freq", C.c_int64), ("out_stride_frame", C.c_int64),
+                ("rate", C.c_double)]
+
+
 _SIGS = {
     "aamd_abi_version": (C.c_int, []),
     "aamd_last_error": (C.c_char_p, []),
@@ -50,6 +58,8 @@ _SIGS = {
     "aamd_melspectrogram_db_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.c_float,
                                              C.c_float, C.c_float, _P, C.c_int64, _P]),
     "aamd_istft_f32": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(StftDesc), C.c_int32, _P]),
+    "aamd_phase_vocoder_f32": (C.c_int, [_P, _P, _P, C.POINTER(VocoderDesc), _P]),
+    "aamd_griffinlim_update_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),
     "aamd_mel_scale_f32": (C.c_int, [_P, C.POINTER(MelBands), _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "aamd_amplitude_to_db_f32": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P]),
     "aamd_db_clamp_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_float, _P]),

@@ -14,6 +14,7 @@
 #include "fftconv.h"
 #include "fftconv_os.h"
 #include "istft.h"
+#include "vocoder.h"
 #include "lfilter.h"
 #include "lfilter_wave.h"
 #include "melspec400.h"
@@ -344,6 +345,33 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGenThreads), lds, (hipStream_t)stream, og, spec, window,
                      reinterpret_cast<const cplx<float>*>(twiddle), inv_envelope, out, pb, bpr);
+  return launch_check();
+}
+
+int aamd_phase_vocoder_f32(const float* spec, const float* phase_advance, float* out, const aamd_vocoder_desc* d,
+                           void* stream) {
+  AAMD_CHECK_ARG(d != nullptr && spec && phase_advance && out, "null buffer");
+  AAMD_CHECK_ARG(d->rows >= 0 && d->n_freq >= 1 && d->n_frames_in >= 0 && d->n_frames_out >= 0, "bad sizes");
+  AAMD_CHECK_ARG(d->rate > 0.0, "rate must be positive");
+  if (d->rows == 0 || d->n_frames_out == 0) return AAMD_OK;
+  VocoderGeom g{d->rows, d->n_freq, d->n_frames_in, d->n_frames_out, d->in_stride_row, d->in_stride_freq,
+                d->in_stride_frame, d->out_stride_row, d->out_stride_freq, d->out_stride_frame, d->rate};
+  const int64_t chains = d->rows * d->n_freq;
+  AAMD_CHECK_ARG((chains + 255) / 256 < (1ll << 31), "too many chains for one launch");
+  hipLaunchKernelGGL(phase_vocoder_kernel, dim3((unsigned)((chains + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g,
+                     reinterpret_cast<const cplx<float>*>(spec), phase_advance, reinterpret_cast<cplx<float>*>(out));
+  return launch_check();
+}
+
+int aamd_griffinlim_update_f32(const float* rebuilt, float* tprev, const float* magnitude, float* next, int64_t n,
+                               float momentum, void* stream) {
+  AAMD_CHECK_ARG(rebuilt && tprev && magnitude && next, "null buffer");
+  AAMD_CHECK_ARG(n >= 0, "bad size");
+  if (n == 0) return AAMD_OK;
+  const int blocks = grid_for(n, 256, dev_props().cu_count * 16);
+  hipLaunchKernelGGL(griffinlim_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const cplx<float>*>(rebuilt), reinterpret_cast<cplx<float>*>(tprev), magnitude,
+                     reinterpret_cast<cplx<float>*>(next), n, momentum);
   return launch_check();
 }
 

@@ -23,7 +23,7 @@ from . import _lib
 from ._host import create_dct, melscale_fbanks  # noqa: F401  (re-exported, host-side constants)
 
 __all__ = [
-    "spectrogram", "inverse_spectrogram", "amplitude_to_DB", "melscale_fbanks", "create_dct", "resample",
+    "spectrogram", "inverse_spectrogram", "griffinlim", "phase_vocoder", "pitch_shift", "speed", "amplitude_to_DB", "melscale_fbanks", "create_dct", "resample",
     "lfilter", "biquad", "fftconvolve", "mel_scale", "filtfilt",
     "lowpass_biquad", "highpass_biquad", "allpass_biquad", "bandpass_biquad",
     "bandreject_biquad", "equalizer_biquad", "band_biquad", "treble_biquad", "bass_biquad",
@@ -362,6 +362,163 @@ def inverse_spectrogram(
     if length is not None and pad > 0:
         out = out[:, pad:-pad]
     return out.reshape(tuple(shape[:-2]) + out.shape[-1:])
+
+
+def _phase_vocoder_launch(spec: Tensor, rate: float, phase_advance: Tensor, frame_major_out: bool) -> Tensor:
+    """spec: complex64 (rows, F, T) view with arbitrary strides -> complex64 (rows, F, T_out), contiguous, or a
+    transposed view of frame-major (rows, T_out, F) memory when `frame_major_out` (what the iSTFT kernel eats)."""
+    rows, n_freq, n_in = spec.shape
+    n_out = int(math.ceil(n_in / rate))
+    dev = spec.device
+    pa = phase_advance.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+    if pa.numel() != n_freq:
+        raise RuntimeError(f"audio_amd: phase_advance must have {n_freq} elements, got {pa.numel()}")
+    if frame_major_out:
+        out = torch.empty((rows, n_out, n_freq), dtype=torch.complex64, device=dev)
+        o_row, o_t, o_f = out.stride()
+    else:
+        out = torch.empty((rows, n_freq, n_out), dtype=torch.complex64, device=dev)
+        o_row, o_f, o_t = out.stride()
+    if out.numel():
+        i_row, i_f, i_t = spec.stride()
+        d = _lib.VocoderDesc(rows, n_freq, n_in, n_out, i_row, i_f, i_t, o_row, o_f, o_t, float(rate))
+        L = _lib.lib()
+        # data_ptr of a complex view points at its first element (storage offset included)
+        _lib.check(L.aamd_phase_vocoder_f32(torch.view_as_real(spec).data_ptr(), pa.data_ptr(),
+                                            torch.view_as_real(out).data_ptr(), C.byref(d), _lib.current_stream(dev)))
+    return out.transpose(-1, -2) if frame_major_out else out
+
+
+def phase_vocoder(complex_specgrams: Tensor, rate: float, phase_advance: Tensor) -> Tensor:
+    r"""Stretch a complex spectrogram in time by ``rate`` without changing pitch
+    (reference: functional/functional.py:732-803) -- one HIP kernel, a thread per (row, frequency) chain."""
+    if rate == 1.0:
+        return complex_specgrams
+    if not complex_specgrams.is_cuda:
+        raise RuntimeError(f"audio_amd: complex_specgrams must be on an MI355X (ROCm) device, got "
+                           f"{complex_specgrams.device}. The HIP kernels have no CPU fallback.")
+    if complex_specgrams.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("audio_amd: phase_vocoder is forward-only; wrap the call in torch.no_grad().")
+    shape = complex_specgrams.size()
+    spec = complex_specgrams.to(torch.complex64).reshape((-1,) + tuple(shape[-2:]))
+    out = _phase_vocoder_launch(spec, rate, phase_advance, frame_major_out=False)
+    return out.reshape(tuple(shape[:-2]) + out.shape[1:])
+
+
+def griffinlim(
+    specgram: Tensor,
+    window: Tensor,
+    n_fft: int,
+    hop_length: int,
+    win_length: int,
+    power: float,
+    n_iter: int,
+    momentum: float,
+    length: Optional[int],
+    rand_init: bool,
+) -> Tensor:
+    r"""Griffin-Lim phase recovery (reference: functional/functional.py:255-353).  Every iteration is three
+    launches on frame-major buffers: inverse STFT (csrc/istft.h), complex STFT (the radix-20x20 fast path
+    for n_fft = 400, the generic Stockham kernel otherwise) and the fused phase update (csrc/vocoder.h)."""
+    if not 0 <= momentum < 1:
+        raise ValueError("momentum must be in range [0, 1). Found: {}".format(momentum))
+    _require_device(specgram, "specgram")
+    momentum = momentum / (1 + momentum)
+    shape = specgram.size()
+    dev = specgram.device
+    n_freq, T = shape[-2], shape[-1]
+    window = window.to(device=dev, dtype=torch.float32)
+    # frame-major magnitude, (rows, T, F)
+    mag = specgram.to(torch.float32).reshape(-1, n_freq, T).transpose(-1, -2).pow(1 / power).contiguous()
+    rows = mag.shape[0]
+    if rand_init:
+        # the reference draws torch.rand in the COMPLEX dtype: uniform real and imaginary parts
+        angles = torch.rand((rows, n_freq, T), dtype=torch.complex64, device=dev).transpose(-1, -2)
+        cur = (mag * angles).contiguous()
+    else:
+        cur = torch.complex(mag, torch.zeros_like(mag))
+    tprev = torch.zeros_like(cur)
+    nxt = torch.empty_like(cur)
+    L = _lib.lib()
+
+    def invert(z: Tensor) -> Tensor:
+        return inverse_spectrogram(z.transpose(-1, -2), length, 0, window, n_fft, hop_length, win_length, False)
+
+    for _ in range(n_iter):
+        inverse = invert(cur)
+        rebuilt = spectrogram(inverse, 0, window, n_fft, hop_length, win_length, None, False)   # (rows, F, T') view
+        rebuilt_fm = rebuilt.transpose(-1, -2)
+        if rebuilt_fm.shape[1] != T:
+            raise RuntimeError("audio_amd: griffinlim needs length consistent with the number of frames")
+        if not rebuilt_fm.is_contiguous():
+            rebuilt_fm = rebuilt_fm.contiguous()
+        _lib.check(L.aamd_griffinlim_update_f32(
+            torch.view_as_real(rebuilt_fm).data_ptr(), torch.view_as_real(tprev).data_ptr(), mag.data_ptr(),
+            torch.view_as_real(nxt).data_ptr(), mag.numel(), float(momentum), _lib.current_stream(dev)))
+        cur, nxt = nxt, cur
+    waveform = invert(cur)
+    return waveform.reshape(tuple(shape[:-2]) + waveform.shape[-1:])
+
+
+def _stretch_waveform(waveform: Tensor, n_steps: int, bins_per_octave: int = 12, n_fft: int = 512,
+                      win_length: Optional[int] = None, hop_length: Optional[int] = None,
+                      window: Optional[Tensor] = None) -> Tensor:
+    """functional/functional.py:1644-1693: STFT -> phase vocoder -> inverse STFT, frame-major end to end."""
+    if hop_length is None:
+        hop_length = n_fft // 4
+    if win_length is None:
+        win_length = n_fft
+    if window is None:
+        window = torch.hann_window(window_length=win_length, device=waveform.device)
+    shape = waveform.size()
+    waveform = waveform.reshape(-1, shape[-1])
+    ori_len = shape[-1]
+    rate = 2.0 ** (-float(n_steps) / bins_per_octave)
+    spec_f = spectrogram(waveform, 0, window, n_fft, hop_length, win_length, None, False)
+    phase_advance = torch.linspace(0, math.pi * hop_length, spec_f.shape[-2], device=spec_f.device)[..., None]
+    if rate == 1.0:
+        spec_stretch = spec_f
+    else:
+        spec_stretch = _phase_vocoder_launch(spec_f, rate, phase_advance, frame_major_out=True)
+    len_stretch = int(round(ori_len / rate))
+    return inverse_spectrogram(spec_stretch, len_stretch, 0, window, n_fft, hop_length, win_length, False)
+
+
+def _fix_waveform_shape(waveform_shift: Tensor, shape) -> Tensor:
+    """functional/functional.py:1696-1719."""
+    ori_len = shape[-1]
+    shift_len = waveform_shift.size()[-1]
+    if shift_len > ori_len:
+        waveform_shift = waveform_shift[..., :ori_len]
+    else:
+        waveform_shift = torch.nn.functional.pad(waveform_shift, [0, ori_len - shift_len])
+    return waveform_shift.reshape(tuple(shape[:-1]) + waveform_shift.shape[-1:])
+
+
+def pitch_shift(waveform: Tensor, sample_rate: int, n_steps: int, bins_per_octave: int = 12, n_fft: int = 512,
+                win_length: Optional[int] = None, hop_length: Optional[int] = None,
+                window: Optional[Tensor] = None) -> Tensor:
+    r"""Shift the pitch by ``n_steps`` (reference: functional/functional.py:1596-1641): time-stretch with the
+    phase vocoder, then resample back -- four HIP kernels (STFT, vocoder, inverse STFT, polyphase resampler)."""
+    _require_device(waveform, "waveform")
+    waveform_stretch = _stretch_waveform(waveform, n_steps, bins_per_octave, n_fft, win_length, hop_length, window)
+    rate = 2.0 ** (-float(n_steps) / bins_per_octave)
+    waveform_shift = resample(waveform_stretch, int(sample_rate / rate), sample_rate)
+    return _fix_waveform_shape(waveform_shift, waveform.size())
+
+
+def speed(waveform: Tensor, orig_freq: int, factor: float, lengths: Optional[Tensor] = None):
+    r"""Adjust waveform speed (reference: functional/functional.py:2385-2423): resample by 1 / factor."""
+    source_sample_rate = int(factor * orig_freq)
+    target_sample_rate = int(orig_freq)
+    gcd = math.gcd(source_sample_rate, target_sample_rate)
+    source_sample_rate = source_sample_rate // gcd
+    target_sample_rate = target_sample_rate // gcd
+    if lengths is None:
+        out_lengths = None
+    else:
+        out_lengths = torch.ceil(lengths * target_sample_rate / source_sample_rate).to(lengths.dtype)
+    return resample(waveform, source_sample_rate, target_sample_rate), out_lengths
 
 
 def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_fft: int, hop_length: int,

@@ -19,7 +19,8 @@ from torch import Tensor
 from . import _host, _lib
 from . import functional as F
 
-__all__ = ["Spectrogram", "MelScale", "MelSpectrogram", "AmplitudeToDB", "MFCC", "Resample", "FFTConvolve"]
+__all__ = ["Spectrogram", "InverseSpectrogram", "GriffinLim", "TimeStretch", "PitchShift", "Speed", "SpeedPerturbation",
+           "MelScale", "MelSpectrogram", "AmplitudeToDB", "MFCC", "Resample", "FFTConvolve"]
 
 
 class Spectrogram(torch.nn.Module):
@@ -98,6 +99,145 @@ class InverseSpectrogram(torch.nn.Module):
     def forward(self, spectrogram: Tensor, length: Optional[int] = None) -> Tensor:
         return F.inverse_spectrogram(spectrogram, length, self.pad, self.window, self.n_fft, self.hop_length,
                                      self.win_length, self.normalized, self.center, self.pad_mode, self.onesided)
+
+
+class GriffinLim(torch.nn.Module):
+    r"""Waveform from a magnitude spectrogram by Griffin-Lim (reference: _transforms.py:212-297)."""
+    __constants__ = ["n_fft", "n_iter", "win_length", "hop_length", "power", "length", "momentum", "rand_init"]
+
+    def __init__(
+        self,
+        n_fft: int = 400,
+        n_iter: int = 32,
+        win_length: Optional[int] = None,
+        hop_length: Optional[int] = None,
+        window_fn: Callable[..., Tensor] = torch.hann_window,
+        power: float = 2.0,
+        wkwargs: Optional[dict] = None,
+        momentum: float = 0.99,
+        length: Optional[int] = None,
+        rand_init: bool = True,
+    ) -> None:
+        super().__init__()
+        if not (0 <= momentum < 1):
+            raise ValueError("momentum must be in the range [0, 1). Found: {}".format(momentum))
+        self.n_fft = n_fft
+        self.n_iter = n_iter
+        self.win_length = win_length if win_length is not None else n_fft
+        self.hop_length = hop_length if hop_length is not None else self.win_length // 2
+        window = window_fn(self.win_length) if wkwargs is None else window_fn(self.win_length, **wkwargs)
+        self.register_buffer("window", window)
+        self.length = length
+        self.power = power
+        self.momentum = momentum
+        self.rand_init = rand_init
+
+    def forward(self, specgram: Tensor) -> Tensor:
+        return F.griffinlim(specgram, self.window, self.n_fft, self.hop_length, self.win_length, self.power,
+                            self.n_iter, self.momentum, self.length, self.rand_init)
+
+
+class TimeStretch(torch.nn.Module):
+    r"""Stretch a complex STFT in time without modifying pitch (reference: _transforms.py:1014-1083)."""
+    __constants__ = ["fixed_rate"]
+
+    def __init__(self, hop_length: Optional[int] = None, n_freq: int = 201, fixed_rate: Optional[float] = None) -> None:
+        super().__init__()
+        self.fixed_rate = fixed_rate
+        n_fft = (n_freq - 1) * 2
+        hop_length = hop_length if hop_length is not None else n_fft // 2
+        self.register_buffer("phase_advance", torch.linspace(0, math.pi * hop_length, n_freq)[..., None])
+
+    def forward(self, complex_specgrams: Tensor, overriding_rate: Optional[float] = None) -> Tensor:
+        if not torch.is_complex(complex_specgrams):
+            raise ValueError("audio_amd: the input to TimeStretch must be a complex tensor")
+        if overriding_rate is None:
+            if self.fixed_rate is None:
+                raise ValueError("If no fixed_rate is specified, must pass a valid rate to the forward method.")
+            rate = self.fixed_rate
+        else:
+            rate = overriding_rate
+        return F.phase_vocoder(complex_specgrams, rate, self.phase_advance)
+
+
+class PitchShift(torch.nn.Module):
+    r"""Shift the pitch of a waveform by ``n_steps`` steps (reference: _transforms.py:1674-1780)."""
+    __constants__ = ["sample_rate", "n_steps", "bins_per_octave", "n_fft", "win_length", "hop_length"]
+
+    def __init__(
+        self,
+        sample_rate: int,
+        n_steps: int,
+        bins_per_octave: int = 12,
+        n_fft: int = 512,
+        win_length: Optional[int] = None,
+        hop_length: Optional[int] = None,
+        window_fn: Callable[..., Tensor] = torch.hann_window,
+        wkwargs: Optional[dict] = None,
+    ) -> None:
+        super().__init__()
+        self.n_steps = n_steps
+        self.bins_per_octave = bins_per_octave
+        self.sample_rate = sample_rate
+        self.n_fft = n_fft
+        self.win_length = win_length if win_length is not None else n_fft
+        self.hop_length = hop_length if hop_length is not None else self.win_length // 4
+        window = window_fn(self.win_length) if wkwargs is None else window_fn(self.win_length, **wkwargs)
+        self.register_buffer("window", window)
+        rate = 2.0 ** (-float(n_steps) / bins_per_octave)
+        self.orig_freq = int(sample_rate / rate)
+        self.gcd = math.gcd(int(self.orig_freq), int(sample_rate))
+        self.width = -1
+        self.kernel = None          # built on the first call (the reference uses a lazy UninitializedParameter)
+
+    def forward(self, waveform: Tensor) -> Tensor:
+        F._require_device(waveform, "waveform")
+        shape = waveform.size()
+        stretch = F._stretch_waveform(waveform, self.n_steps, self.bins_per_octave, self.n_fft, self.win_length,
+                                      self.hop_length, self.window)
+        if self.orig_freq != self.sample_rate:
+            if self.kernel is None or self.kernel.device != waveform.device:
+                kernel, self.width = _host.sinc_resample_kernel(self.orig_freq, self.sample_rate, self.gcd,
+                                                                dtype=waveform.dtype)
+                self.kernel = kernel.to(waveform.device)
+            shift = F._apply_sinc_resample_kernel(stretch, self.orig_freq, self.sample_rate, self.gcd, self.kernel,
+                                                  self.width)
+        else:
+            shift = stretch
+        return F._fix_waveform_shape(shift, shape)
+
+
+class Speed(torch.nn.Module):
+    r"""Adjust waveform speed (reference: _transforms.py:1958-2001)."""
+
+    def __init__(self, orig_freq, factor) -> None:
+        super().__init__()
+        self.orig_freq = orig_freq
+        self.factor = factor
+        source = int(factor * orig_freq)
+        target = int(orig_freq)
+        gcd = math.gcd(source, target)
+        self.source_sample_rate, self.target_sample_rate = source // gcd, target // gcd
+        self.resampler = Resample(orig_freq=self.source_sample_rate, new_freq=self.target_sample_rate)
+
+    def forward(self, waveform, lengths: Optional[Tensor] = None):
+        if lengths is None:
+            out_lengths = None
+        else:
+            out_lengths = torch.ceil(lengths * self.target_sample_rate / self.source_sample_rate).to(lengths.dtype)
+        return self.resampler(waveform), out_lengths
+
+
+class SpeedPerturbation(torch.nn.Module):
+    r"""Pick one of ``factors`` uniformly at random and adjust the speed by it (reference: _transforms.py:2004-2055)."""
+
+    def __init__(self, orig_freq: int, factors) -> None:
+        super().__init__()
+        self.speeders = torch.nn.ModuleList([Speed(orig_freq=orig_freq, factor=factor) for factor in factors])
+
+    def forward(self, waveform: Tensor, lengths: Optional[Tensor] = None):
+        idx = int(torch.randint(len(self.speeders), ()))
+        return self.speeders[idx](waveform, lengths)
 
 
 class AmplitudeToDB(torch.nn.Module):

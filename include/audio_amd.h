@@ -22,6 +22,8 @@
  *                             Spectrogram.forward + MelScale.forward :403-415)
  *   aamd_melspectrogram_db_f32  ... + F.amplitude_to_DB and its top_db group maximum fused
  *                             (first half of MFCC.forward, _transforms.py:692-706)
+ *   aamd_phase_vocoder_f32    functional/functional.py:732-803 (F.phase_vocoder; T.TimeStretch, F.pitch_shift)
+ *   aamd_griffinlim_update_f32  functional/functional.py:336-343 (phase update of F.griffinlim)
  *   aamd_istft_f32            functional/functional.py:148-225 (F.inverse_spectrogram -> torch.istft) and the
  *                             adjoint of the STFT for autograd of the STFT family
  *   aamd_mel_scale_f32        transforms/_transforms.py:403-415 (MelScale.forward on a
@@ -142,6 +144,26 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
  *                 with the forward's pad_mode, so reflected / replicated edges fold back onto the samples they copied. */
 int aamd_istft_f32(const float* spec, const float* window, const float* twiddle, const float* inv_envelope,
                    float* out, const aamd_stft_desc* desc, int32_t adjoint, void* stream);
+
+/* Phase vocoder (functional/functional.py:732-803; T.TimeStretch, F.pitch_shift): stretch a complex
+ * spectrogram in time by `rate`.  Strides are in COMPLEX elements, so the reference's (rows, freq, frames)
+ * tensors and this library's frame-major (rows, frames, freq) buffers are both addressable.
+ * n_frames_out = ceil(n_frames_in / rate); phase_advance: float[n_freq]. */
+typedef struct aamd_vocoder_desc {
+  int64_t rows;
+  int32_t n_freq, n_frames_in, n_frames_out;
+  int64_t in_stride_row, in_stride_freq, in_stride_frame;
+  int64_t out_stride_row, out_stride_freq, out_stride_frame;
+  double rate;
+} aamd_vocoder_desc;
+int aamd_phase_vocoder_f32(const float* spec, const float* phase_advance, float* out, const aamd_vocoder_desc* desc,
+                           void* stream);
+
+/* One phase update of Griffin-Lim (functional/functional.py:336-343), element-wise over n complex values:
+ *   a = rebuilt - momentum * tprev;  a /= |a| + 1e-16;  tprev = rebuilt;  next = magnitude * a
+ * (`momentum` is already momentum / (1 + momentum), :302). */
+int aamd_griffinlim_update_f32(const float* rebuilt, float* tprev, const float* magnitude, float* next, int64_t n,
+                               float momentum, void* stream);
 
 /* MelScale.forward on an existing spectrogram given frame-major: spec float[rows][n_frames][n_freq]
  * -> out float[rows][n_frames][n_mels]. */

@@ -14,6 +14,7 @@
 #include "../../audio_amd/csrc/fftconv.h"
 #include "../../audio_amd/csrc/fftconv_os.h"
 #include "../../audio_amd/csrc/istft.h"
+#include "../../audio_amd/csrc/vocoder.h"
 #include "../../audio_amd/csrc/lfilter.h"
 #include "../../audio_amd/csrc/lfilter_wave.h"
 #include "../../audio_amd/csrc/melspec400.h"
@@ -73,6 +74,28 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
 }
 
 // Replay of ola_kernel (inverse STFT / STFT adjoint): same launcher logic as aamd_istft_f32.
+// phase_vocoder_kernel / griffinlim_update_kernel: one chain / element per "thread"
+int sim_phase_vocoder(const float* spec, const float* phase_advance, float* out, const aamd_vocoder_desc* d) {
+  VocoderGeom g{d->rows, d->n_freq, d->n_frames_in, d->n_frames_out, d->in_stride_row, d->in_stride_freq,
+                d->in_stride_frame, d->out_stride_row, d->out_stride_freq, d->out_stride_frame, d->rate};
+  const cplx<float>* in = reinterpret_cast<const cplx<float>*>(spec);
+  cplx<float>* o = reinterpret_cast<cplx<float>*>(out);
+  for (int64_t chain = 0; chain < g.rows * g.n_freq; ++chain) {
+    const int64_t row = chain / g.n_freq;
+    const int f = (int)(chain - row * g.n_freq);
+    vocoder_chain(g, in + row * g.in_row + f * g.in_f, phase_advance[f], o + row * g.out_row + f * g.out_f);
+  }
+  return 0;
+}
+
+int sim_griffinlim_update(const float* rebuilt, float* tprev, const float* mag, float* next, int64_t n, float momentum) {
+  const cplx<float>* r = reinterpret_cast<const cplx<float>*>(rebuilt);
+  cplx<float>* tp = reinterpret_cast<cplx<float>*>(tprev);
+  cplx<float>* nx = reinterpret_cast<cplx<float>*>(next);
+  for (int64_t i = 0; i < n; ++i) griffinlim_update_elem(r[i], tp[i], mag[i], momentum, nx[i]);
+  return 0;
+}
+
 int sim_istft(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,
               const aamd_stft_desc* d, int adjoint) {
   OlaGeom og{};

@@ -231,3 +231,32 @@ def sim_istft(spec_fm, window_padded, length, n_fft, hop, center=True, pad_mode=
     assert f(spec_fm.view(np.float32).ctypes.data_as(C.c_void_p), fptr(w), fptr(tw), ie, fptr(out), C.byref(desc),
              int(adjoint)) == 0
     return out
+
+
+def sim_phase_vocoder(spec, rate, phase_advance):
+    """spec: complex64 (rows, F, T) C-contiguous -> (rows, F, ceil(T / rate)), like F.phase_vocoder."""
+    import math
+    spec = np.ascontiguousarray(spec, dtype=np.complex64)
+    rows, F, T = spec.shape
+    n_out = int(math.ceil(T / rate))
+    out = np.zeros((rows, F, n_out), dtype=np.complex64)
+    pa = np.ascontiguousarray(phase_advance, dtype=np.float32).reshape(-1)
+    d = _lib.VocoderDesc(rows, F, T, n_out, F * T, T, 1, F * n_out, n_out, 1, float(rate))
+    f = sim().sim_phase_vocoder
+    f.argtypes = [C.c_void_p] * 3 + [C.POINTER(_lib.VocoderDesc)]
+    assert f(spec.view(np.float32).ctypes.data_as(C.c_void_p), fptr(pa), out.view(np.float32).ctypes.data_as(C.c_void_p),
+             C.byref(d)) == 0
+    return out
+
+
+def sim_griffinlim_update(rebuilt, tprev, mag, momentum):
+    """Returns (next, new tprev)."""
+    rebuilt = np.ascontiguousarray(rebuilt, dtype=np.complex64)
+    tprev = np.ascontiguousarray(tprev, dtype=np.complex64).copy()
+    mag = np.ascontiguousarray(mag, dtype=np.float32)
+    nxt = np.zeros_like(rebuilt)
+    f = sim().sim_griffinlim_update
+    f.argtypes = [C.c_void_p] * 4 + [C.c_int64, C.c_float]
+    vp = lambda a: a.view(np.float32).ctypes.data_as(C.c_void_p)   # noqa: E731
+    assert f(vp(rebuilt), vp(tprev), fptr(mag), vp(nxt), rebuilt.size, float(momentum)) == 0
+    return nxt, tprev

@@ -392,3 +392,34 @@ def test_sim_istft_roundtrip_and_adjoint(n_fft, hop, L):
     lhs = np.real(np.sum(Xfm * np.conj(G)))                         # <STFT x, G> as a real inner product
     rhs = np.sum(x * dx)
     assert abs(lhs - rhs) <= 2e-5 * abs(lhs)
+
+
+@pytest.mark.parametrize("name", ["pv_fast", "pv_slow", "pv_big"])
+def test_sim_phase_vocoder_vs_reference_fixture(name):
+    """CPU replay of csrc/vocoder.h's chain walker against the reference's float32 output (see the GPU test of the
+    same name for the tolerance: float32 phase sums)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "widening_goldens.npz"))
+    n_fft, hop, rate = G[f"{name}/cfg"]
+    F = int(n_fft) // 2 + 1
+    pa = torch.linspace(0, np.pi * hop, F).numpy()
+    got = S.sim_phase_vocoder(G[f"{name}/spec"], float(rate), pa)
+    ref = G[f"{name}/out"]
+    assert got.shape == ref.shape
+    assert np.abs(np.abs(got) - np.abs(ref)).max() <= 1e-5 * np.abs(ref).max()
+    d = np.abs(got - ref) / np.abs(ref).max()
+    assert d.max() <= 5e-4 and np.quantile(d, 0.999) <= 1e-4
+
+
+def test_sim_griffinlim_update_matches_formula():
+    rng = np.random.default_rng(3)
+    n = 1000
+    rebuilt = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    tprev = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    mag = rng.random(n).astype(np.float32)
+    for m in (0.0, 0.4974874):
+        nxt, tp = S.sim_griffinlim_update(rebuilt, tprev, mag, m)
+        a = rebuilt.astype(np.complex128) - m * tprev.astype(np.complex128)
+        a = a / (np.abs(a) + 1e-16)
+        assert np.abs(nxt - mag * a).max() <= 2e-6
+        assert np.array_equal(tp, rebuilt)

@@ -762,3 +762,119 @@ def test_inverse_spectrogram_vs_torch_istft(cfg):
     covered = n_fft + hop * (frames - 1) - (2 * (n_fft // 2) if center else 0) - 2 * pad
     n = min(back.shape[-1], L, covered)
     assert peak_rel_err(back[..., :n].cpu().numpy(), x[..., :n].numpy()) <= 1e-5
+
+
+def _widening():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "widening_goldens.npz"))
+
+
+@pytest.mark.parametrize("name", ["pv_fast", "pv_slow", "pv_big"])
+def test_phase_vocoder_vs_reference(name):
+    """T.TimeStretch / F.phase_vocoder (one HIP kernel) against the reference's float32 CPU output.  Magnitudes are
+    interpolated (tight); the phase is a running sum of up to ~1e5 rad held in float32, so the reference's own
+    float32 result differs from its float64 result by 2-3e-4 of the peak (stored as out64; pv_slow's float64 run
+    even picks different frames) -- the complex tolerance is that noise level, the 99.9 % quantile is 1e-4."""
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    G = _widening()
+    n_fft, hop, rate = G[f"{name}/cfg"]
+    n_fft, hop, rate = int(n_fft), int(hop), float(rate)
+    spec = torch.tensor(G[f"{name}/spec"]).cuda()
+    ref = G[f"{name}/out"]
+    with torch.no_grad():
+        t = T.TimeStretch(hop_length=hop, n_freq=n_fft // 2 + 1, fixed_rate=rate).cuda()
+        y = t(spec)
+        assert y.shape == ref.shape and y.dtype == torch.complex64 and y.is_contiguous()
+        got = y.cpu().numpy()
+        assert peak_rel_err(np.abs(got), np.abs(ref)) <= 1e-5
+        d = np.abs(got - ref) / np.abs(ref).max()
+        assert d.max() <= 5e-4 and np.quantile(d, 0.999) <= 1e-4
+        if name != "pv_slow":
+            noise = np.abs(ref - G[f"{name}/out64"]).max() / np.abs(ref).max()
+            assert d.max() <= 1.5 * noise           # no worse than float32 is for the reference itself
+        # frame-major (transposed-view) input, the layout Spectrogram returns: same bits
+        fm = spec.transpose(-1, -2).contiguous().transpose(-1, -2)
+        assert torch.equal(F.phase_vocoder(fm, rate, t.phase_advance), y)
+        assert F.phase_vocoder(spec, 1.0, t.phase_advance) is spec
+        with pytest.raises(ValueError):
+            T.TimeStretch(hop_length=hop, n_freq=n_fft // 2 + 1).cuda()(spec)
+
+
+@pytest.mark.parametrize("name", ["inv_400", "inv_512"])
+def test_inverse_spectrogram_vs_reference_fixture(name):
+    import audio_amd.transforms as T
+    G = _widening()
+    n_fft, hop, length = (int(v) for v in G[f"{name}/cfg"])
+    spec = torch.tensor(G[f"{name}/spec"]).cuda()
+    with torch.no_grad():
+        y = T.InverseSpectrogram(n_fft=n_fft, hop_length=hop).cuda()(spec, None if length < 0 else length)
+    assert y.shape == G[f"{name}/out"].shape
+    assert peak_rel_err(y.cpu().numpy(), G[f"{name}/out"]) <= 1e-5
+
+
+@pytest.mark.parametrize("name", ["gl_400", "gl_512"])
+def test_griffinlim_vs_reference(name):
+    """T.GriffinLim (rand_init=False) against the reference's float32 CPU output.  The iteration divides by |angles|,
+    so float32 rounding is amplified at weak bins: the reference's float32 and float64 runs differ by up to 5e-4
+    of the peak (out64); tolerance 2e-3, and the result must be as consistent with the magnitudes as the reference's."""
+    import audio_amd.transforms as T
+    G = _widening()
+    n_fft, hop, power, n_iter, momentum, L = G[f"{name}/cfg"]
+    spec = torch.tensor(G[f"{name}/spec"]).cuda()
+    with torch.no_grad():
+        t = T.GriffinLim(n_fft=int(n_fft), hop_length=int(hop), power=float(power), n_iter=int(n_iter),
+                         momentum=float(momentum), length=int(L), rand_init=False).cuda()
+        y = t(spec)
+        ref = G[f"{name}/out"]
+        assert y.shape == ref.shape
+        assert peak_rel_err(y.cpu().numpy(), ref) <= 2e-3
+        assert peak_rel_err(y.cpu().numpy(), G[f"{name}/out64"]) <= 2e-3
+        # spectral convergence of the reconstruction (how well |STFT(y)| matches the target magnitudes)
+        s = T.Spectrogram(n_fft=int(n_fft), hop_length=int(hop), power=float(power)).cuda()
+        sc = lambda w: float(((s(w) - spec).norm() / spec.norm()))   # noqa: E731
+        assert sc(y) <= sc(torch.tensor(ref).cuda()) * 1.01 + 1e-6
+        # random start: different phases, same fixed-point quality class
+        t2 = T.GriffinLim(n_fft=int(n_fft), hop_length=int(hop), power=float(power), n_iter=int(n_iter),
+                          momentum=float(momentum), length=int(L), rand_init=True).cuda()
+        assert t2(spec).shape == ref.shape
+    with pytest.raises(ValueError):
+        T.GriffinLim(momentum=1.0)
+
+
+@pytest.mark.parametrize("name", ["ps_up", "ps_down"])
+def test_pitch_shift_vs_reference(name):
+    """T.PitchShift / F.pitch_shift = STFT -> phase vocoder -> inverse STFT -> polyphase resampler, all HIP.  The phase
+    vocoder's float32 phase noise (see test_phase_vocoder_vs_reference) passes through: the reference's float32 and
+    float64 runs differ by 1.1e-3 / 4.5e-4 of the peak (out64); tolerance 3e-3 on the peak, 3e-4 on the 99 % quantile."""
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    G = _widening()
+    sr, n_steps = (int(v) for v in G[f"{name}/cfg"])
+    x = torch.tensor(G[f"{name}/x"]).cuda()
+    with torch.no_grad():
+        y = T.PitchShift(sr, n_steps).cuda()(x)
+        yf = F.pitch_shift(x, sr, n_steps)
+    for got, key in ((y, "out"), (yf, "out_f")):
+        ref = G[f"{name}/{key}"]
+        assert got.shape == ref.shape
+        d = np.abs(got.cpu().numpy() - ref) / np.abs(ref).max()
+        assert d.max() <= 3e-3 and np.quantile(d, 0.99) <= 3e-4
+
+
+def test_speed_and_speed_perturbation_vs_reference():
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    G = _widening()
+    x = torch.tensor(G["speed/x"]).cuda()
+    lengths = torch.tensor(G["speed/lengths"]).cuda()
+    with torch.no_grad():
+        y, yl = T.Speed(16000, 1.1).cuda()(x, lengths)
+        y2, none = F.speed(x, 16000, 1.1)
+        assert none is None
+        assert peak_rel_err(y.cpu().numpy(), G["speed/out"]) <= 1e-5
+        assert peak_rel_err(y2.cpu().numpy(), G["speed/out"]) <= 1e-5
+        assert np.array_equal(yl.cpu().numpy(), G["speed/out_lengths"])
+        torch.manual_seed(0)
+        sp = T.SpeedPerturbation(16000, [0.9, 1.0, 1.1]).cuda()
+        shapes = {tuple(sp(x)[0].shape) for _ in range(12)}
+        assert (3, 4000) in shapes and len(shapes) >= 2
