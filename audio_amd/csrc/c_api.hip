@@ -15,6 +15,7 @@
 #include "fftconv_os.h"
 #include "istft.h"
 #include "vocoder.h"
+#include "stft_pow2.h"
 #include "lfilter.h"
 #include "lfilter_wave.h"
 #include "melspec400.h"
@@ -122,10 +123,38 @@ int validate_bands(const aamd_mel_bands* b, int n_freq, MelBandsDev& mb) {
   return AAMD_OK;
 }
 
+// n_fft = 512 / 1024 / 2048, onesided: the register-resident wave FFT of stft_pow2.h
+template <int EPI, int E>
+int launch_pow2(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
+                const float* twiddle, float* out, hipStream_t s) {
+  const int64_t pairs_per_row = (g.n_frames + 1) / 2;
+  const int64_t n_pairs = g.rows * pairs_per_row;
+  if (n_pairs == 0) return AAMD_OK;
+  size_t lds = (size_t)p2::kWaves * p2::Cfg<E>::lds_complex * sizeof(p2::C32);
+  if (EPI == EPI_MEL && p2::mel_in_lds(mb.n_mels, mb.max_width))
+    lds += (size_t)p2::mel_lds_floats(mb.n_mels, mb.max_width) * sizeof(float);
+  auto kern = p2::stft_pow2_kernel<E, EPI>;
+  if (lds > 48 * 1024)
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // persistent waves: enough workgroups to fill every CU's LDS / wave slots, never more than the work
+  int64_t blocks = (int64_t)dev_props().cu_count * (E == 8 ? 6 : E == 16 ? 4 : 2);
+  const int64_t need = (n_pairs + p2::kWaves - 1) / p2::kWaves;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * p2::kWaves), lds, s, g, wav, window,
+                     reinterpret_cast<const p2::C32*>(twiddle), mb, out, pairs_per_row, n_pairs);
+  return launch_check();
+}
+
 template <int EPI>
 int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
                    const float* twiddle, float* out, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
+  if (g.onesided && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+    if (g.n_fft == 512) return launch_pow2<EPI, 8>(g, mb, wav, window, twiddle, out, s);
+    if (g.n_fft == 1024) return launch_pow2<EPI, 16>(g, mb, wav, window, twiddle, out, s);
+    if (g.n_fft == 2048) return launch_pow2<EPI, 32>(g, mb, wav, window, twiddle, out, s);
+  }
   int pb = gen_pairs_per_block(g.n_fft);
   const int pairs_per_row = (g.n_frames + 1) / 2;
   if (pb > pairs_per_row) pb = pairs_per_row;

@@ -1,0 +1,380 @@
+// Spectrogram / MelSpectrogram for power-of-two n_fft = 64 E (E = 8, 16, 32: n_fft = 512, 1024, 2048), any hop, window
+// and padding mode (functional/functional.py:112-145, transforms/_transforms.py:403-415, 612-622): the frames
+// the radix-20x20 kernel (melspec400.h) does not cover but that TTS / vocoder / librosa-style front-ends use.
+//
+// One WAVE transforms one frame pair (two real frames a, b = a + 1 packed as z = a + i b) with the whole
+// sequence in registers, E complex values per lane, and no workgroup barrier anywhere:
+//   n = l + 64 e,  k = k1 + E (k2a + 8 k2b),  l = l1 + 8 l2   (l = lane)
+//   stage A  lane l:            DFT-E over e of w[n] z[n]            -> Y[l][k1], times W_N^(l k1)
+//   exchange 1 (LDS, [k1][l], rows padded to 72): lane (k1lo, l1) gathers l2 = 0..7 for k1 = k1lo + 8 k1hi
+//   stage B  lane (k1lo, l1):   DFT-8 over l2                         -> [k2a], times W_64^(l1 k2a)
+//   exchange 2 (LDS, [g = k1 + E k2a][l1], rows padded to 9): lane g mod 64 gathers l1 = 0..7 for g = lane + 64 rhi
+//   stage C  lane:              DFT-8 over l1                         -> Z[g + 8 E k2b]
+// so the lane ends up with Z[lane + 64 j], j = 0..E-1: natural order, 64 consecutive bins per register -- the
+// output rows leave as fully coalesced stores straight from registers.  The partner bin Z[N - k] of the real-pair
+// separation comes through one more LDS pass of the upper half.  All three exchanges are conflict-free b64
+// accesses (strides 72 and 9 complex) and are ordered by the wave's own program order (LDS is in-order per wave).
+// Constants per lane (window taps, W_N^(l k1), W_64^(l1 k2a)) live in registers for the whole launch; waves are
+// persistent and stride over the frame pairs.
+#pragma once
+#include "hd.h"
+#include "stft_generic.h"
+
+namespace aamd {
+namespace p2 {
+
+constexpr int kWaves = 4;                    // waves per workgroup (independent of each other)
+constexpr int kRow1 = 72;                    // exchange-1 row stride (complex): 72 * 2 = 16 (mod 128) dwords
+constexpr int kRow2 = 9;                     // exchange-2 row stride (complex)
+
+template <int E>
+struct Cfg {
+  static constexpr int N = 64 * E;
+  static constexpr int G = E / 8;            // DFT-8 groups per lane in stages B and C
+  static constexpr int lds_complex = E * kRow1;          // = 8 E * kRow2; >= N (exchange 3), >= (N/2+1) floats x 2
+  static_assert(E == 8 || E == 16 || E == 32, "n_fft = 512, 1024 or 2048");
+  static_assert(E * kRow1 == 8 * E * kRow2, "one region serves both exchanges");
+};
+
+using C32 = cplx<float>;
+
+// cos / sin of 2 pi q / 32
+AAMD_HD constexpr float cos32(int q) {
+  constexpr float c[32] = {1.0f, 0.98078528f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f, 0.382683432f,
+                           0.195090322f, 0.0f, -0.195090322f, -0.382683432f, -0.555570233f, -0.707106781f,
+                           -0.831469612f, -0.923879533f, -0.98078528f, -1.0f, -0.98078528f, -0.923879533f,
+                           -0.831469612f, -0.707106781f, -0.555570233f, -0.382683432f, -0.195090322f, 0.0f,
+                           0.195090322f, 0.382683432f, 0.555570233f, 0.707106781f, 0.831469612f, 0.923879533f,
+                           0.98078528f};
+  return c[q & 31];
+}
+AAMD_HD constexpr float sin32(int q) { return cos32(q - 8); }
+
+// in-register forward DFT of size M (natural order in and out): decimation in time on top of bfly8
+template <int M>
+struct Dft {
+  static AAMD_HD void run(C32* v) {
+    constexpr int H = M / 2;
+    C32 e[H], o[H];
+#pragma unroll
+    for (int i = 0; i < H; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+    Dft<H>::run(e);
+    Dft<H>::run(o);
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      C32 t;
+      if (k == 0) {
+        t = o[0];
+      } else if (2 * k == H) {
+        t = C32{o[k].y, -o[k].x};                       // W_M^(M/4) = -i
+      } else {
+        const float c = cos32(k * (32 / M)), s = sin32(k * (32 / M));   // W_M^k = c - i s
+        t = C32{o[k].x * c + o[k].y * s, o[k].y * c - o[k].x * s};
+      }
+      v[k] = cadd(e[k], t);
+      v[k + H] = csub(e[k], t);
+    }
+  }
+};
+template <>
+struct Dft<8> {
+  static AAMD_HD void run(C32* v) { bfly8<float>(v); }
+};
+
+// per-lane constants
+template <int E>
+struct LaneTab {
+  float win[E];        // 0.5 * scale * window[l + 64 e]
+  C32 twA[E];          // W_N^(l k1)              (twA[0] unused)
+  C32 twB[8];          // W_64^(l1 k2a), l1 = l & 7 (twB[0] unused)
+};
+
+template <int E>
+AAMD_HD void lane_tab(int lane, const float* window, const C32* tw /* W_N^m, m < N */, float scale, LaneTab<E>& lt) {
+  constexpr int N = Cfg<E>::N;
+#pragma unroll
+  for (int e = 0; e < E; ++e) lt.win[e] = window[lane + 64 * e] * (0.5f * scale);
+#pragma unroll
+  for (int k1 = 0; k1 < E; ++k1) lt.twA[k1] = tw[(lane * k1) % N];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) lt.twB[k] = tw[(E * (lane & 7) * k) % N];
+}
+
+// ---- stage A input: z[l + 64 e] = w (a + i b) ---------------------------------------------------------
+template <int E>
+AAMD_HD void load_pair(int lane, const StftGeom& g, const float* wav_row, int64_t ta, const LaneTab<E>& lt, C32* v) {
+  constexpr int N = Cfg<E>::N;
+  const int64_t tb = ta + 1;
+  const int64_t cpad = g.center ? N / 2 : 0;
+  const int64_t ba = ta * (int64_t)g.hop - cpad - g.pad, bb = ba + g.hop;
+  const bool vb = tb < g.n_frames;
+  if (vb && ba >= 0 && bb + N <= g.length) {                     // interior pair (wave-uniform): coalesced loads
+    const float* pa = wav_row + ba;
+    const float* pb = wav_row + bb;
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = C32{(pa + 64 * e)[lane] * lt.win[e], (pb + 64 * e)[lane] * lt.win[e]};
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int n = lane + 64 * e;
+    const float a = stft_sample<float>(g, wav_row, ta, n);
+    const float b = vb ? stft_sample<float>(g, wav_row, tb, n) : 0.0f;
+    v[e] = C32{a * lt.win[e], b * lt.win[e]};
+  }
+}
+
+template <int E>
+AAMD_HD void stage_a(const LaneTab<E>& lt, C32* v) {
+  Dft<E>::run(v);
+#pragma unroll
+  for (int k1 = 1; k1 < E; ++k1) v[k1] = cmul(v[k1], lt.twA[k1]);
+}
+
+template <int E>
+AAMD_HD void xch1_write(int lane, const C32* v, C32* lds) {
+#pragma unroll
+  for (int k1 = 0; k1 < E; ++k1) lds[k1 * kRow1 + lane] = v[k1];
+}
+template <int E>
+AAMD_HD void xch1_read(int lane, const C32* lds, C32* v) {
+  const int l1 = lane & 7, k1lo = lane >> 3;
+#pragma unroll
+  for (int h = 0; h < Cfg<E>::G; ++h)
+#pragma unroll
+    for (int l2 = 0; l2 < 8; ++l2) v[8 * h + l2] = lds[(k1lo + 8 * h) * kRow1 + l1 + 8 * l2];
+}
+
+template <int E>
+AAMD_HD void stage_b(const LaneTab<E>& lt, C32* v) {
+#pragma unroll
+  for (int h = 0; h < Cfg<E>::G; ++h) {
+    bfly8<float>(v + 8 * h);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[8 * h + k] = cmul(v[8 * h + k], lt.twB[k]);
+  }
+}
+
+template <int E>
+AAMD_HD void xch2_write(int lane, const C32* v, C32* lds) {
+  const int l1 = lane & 7, k1lo = lane >> 3;
+#pragma unroll
+  for (int h = 0; h < Cfg<E>::G; ++h)
+#pragma unroll
+    for (int k2a = 0; k2a < 8; ++k2a) lds[(k1lo + 8 * h + E * k2a) * kRow2 + l1] = v[8 * h + k2a];
+}
+template <int E>
+AAMD_HD void xch2_read(int lane, const C32* lds, C32* v) {
+#pragma unroll
+  for (int r = 0; r < Cfg<E>::G; ++r)
+#pragma unroll
+    for (int l1 = 0; l1 < 8; ++l1) v[8 * r + l1] = lds[(lane + 64 * r) * kRow2 + l1];
+}
+
+// stage C: z[j] = Z[lane + 64 j]
+template <int E>
+AAMD_HD void stage_c(C32* v, C32* z) {
+  constexpr int G = Cfg<E>::G;
+#pragma unroll
+  for (int r = 0; r < G; ++r) {
+    bfly8<float>(v + 8 * r);
+#pragma unroll
+    for (int k2b = 0; k2b < 8; ++k2b) z[r + G * k2b] = v[8 * r + k2b];
+  }
+}
+
+// exchange 3: upper half in natural order, then the partner Z[N - k] of every bin this lane finishes
+template <int E>
+AAMD_HD void xch3_write(int lane, const C32* z, C32* lds) {
+#pragma unroll
+  for (int j = E / 2; j < E; ++j) lds[lane + 64 * j] = z[j];
+}
+// A, B = the two real spectra at bin k (the 0.5 * scale factor is already in the window)
+AAMD_HD void separate(C32 zk, C32 zm, C32& A, C32& B) {
+  A = C32{zk.x + zm.x, zk.y - zm.y};        // (Z[k] + conj Z[N-k])
+  B = C32{zk.y + zm.y, zm.x - zk.x};        // (Z[k] - conj Z[N-k]) / i
+}
+// bins of this lane: k = lane + 64 j, j < E/2, plus k = N/2 on lane 0 (slot E/2)
+template <int E>
+AAMD_HD void finish_bins(int lane, const C32* z, const C32* lds, C32* A, C32* B) {
+  constexpr int N = Cfg<E>::N;
+#pragma unroll
+  for (int j = 0; j < E / 2; ++j) {
+    const int k = lane + 64 * j;
+    const C32 zm = (k == 0) ? z[0] : lds[N - k];
+    separate(z[j], zm, A[j], B[j]);
+  }
+  separate(z[E / 2], z[E / 2], A[E / 2], B[E / 2]);     // k = N/2 (meaningful on lane 0 only)
+}
+
+// ---- epilogues ---------------------------------------------------------------------------------------
+template <int E>
+AAMD_HD void store_spec(int lane, const StftGeom& g, const C32* A, const C32* B, int64_t ta, float* out_row) {
+  constexpr int N = Cfg<E>::N;
+  const bool vb = ta + 1 < g.n_frames;
+  if (g.power <= 0.0f) {                                   // complex: interleaved (re, im)
+    C32* oa = reinterpret_cast<C32*>(out_row + ta * (int64_t)(N + 2));
+    C32* ob = oa + (N / 2 + 1);
+#pragma unroll
+    for (int j = 0; j < E / 2; ++j) {
+      (oa + 64 * j)[lane] = A[j];
+      if (vb) (ob + 64 * j)[lane] = B[j];
+    }
+    if (lane == 0) {
+      oa[N / 2] = A[E / 2];
+      if (vb) ob[N / 2] = B[E / 2];
+    }
+    return;
+  }
+  float* oa = out_row + ta * (int64_t)(N / 2 + 1);
+  float* ob = oa + (N / 2 + 1);
+#pragma unroll
+  for (int j = 0; j < E / 2; ++j) {
+    (oa + 64 * j)[lane] = mag_pow(A[j].x, A[j].y, g.power);
+    if (vb) (ob + 64 * j)[lane] = mag_pow(B[j].x, B[j].y, g.power);
+  }
+  if (lane == 0) {
+    oa[N / 2] = mag_pow(A[E / 2].x, A[E / 2].y, g.power);
+    if (vb) ob[N / 2] = mag_pow(B[E / 2].x, B[E / 2].y, g.power);
+  }
+}
+
+// power rows of the pair in LDS, interleaved per bin: P[k] = (|A[k]|^p, |B[k]|^p), one zero entry after the last bin
+template <int E>
+AAMD_HD void power_rows(int lane, const StftGeom& g, const C32* A, const C32* B, F2* P /* [N/2 + 2] */) {
+  constexpr int F = Cfg<E>::N / 2 + 1;
+#pragma unroll
+  for (int j = 0; j < E / 2; ++j) {
+    F2 p;
+    p.x = mag_pow(A[j].x, A[j].y, g.power);
+    p.y = mag_pow(B[j].x, B[j].y, g.power);
+    P[lane + 64 * j] = p;
+  }
+  if (lane == 0) {
+    F2 p;
+    p.x = mag_pow(A[E / 2].x, A[E / 2].y, g.power);
+    p.y = mag_pow(B[E / 2].x, B[E / 2].y, g.power);
+    P[F - 1] = p;
+    p.x = 0.0f; p.y = 0.0f;
+    P[F] = p;
+  }
+}
+
+// Banded filterbank staged in LDS once per workgroup (dense rows, odd stride, zero padded so that a band can be
+// walked two taps at a time): [n_mels][mel_stride] weights, then lo[n_mels], width[n_mels].  Used when it fits
+// kMelLdsBytes; otherwise the rows are read from global memory, tap by tap.
+constexpr int kMelLdsBytes = 32 * 1024;
+AAMD_HD int mel_stride(int max_width) { return (max_width + 2) | 1; }
+AAMD_HD int mel_lds_floats(int n_mels, int max_width) { return n_mels * mel_stride(max_width) + 2 * n_mels; }
+AAMD_HD bool mel_in_lds(int n_mels, int max_width) {
+  return (size_t)mel_lds_floats(n_mels, max_width) * sizeof(float) <= (size_t)kMelLdsBytes;
+}
+AAMD_HD void mel_stage(int tid, int nthr, const MelBandsDev& mb, float* tab) {
+  const int ms = mel_stride(mb.max_width);
+  for (int i = tid; i < mb.n_mels * ms; i += nthr) {
+    const int m = i / ms, j = i - m * ms;
+    tab[i] = j < mb.max_width ? mb.weights[(int64_t)m * mb.max_width + j] : 0.0f;
+  }
+  int* lo = reinterpret_cast<int*>(tab + mb.n_mels * ms);
+  for (int m = tid; m < mb.n_mels; m += nthr) { lo[m] = mb.lo[m]; lo[mb.n_mels + m] = mb.width[m]; }
+}
+
+// out[t][m] = sum_i w[m][i] P[t][lo[m] + i] for both frames of the pair: lane -> mel (neighbouring lanes hold
+// neighbouring mels: similar band widths, and the two output rows leave as coalesced stores)
+template <int E>
+AAMD_HD void mel_rows(int lane, const StftGeom& g, const MelBandsDev& mb, const float* tab /* LDS table or null */,
+                      const F2* P, int64_t ta, float* out_row) {
+  const bool vb = ta + 1 < g.n_frames;
+  for (int m = lane; m < mb.n_mels; m += 64) {
+    float acc_a = 0.0f, acc_b = 0.0f;
+    if (tab) {
+      const int ms = mel_stride(mb.max_width);
+      const int* lo_tab = reinterpret_cast<const int*>(tab + mb.n_mels * ms);
+      const int lo = lo_tab[m], w = lo_tab[mb.n_mels + m];
+      const float* wt = tab + m * ms;
+      const F2* Pf = P + lo;
+      for (int i = 0; i < w; i += 2) {               // the table and P are zero padded past the band
+        const F2 p0 = Pf[i], p1 = Pf[i + 1];
+        const float w0 = wt[i], w1 = wt[i + 1];
+        acc_a += w0 * p0.x; acc_b += w0 * p0.y;
+        acc_a += w1 * p1.x; acc_b += w1 * p1.y;
+      }
+    } else {
+      const int lo = mb.lo[m], w = mb.width[m];
+      const float* wt = mb.weights + (int64_t)m * mb.max_width;
+      for (int i = 0; i < w; ++i) {
+        const F2 p = P[lo + i];
+        acc_a += wt[i] * p.x; acc_b += wt[i] * p.y;
+      }
+    }
+    out_row[ta * (int64_t)mb.n_mels + m] = acc_a;
+    if (vb) out_row[(ta + 1) * (int64_t)mb.n_mels + m] = acc_b;
+  }
+}
+
+#if defined(__HIPCC__)
+AAMD_D void wave_lds_sync() {     // program order within the wave is the only ordering these exchanges need
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int E, int EPI>
+__global__ void __launch_bounds__(64 * kWaves)
+stft_pow2_kernel(StftGeom g, const float* __restrict__ wav, const float* __restrict__ window,
+                 const C32* __restrict__ tw, MelBandsDev mb, float* __restrict__ out, int64_t pairs_per_row,
+                 int64_t n_pairs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_p2[];
+  constexpr int N = Cfg<E>::N;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  C32* lds = reinterpret_cast<C32*>(smem_p2) + wave * Cfg<E>::lds_complex;
+  const float* mel_tab = nullptr;
+  if (EPI == EPI_MEL && mel_in_lds(mb.n_mels, mb.max_width)) {
+    float* tab = reinterpret_cast<float*>(reinterpret_cast<C32*>(smem_p2) + kWaves * Cfg<E>::lds_complex);
+    mel_stage(threadIdx.x, blockDim.x, mb, tab);
+    __syncthreads();                       // the only workgroup barrier: before the persistent loop
+    mel_tab = tab;
+  }
+  LaneTab<E> lt;
+  lane_tab<E>(lane, window, tw, g.scale, lt);
+  const int64_t n_waves = (int64_t)gridDim.x * kWaves;
+  const int opf = (EPI == EPI_MEL) ? mb.n_mels : (g.power <= 0.0f ? N + 2 : N / 2 + 1);
+#pragma unroll 1
+  for (int64_t pair = (int64_t)blockIdx.x * kWaves + wave; pair < n_pairs; pair += n_waves) {
+    const int64_t row = pair / pairs_per_row;
+    const int64_t ta = 2 * (pair - row * pairs_per_row);
+    C32 v[E], z[E];
+    load_pair<E>(lane, g, wav + row * g.row_stride, ta, lt, v);
+    stage_a<E>(lt, v);
+    wave_lds_sync();                       // the previous pair's epilogue reads are done
+    xch1_write<E>(lane, v, lds);
+    wave_lds_sync();
+    xch1_read<E>(lane, lds, v);
+    stage_b<E>(lt, v);
+    wave_lds_sync();
+    xch2_write<E>(lane, v, lds);
+    wave_lds_sync();
+    xch2_read<E>(lane, lds, v);
+    stage_c<E>(v, z);
+    wave_lds_sync();
+    xch3_write<E>(lane, z, lds);
+    wave_lds_sync();
+    C32 A[E / 2 + 1], B[E / 2 + 1];
+    finish_bins<E>(lane, z, lds, A, B);
+    float* out_row = out + row * g.n_frames * (int64_t)opf;
+    if (EPI == EPI_SPEC) {
+      store_spec<E>(lane, g, A, B, ta, out_row);
+    } else {
+      wave_lds_sync();
+      F2* P = reinterpret_cast<F2*>(lds);
+      power_rows<E>(lane, g, A, B, P);
+      wave_lds_sync();
+      mel_rows<E>(lane, g, mb, mel_tab, P, ta, out_row);
+    }
+  }
+}
+#endif  // __HIPCC__
+
+}  // namespace p2
+}  // namespace aamd

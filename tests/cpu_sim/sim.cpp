@@ -15,6 +15,7 @@
 #include "../../audio_amd/csrc/fftconv_os.h"
 #include "../../audio_amd/csrc/istft.h"
 #include "../../audio_amd/csrc/vocoder.h"
+#include "../../audio_amd/csrc/stft_pow2.h"
 #include "../../audio_amd/csrc/lfilter.h"
 #include "../../audio_amd/csrc/lfilter_wave.h"
 #include "../../audio_amd/csrc/melspec400.h"
@@ -31,6 +32,48 @@ static void fill_geom(const aamd_stft_desc* d, StftGeom& g) {
   g.n_freq = d->onesided ? d->n_fft / 2 + 1 : d->n_fft;
   g.scale = d->scale; g.power = d->power;
   g.n_stages = plan_radices(d->n_fft, g.radix);
+}
+
+// stft_pow2_kernel: one "wave" of 64 lanes per frame pair, phases separated where the kernel has wave_lds_sync()
+template <int E>
+static int sim_pow2_e(const float* wav, const float* window, const float* tw, const MelBandsDev& mb, float* out,
+                      const StftGeom& g, int epi_mel) {
+  using namespace p2;
+  constexpr int N = Cfg<E>::N;
+  const C32* twc = reinterpret_cast<const C32*>(tw);
+  std::vector<LaneTab<E>> lt(64);
+  for (int l = 0; l < 64; ++l) lane_tab<E>(l, window, twc, g.scale, lt[l]);
+  std::vector<C32> lds(Cfg<E>::lds_complex);
+  std::vector<std::array<C32, E>> v(64), z(64);
+  std::vector<std::array<C32, E / 2 + 1>> A(64), B(64);
+  const int64_t ppr = (g.n_frames + 1) / 2;
+  const int opf = epi_mel ? mb.n_mels : (g.power <= 0.0f ? N + 2 : N / 2 + 1);
+  std::vector<float> tab;
+  const float* mel_tab = nullptr;
+  if (epi_mel && mel_in_lds(mb.n_mels, mb.max_width)) {
+    tab.resize(mel_lds_floats(mb.n_mels, mb.max_width));
+    for (int t = 0; t < 256; ++t) mel_stage(t, 256, mb, tab.data());
+    mel_tab = tab.data();
+  }
+  for (int64_t pair = 0; pair < g.rows * ppr; ++pair) {
+    const int64_t row = pair / ppr, ta = 2 * (pair - row * ppr);
+    for (int l = 0; l < 64; ++l) { load_pair<E>(l, g, wav + row * g.row_stride, ta, lt[l], v[l].data()); stage_a<E>(lt[l], v[l].data()); }
+    for (int l = 0; l < 64; ++l) xch1_write<E>(l, v[l].data(), lds.data());
+    for (int l = 0; l < 64; ++l) { xch1_read<E>(l, lds.data(), v[l].data()); stage_b<E>(lt[l], v[l].data()); }
+    for (int l = 0; l < 64; ++l) xch2_write<E>(l, v[l].data(), lds.data());
+    for (int l = 0; l < 64; ++l) { xch2_read<E>(l, lds.data(), v[l].data()); stage_c<E>(v[l].data(), z[l].data()); }
+    for (int l = 0; l < 64; ++l) xch3_write<E>(l, z[l].data(), lds.data());
+    for (int l = 0; l < 64; ++l) finish_bins<E>(l, z[l].data(), lds.data(), A[l].data(), B[l].data());
+    float* out_row = out + row * g.n_frames * (int64_t)opf;
+    if (!epi_mel) {
+      for (int l = 0; l < 64; ++l) store_spec<E>(l, g, A[l].data(), B[l].data(), ta, out_row);
+    } else {
+      F2* P = reinterpret_cast<F2*>(lds.data());
+      for (int l = 0; l < 64; ++l) power_rows<E>(l, g, A[l].data(), B[l].data(), P);
+      for (int l = 0; l < 64; ++l) mel_rows<E>(l, g, mb, mel_tab, P, ta, out_row);
+    }
+  }
+  return 0;
 }
 
 extern "C" {
@@ -74,6 +117,19 @@ int sim_stft_generic(const float* wav, const float* window, const float* tw, con
 }
 
 // Replay of ola_kernel (inverse STFT / STFT adjoint): same launcher logic as aamd_istft_f32.
+int sim_stft_pow2(const float* wav, const float* window, const float* tw, const aamd_mel_bands* bands, float* out,
+                  const aamd_stft_desc* d) {
+  StftGeom g{};
+  fill_geom(d, g);
+  MelBandsDev mb{};
+  if (bands) { mb.n_mels = bands->n_mels; mb.max_width = bands->max_width; mb.lo = bands->lo; mb.width = bands->width; mb.weights = bands->weights; }
+  if (!g.onesided) return -1;
+  if (g.n_fft == 512) return sim_pow2_e<8>(wav, window, tw, mb, out, g, bands != nullptr);
+  if (g.n_fft == 1024) return sim_pow2_e<16>(wav, window, tw, mb, out, g, bands != nullptr);
+  if (g.n_fft == 2048) return sim_pow2_e<32>(wav, window, tw, mb, out, g, bands != nullptr);
+  return -2;
+}
+
 // phase_vocoder_kernel / griffinlim_update_kernel: one chain / element per "thread"
 int sim_phase_vocoder(const float* spec, const float* phase_advance, float* out, const aamd_vocoder_desc* d) {
   VocoderGeom g{d->rows, d->n_freq, d->n_frames_in, d->n_frames_out, d->in_stride_row, d->in_stride_freq,

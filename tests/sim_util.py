@@ -260,3 +260,23 @@ def sim_griffinlim_update(rebuilt, tprev, mag, momentum):
     vp = lambda a: a.view(np.float32).ctypes.data_as(C.c_void_p)   # noqa: E731
     assert f(vp(rebuilt), vp(tprev), fptr(mag), vp(nxt), rebuilt.size, float(momentum)) == 0
     return nxt, tprev
+
+
+def sim_stft_pow2(x, window_padded, desc, bands=None):
+    """stft_pow2.h replay (n_fft = 512 / 1024 / 2048, onesided).  Returns (rows, F or n_mels, T) like the modules."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(window_padded, dtype=np.float32)
+    tw = np.ascontiguousarray(_host.twiddle_table(desc.n_fft))
+    n_freq = desc.n_fft // 2 + 1
+    comp = 2 if (bands is None and desc.power <= 0) else 1
+    width = bands.n_mels if bands is not None else n_freq * comp
+    out = np.zeros((desc.rows, desc.n_frames, width), dtype=np.float32)
+    f = sim().sim_stft_pow2
+    f.argtypes = [C.c_void_p] * 3 + [C.c_void_p, C.c_void_p, C.POINTER(_lib.StftDesc)]
+    rc = f(fptr(x), fptr(w), fptr(tw), None if bands is None else C.cast(C.byref(bands.struct), C.c_void_p), fptr(out),
+           C.byref(desc))
+    assert rc == 0
+    if comp == 2:
+        out = out.reshape(desc.rows, desc.n_frames, n_freq, 2)
+        out = out[..., 0] + 1j * out[..., 1]
+    return np.swapaxes(out, -1, -2)

@@ -423,3 +423,51 @@ def test_sim_griffinlim_update_matches_formula():
         a = a / (np.abs(a) + 1e-16)
         assert np.abs(nxt - mag * a).max() <= 2e-6
         assert np.array_equal(tp, rebuilt)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_fft=512, hop=128, L=3000, power=2.0),
+    dict(n_fft=512, hop=160, L=2222, power=None, pad_mode="constant"),
+    dict(n_fft=512, hop=200, win_length=400, L=1800, power=1.0, normalized=True),
+    dict(n_fft=1024, hop=256, L=5000, power=2.0, center=False),
+    dict(n_fft=1024, hop=300, L=4100, power=None, pad=77),
+    dict(n_fft=2048, hop=512, L=9000, power=2.0, pad_mode="replicate"),
+    dict(n_fft=512, hop=128, L=300, power=2.0, pad_mode="circular"),         # shorter than a frame: every frame is an edge frame
+])
+def test_sim_stft_pow2_vs_torch_stft(cfg):
+    """CPU replay of the register-resident wave FFT (csrc/stft_pow2.h) against torch.stft in float64 (the call
+    functional/functional.py:123-134 makes)."""
+    n_fft, hop, L, power = cfg["n_fft"], cfg["hop"], cfg["L"], cfg["power"]
+    wl = cfg.get("win_length", n_fft)
+    pad, center, pad_mode = cfg.get("pad", 0), cfg.get("center", True), cfg.get("pad_mode", "reflect")
+    g = torch.Generator().manual_seed(n_fft + hop + L)
+    x = 0.5 * torch.randn(3, L, generator=g, dtype=torch.float64)
+    w = torch.hann_window(wl, dtype=torch.float64)
+    xp = torch.nn.functional.pad(x, (pad, pad)) if pad else x
+    ref = torch.stft(xp, n_fft, hop, wl, w, center, pad_mode, False, True, return_complex=True)
+    scale = 1.0
+    if cfg.get("normalized"):
+        scale = 1.0 / float(w.pow(2).sum().sqrt())
+        ref = ref * scale
+    if power is not None:
+        ref = ref.abs().pow(power)
+    wp = _host.center_pad_window(w.float(), n_fft).numpy()
+    d = S.make_desc(3, L, n_fft, hop, pad, center, pad_mode, True, scale, power)
+    got = S.sim_stft_pow2(x.float().numpy(), wp, d)
+    assert got.shape == tuple(ref.shape)
+    assert peak_rel_err(got, ref.numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels", [(512, 160, 80), (1024, 256, 128), (2048, 512, 40)])
+def test_sim_mel_pow2_vs_reference_composition(n_fft, hop, n_mels):
+    from oracle import torch_cpu_ref as R
+    g = torch.Generator().manual_seed(n_fft)
+    x = 0.5 * torch.randn(2, 6000, generator=g, dtype=torch.float64)
+    fb = _host.melscale_fbanks(n_fft // 2 + 1, 0.0, 8000.0, n_mels, 16000, None, "htk")
+    ref = R.mel_spectrogram(x, torch.hann_window(n_fft, dtype=torch.float64), fb.double(), n_fft, hop)
+    bands = S.HostBands(fb.numpy())
+    wp = torch.hann_window(n_fft).numpy()
+    d = S.make_desc(2, 6000, n_fft, hop, 0, True, "reflect", True, 1.0, 2.0)
+    got = S.sim_stft_pow2(x.float().numpy(), wp, d, bands)
+    assert got.shape == tuple(ref.shape)
+    assert peak_rel_err(got, ref.numpy()) <= 2e-6
