@@ -137,8 +137,9 @@ int launch_pow2(const StftGeom& g, const MelBandsDev& mb, const float* wav, cons
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  // persistent waves: enough workgroups to fill every CU's LDS / wave slots, never more than the work
-  int64_t blocks = (int64_t)dev_props().cu_count * (E == 8 ? 6 : E == 16 ? 4 : 2);
+  // persistent waves striding over the pairs; workgroups per CU measured best on 256 x 10 s (among 2..16):
+  // 4 / 2 / 1 workgroups of 4 waves are resident at 126 / 204 / 256 VGPRs, the grid is two resident rounds
+  int64_t blocks = (int64_t)dev_props().cu_count * (E == 8 ? 8 : E == 16 ? 4 : 2);
   const int64_t need = (n_pairs + p2::kWaves - 1) / p2::kWaves;
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * p2::kWaves), lds, s, g, wav, window,

@@ -101,8 +101,9 @@ AAMD_HD void lane_tab(int lane, const float* window, const C32* tw /* W_N^m, m <
 }
 
 // ---- stage A input: z[l + 64 e] = w (a + i b) ---------------------------------------------------------
+// raw samples of the pair (no window yet): the kernel fetches them one pair ahead
 template <int E>
-AAMD_HD void load_pair(int lane, const StftGeom& g, const float* wav_row, int64_t ta, const LaneTab<E>& lt, C32* v) {
+AAMD_HD void load_raw(int lane, const StftGeom& g, const float* wav_row, int64_t ta, float* ra, float* rb) {
   constexpr int N = Cfg<E>::N;
   const int64_t tb = ta + 1;
   const int64_t cpad = g.center ? N / 2 : 0;
@@ -112,16 +113,26 @@ AAMD_HD void load_pair(int lane, const StftGeom& g, const float* wav_row, int64_
     const float* pa = wav_row + ba;
     const float* pb = wav_row + bb;
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = C32{(pa + 64 * e)[lane] * lt.win[e], (pb + 64 * e)[lane] * lt.win[e]};
+    for (int e = 0; e < E; ++e) { ra[e] = (pa + 64 * e)[lane]; rb[e] = (pb + 64 * e)[lane]; }
     return;
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int n = lane + 64 * e;
-    const float a = stft_sample<float>(g, wav_row, ta, n);
-    const float b = vb ? stft_sample<float>(g, wav_row, tb, n) : 0.0f;
-    v[e] = C32{a * lt.win[e], b * lt.win[e]};
+    ra[e] = stft_sample<float>(g, wav_row, ta, n);
+    rb[e] = vb ? stft_sample<float>(g, wav_row, tb, n) : 0.0f;
   }
+}
+template <int E>
+AAMD_HD void apply_window(const LaneTab<E>& lt, const float* ra, const float* rb, C32* v) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) v[e] = C32{ra[e] * lt.win[e], rb[e] * lt.win[e]};
+}
+template <int E>
+AAMD_HD void load_pair(int lane, const StftGeom& g, const float* wav_row, int64_t ta, const LaneTab<E>& lt, C32* v) {
+  float ra[E], rb[E];
+  load_raw<E>(lane, g, wav_row, ta, ra, rb);
+  apply_window<E>(lt, ra, rb, v);
 }
 
 template <int E>
@@ -340,12 +351,28 @@ stft_pow2_kernel(StftGeom g, const float* __restrict__ wav, const float* __restr
   lane_tab<E>(lane, window, tw, g.scale, lt);
   const int64_t n_waves = (int64_t)gridDim.x * kWaves;
   const int opf = (EPI == EPI_MEL) ? mb.n_mels : (g.power <= 0.0f ? N + 2 : N / 2 + 1);
+  constexpr bool kPrefetch = E <= 16;        // E = 32 has no registers to spare
+  float ra[E], rb[E];
+  const int64_t pair0 = (int64_t)blockIdx.x * kWaves + wave;
+  if (kPrefetch && pair0 < n_pairs) {
+    const int64_t row = pair0 / pairs_per_row;
+    load_raw<E>(lane, g, wav + row * g.row_stride, 2 * (pair0 - row * pairs_per_row), ra, rb);
+  }
 #pragma unroll 1
-  for (int64_t pair = (int64_t)blockIdx.x * kWaves + wave; pair < n_pairs; pair += n_waves) {
+  for (int64_t pair = pair0; pair < n_pairs; pair += n_waves) {
     const int64_t row = pair / pairs_per_row;
     const int64_t ta = 2 * (pair - row * pairs_per_row);
     C32 v[E], z[E];
-    load_pair<E>(lane, g, wav + row * g.row_stride, ta, lt, v);
+    if (kPrefetch) {
+      apply_window<E>(lt, ra, rb, v);
+      const int64_t nxt = pair + n_waves;                       // in flight during this pair's FFT
+      if (nxt < n_pairs) {
+        const int64_t nrow = nxt / pairs_per_row;
+        load_raw<E>(lane, g, wav + nrow * g.row_stride, 2 * (nxt - nrow * pairs_per_row), ra, rb);
+      }
+    } else {
+      load_pair<E>(lane, g, wav + row * g.row_stride, ta, lt, v);
+    }
     stage_a<E>(lt, v);
     wave_lds_sync();                       // the previous pair's epilogue reads are done
     xch1_write<E>(lane, v, lds);

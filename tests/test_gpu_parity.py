@@ -878,3 +878,44 @@ def test_speed_and_speed_perturbation_vs_reference():
         sp = T.SpeedPerturbation(16000, [0.9, 1.0, 1.1]).cuda()
         shapes = {tuple(sp(x)[0].shape) for _ in range(12)}
         assert (3, 4000) in shapes and len(shapes) >= 2
+
+
+@pytest.mark.parametrize("n_fft,hop", [(512, 128), (512, 160), (1024, 256), (1024, 411), (2048, 512)])
+def test_pow2_wave_fft_equals_generic_and_torch_stft(n_fft, hop):
+    """The register-resident wave FFT (csrc/stft_pow2.h; n_fft = 512 / 1024 / 2048) against the generic Stockham
+    kernel and torch.stft in float64 on the CPU: power, magnitude, complex and mel outputs, every padding mode,
+    ragged lengths (odd frame counts, rows shorter than a frame)."""
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(n_fft + hop)
+    w64 = torch.hann_window(n_fft, dtype=torch.float64)
+    for L, pad_mode, center in ((n_fft // 2 + 3, "reflect", True), (3 * n_fft + 17, "reflect", True),
+                                (5 * n_fft, "constant", True), (4 * n_fft + 1, "replicate", True),
+                                (2 * n_fft + 100, "circular", True), (6 * n_fft + 5, "reflect", False)):
+        x = torch.randn(3, L, generator=g).clamp_(-1, 1)
+        xc = x.cuda()
+        ref = torch.stft(x.double(), n_fft, hop, n_fft, w64, center, pad_mode, False, True, return_complex=True)
+        for power in (2.0, 1.0, None):
+            t = T.Spectrogram(n_fft=n_fft, hop_length=hop, power=power, center=center, pad_mode=pad_mode).cuda()
+            fast = t(xc)
+            gen = _force_generic(lambda: t(xc))
+            assert fast.shape == gen.shape == ref.shape and fast.stride() == gen.stride()
+            if power is None:
+                exp = torch.view_as_real(ref).numpy()
+                got, gg = torch.view_as_real(fast).cpu().numpy(), torch.view_as_real(gen).cpu().numpy()
+            else:
+                exp = ref.abs().pow(power).numpy()
+                got, gg = fast.cpu().numpy(), gen.cpu().numpy()
+            assert peak_rel_err(got, gg) <= 3e-6, (L, pad_mode, power)
+            assert peak_rel_err(got, exp) <= 1e-5, (L, pad_mode, power)
+        if center and pad_mode == "reflect":
+            m = T.MelSpectrogram(sample_rate=16000, n_fft=n_fft, hop_length=hop, n_mels=96, normalized=True).cuda()
+            fast = m(xc)
+            gen = _force_generic(lambda: m(xc))
+            assert fast.shape == gen.shape and fast.stride() == gen.stride()
+            assert peak_rel_err(fast.cpu().numpy(), gen.cpu().numpy()) <= 3e-6
+            exp = torch.matmul((ref / w64.pow(2).sum().sqrt()).abs().pow(2).transpose(-1, -2), m.mel_scale.fb.cpu().double())
+            assert peak_rel_err(fast.cpu().numpy(), exp.transpose(-1, -2).numpy()) <= 1e-5
+    # wide filterbank (does not fit the LDS table): weights are read from global memory
+    m = T.MelSpectrogram(sample_rate=48000, n_fft=n_fft, hop_length=hop, n_mels=24, f_min=20.0).cuda()
+    x = torch.randn(2, 4 * n_fft, generator=g).clamp_(-1, 1).cuda()
+    assert peak_rel_err(m(x).cpu().numpy(), _force_generic(lambda: m(x)).cpu().numpy()) <= 3e-6

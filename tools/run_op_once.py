@@ -26,6 +26,12 @@ if op == "mel":
 elif op == "spec":
     x, t = noise(256, 160000), T.Spectrogram(n_fft=400, hop_length=160).to(dev)
     fn = lambda: t(x)
+elif op == "spec512":
+    x, t = noise(256, 160000), T.Spectrogram(n_fft=512, hop_length=128).to(dev)
+    fn = lambda: t(x)
+elif op == "mel1024":
+    x, t = noise(256, 160000), T.MelSpectrogram(sample_rate=16000, n_fft=1024, hop_length=256, n_mels=128).to(dev)
+    fn = lambda: t(x)
 elif op == "mfcc":
     x = noise(512, 160000)
     t = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).to(dev)
