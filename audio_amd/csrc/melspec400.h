@@ -327,25 +327,33 @@ AAMD_HD void gather_global(const LaneConst& c, const float* wav_row, int64_t len
 //   A frame b beyond the end of the clip is NOT zeroed here (that cost 20 selects per tile): its
 //   spectrum is garbage that no store path writes (store_direct / store_wide / store_spec mask by
 //   frame) and that the dB epilogue excludes from the running maximum.
-template <int H>
-AAMD_HD void phase_a(const LaneConst& c, const float (&X)[Hop<H>::nx], float* lds) {
+template <int H, bool WREG = false, bool TREG = false>
+AAMD_HD void phase_a(const LaneConst& c, const float (&X)[Hop<H>::nx], float* lds, const float* winr = nullptr,
+                     const float* twr = nullptr) {
   float xr[20], xi[20], yr[20], yi[20];
+  if (WREG) {                           // lab: window taps held in registers instead of the LDS table
 #pragma unroll
-  for (int q4 = 0; q4 < 5; ++q4) {
-    const F4 w = *reinterpret_cast<const F4*>(c.win + 4 * q4);
-    const float wv[4] = {w.x, w.y, w.z, w.w};
+    for (int q = 0; q < 20; ++q) { xr[q] = X[q] * winr[q]; xi[q] = X[q + H] * winr[q]; }
+  } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int q = 4 * q4 + e;
-      xr[q] = X[q] * wv[e];
-      xi[q] = X[q + H] * wv[e];
+    for (int q4 = 0; q4 < 5; ++q4) {
+      const F4 w = *reinterpret_cast<const F4*>(c.win + 4 * q4);
+      const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = 4 * q4 + e;
+        xr[q] = X[q] * wv[e];
+        xi[q] = X[q + H] * wv[e];
+      }
     }
   }
   dft20(xr, xi, yr, yi);
   float* colp = lds + kTPair * c.p + 2 * c.pi;
 #pragma unroll
   for (int s2 = 0; s2 < 10; ++s2) {
-    const F4 t = *reinterpret_cast<const F4*>(c.tw + 4 * s2);   // W^(b * 2 s2), W^(b * (2 s2 + 1))
+    F4 t;
+    if (TREG) { t.x = twr[4 * s2]; t.y = twr[4 * s2 + 1]; t.z = twr[4 * s2 + 2]; t.w = twr[4 * s2 + 3]; }
+    else t = *reinterpret_cast<const F4*>(c.tw + 4 * s2);   // W^(b * 2 s2), W^(b * (2 s2 + 1))
     const int s = 2 * s2;
     float v0r = yr[s], v0i = yi[s];
     if (s != 0) {
@@ -707,6 +715,15 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
   if (LAB & 1024) lab_t1 = wall_clock64();
   LaneConst c;
   lane_init(lane, const_tab, c);
+  float winr[20], twr[40];             // lab bits 8192 / 16384: constants in registers instead of LDS reads
+  if (LAB & 8192) {
+#pragma unroll
+    for (int q = 0; q < 20; ++q) winr[q] = c.win[q];
+  }
+  if (LAB & 16384) {
+#pragma unroll
+    for (int q = 0; q < 40; ++q) twr[q] = c.tw[q];
+  }
   const unsigned long long self_mask = __ballot((c.col == 0) || (c.col == 10));   // wave-uniform (SGPR pair)
   int spiece[HC::ndma];   // tile piece fetched by this lane in DMA instruction k
 #pragma unroll
@@ -797,7 +814,7 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     } else {
       gather_global<H>(c, wav + cur.row * row_stride, length, cur.t0, n_frames, X);
     }
-    phase_a<H>(c, X, lds);
+    phase_a<H, (LAB & 8192) != 0, (LAB & 16384) != 0>(c, X, lds, winr, twr);
     wave_lds_fence();
     float vr[20], vi[20], zr[20], zi[20], qr[10], qi[10];
     phase_b1_load(c, lds, vr, vi);

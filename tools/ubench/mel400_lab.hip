@@ -136,6 +136,19 @@ int main(int argc, char** argv) {
     if (FILE* f = fopen("tools/ubench/order80.txt", "r")) { int v; while (fscanf(f, "%d", &v) == 1) ord.push_back(v); fclose(f); }
     int* dord = nullptr;
     if ((int)ord.size() == 80) { CK(hipMalloc(&dord, 320)); CK(hipMemcpy(dord, ord.data(), 320, hipMemcpyHostToDevice)); mbo.order = dord; }
+    {   // A/B: constants in registers (LAB 8192 window, 16384 twiddles) vs LDS tables
+      std::vector<float> r[4];
+      for (int rep = 0; rep < 9; ++rep) {
+        r[0].push_back(run<0>("", blocks, lds, dx, dwin, dtw, mbo, dout, rows, L, T, 30, 1, 0));
+        r[1].push_back(run<8192>("", blocks, lds, dx, dwin, dtw, mbo, dout, rows, L, T, 30, 1, 0));
+        r[2].push_back(run<16384>("", blocks, lds, dx, dwin, dtw, mbo, dout, rows, L, T, 30, 1, 0));
+        r[3].push_back(run<8192 + 16384>("", blocks, lds, dx, dwin, dtw, mbo, dout, rows, L, T, 30, 1, 0));
+      }
+      const char* nr[4] = {"LDS tables (product)", "window in registers", "twiddles in registers", "both in registers"};
+      for (int i = 0; i < 4; ++i) { std::sort(r[i].begin(), r[i].end()); printf("A/B median %-28s %7.1f us (min %.1f max %.1f)\n", nr[i], r[i][4], r[i].front(), r[i].back()); }
+      fflush(stdout);
+      if (getenv("LAB_AB_ONLY")) return 0;
+    }
     std::vector<float> t[4], tw2[2];
     for (int rep = 0; rep < 7; ++rep) {
       tw2[0].push_back(run<0>("", blocks, lds, dx, dwin, dtw, mbo, dout, rows, L, T, 30, 1, 1));   // wide stores
