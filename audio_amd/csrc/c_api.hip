@@ -361,6 +361,29 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
   if (g.n_stages < 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft has too many prime factors");
   og.interior = adjoint ? 0.5f : 1.0f;
   og.scale = desc->scale * (adjoint ? 1.0f : 1.0f / (float)desc->n_fft);
+  if ((g.n_fft == 512 || g.n_fft == 1024 || g.n_fft == 2048) && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+    // register-resident wave FFT run as the inverse (stft_pow2.h)
+    p2::InvGeom ig{g, og.interior};
+    const int64_t ppr = (g.n_frames + 1) / 2, n_pairs = g.rows * ppr;
+    const auto* sp = reinterpret_cast<const p2::C32*>(spec);
+    const auto* twc = reinterpret_cast<const p2::C32*>(twiddle);
+    int64_t blocks = (int64_t)dev_props().cu_count * (g.n_fft == 512 ? 8 : g.n_fft == 1024 ? 4 : 2);
+    const int64_t need = (n_pairs + p2::kWaves - 1) / p2::kWaves;
+    if (blocks > need) blocks = need;
+#define AAMD_IP2(EE)                                                                                              \
+    {                                                                                                             \
+      const size_t lds2 = (size_t)p2::kWaves * p2::Cfg<EE>::lds_complex * sizeof(p2::C32);                        \
+      auto k2 = p2::istft_pow2_kernel<EE>;                                                                        \
+      if (lds2 > 48 * 1024)                                                                                       \
+        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                     (int)lds2));                                                                 \
+      hipLaunchKernelGGL(k2, dim3((unsigned)blocks), dim3(64 * p2::kWaves), lds2, (hipStream_t)stream, ig, sp,    \
+                         window, twc, inv_envelope, out, og.scale, ppr, n_pairs);                                 \
+    }
+    if (g.n_fft == 512) AAMD_IP2(8) else if (g.n_fft == 1024) AAMD_IP2(16) else AAMD_IP2(32)
+#undef AAMD_IP2
+    return launch_check();
+  }
   int pb = gen_pairs_per_block(g.n_fft);
   const int pairs_per_row = (g.n_frames + 1) / 2;
   if (pb > pairs_per_row) pb = pairs_per_row;

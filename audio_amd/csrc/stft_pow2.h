@@ -323,6 +323,63 @@ AAMD_HD void mel_rows(int lane, const StftGeom& g, const MelBandsDev& mb, const 
   }
 }
 
+// ---- inverse: frames -> waveform (torch.istft numerator / envelope, or the adjoint of the onesided STFT) ------
+// IFFT(Z) = conj(FFT(conj Z)) on the SAME stages: the lane builds conj Z[l + 64 e] from the two onesided spectra
+// (Hermitian extension; `interior` = 1 for irfft, 0.5 for the adjoint), and ends with time samples n = lane + 64 j.
+struct InvGeom {
+  StftGeom g;            // length = output samples per row; n_frames, hop, pad, center, pad_mode as for the forward
+  float interior;
+};
+
+template <int E>
+AAMD_HD void inv_load(int lane, const InvGeom& ig, const C32* Sa, const C32* Sb /* null: no frame b */, C32* v) {
+  constexpr int N = Cfg<E>::N;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = lane + 64 * e;
+    const int kk = (2 * k <= N) ? k : N - k;                 // onesided bin that defines Z[k]
+    const bool edge = (kk == 0) || (2 * kk == N);
+    const float wgt = edge ? 1.0f : ig.interior;
+    const C32 a = Sa[kk];
+    const C32 b = Sb ? Sb[kk] : C32{0.0f, 0.0f};
+    float ar = a.x * wgt, ai = a.y * wgt, br = b.x * wgt, bi = b.y * wgt;
+    if (edge) { ai = 0.0f; bi = 0.0f; }                      // irfft ignores the imaginary part of DC / Nyquist
+    if (2 * k > N) { ai = -ai; bi = -bi; }                   // Hermitian extension
+    v[e] = C32{ar - bi, -(ai + br)};                         // conj(A + i B)
+  }
+}
+
+// overlap-add of the pair's two frames: x_a[n] = Re, x_b[n] = -Im of the stage-C output, times the window
+// (lt.win carries the output scale), through the forward's padding map run backwards (ola_target)
+AAMD_HD int64_t inv_target(const StftGeom& g, int64_t u) {
+  const int64_t L1 = g.length + 2 * (int64_t)g.pad;
+  const int64_t i1 = u - (g.center ? g.n_fft / 2 : 0);
+  const int64_t s1 = g.center ? pad_source_index(i1, L1, g.pad_mode) : i1;
+  if (s1 < 0 || s1 >= L1) return -1;
+  const int64_t s0 = s1 - g.pad;
+  return (s0 >= 0 && s0 < g.length) ? s0 : -1;
+}
+
+template <int E, typename AddFn>
+AAMD_HD void inv_store(int lane, const InvGeom& ig, const LaneTab<E>& lt, const C32* z, int64_t ta, bool vb,
+                       const float* inv_env, float* out_row, AddFn add) {
+  constexpr int N = Cfg<E>::N;
+  const StftGeom& g = ig.g;
+  const int64_t cpad = g.center ? N / 2 : 0;
+  const int64_t ba = ta * (int64_t)g.hop - cpad - g.pad, bb = ba + g.hop;
+  const bool interior = ba >= 0 && bb + N <= g.length;        // wave-uniform: no index folding anywhere in the pair
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int n = lane + 64 * j;
+    float xa = z[j].x * lt.win[j], xb = -z[j].y * lt.win[j];
+    int64_t ia, ib;
+    if (interior) { ia = ba + n; ib = bb + n; }
+    else { ia = inv_target(g, ta * (int64_t)g.hop + n); ib = vb ? inv_target(g, (ta + 1) * (int64_t)g.hop + n) : -1; }
+    if (ia >= 0) add(out_row + ia, inv_env ? xa * inv_env[ia] : xa);
+    if (vb && ib >= 0) add(out_row + ib, inv_env ? xb * inv_env[ib] : xb);
+  }
+}
+
 #if defined(__HIPCC__)
 AAMD_D void wave_lds_sync() {     // program order within the wave is the only ordering these exchanges need
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -399,6 +456,42 @@ stft_pow2_kernel(StftGeom g, const float* __restrict__ wav, const float* __restr
       wave_lds_sync();
       mel_rows<E>(lane, g, mb, mel_tab, P, ta, out_row);
     }
+  }
+}
+template <int E>
+__global__ void __launch_bounds__(64 * kWaves)
+istft_pow2_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __restrict__ window,
+                  const C32* __restrict__ tw, const float* __restrict__ inv_env, float* __restrict__ out,
+                  float out_scale, int64_t pairs_per_row, int64_t n_pairs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_p2[];
+  constexpr int F = Cfg<E>::N / 2 + 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  C32* lds = reinterpret_cast<C32*>(smem_p2) + wave * Cfg<E>::lds_complex;
+  LaneTab<E> lt;
+  lane_tab<E>(lane, window, tw, 2.0f * out_scale, lt);        // lane_tab folds 0.5 * scale into the window
+  const int64_t n_waves = (int64_t)gridDim.x * kWaves;
+  auto add = [](float* p, float v) { atomicAdd(p, v); };
+#pragma unroll 1
+  for (int64_t pair = (int64_t)blockIdx.x * kWaves + wave; pair < n_pairs; pair += n_waves) {
+    const int64_t row = pair / pairs_per_row;
+    const int64_t ta = 2 * (pair - row * pairs_per_row);
+    const bool vb = ta + 1 < ig.g.n_frames;
+    const C32* Sa = spec + (row * ig.g.n_frames + ta) * (int64_t)F;
+    C32 v[E], z[E];
+    inv_load<E>(lane, ig, Sa, vb ? Sa + F : nullptr, v);
+    stage_a<E>(lt, v);
+    wave_lds_sync();
+    xch1_write<E>(lane, v, lds);
+    wave_lds_sync();
+    xch1_read<E>(lane, lds, v);
+    stage_b<E>(lt, v);
+    wave_lds_sync();
+    xch2_write<E>(lane, v, lds);
+    wave_lds_sync();
+    xch2_read<E>(lane, lds, v);
+    stage_c<E>(v, z);
+    inv_store<E>(lane, ig, lt, z, ta, vb, inv_env, out + row * ig.g.length, add);
   }
 }
 #endif  // __HIPCC__

@@ -76,6 +76,34 @@ static int sim_pow2_e(const float* wav, const float* window, const float* tw, co
   return 0;
 }
 
+template <int E>
+static int sim_istft_pow2_e(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,
+                            const StftGeom& g, float interior, float out_scale) {
+  using namespace p2;
+  constexpr int F = Cfg<E>::N / 2 + 1;
+  const C32* twc = reinterpret_cast<const C32*>(tw);
+  const C32* sp = reinterpret_cast<const C32*>(spec);
+  InvGeom ig{g, interior};
+  std::vector<LaneTab<E>> lt(64);
+  for (int l = 0; l < 64; ++l) lane_tab<E>(l, window, twc, 2.0f * out_scale, lt[l]);
+  std::vector<C32> lds(Cfg<E>::lds_complex);
+  std::vector<std::array<C32, E>> v(64), z(64);
+  const int64_t ppr = (g.n_frames + 1) / 2;
+  auto add = [](float* p, float x) { *p += x; };
+  for (int64_t pair = 0; pair < g.rows * ppr; ++pair) {
+    const int64_t row = pair / ppr, ta = 2 * (pair - row * ppr);
+    const bool vb = ta + 1 < g.n_frames;
+    const C32* Sa = sp + (row * g.n_frames + ta) * (int64_t)F;
+    for (int l = 0; l < 64; ++l) { inv_load<E>(l, ig, Sa, vb ? Sa + F : nullptr, v[l].data()); stage_a<E>(lt[l], v[l].data()); }
+    for (int l = 0; l < 64; ++l) xch1_write<E>(l, v[l].data(), lds.data());
+    for (int l = 0; l < 64; ++l) { xch1_read<E>(l, lds.data(), v[l].data()); stage_b<E>(lt[l], v[l].data()); }
+    for (int l = 0; l < 64; ++l) xch2_write<E>(l, v[l].data(), lds.data());
+    for (int l = 0; l < 64; ++l) { xch2_read<E>(l, lds.data(), v[l].data()); stage_c<E>(v[l].data(), z[l].data()); }
+    for (int l = 0; l < 64; ++l) inv_store<E>(l, ig, lt[l], z[l].data(), ta, vb, inv_env, out + row * g.length, add);
+  }
+  return 0;
+}
+
 extern "C" {
 
 int sim_stft_generic(const float* wav, const float* window, const float* tw, const aamd_mel_bands* bands,
@@ -150,6 +178,19 @@ int sim_griffinlim_update(const float* rebuilt, float* tprev, const float* mag, 
   cplx<float>* nx = reinterpret_cast<cplx<float>*>(next);
   for (int64_t i = 0; i < n; ++i) griffinlim_update_elem(r[i], tp[i], mag[i], momentum, nx[i]);
   return 0;
+}
+
+int sim_istft_pow2(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,
+                   const aamd_stft_desc* d, int adjoint) {
+  StftGeom g{};
+  fill_geom(d, g);
+  g.onesided = 1; g.n_freq = g.n_fft / 2 + 1; g.row_stride = g.length;
+  const float interior = adjoint ? 0.5f : 1.0f;
+  const float scale = d->scale * (adjoint ? 1.0f : 1.0f / (float)d->n_fft);
+  if (g.n_fft == 512) return sim_istft_pow2_e<8>(spec, window, tw, inv_env, out, g, interior, scale);
+  if (g.n_fft == 1024) return sim_istft_pow2_e<16>(spec, window, tw, inv_env, out, g, interior, scale);
+  if (g.n_fft == 2048) return sim_istft_pow2_e<32>(spec, window, tw, inv_env, out, g, interior, scale);
+  return -2;
 }
 
 int sim_istft(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,
