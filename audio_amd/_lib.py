@@ -57,6 +57,8 @@ _SIGS = {
     "aamd_melspectrogram_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), _P]),
     "aamd_melspectrogram_db_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.c_float,
                                              C.c_float, C.c_float, _P, C.c_int64, _P]),
+    "aamd_melspectrogram_lognorm_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.c_float,
+                                                  _P, _P, C.c_int64, _P]),
     "aamd_istft_f32": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(StftDesc), C.c_int32, _P]),
     "aamd_phase_vocoder_f32": (C.c_int, [_P, _P, _P, C.POINTER(VocoderDesc), _P]),
     "aamd_griffinlim_update_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),

@@ -342,6 +342,35 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
                                   stream);
 }
 
+int aamd_melspectrogram_lognorm_f32(const float* wav, const float* window, const float* twiddle,
+                                    const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
+                                    const float* mean, const float* invstddev, int64_t out_frames, void* stream) {
+  StftGeom g;
+  int rc = validate_desc(desc, g);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(wav && window && twiddle && out && mean && invstddev, "null buffer");
+  AAMD_CHECK_ARG(desc->power > 0.0f, "mel spectrogram needs power > 0");
+  AAMD_CHECK_ARG(desc->onesided, "mel spectrogram needs a onesided spectrum");
+  AAMD_CHECK_ARG(out_frames >= desc->n_frames, "out_frames must be >= n_frames");
+  MelBandsDev mb;
+  rc = validate_bands(bands, g.n_freq, mb);
+  if (rc != AAMD_OK) return rc;
+  if (mel400_eligible(g, mb)) {
+    m400::Epi400 epi{};
+    epi.gain = gain; epi.mean = mean; epi.invstd = invstddev; epi.out_frames = out_frames;
+    return launch_fft400<m400::EPI400_MEL_NORM>(g, mb, wav, window, twiddle, out, epi, (hipStream_t)stream);
+  }
+  if (out_frames != g.n_frames)
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: padded feature rows need the n_fft = 400 fast path");
+  rc = launch_generic<EPI_MEL>(g, mb, wav, window, twiddle, out, (hipStream_t)stream);
+  if (rc != AAMD_OK) return rc;
+  const int64_t n = g.rows * g.n_frames * (int64_t)mb.n_mels;
+  if (n == 0) return AAMD_OK;
+  hipLaunchKernelGGL(lognorm_kernel, dim3(grid_for(n, 256, dev_props().cu_count * 16)), dim3(256), 0,
+                     (hipStream_t)stream, out, n, mb.n_mels, gain, mean, invstddev);
+  return launch_check();
+}
+
 int aamd_istft_f32(const float* spec, const float* window, const float* twiddle, const float* inv_envelope,
                    float* out, const aamd_stft_desc* desc, int32_t adjoint, void* stream) {
   AAMD_CHECK_ARG(desc != nullptr && spec && window && twiddle && out, "null buffer");

@@ -89,6 +89,20 @@ db_clamp_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
     out[i] = fmaxf(x[i], group_max[i / group_size] - top_db);
 }
 
+// RNN-T feature post-processing on a frame-major mel buffer (the unfused form of EPI400_MEL_NORM)
+__global__ void __launch_bounds__(256)
+lognorm_kernel(float* __restrict__ x, int64_t n, int n_mels, float gain, const float* __restrict__ mean,
+               const float* __restrict__ invstd) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int m = (int)(i % n_mels);
+    const float y = x[i] * gain;
+    const float t = y > 2.718281828459045f ? __log2f(y) * 0.69314718055994531f : y;   // see epi_plog (melspec400.h):
+    const float l = t <= 2.718281828459045f ? t / 2.718281828459045f : t;             // the reference's second mask
+    x[i] = (l - mean[m]) * invstd[m];
+  }
+}
+
 // MelScale on a frame-major spectrogram: one thread per (vector, mel).
 __global__ void __launch_bounds__(256)
 mel_scale_kernel(const float* __restrict__ spec, MelBandsDev mb, float* __restrict__ out,

@@ -88,12 +88,18 @@ static_assert(Hop<8>::lds_dwords == kLdsDwordsPerWave && Hop<8>::ndma == 5 && Ho
 //   EPI400_MEL_DB  ... then amplitude_to_DB (functional.py:390-391) fused, plus the running
 //                  maximum per cut-off group (the top_db reduction of :393-402)
 //   EPI400_SPEC    no mel: |X|^power for the 201 one-sided bins -> out[rows][T][201]
-enum { EPI400_MEL = 0, EPI400_MEL_DB = 1, EPI400_SPEC = 2 };
+//   EPI400_MEL_NORM  the RNN-T front-end's feature post-processing fused (pipelines/rnnt_pipeline.py:16-47, 319-326):
+//                  y = piecewise_linear_log(mel * gain), (y - mean[m]) * invstddev[m], rows of out_frames >= T frames
+enum { EPI400_MEL = 0, EPI400_MEL_DB = 1, EPI400_SPEC = 2, EPI400_MEL_NORM = 3 };
 struct Epi400 {
   float multiplier, amin, db_sub;   // MEL_DB: y = multiplier * log10(max(x, amin)) - db_sub
   float* group_max;                 // MEL_DB: [n_groups] running max of y (float bit pattern), may be null
   int64_t rows_per_group;           // MEL_DB: waveform rows per cut-off group
   float power;                      // SPEC: 2 -> |X|^2, 1 -> |X|, else |X|^power
+  float gain;                       // MEL_NORM: y = plog(mel * gain)
+  const float* mean;                // MEL_NORM: [n_mels]
+  const float* invstd;              // MEL_NORM: [n_mels]
+  int64_t out_frames;               // MEL_NORM: frames per clip in `out` (>= n_frames; the tail is the caller's)
 };
 constexpr int kSpecBins = 201;
 static_assert(kFramesPerWave * kSpecBins + 3 <= kSOff && 3 * 2 * kSpecBins + 3 <= kSOff, "SPEC rows must fit below the staging area");
@@ -498,6 +504,20 @@ AAMD_HD float fast_log10(float x) {
   return log10(x);
 #endif
 }
+// _piecewise_linear_log (pipelines/rnnt_pipeline.py:20-23) EXACTLY as the reference evaluates it: two in-place
+// masked assignments, `x[x > e] = log(x[x > e])` then `x[x <= e] = x[x <= e] / e` -- the second mask is taken
+// AFTER the first assignment, so values in (e, e^e] (whose log is <= e) are divided by e as well:
+//   x <= e: x / e;   e < x <= e^e: ln(x) / e;   x > e^e: ln(x).   The trained models expect exactly this.
+AAMD_HD float epi_plog(float x) {
+  const float kE = 2.718281828459045f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float lg = __log2f(x) * 0.69314718055994531f;
+#else
+  const float lg = log(x);
+#endif
+  const float t = x > kE ? lg : x;
+  return t <= kE ? t / kE : t;
+}
 AAMD_HD float epi_db(float x, const Epi400& e) {
   return e.multiplier * fast_log10(fmax(x, e.amin)) - e.db_sub;
 }
@@ -724,6 +744,15 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
 #pragma unroll
     for (int q = 0; q < 40; ++q) twr[q] = c.tw[q];
   }
+  float nrm_mean[kMelMaxRounds], nrm_inv[kMelMaxRounds];   // MEL_NORM: statistics of this lane's mels
+  if (EPI == EPI400_MEL_NORM) {
+#pragma unroll
+    for (int r = 0; r < kMelMaxRounds; ++r) {
+      const int m = r < mt.n_rounds ? mt.row_mel[r * kMelSlots + c.pi] : -1;
+      nrm_mean[r] = m >= 0 ? epi.mean[m] : 0.0f;
+      nrm_inv[r] = m >= 0 ? epi.invstd[m] : 0.0f;
+    }
+  }
   const unsigned long long self_mask = __ballot((c.col == 0) || (c.col == 10));   // wave-uniform (SGPR pair)
   int spiece[HC::ndma];   // tile piece fetched by this lane in DMA instruction k
 #pragma unroll
@@ -873,7 +902,16 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
         }
       }
     }
-    float* out_row = out + cur.row * n_frames * (int64_t)mb.n_mels;
+    if (EPI == EPI400_MEL_NORM) {
+#pragma unroll
+      for (int r = 0; r < kMelMaxRounds; ++r) {
+        if (r < mt.n_rounds) {
+          acc_a[r] = (epi_plog(acc_a[r] * epi.gain) - nrm_mean[r]) * nrm_inv[r];
+          acc_b[r] = (epi_plog(acc_b[r] * epi.gain) - nrm_mean[r]) * nrm_inv[r];
+        }
+      }
+    }
+    float* out_row = out + cur.row * (EPI == EPI400_MEL_NORM ? epi.out_frames : (int64_t)n_frames) * (int64_t)mb.n_mels;
     if (out_wide) {
       wave_lds_fence();
       store_stage(c, mt, acc_a, acc_b, lds);

@@ -557,6 +557,40 @@ def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_ff
     return out
 
 
+def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_length: int, gain: float,
+                 mean: Tensor, invstddev: Tensor, right_padding: int,
+                 bands: Optional[MelBandsOnDevice] = None) -> Tensor:
+    """MelSpectrogram (power 2, centre / reflect) with the RNN-T feature post-processing fused
+    (pipelines/rnnt_pipeline.py:16-47, 319-326).  Returns (rows, T + right_padding, n_mels), the padding rows zero."""
+    _require_device(waveform, "waveform")
+    dev = waveform.device
+    window = window.to(device=dev, dtype=torch.float32)
+    x2 = _rows2d(waveform)
+    desc = _stft_desc(x2, 0, window, n_fft, hop_length, 2.0, False, True, "reflect", True)
+    if bands is None:
+        bands = _mel_bands(fb, dev)
+    mean = mean.to(device=dev, dtype=torch.float32).contiguous()
+    invstddev = invstddev.to(device=dev, dtype=torch.float32).contiguous()
+    if mean.numel() != bands.n_mels or invstddev.numel() != bands.n_mels:
+        raise RuntimeError(f"audio_amd: global statistics must have n_mels = {bands.n_mels} entries")
+    T = desc.n_frames
+    fused_pad = n_fft == 400                       # rows of T + right_padding frames come straight from the kernel
+    frames = T + right_padding if fused_pad else T
+    out = torch.empty((desc.rows, frames, bands.n_mels), dtype=torch.float32, device=dev)
+    if out.numel():
+        if frames > T:
+            out[:, T:].zero_()
+        if T:
+            L = _lib.lib()
+            _lib.check(L.aamd_melspectrogram_lognorm_f32(
+                x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),
+                C.byref(bands.struct), out.data_ptr(), C.byref(desc), float(gain), mean.data_ptr(), invstddev.data_ptr(),
+                frames, _lib.current_stream(dev)))
+    if not fused_pad and right_padding:
+        out = torch.nn.functional.pad(out, (0, 0, 0, right_padding))
+    return out
+
+
 def _mfcc(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, dct_mat: Tensor, n_fft: int, hop_length: int,
           win_length: int, power: float, normalized, center: bool, pad_mode: str, log_mels: bool, top_db: float,
           db=(10.0, 1e-10, 0.0), group_max_hook=None) -> Tensor:

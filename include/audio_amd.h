@@ -22,6 +22,8 @@
  *                             Spectrogram.forward + MelScale.forward :403-415)
  *   aamd_melspectrogram_db_f32  ... + F.amplitude_to_DB and its top_db group maximum fused
  *                             (first half of MFCC.forward, _transforms.py:692-706)
+ *   aamd_melspectrogram_lognorm_f32  pipelines/rnnt_pipeline.py:16-47, 319-326 (RNN-T feature extractor: the
+ *                             MelSpectrogram + transpose + gain/log + global-stats normalisation chain)
  *   aamd_phase_vocoder_f32    functional/functional.py:732-803 (F.phase_vocoder; T.TimeStretch, F.pitch_shift)
  *   aamd_griffinlim_update_f32  functional/functional.py:336-343 (phase update of F.griffinlim)
  *   aamd_istft_f32            functional/functional.py:148-225 (F.inverse_spectrogram -> torch.istft) and the
@@ -130,6 +132,18 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
                                const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
                                float multiplier, float amin, float db_multiplier, float* group_max,
                                int64_t rows_per_group, void* stream);
+
+/* MelSpectrogram with the RNN-T front-end's feature post-processing fused into the epilogue
+ * (pipelines/rnnt_pipeline.py:16-47, 319-326: x * gain -> _piecewise_linear_log -> (x - mean) * invstddev):
+ *   out[row][t][m] = (plog(mel[row][t][m] * gain) - mean[m]) * invstddev[m]
+ *   plog = the reference's two in-place masked assignments as evaluated: y <= e: y / e; e < y <= e^e: ln(y) / e;
+ *   y > e^e: ln(y)   (the second mask sees the values the first one wrote)
+ * out is frame-major float[rows][out_frames][n_mels] with out_frames >= n_frames; frames n_frames .. out_frames-1
+ * (the pipeline's right padding) are NOT written: the caller zero-fills them.  mean / invstddev: float[n_mels].
+ * Shapes outside the n_fft = 400 fast path need out_frames == n_frames. */
+int aamd_melspectrogram_lognorm_f32(const float* wav, const float* window, const float* twiddle,
+                                    const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
+                                    const float* mean, const float* invstddev, int64_t out_frames, void* stream);
 
 /* Frames -> waveform (overlap-add).  spec: interleaved complex float[rows][n_frames][n_fft/2+1][2] (frame-major,
  * onesided); window / twiddle as for aamd_spectrogram_f32; out: float[rows][length], MUST be zero-filled by the

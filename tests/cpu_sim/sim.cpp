@@ -252,6 +252,8 @@ static int sim_melspec400_h(const float* wav, const float* window, const float* 
   }
   Epi400 epi{};
   if (epi_mode == EPI400_MEL_DB) { epi.multiplier = db[0]; epi.amin = db[1]; epi.db_sub = db[2]; }
+  // MEL_NORM: db = {gain, out_frames}; gmax = [mean(n_mels) | invstddev(n_mels)]
+  if (epi_mode == EPI400_MEL_NORM) { epi.gain = db[0]; epi.out_frames = (int64_t)db[1]; epi.mean = gmax; epi.invstd = gmax + bands->n_mels; }
   epi.power = power;
   alignas(16) static float lds[HC::lds_dwords];
   alignas(16) static float tab[kMelMaxRounds * kMelSlots * (kMelMaxTaps + 4 + 2) + 256];
@@ -338,7 +340,16 @@ static int sim_melspec400_h(const float* wav, const float* window, const float* 
         }
       if (gmax) { float& g = gmax[row / rows_per_group]; g = std::fmax(g, m); }
     }
-    float* out_row = out + row * n_frames * (int64_t)mb.n_mels;
+    if (epi_mode == EPI400_MEL_NORM) {
+      for (int l = 0; l < 64; ++l)
+        for (int r = 0; r < mt.n_rounds; ++r) {
+          const int m = mt.row_mel[r * kMelSlots + c[l].pi];
+          const float mu = m >= 0 ? epi.mean[m] : 0.0f, is = m >= 0 ? epi.invstd[m] : 0.0f;
+          acc_a[l][r] = (epi_plog(acc_a[l][r] * epi.gain) - mu) * is;
+          acc_b[l][r] = (epi_plog(acc_b[l][r] * epi.gain) - mu) * is;
+        }
+    }
+    float* out_row = out + row * (epi_mode == EPI400_MEL_NORM ? epi.out_frames : (int64_t)n_frames) * (int64_t)mb.n_mels;
     if (out_wide) {
       for (int l = 0; l < 64; ++l) store_stage(c[l], mt, acc_a[l], acc_b[l], lds);
       for (int l = 0; l < 64; ++l) store_wide(l, mt, lds, out_row, t0, n_frames);

@@ -75,5 +75,24 @@ x = noise(3, 4000)
 lengths = torch.tensor([4000.0, 3000.0, 1234.0])
 y, yl = T.Speed(16000, 1.1)(x, lengths)
 out["speed/x"] = x.numpy(); out["speed/out"] = y.numpy(); out["speed/lengths"] = lengths.numpy(); out["speed/out_lengths"] = yl.numpy()
+# RNN-T feature extractor: the reference's own Sequential (rnnt_pipeline.py:319-326) with synthetic global statistics
+import json, tempfile  # noqa: E402
+from torchaudio.pipelines import rnnt_pipeline as RP  # noqa: E402
+stats = {"mean": (10 + 3 * torch.randn(80, generator=g)).tolist(), "invstddev": (0.2 + torch.rand(80, generator=g)).tolist()}
+with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+    f.write(json.dumps(stats))
+ref_fe = RP._ModuleFeatureExtractor(torch.nn.Sequential(
+    T.MelSpectrogram(sample_rate=16000, n_fft=400, n_mels=80, hop_length=160),
+    RP._FunctionalModule(lambda x: x.transpose(1, 0)),
+    RP._FunctionalModule(lambda x: RP._piecewise_linear_log(x * RP._gain)),
+    RP._GlobalStatsNormalization(f.name),
+    RP._FunctionalModule(lambda x: torch.nn.functional.pad(x, (0, 0, 0, 4))),
+))
+xs = [0.1 * noise(16000), torch.cat([0.3 * tone(9000), torch.zeros(3000), 1e-4 * noise(4321)])]
+for i, xw in enumerate(xs):
+    feats, length = ref_fe(xw.clone())
+    out[f"rnnt{i}/x"] = xw.numpy(); out[f"rnnt{i}/out"] = feats.numpy(); out[f"rnnt{i}/length"] = length.numpy()
+    print("rnnt", i, tuple(feats.shape), int(length), "linear-branch share", float((feats == feats).float().mean()))
+out["rnnt/mean"] = np.array(stats["mean"], dtype=np.float32); out["rnnt/invstddev"] = np.array(stats["invstddev"], dtype=np.float32)
 np.savez_compressed(os.path.join(HERE, "widening_goldens.npz"), **out)
 print("widening_goldens.npz:", len(out), "arrays", os.path.getsize(os.path.join(HERE, "widening_goldens.npz")) // 1024, "KiB")

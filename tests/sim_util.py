@@ -83,13 +83,13 @@ def sim_mel_generic(x, window_padded, bands, desc):
 
 
 def _sim_fft400(x, window, bands, scale, epi, db=None, gmax=None, rows_per_group=1, power=2.0, out_width=None,
-                wide=0, hop=160):
+                wide=0, hop=160, out_frames=None):
     x = np.ascontiguousarray(x, dtype=np.float32)
     rows, length = x.shape
     w = np.ascontiguousarray(window, dtype=np.float32)
     tw = np.ascontiguousarray(_host.twiddle_table(400))
     T = _host.frame_count(length, 400, hop, True)
-    out = np.zeros((rows, T, out_width), dtype=np.float32)
+    out = np.zeros((rows, out_frames or T, out_width), dtype=np.float32)
     f = sim().sim_melspec400
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                   C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_int]
@@ -109,6 +109,17 @@ def sim_mel400_db(x, window, bands, multiplier, amin, db_multiplier, gmax, rows_
     """gmax: float32 array pre-filled with -inf, max-reduced in place."""
     return _sim_fft400(x, window, bands, scale, 1, db=[multiplier, amin, multiplier * db_multiplier], gmax=gmax,
                        rows_per_group=rows_per_group, out_width=bands.n_mels)
+
+
+def sim_mel400_norm(x, window, bands, gain, mean, invstddev, right_padding=0, hop=160):
+    """Fused RNN-T feature epilogue: ((plog(mel * gain)) - mean) * invstddev, rows of T + right_padding frames
+    (the padding rows stay zero).  Returns frame-major (rows, T + right_padding, n_mels)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    T = _host.frame_count(x.shape[1], 400, hop, True)
+    stats = np.ascontiguousarray(np.concatenate([mean, invstddev]), dtype=np.float32)
+    o = _sim_fft400(x, window, bands, 1.0, 3, db=[gain, float(T + right_padding)], gmax=stats, out_width=bands.n_mels,
+                    hop=hop, out_frames=T + right_padding)
+    return np.swapaxes(o, -1, -2)
 
 
 def sim_spec400(x, window, power, scale=1.0, hop=160):

@@ -501,3 +501,29 @@ def test_sim_istft_pow2_roundtrip_and_adjoint(n_fft, hop, L):
         lhs = np.real(np.sum(Xm * np.conj(G)))
         rhs = np.sum(x * dx)
         assert abs(lhs - rhs) <= 5e-5 * max(abs(lhs), np.sqrt(np.sum(np.abs(Xm) ** 2) * np.sum(np.abs(G) ** 2)) * 1e-3), mode
+
+
+def test_sim_mel400_rnnt_feature_epilogue():
+    """EPI400_MEL_NORM: the RNN-T front-end's post-processing (pipelines/rnnt_pipeline.py:16-47, 319-326) fused into
+    the headline kernel, against the same steps in float64."""
+    import math
+    rng = np.random.default_rng(11)
+    x = (0.05 * rng.standard_normal((2, 4000))).astype(np.float32)
+    x[1, 2000:] = 0.0                                      # silence: exercises the linear branch of the piecewise log
+    fb = _host.melscale_fbanks(201, 0.0, 8000.0, 80, 16000, None, "htk")
+    bands = S.HostBands(fb.numpy(), permute=True)
+    w = torch.hann_window(400).numpy()
+    gain = pow(10, 0.05 * (2 * 20 * math.log10(32767)))
+    mean = rng.standard_normal(80).astype(np.float32) * 3 + 10
+    invstd = (0.2 + rng.random(80)).astype(np.float32)
+    got = S.sim_mel400_norm(x, w, bands, gain, mean, invstd, right_padding=4)
+    from oracle import torch_cpu_ref as R
+    mel = R.mel_spectrogram(torch.from_numpy(x).double(), torch.hann_window(400, dtype=torch.float64), fb.double(), 400, 160)
+    y = mel.transpose(-1, -2) * gain
+    y = torch.where(y > math.e, torch.log(torch.clamp(y, min=1e-300)), y)       # the reference's two in-place masked
+    y = torch.where(y <= math.e, y / math.e, y)                                 # assignments (second mask sees the log)
+    y = (y - torch.from_numpy(mean).double()) * torch.from_numpy(invstd).double()
+    T = y.shape[1]
+    assert got.shape == (2, T + 4, 80)
+    assert np.all(got[:, T:] == 0)
+    assert peak_rel_err(got[:, :T], y.numpy()) <= 2e-6

@@ -919,3 +919,62 @@ def test_pow2_wave_fft_equals_generic_and_torch_stft(n_fft, hop):
     m = T.MelSpectrogram(sample_rate=48000, n_fft=n_fft, hop_length=hop, n_mels=24, f_min=20.0).cuda()
     x = torch.randn(2, 4 * n_fft, generator=g).clamp_(-1, 1).cuda()
     assert peak_rel_err(m(x).cpu().numpy(), _force_generic(lambda: m(x)).cpu().numpy()) <= 3e-6
+
+
+def _assert_rnnt_features_close(got, ref, x_cpu, fe):
+    """Feature-domain comparison with the conditioning of the transform written out.  The mel spectrogram itself is
+    held to 2e-6 of each frame's peak (fp32 FFT noise floor, ours and the reference's); the post-processing maps a mel
+    error dm to dm * gain * plog'(y) * invstddev, which for bins 1e-12 below the frame peak (a tone's far leakage
+    bins, amplified by gain = 1.07e9) is not small, and plog itself JUMPS from 1 to e at y = e^e (rnnt_pipeline.py:20-23
+    as evaluated).  So: |got - ref| <= 2e-4 + invstddev * gain * plog'(y) * 2e-6 * peak_mel(frame), elements within
+    0.5 % of the two break points excluded."""
+    import math
+    from audio_amd.pipelines import GAIN
+    from oracle import torch_cpu_ref as R
+    fb = fe.mel.mel_scale.fb.cpu().double()
+    mel = R.mel_spectrogram(x_cpu.double()[None], torch.hann_window(400, dtype=torch.float64), fb, 400, 160)[0].transpose(0, 1)
+    y = (mel * GAIN).numpy()
+    inv = fe.invstddev.cpu().numpy().astype(np.float64)
+    e, ee = math.e, math.e ** math.e
+    dplog = np.where(y <= e, 1.0 / e, np.where(y <= ee, 1.0 / (np.maximum(y, e) * e), 1.0 / np.maximum(y, e)))
+    peak = mel.numpy().max(axis=1, keepdims=True)
+    tol = 2e-4 + inv[None, :] * GAIN * dplog * 2e-6 * peak
+    near = (np.abs(y / e - 1) < 5e-3) | (np.abs(y / ee - 1) < 5e-3)
+    bad = (np.abs(got - ref) > tol) & ~near
+    assert not bad.any(), (int(bad.sum()), float(np.abs(got - ref)[bad].max()))
+    # and the well-conditioned elements (bins within 1e-5 of the frame peak) are tight
+    strong = (mel.numpy() > 1e-5 * peak) & ~near
+    assert np.abs(got - ref)[strong].max() <= 2e-4
+
+
+def test_rnnt_feature_extractor_vs_reference():
+    """audio_amd.pipelines.RNNTFeatureExtractor (MelSpectrogram + transpose + gain / piecewise log + global-stats
+    normalisation + right padding in ONE launch of the headline kernel) against the reference's own Sequential
+    (pipelines/rnnt_pipeline.py:319-326) run on the CPU, and against the unfused composition on the GPU."""
+    from audio_amd.pipelines import GAIN, RNNTFeatureExtractor, piecewise_linear_log
+    import audio_amd.transforms as T
+    G = _widening()
+    stats = {"mean": G["rnnt/mean"].tolist(), "invstddev": G["rnnt/invstddev"].tolist()}
+    fe = RNNTFeatureExtractor(stats).cuda()
+    with torch.no_grad():
+        for i in range(2):
+            x = torch.tensor(G[f"rnnt{i}/x"]).cuda()
+            feats, length = fe(x)
+            ref = G[f"rnnt{i}/out"]
+            assert feats.shape == ref.shape and int(length) == int(G[f"rnnt{i}/length"])
+            assert torch.all(feats[-4:] == 0)
+            _assert_rnnt_features_close(feats.cpu().numpy()[:-4], ref[:-4], x.cpu(), fe)
+        # batched, vs the same steps unfused on the device
+        xb = torch.stack([torch.tensor(G["rnnt0/x"])[:15000], torch.tensor(G["rnnt1/x"])[:15000]]).cuda().reshape(2, 1, 15000)
+        fb = fe(xb)
+        mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, n_mels=80, hop_length=160).cuda()(xb).transpose(-1, -2)
+        ref = (piecewise_linear_log(mel * GAIN) - fe.mean) * fe.invstddev
+        assert fb.shape == (2, 1, ref.shape[-2] + 4, 80)
+        assert float((fb[..., :-4, :] - ref).abs().max()) <= 2e-4 and torch.all(fb[..., -4:, :] == 0)
+        # a shape outside the n_fft = 400 fast path: generic mel + the element-wise kernel + torch padding
+        fe2 = RNNTFeatureExtractor(stats, n_fft=512, hop_length=128).cuda()
+        f2 = fe2(xb)
+        mel2 = T.MelSpectrogram(sample_rate=16000, n_fft=512, n_mels=80, hop_length=128).cuda()(xb).transpose(-1, -2)
+        ref2 = (piecewise_linear_log(mel2 * GAIN) - fe.mean) * fe.invstddev
+        assert f2.shape[-2] == ref2.shape[-2] + 4
+        assert float((f2[..., :-4, :] - ref2).abs().max()) <= 2e-4

@@ -133,6 +133,22 @@ def main():
             os.environ["AAMD_FORCE_GENERIC"] = "1"
             print(f"  same, time-domain kernel: {timeit(lambda: F.fftconvolve(x1, y1), 1, 3):9.1f} us")
             del os.environ["AAMD_FORCE_GENERIC"]
+    if "rnnt" in what:
+        from audio_amd.pipelines import GAIN, RNNTFeatureExtractor, piecewise_linear_log
+        x = (0.1 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
+        stats = {"mean": (10 + 3 * torch.randn(80)).tolist(), "invstddev": (0.2 + torch.rand(80)).tolist()}
+        fe = RNNTFeatureExtractor(stats).to(dev)
+        mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, n_mels=80, hop_length=160).to(dev)
+        with torch.no_grad():
+            us = timeit(lambda: fe(x), 10, 100)
+            print(f"RNN-T features 256x10s, fused epilogue (one kernel + 82 KB memset): {us:9.1f} us")
+
+            def unfused():
+                m = mel(x).transpose(-1, -2)
+                y = (piecewise_linear_log(m * GAIN) - fe.mean) * fe.invstddev
+                return torch.nn.functional.pad(y, (0, 0, 0, 4))
+            us = timeit(unfused, 10, 100)
+            print(f"  same steps unfused (HIP mel kernel + torch element-wise chain):   {us:9.1f} us")
     if "istft" in what:
         x = (0.5 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
         with torch.no_grad():
