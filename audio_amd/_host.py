@@ -303,3 +303,117 @@ def resample_adjoint_table(kernel: np.ndarray, orig: int, new: int, width: int):
     ok = (k >= 0) & (k < taps)
     out[ok] = h[np.broadcast_to(p, k.shape)[ok], k[ok]]
     return out, Wp
+
+
+# --------------------------------------------------------------------------- #
+# Kaldi-compatible constants (reference: compliance/kaldi.py:86-113, 318-511)   #
+# --------------------------------------------------------------------------- #
+
+
+def kaldi_window(window_type: str, window_size: int, blackman_coeff: float) -> torch.Tensor:
+    """The window functions of compliance/kaldi.py:86-113 (float32, symmetric = periodic=False)."""
+    if window_type == "hanning":
+        return torch.hann_window(window_size, periodic=False)
+    if window_type == "hamming":
+        return torch.hamming_window(window_size, periodic=False, alpha=0.54, beta=0.46)
+    if window_type == "povey":                       # hann ** 0.85: goes to zero at the edges
+        return torch.hann_window(window_size, periodic=False).pow(0.85)
+    if window_type == "rectangular":
+        return torch.ones(window_size)
+    if window_type == "blackman":
+        a = 2 * math.pi / (window_size - 1)
+        n = torch.arange(window_size, dtype=torch.float32)
+        return blackman_coeff - 0.5 * torch.cos(a * n) + (0.5 - blackman_coeff) * torch.cos(2 * a * n)
+    raise Exception("Invalid window type " + window_type)
+
+
+def kaldi_mel_scale_scalar(freq: float) -> float:
+    return 1127.0 * math.log(1.0 + freq / 700.0)                     # kaldi.py:326-327
+
+
+def kaldi_mel_scale(freq: torch.Tensor) -> torch.Tensor:
+    return 1127.0 * (1.0 + freq / 700.0).log()                       # kaldi.py:330-331
+
+
+def kaldi_inverse_mel_scale_scalar(mel_freq: float) -> float:
+    return 700.0 * (math.exp(mel_freq / 1127.0) - 1.0)               # kaldi.py:318-319
+
+
+def kaldi_inverse_mel_scale(mel_freq: torch.Tensor) -> torch.Tensor:
+    return 700.0 * ((mel_freq / 1127.0).exp() - 1.0)                 # kaldi.py:322-323
+
+
+def kaldi_vtln_warp_freq(vtln_low_cutoff: float, vtln_high_cutoff: float, low_freq: float, high_freq: float,
+                         vtln_warp_factor: float, freq: torch.Tensor) -> torch.Tensor:
+    """Piecewise-linear VTLN warp with two inflection points l < h (kaldi.py:334-406): identity outside
+    [low_freq, high_freq], slope 1/warp between l and h, and straight lines joining (low_freq, low_freq) to (l, l/warp)
+    and (h, h/warp) to (high_freq, high_freq)."""
+    assert vtln_low_cutoff > low_freq, "be sure to set the vtln_low option higher than low_freq"
+    assert vtln_high_cutoff < high_freq, "be sure to set the vtln_high option lower than high_freq [or negative]"
+    lo_pt = vtln_low_cutoff * max(1.0, vtln_warp_factor)
+    hi_pt = vtln_high_cutoff * min(1.0, vtln_warp_factor)
+    slope = 1.0 / vtln_warp_factor
+    assert lo_pt > low_freq and hi_pt < high_freq
+    slope_left = (slope * lo_pt - low_freq) / (lo_pt - low_freq)
+    slope_right = (high_freq - slope * hi_pt) / (high_freq - hi_pt)
+    warped = torch.empty_like(freq)
+    # later assignments win, exactly in the reference's order: >= h, < h, < l, outside
+    upper = torch.ge(freq, hi_pt)
+    warped[upper] = high_freq + slope_right * (freq[upper] - high_freq)
+    mid = torch.lt(freq, hi_pt)
+    warped[mid] = slope * freq[mid]
+    lower = torch.lt(freq, lo_pt)
+    warped[lower] = low_freq + slope_left * (freq[lower] - low_freq)
+    outside = torch.lt(freq, low_freq) | torch.gt(freq, high_freq)
+    warped[outside] = freq[outside]
+    return warped
+
+
+def kaldi_vtln_warp_mel_freq(vtln_low_cutoff: float, vtln_high_cutoff: float, low_freq, high_freq: float,
+                             vtln_warp_factor: float, mel_freq: torch.Tensor) -> torch.Tensor:
+    return kaldi_mel_scale(kaldi_vtln_warp_freq(vtln_low_cutoff, vtln_high_cutoff, low_freq, high_freq, vtln_warp_factor,
+                                                kaldi_inverse_mel_scale(mel_freq)))      # kaldi.py:409-433
+
+
+def kaldi_get_mel_banks(num_bins: int, window_length_padded: int, sample_freq: float, low_freq: float, high_freq: float,
+                        vtln_low: float, vtln_high: float, vtln_warp_factor: float):
+    """Triangular banks that are linear in MEL (kaldi.py:436-511).  Returns (bins (num_bins, padded / 2), center_freqs)."""
+    assert num_bins > 3, "Must have at least 3 mel bins"
+    assert window_length_padded % 2 == 0
+    num_fft_bins = window_length_padded / 2
+    nyquist = 0.5 * sample_freq
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    assert (0.0 <= low_freq < nyquist) and (0.0 < high_freq <= nyquist) and (low_freq < high_freq), (
+        "Bad values in options: low-freq {} and high-freq {} vs. nyquist {}".format(low_freq, high_freq, nyquist))
+    fft_bin_width = sample_freq / window_length_padded
+    mel_lo = kaldi_mel_scale_scalar(low_freq)
+    mel_hi = kaldi_mel_scale_scalar(high_freq)
+    step = (mel_hi - mel_lo) / (num_bins + 1)
+    if vtln_high < 0.0:
+        vtln_high += nyquist
+    assert vtln_warp_factor == 1.0 or ((low_freq < vtln_low < high_freq) and (0.0 < vtln_high < high_freq) and
+                                       (vtln_low < vtln_high)), (
+        "Bad values in options: vtln-low {} and vtln-high {}, versus " "low-freq {} and high-freq {}".format(
+            vtln_low, vtln_high, low_freq, high_freq))
+    idx = torch.arange(num_bins).unsqueeze(1)
+    left = mel_lo + idx * step
+    center = mel_lo + (idx + 1.0) * step
+    right = mel_lo + (idx + 2.0) * step
+    if vtln_warp_factor != 1.0:
+        left = kaldi_vtln_warp_mel_freq(vtln_low, vtln_high, low_freq, high_freq, vtln_warp_factor, left)
+        center = kaldi_vtln_warp_mel_freq(vtln_low, vtln_high, low_freq, high_freq, vtln_warp_factor, center)
+        right = kaldi_vtln_warp_mel_freq(vtln_low, vtln_high, low_freq, high_freq, vtln_warp_factor, right)
+    center_freqs = kaldi_inverse_mel_scale(center)
+    mel = kaldi_mel_scale(fft_bin_width * torch.arange(num_fft_bins)).unsqueeze(0)
+    up = (mel - left) / (center - left)
+    down = (right - mel) / (right - center)
+    if vtln_warp_factor == 1.0:
+        bins = torch.max(torch.zeros(1), torch.min(up, down))
+    else:                                              # warped banks: the two slopes are gated separately
+        bins = torch.zeros_like(up)
+        rising = torch.gt(mel, left) & torch.le(mel, center)
+        falling = torch.gt(mel, center) & torch.lt(mel, right)
+        bins[rising] = up[rising]
+        bins[falling] = down[falling]
+    return bins, center_freqs

@@ -49,6 +49,15 @@ class VocoderDesc(C.Structure):
                 ("rate", C.c_double)]
 
 
+class KaldiDesc(C.Structure):
+    """aamd_kaldi_desc (include/audio_amd.h)."""
+    _fields_ = [("n_samples", C.c_int64), ("n_frames", C.c_int64), ("n_fft", C.c_int32), ("shift", C.c_int32),
+                ("win", C.c_int32), ("snip_edges", C.c_int32), ("preemphasis", C.c_float),
+                ("remove_dc_offset", C.c_int32), ("raw_energy", C.c_int32), ("energy_floor", C.c_float),
+                ("use_power", C.c_int32), ("use_log", C.c_int32), ("energy_col", C.c_int32), ("first_col", C.c_int32),
+                ("n_cols", C.c_int32)]
+
+
 _SIGS = {
     "aamd_abi_version": (C.c_int, []),
     "aamd_last_error": (C.c_char_p, []),
@@ -59,6 +68,7 @@ _SIGS = {
                                              C.c_float, C.c_float, _P, C.c_int64, _P]),
     "aamd_melspectrogram_lognorm_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.c_float,
                                                   _P, _P, C.c_int64, _P]),
+    "aamd_kaldi_features_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(KaldiDesc), _P]),
     "aamd_istft_f32": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(StftDesc), C.c_int32, _P]),
     "aamd_phase_vocoder_f32": (C.c_int, [_P, _P, _P, C.POINTER(VocoderDesc), _P]),
     "aamd_griffinlim_update_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),

@@ -371,6 +371,54 @@ int aamd_melspectrogram_lognorm_f32(const float* wav, const float* window, const
   return launch_check();
 }
 
+int aamd_kaldi_features_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
+                            float* out, const aamd_kaldi_desc* d, void* stream) {
+  AAMD_CHECK_ARG(d != nullptr && wav && window && twiddle && out, "null buffer");
+  AAMD_CHECK_ARG(d->n_samples >= 0 && d->n_frames >= 0, "negative sizes");
+  AAMD_CHECK_ARG(d->shift >= 1 && d->win >= 2 && d->win <= d->n_fft, "need shift >= 1 and 2 <= win <= n_fft");
+  AAMD_CHECK_ARG(d->preemphasis >= 0.0f && d->preemphasis <= 1.0f, "preemphasis must be in [0, 1]");
+  if (d->n_fft != 512 && d->n_fft != 1024 && d->n_fft != 2048)
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: the Kaldi front-end needs a padded window of 512, 1024 or 2048 samples");
+  if (d->n_frames == 0) return AAMD_OK;
+  MelBandsDev mb{};
+  if (bands != nullptr) {
+    int rc = validate_bands(bands, d->n_fft / 2 + 1, mb);
+    if (rc != AAMD_OK) return rc;
+    AAMD_CHECK_ARG(d->n_cols >= mb.n_mels && d->first_col >= 0 && d->first_col + mb.n_mels <= d->n_cols &&
+                   d->energy_col < d->n_cols, "bad output columns");
+  }
+  p2::KaldiGeom kg{};
+  kg.n_samples = d->n_samples; kg.n_frames = d->n_frames; kg.shift = d->shift; kg.win = d->win;
+  kg.snip_edges = d->snip_edges; kg.pad_left = d->win / 2 - d->shift / 2;
+  kg.preemph = d->preemphasis; kg.remove_dc = d->remove_dc_offset; kg.raw_energy = d->raw_energy;
+  kg.log_energy_floor = d->energy_floor > 0.0f ? std::log(d->energy_floor) : -INFINITY;
+  kg.eps = 1.1920928955078125e-07f;
+  kg.use_power = d->use_power; kg.use_log = d->use_log;
+  kg.energy_col = d->energy_col; kg.first_col = d->first_col; kg.n_cols = d->n_cols;
+  const int64_t n_pairs = (d->n_frames + 1) / 2;
+  int64_t blocks = (int64_t)dev_props().cu_count * 4;
+  const int64_t need = (n_pairs + p2::kWaves - 1) / p2::kWaves;
+  if (blocks > need) blocks = need;
+  const auto* twc = reinterpret_cast<const p2::C32*>(twiddle);
+#define AAMD_KALDI(EE, MODE)                                                                                       \
+  {                                                                                                                \
+    const size_t lds2 = (size_t)p2::kWaves * p2::Cfg<EE>::lds_complex * sizeof(p2::C32);                           \
+    auto k2 = p2::kaldi_pow2_kernel<EE, MODE>;                                                                     \
+    if (lds2 > 48 * 1024)                                                                                          \
+      AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                   (int)lds2));                                                                    \
+    hipLaunchKernelGGL(k2, dim3((unsigned)blocks), dim3(64 * p2::kWaves), lds2, (hipStream_t)stream, kg, wav,      \
+                       window, twc, mb, out);                                                                      \
+  }
+  if (bands == nullptr) {
+    if (d->n_fft == 512) AAMD_KALDI(8, 0) else if (d->n_fft == 1024) AAMD_KALDI(16, 0) else AAMD_KALDI(32, 0)
+  } else {
+    if (d->n_fft == 512) AAMD_KALDI(8, 1) else if (d->n_fft == 1024) AAMD_KALDI(16, 1) else AAMD_KALDI(32, 1)
+  }
+#undef AAMD_KALDI
+  return launch_check();
+}
+
 int aamd_istft_f32(const float* spec, const float* window, const float* twiddle, const float* inv_envelope,
                    float* out, const aamd_stft_desc* desc, int32_t adjoint, void* stream) {
   AAMD_CHECK_ARG(desc != nullptr && spec && window && twiddle && out, "null buffer");

@@ -380,6 +380,135 @@ AAMD_HD void inv_store(int lane, const InvGeom& ig, const LaneTab<E>& lt, const 
   }
 }
 
+// ---- Kaldi-compatible front-end (compliance/kaldi.py:154-217 _get_window, :229-315 spectrogram, :514-645 fbank) ------
+// Frames of `win` samples every `shift` samples (snip_edges, or Kaldi's edge-repeating reflection), per frame:
+// DC removal, raw log-energy, pre-emphasis, window, zero padding to N = 64 E, power spectrum, then either
+// log-power rows or mel-bank energies -- the same register FFT, a different way in and out.
+struct KaldiGeom {
+  int64_t n_samples, n_frames;
+  int32_t shift, win;                 // frame shift / length in samples (win <= N)
+  int32_t snip_edges, pad_left;       // !snip_edges: frame t starts at t * shift - pad_left of the reflected signal
+  float preemph;                      // 0 = off
+  int32_t remove_dc, raw_energy;
+  float log_energy_floor;             // log(energy_floor), or -inf when energy_floor == 0
+  float eps;                          // torch.finfo(float32).eps
+  int32_t use_power, use_log;
+  int32_t energy_col, first_col, n_cols;   // output row: [n_cols]; energy_col < 0: no energy column
+};
+
+// sample j of frame t (kaldi.py:44-83 _get_strided): snip_edges reads the signal as is; otherwise the signal is
+// extended by its mirror image WITH the edge sample repeated ([2, 1, 0, 0, 1, 2])
+AAMD_HD float kaldi_sample(const KaldiGeom& kg, const float* x, int64_t t, int j) {
+  int64_t i = t * (int64_t)kg.shift + j - (kg.snip_edges ? 0 : kg.pad_left);
+  if (i < 0) i = -1 - i;
+  if (i >= kg.n_samples) i = 2 * kg.n_samples - 1 - i;
+  return (i >= 0 && i < kg.n_samples) ? x[i] : 0.0f;
+}
+
+// raw samples of the frame and their predecessors (for the pre-emphasis), this lane's E taps; taps >= win are 0
+template <int E>
+AAMD_HD void kaldi_load(int lane, const KaldiGeom& kg, const float* x, int64_t t, float* r, float* rp) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = lane + 64 * e;
+    const bool in = j < kg.win && t < kg.n_frames;
+    r[e] = in ? kaldi_sample(kg, x, t, j) : 0.0f;
+    rp[e] = in ? kaldi_sample(kg, x, t, j > 0 ? j - 1 : 0) : 0.0f;
+  }
+}
+template <int E>
+AAMD_HD float kaldi_partial_sum(const float* r) {
+  float s = 0.0f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) s += r[e];
+  return s;
+}
+template <int E>
+AAMD_HD float kaldi_partial_sumsq(int lane, const KaldiGeom& kg, const float* r, float mean) {
+  float s = 0.0f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const float d = (lane + 64 * e < kg.win) ? r[e] - mean : 0.0f;
+    s += d * d;
+  }
+  return s;
+}
+// DC removal + pre-emphasis + window for one frame: y[j] = ((x[j] - mean) - c (x[max(j-1, 0)] - mean)) w[j]
+template <int E>
+AAMD_HD void kaldi_shape(int lane, const KaldiGeom& kg, const float* win, const float* r, const float* rp, float mean,
+                         float* y) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const bool in = lane + 64 * e < kg.win;
+    const float d = r[e] - mean, dp = rp[e] - mean;
+    y[e] = in ? (d - kg.preemph * dp) * win[e] : 0.0f;
+  }
+}
+AAMD_HD float kaldi_log_energy(const KaldiGeom& kg, float sumsq) {
+  const float le = log(fmax(sumsq, kg.eps));
+  return fmax(le, kg.log_energy_floor);
+}
+// spectrogram rows (kaldi.py:306-315): log(max(|X|^2, eps)), column 0 replaced by the log energy
+template <int E>
+AAMD_HD void kaldi_store_spec(int lane, const KaldiGeom& kg, const C32* A, const C32* B, int64_t ta, float ea, float eb,
+                              float* out) {
+  constexpr int N = Cfg<E>::N;
+  const bool vb = ta + 1 < kg.n_frames;
+  float* oa = out + ta * (int64_t)(N / 2 + 1);
+  float* ob = oa + (N / 2 + 1);
+#pragma unroll
+  for (int j = 0; j < E / 2; ++j) {
+    const int k = lane + 64 * j;
+    const float pa = log(fmax(A[j].x * A[j].x + A[j].y * A[j].y, kg.eps));
+    const float pb = log(fmax(B[j].x * B[j].x + B[j].y * B[j].y, kg.eps));
+    oa[k] = k == 0 ? ea : pa;
+    if (vb) ob[k] = k == 0 ? eb : pb;
+  }
+  if (lane == 0) {
+    oa[N / 2] = log(fmax(A[E / 2].x * A[E / 2].x + A[E / 2].y * A[E / 2].y, kg.eps));
+    if (vb) ob[N / 2] = log(fmax(B[E / 2].x * B[E / 2].x + B[E / 2].y * B[E / 2].y, kg.eps));
+  }
+}
+// |X| or |X|^2 rows of the pair in LDS, interleaved per bin (as power_rows)
+template <int E>
+AAMD_HD void kaldi_power_rows(int lane, const KaldiGeom& kg, const C32* A, const C32* B, F2* P) {
+  constexpr int F = Cfg<E>::N / 2 + 1;
+#pragma unroll
+  for (int j = 0; j <= E / 2; ++j) {
+    if (j == E / 2 && lane != 0) continue;
+    F2 p;
+    p.x = A[j].x * A[j].x + A[j].y * A[j].y;
+    p.y = B[j].x * B[j].x + B[j].y * B[j].y;
+    if (!kg.use_power) { p.x = sqrt(p.x); p.y = sqrt(p.y); }
+    P[j == E / 2 ? F - 1 : lane + 64 * j] = p;
+  }
+  if (lane == 0) { F2 z; z.x = 0.0f; z.y = 0.0f; P[F] = z; }
+}
+// mel-bank rows (kaldi.py:625-643): sum over the band, log(max(., eps)), plus the energy column
+template <int E>
+AAMD_HD void kaldi_fbank_rows(int lane, const KaldiGeom& kg, const MelBandsDev& mb, const F2* P, int64_t ta, float ea,
+                              float eb, float* out) {
+  const bool vb = ta + 1 < kg.n_frames;
+  float* oa = out + ta * (int64_t)kg.n_cols;
+  float* ob = oa + kg.n_cols;
+  for (int m = lane; m < mb.n_mels; m += 64) {
+    const int lo = mb.lo[m], w = mb.width[m];
+    const float* wt = mb.weights + (int64_t)m * mb.max_width;
+    float acc_a = 0.0f, acc_b = 0.0f;
+    for (int i = 0; i < w; ++i) {
+      const F2 p = P[lo + i];
+      acc_a += wt[i] * p.x; acc_b += wt[i] * p.y;
+    }
+    if (kg.use_log) { acc_a = log(fmax(acc_a, kg.eps)); acc_b = log(fmax(acc_b, kg.eps)); }
+    oa[kg.first_col + m] = acc_a;
+    if (vb) ob[kg.first_col + m] = acc_b;
+  }
+  if (lane == 0 && kg.energy_col >= 0) {
+    oa[kg.energy_col] = ea;
+    if (vb) ob[kg.energy_col] = eb;
+  }
+}
+
 #if defined(__HIPCC__)
 AAMD_D void wave_lds_sync() {     // program order within the wave is the only ordering these exchanges need
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -492,6 +621,75 @@ istft_pow2_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __restr
     xch2_read<E>(lane, lds, v);
     stage_c<E>(v, z);
     inv_store<E>(lane, ig, lt, z, ta, vb, inv_env, out + row * ig.g.length, add);
+  }
+}
+AAMD_D float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// MODE 0: kaldi.spectrogram rows [N/2 + 1]; MODE 1: kaldi.fbank rows [n_cols]
+template <int E, int MODE>
+__global__ void __launch_bounds__(64 * kWaves)
+kaldi_pow2_kernel(KaldiGeom kg, const float* __restrict__ wav, const float* __restrict__ window /* [N], 0 past win */,
+                  const C32* __restrict__ tw, MelBandsDev mb, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_p2[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  C32* lds = reinterpret_cast<C32*>(smem_p2) + wave * Cfg<E>::lds_complex;
+  LaneTab<E> lt;
+  lane_tab<E>(lane, window, tw, 2.0f, lt);                   // win = window (lane_tab folds 0.5 * scale)
+  const int64_t n_pairs = (kg.n_frames + 1) / 2;
+  const int64_t n_waves = (int64_t)gridDim.x * kWaves;
+  const float inv_win = 1.0f / (float)kg.win;
+#pragma unroll 1
+  for (int64_t pair = (int64_t)blockIdx.x * kWaves + wave; pair < n_pairs; pair += n_waves) {
+    const int64_t ta = 2 * pair;
+    float ra[E], rpa[E], rb[E], rpb[E], ya[E], yb[E];
+    kaldi_load<E>(lane, kg, wav, ta, ra, rpa);
+    kaldi_load<E>(lane, kg, wav, ta + 1, rb, rpb);
+    const float mean_a = kg.remove_dc ? wave_sum(kaldi_partial_sum<E>(ra)) * inv_win : 0.0f;
+    const float mean_b = kg.remove_dc ? wave_sum(kaldi_partial_sum<E>(rb)) * inv_win : 0.0f;
+    float ea = 0.0f, eb = 0.0f;
+    if (kg.raw_energy) {
+      ea = kaldi_log_energy(kg, wave_sum(kaldi_partial_sumsq<E>(lane, kg, ra, mean_a)));
+      eb = kaldi_log_energy(kg, wave_sum(kaldi_partial_sumsq<E>(lane, kg, rb, mean_b)));
+    }
+    kaldi_shape<E>(lane, kg, lt.win, ra, rpa, mean_a, ya);
+    kaldi_shape<E>(lane, kg, lt.win, rb, rpb, mean_b, yb);
+    if (!kg.raw_energy) {
+      ea = kaldi_log_energy(kg, wave_sum(kaldi_partial_sumsq<E>(lane, kg, ya, 0.0f)));
+      eb = kaldi_log_energy(kg, wave_sum(kaldi_partial_sumsq<E>(lane, kg, yb, 0.0f)));
+    }
+    C32 v[E], z[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = C32{0.5f * ya[e], 0.5f * yb[e]};   // separate() returns 2 X
+    stage_a<E>(lt, v);
+    wave_lds_sync();
+    xch1_write<E>(lane, v, lds);
+    wave_lds_sync();
+    xch1_read<E>(lane, lds, v);
+    stage_b<E>(lt, v);
+    wave_lds_sync();
+    xch2_write<E>(lane, v, lds);
+    wave_lds_sync();
+    xch2_read<E>(lane, lds, v);
+    stage_c<E>(v, z);
+    wave_lds_sync();
+    xch3_write<E>(lane, z, lds);
+    wave_lds_sync();
+    C32 A[E / 2 + 1], B[E / 2 + 1];
+    finish_bins<E>(lane, z, lds, A, B);
+    if (MODE == 0) {
+      kaldi_store_spec<E>(lane, kg, A, B, ta, ea, eb, out);
+    } else {
+      wave_lds_sync();
+      F2* P = reinterpret_cast<F2*>(lds);
+      kaldi_power_rows<E>(lane, kg, A, B, P);
+      wave_lds_sync();
+      kaldi_fbank_rows<E>(lane, kg, mb, P, ta, ea, eb, out);
+    }
   }
 }
 #endif  // __HIPCC__

@@ -633,6 +633,18 @@ def _mfcc(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, dct_mat: Tenso
     return out.view(lead + (T, n_mfcc)).transpose(-1, -2)
 
 
+def _dct_rows(x: Tensor, dct: Tensor) -> Tensor:
+    """(n_vec, n_in) @ (n_in, n_out) on the MFCC path's matrix-core DCT kernel (log_mode 2 without a cut-off =
+    plain product).  Used by compliance.kaldi.mfcc."""
+    n_vec, n_in = x.shape
+    out = torch.empty((n_vec, dct.shape[1]), dtype=torch.float32, device=x.device)
+    if out.numel():
+        L = _lib.lib()
+        _lib.check(L.aamd_mfcc_dct_f32(x.data_ptr(), dct.data_ptr(), out.data_ptr(), n_vec, n_in, dct.shape[1], 2, None, 1,
+                                       -1.0, _lib.current_stream(x.device)))
+    return out
+
+
 def mel_scale(specgram: Tensor, fb: Tensor) -> Tensor:
     """MelScale.forward (transforms/_transforms.py:403-415): (..., freq, time) -> (..., n_mels, time)."""
     _require_device(specgram, "specgram")

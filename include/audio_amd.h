@@ -24,6 +24,7 @@
  *                             (first half of MFCC.forward, _transforms.py:692-706)
  *   aamd_melspectrogram_lognorm_f32  pipelines/rnnt_pipeline.py:16-47, 319-326 (RNN-T feature extractor: the
  *                             MelSpectrogram + transpose + gain/log + global-stats normalisation chain)
+ *   aamd_kaldi_features_f32   compliance/kaldi.py:229-315 (spectrogram), :514-645 (fbank; mfcc = fbank + aamd_mfcc_dct_f32)
  *   aamd_phase_vocoder_f32    functional/functional.py:732-803 (F.phase_vocoder; T.TimeStretch, F.pitch_shift)
  *   aamd_griffinlim_update_f32  functional/functional.py:336-343 (phase update of F.griffinlim)
  *   aamd_istft_f32            functional/functional.py:148-225 (F.inverse_spectrogram -> torch.istft) and the
@@ -144,6 +145,27 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
 int aamd_melspectrogram_lognorm_f32(const float* wav, const float* window, const float* twiddle,
                                     const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
                                     const float* mean, const float* invstddev, int64_t out_frames, void* stream);
+
+/* Kaldi-compatible front-end (compliance/kaldi.py: spectrogram :229-315, fbank :514-645; the framing and per-frame
+ * conditioning of _get_window :154-217): frames of `win` samples every `shift` samples of ONE waveform, DC removal, raw
+ * or windowed log-energy, pre-emphasis, window, zero padding to n_fft, power spectrum, then
+ *   bands == NULL: rows float[n_frames][n_fft/2 + 1] = log(max(|X|^2, eps)), column 0 = log energy   (kaldi.spectrogram)
+ *   bands != NULL: rows float[n_frames][n_cols]: column first_col + m = mel-bank energy m (log(max(., eps)) if use_log),
+ *                  column energy_col (if >= 0) = log energy                                        (kaldi.fbank)
+ * window: float[n_fft], the window function in the first `win` entries, zero after.  n_fft in {512, 1024, 2048}.
+ * Dither is not applied (the reference's tests run with dither = 0). */
+typedef struct aamd_kaldi_desc {
+  int64_t n_samples, n_frames;
+  int32_t n_fft, shift, win;
+  int32_t snip_edges;
+  float preemphasis;
+  int32_t remove_dc_offset, raw_energy;
+  float energy_floor;                  /* 0: no floor */
+  int32_t use_power, use_log;
+  int32_t energy_col, first_col, n_cols;
+} aamd_kaldi_desc;
+int aamd_kaldi_features_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
+                            float* out, const aamd_kaldi_desc* desc, void* stream);
 
 /* Frames -> waveform (overlap-add).  spec: interleaved complex float[rows][n_frames][n_fft/2+1][2] (frame-major,
  * onesided); window / twiddle as for aamd_spectrogram_f32; out: float[rows][length], MUST be zero-filled by the

@@ -104,6 +104,70 @@ static int sim_istft_pow2_e(const float* spec, const float* window, const float*
   return 0;
 }
 
+template <int E>
+static int sim_kaldi_e(const float* wav, const float* window, const float* tw, const MelBandsDev& mb, float* out,
+                       const p2::KaldiGeom& kg, int mode) {
+  using namespace p2;
+  const C32* twc = reinterpret_cast<const C32*>(tw);
+  std::vector<LaneTab<E>> lt(64);
+  for (int l = 0; l < 64; ++l) lane_tab<E>(l, window, twc, 2.0f, lt[l]);
+  std::vector<C32> lds(Cfg<E>::lds_complex);
+  std::vector<std::array<C32, E>> v(64), z(64);
+  std::vector<std::array<C32, E / 2 + 1>> A(64), B(64);
+  std::vector<std::array<float, E>> ra(64), rpa(64), rb(64), rpb(64), ya(64), yb(64);
+  auto wave_sum = [](float* s) {           // the kernel's __shfl_xor butterfly, bit for bit
+    for (int off = 32; off > 0; off >>= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = s[l] + s[l ^ off]; std::memcpy(s, t, sizeof(t)); }
+    return s[0];
+  };
+  const float inv_win = 1.0f / (float)kg.win;
+  for (int64_t pair = 0; pair < (kg.n_frames + 1) / 2; ++pair) {
+    const int64_t ta = 2 * pair;
+    float s[64];
+    for (int l = 0; l < 64; ++l) { kaldi_load<E>(l, kg, wav, ta, ra[l].data(), rpa[l].data()); kaldi_load<E>(l, kg, wav, ta + 1, rb[l].data(), rpb[l].data()); }
+    float mean_a = 0, mean_b = 0, ea = 0, eb = 0;
+    if (kg.remove_dc) {
+      for (int l = 0; l < 64; ++l) s[l] = kaldi_partial_sum<E>(ra[l].data());
+      mean_a = wave_sum(s) * inv_win;
+      for (int l = 0; l < 64; ++l) s[l] = kaldi_partial_sum<E>(rb[l].data());
+      mean_b = wave_sum(s) * inv_win;
+    }
+    if (kg.raw_energy) {
+      for (int l = 0; l < 64; ++l) s[l] = kaldi_partial_sumsq<E>(l, kg, ra[l].data(), mean_a);
+      ea = kaldi_log_energy(kg, wave_sum(s));
+      for (int l = 0; l < 64; ++l) s[l] = kaldi_partial_sumsq<E>(l, kg, rb[l].data(), mean_b);
+      eb = kaldi_log_energy(kg, wave_sum(s));
+    }
+    for (int l = 0; l < 64; ++l) {
+      kaldi_shape<E>(l, kg, lt[l].win, ra[l].data(), rpa[l].data(), mean_a, ya[l].data());
+      kaldi_shape<E>(l, kg, lt[l].win, rb[l].data(), rpb[l].data(), mean_b, yb[l].data());
+    }
+    if (!kg.raw_energy) {
+      for (int l = 0; l < 64; ++l) s[l] = kaldi_partial_sumsq<E>(l, kg, ya[l].data(), 0.0f);
+      ea = kaldi_log_energy(kg, wave_sum(s));
+      for (int l = 0; l < 64; ++l) s[l] = kaldi_partial_sumsq<E>(l, kg, yb[l].data(), 0.0f);
+      eb = kaldi_log_energy(kg, wave_sum(s));
+    }
+    for (int l = 0; l < 64; ++l) {
+      for (int e = 0; e < E; ++e) v[l][e] = C32{0.5f * ya[l][e], 0.5f * yb[l][e]};
+      stage_a<E>(lt[l], v[l].data());
+    }
+    for (int l = 0; l < 64; ++l) xch1_write<E>(l, v[l].data(), lds.data());
+    for (int l = 0; l < 64; ++l) { xch1_read<E>(l, lds.data(), v[l].data()); stage_b<E>(lt[l], v[l].data()); }
+    for (int l = 0; l < 64; ++l) xch2_write<E>(l, v[l].data(), lds.data());
+    for (int l = 0; l < 64; ++l) { xch2_read<E>(l, lds.data(), v[l].data()); stage_c<E>(v[l].data(), z[l].data()); }
+    for (int l = 0; l < 64; ++l) xch3_write<E>(l, z[l].data(), lds.data());
+    for (int l = 0; l < 64; ++l) finish_bins<E>(l, z[l].data(), lds.data(), A[l].data(), B[l].data());
+    if (mode == 0) {
+      for (int l = 0; l < 64; ++l) kaldi_store_spec<E>(l, kg, A[l].data(), B[l].data(), ta, ea, eb, out);
+    } else {
+      F2* P = reinterpret_cast<F2*>(lds.data());
+      for (int l = 0; l < 64; ++l) kaldi_power_rows<E>(l, kg, A[l].data(), B[l].data(), P);
+      for (int l = 0; l < 64; ++l) kaldi_fbank_rows<E>(l, kg, mb, P, ta, ea, eb, out);
+    }
+  }
+  return 0;
+}
+
 extern "C" {
 
 int sim_stft_generic(const float* wav, const float* window, const float* tw, const aamd_mel_bands* bands,
@@ -178,6 +242,25 @@ int sim_griffinlim_update(const float* rebuilt, float* tprev, const float* mag, 
   cplx<float>* nx = reinterpret_cast<cplx<float>*>(next);
   for (int64_t i = 0; i < n; ++i) griffinlim_update_elem(r[i], tp[i], mag[i], momentum, nx[i]);
   return 0;
+}
+
+int sim_kaldi_features(const float* wav, const float* window, const float* tw, const aamd_mel_bands* bands, float* out,
+                       const aamd_kaldi_desc* d) {
+  p2::KaldiGeom kg{};
+  kg.n_samples = d->n_samples; kg.n_frames = d->n_frames; kg.shift = d->shift; kg.win = d->win;
+  kg.snip_edges = d->snip_edges; kg.pad_left = d->win / 2 - d->shift / 2;
+  kg.preemph = d->preemphasis; kg.remove_dc = d->remove_dc_offset; kg.raw_energy = d->raw_energy;
+  kg.log_energy_floor = d->energy_floor > 0.0f ? std::log(d->energy_floor) : -INFINITY;
+  kg.eps = 1.1920928955078125e-07f;
+  kg.use_power = d->use_power; kg.use_log = d->use_log;
+  kg.energy_col = d->energy_col; kg.first_col = d->first_col; kg.n_cols = d->n_cols;
+  MelBandsDev mb{};
+  if (bands) { mb.n_mels = bands->n_mels; mb.max_width = bands->max_width; mb.lo = bands->lo; mb.width = bands->width; mb.weights = bands->weights; }
+  const int mode = bands ? 1 : 0;
+  if (d->n_fft == 512) return sim_kaldi_e<8>(wav, window, tw, mb, out, kg, mode);
+  if (d->n_fft == 1024) return sim_kaldi_e<16>(wav, window, tw, mb, out, kg, mode);
+  if (d->n_fft == 2048) return sim_kaldi_e<32>(wav, window, tw, mb, out, kg, mode);
+  return -2;
 }
 
 int sim_istft_pow2(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,

@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Fixtures for the Kaldi-compatible front-end from the REFERENCE's compliance/kaldi.py on the CPU.
+Run only in the build container:   python tests/golden/make_kaldi_golden.py"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "/root/reference/src")
+import torchaudio.compliance.kaldi as K  # noqa: E402  (the reference)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+g = torch.Generator().manual_seed(7)
+t = torch.arange(24000) / 16000.0
+wav = (0.3 * torch.sin(2 * torch.pi * 300 * t) + 0.1 * torch.sin(2 * torch.pi * 2500 * t + 1.0)
+       + 0.05 * torch.randn(24000, generator=g) + 0.02)                  # DC offset on purpose
+wav = torch.stack([wav, 0.5 * torch.randn(24000, generator=g)]) * 32768.0   # Kaldi reads 16-bit scaled samples
+out = {"wav": wav.numpy()}
+cases = {
+    "fbank_default": ("fbank", dict()),
+    "fbank_80_energy": ("fbank", dict(num_mel_bins=80, use_energy=True, channel=1)),
+    "fbank_htk_nopower": ("fbank", dict(num_mel_bins=40, use_energy=True, htk_compat=True, use_power=False, raw_energy=False)),
+    "fbank_nolog_nosnip": ("fbank", dict(use_log_fbank=False, snip_edges=False, remove_dc_offset=False, preemphasis_coefficient=0.0,
+                                          window_type="hamming", energy_floor=0.0)),
+    "fbank_vtln": ("fbank", dict(num_mel_bins=30, vtln_warp=1.1, low_freq=40.0, high_freq=-200.0, subtract_mean=True)),
+    "fbank_22k": ("fbank", dict(sample_frequency=22050.0, num_mel_bins=64, window_type="blackman")),
+    "fbank_44k": ("fbank", dict(sample_frequency=44100.0, num_mel_bins=40, window_type="hanning", snip_edges=False)),
+    "spec_default": ("spectrogram", dict()),
+    "spec_rect_nosnip": ("spectrogram", dict(window_type="rectangular", snip_edges=False, raw_energy=False, subtract_mean=True)),
+    "mfcc_default": ("mfcc", dict()),
+    "mfcc_energy_htk": ("mfcc", dict(use_energy=True, htk_compat=True, num_ceps=20, num_mel_bins=40, cepstral_lifter=0.0)),
+    "mfcc_htk_noenergy": ("mfcc", dict(htk_compat=True, channel=1, subtract_mean=True)),
+}
+meta = {}
+for name, (fn, kw) in cases.items():
+    y = getattr(K, fn)(wav, **kw)
+    out[name] = y.numpy()
+    meta[name] = {"fn": fn, "kw": kw}
+    print(name, tuple(y.shape), float(y.abs().max()))
+out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+np.savez_compressed(os.path.join(HERE, "kaldi_goldens.npz"), **out)
+print("kaldi_goldens.npz", os.path.getsize(os.path.join(HERE, "kaldi_goldens.npz")) // 1024, "KiB")

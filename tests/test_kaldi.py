@@ -1,0 +1,117 @@
+"""Kaldi-compatible front-end: CPU replay of p2::kaldi_pow2_kernel and, on the GPU, the
+audio_amd.compliance.kaldi functions, against fixtures recorded from the reference's compliance/kaldi.py
+(tests/golden/make_kaldi_golden.py).  Tolerance: log-domain features, absolute 2e-3 nats / 1e-4 of the peak for linear
+outputs (the reference's own Kaldi comparison uses atol 1e-1 ... 1e-3, test/torchaudio_unittest/compliance/kaldi_*)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audio_amd import _host
+import sim_util as S
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kaldi_goldens.npz"))
+META = json.loads(bytes(G["meta"]).decode())
+DEFAULTS = dict(blackman_coeff=0.42, channel=-1, energy_floor=1.0, frame_length=25.0, frame_shift=10.0, high_freq=0.0,
+                htk_compat=False, low_freq=20.0, num_mel_bins=23, preemphasis_coefficient=0.97, raw_energy=True,
+                remove_dc_offset=True, sample_frequency=16000.0, snip_edges=True, subtract_mean=False, use_energy=False,
+                use_log_fbank=True, use_power=True, vtln_high=-500.0, vtln_low=100.0, vtln_warp=1.0, window_type="povey",
+                num_ceps=13, cepstral_lifter=22.0)
+
+
+def _close(got, ref, linear=False):
+    assert got.shape == ref.shape
+    if linear:
+        assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    else:
+        assert np.abs(got - ref).max() <= 2e-3
+
+
+def _sim(name):
+    fn, kw = META[name]["fn"], dict(DEFAULTS, **META[name]["kw"])
+    x = G["wav"][max(kw["channel"], 0)]
+    sr = kw["sample_frequency"]
+    shift, win = int(sr * kw["frame_shift"] * 0.001), int(sr * kw["frame_length"] * 0.001)
+    n_fft = 2 ** (win - 1).bit_length()
+    w = np.zeros(n_fft, dtype=np.float32)
+    w[:win] = _host.kaldi_window(kw["window_type"], win, kw["blackman_coeff"]).numpy()
+    common = dict(snip_edges=kw["snip_edges"], preemph=kw["preemphasis_coefficient"], remove_dc=kw["remove_dc_offset"],
+                  raw_energy=kw["raw_energy"], energy_floor=kw["energy_floor"])
+    if fn == "spectrogram":
+        out = S.sim_kaldi_features(x, w, n_fft, shift, win, **common)
+    else:
+        nb = kw["num_mel_bins"]
+        bins, _ = _host.kaldi_get_mel_banks(nb, n_fft, sr, kw["low_freq"], kw["high_freq"], kw["vtln_low"], kw["vtln_high"],
+                                            kw["vtln_warp"])
+        fb = torch.nn.functional.pad(bins.float(), (0, 1)).T.contiguous().numpy()
+        bands = S.HostBands(fb)
+        ue, htk = kw["use_energy"], kw["htk_compat"]
+        out = S.sim_kaldi_features(x, w, n_fft, shift, win, bands=bands, use_power=True if fn == "mfcc" else kw["use_power"],
+                                   use_log=True if fn == "mfcc" else kw["use_log_fbank"],
+                                   energy_col=-1 if not ue else (nb if htk else 0), first_col=1 if (ue and not htk) else 0,
+                                   n_cols=nb + int(ue), **common)
+        if fn == "mfcc":
+            energy = out[:, nb if htk else 0].copy() if ue else None
+            feat = out[:, int(ue and not htk):int(ue and not htk) + nb]
+            dct = _host.create_dct(nb, nb, "ortho")
+            dct[:, 0] = math.sqrt(1 / float(nb))
+            feat = feat @ dct[:, :kw["num_ceps"]].numpy()
+            if kw["cepstral_lifter"] != 0.0:
+                i = np.arange(kw["num_ceps"])
+                feat = feat * (1.0 + 0.5 * kw["cepstral_lifter"] * np.sin(math.pi * i / kw["cepstral_lifter"])).astype(np.float32)
+            if ue:
+                feat[:, 0] = energy
+            if htk:
+                e = feat[:, :1] * (1.0 if ue else math.sqrt(2))
+                feat = np.concatenate([feat[:, 1:], e], axis=1)
+            out = feat
+    if kw["subtract_mean"]:
+        out = out - out.mean(axis=0, keepdims=True)
+    return out, fn, kw
+
+
+@pytest.mark.parametrize("name", sorted(META))
+def test_sim_kaldi_vs_reference(name):
+    out, fn, kw = _sim(name)
+    _close(out, G[name], linear=(fn == "fbank" and not kw["use_log_fbank"]))
+
+
+def test_kaldi_mel_banks_match_reference_formula():
+    """Host constants: the triangles are linear in mel, sum to <= 1 per bin pair, and the warped variant keeps them ordered."""
+    bins, centers = _host.kaldi_get_mel_banks(23, 512, 16000.0, 20.0, 0.0, 100.0, -500.0, 1.0)
+    assert bins.shape == (23, 256) and torch.all(bins >= 0) and torch.all(bins <= 1)
+    assert torch.all(centers[1:] > centers[:-1])
+    peak = bins.argmax(dim=1)
+    assert torch.all(peak[1:] >= peak[:-1])
+    warped, _ = _host.kaldi_get_mel_banks(23, 512, 16000.0, 20.0, 0.0, 100.0, -500.0, 1.2)
+    assert warped.shape == bins.shape and not torch.allclose(warped, bins)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(META))
+def test_gpu_kaldi_vs_reference(name):
+    import audio_amd.compliance.kaldi as K
+    fn, kw = META[name]["fn"], META[name]["kw"]
+    wav = torch.tensor(G["wav"]).cuda()
+    with torch.no_grad():
+        y = getattr(K, fn)(wav, **kw)
+    _close(y.cpu().numpy(), G[name], linear=(fn == "fbank" and kw.get("use_log_fbank") is False))
+
+
+@pytest.mark.gpu
+def test_gpu_kaldi_errors_and_edges():
+    import audio_amd.compliance.kaldi as K
+    wav = torch.randn(1, 8000).cuda() * 1000
+    with pytest.raises(NotImplementedError):
+        K.fbank(wav, dither=1.0)
+    with pytest.raises(NotImplementedError):
+        K.fbank(wav, sample_frequency=8000.0)               # 200 -> 256: outside the register-FFT sizes
+    with pytest.raises(AssertionError):
+        K.fbank(wav[:, :300])                               # shorter than a window (reference assertion)
+    with pytest.raises(RuntimeError):
+        K.fbank(wav.cpu())
+    assert K.fbank(wav, min_duration=10.0).numel() == 0
+    assert K.fbank(wav).shape == (48, 23) and K.spectrogram(wav).shape == (48, 257) and K.mfcc(wav).shape == (48, 13)
