@@ -1,0 +1,228 @@
+"""Seeded differential fuzzing on the device: every product path against an INDEPENDENT implementation of the same
+reference semantics -- torch.stft / torch.istft (ATen + rocFFT on the same GPU, float64), the reference's pad + conv1d
+resampling composition, the float64 numpy oracle for lfilter, torch.fft for fftconvolve.  The fixture tests pin chosen
+cases; this file sweeps the parameter space (n_fft served by all three STFT kernels, every pad mode, ragged lengths,
+win_length < n_fft, pad > 0, normalisation modes, powers, batch shapes)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import peak_rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+N_FFTS = [400, 400, 400, 512, 1024, 2048, 64, 96, 200, 256, 320, 97, 480, 600, 1000]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_spectrogram_family_vs_aten_stft(seed):
+    import audio_amd.transforms as T
+    r = _rng(1000 + seed)
+    n_fft = int(r.choice(N_FFTS))
+    win_length = n_fft if r.random() < 0.7 else int(r.integers(max(2, n_fft // 3), n_fft + 1))
+    hop = int(r.choice([n_fft // 4, n_fft // 2, 160, 100, 200, int(r.integers(1, n_fft + 1))]))
+    hop = max(1, min(hop, n_fft))
+    center = bool(r.random() < 0.8)
+    pad_mode = str(r.choice(["reflect", "reflect", "constant", "replicate", "circular"]))
+    pad = int(r.choice([0, 0, 0, 13, 200]))
+    power = [2.0, 2.0, 1.0, None, 0.5, 3.0][int(r.integers(0, 6))]
+    normalized = [False, False, True, "window", "frame_length"][int(r.integers(0, 5))]
+    lead = [(1,), (3,), (2, 2), (5, 1), ()][int(r.integers(0, 5))]
+    L = int(r.integers(n_fft + 1, 6 * n_fft + 50)) if r.random() < 0.8 else int(r.integers(n_fft // 2 + 2, n_fft + 1))
+    if not center and L + 2 * pad < n_fft:
+        L = n_fft + 5
+    if pad_mode == "circular" and center and L + 2 * pad < n_fft // 2 + 1:
+        L = n_fft
+    g = torch.Generator().manual_seed(seed)
+    x = (0.5 * torch.randn(*lead, L, generator=g)).clamp_(-1, 1)
+    w = torch.hann_window(win_length, dtype=torch.float64).cuda() if r.random() < 0.7 else \
+        torch.hamming_window(win_length, dtype=torch.float64).cuda()
+    wfn = (lambda n, _w=w: _w.float().cpu())
+    t = T.Spectrogram(n_fft=n_fft, win_length=win_length, hop_length=hop, pad=pad, power=power, normalized=normalized,
+                      center=center, pad_mode=pad_mode, window_fn=wfn).cuda()
+    xc = x.cuda()
+    with torch.no_grad():
+        got = t(xc)
+    xd = xc.double()
+    if pad:
+        xd = torch.nn.functional.pad(xd, (pad, pad))
+    shp = xd.shape
+    ref = torch.stft(xd.reshape(-1, shp[-1]), n_fft, hop, win_length, w, center, pad_mode, False, True, return_complex=True)
+    ref = ref.reshape(shp[:-1] + ref.shape[-2:])
+    if normalized is True or normalized == "window":
+        ref = ref / w.pow(2).sum().sqrt()
+    elif normalized == "frame_length":
+        ref = ref / math.sqrt(n_fft)
+    cfg = dict(n_fft=n_fft, wl=win_length, hop=hop, center=center, pad_mode=pad_mode, pad=pad, power=power, norm=normalized, L=L)
+    assert got.shape == ref.shape, cfg
+    if power is None:
+        e = peak_rel_err(torch.view_as_real(got).cpu().numpy(), torch.view_as_real(ref).cpu().numpy())
+    else:
+        # compare in the power-spectrum domain: fractional powers amplify the rounding of near-zero bins without bound
+        back = 2.0 / power
+        e = peak_rel_err(got.double().pow(back).cpu().numpy(), ref.abs().pow(2.0).cpu().numpy())
+    assert e <= 2e-5, (cfg, e)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_melspectrogram_and_mfcc_vs_aten(seed):
+    import audio_amd.transforms as T
+    from oracle import torch_cpu_ref as R
+    r = _rng(2000 + seed)
+    n_fft = int(r.choice([400, 400, 512, 1024, 2048, 320, 256]))
+    hop = int(r.choice([n_fft // 4, n_fft // 2, 160 if n_fft >= 320 else 64]))
+    n_mels = int(r.choice([23, 40, 64, 80, 128]))
+    sr = int(r.choice([16000, 22050, 44100]))
+    mel_scale = str(r.choice(["htk", "slaney"]))
+    norm = [None, "slaney"][int(r.integers(0, 2))]
+    lead = [(2,), (3, 1), (2, 2)][int(r.integers(0, 3))]
+    L = int(r.integers(2 * n_fft, 8 * n_fft))
+    g = torch.Generator().manual_seed(seed)
+    x = (0.5 * torch.randn(*lead, L, generator=g)).clamp_(-1, 1)
+    m = T.MelSpectrogram(sample_rate=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, mel_scale=mel_scale, norm=norm).cuda()
+    with torch.no_grad():
+        got = m(x.cuda())
+    w = torch.hann_window(n_fft, dtype=torch.float64).cuda()
+    ref = R.mel_spectrogram(x.cuda().double(), w, m.mel_scale.fb.double(), n_fft, hop)
+    assert got.shape == ref.shape
+    assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (n_fft, hop, n_mels, sr, mel_scale, norm)
+    n_mfcc = min(n_mels, int(r.choice([13, 20, 40])))
+    log_mels = bool(r.random() < 0.3)
+    mf = T.MFCC(sample_rate=sr, n_mfcc=n_mfcc, log_mels=log_mels,
+                melkwargs=dict(n_fft=n_fft, hop_length=hop, n_mels=n_mels, mel_scale=mel_scale, norm=norm)).cuda()
+    with torch.no_grad():
+        got = mf(x.cuda())
+    mel64 = R.mel_spectrogram(x.cuda().double(), w, mf.MelSpectrogram.mel_scale.fb.double(), n_fft, hop)
+    y = torch.log(mel64 + 1e-6) if log_mels else R.amplitude_to_db(mel64)
+    ref = torch.matmul(y.transpose(-1, -2), mf.dct_mat.double()).transpose(-1, -2)
+    assert got.shape == ref.shape
+    # dB / log features: absolute tolerance relative to the feature range (80 dB window)
+    assert np.abs(got.cpu().numpy() - ref.cpu().numpy()).max() <= 2e-3 * max(1.0, float(ref.abs().max()) / 80.0), \
+        (n_fft, hop, n_mels, n_mfcc, log_mels)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_inverse_spectrogram_vs_aten_istft(seed):
+    import audio_amd.transforms as T
+    r = _rng(3000 + seed)
+    n_fft = int(r.choice([400, 512, 1024, 2048, 200, 96, 256]))
+    hop = int(r.choice([n_fft // 4, n_fft // 2, n_fft // 3]))
+    win_length = n_fft if r.random() < 0.7 else int(n_fft * 0.75)
+    normalized = [False, "window", "frame_length"][int(r.integers(0, 3))]
+    L = int(r.integers(3 * n_fft, 10 * n_fft))
+    use_length = bool(r.random() < 0.5)
+    g = torch.Generator().manual_seed(seed)
+    x = (0.5 * torch.randn(3, L, generator=g)).cuda()
+    s = T.Spectrogram(n_fft=n_fft, win_length=win_length, hop_length=hop, power=None, normalized=normalized).cuda()
+    inv = T.InverseSpectrogram(n_fft=n_fft, win_length=win_length, hop_length=hop, normalized=normalized).cuda()
+    with torch.no_grad():
+        X = s(x)
+        got = inv(X, L if use_length else None)
+    w = torch.hann_window(win_length, dtype=torch.float64).cuda()
+    Xs = X.to(torch.complex128)
+    if normalized == "window":
+        Xs = Xs * w.pow(2).sum().sqrt()
+    elif normalized == "frame_length":
+        Xs = Xs * math.sqrt(n_fft)
+    ref = torch.istft(Xs, n_fft, hop, win_length, w, True, False, True, L if use_length else None, False)
+    assert got.shape == ref.shape
+    assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (n_fft, hop, win_length, normalized, L, use_length)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_resample_vs_reference_composition(seed):
+    import audio_amd.transforms as T
+    from oracle import torch_cpu_ref as R
+    r = _rng(4000 + seed)
+    rates = [(44100, 16000), (16000, 44100), (48000, 16000), (8000, 16000), (16000, 8000), (22050, 16000), (48000, 44100),
+             (16000, 22050), (32000, 48000), (11025, 8000), (16000, 15999), (7, 3)]
+    orig, new = rates[int(r.integers(0, len(rates)))]
+    kw = {}
+    if r.random() < 0.4:
+        kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=int(r.choice([6, 16, 64])),
+                  rolloff=float(r.choice([0.99, 0.9475937167399596])), beta=float(r.choice([14.769656459379492, 8.0])))
+    elif r.random() < 0.5:
+        kw = dict(lowpass_filter_width=int(r.choice([6, 12])), rolloff=float(r.choice([0.99, 0.85])))
+    lead = [(2,), (2, 2), (1, 3)][int(r.integers(0, 3))]
+    L = int(r.integers(50, 30000))
+    g = torch.Generator().manual_seed(seed)
+    x = (0.5 * torch.randn(*lead, L, generator=g)).clamp_(-1, 1)
+    t = T.Resample(orig, new, **kw).cuda()
+    with torch.no_grad():
+        got = t(x.cuda())
+    gcd = math.gcd(orig, new)
+    ref = R.resample(x.cuda().double(), t.kernel.double(), orig // gcd, new // gcd, t.width)
+    assert got.shape == ref.shape, (orig, new, kw, L)
+    assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (orig, new, kw, L)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_lfilter_vs_oracle(seed):
+    import audio_amd.functional as F
+    from oracle import dsp_oracle as O
+    r = _rng(5000 + seed)
+    order = int(r.choice([1, 2, 2, 2, 3, 4, 6, 8]))
+    # stable filters: poles drawn inside the unit circle (radius <= 0.9)
+    poles = []
+    while len(poles) < order:
+        if order - len(poles) >= 2 and r.random() < 0.7:
+            rad, th = r.uniform(0.2, 0.9), r.uniform(0.1, 3.0)
+            poles += [rad * np.exp(1j * th), rad * np.exp(-1j * th)]
+        else:
+            poles.append(r.uniform(-0.9, 0.9))
+    a = np.real(np.poly(poles))
+    b = r.uniform(-0.5, 0.5, size=order + 1)
+    a0 = r.uniform(0.5, 2.0)
+    a, b = a * a0, b * a0
+    batched = bool(r.random() < 0.3)
+    clamp = bool(r.random() < 0.5)
+    shape = [(3, 5000), (2, 3, 2500), (4, 17), (1, 100000)][int(r.integers(0, 4))]
+    g = torch.Generator().manual_seed(seed)
+    x = (0.4 * torch.randn(*shape, generator=g)).clamp_(-1, 1)
+    if batched:
+        nf = shape[-2]
+        A = np.stack([a * (1 + 0.01 * i) for i in range(nf)])
+        B = np.stack([b * (1 - 0.02 * i) for i in range(nf)])
+        A[:, 0] = a[0]
+    else:
+        A, B = a, b
+    with torch.no_grad():
+        got = F.lfilter(x.cuda(), torch.tensor(A, dtype=torch.float32).cuda(), torch.tensor(B, dtype=torch.float32).cuda(), clamp=clamp)
+    ref = O.lfilter(x.numpy().astype(np.float64), np.asarray(A, dtype=np.float32).astype(np.float64),
+                    np.asarray(B, dtype=np.float32).astype(np.float64), clamp=clamp)
+    tol = 1e-4 if order <= 2 else 5e-4            # the reference's own fp32 recursion drifts at high order
+    assert got.shape == ref.shape
+    assert peak_rel_err(got.cpu().numpy(), ref) <= tol, (order, batched, clamp, shape)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_fftconvolve_vs_fft(seed):
+    import audio_amd.functional as F
+    r = _rng(6000 + seed)
+    nx = int(r.choice([17, 500, 4096, 20000, 70000]))
+    ny = int(r.choice([1, 3, 64, 191, 193, 700, 8192, 8193, 17000, 30000]))
+    mode = str(r.choice(["full", "same", "valid"]))
+    xs, ys = [((3, nx), (3, ny)), ((2, 2, nx), (1, 1, ny)), ((1, nx), (4, ny)), ((2, 1, nx), (2, 3, ny))][int(r.integers(0, 4))]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*xs, generator=g)
+    y = torch.randn(*ys, generator=g) * 0.2
+    with torch.no_grad():
+        got = F.fftconvolve(x.cuda(), y.cuda(), mode)
+    n = nx + ny - 1
+    xd, yd = x.cuda().double(), y.cuda().double()
+    full = torch.fft.irfft(torch.fft.rfft(xd, n=n) * torch.fft.rfft(yd, n=n), n=n)
+    if mode == "full":
+        ref = full
+    else:
+        m = nx if mode == "same" else max(nx, ny) - min(nx, ny) + 1
+        s0 = (n - m) // 2
+        ref = full[..., s0:s0 + m]
+    assert got.shape == ref.shape, (xs, ys, mode)
+    assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (xs, ys, mode)
