@@ -447,15 +447,34 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
     int64_t blocks = (int64_t)dev_props().cu_count * (g.n_fft == 512 ? 8 : g.n_fft == 1024 ? 4 : 2);
     const int64_t need = (n_pairs + p2::kWaves - 1) / p2::kWaves;
     if (blocks > need) blocks = need;
+    // runs of consecutive pairs per wave (overlap-add in an LDS ring, plain stores); hop > n_fft leaves gaps the ring
+    // logic does not model: pair-at-a-time atomics there
+    const bool use_runs = g.hop <= g.n_fft && std::getenv("AAMD_ISTFT_ATOMIC") == nullptr;
+    const int run_len = 16;
+    const int64_t rpr = (ppr + run_len - 1) / run_len, n_runs = g.rows * rpr;
+    if (use_runs) {
+      const int64_t need_r = (n_runs + p2::kWaves - 1) / p2::kWaves;
+      if (blocks > need_r) blocks = need_r;
+    }
 #define AAMD_IP2(EE)                                                                                              \
     {                                                                                                             \
-      const size_t lds2 = (size_t)p2::kWaves * p2::Cfg<EE>::lds_complex * sizeof(p2::C32);                        \
-      auto k2 = p2::istft_pow2_kernel<EE>;                                                                        \
-      if (lds2 > 48 * 1024)                                                                                       \
-        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                     (int)lds2));                                                                 \
-      hipLaunchKernelGGL(k2, dim3((unsigned)blocks), dim3(64 * p2::kWaves), lds2, (hipStream_t)stream, ig, sp,    \
-                         window, twc, inv_envelope, out, og.scale, ppr, n_pairs);                                 \
+      if (use_runs) {                                                                                             \
+        const size_t lds2 = (size_t)p2::kWaves * (2 * p2::Cfg<EE>::lds_complex + 2 * p2::Cfg<EE>::N) * sizeof(float); \
+        auto k2 = p2::istft_pow2_run_kernel<EE>;                                                                  \
+        if (lds2 > 48 * 1024)                                                                                     \
+          AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds2));                                                               \
+        hipLaunchKernelGGL(k2, dim3((unsigned)blocks), dim3(64 * p2::kWaves), lds2, (hipStream_t)stream, ig, sp,  \
+                           window, twc, inv_envelope, out, og.scale, ppr, rpr, n_runs, run_len);                  \
+      } else {                                                                                                    \
+        const size_t lds2 = (size_t)p2::kWaves * p2::Cfg<EE>::lds_complex * sizeof(p2::C32);                      \
+        auto k2 = p2::istft_pow2_kernel<EE>;                                                                      \
+        if (lds2 > 48 * 1024)                                                                                     \
+          AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds2));                                                               \
+        hipLaunchKernelGGL(k2, dim3((unsigned)blocks), dim3(64 * p2::kWaves), lds2, (hipStream_t)stream, ig, sp,  \
+                           window, twc, inv_envelope, out, og.scale, ppr, n_pairs);                               \
+      }                                                                                                           \
     }
     if (g.n_fft == 512) AAMD_IP2(8) else if (g.n_fft == 1024) AAMD_IP2(16) else AAMD_IP2(32)
 #undef AAMD_IP2

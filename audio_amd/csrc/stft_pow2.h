@@ -380,6 +380,67 @@ AAMD_HD void inv_store(int lane, const InvGeom& ig, const LaneTab<E>& lt, const 
   }
 }
 
+// Run-based overlap-add: a wave walks a RUN of consecutive pairs of one row and sums their overlapping frames in a
+// wave-private LDS ring (2 N floats, LDS float adds), writing every finished sample once.  Samples that only this run's
+// interior frames touch are PLAIN stores; the halo a neighbouring run, an edge pair or a folded (reflected / wrapped)
+// contribution can also reach is added atomically.  Cuts the global atomics of the pair-at-a-time scheme (every sample
+// hit N / hop times) to the ~N / (run_len hop) halo share.
+struct RunPlan {
+  int64_t excl_lo, excl_hi;      // samples s with excl_lo <= s < excl_hi belong to this run alone
+  int64_t pi_lo, pi_hi;          // interior pairs of the run (inclusive; pi_lo > pi_hi: none)
+};
+template <int E>
+AAMD_HD RunPlan run_plan(const StftGeom& g, int64_t p_lo, int64_t p_hi /* exclusive */) {
+  constexpr int N = Cfg<E>::N;
+  const int64_t c = (g.center ? N / 2 : 0) + g.pad, hop = g.hop;
+  // pair p is interior iff 2 p hop - c >= 0 and (2 p + 1) hop - c + N <= length (and frame 2 p + 1 exists)
+  int64_t first = (c + 2 * hop - 1) / (2 * hop);
+  int64_t last_t = (g.length + c - N) / hop;                       // last frame that ends inside the row
+  if (g.length + c - N < 0) last_t = -1;
+  if (last_t > g.n_frames - 1) last_t = g.n_frames - 1;
+  int64_t last = (last_t - 1) / 2;                                   // 2 p + 1 <= last_t
+  if (last_t < 1) last = -1;
+  RunPlan rp;
+  rp.pi_lo = p_lo > first ? p_lo : first;
+  rp.pi_hi = (p_hi - 1) < last ? (p_hi - 1) : last;
+  const int64_t tA = 2 * rp.pi_lo, tB = 2 * rp.pi_hi + 1;
+  rp.excl_lo = (tA - 1) * hop + N - c;
+  if (rp.excl_lo < c + 1) rp.excl_lo = c + 1;                        // folded / wrapped edge contributions land below c + 1 ...
+  rp.excl_hi = (tB + 1) * hop - c;
+  if (rp.excl_hi > g.length - c - 1) rp.excl_hi = g.length - c - 1;  // ... and above length - c - 1
+  return rp;
+}
+// add the pair's two frames into the ring (positions are row-local output samples, ring index = s mod 2 N): plain
+// read-add-write -- lanes of one frame touch distinct words, frame b starts after frame a's writes (in-order LDS);
+// LDS float atomics cost ~64 cycles per instruction here and made the kernel slower than global atomics
+template <int E>
+AAMD_HD void ring_add(int lane, const LaneTab<E>& lt, const C32* z, int64_t sa, int hop, bool vb, float* ring) {
+  constexpr int M = 2 * Cfg<E>::N - 1;
+  float cur[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) cur[j] = ring[(sa + lane + 64 * j) & M];
+#pragma unroll
+  for (int j = 0; j < E; ++j) ring[(sa + lane + 64 * j) & M] = cur[j] + z[j].x * lt.win[j];
+  if (!vb) return;
+#pragma unroll
+  for (int j = 0; j < E; ++j) cur[j] = ring[(sa + hop + lane + 64 * j) & M];
+#pragma unroll
+  for (int j = 0; j < E; ++j) ring[(sa + hop + lane + 64 * j) & M] = cur[j] - z[j].y * lt.win[j];
+}
+// write out (and clear) the finished samples [s0, s1)
+template <int E, typename AddFn>
+AAMD_HD void ring_flush(int lane, const RunPlan& rp, int64_t s0, int64_t s1, const float* inv_env, float* ring,
+                        float* out_row, AddFn add) {
+  constexpr int M = 2 * Cfg<E>::N - 1;
+  for (int64_t s = s0 + lane; s < s1; s += 64) {
+    float v = ring[s & M];
+    ring[s & M] = 0.0f;
+    if (inv_env) v *= inv_env[s];
+    if (s >= rp.excl_lo && s < rp.excl_hi) out_row[s] = v;
+    else add(out_row + s, v);
+  }
+}
+
 // ---- Kaldi-compatible front-end (compliance/kaldi.py:154-217 _get_window, :229-315 spectrogram, :514-645 fbank) ------
 // Frames of `win` samples every `shift` samples (snip_edges, or Kaldi's edge-repeating reflection), per frame:
 // DC removal, raw log-energy, pre-emphasis, window, zero padding to N = 64 E, power spectrum, then either
@@ -623,6 +684,70 @@ istft_pow2_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __restr
     inv_store<E>(lane, ig, lt, z, ta, vb, inv_env, out + row * ig.g.length, add);
   }
 }
+template <int E>
+__global__ void __launch_bounds__(64 * kWaves)
+istft_pow2_run_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __restrict__ window,
+                      const C32* __restrict__ tw, const float* __restrict__ inv_env, float* __restrict__ out,
+                      float out_scale, int64_t pairs_per_row, int64_t runs_per_row, int64_t n_runs, int run_len) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_p2[];
+  constexpr int N = Cfg<E>::N, F = N / 2 + 1;
+  constexpr int kWaveFloats = 2 * Cfg<E>::lds_complex + 2 * N;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* wbase = reinterpret_cast<float*>(smem_p2) + wave * kWaveFloats;
+  C32* lds = reinterpret_cast<C32*>(wbase);
+  float* ring = wbase + 2 * Cfg<E>::lds_complex;
+  for (int i = lane; i < 2 * N; i += 64) ring[i] = 0.0f;
+  LaneTab<E> lt;
+  lane_tab<E>(lane, window, tw, 2.0f * out_scale, lt);
+  const StftGeom& g = ig.g;
+  const int64_t c = (g.center ? N / 2 : 0) + g.pad;
+  const int64_t n_waves = (int64_t)gridDim.x * kWaves;
+  auto add = [](float* p, float v) { atomicAdd(p, v); };
+  wave_lds_sync();
+#pragma unroll 1
+  for (int64_t run = (int64_t)blockIdx.x * kWaves + wave; run < n_runs; run += n_waves) {
+    const int64_t row = run / runs_per_row;
+    const int64_t p_lo = (run - row * runs_per_row) * run_len;
+    const int64_t p_hi = p_lo + run_len < pairs_per_row ? p_lo + run_len : pairs_per_row;
+    const RunPlan rp = run_plan<E>(g, p_lo, p_hi);
+    float* out_row = out + row * g.length;
+    const float* env = inv_env;
+    int64_t flushed = 0;
+#pragma unroll 1
+    for (int64_t p = p_lo; p < p_hi; ++p) {
+      const int64_t ta = 2 * p;
+      const bool vb = ta + 1 < g.n_frames;
+      const C32* Sa = spec + (row * g.n_frames + ta) * (int64_t)F;
+      C32 v[E], z[E];
+      inv_load<E>(lane, ig, Sa, vb ? Sa + F : nullptr, v);
+      stage_a<E>(lt, v);
+      wave_lds_sync();
+      xch1_write<E>(lane, v, lds);
+      wave_lds_sync();
+      xch1_read<E>(lane, lds, v);
+      stage_b<E>(lt, v);
+      wave_lds_sync();
+      xch2_write<E>(lane, v, lds);
+      wave_lds_sync();
+      xch2_read<E>(lane, lds, v);
+      stage_c<E>(v, z);
+      if (p >= rp.pi_lo && p <= rp.pi_hi) {                   // interior pair: through the ring
+        const int64_t sa = ta * (int64_t)g.hop - c;
+        if (p == rp.pi_lo) flushed = sa;
+        ring_add<E>(lane, lt, z, sa, g.hop, true, ring);
+        wave_lds_sync();
+        const int64_t s1 = p == rp.pi_hi ? sa + g.hop + N : sa + 2 * (int64_t)g.hop;   // run end: everything left
+        ring_flush<E>(lane, rp, flushed, s1, env, ring, out_row, add);
+        flushed = s1;
+        wave_lds_sync();
+      } else {                                                // edge pair: index map per sample, atomics
+        inv_store<E>(lane, ig, lt, z, ta, vb, env, out_row, add);
+      }
+    }
+  }
+}
+
 AAMD_D float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -78,29 +78,63 @@ static int sim_pow2_e(const float* wav, const float* window, const float* tw, co
 
 template <int E>
 static int sim_istft_pow2_e(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,
-                            const StftGeom& g, float interior, float out_scale) {
+                            const StftGeom& g, float interior, float out_scale, int runs) {
   using namespace p2;
-  constexpr int F = Cfg<E>::N / 2 + 1;
+  constexpr int N = Cfg<E>::N, F = N / 2 + 1;
   const C32* twc = reinterpret_cast<const C32*>(tw);
   const C32* sp = reinterpret_cast<const C32*>(spec);
   InvGeom ig{g, interior};
   std::vector<LaneTab<E>> lt(64);
   for (int l = 0; l < 64; ++l) lane_tab<E>(l, window, twc, 2.0f * out_scale, lt[l]);
   std::vector<C32> lds(Cfg<E>::lds_complex);
+  std::vector<float> ring(2 * N, 0.0f);
   std::vector<std::array<C32, E>> v(64), z(64);
   const int64_t ppr = (g.n_frames + 1) / 2;
+  const int64_t c = (g.center ? N / 2 : 0) + g.pad;
   auto add = [](float* p, float x) { *p += x; };
-  for (int64_t pair = 0; pair < g.rows * ppr; ++pair) {
-    const int64_t row = pair / ppr, ta = 2 * (pair - row * ppr);
-    const bool vb = ta + 1 < g.n_frames;
+  auto fft_pair = [&](int64_t row, int64_t ta, bool vb) {
     const C32* Sa = sp + (row * g.n_frames + ta) * (int64_t)F;
     for (int l = 0; l < 64; ++l) { inv_load<E>(l, ig, Sa, vb ? Sa + F : nullptr, v[l].data()); stage_a<E>(lt[l], v[l].data()); }
     for (int l = 0; l < 64; ++l) xch1_write<E>(l, v[l].data(), lds.data());
     for (int l = 0; l < 64; ++l) { xch1_read<E>(l, lds.data(), v[l].data()); stage_b<E>(lt[l], v[l].data()); }
     for (int l = 0; l < 64; ++l) xch2_write<E>(l, v[l].data(), lds.data());
     for (int l = 0; l < 64; ++l) { xch2_read<E>(l, lds.data(), v[l].data()); stage_c<E>(v[l].data(), z[l].data()); }
-    for (int l = 0; l < 64; ++l) inv_store<E>(l, ig, lt[l], z[l].data(), ta, vb, inv_env, out + row * g.length, add);
+  };
+  if (!runs) {
+    for (int64_t pair = 0; pair < g.rows * ppr; ++pair) {
+      const int64_t row = pair / ppr, ta = 2 * (pair - row * ppr);
+      const bool vb = ta + 1 < g.n_frames;
+      fft_pair(row, ta, vb);
+      for (int l = 0; l < 64; ++l) inv_store<E>(l, ig, lt[l], z[l].data(), ta, vb, inv_env, out + row * g.length, add);
+    }
+    return 0;
   }
+  // istft_pow2_run_kernel; plain stores are modelled as stores (a double write would show up as a wrong value)
+  const int run_len = runs;
+  const int64_t rpr = (ppr + run_len - 1) / run_len;
+  for (int64_t run = 0; run < g.rows * rpr; ++run) {
+    const int64_t row = run / rpr, p_lo = (run - row * rpr) * run_len;
+    const int64_t p_hi = p_lo + run_len < ppr ? p_lo + run_len : ppr;
+    const RunPlan rp = run_plan<E>(g, p_lo, p_hi);
+    float* out_row = out + row * g.length;
+    int64_t flushed = 0;
+    for (int64_t p = p_lo; p < p_hi; ++p) {
+      const int64_t ta = 2 * p;
+      const bool vb = ta + 1 < g.n_frames;
+      fft_pair(row, ta, vb);
+      if (p >= rp.pi_lo && p <= rp.pi_hi) {
+        const int64_t sa = ta * (int64_t)g.hop - c;
+        if (p == rp.pi_lo) flushed = sa;
+        for (int l = 0; l < 64; ++l) ring_add<E>(l, lt[l], z[l].data(), sa, g.hop, true, ring.data());
+        const int64_t s1 = p == rp.pi_hi ? sa + g.hop + N : sa + 2 * (int64_t)g.hop;
+        for (int l = 0; l < 64; ++l) ring_flush<E>(l, rp, flushed, s1, inv_env, ring.data(), out_row, add);
+        flushed = s1;
+      } else {
+        for (int l = 0; l < 64; ++l) inv_store<E>(l, ig, lt[l], z[l].data(), ta, vb, inv_env, out_row, add);
+      }
+    }
+  }
+  for (float r : ring) if (r != 0.0f) return -3;      // every sample must have been flushed
   return 0;
 }
 
@@ -264,15 +298,15 @@ int sim_kaldi_features(const float* wav, const float* window, const float* tw, c
 }
 
 int sim_istft_pow2(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,
-                   const aamd_stft_desc* d, int adjoint) {
+                   const aamd_stft_desc* d, int adjoint, int runs) {
   StftGeom g{};
   fill_geom(d, g);
   g.onesided = 1; g.n_freq = g.n_fft / 2 + 1; g.row_stride = g.length;
   const float interior = adjoint ? 0.5f : 1.0f;
   const float scale = d->scale * (adjoint ? 1.0f : 1.0f / (float)d->n_fft);
-  if (g.n_fft == 512) return sim_istft_pow2_e<8>(spec, window, tw, inv_env, out, g, interior, scale);
-  if (g.n_fft == 1024) return sim_istft_pow2_e<16>(spec, window, tw, inv_env, out, g, interior, scale);
-  if (g.n_fft == 2048) return sim_istft_pow2_e<32>(spec, window, tw, inv_env, out, g, interior, scale);
+  if (g.n_fft == 512) return sim_istft_pow2_e<8>(spec, window, tw, inv_env, out, g, interior, scale, runs);
+  if (g.n_fft == 1024) return sim_istft_pow2_e<16>(spec, window, tw, inv_env, out, g, interior, scale, runs);
+  if (g.n_fft == 2048) return sim_istft_pow2_e<32>(spec, window, tw, inv_env, out, g, interior, scale, runs);
   return -2;
 }
 
