@@ -188,8 +188,8 @@ bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
          m400::mel_rounds(mb.n_mels) <= m400::kMelMaxRounds;
 }
 
-template <int EPI, int H>
-int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
+template <int EPI, int H, typename TIn = float>
+int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, const float* window,
                     const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
   const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
@@ -200,7 +200,7 @@ int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const float* wav, 
   const size_t lds = (EPI == m400::EPI400_SPEC) ? m400::lds_bytes(0, 1, wdw) : m400::lds_bytes(mb.n_mels, mb.max_width, wdw);
   if (lds > dev_props().lds_per_block_optin)
     return fail(AAMD_EUNSUPPORTED, "audio_amd: mel filterbank too large for the LDS of this device");
-  auto kern = m400::melspec400_kernel<0, EPI, H>;
+  auto kern = m400::melspec400_kernel<0, EPI, H, TIn>;
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -213,7 +213,7 @@ int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const float* wav, 
   if (blocks < 1) blocks = 1;
   const int tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
   // 16-B paths: LDS-DMA staging of the waveform, dwordx4 stores of the output rows
-  const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (g.row_stride % 4 == 0);
+  const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (g.row_stride % (16 / (int)sizeof(TIn)) == 0);
   // mel rows leave as 4-byte stores straight from the accumulators: the LDS pipe is this kernel's
   // bottleneck and the LDS-staged dwordx4 path measured 3-4 us slower (AAMD_MEL400_WIDE=1 selects it)
   const bool want_wide = (EPI == m400::EPI400_SPEC) || std::getenv("AAMD_MEL400_WIDE") != nullptr;
@@ -369,6 +369,32 @@ int aamd_melspectrogram_lognorm_f32(const float* wav, const float* window, const
   hipLaunchKernelGGL(lognorm_kernel, dim3(grid_for(n, 256, dev_props().cu_count * 16)), dim3(256), 0,
                      (hipStream_t)stream, out, n, mb.n_mels, gain, mean, invstddev);
   return launch_check();
+}
+
+int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const float* twiddle,
+                                  const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
+                                  const float* mean, const float* invstddev, int64_t out_frames, void* stream) {
+  StftGeom g;
+  int rc = validate_desc(desc, g);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(wav && window && twiddle && out, "null buffer");
+  AAMD_CHECK_ARG((mean == nullptr) == (invstddev == nullptr), "mean and invstddev come together");
+  AAMD_CHECK_ARG(desc->power > 0.0f && desc->onesided, "mel spectrogram needs power > 0 and a onesided spectrum");
+  MelBandsDev mb;
+  rc = validate_bands(bands, g.n_freq, mb);
+  if (rc != AAMD_OK) return rc;
+  if (!mel400_eligible(g, mb) || (g.hop != 160 && g.hop != 200))
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: int16 PCM input is served by the n_fft = 400, hop 160 / 200 kernel only");
+  hipStream_t s = (hipStream_t)stream;
+  if (mean != nullptr) {
+    AAMD_CHECK_ARG(out_frames >= desc->n_frames, "out_frames must be >= n_frames");
+    m400::Epi400 epi{};
+    epi.gain = gain; epi.mean = mean; epi.invstd = invstddev; epi.out_frames = out_frames;
+    return g.hop == 160 ? launch_fft400_h<m400::EPI400_MEL_NORM, 8, int16_t>(g, mb, wav, window, twiddle, out, epi, s)
+                        : launch_fft400_h<m400::EPI400_MEL_NORM, 10, int16_t>(g, mb, wav, window, twiddle, out, epi, s);
+  }
+  return g.hop == 160 ? launch_fft400_h<m400::EPI400_MEL, 8, int16_t>(g, mb, wav, window, twiddle, out, m400::Epi400{}, s)
+                      : launch_fft400_h<m400::EPI400_MEL, 10, int16_t>(g, mb, wav, window, twiddle, out, m400::Epi400{}, s);
 }
 
 int aamd_kaldi_features_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,

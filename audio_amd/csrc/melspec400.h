@@ -75,6 +75,31 @@ struct Hop {
   static constexpr int lds_dwords = (kSOff + 256 * ndma > kLdsDwordsPerWave) ? kSOff + 256 * ndma : kLdsDwordsPerWave;
   static_assert(pad % 4 == 0 && (pair_stride + pad) % 32 == 20, "staging pad");
 };
+// Staging layout of the NEXT tile's samples for an input element type TIn (float, or int16 PCM: SURVEY 8(f) rank 4,
+// the upstream half -- the waveform is read as the 16-bit samples the decoder produced and converted in the gather, so
+// the separate int16 -> float pass and half of the input bytes disappear).  16-B pieces hold 4 or 8 samples; `pad`
+// dwords after every pair_stride samples put the three pairs' strided rows on disjoint banks:
+//   float: (pair dwords + pad) = 20 (mod 32);  int16: two lanes share a dword, a pair's row spans 10 dwords, and
+//   (pair dwords + pad) = 44 (mod 64) puts the three rows at banks 0.., 44.., 24..
+template <int H, typename TIn>
+struct Stage {
+  using HC = Hop<H>;
+  static constexpr int spp = 16 / (int)sizeof(TIn);                                  // samples per piece
+  static constexpr int pair_dwords = HC::pair_stride * (int)sizeof(TIn) / 4;
+  static constexpr int pad = sizeof(TIn) == 4 ? HC::pad : ((44 - pair_dwords % 64) + 64) % 64;   // dwords
+  static constexpr int pad_elems = pad * 4 / (int)sizeof(TIn);
+  static constexpr int blk_data = HC::pair_stride / spp, blk_pieces = blk_data + pad / 4;
+  static constexpr int data_pieces = HC::tile_samples / spp;
+  static constexpr int pieces = data_pieces + (pad / 4) * ((HC::tile_samples - 1) / HC::pair_stride);
+  static constexpr int ndma = (pieces + 63) / 64;
+  static constexpr bool ok = (HC::pair_stride % spp == 0) && (HC::tile_samples % spp == 0) && (pad % 4 == 0) &&
+                             (kSOff + 256 * ndma <= HC::lds_dwords);
+};
+static_assert(Stage<8, float>::blk_data == Hop<8>::blk_data && Stage<8, float>::blk_pieces == Hop<8>::blk_pieces &&
+              Stage<8, float>::pieces == Hop<8>::pieces && Stage<8, float>::ndma == Hop<8>::ndma, "float staging = Hop");
+static_assert(Stage<8, int16_t>::ok && Stage<8, int16_t>::pad == 12 && Stage<8, int16_t>::ndma == 3, "int16 staging, hop 160");
+static_assert(Stage<10, int16_t>::ok && Stage<5, float>::ok && Stage<10, float>::ok, "staging geometry");
+
 constexpr int kMelSlots = 20;                  // mels per round
 constexpr int kMelMaxRounds = 8;               // n_mels <= 160
 constexpr int kMelMaxTaps = 64;                // widest padded band (taps)
@@ -299,25 +324,26 @@ AAMD_HD int64_t reflect_idx(int64_t i, int64_t len) {
 // (coalesced 16-B pieces, issued one tile ahead); sample i of the tile lives at staging dword
 // i + 20 * (i / 320): the 20-dword pad per 320 samples moves the three pairs' rows onto disjoint
 // banks, so the strided gather below is conflict free.
-template <int H>
-AAMD_HD int stage_src_piece(int u) {   // staging piece u (16 B) <- tile piece (4 samples)
-  using HC = Hop<H>;
-  const int blk = u / HC::blk_pieces, r = u - HC::blk_pieces * blk;
-  const int s = HC::blk_data * blk + (r < HC::blk_data ? r : HC::blk_data - 1);
-  return s < HC::data_pieces ? s : HC::data_pieces - 1;
+template <int H, typename TIn = float>
+AAMD_HD int stage_src_piece(int u) {   // staging piece u (16 B) <- tile piece (4 or 8 samples)
+  using SG = Stage<H, TIn>;
+  const int blk = u / SG::blk_pieces, r = u - SG::blk_pieces * blk;
+  const int s = SG::blk_data * blk + (r < SG::blk_data ? r : SG::blk_data - 1);
+  return s < SG::data_pieces ? s : SG::data_pieces - 1;
 }
 
-template <int H>
-AAMD_HD void gather_lds(const LaneConst& c, const float* S, float (&X)[Hop<H>::nx]) {
+template <int H, typename TIn = float>
+AAMD_HD void gather_lds(const LaneConst& c, const TIn* S, float (&X)[Hop<H>::nx]) {
   using HC = Hop<H>;
-  const float* src = S + (HC::pair_stride + HC::pad) * c.p + c.pi;
+  using SG = Stage<H, TIn>;
+  const TIn* src = S + (HC::pair_stride + SG::pad_elems) * c.p + c.pi;
 #pragma unroll
-  for (int q = 0; q < HC::nx; ++q) X[q] = src[20 * q + HC::pad * (q / (2 * H))];
+  for (int q = 0; q < HC::nx; ++q) X[q] = (float)src[20 * q + SG::pad_elems * (q / (2 * H))];
 }
 
 // Unstaged tiles (clip edges: reflect padding; or inputs that are not 16-B aligned): direct loads.
-template <int H>
-AAMD_HD void gather_global(const LaneConst& c, const float* wav_row, int64_t length, int64_t t0,
+template <int H, typename TIn = float>
+AAMD_HD void gather_global(const LaneConst& c, const TIn* wav_row, int64_t length, int64_t t0,
                            int n_frames, float (&X)[Hop<H>::nx]) {
   const int64_t ta = t0 + 2 * c.p;
   const int64_t i0 = ta * Hop<H>::hop - kPad + c.pi;
@@ -326,7 +352,7 @@ AAMD_HD void gather_global(const LaneConst& c, const float* wav_row, int64_t len
     const int64_t i = i0 + 20 * q;
     // q < 20 belongs to frame a (and to a + 1 when q >= H); q >= 20 only to frame a + 1
     const bool need = (q < 20) ? (ta < n_frames) : (ta + 1 < n_frames);
-    X[q] = need ? wav_row[reflect_idx(i, length)] : 0.0f;
+    X[q] = need ? (float)wav_row[reflect_idx(i, length)] : 0.0f;
   }
 }
 
@@ -680,7 +706,7 @@ __device__ __forceinline__ void exchange_partner(float (&qr)[10], float (&qi)[10
 
 // LDS-DMA of one 16-B piece per lane: 64 lanes fill 1 KiB at LDS byte address `lds_dst`
 // (wave-uniform).  hipcc does not count this load: the consumer waits with stage_wait().
-__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_dst) {
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
@@ -702,9 +728,9 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
-template <int LAB, int EPI, int H = 8>
+template <int LAB, int EPI, int H = 8, typename TIn = float>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, AAMD_M400_MINWAVES)
-melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ window,
+melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
                   const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
                   int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
                   int tiles_per_row, int64_t n_tiles, int tiles_per_block, int in_aligned,
@@ -754,9 +780,11 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     }
   }
   const unsigned long long self_mask = __ballot((c.col == 0) || (c.col == 10));   // wave-uniform (SGPR pair)
-  int spiece[HC::ndma];   // tile piece fetched by this lane in DMA instruction k
+  using SG = Stage<H, TIn>;
+  static_assert(SG::ok, "no staging layout for this hop / input type");
+  int spiece[SG::ndma];   // first sample of the tile piece fetched by this lane in DMA instruction k
 #pragma unroll
-  for (int k = 0; k < HC::ndma; ++k) spiece[k] = 4 * stage_src_piece<H>(64 * k + lane);
+  for (int k = 0; k < SG::ndma; ++k) spiece[k] = SG::spp * stage_src_piece<H, TIn>(64 * k + lane);
 
   // XCD-aware remap: hardware places block b on XCD b % 8; give each XCD a contiguous
   // range of tiles so the frame-overlap re-reads stay inside one L2.
@@ -789,10 +817,10 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
     return ti;
   };
   auto stage_issue = [&](const TileInfo& ti) {
-    const float* src = wav + ti.row * row_stride + (ti.t0 * kHop - kPad);
+    const TIn* src = wav + ti.row * row_stride + (ti.t0 * kHop - kPad);
     if (LAB & 32) src = wav + 6 * kHop;                 // lab: always the same (cache-resident) tile
 #pragma unroll
-    for (int k = 0; k < HC::ndma; ++k)
+    for (int k = 0; k < SG::ndma; ++k)
       if (!(LAB & 64) || k == 0) glds16(src + spiece[k], s_addr + 1024 * k);   // lab bit 6: one piece only
   };
 
@@ -838,10 +866,10 @@ melspec400_kernel(const float* __restrict__ wav, const float* __restrict__ windo
 #pragma unroll
         for (int q = 0; q < HC::nx; ++q) X[q] = (float)(q + lane) * scale;
       } else {
-        gather_lds<H>(c, lds + kSOff, X);
+        gather_lds<H, TIn>(c, reinterpret_cast<const TIn*>(lds + kSOff), X);
       }
     } else {
-      gather_global<H>(c, wav + cur.row * row_stride, length, cur.t0, n_frames, X);
+      gather_global<H, TIn>(c, wav + cur.row * row_stride, length, cur.t0, n_frames, X);
     }
     phase_a<H, (LAB & 8192) != 0, (LAB & 16384) != 0>(c, X, lds, winr, twr);
     wave_lds_fence();

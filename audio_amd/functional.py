@@ -562,11 +562,21 @@ def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_l
                  bands: Optional[MelBandsOnDevice] = None) -> Tensor:
     """MelSpectrogram (power 2, centre / reflect) with the RNN-T feature post-processing fused
     (pipelines/rnnt_pipeline.py:16-47, 319-326).  Returns (rows, T + right_padding, n_mels), the padding rows zero."""
-    _require_device(waveform, "waveform")
+    pcm16 = waveform.dtype == torch.int16
+    if pcm16 and not (n_fft == 400 and hop_length in (160, 200)):
+        waveform, pcm16 = waveform.to(torch.float32) * (1.0 / 32768.0), False   # shapes the PCM kernel does not serve
+    if pcm16:
+        if not waveform.is_cuda:
+            raise RuntimeError(f"audio_amd: waveform must be on an MI355X (ROCm) device, got {waveform.device}. "
+                               "The HIP kernels have no CPU fallback.")
+    else:
+        _require_device(waveform, "waveform")
     dev = waveform.device
     window = window.to(device=dev, dtype=torch.float32)
     x2 = _rows2d(waveform)
     desc = _stft_desc(x2, 0, window, n_fft, hop_length, 2.0, False, True, "reflect", True)
+    if pcm16:
+        desc.scale = desc.scale / 32768.0          # float = int16 / 32768 (what the decoder's normalisation does)
     if bands is None:
         bands = _mel_bands(fb, dev)
     mean = mean.to(device=dev, dtype=torch.float32).contiguous()
@@ -582,7 +592,8 @@ def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_l
             out[:, T:].zero_()
         if T:
             L = _lib.lib()
-            _lib.check(L.aamd_melspectrogram_lognorm_f32(
+            entry = L.aamd_melspectrogram_pcm16_f32 if pcm16 else L.aamd_melspectrogram_lognorm_f32
+            _lib.check(entry(
                 x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),
                 C.byref(bands.struct), out.data_ptr(), C.byref(desc), float(gain), mean.data_ptr(), invstddev.data_ptr(),
                 frames, _lib.current_stream(dev)))

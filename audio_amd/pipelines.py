@@ -10,6 +10,9 @@ headline kernel (`EPI400_MEL_NORM`, csrc/melspec400.h): the features are born fr
 transpose produces -- normalised, in rows that already contain the right padding.  Batches are first class:
 `forward` takes (..., time) and returns (..., frames + right_padding, n_mels); `__call__` on a 1-D waveform returns
 `(features, length)` exactly like the reference's `_ModuleFeatureExtractor`.
+
+The upstream step is fused as well: an **int16** waveform (the PCM samples the decoder produces; torchaudio's loaders hand
+out `int16 / 32768` as float32) is read directly by the kernel -- no conversion pass, half the input bytes.
 """
 from __future__ import annotations
 
@@ -59,7 +62,7 @@ class RNNTFeatureExtractor(torch.nn.Module):
         self.gain = gain
 
     def features(self, waveform: Tensor) -> Tensor:
-        """(..., time) -> (..., frames + right_padding, n_mels)."""
+        """(..., time) float32 in [-1, 1], or int16 PCM -> (..., frames + right_padding, n_mels)."""
         sp = self.mel.spectrogram
         out = F._mel_lognorm(waveform, sp.window, self.mel.mel_scale.fb, sp.n_fft, sp.hop_length, self.gain, self.mean,
                              self.invstddev, self.right_padding)

@@ -146,6 +146,15 @@ int aamd_melspectrogram_lognorm_f32(const float* wav, const float* window, const
                                     const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
                                     const float* mean, const float* invstddev, int64_t out_frames, void* stream);
 
+/* The same two kernels reading 16-bit PCM directly (what the decoder upstream of the transform produces,
+ * torchaudio/_torchcodec.py -> float = int16 / 32768): the int16 -> float pass and half of the input bytes disappear.
+ * wav: int16[rows][row_stride]; fold the 1 / 32768 into desc->scale.  mean == invstddev == NULL: plain mel spectrogram
+ * (out_frames ignored); otherwise the RNN-T feature epilogue of aamd_melspectrogram_lognorm_f32.
+ * Served for n_fft = 400, hop 160 / 200 (centre, reflect, power 2); other shapes: AAMD_EUNSUPPORTED (convert first). */
+int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const float* twiddle,
+                                  const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
+                                  const float* mean, const float* invstddev, int64_t out_frames, void* stream);
+
 /* Kaldi-compatible front-end (compliance/kaldi.py: spectrogram :229-315, fbank :514-645; the framing and per-frame
  * conditioning of _get_window :154-217): frames of `win` samples every `shift` samples of ONE waveform, DC removal, raw
  * or windowed log-energy, pre-emphasis, window, zero padding to n_fft, power spectrum, then

@@ -354,8 +354,8 @@ int sim_istft(const float* spec, const float* window, const float* tw, const flo
 // epi: 0 mel, 1 mel + dB (db = {multiplier, amin, db_sub}; gmax[rows / rows_per_group] max-reduced),
 //      2 spectrogram |X|^power (bands unused)
 }  // extern "C" (pause: template)
-template <int H>
-static int sim_melspec400_h(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
+template <int H, typename TIn>
+static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
                             float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
                             int epi_mode, const float* db, float* gmax, int64_t rows_per_group, float power,
                             int want_wide) {
@@ -385,7 +385,7 @@ static int sim_melspec400_h(const float* wav, const float* window, const float* 
   for (int l = 0; l < 64; ++l) lane_init(l, ctab, c[l]);
   const int tiles_per_row = (n_frames + kFramesPerWave - 1) / kFramesPerWave;
   // same launch-time switches as launch_mel400() in c_api.hip
-  const bool in_aligned = (row_stride % 4 == 0);
+  const bool in_aligned = (row_stride % (16 / (int)sizeof(TIn)) == 0);
   const bool out_wide = (epi_mode == EPI400_SPEC) || (want_wide && mb.n_mels % 4 == 0);
   static float X[64][HC::nx], vr[64][20], vi[64][20], zr[64][20], zi[64][20], qr[64][10], qi[64][10];
   static float acc_a[64][kMelMaxRounds], acc_b[64][kMelMaxRounds];
@@ -395,9 +395,11 @@ static int sim_melspec400_h(const float* wav, const float* window, const float* 
   };
   // what the 5 LDS-DMA instructions of stage_issue() do: staging piece u <- tile piece stage_src_piece(u)
   auto stage = [&](int64_t row, int64_t t0) {
-    const float* src = wav + row * row_stride + (t0 * kHop - kPad);
-    for (int u = 0; u < 64 * HC::ndma; ++u)
-      for (int e = 0; e < 4; ++e) lds[kSOff + 4 * u + e] = src[4 * stage_src_piece<H>(u) + e];
+    const TIn* src = wav + row * row_stride + (t0 * kHop - kPad);
+    using SG = Stage<H, TIn>;
+    for (int u = 0; u < 64 * SG::ndma; ++u)      // 16-B pieces, byte for byte
+      std::memcpy(reinterpret_cast<char*>(lds + kSOff) + 16 * u,
+                  reinterpret_cast<const char*>(src) + 16 * stage_src_piece<H, TIn>(u), 16);
   };
   // one wave walks all tiles in order, exactly like the kernel's tile loop
   const int64_t n_tiles = rows * tiles_per_row;
@@ -407,10 +409,10 @@ static int sim_melspec400_h(const float* wav, const float* window, const float* 
     const int64_t row = tile / tiles_per_row, t0 = (tile % tiles_per_row) * kFramesPerWave;
     const int64_t nrow = (tile + 1) / tiles_per_row, nt0 = ((tile + 1) % tiles_per_row) * kFramesPerWave;
     const bool nxt_staged = (tile + 1 < n_tiles) && staged(nt0);
-    const float* wr = wav + row * row_stride;
+    const TIn* wr = wav + row * row_stride;
     for (int l = 0; l < 64; ++l) {
-      if (cur_staged) gather_lds<H>(c[l], lds + kSOff, X[l]);
-      else gather_global<H>(c[l], wr, length, t0, n_frames, X[l]);
+      if (cur_staged) gather_lds<H, TIn>(c[l], reinterpret_cast<const TIn*>(lds + kSOff), X[l]);
+      else gather_global<H, TIn>(c[l], wr, length, t0, n_frames, X[l]);
     }
     for (int l = 0; l < 64; ++l) phase_a<H>(c[l], X[l], lds);
     for (int l = 0; l < 64; ++l) phase_b1_load(c[l], lds, vr[l], vi[l]);
@@ -479,12 +481,19 @@ static int sim_melspec400_h(const float* wav, const float* window, const float* 
 }
 
 extern "C" {
-int sim_melspec400(const float* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
+int sim_melspec400(const void* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
                    float* out, int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale,
                    int epi_mode, const float* db, float* gmax, int64_t rows_per_group, float power, int want_wide,
-                   int hop) {
-#define SIM_M400(H) return sim_melspec400_h<H>(wav, window, tw400, bands, out, rows, length, row_stride, n_frames, scale, \
-                                               epi_mode, db, gmax, rows_per_group, power, want_wide)
+                   int hop, int in_i16) {
+#define SIM_M400(H) return sim_melspec400_h<H, float>(static_cast<const float*>(wav), window, tw400, bands, out, rows, length, \
+                                               row_stride, n_frames, scale, epi_mode, db, gmax, rows_per_group, power, want_wide)
+#define SIM_M400_I16(H) return sim_melspec400_h<H, int16_t>(static_cast<const int16_t*>(wav), window, tw400, bands, out, rows, \
+                                               length, row_stride, n_frames, scale, epi_mode, db, gmax, rows_per_group, power, want_wide)
+  if (in_i16) {
+    if (hop == 160) SIM_M400_I16(8);
+    if (hop == 200) SIM_M400_I16(10);
+    return -4;
+  }
   if (hop == 100) SIM_M400(5);
   if (hop == 200) SIM_M400(10);
   if (hop == 160) SIM_M400(8);

@@ -83,8 +83,8 @@ def sim_mel_generic(x, window_padded, bands, desc):
 
 
 def _sim_fft400(x, window, bands, scale, epi, db=None, gmax=None, rows_per_group=1, power=2.0, out_width=None,
-                wide=0, hop=160, out_frames=None):
-    x = np.ascontiguousarray(x, dtype=np.float32)
+                wide=0, hop=160, out_frames=None, i16=False):
+    x = np.ascontiguousarray(x, dtype=np.int16 if i16 else np.float32)
     rows, length = x.shape
     w = np.ascontiguousarray(window, dtype=np.float32)
     tw = np.ascontiguousarray(_host.twiddle_table(400))
@@ -92,17 +92,18 @@ def _sim_fft400(x, window, bands, scale, epi, db=None, gmax=None, rows_per_group
     out = np.zeros((rows, out_frames or T, out_width), dtype=np.float32)
     f = sim().sim_melspec400
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
-                  C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_int]
+                  C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_int]
     dbv = None if db is None else fptr(np.ascontiguousarray(db, dtype=np.float32))
-    rc = f(fptr(x), fptr(w), fptr(tw), None if bands is None else C.cast(C.byref(bands.struct), C.c_void_p),
+    rc = f(x.ctypes.data_as(C.c_void_p), fptr(w), fptr(tw),
+           None if bands is None else C.cast(C.byref(bands.struct), C.c_void_p),
            fptr(out), rows, length, length, T, scale, epi, dbv, None if gmax is None else fptr(gmax),
-           rows_per_group, power, wide, hop)
+           rows_per_group, power, wide, hop, int(i16))
     assert rc == 0
     return np.swapaxes(out, -1, -2)
 
 
-def sim_mel400(x, window, bands, scale=1.0, wide=0, hop=160):
-    return _sim_fft400(x, window, bands, scale, 0, out_width=bands.n_mels, wide=wide, hop=hop)
+def sim_mel400(x, window, bands, scale=1.0, wide=0, hop=160, i16=False):
+    return _sim_fft400(x, window, bands, scale, 0, out_width=bands.n_mels, wide=wide, hop=hop, i16=i16)
 
 
 def sim_mel400_db(x, window, bands, multiplier, amin, db_multiplier, gmax, rows_per_group, scale=1.0):
@@ -111,14 +112,14 @@ def sim_mel400_db(x, window, bands, multiplier, amin, db_multiplier, gmax, rows_
                        rows_per_group=rows_per_group, out_width=bands.n_mels)
 
 
-def sim_mel400_norm(x, window, bands, gain, mean, invstddev, right_padding=0, hop=160):
+def sim_mel400_norm(x, window, bands, gain, mean, invstddev, right_padding=0, hop=160, i16=False, scale=1.0):
     """Fused RNN-T feature epilogue: ((plog(mel * gain)) - mean) * invstddev, rows of T + right_padding frames
     (the padding rows stay zero).  Returns frame-major (rows, T + right_padding, n_mels)."""
-    x = np.ascontiguousarray(x, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.int16 if i16 else np.float32)
     T = _host.frame_count(x.shape[1], 400, hop, True)
     stats = np.ascontiguousarray(np.concatenate([mean, invstddev]), dtype=np.float32)
-    o = _sim_fft400(x, window, bands, 1.0, 3, db=[gain, float(T + right_padding)], gmax=stats, out_width=bands.n_mels,
-                    hop=hop, out_frames=T + right_padding)
+    o = _sim_fft400(x, window, bands, scale, 3, db=[gain, float(T + right_padding)], gmax=stats, out_width=bands.n_mels,
+                    hop=hop, out_frames=T + right_padding, i16=i16)
     return np.swapaxes(o, -1, -2)
 
 

@@ -535,3 +535,24 @@ def test_sim_mel400_rnnt_feature_epilogue():
     assert got.shape == (2, T + 4, 80)
     assert np.all(got[:, T:] == 0)
     assert peak_rel_err(got[:, :T], y.numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize("hop", [160, 200])
+def test_sim_mel400_int16_pcm_input(hop):
+    """int16 PCM read straight by the headline kernel (staging in 8-sample pieces, conversion in the gather): identical
+    to feeding the float kernel the exactly converted samples (scale = 1/32768 folded into the window)."""
+    rng = np.random.default_rng(hop)
+    pcm = rng.integers(-20000, 20000, size=(3, 8000), dtype=np.int16)
+    pcm[1, :37] = 32767
+    pcm[2, -5:] = -32768
+    fb = _host.melscale_fbanks(201, 0.0, 8000.0, 80, 16000, None, "htk")
+    bands = S.HostBands(fb.numpy(), permute=True)
+    w = torch.hann_window(400).numpy()
+    got = S.sim_mel400(pcm, w, bands, scale=1.0 / 32768.0, hop=hop, i16=True)
+    ref = S.sim_mel400(pcm.astype(np.float32), w, bands, scale=1.0 / 32768.0, hop=hop)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)                       # int16 -> float32 is exact: bit-identical features
+    # odd length: every tile takes the unstaged path
+    got2 = S.sim_mel400(pcm[:, :7999], w, bands, scale=1.0 / 32768.0, hop=hop, i16=True)
+    ref2 = S.sim_mel400(pcm[:, :7999].astype(np.float32), w, bands, scale=1.0 / 32768.0, hop=hop)
+    assert np.array_equal(got2, ref2)

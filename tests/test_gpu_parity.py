@@ -978,3 +978,31 @@ def test_rnnt_feature_extractor_vs_reference():
         ref2 = (piecewise_linear_log(mel2 * GAIN) - fe.mean) * fe.invstddev
         assert f2.shape[-2] == ref2.shape[-2] + 4
         assert float((f2[..., :-4, :] - ref2).abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize("hop", [160, 200])
+def test_rnnt_features_from_int16_pcm(hop):
+    """int16 PCM read directly by the headline kernel (rank 4, upstream half): bit-identical to the float path fed the
+    exactly converted samples; ragged / unaligned rows take the unstaged path; other shapes convert first."""
+    from audio_amd.pipelines import RNNTFeatureExtractor
+    g = torch.Generator().manual_seed(hop)
+    stats = {"mean": (10 + 3 * torch.randn(80, generator=g)).tolist(), "invstddev": (0.2 + torch.rand(80, generator=g)).tolist()}
+    fe = RNNTFeatureExtractor(stats, hop_length=hop).cuda()
+    pcm = torch.randint(-20000, 20000, (5, 48000), generator=g, dtype=torch.int16)
+    pcm[1, :50] = 32767
+    pcm[2, -7:] = -32768
+    with torch.no_grad():
+        a = fe(pcm.cuda())
+        b = fe(pcm.cuda().float() * (1.0 / 32768.0))
+        assert a.shape == b.shape and a.dtype == torch.float32
+        # same kernel arithmetic; the only difference is where the 2^-15 factor enters (window vs samples): exact power of two
+        assert torch.equal(a, b)
+        a2 = fe(pcm[:, 1:47990].cuda())                    # misaligned rows: unstaged gather
+        b2 = fe(pcm[:, 1:47990].cuda().float() * (1.0 / 32768.0))
+        assert torch.equal(a2, b2)
+        one, length = fe(pcm[0].cuda())
+        assert torch.equal(one, a[0]) and int(length) == a.shape[1]
+        fe512 = RNNTFeatureExtractor(stats, n_fft=512, hop_length=128).cuda()    # not served by the PCM kernel: converts
+        c = fe512(pcm.cuda())
+        d = fe512(pcm.cuda().float() * (1.0 / 32768.0))
+        assert float((c - d).abs().max()) <= 2e-4

@@ -149,6 +149,11 @@ def main():
                 return torch.nn.functional.pad(y, (0, 0, 0, 4))
             us = timeit(unfused, 10, 100)
             print(f"  same steps unfused (HIP mel kernel + torch element-wise chain):   {us:9.1f} us")
+            pcm = (x * 32767).to(torch.int16)
+            us = timeit(lambda: fe(pcm), 10, 100)
+            print(f"RNN-T features from int16 PCM, one kernel (82 MB in, 82 MB out):     {us:9.1f} us")
+            us = timeit(lambda: fe(pcm.float() * (1.0 / 32768.0)), 10, 100)
+            print(f"  int16 -> float pass + fused kernel:                                {us:9.1f} us")
     if "istft" in what:
         x = (0.5 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
         with torch.no_grad():
