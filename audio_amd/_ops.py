@@ -37,6 +37,11 @@ _DEF.define("resample_apply(Tensor waveform, Tensor kernel, int orig_freq, int n
 _DEF.define("lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, bool clamp, bool batching) -> Tensor")
 _DEF.define("lfilter_cascade(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, bool clamp) -> Tensor")
 _DEF.define("fftconvolve(Tensor x, Tensor y, str mode) -> Tensor")
+_DEF.define("phase_vocoder(Tensor complex_specgrams, float rate, Tensor phase_advance) -> Tensor")
+_DEF.define("griffinlim(Tensor specgram, Tensor window, int n_fft, int hop_length, int win_length, float power, int n_iter, "
+            "float momentum, int? length, bool rand_init) -> Tensor")
+_DEF.define("rnnt_features(Tensor waveform, Tensor window, Tensor fb, int n_fft, int hop_length, float gain, Tensor mean, "
+            "Tensor invstddev, int right_padding) -> Tensor")
 
 _CUDA = torch.library.Library("audio_amd", "IMPL", "CUDA")
 _META = torch.library.Library("audio_amd", "IMPL", "Meta")
@@ -74,6 +79,16 @@ _CUDA.impl("resample_apply", F._apply_sinc_resample_kernel)
 _CUDA.impl("lfilter", F.lfilter)
 _CUDA.impl("lfilter_cascade", F.biquad_cascade)
 _CUDA.impl("fftconvolve", F.fftconvolve)
+_CUDA.impl("phase_vocoder", F.phase_vocoder)
+_CUDA.impl("griffinlim", F.griffinlim)
+
+
+def _rnnt_features(waveform, window, fb, n_fft, hop_length, gain, mean, invstddev, right_padding):
+    out = F._mel_lognorm(waveform, window, fb, n_fft, hop_length, gain, mean, invstddev, right_padding)
+    return out.view(tuple(waveform.shape[:-1]) + out.shape[-2:])
+
+
+_CUDA.impl("rnnt_features", _rnnt_features)
 
 
 # ---- Meta implementations: shapes / strides only ---------------------------------------------
@@ -134,3 +149,33 @@ _META.impl("resample_apply", _resample_meta)
 _META.impl("lfilter", _lfilter_meta)
 _META.impl("lfilter_cascade", lambda waveform, a_coeffs, b_coeffs, clamp: torch.empty_like(waveform))
 _META.impl("fftconvolve", _fftconvolve_meta)
+
+
+def _inverse_spectrogram_meta(spectrogram, length, window, pad, n_fft, hop_length, win_length, norm_mode, center, pad_mode,
+                              onesided):
+    T = spectrogram.shape[-1]
+    n = length if length is not None else n_fft + hop_length * (T - 1) - (2 * (n_fft // 2) if center else 0)
+    return spectrogram.new_empty(tuple(spectrogram.shape[:-2]) + (n,), dtype=torch.float32)
+
+
+def _phase_vocoder_meta(complex_specgrams, rate, phase_advance):
+    if rate == 1.0:
+        return complex_specgrams
+    T = int(math.ceil(complex_specgrams.shape[-1] / rate))
+    return complex_specgrams.new_empty(tuple(complex_specgrams.shape[:-1]) + (T,), dtype=torch.complex64)
+
+
+def _griffinlim_meta(specgram, window, n_fft, hop_length, win_length, power, n_iter, momentum, length, rand_init):
+    n = length if length is not None else hop_length * (specgram.shape[-1] - 1)
+    return specgram.new_empty(tuple(specgram.shape[:-2]) + (n,), dtype=torch.float32)
+
+
+def _rnnt_features_meta(waveform, window, fb, n_fft, hop_length, gain, mean, invstddev, right_padding):
+    T = _stft_frames(waveform.shape[-1], 0, n_fft, hop_length, True)
+    return waveform.new_empty(tuple(waveform.shape[:-1]) + (T + right_padding, fb.shape[1]), dtype=torch.float32)
+
+
+_META.impl("inverse_spectrogram", _inverse_spectrogram_meta)
+_META.impl("phase_vocoder", _phase_vocoder_meta)
+_META.impl("griffinlim", _griffinlim_meta)
+_META.impl("rnnt_features", _rnnt_features_meta)

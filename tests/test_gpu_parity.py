@@ -303,6 +303,25 @@ def test_registered_ops_equal_modules():
     assert torch.equal(torch.ops.audio_amd.lfilter(x, a, b, True, True), F.lfilter(x, a, b))
     y = torch.randn(1, 1, 300, device="cuda")
     assert torch.equal(torch.ops.audio_amd.fftconvolve(x, y, "same"), F.fftconvolve(x, y, "same"))
+    # the widened surface: inverse STFT, phase vocoder, Griffin-Lim, RNN-T features (float and int16 PCM)
+    from audio_amd.pipelines import GAIN, RNNTFeatureExtractor
+    sp = T.Spectrogram(n_fft=400, hop_length=160, power=None).cuda()
+    X = sp(x)
+    inv = T.InverseSpectrogram(n_fft=400, hop_length=160).cuda()
+    got = torch.ops.audio_amd.inverse_spectrogram(X, 8000, inv.window, 0, 400, 160, 400, 0, True, "reflect", True)
+    assert peak_rel_err(got.cpu().numpy(), inv(X, 8000).cpu().numpy()) <= 1e-6      # atomics: order-dependent rounding
+    ts = T.TimeStretch(hop_length=160, n_freq=201, fixed_rate=1.2).cuda()
+    assert torch.equal(torch.ops.audio_amd.phase_vocoder(X, 1.2, ts.phase_advance), ts(X))
+    gl = T.GriffinLim(n_fft=400, hop_length=160, n_iter=3, rand_init=False, length=8000).cuda()
+    got = torch.ops.audio_amd.griffinlim(X.abs().pow(2.0), gl.window, 400, 160, 400, 2.0, 3, 0.99, 8000, False)
+    assert peak_rel_err(got.cpu().numpy(), gl(X.abs().pow(2.0)).cpu().numpy()) <= 1e-4
+    stats = {"mean": torch.randn(80).tolist(), "invstddev": (0.5 + torch.rand(80)).tolist()}
+    fe = RNNTFeatureExtractor(stats).cuda()
+    got = torch.ops.audio_amd.rnnt_features(x, mel.spectrogram.window, mel.mel_scale.fb, 400, 160, GAIN, fe.mean, fe.invstddev, 4)
+    assert torch.equal(got, fe(x))
+    pcm = (x * 20000).to(torch.int16)
+    got = torch.ops.audio_amd.rnnt_features(pcm, mel.spectrogram.window, mel.mel_scale.fb, 400, 160, GAIN, fe.mean, fe.invstddev, 4)
+    assert torch.equal(got, fe(pcm))
 
 
 @pytest.mark.parametrize("case", [((3, 40000), (3, 9000), "full"), ((2, 2, 20000), (1, 1, 700), "same"),

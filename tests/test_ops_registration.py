@@ -6,7 +6,7 @@ import torch
 import audio_amd  # noqa: F401  (registers the ops)
 
 OPS = ["spectrogram", "mel_spectrogram", "mfcc", "amplitude_to_DB", "resample_apply", "lfilter", "lfilter_cascade",
-       "fftconvolve"]
+       "fftconvolve", "inverse_spectrogram", "phase_vocoder", "griffinlim", "rnnt_features"]
 
 
 def test_ops_are_registered():
@@ -33,6 +33,18 @@ def test_meta_shapes_and_strides_match_reference_layout():
     assert r.shape == (4, 16000)
     f = torch.ops.audio_amd.fftconvolve(torch.empty(4, 1, 100, device="meta"), torch.empty(1, 3, 7, device="meta"), "full")
     assert f.shape == (4, 3, 106)
+    i = torch.ops.audio_amd.inverse_spectrogram(c, None, w, 0, 400, 160, 400, 0, True, "reflect", True)
+    assert i.shape == (3, 2, 16000) and i.dtype == torch.float32
+    v = torch.ops.audio_amd.phase_vocoder(c, 1.3, torch.empty(201, 1, device="meta"))
+    assert v.shape == (3, 2, 201, 78) and v.dtype == torch.complex64
+    gl = torch.ops.audio_amd.griffinlim(s, w, 400, 160, 400, 2.0, 4, 0.99, 16000, False)
+    assert gl.shape == (3, 2, 16000)
+    ft = torch.ops.audio_amd.rnnt_features(x, w, fb, 400, 160, 1.0, torch.empty(80, device="meta"),
+                                           torch.empty(80, device="meta"), 4)
+    assert ft.shape == (3, 2, 105, 80)
+    pcm = torch.ops.audio_amd.rnnt_features(torch.empty(5, 16000, device="meta", dtype=torch.int16), w, fb, 400, 160, 1.0,
+                                            torch.empty(80, device="meta"), torch.empty(80, device="meta"), 0)
+    assert pcm.shape == (5, 101, 80) and pcm.dtype == torch.float32
 
 
 def test_cpu_tensor_has_no_kernel():
