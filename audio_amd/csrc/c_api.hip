@@ -397,6 +397,15 @@ int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const
                       : launch_fft400_h<m400::EPI400_MEL, 10, int16_t>(g, mb, wav, window, twiddle, out, m400::Epi400{}, s);
 }
 
+int aamd_spectrogram_grad_f32(const float* spec, const float* dpower, float* out, int64_t n, float power, void* stream) {
+  AAMD_CHECK_ARG(spec && dpower && out, "null buffer");
+  AAMD_CHECK_ARG(n >= 0 && power > 0.0f, "bad sizes / power");
+  if (n == 0) return AAMD_OK;
+  hipLaunchKernelGGL(spec_grad_kernel, dim3(grid_for(n, 256, dev_props().cu_count * 16)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float2*>(spec), dpower, reinterpret_cast<float2*>(out), n, power);
+  return launch_check();
+}
+
 int aamd_kaldi_features_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
                             float* out, const aamd_kaldi_desc* d, void* stream) {
   AAMD_CHECK_ARG(d != nullptr && wav && window && twiddle && out, "null buffer");

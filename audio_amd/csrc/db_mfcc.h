@@ -103,6 +103,22 @@ lognorm_kernel(float* __restrict__ x, int64_t n, int n_mels, float gain, const f
   }
 }
 
+// Backward of |X|^p: G = dP * p * |X|^(p-2) * X per bin (0 where X = 0 and p < 2) -- the spectrum-domain cotangent the
+// STFT adjoint (aamd_istft_f32, adjoint = 1) consumes; X and G interleaved complex, dP real, all frame-major
+__global__ void __launch_bounds__(256)
+spec_grad_kernel(const float2* __restrict__ X, const float* __restrict__ dP, float2* __restrict__ G, int64_t n, float power) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float2 x = X[i];
+    float f = power * dP[i];
+    if (power != 2.0f) {
+      const float m2 = x.x * x.x + x.y * x.y;
+      f = m2 > 0.0f ? f * powf(m2, 0.5f * power - 1.0f) : 0.0f;
+    }
+    G[i] = make_float2(f * x.x, f * x.y);
+  }
+}
+
 // MelScale on a frame-major spectrogram: one thread per (vector, mel).
 __global__ void __launch_bounds__(256)
 mel_scale_kernel(const float* __restrict__ spec, MelBandsDev mb, float* __restrict__ out,

@@ -256,6 +256,53 @@ def _istft_launch(spec_fm: Tensor, window_padded: Tensor, desc, adjoint: bool, i
     return out
 
 
+def _spectrum_cotangent(x2: Tensor, window_padded: Tensor, desc, dpower: Tensor, power: float) -> Tensor:
+    """G = dP * p * |X|^(p-2) * X with X recomputed by the fast complex STFT kernel; (rows, T, 2 * n_freq) float32."""
+    dX = _copy_desc(desc, power=0.0)
+    G = _spectrogram_launch(x2, window_padded, dX, None)               # X: (rows, T, 2 * n_freq) interleaved complex
+    n = G.numel() // 2
+    if n:
+        L = _lib.lib()                                                 # in place: G <- dP p |X|^(p-2) X
+        _lib.check(L.aamd_spectrogram_grad_f32(G.data_ptr(), dpower.contiguous().data_ptr(), G.data_ptr(), n, float(power),
+                                               _lib.current_stream(x2.device)))
+    return G
+
+
+class _MelSpectrogramFunction(torch.autograd.Function):
+    """MelSpectrogram in training mode: forward = the fused mel kernel (same launch as inference); backward =
+    filterbank transpose (aamd_mel_scale_f32 on the band table of fb^T) -> spectrum cotangent (aamd_spectrogram_grad_f32
+    on the recomputed complex STFT) -> STFT adjoint (aamd_istft_f32, adjoint = 1).  All four are HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x2, window, fb, args):
+        pad, n_fft, hop_length, win_length, power, normalized, center, pad_mode = args
+        out = _melspectrogram(x2.detach(), pad, window, fb, n_fft, hop_length, win_length, power, normalized, center, pad_mode)
+        ctx.save_for_backward(x2, window, fb)
+        ctx.args = args
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, window, fb = ctx.saved_tensors
+        pad, n_fft, hop_length, win_length, power, normalized, center, pad_mode = ctx.args
+        dev = x2.device
+        window = window.to(device=dev, dtype=torch.float32)
+        desc = _stft_desc(x2, pad, window, n_fft, hop_length, power, normalized, center, pad_mode, True)
+        wp = _padded_window(window, n_fft)
+        rows, T, n_mels = dy.shape
+        n_freq = n_fft // 2 + 1
+        bands_t = _tensor_cached(fb, ("bands_T", str(dev)), lambda: MelBandsOnDevice(fb.t().contiguous(), dev))
+        dy = dy.contiguous()
+        dP = torch.empty((rows, T, n_freq), dtype=torch.float32, device=dev)
+        if dP.numel():
+            L = _lib.lib()
+            _lib.check(L.aamd_mel_scale_f32(dy.data_ptr(), C.byref(bands_t.struct), dP.data_ptr(), rows, T, n_mels,
+                                            _lib.current_stream(dev)))
+        G = _spectrum_cotangent(x2, wp, desc, dP, power)
+        dx = _istft_launch(G, wp, _copy_desc(desc), True, None)
+        return dx, None, None, None
+
+
 class _SpectrogramFunction(torch.autograd.Function):
     """d/d waveform of the (onesided) spectrogram on the HIP kernels.  Backward recomputes the complex STFT
     X (fast kernel), forms G = dL/dRe Y + i dL/dIm Y for complex output or G = dY p |X|^(p-2) X for
@@ -278,15 +325,7 @@ class _SpectrogramFunction(torch.autograd.Function):
         if power is None:
             G = dy                                             # (rows, T, n_freq * 2): dL/dRe, dL/dIm interleaved
         else:
-            dX = _copy_desc(desc, power=0.0)
-            Xc = torch.view_as_complex(_spectrogram_launch(x2, window_padded, dX, None).view(desc.rows, -1, n_freq, 2))
-            if power == 2.0:
-                Gc = (2.0 * dy) * Xc
-            else:
-                mag = Xc.abs()
-                fac = torch.where(mag > 0, float(power) * mag.pow(power - 2.0), torch.zeros_like(mag))
-                Gc = (dy * fac) * Xc
-            G = torch.view_as_real(Gc.contiguous()).view(desc.rows, -1, 2 * n_freq)
+            G = _spectrum_cotangent(x2, window_padded, desc, dy, power)
         dA = _copy_desc(desc)                                  # same geometry, scale and padding map
         dx = _istft_launch(G.contiguous(), window_padded, dA, True, None)
         return dx, None, None, None

@@ -346,11 +346,15 @@ class MelSpectrogram(torch.nn.Module):
 
     def forward(self, waveform: Tensor) -> Tensor:
         if torch.is_grad_enabled() and waveform.requires_grad:
-            # differentiable path: spectrogram with its HIP adjoint, then the reference's own filterbank
-            # product (transforms/_transforms.py:403-415) so that autograd sees it
-            spec = self.spectrogram(waveform)
-            fb = self.mel_scale.fb.to(spec.device)
-            return torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
+            # training mode: the same fused forward launch; backward = filterbank transpose, spectrum cotangent and
+            # STFT adjoint, all HIP kernels (F._MelSpectrogramFunction)
+            sp = self.spectrogram
+            if sp.power is None:
+                raise ValueError("audio_amd: MelSpectrogram needs a real power (got None)")
+            out = F._MelSpectrogramFunction.apply(
+                F._rows2d(waveform), sp.window, self.mel_scale.fb,
+                (sp.pad, sp.n_fft, sp.hop_length, sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode))
+            return out.view(tuple(waveform.shape[:-1]) + out.shape[-2:]).transpose(-1, -2)
         out = self._frame_major(waveform)                       # (rows, T, n_mels)
         lead = tuple(waveform.shape[:-1])
         return out.view(lead + out.shape[-2:]).transpose(-1, -2)

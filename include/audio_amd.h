@@ -155,6 +155,12 @@ int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const
                                   const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
                                   const float* mean, const float* invstddev, int64_t out_frames, void* stream);
 
+/* Backward of the |X|^p stage of F.spectrogram (functional.py:141-145), element-wise over n bins:
+ *   out = dpower * p * |X|^(p-2) * X   (interleaved complex; 0 where X = 0 and p < 2)
+ * -- the spectrum-domain cotangent aamd_istft_f32(adjoint = 1) turns into d loss / d waveform.  The filterbank's backward
+ * (dpower = dmel * fb^T) is aamd_mel_scale_f32 with the band table of fb^T. */
+int aamd_spectrogram_grad_f32(const float* spec, const float* dpower, float* out, int64_t n, float power, void* stream);
+
 /* Kaldi-compatible front-end (compliance/kaldi.py: spectrogram :229-315, fbank :514-645; the framing and per-frame
  * conditioning of _get_window :154-217): frames of `win` samples every `shift` samples of ONE waveform, DC removal, raw
  * or windowed log-energy, pre-emphasis, window, zero padding to n_fft, power spectrum, then

@@ -178,7 +178,7 @@ def main():
             xg.grad = None
             (mel(xg) * r).sum().backward()
         us = timeit(fwd_bwd, 3, 20)
-        print(f"MelSpectrogram fwd+bwd 256x10s (HIP spectrogram + adjoint, torch tail): {us:9.1f} us")
+        print(f"MelSpectrogram fwd+bwd 256x10s (fused fwd; fb^T, cotangent, STFT adjoint): {us:9.1f} us")
         mt = mel_torch_composition(mel)
 
         def fwd_bwd_t():
