@@ -4,8 +4,8 @@
 (DC removal, log-energy, pre-emphasis, window, zero padding), the FFT, the mel banks and the logs run in ONE HIP kernel
 (`p2::kaldi_pow2_kernel`, csrc/stft_pow2.h, through `aamd_kaldi_features_f32`); `mfcc` adds the DCT on the matrix-core kernel
 of the MFCC path.  Constants (window function, mel banks, DCT matrix, lifter) are built on the host exactly as the reference
-builds them.  Limits, raised loudly: the padded window must be 512, 1024 or 2048 samples (16 / 22.05 / 32 / 44.1 / 48 kHz at the
-usual 25 ms), and `dither` must be 0 (the reference draws fresh noise per call; its own tests run with dither = 0).
+builds them.  Limits, raised loudly: the padded window must be 256, 512, 1024 or 2048 samples (8 / 16 / 22.05 / 32 / 44.1 / 48 kHz at
+the usual 25 ms), and `dither` must be 0 (the reference draws fresh noise per call; its own tests run with dither = 0).
 """
 from __future__ import annotations
 
@@ -72,8 +72,8 @@ def _features(waveform: Tensor, window_shift: int, window_size: int, padded: int
               n_cols: int) -> Tensor:
     if dither != 0.0:
         raise NotImplementedError("audio_amd: kaldi features run with dither = 0 only (fresh noise per call is not reproduced)")
-    if padded not in (512, 1024, 2048):
-        raise NotImplementedError(f"audio_amd: the padded window must be 512, 1024 or 2048 samples, got {padded}")
+    if padded not in (256, 512, 1024, 2048):
+        raise NotImplementedError(f"audio_amd: the padded window must be 256, 512, 1024 or 2048 samples, got {padded}")
     if not waveform.is_cuda:
         raise RuntimeError(f"audio_amd: waveform must be on an MI355X (ROCm) device, got {waveform.device}. "
                            "The HIP kernels have no CPU fallback.")

@@ -123,7 +123,7 @@ int validate_bands(const aamd_mel_bands* b, int n_freq, MelBandsDev& mb) {
   return AAMD_OK;
 }
 
-// n_fft = 512 / 1024 / 2048, onesided: the register-resident wave FFT of stft_pow2.h
+// n_fft = 256 / 512 / 1024 / 2048, onesided: the register-resident wave FFT of stft_pow2.h
 template <int EPI, int E>
 int launch_pow2(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
                 const float* twiddle, float* out, hipStream_t s) {
@@ -139,7 +139,7 @@ int launch_pow2(const StftGeom& g, const MelBandsDev& mb, const float* wav, cons
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // persistent waves striding over the pairs; workgroups per CU measured best on 256 x 10 s (among 2..16):
   // 4 / 2 / 1 workgroups of 4 waves are resident at 126 / 204 / 256 VGPRs, the grid is two resident rounds
-  int64_t blocks = (int64_t)dev_props().cu_count * (E == 8 ? 8 : E == 16 ? 4 : 2);
+  int64_t blocks = (int64_t)dev_props().cu_count * (E <= 8 ? 8 : E == 16 ? 4 : 2);
   const int64_t need = (n_pairs + p2::kWaves - 1) / p2::kWaves;
   if (blocks > need) blocks = need;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * p2::kWaves), lds, s, g, wav, window,
@@ -152,6 +152,7 @@ int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, c
                    const float* twiddle, float* out, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
   if (g.onesided && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+    if (g.n_fft == 256) return launch_pow2<EPI, 4>(g, mb, wav, window, twiddle, out, s);
     if (g.n_fft == 512) return launch_pow2<EPI, 8>(g, mb, wav, window, twiddle, out, s);
     if (g.n_fft == 1024) return launch_pow2<EPI, 16>(g, mb, wav, window, twiddle, out, s);
     if (g.n_fft == 2048) return launch_pow2<EPI, 32>(g, mb, wav, window, twiddle, out, s);
@@ -412,8 +413,8 @@ int aamd_kaldi_features_f32(const float* wav, const float* window, const float* 
   AAMD_CHECK_ARG(d->n_samples >= 0 && d->n_frames >= 0, "negative sizes");
   AAMD_CHECK_ARG(d->shift >= 1 && d->win >= 2 && d->win <= d->n_fft, "need shift >= 1 and 2 <= win <= n_fft");
   AAMD_CHECK_ARG(d->preemphasis >= 0.0f && d->preemphasis <= 1.0f, "preemphasis must be in [0, 1]");
-  if (d->n_fft != 512 && d->n_fft != 1024 && d->n_fft != 2048)
-    return fail(AAMD_EUNSUPPORTED, "audio_amd: the Kaldi front-end needs a padded window of 512, 1024 or 2048 samples");
+  if (d->n_fft != 256 && d->n_fft != 512 && d->n_fft != 1024 && d->n_fft != 2048)
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: the Kaldi front-end needs a padded window of 256, 512, 1024 or 2048 samples");
   if (d->n_frames == 0) return AAMD_OK;
   MelBandsDev mb{};
   if (bands != nullptr) {
@@ -446,9 +447,9 @@ int aamd_kaldi_features_f32(const float* wav, const float* window, const float* 
                        window, twc, mb, out);                                                                      \
   }
   if (bands == nullptr) {
-    if (d->n_fft == 512) AAMD_KALDI(8, 0) else if (d->n_fft == 1024) AAMD_KALDI(16, 0) else AAMD_KALDI(32, 0)
+    if (d->n_fft == 256) AAMD_KALDI(4, 0) else if (d->n_fft == 512) AAMD_KALDI(8, 0) else if (d->n_fft == 1024) AAMD_KALDI(16, 0) else AAMD_KALDI(32, 0)
   } else {
-    if (d->n_fft == 512) AAMD_KALDI(8, 1) else if (d->n_fft == 1024) AAMD_KALDI(16, 1) else AAMD_KALDI(32, 1)
+    if (d->n_fft == 256) AAMD_KALDI(4, 1) else if (d->n_fft == 512) AAMD_KALDI(8, 1) else if (d->n_fft == 1024) AAMD_KALDI(16, 1) else AAMD_KALDI(32, 1)
   }
 #undef AAMD_KALDI
   return launch_check();
@@ -473,13 +474,13 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
   if (g.n_stages < 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft has too many prime factors");
   og.interior = adjoint ? 0.5f : 1.0f;
   og.scale = desc->scale * (adjoint ? 1.0f : 1.0f / (float)desc->n_fft);
-  if ((g.n_fft == 512 || g.n_fft == 1024 || g.n_fft == 2048) && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+  if ((g.n_fft == 256 || g.n_fft == 512 || g.n_fft == 1024 || g.n_fft == 2048) && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
     // register-resident wave FFT run as the inverse (stft_pow2.h)
     p2::InvGeom ig{g, og.interior};
     const int64_t ppr = (g.n_frames + 1) / 2, n_pairs = g.rows * ppr;
     const auto* sp = reinterpret_cast<const p2::C32*>(spec);
     const auto* twc = reinterpret_cast<const p2::C32*>(twiddle);
-    int64_t blocks = (int64_t)dev_props().cu_count * (g.n_fft == 512 ? 8 : g.n_fft == 1024 ? 4 : 2);
+    int64_t blocks = (int64_t)dev_props().cu_count * (g.n_fft <= 512 ? 8 : g.n_fft == 1024 ? 4 : 2);
     const int64_t need = (n_pairs + p2::kWaves - 1) / p2::kWaves;
     if (blocks > need) blocks = need;
     // runs of consecutive pairs per wave (overlap-add in an LDS ring, plain stores); hop > n_fft leaves gaps the ring
@@ -511,7 +512,7 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
                            window, twc, inv_envelope, out, og.scale, ppr, n_pairs);                               \
       }                                                                                                           \
     }
-    if (g.n_fft == 512) AAMD_IP2(8) else if (g.n_fft == 1024) AAMD_IP2(16) else AAMD_IP2(32)
+    if (g.n_fft == 256) AAMD_IP2(4) else if (g.n_fft == 512) AAMD_IP2(8) else if (g.n_fft == 1024) AAMD_IP2(16) else AAMD_IP2(32)
 #undef AAMD_IP2
     return launch_check();
   }

@@ -30,9 +30,11 @@ constexpr int kRow2 = 9;                     // exchange-2 row stride (complex)
 template <int E>
 struct Cfg {
   static constexpr int N = 64 * E;
-  static constexpr int G = E / 8;            // DFT-8 groups per lane in stages B and C
+  static constexpr int G = E >= 8 ? E / 8 : 1;   // DFT-8 groups per lane in stages B and C
+  static constexpr int VR = E >= 8 ? E : 8;      // registers a lane needs in stages B / C (E = 4: 32 lanes x 8)
+  static constexpr int active = 8 * E < 64 ? 8 * E : 64;   // lanes that take part in stages B / C
   static constexpr int lds_complex = E * kRow1;          // = 8 E * kRow2; >= N (exchange 3), >= (N/2+1) floats x 2
-  static_assert(E == 8 || E == 16 || E == 32, "n_fft = 512, 1024 or 2048");
+  static_assert(E == 4 || E == 8 || E == 16 || E == 32, "n_fft = 256, 512, 1024 or 2048");
   static_assert(E * kRow1 == 8 * E * kRow2, "one region serves both exchanges");
 };
 
@@ -79,6 +81,10 @@ struct Dft {
 template <>
 struct Dft<8> {
   static AAMD_HD void run(C32* v) { bfly8<float>(v); }
+};
+template <>
+struct Dft<4> {
+  static AAMD_HD void run(C32* v) { bfly4<float>(v); }
 };
 
 // per-lane constants
@@ -150,6 +156,7 @@ AAMD_HD void xch1_write(int lane, const C32* v, C32* lds) {
 template <int E>
 AAMD_HD void xch1_read(int lane, const C32* lds, C32* v) {
   const int l1 = lane & 7, k1lo = lane >> 3;
+  if (lane >= Cfg<E>::active) return;
 #pragma unroll
   for (int h = 0; h < Cfg<E>::G; ++h)
 #pragma unroll
@@ -169,6 +176,7 @@ AAMD_HD void stage_b(const LaneTab<E>& lt, C32* v) {
 template <int E>
 AAMD_HD void xch2_write(int lane, const C32* v, C32* lds) {
   const int l1 = lane & 7, k1lo = lane >> 3;
+  if (lane >= Cfg<E>::active) return;
 #pragma unroll
   for (int h = 0; h < Cfg<E>::G; ++h)
 #pragma unroll
@@ -176,6 +184,7 @@ AAMD_HD void xch2_write(int lane, const C32* v, C32* lds) {
 }
 template <int E>
 AAMD_HD void xch2_read(int lane, const C32* lds, C32* v) {
+  if (lane >= Cfg<E>::active) return;
 #pragma unroll
   for (int r = 0; r < Cfg<E>::G; ++r)
 #pragma unroll
@@ -192,6 +201,20 @@ AAMD_HD void stage_c(C32* v, C32* z) {
 #pragma unroll
     for (int k2b = 0; k2b < 8; ++k2b) z[r + G * k2b] = v[8 * r + k2b];
   }
+}
+
+// E = 4 (n_fft = 256) only: stage C leaves Z[lane + 32 j], j < 8, on 32 lanes; one more LDS pass spreads it to the
+// layout every epilogue expects, Z[lane + 64 j], j < 4, on 64 lanes
+template <int E>
+AAMD_HD void redist_write(int lane, const C32* z, C32* lds) {
+  if (lane >= Cfg<E>::active) return;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lds[lane + Cfg<E>::active * j] = z[j];
+}
+template <int E>
+AAMD_HD void redist_read(int lane, const C32* lds, C32* z) {
+#pragma unroll
+  for (int j = 0; j < E; ++j) z[j] = lds[lane + 64 * j];
 }
 
 // exchange 3: upper half in natural order, then the partner Z[N - k] of every bin this lane finishes
@@ -609,7 +632,7 @@ stft_pow2_kernel(StftGeom g, const float* __restrict__ wav, const float* __restr
   for (int64_t pair = pair0; pair < n_pairs; pair += n_waves) {
     const int64_t row = pair / pairs_per_row;
     const int64_t ta = 2 * (pair - row * pairs_per_row);
-    C32 v[E], z[E];
+    C32 v[Cfg<E>::VR], z[Cfg<E>::VR];
     if (kPrefetch) {
       apply_window<E>(lt, ra, rb, v);
       const int64_t nxt = pair + n_waves;                       // in flight during this pair's FFT
@@ -631,6 +654,7 @@ stft_pow2_kernel(StftGeom g, const float* __restrict__ wav, const float* __restr
     wave_lds_sync();
     xch2_read<E>(lane, lds, v);
     stage_c<E>(v, z);
+    if (E < 8) { wave_lds_sync(); redist_write<E>(lane, z, lds); wave_lds_sync(); redist_read<E>(lane, lds, z); }
     wave_lds_sync();
     xch3_write<E>(lane, z, lds);
     wave_lds_sync();
@@ -668,7 +692,7 @@ istft_pow2_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __restr
     const int64_t ta = 2 * (pair - row * pairs_per_row);
     const bool vb = ta + 1 < ig.g.n_frames;
     const C32* Sa = spec + (row * ig.g.n_frames + ta) * (int64_t)F;
-    C32 v[E], z[E];
+    C32 v[Cfg<E>::VR], z[Cfg<E>::VR];
     inv_load<E>(lane, ig, Sa, vb ? Sa + F : nullptr, v);
     stage_a<E>(lt, v);
     wave_lds_sync();
@@ -681,6 +705,7 @@ istft_pow2_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __restr
     wave_lds_sync();
     xch2_read<E>(lane, lds, v);
     stage_c<E>(v, z);
+    if (E < 8) { wave_lds_sync(); redist_write<E>(lane, z, lds); wave_lds_sync(); redist_read<E>(lane, lds, z); }
     inv_store<E>(lane, ig, lt, z, ta, vb, inv_env, out + row * ig.g.length, add);
   }
 }
@@ -719,7 +744,7 @@ istft_pow2_run_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __r
       const int64_t ta = 2 * p;
       const bool vb = ta + 1 < g.n_frames;
       const C32* Sa = spec + (row * g.n_frames + ta) * (int64_t)F;
-      C32 v[E], z[E];
+      C32 v[Cfg<E>::VR], z[Cfg<E>::VR];
       inv_load<E>(lane, ig, Sa, vb ? Sa + F : nullptr, v);
       stage_a<E>(lt, v);
       wave_lds_sync();
@@ -732,6 +757,7 @@ istft_pow2_run_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __r
       wave_lds_sync();
       xch2_read<E>(lane, lds, v);
       stage_c<E>(v, z);
+    if (E < 8) { wave_lds_sync(); redist_write<E>(lane, z, lds); wave_lds_sync(); redist_read<E>(lane, lds, z); }
       if (p >= rp.pi_lo && p <= rp.pi_hi) {                   // interior pair: through the ring
         const int64_t sa = ta * (int64_t)g.hop - c;
         if (p == rp.pi_lo) flushed = sa;
@@ -787,7 +813,7 @@ kaldi_pow2_kernel(KaldiGeom kg, const float* __restrict__ wav, const float* __re
       ea = kaldi_log_energy(kg, wave_sum(kaldi_partial_sumsq<E>(lane, kg, ya, 0.0f)));
       eb = kaldi_log_energy(kg, wave_sum(kaldi_partial_sumsq<E>(lane, kg, yb, 0.0f)));
     }
-    C32 v[E], z[E];
+    C32 v[Cfg<E>::VR], z[Cfg<E>::VR];
 #pragma unroll
     for (int e = 0; e < E; ++e) v[e] = C32{0.5f * ya[e], 0.5f * yb[e]};   // separate() returns 2 X
     stage_a<E>(lt, v);
@@ -801,6 +827,7 @@ kaldi_pow2_kernel(KaldiGeom kg, const float* __restrict__ wav, const float* __re
     wave_lds_sync();
     xch2_read<E>(lane, lds, v);
     stage_c<E>(v, z);
+    if (E < 8) { wave_lds_sync(); redist_write<E>(lane, z, lds); wave_lds_sync(); redist_read<E>(lane, lds, z); }
     wave_lds_sync();
     xch3_write<E>(lane, z, lds);
     wave_lds_sync();

@@ -44,7 +44,7 @@ static int sim_pow2_e(const float* wav, const float* window, const float* tw, co
   std::vector<LaneTab<E>> lt(64);
   for (int l = 0; l < 64; ++l) lane_tab<E>(l, window, twc, g.scale, lt[l]);
   std::vector<C32> lds(Cfg<E>::lds_complex);
-  std::vector<std::array<C32, E>> v(64), z(64);
+  std::vector<std::array<C32, p2::Cfg<E>::VR>> v(64), z(64);
   std::vector<std::array<C32, E / 2 + 1>> A(64), B(64);
   const int64_t ppr = (g.n_frames + 1) / 2;
   const int opf = epi_mel ? mb.n_mels : (g.power <= 0.0f ? N + 2 : N / 2 + 1);
@@ -62,6 +62,10 @@ static int sim_pow2_e(const float* wav, const float* window, const float* tw, co
     for (int l = 0; l < 64; ++l) { xch1_read<E>(l, lds.data(), v[l].data()); stage_b<E>(lt[l], v[l].data()); }
     for (int l = 0; l < 64; ++l) xch2_write<E>(l, v[l].data(), lds.data());
     for (int l = 0; l < 64; ++l) { xch2_read<E>(l, lds.data(), v[l].data()); stage_c<E>(v[l].data(), z[l].data()); }
+    if (E < 8) {
+      for (int l = 0; l < 64; ++l) redist_write<E>(l, z[l].data(), lds.data());
+      for (int l = 0; l < 64; ++l) redist_read<E>(l, lds.data(), z[l].data());
+    }
     for (int l = 0; l < 64; ++l) xch3_write<E>(l, z[l].data(), lds.data());
     for (int l = 0; l < 64; ++l) finish_bins<E>(l, z[l].data(), lds.data(), A[l].data(), B[l].data());
     float* out_row = out + row * g.n_frames * (int64_t)opf;
@@ -88,7 +92,7 @@ static int sim_istft_pow2_e(const float* spec, const float* window, const float*
   for (int l = 0; l < 64; ++l) lane_tab<E>(l, window, twc, 2.0f * out_scale, lt[l]);
   std::vector<C32> lds(Cfg<E>::lds_complex);
   std::vector<float> ring(2 * N, 0.0f);
-  std::vector<std::array<C32, E>> v(64), z(64);
+  std::vector<std::array<C32, p2::Cfg<E>::VR>> v(64), z(64);
   const int64_t ppr = (g.n_frames + 1) / 2;
   const int64_t c = (g.center ? N / 2 : 0) + g.pad;
   auto add = [](float* p, float x) { *p += x; };
@@ -99,6 +103,10 @@ static int sim_istft_pow2_e(const float* spec, const float* window, const float*
     for (int l = 0; l < 64; ++l) { xch1_read<E>(l, lds.data(), v[l].data()); stage_b<E>(lt[l], v[l].data()); }
     for (int l = 0; l < 64; ++l) xch2_write<E>(l, v[l].data(), lds.data());
     for (int l = 0; l < 64; ++l) { xch2_read<E>(l, lds.data(), v[l].data()); stage_c<E>(v[l].data(), z[l].data()); }
+    if (E < 8) {
+      for (int l = 0; l < 64; ++l) redist_write<E>(l, z[l].data(), lds.data());
+      for (int l = 0; l < 64; ++l) redist_read<E>(l, lds.data(), z[l].data());
+    }
   };
   if (!runs) {
     for (int64_t pair = 0; pair < g.rows * ppr; ++pair) {
@@ -146,7 +154,7 @@ static int sim_kaldi_e(const float* wav, const float* window, const float* tw, c
   std::vector<LaneTab<E>> lt(64);
   for (int l = 0; l < 64; ++l) lane_tab<E>(l, window, twc, 2.0f, lt[l]);
   std::vector<C32> lds(Cfg<E>::lds_complex);
-  std::vector<std::array<C32, E>> v(64), z(64);
+  std::vector<std::array<C32, p2::Cfg<E>::VR>> v(64), z(64);
   std::vector<std::array<C32, E / 2 + 1>> A(64), B(64);
   std::vector<std::array<float, E>> ra(64), rpa(64), rb(64), rpb(64), ya(64), yb(64);
   auto wave_sum = [](float* s) {           // the kernel's __shfl_xor butterfly, bit for bit
@@ -189,6 +197,10 @@ static int sim_kaldi_e(const float* wav, const float* window, const float* tw, c
     for (int l = 0; l < 64; ++l) { xch1_read<E>(l, lds.data(), v[l].data()); stage_b<E>(lt[l], v[l].data()); }
     for (int l = 0; l < 64; ++l) xch2_write<E>(l, v[l].data(), lds.data());
     for (int l = 0; l < 64; ++l) { xch2_read<E>(l, lds.data(), v[l].data()); stage_c<E>(v[l].data(), z[l].data()); }
+    if (E < 8) {
+      for (int l = 0; l < 64; ++l) redist_write<E>(l, z[l].data(), lds.data());
+      for (int l = 0; l < 64; ++l) redist_read<E>(l, lds.data(), z[l].data());
+    }
     for (int l = 0; l < 64; ++l) xch3_write<E>(l, z[l].data(), lds.data());
     for (int l = 0; l < 64; ++l) finish_bins<E>(l, z[l].data(), lds.data(), A[l].data(), B[l].data());
     if (mode == 0) {
@@ -250,6 +262,7 @@ int sim_stft_pow2(const float* wav, const float* window, const float* tw, const 
   MelBandsDev mb{};
   if (bands) { mb.n_mels = bands->n_mels; mb.max_width = bands->max_width; mb.lo = bands->lo; mb.width = bands->width; mb.weights = bands->weights; }
   if (!g.onesided) return -1;
+  if (g.n_fft == 256) return sim_pow2_e<4>(wav, window, tw, mb, out, g, bands != nullptr);
   if (g.n_fft == 512) return sim_pow2_e<8>(wav, window, tw, mb, out, g, bands != nullptr);
   if (g.n_fft == 1024) return sim_pow2_e<16>(wav, window, tw, mb, out, g, bands != nullptr);
   if (g.n_fft == 2048) return sim_pow2_e<32>(wav, window, tw, mb, out, g, bands != nullptr);
@@ -291,6 +304,7 @@ int sim_kaldi_features(const float* wav, const float* window, const float* tw, c
   MelBandsDev mb{};
   if (bands) { mb.n_mels = bands->n_mels; mb.max_width = bands->max_width; mb.lo = bands->lo; mb.width = bands->width; mb.weights = bands->weights; }
   const int mode = bands ? 1 : 0;
+  if (d->n_fft == 256) return sim_kaldi_e<4>(wav, window, tw, mb, out, kg, mode);
   if (d->n_fft == 512) return sim_kaldi_e<8>(wav, window, tw, mb, out, kg, mode);
   if (d->n_fft == 1024) return sim_kaldi_e<16>(wav, window, tw, mb, out, kg, mode);
   if (d->n_fft == 2048) return sim_kaldi_e<32>(wav, window, tw, mb, out, kg, mode);
@@ -304,6 +318,7 @@ int sim_istft_pow2(const float* spec, const float* window, const float* tw, cons
   g.onesided = 1; g.n_freq = g.n_fft / 2 + 1; g.row_stride = g.length;
   const float interior = adjoint ? 0.5f : 1.0f;
   const float scale = d->scale * (adjoint ? 1.0f : 1.0f / (float)d->n_fft);
+  if (g.n_fft == 256) return sim_istft_pow2_e<4>(spec, window, tw, inv_env, out, g, interior, scale, runs);
   if (g.n_fft == 512) return sim_istft_pow2_e<8>(spec, window, tw, inv_env, out, g, interior, scale, runs);
   if (g.n_fft == 1024) return sim_istft_pow2_e<16>(spec, window, tw, inv_env, out, g, interior, scale, runs);
   if (g.n_fft == 2048) return sim_istft_pow2_e<32>(spec, window, tw, inv_env, out, g, interior, scale, runs);

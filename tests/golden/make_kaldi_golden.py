@@ -27,6 +27,7 @@ cases = {
     "fbank_vtln": ("fbank", dict(num_mel_bins=30, vtln_warp=1.1, low_freq=40.0, high_freq=-200.0, subtract_mean=True)),
     "fbank_22k": ("fbank", dict(sample_frequency=22050.0, num_mel_bins=64, window_type="blackman")),
     "fbank_44k": ("fbank", dict(sample_frequency=44100.0, num_mel_bins=40, window_type="hanning", snip_edges=False)),
+    "fbank_8k": ("fbank", dict(sample_frequency=8000.0, num_mel_bins=23, use_energy=True)),
     "spec_default": ("spectrogram", dict()),
     "spec_rect_nosnip": ("spectrogram", dict(window_type="rectangular", snip_edges=False, raw_energy=False, subtract_mean=True)),
     "mfcc_default": ("mfcc", dict()),

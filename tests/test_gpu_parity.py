@@ -899,7 +899,7 @@ def test_speed_and_speed_perturbation_vs_reference():
         assert (3, 4000) in shapes and len(shapes) >= 2
 
 
-@pytest.mark.parametrize("n_fft,hop", [(512, 128), (512, 160), (1024, 256), (1024, 411), (2048, 512)])
+@pytest.mark.parametrize("n_fft,hop", [(256, 64), (256, 100), (512, 128), (512, 160), (1024, 256), (1024, 411), (2048, 512)])
 def test_pow2_wave_fft_equals_generic_and_torch_stft(n_fft, hop):
     """The register-resident wave FFT (csrc/stft_pow2.h; n_fft = 512 / 1024 / 2048) against the generic Stockham
     kernel and torch.stft in float64 on the CPU: power, magnitude, complex and mel outputs, every padding mode,
