@@ -16,6 +16,7 @@
 #include "istft.h"
 #include "vocoder.h"
 #include "stft_pow2.h"
+#include "istft400.h"
 #include "lfilter.h"
 #include "lfilter_wave.h"
 #include "melspec400.h"
@@ -474,6 +475,29 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
   if (g.n_stages < 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft has too many prime factors");
   og.interior = adjoint ? 0.5f : 1.0f;
   og.scale = desc->scale * (adjoint ? 1.0f : 1.0f / (float)desc->n_fft);
+  if (g.n_fft == 400 && (g.hop == 100 || g.hop == 160 || g.hop == 200) && g.center && g.pad == 0 &&
+      std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+    // radix-20x20 register FFT run backwards (istft400.h)
+    m400::Inv400Geom ig{g, og.interior};
+    const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
+    const int64_t n_tiles = g.rows * tiles_per_row;
+    int64_t blocks = dev_props().cu_count;
+    const int64_t need = (n_tiles + m400::kInvWaves - 1) / m400::kInvWaves;
+    if (blocks > need) blocks = need;
+    const auto* sp = reinterpret_cast<const cplx<float>*>(spec);
+#define AAMD_I400(HH)                                                                                             \
+    {                                                                                                             \
+      const size_t lds4 = ((size_t)m400::kInvWaves * m400::Hop<HH>::lds_dwords + m400::kConstDwords) * sizeof(float); \
+      auto k4 = m400::istft400_kernel<HH>;                                                                        \
+      AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)lds4));                                                                   \
+      hipLaunchKernelGGL(k4, dim3((unsigned)blocks), dim3(64 * m400::kInvWaves), lds4, (hipStream_t)stream, ig, sp, \
+                         window, twiddle, inv_envelope, out, og.scale, tiles_per_row, n_tiles);                   \
+    }
+    if (g.hop == 100) AAMD_I400(5) else if (g.hop == 200) AAMD_I400(10) else AAMD_I400(8)
+#undef AAMD_I400
+    return launch_check();
+  }
   if ((g.n_fft == 256 || g.n_fft == 512 || g.n_fft == 1024 || g.n_fft == 2048) && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
     // register-resident wave FFT run as the inverse (stft_pow2.h)
     p2::InvGeom ig{g, og.interior};

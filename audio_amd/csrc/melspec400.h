@@ -359,26 +359,12 @@ AAMD_HD void gather_global(const LaneConst& c, const TIn* wav_row, int64_t lengt
 //   A frame b beyond the end of the clip is NOT zeroed here (that cost 20 selects per tile): its
 //   spectrum is garbage that no store path writes (store_direct / store_wide / store_spec mask by
 //   frame) and that the dB epilogue excludes from the running maximum.
-template <int H, bool WREG = false, bool TREG = false>
-AAMD_HD void phase_a(const LaneConst& c, const float (&X)[Hop<H>::nx], float* lds, const float* winr = nullptr,
-                     const float* twr = nullptr) {
-  float xr[20], xi[20], yr[20], yi[20];
-  if (WREG) {                           // lab: window taps held in registers instead of the LDS table
-#pragma unroll
-    for (int q = 0; q < 20; ++q) { xr[q] = X[q] * winr[q]; xi[q] = X[q + H] * winr[q]; }
-  } else {
-#pragma unroll
-    for (int q4 = 0; q4 < 5; ++q4) {
-      const F4 w = *reinterpret_cast<const F4*>(c.win + 4 * q4);
-      const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int q = 4 * q4 + e;
-        xr[q] = X[q] * wv[e];
-        xi[q] = X[q + H] * wv[e];
-      }
-    }
-  }
+// DFT-20 over q of the lane's 20 complex inputs, twiddle by W400^(b s), transposed write (shared by the forward
+// kernel and the inverse / adjoint kernel of istft400.h, whose inputs are spectrum bins instead of windowed samples)
+template <bool TREG = false>
+AAMD_HD void phase_a_core(const LaneConst& c, const float (&xr)[20], const float (&xi)[20], float* lds,
+                          const float* twr = nullptr) {
+  float yr[20], yi[20];
   dft20(xr, xi, yr, yi);
   float* colp = lds + kTPair * c.p + 2 * c.pi;
 #pragma unroll
@@ -399,6 +385,29 @@ AAMD_HD void phase_a(const LaneConst& c, const float (&X)[Hop<H>::nx], float* ld
       *reinterpret_cast<F2*>(colp + kTRow * pos_of_col(s + 1)) = F2{v1r, v1i};
     }
   }
+}
+
+template <int H, bool WREG = false, bool TREG = false>
+AAMD_HD void phase_a(const LaneConst& c, const float (&X)[Hop<H>::nx], float* lds, const float* winr = nullptr,
+                     const float* twr = nullptr) {
+  float xr[20], xi[20];
+  if (WREG) {                           // lab: window taps held in registers instead of the LDS table
+#pragma unroll
+    for (int q = 0; q < 20; ++q) { xr[q] = X[q] * winr[q]; xi[q] = X[q + H] * winr[q]; }
+  } else {
+#pragma unroll
+    for (int q4 = 0; q4 < 5; ++q4) {
+      const F4 w = *reinterpret_cast<const F4*>(c.win + 4 * q4);
+      const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = 4 * q4 + e;
+        xr[q] = X[q] * wv[e];
+        xi[q] = X[q + H] * wv[e];
+      }
+    }
+  }
+  phase_a_core<TREG>(c, xr, xi, lds, twr);
 }
 
 // ---- phase B1: read own row (then DFT-20 over b  ->  Z[col + 20 d] in registers) ----------

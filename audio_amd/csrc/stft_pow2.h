@@ -357,17 +357,27 @@ struct InvGeom {
 template <int E>
 AAMD_HD void inv_load(int lane, const InvGeom& ig, const C32* Sa, const C32* Sb /* null: no frame b */, C32* v) {
   constexpr int N = Cfg<E>::N;
+  // all loads first, branch-free (a missing frame b re-reads frame a and is zeroed by `mb`): a branch between two loads
+  // makes the compiler drain the memory counter, i.e. one round trip per load
+  const float mb = Sb ? 1.0f : 0.0f;
+  const C32* Sb2 = Sb ? Sb : Sa;
+  C32 a[E], b[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int k = lane + 64 * e;
-    const int kk = (2 * k <= N) ? k : N - k;                 // onesided bin that defines Z[k]
-    const bool edge = (kk == 0) || (2 * kk == N);
+    const int kk = k < N - k ? k : N - k;                    // onesided bin that defines Z[k]
+    a[e] = Sa[kk];
+    b[e] = Sb2[kk];
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int k = lane + 64 * e;
+    const int kk = k < N - k ? k : N - k;
+    const bool edge = (kk == 0) | (2 * kk == N);
     const float wgt = edge ? 1.0f : ig.interior;
-    const C32 a = Sa[kk];
-    const C32 b = Sb ? Sb[kk] : C32{0.0f, 0.0f};
-    float ar = a.x * wgt, ai = a.y * wgt, br = b.x * wgt, bi = b.y * wgt;
-    if (edge) { ai = 0.0f; bi = 0.0f; }                      // irfft ignores the imaginary part of DC / Nyquist
-    if (2 * k > N) { ai = -ai; bi = -bi; }                   // Hermitian extension
+    const float sgn = edge ? 0.0f : (2 * k > N ? -1.0f : 1.0f);   // Im: ignored at DC / Nyquist, negated in the mirror half
+    const float ar = a[e].x * wgt, ai = a[e].y * (wgt * sgn);
+    const float br = b[e].x * (wgt * mb), bi = b[e].y * (wgt * mb * sgn);
     v[e] = C32{ar - bi, -(ai + br)};                         // conj(A + i B)
   }
 }

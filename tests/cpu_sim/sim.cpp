@@ -16,6 +16,7 @@
 #include "../../audio_amd/csrc/istft.h"
 #include "../../audio_amd/csrc/vocoder.h"
 #include "../../audio_amd/csrc/stft_pow2.h"
+#include "../../audio_amd/csrc/istft400.h"
 #include "../../audio_amd/csrc/lfilter.h"
 #include "../../audio_amd/csrc/lfilter_wave.h"
 #include "../../audio_amd/csrc/melspec400.h"
@@ -214,6 +215,38 @@ static int sim_kaldi_e(const float* wav, const float* window, const float* tw, c
   return 0;
 }
 
+template <int H>
+static int sim_istft400_h(const float* spec, const float* window, const float* tw400, const float* inv_env, float* out,
+                          const StftGeom& g, float interior, float out_scale) {
+  using namespace m400;
+  using HC = Hop<H>;
+  alignas(16) static float lds[HC::lds_dwords];
+  alignas(16) static float ctab[kConstDwords];
+  for (int tid = 0; tid < 256; ++tid) const_tab_build(tid, 256, window, tw400, 2.0f * out_scale, ctab);
+  LaneConst c[64];
+  for (int l = 0; l < 64; ++l) lane_init(l, ctab, c[l]);
+  Inv400Geom ig{g, interior};
+  const cplx<float>* sp = reinterpret_cast<const cplx<float>*>(spec);
+  const int tiles_per_row = (g.n_frames + kFramesPerWave - 1) / kFramesPerWave;
+  static float xr[64][20], xi[64][20], vr[64][20], vi[64][20], zr[64][20], zi[64][20];
+  auto add = [](float* p, float v) { *p += v; };
+  for (int64_t tile = 0; tile < g.rows * tiles_per_row; ++tile) {
+    const int64_t row = tile / tiles_per_row, t0 = (tile - row * tiles_per_row) * kFramesPerWave;
+    const int64_t left = g.n_frames - t0;
+    const int n_valid = left < kFramesPerWave ? (int)left : kFramesPerWave;
+    for (int l = 0; l < 64; ++l) inv400_load(c[l], ig, sp + row * g.n_frames * (int64_t)kSpecBins, t0, xr[l], xi[l]);
+    for (int l = 0; l < 64; ++l) phase_a_core<false>(c[l], xr[l], xi[l], lds);
+    for (int l = 0; l < 64; ++l) phase_b1_load(c[l], lds, vr[l], vi[l]);
+    for (int l = 0; l < 64; ++l) inv400_zero<H>(l, lds);
+    for (int l = 0; l < 64; ++l) dft20(vr[l], vi[l], zr[l], zi[l]);
+    for (int ph = 0; ph < 4; ++ph)
+      for (int l = 0; l < 64; ++l)
+        inv400_add<H>(c[l], ctab + 20 * kTwRow + 20 * c[l].col, zr[l], zi[l], ph & 1, ph >> 1, n_valid, lds);
+    for (int l = 0; l < 64; ++l) inv400_flush<H>(l, ig, t0, n_valid, lds, inv_env, out + row * g.length, add);
+  }
+  return 0;
+}
+
 extern "C" {
 
 int sim_stft_generic(const float* wav, const float* window, const float* tw, const aamd_mel_bands* bands,
@@ -289,6 +322,20 @@ int sim_griffinlim_update(const float* rebuilt, float* tprev, const float* mag, 
   cplx<float>* nx = reinterpret_cast<cplx<float>*>(next);
   for (int64_t i = 0; i < n; ++i) griffinlim_update_elem(r[i], tp[i], mag[i], momentum, nx[i]);
   return 0;
+}
+
+int sim_istft400(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,
+                 const aamd_stft_desc* d, int adjoint) {
+  StftGeom g{};
+  fill_geom(d, g);
+  g.onesided = 1; g.n_freq = 201; g.row_stride = g.length;
+  if (g.n_fft != 400 || !g.center || g.pad != 0) return -2;
+  const float interior = adjoint ? 0.5f : 1.0f;
+  const float scale = d->scale * (adjoint ? 1.0f : 1.0f / 400.0f);
+  if (g.hop == 100) return sim_istft400_h<5>(spec, window, tw, inv_env, out, g, interior, scale);
+  if (g.hop == 160) return sim_istft400_h<8>(spec, window, tw, inv_env, out, g, interior, scale);
+  if (g.hop == 200) return sim_istft400_h<10>(spec, window, tw, inv_env, out, g, interior, scale);
+  return -2;
 }
 
 int sim_kaldi_features(const float* wav, const float* window, const float* tw, const aamd_mel_bands* bands, float* out,

@@ -229,7 +229,7 @@ def sim_fftconv_os(x, y, start, out_len, xmap=None, ymap=None, rows=None):
 
 
 def sim_istft(spec_fm, window_padded, length, n_fft, hop, center=True, pad_mode="constant", pad=0, scale=1.0,
-              adjoint=False, inv_env=None, pow2=False, runs=0):
+              adjoint=False, inv_env=None, pow2=False, runs=0, fast400=False):
     """spec_fm: complex (rows, T, n_freq) frame-major.  Returns (rows, length)."""
     spec_fm = np.ascontiguousarray(spec_fm, dtype=np.complex64)
     rows, T, n_freq = spec_fm.shape
@@ -238,6 +238,12 @@ def sim_istft(spec_fm, window_padded, length, n_fft, hop, center=True, pad_mode=
     out = np.zeros((rows, length), dtype=np.float32)
     desc = _lib.StftDesc(rows, length, length, n_fft, hop, pad, int(center), _lib.PAD_MODES[pad_mode], 1, T, scale, 0.0)
     ie = None if inv_env is None else fptr(np.ascontiguousarray(inv_env, dtype=np.float32))
+    if fast400:
+        f = sim().sim_istft400
+        f.argtypes = [C.c_void_p] * 5 + [C.POINTER(_lib.StftDesc), C.c_int]
+        assert f(spec_fm.view(np.float32).ctypes.data_as(C.c_void_p), fptr(w), fptr(tw), ie, fptr(out), C.byref(desc),
+                 int(adjoint)) == 0
+        return out
     if pow2:
         f = sim().sim_istft_pow2
         f.argtypes = [C.c_void_p] * 5 + [C.POINTER(_lib.StftDesc), C.c_int, C.c_int]

@@ -558,3 +558,36 @@ def test_sim_mel400_int16_pcm_input(hop):
     got2 = S.sim_mel400(pcm[:, :7999], w, bands, scale=1.0 / 32768.0, hop=hop, i16=True)
     ref2 = S.sim_mel400(pcm[:, :7999].astype(np.float32), w, bands, scale=1.0 / 32768.0, hop=hop)
     assert np.array_equal(got2, ref2)
+
+
+@pytest.mark.parametrize("hop,L", [(160, 4000), (160, 2403), (100, 2500), (200, 3100), (160, 500)])
+def test_sim_istft400_roundtrip_and_adjoint(hop, L):
+    """istft400_kernel (the radix-20x20 register FFT run backwards): agrees with the generic ola_kernel replay, inverts
+    the STFT, and is the exact adjoint of the onesided STFT in every padding mode (halo atomics + plain-store middle)."""
+    rng = np.random.default_rng(hop + L)
+    x = rng.standard_normal((2, L))
+    w = O.hann_window(400)
+    X = O.stft(x, w, 400, hop)
+    Xfm = np.swapaxes(X, -1, -2)
+    T = Xfm.shape[1]
+    env = np.zeros(L + 400 + hop * T)
+    for t in range(T):
+        env[t * hop: t * hop + 400] += w ** 2
+    env = env[200: 200 + L]
+    inv = np.where(env > 1e-3, 1.0 / np.maximum(env, 1e-3), 1.0)
+    got = S.sim_istft(Xfm, w, L, 400, hop, inv_env=inv, fast400=True)
+    gen = S.sim_istft(Xfm, w, L, 400, hop, inv_env=inv)
+    assert np.abs(got - gen).max() <= 5e-6 * np.abs(x).max()
+    covered = min(L, hop * (T - 1))
+    if 2 * hop <= 400:
+        assert np.abs(got[:, 1:covered] - x[:, 1:covered]).max() <= 2e-4 * np.abs(x).max()
+    G = rng.standard_normal(Xfm.shape) + 1j * rng.standard_normal(Xfm.shape)
+    for mode in ("reflect", "replicate", "circular", "constant"):
+        dx = S.sim_istft(G, w, L, 400, hop, pad_mode=mode, adjoint=True, fast400=True)
+        dg = S.sim_istft(G, w, L, 400, hop, pad_mode=mode, adjoint=True)
+        assert np.abs(dx - dg).max() <= 1e-5 * np.abs(dg).max(), mode
+        Xm = np.swapaxes(torch.stft(torch.from_numpy(x), 400, hop, 400, torch.from_numpy(w), True, mode, False, True,
+                                    return_complex=True).numpy(), -1, -2)
+        lhs = np.real(np.sum(Xm * np.conj(G)))
+        rhs = np.sum(x * dx)
+        assert abs(lhs - rhs) <= 5e-5 * max(abs(lhs), np.sqrt(np.sum(np.abs(Xm) ** 2) * np.sum(np.abs(G) ** 2)) * 1e-3), mode
