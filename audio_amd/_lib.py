@@ -71,6 +71,7 @@ _SIGS = {
     "aamd_melspectrogram_pcm16_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.c_float,
                                                 _P, _P, C.c_int64, _P]),
     "aamd_spectrogram_grad_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
+    "aamd_melspectrogram_grad_f32": (C.c_int, [_P, _P, C.POINTER(MelBands), C.c_int64, C.c_int32, C.c_int32, C.c_float, _P]),
     "aamd_kaldi_features_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(KaldiDesc), _P]),
     "aamd_istft_f32": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(StftDesc), C.c_int32, _P]),
     "aamd_phase_vocoder_f32": (C.c_int, [_P, _P, _P, C.POINTER(VocoderDesc), _P]),

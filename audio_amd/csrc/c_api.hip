@@ -408,6 +408,21 @@ int aamd_spectrogram_grad_f32(const float* spec, const float* dpower, float* out
   return launch_check();
 }
 
+int aamd_melspectrogram_grad_f32(float* spec_inout, const float* dmel, const aamd_mel_bands* bands_t, int64_t n_vec,
+                                 int32_t n_freq, int32_t n_mels, float power, void* stream) {
+  AAMD_CHECK_ARG(spec_inout && dmel, "null buffer");
+  AAMD_CHECK_ARG(n_vec >= 0 && n_freq >= 1 && n_mels >= 1 && power > 0.0f, "bad sizes / power");
+  MelBandsDev bt;
+  int rc = validate_bands(bands_t, n_mels, bt);          // table of fb^T: one band of mels per bin
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(bt.n_mels == n_freq, "the transposed band table must have one band per bin");
+  const int64_t n = n_vec * n_freq;
+  if (n == 0) return AAMD_OK;
+  hipLaunchKernelGGL(mel_grad_kernel, dim3(grid_for(n, 256, dev_props().cu_count * 16)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<float2*>(spec_inout), dmel, bt, n_vec, n_mels, power);
+  return launch_check();
+}
+
 int aamd_kaldi_features_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
                             float* out, const aamd_kaldi_desc* d, void* stream) {
   AAMD_CHECK_ARG(d != nullptr && wav && window && twiddle && out, "null buffer");

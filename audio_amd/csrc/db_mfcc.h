@@ -119,6 +119,32 @@ spec_grad_kernel(const float2* __restrict__ X, const float* __restrict__ dP, flo
   }
 }
 
+// Backward of MelSpectrogram's two element-wise stages in one pass: dP[k] = sum_m fb[k][m] dY[m] (band table of fb^T)
+// and G = dP p |X|^(p-2) X, written over X (`XG`)
+__global__ void __launch_bounds__(256)
+mel_grad_kernel(float2* __restrict__ XG, const float* __restrict__ dY, MelBandsDev bt /* bands of fb^T: one per bin */,
+                int64_t n_vec, int n_mels, float power) {
+  const int n_freq = bt.n_mels;                          // "mels" of the transposed table are the bins
+  const int64_t total = n_vec * n_freq;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += stride) {
+    const int64_t v = o / n_freq;
+    const int k = (int)(o - v * n_freq);
+    const int lo = bt.lo[k], w = bt.width[k];
+    const float* wt = bt.weights + (int64_t)k * bt.max_width;
+    const float* row = dY + v * n_mels + lo;
+    float dp = 0.0f;
+    for (int i = 0; i < w; ++i) dp += wt[i] * row[i];
+    const float2 x = XG[o];
+    float f = power * dp;
+    if (power != 2.0f) {
+      const float m2 = x.x * x.x + x.y * x.y;
+      f = m2 > 0.0f ? f * powf(m2, 0.5f * power - 1.0f) : 0.0f;
+    }
+    XG[o] = make_float2(f * x.x, f * x.y);
+  }
+}
+
 // MelScale on a frame-major spectrogram: one thread per (vector, mel).
 __global__ void __launch_bounds__(256)
 mel_scale_kernel(const float* __restrict__ spec, MelBandsDev mb, float* __restrict__ out,

@@ -270,8 +270,8 @@ def _spectrum_cotangent(x2: Tensor, window_padded: Tensor, desc, dpower: Tensor,
 
 class _MelSpectrogramFunction(torch.autograd.Function):
     """MelSpectrogram in training mode: forward = the fused mel kernel (same launch as inference); backward =
-    filterbank transpose (aamd_mel_scale_f32 on the band table of fb^T) -> spectrum cotangent (aamd_spectrogram_grad_f32
-    on the recomputed complex STFT) -> STFT adjoint (aamd_istft_f32, adjoint = 1).  All four are HIP kernels."""
+    complex STFT recompute -> filterbank transpose + spectrum cotangent in one pass (aamd_melspectrogram_grad_f32, in
+    place) -> STFT adjoint (aamd_istft_f32, adjoint = 1).  All HIP kernels."""
 
     @staticmethod
     def forward(ctx, x2, window, fb, args):
@@ -293,12 +293,11 @@ class _MelSpectrogramFunction(torch.autograd.Function):
         n_freq = n_fft // 2 + 1
         bands_t = _tensor_cached(fb, ("bands_T", str(dev)), lambda: MelBandsOnDevice(fb.t().contiguous(), dev))
         dy = dy.contiguous()
-        dP = torch.empty((rows, T, n_freq), dtype=torch.float32, device=dev)
-        if dP.numel():
-            L = _lib.lib()
-            _lib.check(L.aamd_mel_scale_f32(dy.data_ptr(), C.byref(bands_t.struct), dP.data_ptr(), rows, T, n_mels,
-                                            _lib.current_stream(dev)))
-        G = _spectrum_cotangent(x2, wp, desc, dP, power)
+        G = _spectrogram_launch(x2, wp, _copy_desc(desc, power=0.0), None)      # X: (rows, T, 2 * n_freq)
+        if G.numel():
+            L = _lib.lib()                                                      # in place: X -> (fb dY) p |X|^(p-2) X
+            _lib.check(L.aamd_melspectrogram_grad_f32(G.data_ptr(), dy.data_ptr(), C.byref(bands_t.struct), rows * T, n_freq,
+                                                      n_mels, float(power), _lib.current_stream(dev)))
         dx = _istft_launch(G, wp, _copy_desc(desc), True, None)
         return dx, None, None, None
 

@@ -161,6 +161,12 @@ int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const
  * (dpower = dmel * fb^T) is aamd_mel_scale_f32 with the band table of fb^T. */
 int aamd_spectrogram_grad_f32(const float* spec, const float* dpower, float* out, int64_t n, float power, void* stream);
 
+/* Both of the above in one pass for MelSpectrogram's backward: spec_inout holds the complex STFT X
+ * (float[n_vec][n_freq][2]) and receives G = (sum_m fb[k][m] dmel[v][m]) * p |X|^(p-2) X.  bands_t: band table of
+ * fb^T (one band of mels per bin).  dmel: float[n_vec][n_mels]. */
+int aamd_melspectrogram_grad_f32(float* spec_inout, const float* dmel, const aamd_mel_bands* bands_t, int64_t n_vec,
+                                 int32_t n_freq, int32_t n_mels, float power, void* stream);
+
 /* Kaldi-compatible front-end (compliance/kaldi.py: spectrogram :229-315, fbank :514-645; the framing and per-frame
  * conditioning of _get_window :154-217): frames of `win` samples every `shift` samples of ONE waveform, DC removal, raw
  * or windowed log-energy, pre-emphasis, window, zero padding to n_fft, power spectrum, then
