@@ -55,10 +55,22 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+        # RCCL prints a version banner to STDOUT when the communicator comes up; the driver reads ONE JSON line from
+        # stdout, so the file descriptor points at stderr until the communicator exists
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
-        except TypeError:                                     # older signature without device_id
-            dist.init_process_group("nccl")
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+            except TypeError:                                 # older signature without device_id
+                dist.init_process_group("nccl")
+            dist.barrier(device_ids=[local_rank])             # forces communicator creation (and the banner) now
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     import audio_amd.transforms as T
     mel = T.MelSpectrogram(sample_rate=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS).to(dev)
