@@ -121,7 +121,13 @@ AAMD_HD void inv400_flush(int lane, const Inv400Geom& ig, int64_t t0, int n_vali
       const int pos = lane + 64 * i;
       if (pos >= I::tile) continue;
       const float r = v[i] * e[i];
-      if (pos >= I::halo && pos < I::step) o[pos] = r;                   // no other tile reaches these samples
+      // plain store only where no other tile's frame reaches (the tile's middle) AND no folded contribution of an edge
+      // tile can land: reflect / circular / replicate padding map the outermost n_fft / 2 (+ 1) samples of the row back
+      // into [0, kPad] and [length - kPad - 1, length) -- with hop 200 and length = 0 (mod 1200) the last interior
+      // tile's middle ends exactly there
+      const int64_t sidx = start + pos;
+      const bool exclusive = pos >= I::halo && pos < I::step && sidx > kPad && sidx < g.length - kPad - 1;
+      if (exclusive) o[pos] = r;
       else add(o + pos, r);
     }
     return;

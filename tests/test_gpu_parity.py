@@ -655,6 +655,9 @@ def _ref_spectrogram(x, window, n_fft, hop, pad, power, normalized, center, pad_
     dict(n_fft=400, hop=160, L=4000, power=2.0),                                    # radix-20x20 fast path
     dict(n_fft=400, hop=160, L=4000, power=1.0),
     dict(n_fft=400, hop=200, L=3001, power=None),
+    dict(n_fft=400, hop=200, L=12000, power=2.0),                 # last interior tile ends exactly at the row end
+    dict(n_fft=400, hop=200, L=12000, power=None, pad_mode="circular"),
+    dict(n_fft=400, hop=100, L=6700, power=1.0, pad_mode="replicate"),
     dict(n_fft=512, hop=128, L=3000, power=2.0, pad_mode="constant"),
     dict(n_fft=256, hop=64, L=2000, power=2.0, center=False, normalized="window"),
     dict(n_fft=200, hop=50, L=1777, power=1.0, pad=37, normalized="frame_length"),
