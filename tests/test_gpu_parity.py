@@ -983,7 +983,7 @@ def test_rnnt_feature_extractor_vs_reference():
             x = torch.tensor(G[f"rnnt{i}/x"]).cuda()
             feats, length = fe(x)
             ref = G[f"rnnt{i}/out"]
-            assert feats.shape == ref.shape and int(length) == int(G[f"rnnt{i}/length"])
+            assert feats.shape == ref.shape and int(length) == int(G[f"rnnt{i}/length"].item())
             assert torch.all(feats[-4:] == 0)
             _assert_rnnt_features_close(feats.cpu().numpy()[:-4], ref[:-4], x.cpu(), fe)
         # batched, vs the same steps unfused on the device
