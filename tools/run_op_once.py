@@ -32,6 +32,11 @@ elif op == "spec512":
 elif op == "mel1024":
     x, t = noise(256, 160000), T.MelSpectrogram(sample_rate=16000, n_fft=1024, hop_length=256, n_mels=128).to(dev)
     fn = lambda: t(x)
+elif op == "istft400":
+    x = noise(256, 160000)
+    X = T.Spectrogram(n_fft=400, hop_length=160, power=None).to(dev)(x)
+    t = T.InverseSpectrogram(n_fft=400, hop_length=160).to(dev)
+    fn = lambda: t(X, 160000)
 elif op == "mfcc":
     x = noise(512, 160000)
     t = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).to(dev)
