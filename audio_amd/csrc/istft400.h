@@ -93,9 +93,9 @@ AAMD_HD void inv400_add(const LaneConst& c, const float* win_row /* window[col +
 
 // write the tile's samples: u = t0 * hop + pos on the padded axis.  Straight-line code for interior tiles: every
 // envelope load and LDS read is in flight before the first store (a rolled loop paid one memory round trip per 64 samples)
-template <int H, typename AddFn>
+template <int H, typename AddFn, typename StoreFn>
 AAMD_HD void inv400_flush(int lane, const Inv400Geom& ig, int64_t t0, int n_valid, const float* buf, const float* inv_env,
-                          float* out_row, AddFn add) {
+                          float* out_row, AddFn add, StoreFn store) {
   using I = Inv400<H>;
   constexpr int kIter = (I::tile + 63) / 64;
   const StftGeom& g = ig.g;
@@ -127,7 +127,7 @@ AAMD_HD void inv400_flush(int lane, const Inv400Geom& ig, int64_t t0, int n_vali
       // tile's middle ends exactly there
       const int64_t sidx = start + pos;
       const bool exclusive = pos >= I::halo && pos < I::step && sidx > kPad && sidx < g.length - kPad - 1;
-      if (exclusive) o[pos] = r;
+      if (exclusive) store(o + pos, r);
       else add(o + pos, r);
     }
     return;
@@ -161,6 +161,7 @@ istft400_kernel(Inv400Geom ig, const cplx<float>* __restrict__ spec, const float
   lane_init(lane, const_tab, c);
   const float* win_row = const_tab + 20 * kTwRow + 20 * c.col;           // window[col + 20 d]
   auto add = [](float* p, float v) { atomicAdd(p, v); };
+  auto store = [](float* p, float v) { *p = v; };
   const int64_t n_waves = (int64_t)gridDim.x * kInvWaves;
 #pragma unroll 1
   for (int64_t tile = (int64_t)blockIdx.x * kInvWaves + wave; tile < n_tiles; tile += n_waves) {
@@ -183,7 +184,7 @@ istft400_kernel(Inv400Geom ig, const cplx<float>* __restrict__ spec, const float
       inv400_add<H>(c, win_row, zr, zi, ph & 1, ph >> 1, n_valid, lds);
       wave_lds_fence();
     }
-    inv400_flush<H>(lane, ig, t0, n_valid, lds, inv_env, out + row * ig.g.length, add);
+    inv400_flush<H>(lane, ig, t0, n_valid, lds, inv_env, out + row * ig.g.length, add, store);
     wave_lds_fence();
   }
 }

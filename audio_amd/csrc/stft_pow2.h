@@ -461,15 +461,15 @@ AAMD_HD void ring_add(int lane, const LaneTab<E>& lt, const C32* z, int64_t sa, 
   for (int j = 0; j < E; ++j) ring[(sa + hop + lane + 64 * j) & M] = cur[j] - z[j].y * lt.win[j];
 }
 // write out (and clear) the finished samples [s0, s1)
-template <int E, typename AddFn>
+template <int E, typename AddFn, typename StoreFn>
 AAMD_HD void ring_flush(int lane, const RunPlan& rp, int64_t s0, int64_t s1, const float* inv_env, float* ring,
-                        float* out_row, AddFn add) {
+                        float* out_row, AddFn add, StoreFn store) {
   constexpr int M = 2 * Cfg<E>::N - 1;
   for (int64_t s = s0 + lane; s < s1; s += 64) {
     float v = ring[s & M];
     ring[s & M] = 0.0f;
     if (inv_env) v *= inv_env[s];
-    if (s >= rp.excl_lo && s < rp.excl_hi) out_row[s] = v;
+    if (s >= rp.excl_lo && s < rp.excl_hi) store(out_row + s, v);
     else add(out_row + s, v);
   }
 }
@@ -739,6 +739,7 @@ istft_pow2_run_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __r
   const int64_t c = (g.center ? N / 2 : 0) + g.pad;
   const int64_t n_waves = (int64_t)gridDim.x * kWaves;
   auto add = [](float* p, float v) { atomicAdd(p, v); };
+  auto store = [](float* p, float v) { *p = v; };
   wave_lds_sync();
 #pragma unroll 1
   for (int64_t run = (int64_t)blockIdx.x * kWaves + wave; run < n_runs; run += n_waves) {
@@ -774,7 +775,7 @@ istft_pow2_run_kernel(InvGeom ig, const C32* __restrict__ spec, const float* __r
         ring_add<E>(lane, lt, z, sa, g.hop, true, ring);
         wave_lds_sync();
         const int64_t s1 = p == rp.pi_hi ? sa + g.hop + N : sa + 2 * (int64_t)g.hop;   // run end: everything left
-        ring_flush<E>(lane, rp, flushed, s1, env, ring, out_row, add);
+        ring_flush<E>(lane, rp, flushed, s1, env, ring, out_row, add, store);
         flushed = s1;
         wave_lds_sync();
       } else {                                                // edge pair: index map per sample, atomics

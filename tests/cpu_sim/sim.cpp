@@ -81,6 +81,12 @@ static int sim_pow2_e(const float* wav, const float* window, const float* tw, co
   return 0;
 }
 
+// Write tracing for the inverse kernels (set by sim_trace_writes): per output sample, how many PLAIN stores and how many
+// atomic adds hit it.  A sequential replay cannot show a store/atomic race by its value; the counts can.
+static int32_t* g_trace_store = nullptr;
+static int32_t* g_trace_add = nullptr;
+static const float* g_trace_base = nullptr;
+
 template <int E>
 static int sim_istft_pow2_e(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,
                             const StftGeom& g, float interior, float out_scale, int runs) {
@@ -96,7 +102,8 @@ static int sim_istft_pow2_e(const float* spec, const float* window, const float*
   std::vector<std::array<C32, p2::Cfg<E>::VR>> v(64), z(64);
   const int64_t ppr = (g.n_frames + 1) / 2;
   const int64_t c = (g.center ? N / 2 : 0) + g.pad;
-  auto add = [](float* p, float x) { *p += x; };
+  auto add = [](float* p, float x) { *p += x; if (g_trace_add) ++g_trace_add[p - g_trace_base]; };
+  auto store = [](float* p, float x) { *p = x; if (g_trace_store) ++g_trace_store[p - g_trace_base]; };
   auto fft_pair = [&](int64_t row, int64_t ta, bool vb) {
     const C32* Sa = sp + (row * g.n_frames + ta) * (int64_t)F;
     for (int l = 0; l < 64; ++l) { inv_load<E>(l, ig, Sa, vb ? Sa + F : nullptr, v[l].data()); stage_a<E>(lt[l], v[l].data()); }
@@ -136,7 +143,7 @@ static int sim_istft_pow2_e(const float* spec, const float* window, const float*
         if (p == rp.pi_lo) flushed = sa;
         for (int l = 0; l < 64; ++l) ring_add<E>(l, lt[l], z[l].data(), sa, g.hop, true, ring.data());
         const int64_t s1 = p == rp.pi_hi ? sa + g.hop + N : sa + 2 * (int64_t)g.hop;
-        for (int l = 0; l < 64; ++l) ring_flush<E>(l, rp, flushed, s1, inv_env, ring.data(), out_row, add);
+        for (int l = 0; l < 64; ++l) ring_flush<E>(l, rp, flushed, s1, inv_env, ring.data(), out_row, add, store);
         flushed = s1;
       } else {
         for (int l = 0; l < 64; ++l) inv_store<E>(l, ig, lt[l], z[l].data(), ta, vb, inv_env, out_row, add);
@@ -229,7 +236,8 @@ static int sim_istft400_h(const float* spec, const float* window, const float* t
   const cplx<float>* sp = reinterpret_cast<const cplx<float>*>(spec);
   const int tiles_per_row = (g.n_frames + kFramesPerWave - 1) / kFramesPerWave;
   static float xr[64][20], xi[64][20], vr[64][20], vi[64][20], zr[64][20], zi[64][20];
-  auto add = [](float* p, float v) { *p += v; };
+  auto add = [](float* p, float v) { *p += v; if (g_trace_add) ++g_trace_add[p - g_trace_base]; };
+  auto store = [](float* p, float v) { *p = v; if (g_trace_store) ++g_trace_store[p - g_trace_base]; };
   for (int64_t tile = 0; tile < g.rows * tiles_per_row; ++tile) {
     const int64_t row = tile / tiles_per_row, t0 = (tile - row * tiles_per_row) * kFramesPerWave;
     const int64_t left = g.n_frames - t0;
@@ -242,7 +250,7 @@ static int sim_istft400_h(const float* spec, const float* window, const float* t
     for (int ph = 0; ph < 4; ++ph)
       for (int l = 0; l < 64; ++l)
         inv400_add<H>(c[l], ctab + 20 * kTwRow + 20 * c[l].col, zr[l], zi[l], ph & 1, ph >> 1, n_valid, lds);
-    for (int l = 0; l < 64; ++l) inv400_flush<H>(l, ig, t0, n_valid, lds, inv_env, out + row * g.length, add);
+    for (int l = 0; l < 64; ++l) inv400_flush<H>(l, ig, t0, n_valid, lds, inv_env, out + row * g.length, add, store);
   }
   return 0;
 }
@@ -322,6 +330,10 @@ int sim_griffinlim_update(const float* rebuilt, float* tprev, const float* mag, 
   cplx<float>* nx = reinterpret_cast<cplx<float>*>(next);
   for (int64_t i = 0; i < n; ++i) griffinlim_update_elem(r[i], tp[i], mag[i], momentum, nx[i]);
   return 0;
+}
+
+void sim_trace_writes(const float* base, int32_t* stores, int32_t* adds) {
+  g_trace_base = base; g_trace_store = stores; g_trace_add = adds;
 }
 
 int sim_istft400(const float* spec, const float* window, const float* tw, const float* inv_env, float* out,

@@ -229,7 +229,8 @@ def sim_fftconv_os(x, y, start, out_len, xmap=None, ymap=None, rows=None):
 
 
 def sim_istft(spec_fm, window_padded, length, n_fft, hop, center=True, pad_mode="constant", pad=0, scale=1.0,
-              adjoint=False, inv_env=None, pow2=False, runs=0, fast400=False):
+              adjoint=False, inv_env=None, pow2=False, runs=0, fast400=False, trace=None):
+    """trace: optional dict; filled with 'stores' / 'adds' int32 arrays (rows, length): plain stores / atomic adds per sample."""
     """spec_fm: complex (rows, T, n_freq) frame-major.  Returns (rows, length)."""
     spec_fm = np.ascontiguousarray(spec_fm, dtype=np.complex64)
     rows, T, n_freq = spec_fm.shape
@@ -238,6 +239,21 @@ def sim_istft(spec_fm, window_padded, length, n_fft, hop, center=True, pad_mode=
     out = np.zeros((rows, length), dtype=np.float32)
     desc = _lib.StftDesc(rows, length, length, n_fft, hop, pad, int(center), _lib.PAD_MODES[pad_mode], 1, T, scale, 0.0)
     ie = None if inv_env is None else fptr(np.ascontiguousarray(inv_env, dtype=np.float32))
+    if trace is not None:
+        trace["stores"] = np.zeros((rows, length), dtype=np.int32)
+        trace["adds"] = np.zeros((rows, length), dtype=np.int32)
+        tf = sim().sim_trace_writes
+        tf.argtypes = [C.c_void_p] * 3
+        tf.restype = None
+        tf(fptr(out), trace["stores"].ctypes.data_as(C.c_void_p), trace["adds"].ctypes.data_as(C.c_void_p))
+    try:
+        return _sim_istft_dispatch(spec_fm, w, tw, ie, out, desc, adjoint, pow2, runs, fast400)
+    finally:
+        if trace is not None:
+            sim().sim_trace_writes(None, None, None)
+
+
+def _sim_istft_dispatch(spec_fm, w, tw, ie, out, desc, adjoint, pow2, runs, fast400):
     if fast400:
         f = sim().sim_istft400
         f.argtypes = [C.c_void_p] * 5 + [C.POINTER(_lib.StftDesc), C.c_int]

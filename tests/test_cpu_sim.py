@@ -591,3 +591,40 @@ def test_sim_istft400_roundtrip_and_adjoint(hop, L):
         lhs = np.real(np.sum(Xm * np.conj(G)))
         rhs = np.sum(x * dx)
         assert abs(lhs - rhs) <= 5e-5 * max(abs(lhs), np.sqrt(np.sum(np.abs(Xm) ** 2) * np.sum(np.abs(G) ** 2)) * 1e-3), mode
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_inverse_kernels_plain_stores_are_exclusive(seed):
+    """Race freedom of the inverse kernels' write scheme, which a sequential replay cannot see in the values: every
+    output sample gets at most ONE plain store, and a sample that gets a plain store gets no atomic add at all
+    (atomics and a store to one address from different waves would race on the GPU).  Random geometries, every padding
+    mode, inverse and adjoint, run lengths 1 .. 16."""
+    rng = np.random.default_rng(9000 + seed)
+    fast400 = seed % 2 == 0
+    if fast400:
+        n_fft, hop = 400, int(rng.choice([100, 160, 200]))
+        L = int(rng.choice([int(rng.integers(500, 9000)), 1200 * int(rng.integers(1, 8)), 960 * int(rng.integers(1, 8)) + 1000,
+                            600 * int(rng.integers(1, 9)) + 700]))
+    else:
+        n_fft = int(rng.choice([256, 512, 1024]))
+        hop = int(rng.choice([n_fft // 4, n_fft // 2, n_fft // 3, n_fft, int(rng.integers(1, n_fft + 1))]))
+        L = int(rng.integers(n_fft + 10, 12 * n_fft))
+    mode = str(rng.choice(["reflect", "replicate", "circular", "constant"]))
+    adjoint = bool(rng.random() < 0.6)
+    T = 1 + L // hop
+    spec = (rng.standard_normal((2, T, n_fft // 2 + 1)) + 1j * rng.standard_normal((2, T, n_fft // 2 + 1))).astype(np.complex64)
+    w = O.hann_window(n_fft)
+    tr = {}
+    kw = dict(pad_mode=mode if adjoint else "constant", adjoint=adjoint, trace=tr)
+    if fast400:
+        got = S.sim_istft(spec, w, L, n_fft, hop, fast400=True, **kw)
+    else:
+        run_len = int(rng.choice([1, 2, 5, 16]))
+        got = S.sim_istft(spec, w, L, n_fft, hop, pow2=True, runs=run_len, **kw)
+    st, ad = tr["stores"], tr["adds"]
+    assert st.max() <= 1, (n_fft, hop, L, mode, adjoint)
+    assert not np.any((st == 1) & (ad > 0)), (n_fft, hop, L, mode, adjoint, np.argwhere((st == 1) & (ad > 0))[:5])
+    ref = S.sim_istft(spec, w, L, n_fft, hop, pad_mode=mode if adjoint else "constant", adjoint=adjoint)   # generic kernel
+    assert np.abs(got - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-6)
+    if st.sum() == 0 and L > 8 * n_fft and hop <= n_fft // 2 and (fast400 or run_len == 16):
+        pytest.fail("no plain stores at all: the fast write path is not exercised")
