@@ -78,6 +78,8 @@ _SIGS = {
     "aamd_griffinlim_update_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, _P]),
     "aamd_mel_scale_f32": (C.c_int, [_P, C.POINTER(MelBands), _P, C.c_int64, C.c_int32, C.c_int32, _P]),
     "aamd_amplitude_to_db_f32": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P]),
+    "aamd_amplitude_to_db_clamped_f32": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P, C.c_int64,
+                                                   C.c_float, _P]),
     "aamd_db_clamp_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_float, _P]),
     "aamd_mfcc_dct_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64,
                                     C.c_float, _P]),

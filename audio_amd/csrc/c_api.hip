@@ -608,21 +608,61 @@ int aamd_mel_scale_f32(const float* spec, const aamd_mel_bands* bands, float* ou
   if (rc != AAMD_OK) return rc;
   const int64_t n_vec = rows * n_frames;
   if (n_vec == 0) return AAMD_OK;
+  const size_t lds = ms_lds_floats(mb.n_mels, mb.max_width, n_freq) * sizeof(float);
+  if (lds <= 96 * 1024) {                                  // band table + 16 spectrum rows in LDS, persistent workgroups
+    if (lds > 48 * 1024)
+      AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mel_scale_lds_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int blocks = grid_for(n_vec, kMsVec, dev_props().cu_count * 8);
+    hipLaunchKernelGGL(mel_scale_lds_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, spec, mb, out, n_vec, n_freq);
+    return launch_check();
+  }
   const int blocks = grid_for(n_vec * mb.n_mels, 256, dev_props().cu_count * 16);
   hipLaunchKernelGGL(mel_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, spec, mb, out,
                      n_vec, n_freq);
   return launch_check();
 }
 
+// launch geometry of db_group_kernel: one workgroup per kDbChunk elements of one group
+static int db_grid(int64_t n, int64_t group_size, int64_t* chunks_per_group, int64_t* blocks) {
+  const int64_t n_groups = (n + group_size - 1) / group_size;
+  *chunks_per_group = (group_size + kDbChunk - 1) / kDbChunk;
+  *blocks = n_groups * *chunks_per_group;
+  return *blocks < (1ll << 31) ? AAMD_OK : AAMD_EINVAL;
+}
+
 int aamd_amplitude_to_db_f32(const float* x, float* out, int64_t n, float multiplier, float amin,
                              float db_multiplier, float* group_max, int64_t group_size, void* stream) {
-  AAMD_CHECK_ARG(x && out, "null buffer");
+  AAMD_CHECK_ARG(x && (out || group_max), "null buffer");
   AAMD_CHECK_ARG(n >= 0, "negative size");
   AAMD_CHECK_ARG(group_max == nullptr || group_size >= 1, "group_size must be >= 1");
   if (n == 0) return AAMD_OK;
-  const int blocks = grid_for(n, 256, dev_props().cu_count * 16);
-  hipLaunchKernelGGL(amplitude_to_db_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, out, n,
-                     multiplier, amin, db_multiplier, group_max, group_size < 1 ? 1 : group_size);
+  const int64_t gs = group_max ? group_size : n;
+  int64_t cpg, blocks;
+  AAMD_CHECK_ARG(db_grid(n, gs, &cpg, &blocks) == AAMD_OK, "too many chunks for one launch");
+  hipStream_t s = (hipStream_t)stream;
+  if (group_max == nullptr)
+    hipLaunchKernelGGL((db_group_kernel<true, false, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, out, n, multiplier,
+                       amin, db_multiplier, group_max, gs, cpg, 0.0f);
+  else if (out != nullptr)
+    hipLaunchKernelGGL((db_group_kernel<true, true, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, out, n, multiplier,
+                       amin, db_multiplier, group_max, gs, cpg, 0.0f);
+  else                                                     // maximum only: first pass of a top_db conversion
+    hipLaunchKernelGGL((db_group_kernel<false, true, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, out, n, multiplier,
+                       amin, db_multiplier, group_max, gs, cpg, 0.0f);
+  return launch_check();
+}
+
+int aamd_amplitude_to_db_clamped_f32(const float* x, float* out, int64_t n, float multiplier, float amin,
+                                     float db_multiplier, const float* group_max, int64_t group_size, float top_db,
+                                     void* stream) {
+  AAMD_CHECK_ARG(x && out && group_max, "null buffer");
+  AAMD_CHECK_ARG(n >= 0 && group_size >= 1, "bad sizes");
+  if (n == 0) return AAMD_OK;
+  int64_t cpg, blocks;
+  AAMD_CHECK_ARG(db_grid(n, group_size, &cpg, &blocks) == AAMD_OK, "too many chunks for one launch");
+  hipLaunchKernelGGL((db_group_kernel<true, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, out, n,
+                     multiplier, amin, db_multiplier, const_cast<float*>(group_max), group_size, cpg, top_db);
   return launch_check();
 }
 

@@ -89,6 +89,111 @@ db_clamp_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
     out[i] = fmaxf(x[i], group_max[i / group_size] - top_db);
 }
 
+// amplitude_to_DB, second version: one workgroup = one chunk of ONE cut-off group, so there is no per-element 64-bit
+// division, the body moves 16 bytes per lane, and the group maximum costs one atomic per workgroup.
+//   STORE  write the dB values;  REDUCE  max-reduce them into group_max[g];  CLAMP  y = max(y, group_max[g] - top_db)
+// (REDUCE without STORE = the first pass of a top_db conversion: it reads x once and writes nothing; the second pass
+// recomputes the logarithm, clamps and stores -- 3 instead of 4 sweeps over the tensor.)
+constexpr int kDbChunk = 8192;
+template <bool STORE, bool REDUCE, bool CLAMP>
+__global__ void __launch_bounds__(256)
+db_group_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float multiplier, float amin,
+                float db_multiplier, float* __restrict__ group_max, int64_t group_size, int64_t chunks_per_group,
+                float top_db) {
+  __shared__ float wmax[4];
+  const int64_t g = blockIdx.x / chunks_per_group;
+  const int64_t c = blockIdx.x - g * chunks_per_group;
+  const int64_t gend = (g + 1) * group_size < n ? (g + 1) * group_size : n;
+  const int64_t lo = g * group_size + c * kDbChunk;
+  const int64_t hi = lo + kDbChunk < gend ? lo + kDbChunk : gend;
+  const float cut = CLAMP ? group_max[g] - top_db : -INFINITY;
+  float run = -INFINITY;
+  auto one = [&](int64_t i) {
+    float v = to_db(x[i], multiplier, amin, db_multiplier);
+    if (REDUCE) run = fmaxf(run, v);
+    if (CLAMP) v = fmaxf(v, cut);
+    if (STORE) out[i] = v;
+  };
+  // scalar head up to the next 16-byte boundary of x (out shares the index, hence the alignment, when both bases are
+  // 16-byte aligned; otherwise everything goes through the scalar loop), 16-byte body, scalar tail.
+  // NB: plain loop bounds and vectorize(disable): with select-valued bounds hipcc's loop passes did not terminate.
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (!STORE || reinterpret_cast<uintptr_t>(out) % 16 == 0);
+  int64_t head_end = hi, body_end = hi;
+  if (vec_ok) {
+    head_end = (lo + 3) & ~(int64_t)3;
+    if (head_end > hi) head_end = hi;
+    body_end = head_end + ((hi - head_end) & ~(int64_t)3);
+  }
+#pragma clang loop vectorize(disable) unroll(disable)
+  for (int64_t i = lo + threadIdx.x; i < head_end; i += 256) one(i);
+  const int64_t n_vec4 = (body_end - head_end) >> 2;
+  const float4* xv4 = reinterpret_cast<const float4*>(x + head_end);
+  float4* ov4 = reinterpret_cast<float4*>(out + head_end);
+#pragma clang loop vectorize(disable) unroll(disable)
+  for (int64_t j = threadIdx.x; j < n_vec4; j += 256) {
+    const float4 xv = xv4[j];
+    float4 y;
+    y.x = to_db(xv.x, multiplier, amin, db_multiplier);
+    y.y = to_db(xv.y, multiplier, amin, db_multiplier);
+    y.z = to_db(xv.z, multiplier, amin, db_multiplier);
+    y.w = to_db(xv.w, multiplier, amin, db_multiplier);
+    if (REDUCE) run = fmaxf(run, fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)));
+    if (CLAMP) { y.x = fmaxf(y.x, cut); y.y = fmaxf(y.y, cut); y.z = fmaxf(y.z, cut); y.w = fmaxf(y.w, cut); }
+    if (STORE) ov4[j] = y;
+  }
+#pragma clang loop vectorize(disable) unroll(disable)
+  for (int64_t i = body_end + threadIdx.x; i < hi; i += 256) one(i);
+  if (REDUCE) {
+    const float m = wave_max(run);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_max_float(group_max + g, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])));
+  }
+}
+
+// MelScale, second version: the band table and kMsVec spectrum rows live in LDS; workgroups are persistent
+constexpr int kMsVec = 16;
+AAMD_HD int ms_stride(int max_width) { return max_width | 1; }
+AAMD_HD size_t ms_lds_floats(int n_mels, int max_width, int n_freq) {
+  return (size_t)n_mels * ms_stride(max_width) + 2 * (size_t)n_mels + (size_t)kMsVec * (n_freq | 1);
+}
+__global__ void __launch_bounds__(256)
+mel_scale_lds_kernel(const float* __restrict__ spec, MelBandsDev mb, float* __restrict__ out, int64_t n_vec, int n_freq) {
+  extern __shared__ __attribute__((aligned(16))) float smem_ms[];
+  const int ms = ms_stride(mb.max_width), fs = n_freq | 1;
+  float* wt = smem_ms;
+  int* lo = reinterpret_cast<int*>(wt + mb.n_mels * ms);
+  int* wd = lo + mb.n_mels;
+  float* S = reinterpret_cast<float*>(wd + mb.n_mels);
+  for (int i = threadIdx.x; i < mb.n_mels * ms; i += 256) {
+    const int m = i / ms, j = i - m * ms;
+    wt[i] = j < mb.max_width ? mb.weights[(int64_t)m * mb.max_width + j] : 0.0f;
+  }
+  for (int m = threadIdx.x; m < mb.n_mels; m += 256) { lo[m] = mb.lo[m]; wd[m] = mb.width[m]; }
+  const int64_t n_grp = (n_vec + kMsVec - 1) / kMsVec;
+  for (int64_t grp = blockIdx.x; grp < n_grp; grp += gridDim.x) {
+    const int64_t v0 = grp * kMsVec;
+    const int nv = n_vec - v0 < kMsVec ? (int)(n_vec - v0) : kMsVec;
+    __syncthreads();                                     // table ready / previous rows consumed
+    const float* src = spec + v0 * n_freq;
+    for (int i = threadIdx.x; i < nv * n_freq; i += 256) {
+      const int v = i / n_freq, k = i - v * n_freq;
+      S[v * fs + k] = src[i];
+    }
+    __syncthreads();
+    float* dst = out + v0 * mb.n_mels;
+    for (int o = threadIdx.x; o < nv * mb.n_mels; o += 256) {
+      const int v = o / mb.n_mels, m = o - v * mb.n_mels;
+      const float* w = wt + m * ms;
+      const float* P = S + v * fs + lo[m];
+      const int n = wd[m];
+      float acc = 0.0f;
+      for (int i = 0; i < n; ++i) acc += w[i] * P[i];
+      dst[o] = acc;
+    }
+  }
+}
+
 // RNN-T feature post-processing on a frame-major mel buffer (the unfused form of EPI400_MEL_NORM)
 __global__ void __launch_bounds__(256)
 lognorm_kernel(float* __restrict__ x, int64_t n, int n_mels, float gain, const float* __restrict__ mean,

@@ -740,9 +740,11 @@ def amplitude_to_DB(x: Tensor, multiplier: float, amin: float, db_multiplier: fl
     group = packed * shape[-2] * shape[-1]
     n_groups = n // group
     gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=x.device)
-    _lib.check(L.aamd_amplitude_to_db_f32(xc.data_ptr(), out.data_ptr(), n, multiplier, amin, db_multiplier,
-                                          gmax.data_ptr(), group, stream))
-    _lib.check(L.aamd_db_clamp_f32(out.data_ptr(), out.data_ptr(), n, gmax.data_ptr(), group, float(top_db), stream))
+    # pass 1: group maxima only (reads x, writes nothing); pass 2: dB + clamp + store
+    _lib.check(L.aamd_amplitude_to_db_f32(xc.data_ptr(), None, n, multiplier, amin, db_multiplier, gmax.data_ptr(), group,
+                                          stream))
+    _lib.check(L.aamd_amplitude_to_db_clamped_f32(xc.data_ptr(), out.data_ptr(), n, multiplier, amin, db_multiplier,
+                                                  gmax.data_ptr(), group, float(top_db), stream))
     return out.view(shape)
 
 

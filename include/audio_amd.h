@@ -235,6 +235,12 @@ int aamd_mel_scale_f32(const float* spec, const aamd_mel_bands* bands, float* ou
 int aamd_amplitude_to_db_f32(const float* x, float* out, int64_t n, float multiplier, float amin,
                              float db_multiplier, float* group_max, int64_t group_size, void* stream);
 
+/* dB conversion and top_db clamp in one sweep, given the group maxima of a previous aamd_amplitude_to_db_f32(x, NULL, ...)
+ * call (out == NULL there = maximum only): out[i] = max(dB(x[i]), group_max[i / group_size] - top_db). */
+int aamd_amplitude_to_db_clamped_f32(const float* x, float* out, int64_t n, float multiplier, float amin,
+                                     float db_multiplier, const float* group_max, int64_t group_size, float top_db,
+                                     void* stream);
+
 /* out[i] = max(x[i], group_max[i / group_size] - top_db)  (functional.py:393-402). */
 int aamd_db_clamp_f32(const float* x, float* out, int64_t n, const float* group_max,
                       int64_t group_size, float top_db, void* stream);
