@@ -356,9 +356,6 @@ AAMD_HD void gather_global(const LaneConst& c, const TIn* wav_row, int64_t lengt
   }
 }
 
-//   A frame b beyond the end of the clip is NOT zeroed here (that cost 20 selects per tile): its
-//   spectrum is garbage that no store path writes (store_direct / store_wide / store_spec mask by
-//   frame) and that the dB epilogue excludes from the running maximum.
 // DFT-20 over q of the lane's 20 complex inputs, twiddle by W400^(b s), transposed write (shared by the forward
 // kernel and the inverse / adjoint kernel of istft400.h, whose inputs are spectrum bins instead of windowed samples)
 template <bool TREG = false>
@@ -387,6 +384,9 @@ AAMD_HD void phase_a_core(const LaneConst& c, const float (&xr)[20], const float
   }
 }
 
+//   A frame b beyond the end of the clip is NOT zeroed here (that cost 20 selects per tile): its
+//   spectrum is garbage that no store path writes (store_direct / store_wide / store_spec mask by
+//   frame) and that the dB epilogue excludes from the running maximum.
 template <int H, bool WREG = false, bool TREG = false>
 AAMD_HD void phase_a(const LaneConst& c, const float (&X)[Hop<H>::nx], float* lds, const float* winr = nullptr,
                      const float* twr = nullptr) {
