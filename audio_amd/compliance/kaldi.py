@@ -105,22 +105,11 @@ def _subtract_column_mean(tensor: Tensor, subtract_mean: bool) -> Tensor:
 
 
 def spectrogram(
-    waveform: Tensor,
-    blackman_coeff: float = 0.42,
-    channel: int = -1,
-    dither: float = 0.0,
-    energy_floor: float = 1.0,
-    frame_length: float = 25.0,
-    frame_shift: float = 10.0,
-    min_duration: float = 0.0,
-    preemphasis_coefficient: float = 0.97,
-    raw_energy: bool = True,
-    remove_dc_offset: bool = True,
-    round_to_power_of_two: bool = True,
-    sample_frequency: float = 16000.0,
-    snip_edges: bool = True,
-    subtract_mean: bool = False,
-    window_type: str = POVEY,
+    waveform: Tensor, blackman_coeff: float = 0.42, channel: int = -1, dither: float = 0.0,
+    energy_floor: float = 1.0, frame_length: float = 25.0, frame_shift: float = 10.0, min_duration: float = 0.0,
+    preemphasis_coefficient: float = 0.97, raw_energy: bool = True, remove_dc_offset: bool = True,
+    round_to_power_of_two: bool = True, sample_frequency: float = 16000.0, snip_edges: bool = True,
+    subtract_mean: bool = False, window_type: str = POVEY,
 ) -> Tensor:
     r"""Kaldi's compute-spectrogram-feats (reference: compliance/kaldi.py:229-315): (m, padded_window_size // 2 + 1)."""
     waveform, window_shift, window_size, padded = _properties(
@@ -133,32 +122,13 @@ def spectrogram(
 
 
 def fbank(
-    waveform: Tensor,
-    blackman_coeff: float = 0.42,
-    channel: int = -1,
-    dither: float = 0.0,
-    energy_floor: float = 1.0,
-    frame_length: float = 25.0,
-    frame_shift: float = 10.0,
-    high_freq: float = 0.0,
-    htk_compat: bool = False,
-    low_freq: float = 20.0,
-    min_duration: float = 0.0,
-    num_mel_bins: int = 23,
-    preemphasis_coefficient: float = 0.97,
-    raw_energy: bool = True,
-    remove_dc_offset: bool = True,
-    round_to_power_of_two: bool = True,
-    sample_frequency: float = 16000.0,
-    snip_edges: bool = True,
-    subtract_mean: bool = False,
-    use_energy: bool = False,
-    use_log_fbank: bool = True,
-    use_power: bool = True,
-    vtln_high: float = -500.0,
-    vtln_low: float = 100.0,
-    vtln_warp: float = 1.0,
-    window_type: str = POVEY,
+    waveform: Tensor, blackman_coeff: float = 0.42, channel: int = -1, dither: float = 0.0,
+    energy_floor: float = 1.0, frame_length: float = 25.0, frame_shift: float = 10.0, high_freq: float = 0.0,
+    htk_compat: bool = False, low_freq: float = 20.0, min_duration: float = 0.0, num_mel_bins: int = 23,
+    preemphasis_coefficient: float = 0.97, raw_energy: bool = True, remove_dc_offset: bool = True,
+    round_to_power_of_two: bool = True, sample_frequency: float = 16000.0, snip_edges: bool = True,
+    subtract_mean: bool = False, use_energy: bool = False, use_log_fbank: bool = True, use_power: bool = True,
+    vtln_high: float = -500.0, vtln_low: float = 100.0, vtln_warp: float = 1.0, window_type: str = POVEY,
 ) -> Tensor:
     r"""Kaldi's compute-fbank-feats (reference: compliance/kaldi.py:514-645): (m, num_mel_bins + use_energy)."""
     device, dtype = waveform.device, waveform.dtype
@@ -197,31 +167,13 @@ def _get_lifter_coeffs(num_ceps: int, cepstral_lifter: float) -> Tensor:
 
 
 def mfcc(
-    waveform: Tensor,
-    blackman_coeff: float = 0.42,
-    cepstral_lifter: float = 22.0,
-    channel: int = -1,
-    dither: float = 0.0,
-    energy_floor: float = 1.0,
-    frame_length: float = 25.0,
-    frame_shift: float = 10.0,
-    high_freq: float = 0.0,
-    htk_compat: bool = False,
-    low_freq: float = 20.0,
-    num_ceps: int = 13,
-    min_duration: float = 0.0,
-    num_mel_bins: int = 23,
-    preemphasis_coefficient: float = 0.97,
-    raw_energy: bool = True,
-    remove_dc_offset: bool = True,
-    round_to_power_of_two: bool = True,
-    sample_frequency: float = 16000.0,
-    snip_edges: bool = True,
-    subtract_mean: bool = False,
-    use_energy: bool = False,
-    vtln_high: float = -500.0,
-    vtln_low: float = 100.0,
-    vtln_warp: float = 1.0,
+    waveform: Tensor, blackman_coeff: float = 0.42, cepstral_lifter: float = 22.0, channel: int = -1,
+    dither: float = 0.0, energy_floor: float = 1.0, frame_length: float = 25.0, frame_shift: float = 10.0,
+    high_freq: float = 0.0, htk_compat: bool = False, low_freq: float = 20.0, num_ceps: int = 13,
+    min_duration: float = 0.0, num_mel_bins: int = 23, preemphasis_coefficient: float = 0.97,
+    raw_energy: bool = True, remove_dc_offset: bool = True, round_to_power_of_two: bool = True,
+    sample_frequency: float = 16000.0, snip_edges: bool = True, subtract_mean: bool = False,
+    use_energy: bool = False, vtln_high: float = -500.0, vtln_low: float = 100.0, vtln_warp: float = 1.0,
     window_type: str = POVEY,
 ) -> Tensor:
     r"""Kaldi's compute-mfcc-feats (reference: compliance/kaldi.py:669-813): (m, num_ceps)."""
