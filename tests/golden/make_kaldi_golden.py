@@ -40,6 +40,18 @@ for name, (fn, kw) in cases.items():
     out[name] = y.numpy()
     meta[name] = {"fn": fn, "kw": kw}
     print(name, tuple(y.shape), float(y.abs().max()))
+# host-side constants of the reference, for bit-exact comparison with audio_amd/_host.py
+for tag, args in {"banks_default": (23, 512, 16000.0, 20.0, 0.0, 100.0, -500.0, 1.0),
+                  "banks_80": (80, 512, 16000.0, 20.0, -400.0, 100.0, -500.0, 1.0),
+                  "banks_vtln": (30, 512, 16000.0, 40.0, -200.0, 100.0, -500.0, 1.1),
+                  "banks_44k": (40, 2048, 44100.0, 20.0, 0.0, 100.0, -500.0, 0.9)}.items():
+    bins, centers = K.get_mel_banks(*args)
+    out[f"const/{tag}/bins"] = bins.numpy(); out[f"const/{tag}/centers"] = centers.numpy()
+    out[f"const/{tag}/args"] = np.array(args, dtype=np.float64)
+for wt in ("povey", "hanning", "hamming", "rectangular", "blackman"):
+    out[f"const/win_{wt}"] = K._feature_window_function(wt, 400, 0.42, torch.device("cpu"), torch.float32).numpy()
+out["const/dct_13_23"] = K._get_dct_matrix(13, 23).numpy()
+out["const/lifter_13_22"] = K._get_lifter_coeffs(13, 22.0).numpy()
 out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
 np.savez_compressed(os.path.join(HERE, "kaldi_goldens.npz"), **out)
 print("kaldi_goldens.npz", os.path.getsize(os.path.join(HERE, "kaldi_goldens.npz")) // 1024, "KiB")

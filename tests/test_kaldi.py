@@ -115,3 +115,21 @@ def test_gpu_kaldi_errors_and_edges():
         K.fbank(wav.cpu())
     assert K.fbank(wav, min_duration=10.0).numel() == 0
     assert K.fbank(wav).shape == (48, 23) and K.spectrogram(wav).shape == (48, 257) and K.mfcc(wav).shape == (48, 13)
+
+
+@pytest.mark.parametrize("tag", ["banks_default", "banks_80", "banks_vtln", "banks_44k"])
+def test_kaldi_mel_banks_bit_exact_vs_reference(tag):
+    """Host constants are built with the same torch ops in the same order as the reference (compliance/kaldi.py:436-511)."""
+    a = G[f"const/{tag}/args"]
+    bins, centers = _host.kaldi_get_mel_banks(int(a[0]), int(a[1]), float(a[2]), float(a[3]), float(a[4]), float(a[5]),
+                                              float(a[6]), float(a[7]))
+    assert np.array_equal(bins.numpy(), G[f"const/{tag}/bins"])
+    assert np.array_equal(centers.numpy(), G[f"const/{tag}/centers"])
+
+
+def test_kaldi_windows_dct_lifter_bit_exact_vs_reference():
+    import audio_amd.compliance.kaldi as K
+    for wt in ("povey", "hanning", "hamming", "rectangular", "blackman"):
+        assert np.array_equal(_host.kaldi_window(wt, 400, 0.42).numpy(), G[f"const/win_{wt}"]), wt
+    assert np.array_equal(K._get_dct_matrix(13, 23).numpy(), G["const/dct_13_23"])
+    assert np.array_equal(K._get_lifter_coeffs(13, 22.0).numpy(), G["const/lifter_13_22"])
