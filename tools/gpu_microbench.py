@@ -133,6 +133,25 @@ def main():
             os.environ["AAMD_FORCE_GENERIC"] = "1"
             print(f"  same, time-domain kernel: {timeit(lambda: F.fftconvolve(x1, y1), 1, 3):9.1f} us")
             del os.environ["AAMD_FORCE_GENERIC"]
+    if "standalone" in what:
+        x = (0.5 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
+        with torch.no_grad():
+            spec = T.Spectrogram(n_fft=400, hop_length=160).to(dev)(x)
+            ms = T.MelScale(n_mels=80, sample_rate=16000, n_stft=201).to(dev)
+            db = T.AmplitudeToDB(top_db=80.0).to(dev)
+            db0 = T.AmplitudeToDB(top_db=None).to(dev)
+            mel = ms(spec)
+            print(f"MelScale 256x201x1001 -> 80 (288 MB):          {timeit(lambda: ms(spec), 5, 30):8.1f} us")
+            print(f"AmplitudeToDB top_db=80, 256x80x1001 (246 MB): {timeit(lambda: db(mel), 5, 30):8.1f} us")
+            print(f"AmplitudeToDB top_db=None (164 MB):            {timeit(lambda: db0(mel), 5, 30):8.1f} us")
+            gl = T.GriffinLim(n_fft=400, n_iter=32, rand_init=False, length=160000).to(dev)
+            p = T.Spectrogram(n_fft=400).to(dev)(x[:64])
+            print(f"GriffinLim 64x10s, n_fft=400 hop=200, 32 iterations:   {timeit(lambda: gl(p), 1, 3):8.1f} us")
+            ps = T.PitchShift(16000, 4).to(dev)
+            print(f"PitchShift 64x10s (+4 semitones, n_fft=512):           {timeit(lambda: ps(x[:64]), 1, 3):8.1f} us")
+            import audio_amd.compliance.kaldi as K
+            one = x[:1] * 32768
+            print(f"kaldi.fbank 1x10s, 80 bins (one utterance per call):   {timeit(lambda: K.fbank(one, num_mel_bins=80), 3, 20):8.1f} us")
     if "rnnt" in what:
         from audio_amd.pipelines import GAIN, RNNTFeatureExtractor, piecewise_linear_log
         x = (0.1 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
