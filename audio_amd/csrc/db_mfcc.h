@@ -116,7 +116,6 @@ db_group_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
   };
   // scalar head up to the next 16-byte boundary of x (out shares the index, hence the alignment, when both bases are
   // 16-byte aligned; otherwise everything goes through the scalar loop), 16-byte body, scalar tail.
-  // NB: plain loop bounds and vectorize(disable): with select-valued bounds hipcc's loop passes did not terminate.
   const bool vec_ok = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (!STORE || reinterpret_cast<uintptr_t>(out) % 16 == 0);
   int64_t head_end = hi, body_end = hi;
   if (vec_ok) {
@@ -129,7 +128,7 @@ db_group_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n,
   const int64_t n_vec4 = (body_end - head_end) >> 2;
   const float4* xv4 = reinterpret_cast<const float4*>(x + head_end);
   float4* ov4 = reinterpret_cast<float4*>(out + head_end);
-#pragma clang loop vectorize(disable) unroll(disable)
+#pragma unroll 4
   for (int64_t j = threadIdx.x; j < n_vec4; j += 256) {
     const float4 xv = xv4[j];
     float4 y;

@@ -724,6 +724,12 @@ def amplitude_to_DB(x: Tensor, multiplier: float, amin: float, db_multiplier: fl
     r"""Power/amplitude -> decibel (functional/functional.py:356-404).  With ``top_db`` the cut-off
     is per leading item of the ``(-1, C, F, T)`` view, ``C = shape[-3]`` if ``x.dim() > 2`` else 1."""
     _require_device(x, "x")
+    # The op is element-wise plus a maximum over whole (C, F, T) blocks, so it runs in MEMORY order: the frame-major
+    # tensors Spectrogram / MelSpectrogram / MelScale return ((..., F, T) views of (..., T, F) storage) are processed
+    # as they lie and come back with the same strides -- what the reference's element-wise ops do -- instead of
+    # paying a transposing copy first.
+    if not x.is_contiguous() and x.dim() >= 2 and x.transpose(-1, -2).is_contiguous():
+        return amplitude_to_DB(x.transpose(-1, -2), multiplier, amin, db_multiplier, top_db).transpose(-1, -2)
     xc = x if x.is_contiguous() else x.contiguous()
     n = xc.numel()
     out = torch.empty_like(xc)
