@@ -560,7 +560,8 @@ def test_sim_mel400_int16_pcm_input(hop):
     assert np.array_equal(got2, ref2)
 
 
-@pytest.mark.parametrize("hop,L", [(160, 4000), (160, 2403), (100, 2500), (200, 3100), (160, 500), (200, 3600)])
+@pytest.mark.parametrize("hop,L", [(160, 4000), (160, 2403), (100, 2500), (200, 3100), (160, 500), (200, 3600), (160, 301),
+                                   (100, 250), (200, 12000)])
 def test_sim_istft400_roundtrip_and_adjoint(hop, L):
     """istft400_kernel (the radix-20x20 register FFT run backwards): agrees with the generic ola_kernel replay, inverts
     the STFT, and is the exact adjoint of the onesided STFT in every padding mode (halo atomics + plain-store middle)."""
