@@ -11,8 +11,44 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--reverse-order", action="store_true", default=False,
+                     help="run the collected tests in reverse order (proves no kernel depends on what ran before it / on "
+                          "the allocator neighbourhood a warm process leaves behind)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--reverse-order"):
+        # keep the torch-only preflight first: its job is to attribute a dead box before product code runs
+        pre = [i for i in items if "test_gpu_00_preflight" in i.nodeid]
+        rest = [i for i in items if "test_gpu_00_preflight" not in i.nodeid]
+        items[:] = pre + rest[::-1]
+
+
+PREFLIGHT = None
+
+
+def pytest_sessionstart(session):
+    """`-m gpu` runs on a GPU box: before THIS process touches the device, a torch-only child process exercises device
+    fill, H2D (pageable + pinned) and D2H (tests/gpu_preflight.py).  A box that cannot do that is reported as such -- the
+    round-1 driver run aborted at the first host-to-device copy, before the product library was loaded."""
+    global PREFLIGHT
+    mexpr = session.config.getoption("-m") or ""
+    if "gpu" not in mexpr or "not gpu" in mexpr:
+        return
+    import gpu_preflight
+    if not gpu_preflight.gpu_present():
+        return
+    capman = session.config.pluginmanager.getplugin("capturemanager")
+    if capman is not None:
+        with capman.global_and_fixture_disabled():       # the report must reach the log even if the run then aborts
+            PREFLIGHT = gpu_preflight.preflight(verbose=True, apply_env=True)
+    else:
+        PREFLIGHT = gpu_preflight.preflight(verbose=True, apply_env=True)
 
 
 @pytest.fixture(scope="session")
