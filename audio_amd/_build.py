@@ -22,11 +22,43 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+SHIM_OUT = os.path.join(HERE, "lib", "libaudio_amd_torch.so")
+SHIM_SRC = os.path.join(CSRC, "torch_shim.cpp")
+
+
+def shim_stale() -> bool:
+    if not os.path.exists(SHIM_OUT):
+        return True
+    t = os.path.getmtime(SHIM_OUT)
+    deps = [SHIM_SRC, os.path.join(os.path.dirname(HERE), "include", "audio_amd.h"), os.path.abspath(__file__), OUT]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_shim(force: bool = False, verbose: bool = False) -> str:
+    """libaudio_amd_torch.so: the LibTorch-stable-ABI shim (host code only: g++ against the torch headers), linked
+    against libaudio_amd.so through an $ORIGIN rpath so the pair travels together."""
+    if not force and not shim_stale():
+        return SHIM_OUT
+    import torch
+    tp = os.path.dirname(torch.__file__)
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DUSE_ROCM",
+           "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", os.path.join(tp, "include"),
+           SHIM_SRC, "-o", SHIM_OUT + ".tmp", "-L", os.path.dirname(OUT), "-laudio_amd",
+           "-L", os.path.join(tp, "lib"), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10",
+           "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(tp, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(SHIM_OUT + ".tmp", SHIM_OUT)
+    return SHIM_OUT
+
+
 def stale() -> bool:
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "torch_shim.cpp"]
     deps.append(os.path.join(os.path.dirname(HERE), "include", "audio_amd.h"))
     deps.append(os.path.abspath(__file__))
     return any(os.path.getmtime(d) > t for d in deps)
@@ -47,3 +79,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_shim(force="--force" in sys.argv, verbose="-v" in sys.argv))

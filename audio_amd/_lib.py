@@ -61,6 +61,7 @@ class KaldiDesc(C.Structure):
 _SIGS = {
     "aamd_abi_version": (C.c_int, []),
     "aamd_last_error": (C.c_char_p, []),
+    "aamd_set_kernel_policy": (C.c_int, [C.c_int]),
     "aamd_device_info": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "aamd_spectrogram_f32": (C.c_int, [_P, _P, _P, _P, C.POINTER(StftDesc), _P]),
     "aamd_melspectrogram_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), _P]),
@@ -117,6 +118,24 @@ def lib():
                 raise RuntimeError("audio_amd: ABI version mismatch between _lib.py and libaudio_amd.so")
             _lib = h
     return _lib
+
+
+POLICY_FORCE_GENERIC, POLICY_MEL400_WIDE, POLICY_ISTFT_ATOMIC = 1, 2, 4
+
+
+class kernel_policy:
+    """``with _lib.kernel_policy(_lib.POLICY_FORCE_GENERIC): ...`` -- tests / A-B runs pick the kernel family."""
+
+    def __init__(self, flags: int):
+        self.flags = flags
+
+    def __enter__(self):
+        self.prev = lib().aamd_set_kernel_policy(self.flags)
+        return self
+
+    def __exit__(self, *exc):
+        lib().aamd_set_kernel_policy(self.prev)
+        return False
 
 
 def check(rc: int) -> None:

@@ -3,7 +3,9 @@
 // per-process cache of immutable device properties.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -51,6 +53,49 @@ int launch_check() {
   if (e != hipSuccess) return fail(AAMD_EHIP, std::string("audio_amd: kernel launch failed: ") + hipGetErrorString(e));
   return AAMD_OK;
 }
+
+// Kernel-selection switches (tests / A-B experiments): a process-wide bit mask, initialised ONCE from the environment
+// (AAMD_FORCE_GENERIC, AAMD_MEL400_WIDE, AAMD_ISTFT_ATOMIC) and changed afterwards only through
+// aamd_set_kernel_policy() -- no getenv() on the launch path.
+std::atomic<int> g_policy{-1};
+
+int policy() {
+  int p = g_policy.load(std::memory_order_relaxed);
+  if (p < 0) {
+    p = 0;
+    if (std::getenv("AAMD_FORCE_GENERIC") != nullptr) p |= AAMD_POLICY_FORCE_GENERIC;
+    if (std::getenv("AAMD_MEL400_WIDE") != nullptr) p |= AAMD_POLICY_MEL400_WIDE;
+    if (std::getenv("AAMD_ISTFT_ATOMIC") != nullptr) p |= AAMD_POLICY_ISTFT_ATOMIC;
+    int expected = -1;
+    g_policy.compare_exchange_strong(expected, p);
+    p = g_policy.load(std::memory_order_relaxed);
+  }
+  return p;
+}
+inline bool force_generic() { return (policy() & AAMD_POLICY_FORCE_GENERIC) != 0; }
+
+// The launches size their grids from, and set function attributes on, the CURRENT device.  In a process that sees
+// several GPUs (not the one-process-per-GPU deployment) the caller's tensors may live on another one: make the
+// device that owns the buffer current for the duration of the call.  Costs nothing when one GPU is visible.
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(const void* p) {
+    static const int n_dev = [] { int n = 1; (void)hipGetDeviceCount(&n); return n; }();
+    if (n_dev <= 1 || p == nullptr) return;
+    int cur = 0, own = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return;
+    if (hipPointerGetAttribute(&own, HIP_POINTER_ATTRIBUTE_DEVICE_ORDINAL, const_cast<void*>(p)) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    if (own != cur && own >= 0 && own < n_dev && hipSetDevice(own) == hipSuccess) prev = cur;
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
 
 struct DevProps {
   int cu_count = 0;
@@ -152,7 +197,7 @@ template <int EPI>
 int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, const float* window,
                    const float* twiddle, float* out, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
-  if (g.onesided && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+  if (g.onesided && !force_generic()) {
     if (g.n_fft == 256) return launch_pow2<EPI, 4>(g, mb, wav, window, twiddle, out, s);
     if (g.n_fft == 512) return launch_pow2<EPI, 8>(g, mb, wav, window, twiddle, out, s);
     if (g.n_fft == 1024) return launch_pow2<EPI, 16>(g, mb, wav, window, twiddle, out, s);
@@ -177,7 +222,7 @@ int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, c
 
 bool fft400_eligible(const StftGeom& g) {
   return g.n_fft == 400 && (g.hop == 160 || g.hop == 200 || g.hop == 100) && g.center && g.pad_mode == AAMD_PAD_REFLECT &&
-         g.onesided && g.pad == 0 && g.length > 400 && std::getenv("AAMD_FORCE_GENERIC") == nullptr;
+         g.onesided && g.pad == 0 && g.length > 400 && !force_generic();
 }
 
 template <int EPI>
@@ -218,7 +263,7 @@ int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, co
   const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (g.row_stride % (16 / (int)sizeof(TIn)) == 0);
   // mel rows leave as 4-byte stores straight from the accumulators: the LDS pipe is this kernel's
   // bottleneck and the LDS-staged dwordx4 path measured 3-4 us slower (AAMD_MEL400_WIDE=1 selects it)
-  const bool want_wide = (EPI == m400::EPI400_SPEC) || std::getenv("AAMD_MEL400_WIDE") != nullptr;
+  const bool want_wide = (EPI == m400::EPI400_SPEC) || (policy() & AAMD_POLICY_MEL400_WIDE) != 0;
   const int out_wide = want_wide && (reinterpret_cast<uintptr_t>(out) % 16 == 0) &&
                        (EPI == m400::EPI400_SPEC || mb.n_mels % 4 == 0);
   if (EPI == m400::EPI400_SPEC && !out_wide)
@@ -269,6 +314,12 @@ extern "C" {
 
 int aamd_abi_version(void) { return AAMD_ABI_VERSION; }
 
+int aamd_set_kernel_policy(int flags) {
+  const int prev = policy();
+  if (flags >= 0) g_policy.store(flags & (AAMD_POLICY_FORCE_GENERIC | AAMD_POLICY_MEL400_WIDE | AAMD_POLICY_ISTFT_ATOMIC));
+  return prev;
+}
+
 const char* aamd_last_error(void) { return g_err.c_str(); }
 
 int aamd_device_info(char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes) {
@@ -286,6 +337,7 @@ int aamd_device_info(char* name, int32_t name_len, int32_t* cu_count, int64_t* h
 
 int aamd_spectrogram_f32(const float* wav, const float* window, const float* twiddle, float* out,
                          const aamd_stft_desc* desc, void* stream) {
+  DeviceScope dev_scope_(wav);
   StftGeom g;
   int rc = validate_desc(desc, g);
   if (rc != AAMD_OK) return rc;
@@ -302,6 +354,7 @@ int aamd_spectrogram_f32(const float* wav, const float* window, const float* twi
 int aamd_melspectrogram_f32(const float* wav, const float* window, const float* twiddle,
                             const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
                             void* stream) {
+  DeviceScope dev_scope_(wav);
   StftGeom g;
   int rc = validate_desc(desc, g);
   if (rc != AAMD_OK) return rc;
@@ -320,6 +373,7 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
                                const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
                                float multiplier, float amin, float db_multiplier, float* group_max,
                                int64_t rows_per_group, void* stream) {
+  DeviceScope dev_scope_(wav);
   StftGeom g;
   int rc = validate_desc(desc, g);
   if (rc != AAMD_OK) return rc;
@@ -347,6 +401,7 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
 int aamd_melspectrogram_lognorm_f32(const float* wav, const float* window, const float* twiddle,
                                     const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
                                     const float* mean, const float* invstddev, int64_t out_frames, void* stream) {
+  DeviceScope dev_scope_(wav);
   StftGeom g;
   int rc = validate_desc(desc, g);
   if (rc != AAMD_OK) return rc;
@@ -376,6 +431,7 @@ int aamd_melspectrogram_lognorm_f32(const float* wav, const float* window, const
 int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const float* twiddle,
                                   const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
                                   const float* mean, const float* invstddev, int64_t out_frames, void* stream) {
+  DeviceScope dev_scope_(wav);
   StftGeom g;
   int rc = validate_desc(desc, g);
   if (rc != AAMD_OK) return rc;
@@ -400,6 +456,7 @@ int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const
 }
 
 int aamd_spectrogram_grad_f32(const float* spec, const float* dpower, float* out, int64_t n, float power, void* stream) {
+  DeviceScope dev_scope_(spec);
   AAMD_CHECK_ARG(spec && dpower && out, "null buffer");
   AAMD_CHECK_ARG(n >= 0 && power > 0.0f, "bad sizes / power");
   if (n == 0) return AAMD_OK;
@@ -410,6 +467,7 @@ int aamd_spectrogram_grad_f32(const float* spec, const float* dpower, float* out
 
 int aamd_melspectrogram_grad_f32(float* spec_inout, const float* dmel, const aamd_mel_bands* bands_t, int64_t n_vec,
                                  int32_t n_freq, int32_t n_mels, float power, void* stream) {
+  DeviceScope dev_scope_(spec_inout);
   AAMD_CHECK_ARG(spec_inout && dmel, "null buffer");
   AAMD_CHECK_ARG(n_vec >= 0 && n_freq >= 1 && n_mels >= 1 && power > 0.0f, "bad sizes / power");
   MelBandsDev bt;
@@ -425,6 +483,7 @@ int aamd_melspectrogram_grad_f32(float* spec_inout, const float* dmel, const aam
 
 int aamd_kaldi_features_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
                             float* out, const aamd_kaldi_desc* d, void* stream) {
+  DeviceScope dev_scope_(wav);
   AAMD_CHECK_ARG(d != nullptr && wav && window && twiddle && out, "null buffer");
   AAMD_CHECK_ARG(d->n_samples >= 0 && d->n_frames >= 0, "negative sizes");
   AAMD_CHECK_ARG(d->shift >= 1 && d->win >= 2 && d->win <= d->n_fft, "need shift >= 1 and 2 <= win <= n_fft");
@@ -473,6 +532,7 @@ int aamd_kaldi_features_f32(const float* wav, const float* window, const float* 
 
 int aamd_istft_f32(const float* spec, const float* window, const float* twiddle, const float* inv_envelope,
                    float* out, const aamd_stft_desc* desc, int32_t adjoint, void* stream) {
+  DeviceScope dev_scope_(spec);
   AAMD_CHECK_ARG(desc != nullptr && spec && window && twiddle && out, "null buffer");
   AAMD_CHECK_ARG(desc->rows >= 0 && desc->length >= 0 && desc->n_frames >= 0, "negative sizes");
   AAMD_CHECK_ARG(desc->n_fft >= 2 && desc->hop >= 1 && desc->pad >= 0, "n_fft must be >= 2, hop >= 1, pad >= 0");
@@ -491,7 +551,7 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
   og.interior = adjoint ? 0.5f : 1.0f;
   og.scale = desc->scale * (adjoint ? 1.0f : 1.0f / (float)desc->n_fft);
   if (g.n_fft == 400 && (g.hop == 100 || g.hop == 160 || g.hop == 200) && g.center && g.pad == 0 &&
-      std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+      !force_generic()) {
     // radix-20x20 register FFT run backwards (istft400.h)
     m400::Inv400Geom ig{g, og.interior};
     const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
@@ -513,7 +573,7 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
 #undef AAMD_I400
     return launch_check();
   }
-  if ((g.n_fft == 256 || g.n_fft == 512 || g.n_fft == 1024 || g.n_fft == 2048) && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+  if ((g.n_fft == 256 || g.n_fft == 512 || g.n_fft == 1024 || g.n_fft == 2048) && !force_generic()) {
     // register-resident wave FFT run as the inverse (stft_pow2.h)
     p2::InvGeom ig{g, og.interior};
     const int64_t ppr = (g.n_frames + 1) / 2, n_pairs = g.rows * ppr;
@@ -524,7 +584,7 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
     if (blocks > need) blocks = need;
     // runs of consecutive pairs per wave (overlap-add in an LDS ring, plain stores); hop > n_fft leaves gaps the ring
     // logic does not model: pair-at-a-time atomics there
-    const bool use_runs = g.hop <= g.n_fft && std::getenv("AAMD_ISTFT_ATOMIC") == nullptr;
+    const bool use_runs = g.hop <= g.n_fft && (policy() & AAMD_POLICY_ISTFT_ATOMIC) == 0;
     const int run_len = 16;
     const int64_t rpr = (ppr + run_len - 1) / run_len, n_runs = g.rows * rpr;
     if (use_runs) {
@@ -574,6 +634,7 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
 
 int aamd_phase_vocoder_f32(const float* spec, const float* phase_advance, float* out, const aamd_vocoder_desc* d,
                            void* stream) {
+  DeviceScope dev_scope_(spec);
   AAMD_CHECK_ARG(d != nullptr && spec && phase_advance && out, "null buffer");
   AAMD_CHECK_ARG(d->rows >= 0 && d->n_freq >= 1 && d->n_frames_in >= 0 && d->n_frames_out >= 0, "bad sizes");
   AAMD_CHECK_ARG(d->rate > 0.0, "rate must be positive");
@@ -589,6 +650,7 @@ int aamd_phase_vocoder_f32(const float* spec, const float* phase_advance, float*
 
 int aamd_griffinlim_update_f32(const float* rebuilt, float* tprev, const float* magnitude, float* next, int64_t n,
                                float momentum, void* stream) {
+  DeviceScope dev_scope_(rebuilt);
   AAMD_CHECK_ARG(rebuilt && tprev && magnitude && next, "null buffer");
   AAMD_CHECK_ARG(n >= 0, "bad size");
   if (n == 0) return AAMD_OK;
@@ -601,6 +663,7 @@ int aamd_griffinlim_update_f32(const float* rebuilt, float* tprev, const float* 
 
 int aamd_mel_scale_f32(const float* spec, const aamd_mel_bands* bands, float* out, int64_t rows,
                        int32_t n_frames, int32_t n_freq, void* stream) {
+  DeviceScope dev_scope_(spec);
   AAMD_CHECK_ARG(spec && out, "null buffer");
   AAMD_CHECK_ARG(rows >= 0 && n_frames >= 0 && n_freq >= 1, "bad sizes");
   MelBandsDev mb;
@@ -633,6 +696,7 @@ static int db_grid(int64_t n, int64_t group_size, int64_t* chunks_per_group, int
 
 int aamd_amplitude_to_db_f32(const float* x, float* out, int64_t n, float multiplier, float amin,
                              float db_multiplier, float* group_max, int64_t group_size, void* stream) {
+  DeviceScope dev_scope_(x);
   AAMD_CHECK_ARG(x && (out || group_max), "null buffer");
   AAMD_CHECK_ARG(n >= 0, "negative size");
   AAMD_CHECK_ARG(group_max == nullptr || group_size >= 1, "group_size must be >= 1");
@@ -656,6 +720,7 @@ int aamd_amplitude_to_db_f32(const float* x, float* out, int64_t n, float multip
 int aamd_amplitude_to_db_clamped_f32(const float* x, float* out, int64_t n, float multiplier, float amin,
                                      float db_multiplier, const float* group_max, int64_t group_size, float top_db,
                                      void* stream) {
+  DeviceScope dev_scope_(x);
   AAMD_CHECK_ARG(x && out && group_max, "null buffer");
   AAMD_CHECK_ARG(n >= 0 && group_size >= 1, "bad sizes");
   if (n == 0) return AAMD_OK;
@@ -668,6 +733,7 @@ int aamd_amplitude_to_db_clamped_f32(const float* x, float* out, int64_t n, floa
 
 int aamd_db_clamp_f32(const float* x, float* out, int64_t n, const float* group_max,
                       int64_t group_size, float top_db, void* stream) {
+  DeviceScope dev_scope_(x);
   AAMD_CHECK_ARG(x && out && group_max, "null buffer");
   AAMD_CHECK_ARG(n >= 0 && group_size >= 1, "bad sizes");
   if (n == 0) return AAMD_OK;
@@ -680,6 +746,7 @@ int aamd_db_clamp_f32(const float* x, float* out, int64_t n, const float* group_
 int aamd_mfcc_dct_f32(const float* mel, const float* dct, float* out, int64_t n_vec, int32_t n_mels,
                       int32_t n_mfcc, int32_t log_mode, const float* group_max,
                       int64_t vec_per_group, float top_db, void* stream) {
+  DeviceScope dev_scope_(mel);
   AAMD_CHECK_ARG(mel && dct && out, "null buffer");
   AAMD_CHECK_ARG(n_vec >= 0 && n_mels >= 1 && n_mfcc >= 1, "bad sizes");
   AAMD_CHECK_ARG(log_mode >= 0 && log_mode <= 2, "bad log_mode");
@@ -687,7 +754,7 @@ int aamd_mfcc_dct_f32(const float* mel, const float* dct, float* out, int64_t n_
   if (n_vec == 0) return AAMD_OK;
   const int nt = (n_mfcc + 15) / 16;
   if (n_mels % 4 == 0 && n_mels <= 16 * kDctMaxChunks && nt <= 4 && reinterpret_cast<uintptr_t>(mel) % 16 == 0 &&
-      reinterpret_cast<uintptr_t>(out) % 16 == 0 && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+      reinterpret_cast<uintptr_t>(out) % 16 == 0 && !force_generic()) {
     const size_t flds = (size_t)dct_frag_floats(n_mels, n_mfcc) * sizeof(float);
     if (flds <= 64 * 1024) {
       const int64_t tiles = (n_vec + kDctFramesPerTile - 1) / kDctFramesPerTile;
@@ -726,6 +793,7 @@ int aamd_mfcc_dct_f32(const float* mel, const float* dct, float* out, int64_t n_
 int aamd_resample_f32(const float* wav, const float* kernel, float* out, int64_t rows, int64_t length,
                       int64_t row_stride, int32_t orig, int32_t new_, int32_t width, int64_t out_len,
                       void* stream) {
+  DeviceScope dev_scope_(wav);
   AAMD_CHECK_ARG(wav && kernel && out, "null buffer");
   AAMD_CHECK_ARG(rows >= 0 && length >= 0 && orig >= 1 && new_ >= 1 && width >= 0, "bad sizes");
   AAMD_CHECK_ARG(row_stride >= length, "row_stride < length");
@@ -759,9 +827,10 @@ int aamd_resample_f32(const float* wav, const float* kernel, float* out, int64_t
 int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, int64_t rows,
                              int64_t length, int64_t row_stride, int32_t orig, int32_t new_, int32_t width,
                              int64_t out_len, const aamd_resample_bands* bands, void* stream) {
+  DeviceScope dev_scope_(wav);
   const int n_tiles = (new_ + 15) / 16;
   const int ks = bands ? rsm::pick_ks(bands->tap_span) : 0;
-  if (bands == nullptr || ks == 0 || std::getenv("AAMD_FORCE_GENERIC") != nullptr)
+  if (bands == nullptr || ks == 0 || force_generic())
     return aamd_resample_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, stream);
   AAMD_CHECK_ARG(wav && kernel && out, "null buffer");
   AAMD_CHECK_ARG(rows >= 0 && length >= 0 && orig >= 1 && new_ >= 1 && width >= 0, "bad sizes");
@@ -832,6 +901,7 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
 int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, int64_t batch,
                      int32_t channels, int64_t length, int32_t n_order, int32_t n_coeff_rows,
                      int32_t n_stages, int32_t clamp, void* stream) {
+  DeviceScope dev_scope_(x);
   AAMD_CHECK_ARG(x && a && b && y, "null buffer");
   AAMD_CHECK_ARG(batch >= 0 && channels >= 1 && length >= 0, "bad sizes");
   AAMD_CHECK_ARG(n_order >= 1 && n_stages >= 1, "n_order and n_stages must be >= 1");
@@ -841,7 +911,7 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
   hipStream_t s = (hipStream_t)stream;
   const int d = n_order - 1;
   // biquad-class filters: W waves per sequence with shuffle scans (lfilter_wave.h); W fills the chip
-  if (n_order <= 3 && n_stages <= lfw::kMaxCascade && length < (1ll << 30) && std::getenv("AAMD_FORCE_GENERIC") == nullptr) {
+  if (n_order <= 3 && n_stages <= lfw::kMaxCascade && length < (1ll << 30) && !force_generic()) {
     int W = 1;
     while (W < lfw::kMaxWaves && n_seq * (2 * W) <= 8192 && (int64_t)W * lfw::kWaveBlock < length) W *= 2;
     const size_t cap = dev_props().lds_per_block_optin ? dev_props().lds_per_block_optin : 64 * 1024;
@@ -875,7 +945,7 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
 static const int64_t kFftConvMinTaps = 192;
 
 static bool fftconv_use_fft(int64_t n_taps) {
-  return n_taps > kFftConvMinTaps && std::getenv("AAMD_FORCE_GENERIC") == nullptr;
+  return n_taps > kFftConvMinTaps && !force_generic();
 }
 
 int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_rows, int64_t nx, int64_t ny) {
@@ -893,6 +963,7 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
                          int64_t n_y_rows, int64_t nx, int64_t ny, const int64_t* x_row_of,
                          const int64_t* y_row_of, int64_t start, int64_t out_len, void* workspace,
                          void* stream) {
+  DeviceScope dev_scope_(x);
   AAMD_CHECK_ARG(x && y && out, "null buffer");
   AAMD_CHECK_ARG(rows >= 0 && nx >= 1 && ny >= 1 && n_x_rows >= 1 && n_y_rows >= 1, "bad sizes");
   AAMD_CHECK_ARG(start >= 0 && out_len >= 0 && start + out_len <= nx + ny - 1, "slice outside the full convolution");

@@ -210,7 +210,7 @@ lognorm_kernel(float* __restrict__ x, int64_t n, int n_mels, float gain, const f
 // Backward of |X|^p: G = dP * p * |X|^(p-2) * X per bin (0 where X = 0 and p < 2) -- the spectrum-domain cotangent the
 // STFT adjoint (aamd_istft_f32, adjoint = 1) consumes; X and G interleaved complex, dP real, all frame-major
 __global__ void __launch_bounds__(256)
-spec_grad_kernel(const float2* __restrict__ X, const float* __restrict__ dP, float2* __restrict__ G, int64_t n, float power) {
+spec_grad_kernel(const float2* X, const float* __restrict__ dP, float2* G, int64_t n, float power) {   // G may alias X (in-place backward)
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float2 x = X[i];

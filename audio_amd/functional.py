@@ -7,9 +7,11 @@ device (``tensor.is_cuda``) and be float32; there is no CPU fallback.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import math
 import os
+import threading
 import warnings
 import weakref
 from typing import Optional, Union
@@ -20,6 +22,7 @@ from torch import Tensor
 
 from . import _host
 from . import _lib
+from . import _shim
 from ._host import create_dct, melscale_fbanks  # noqa: F401  (re-exported, host-side constants)
 
 __all__ = [
@@ -46,6 +49,20 @@ def _require_device(t: Tensor, what: str, allow_grad: bool = False) -> None:
                            "wrap the call in torch.no_grad().")
 
 
+def _reject_param_grad(**params) -> None:
+    """The window / mel filterbank / DCT matrix are constants of this implementation's autograd (as in the reference's
+    own gradient tests).  The reference would propagate into them through stft / matmul; silently returning no
+    gradient would be wrong, so a learnable one is refused loudly."""
+    if not torch.is_grad_enabled():
+        return
+    for name, t in params.items():
+        if t is not None and t.requires_grad:
+            raise RuntimeError(
+                f"audio_amd: `{name}` requires grad, but gradients with respect to {name} are not implemented on the "
+                "HIP path (only the waveform is differentiated). Detach it (e.g. register it as a buffer), or use the "
+                "ATen composition for a learnable " + name + ".")
+
+
 def _rows2d(t: Tensor) -> Tensor:
     """(..., L) -> contiguous (rows, L) view/copy."""
     x = t.reshape(-1, t.shape[-1])
@@ -54,17 +71,51 @@ def _rows2d(t: Tensor) -> Tensor:
     return x
 
 
-_CACHE: dict = {}        # value-keyed constants (twiddles, sinc kernels): key holds every parameter
+# Launch route, decided ONCE per process: the compiled dispatcher-level boundary (torch.ops.aamd.*, csrc/torch_shim.cpp:
+# boxed stable-ABI kernels that take the current stream and call the C ABI) when libaudio_amd_torch.so is built, else /
+# with AAMD_NO_TORCH_SHIM=1 the ctypes binding of the same C ABI (_lib.py).  Both end in the same aamd_* entry points.
+_ROUTE = {"ops": None, "decided": False}
+
+
+def _ops():
+    if not _ROUTE["decided"]:
+        if os.environ.get("AAMD_NO_TORCH_SHIM") is None and _shim.available():
+            _shim.load()
+            _ROUTE["ops"] = torch.ops.aamd
+        _ROUTE["decided"] = True
+    return _ROUTE["ops"]
+
+
+def _force_route(kind: Optional[str]) -> None:
+    """Tests: 'shim', 'ctypes', or None = decide again from the environment."""
+    if kind is None:
+        _ROUTE["decided"] = False
+        _ROUTE["ops"] = None
+    elif kind == "shim":
+        _shim.load()
+        _ROUTE["ops"], _ROUTE["decided"] = torch.ops.aamd, True
+    else:
+        _ROUTE["ops"], _ROUTE["decided"] = None, True
+
+
+_CACHE: "collections.OrderedDict" = collections.OrderedDict()   # value-keyed constants (twiddles, sinc kernels), LRU
 _TENSOR_CACHE: dict = {}  # id(tensor) -> (weakref(tensor), {key: value})
+_CACHE_LOCK = threading.RLock()   # transforms are called from data-loader / serving threads: plan caches are shared
+_CACHE_MAX = 256
 
 
 def _cached(key, make):
-    v = _CACHE.get(key)
-    if v is None:
-        if len(_CACHE) > 256:
-            _CACHE.clear()
-        v = make()
-        _CACHE[key] = v
+    with _CACHE_LOCK:
+        v = _CACHE.get(key)
+        if v is not None:
+            _CACHE.move_to_end(key)
+            return v
+    v = make()                                   # built outside the lock (may launch / copy); a race builds it twice
+    with _CACHE_LOCK:
+        v = _CACHE.setdefault(key, v)
+        _CACHE.move_to_end(key)
+        while len(_CACHE) > _CACHE_MAX:
+            _CACHE.popitem(last=False)           # least recently used, not clear-all
     return v
 
 
@@ -72,20 +123,27 @@ def _tensor_cached(t: Tensor, key, make):
     """Cache a constant derived from tensor `t` (window / fb buffers).  The slot is found by
     object id but is only trusted while its weak reference still resolves to `t` itself, so a
     new tensor that reuses a dead tensor's id can never hit a stale entry (finalizers of tensor
-    wrappers may run late); the in-place version counter invalidates on mutation."""
+    wrappers may run late).  The key holds the in-place version counter AND the storage address, so
+    `t.add_(...)` and `t.data = other` both invalidate; writes through `t.data.copy_()` bump neither and
+    are not seen (use `t.copy_()`)."""
     tid = id(t)
-    slot = _TENSOR_CACHE.get(tid)
-    if slot is None or slot[0]() is not t:
-        if len(_TENSOR_CACHE) > 512:
-            for k in [k for k, s in _TENSOR_CACHE.items() if s[0]() is None]:
-                del _TENSOR_CACHE[k]
-        slot = (weakref.ref(t), {})
-        _TENSOR_CACHE[tid] = slot
-    k = (key, t._version, str(t.device), t.dtype)
-    v = slot[1].get(k)
-    if v is None:
-        v = make()
-        slot[1][k] = v
+    k = (key, t._version, t.data_ptr(), str(t.device), t.dtype)
+    with _CACHE_LOCK:
+        slot = _TENSOR_CACHE.get(tid)
+        if slot is None or slot[0]() is not t:
+            if len(_TENSOR_CACHE) > 512:
+                for kk in [kk for kk, sl in _TENSOR_CACHE.items() if sl[0]() is None]:
+                    del _TENSOR_CACHE[kk]
+            slot = (weakref.ref(t), {})
+            _TENSOR_CACHE[tid] = slot
+        v = slot[1].get(k)
+        if v is not None:
+            return v
+    v = make()
+    with _CACHE_LOCK:
+        if len(slot[1]) > 64:                    # a tensor mutated every step: keep only the newest derivations
+            slot[1].clear()
+        v = slot[1].setdefault(k, v)
     return v
 
 
@@ -198,6 +256,7 @@ def spectrogram(
             "`torchaudio.functional.spectrogram(power=None)` always returns a tensor with "
             "complex dtype. Please remove the argument in the function call."
         )
+    _reject_param_grad(window=window)
     _require_device(waveform, "waveform", allow_grad=True)
     if window.shape[0] != win_length:
         raise RuntimeError(
@@ -227,6 +286,11 @@ def _spectrogram_launch(x2: Tensor, window_padded: Tensor, desc, power) -> Tenso
     """Frame-major (rows, T, n_freq [* 2 for complex]) float32 through aamd_spectrogram_f32."""
     n_freq = desc.n_fft // 2 + 1 if desc.onesided else desc.n_fft
     comp = 2 if power is None else 1
+    ops = _ops()
+    if ops is not None:
+        return ops.spectrogram(x2, window_padded, _twiddles(desc.n_fft, x2.device), desc.n_fft, desc.hop, desc.pad,
+                               bool(desc.center), desc.pad_mode, bool(desc.onesided), desc.n_frames, desc.scale,
+                               desc.power)
     out = torch.empty((desc.rows, desc.n_frames, n_freq * comp), dtype=torch.float32, device=x2.device)
     if out.numel():
         L = _lib.lib()
@@ -364,7 +428,9 @@ def inverse_spectrogram(
     if n_freq != n_fft // 2 + 1:
         raise RuntimeError(f"istft: expected the frequency dimension of the input to be n_fft / 2 + 1 = "
                            f"{n_fft // 2 + 1}, but got {n_freq}")
-    fm = spectrogram.to(torch.complex64).transpose(-1, -2).reshape(-1, T, n_freq)
+    if spectrogram.dtype != torch.complex64:
+        raise TypeError(f"audio_amd: spectrogram must be complex64 (got {spectrogram.dtype}); kernels compute in fp32.")
+    fm = spectrogram.transpose(-1, -2).reshape(-1, T, n_freq)
     if not fm.is_contiguous():
         fm = fm.contiguous()
     rows = fm.shape[0]
@@ -438,7 +504,10 @@ def phase_vocoder(complex_specgrams: Tensor, rate: float, phase_advance: Tensor)
     if complex_specgrams.requires_grad and torch.is_grad_enabled():
         raise RuntimeError("audio_amd: phase_vocoder is forward-only; wrap the call in torch.no_grad().")
     shape = complex_specgrams.size()
-    spec = complex_specgrams.to(torch.complex64).reshape((-1,) + tuple(shape[-2:]))
+    if complex_specgrams.dtype != torch.complex64:
+        raise TypeError(f"audio_amd: complex_specgrams must be complex64 (got {complex_specgrams.dtype}); "
+                        "kernels compute in fp32.")
+    spec = complex_specgrams.reshape((-1,) + tuple(shape[-2:]))
     out = _phase_vocoder_launch(spec, rate, phase_advance, frame_major_out=False)
     return out.reshape(tuple(shape[:-2]) + out.shape[1:])
 
@@ -580,6 +649,15 @@ def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_ff
         raise RuntimeError(
             f"mat1 and mat2 shapes cannot be multiplied ({desc.n_frames}x{n_fft // 2 + 1} and "
             f"{bands.n_freq}x{bands.n_mels})")
+    ops = _ops()
+    if ops is not None:
+        targs = (x2, _padded_window(window, n_fft), _twiddles(n_fft, waveform.device), bands.lo, bands.width,
+                 bands.weights, bands.lane_order, n_fft, hop_length, pad, bool(center), desc.pad_mode, desc.n_frames,
+                 desc.scale, desc.power)
+        if db is None:
+            return ops.mel_spectrogram(*targs)
+        multiplier, amin, db_multiplier, group_max, rows_per_group = db
+        return ops.mel_spectrogram_db(*targs, multiplier, amin, db_multiplier, group_max, rows_per_group)
     out = torch.empty((desc.rows, desc.n_frames, bands.n_mels), dtype=torch.float32, device=waveform.device)
     if out.numel():
         L = _lib.lib()
@@ -601,7 +679,9 @@ def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_l
     """MelSpectrogram (power 2, centre / reflect) with the RNN-T feature post-processing fused
     (pipelines/rnnt_pipeline.py:16-47, 319-326).  Returns (rows, T + right_padding, n_mels), the padding rows zero."""
     pcm16 = waveform.dtype == torch.int16
-    if pcm16 and not (n_fft == 400 and hop_length in (160, 200)):
+    L0 = _lib.lib()
+    if pcm16 and not (n_fft == 400 and hop_length in (160, 200) and waveform.shape[-1] > 400
+                      and not (L0.aamd_set_kernel_policy(-1) & _lib.POLICY_FORCE_GENERIC)):
         waveform, pcm16 = waveform.to(torch.float32) * (1.0 / 32768.0), False   # shapes the PCM kernel does not serve
     if pcm16:
         if not waveform.is_cuda:
@@ -621,22 +701,55 @@ def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_l
     invstddev = invstddev.to(device=dev, dtype=torch.float32).contiguous()
     if mean.numel() != bands.n_mels or invstddev.numel() != bands.n_mels:
         raise RuntimeError(f"audio_amd: global statistics must have n_mels = {bands.n_mels} entries")
+    if pcm16 and not (bands.n_mels <= 160 and bands.max_width <= 62):   # filterbank outside the radix-20x20 kernel
+        return _mel_lognorm(waveform.to(torch.float32) * (1.0 / 32768.0), window, fb, n_fft, hop_length, gain, mean,
+                            invstddev, right_padding, bands)
     T = desc.n_frames
-    fused_pad = n_fft == 400                       # rows of T + right_padding frames come straight from the kernel
-    frames = T + right_padding if fused_pad else T
-    out = torch.empty((desc.rows, frames, bands.n_mels), dtype=torch.float32, device=dev)
-    if out.numel():
-        if frames > T:
-            out[:, T:].zero_()
-        if T:
-            L = _lib.lib()
-            entry = L.aamd_melspectrogram_pcm16_f32 if pcm16 else L.aamd_melspectrogram_lognorm_f32
-            _lib.check(entry(
-                x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),
-                C.byref(bands.struct), out.data_ptr(), C.byref(desc), float(gain), mean.data_ptr(), invstddev.data_ptr(),
-                frames, _lib.current_stream(dev)))
-    if not fused_pad and right_padding:
+    # Rows of T + right_padding frames come straight from the kernel only on the radix-20x20 fast path.  Its
+    # eligibility (csrc/c_api.hip: mel400_eligible -- hop, clip length, filterbank geometry, kernel policy) is mirrored
+    # here; every other shape writes T frames and is padded afterwards, as the reference does.
+    fused_pad = (right_padding > 0 and n_fft == 400 and hop_length in (100, 160, 200) and x2.shape[1] > 400
+                 and bands.n_mels <= 160 and bands.max_width <= 62
+                 and not (L0.aamd_set_kernel_policy(-1) & _lib.POLICY_FORCE_GENERIC))
+    entry = L0.aamd_melspectrogram_pcm16_f32 if pcm16 else L0.aamd_melspectrogram_lognorm_f32
+
+    def launch(frames: int) -> Tensor:
+        out = torch.empty((desc.rows, frames, bands.n_mels), dtype=torch.float32, device=dev)
+        if out.numel():
+            if frames > T:
+                out[:, T:].zero_()
+            if T:
+                _lib.check(entry(
+                    x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),
+                    C.byref(bands.struct), out.data_ptr(), C.byref(desc), float(gain), mean.data_ptr(),
+                    invstddev.data_ptr(), frames, _lib.current_stream(dev)))
+        return out
+
+    if fused_pad:
+        try:
+            return launch(T + right_padding)
+        except RuntimeError as e:                   # the C side's eligibility is the authority: fall back to T frames
+            if "padded feature rows" not in str(e):
+                raise
+    out = launch(T)
+    if right_padding:
         out = torch.nn.functional.pad(out, (0, 0, 0, right_padding))
+    return out
+
+
+def _mfcc_dct_launch(mel2: Tensor, dct: Tensor, log_mode: int, gmax: Optional[Tensor], vec_per_group: int,
+                     top_db: float) -> Tensor:
+    """(n_vec, n_mels) frame-major features -> (n_vec, n_mfcc) through aamd_mfcc_dct_f32."""
+    n_vec, n_mels = mel2.shape
+    ops = _ops()
+    if ops is not None:
+        return ops.mfcc_dct(mel2, dct, log_mode, gmax, vec_per_group, top_db)
+    out = torch.empty((n_vec, dct.shape[1]), dtype=torch.float32, device=mel2.device)
+    if out.numel():
+        L = _lib.lib()
+        _lib.check(L.aamd_mfcc_dct_f32(mel2.data_ptr(), dct.data_ptr(), out.data_ptr(), n_vec, n_mels, dct.shape[1],
+                                       log_mode, None if gmax is None else gmax.data_ptr(), vec_per_group, float(top_db),
+                                       _lib.current_stream(mel2.device)))
     return out
 
 
@@ -656,10 +769,7 @@ def _mfcc(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, dct_mat: Tenso
         mel = _melspectrogram(waveform, pad, window, fb, n_fft, hop_length, win_length, power, normalized, center,
                               pad_mode)                                  # (rows, T, n_mels) frame-major
         rows, T, n_mels = mel.shape
-        out = torch.empty((rows, T, n_mfcc), dtype=torch.float32, device=dev)
-        if out.numel():
-            _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), rows * T, n_mels, n_mfcc,
-                                           1, None, 1, -1.0, _lib.current_stream(dev)))
+        out = _mfcc_dct_launch(mel.view(rows * T, n_mels), dct, 1, None, 1, -1.0)
     else:
         # amplitude_to_DB's cut-off groups: the mel tensor is (..., C?, n_mels, T); one cut-off per
         # leading item of its (-1, C, n_mels, T) view (functional.py:393-402)
@@ -672,26 +782,16 @@ def _mfcc(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, dct_mat: Tenso
         mel = _melspectrogram(waveform, pad, window, fb, n_fft, hop_length, win_length, power, normalized, center,
                               pad_mode, db=(db[0], db[1], db[2], gmax, max(packed, 1)))
         rows, T, n_mels = mel.shape
-        out = torch.empty((rows, T, n_mfcc), dtype=torch.float32, device=dev)
         if group_max_hook is not None:
             group_max_hook(gmax)
-        if out.numel():
-            _lib.check(L.aamd_mfcc_dct_f32(mel.data_ptr(), dct.data_ptr(), out.data_ptr(), rows * T, n_mels, n_mfcc,
-                                           2, gmax.data_ptr(), max(packed, 1) * T, float(top_db),
-                                           _lib.current_stream(dev)))
+        out = _mfcc_dct_launch(mel.view(rows * T, n_mels), dct, 2, gmax, max(packed, 1) * max(T, 1), float(top_db))
     return out.view(lead + (T, n_mfcc)).transpose(-1, -2)
 
 
 def _dct_rows(x: Tensor, dct: Tensor) -> Tensor:
     """(n_vec, n_in) @ (n_in, n_out) on the MFCC path's matrix-core DCT kernel (log_mode 2 without a cut-off =
     plain product).  Used by compliance.kaldi.mfcc."""
-    n_vec, n_in = x.shape
-    out = torch.empty((n_vec, dct.shape[1]), dtype=torch.float32, device=x.device)
-    if out.numel():
-        L = _lib.lib()
-        _lib.check(L.aamd_mfcc_dct_f32(x.data_ptr(), dct.data_ptr(), out.data_ptr(), n_vec, n_in, dct.shape[1], 2, None, 1,
-                                       -1.0, _lib.current_stream(x.device)))
-    return out
+    return _mfcc_dct_launch(x, dct, 2, None, 1, -1.0)
 
 
 def mel_scale(specgram: Tensor, fb: Tensor) -> Tensor:
@@ -763,13 +863,19 @@ def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new
     """(rows, L) -> (rows, ceil(new L / orig)) through aamd_resample_banded_f32; band table cached per tensor."""
     rows, length = x2.shape
     out_len = int(math.ceil(new * length / orig))
+    # band table of the taps (host, once per kernel tensor): the matrix-core kernel skips the
+    # ~1e-20-sized window tails outside each phase tile's band
+    tap_lo, span = _tensor_cached(key_tensor, ("rs_bands", key, new),
+                                  lambda: _host.resample_band_table(kern.cpu().numpy()))
+    ops = _ops()
+    if ops is not None:
+        if x2.stride(0) != length and rows > 1:
+            x2 = x2.contiguous()
+        lo_list = _tensor_cached(key_tensor, ("rs_bands_list", key, new), lambda: [int(v) for v in tap_lo])
+        return ops.resample(x2, kern, orig, new, width, out_len, lo_list, int(span))
     out = torch.empty((rows, out_len), dtype=torch.float32, device=x2.device)
     if out.numel():
         L = _lib.lib()
-        # band table of the taps (host, once per kernel tensor): the matrix-core kernel skips the
-        # ~1e-20-sized window tails outside each phase tile's band
-        tap_lo, span = _tensor_cached(key_tensor, ("rs_bands", key, new),
-                                      lambda: _host.resample_band_table(kern.cpu().numpy()))
         bands = _lib.ResampleBands(tap_lo.shape[0], span, tap_lo.ctypes.data_as(C.POINTER(C.c_int32)))
         _lib.check(L.aamd_resample_banded_f32(x2.data_ptr(), kern.data_ptr(), out.data_ptr(), rows, length,
                                               x2.stride(0) if rows > 1 else max(length, 1), orig, new, width,
@@ -838,13 +944,12 @@ def resample(
     gcd = math.gcd(int(orig_freq), int(new_freq))
     key = ("sinc", int(orig_freq), int(new_freq), lowpass_filter_width, rolloff, resampling_method, beta,
            str(waveform.dtype), str(waveform.device))
-    if key in _CACHE:
-        kernel, width = _CACHE[key]
-    else:
-        kernel, width = _host.sinc_resample_kernel(orig_freq, new_freq, gcd, lowpass_filter_width, rolloff,
-                                                   resampling_method, beta, dtype=waveform.dtype)
-        kernel = kernel.to(waveform.device)
-        _CACHE[key] = (kernel, width)
+    def make():
+        k, w = _host.sinc_resample_kernel(orig_freq, new_freq, gcd, lowpass_filter_width, rolloff, resampling_method,
+                                          beta, dtype=waveform.dtype)
+        return k.to(waveform.device), w
+
+    kernel, width = _cached(key, make)
     return _apply_sinc_resample_kernel(waveform, orig_freq, new_freq, gcd, kernel, width)
 
 
@@ -856,6 +961,10 @@ def resample(
 def _lfilter_launch(x3: Tensor, a: Tensor, b: Tensor, clamp: bool, n_stages: int = 1) -> Tensor:
     """x3: (batch, channels, L) contiguous; a, b: (n_stages, rows, n_order)."""
     batch, channels, length = x3.shape
+    ops = _ops()
+    if ops is not None:
+        return ops.lfilter(x3, a.reshape(n_stages, -1, a.shape[-1]), b.reshape(n_stages, -1, b.shape[-1]), n_stages,
+                           bool(clamp))
     y = torch.empty_like(x3)
     if y.numel():
         L = _lib.lib()
@@ -1138,6 +1247,9 @@ def _conv_slice(x: Tensor, y: Tensor, start: int, out_len: int) -> Tensor:
         return idx.expand(lead).reshape(-1).contiguous()
 
     xmap, ymap = row_map(x, xr.shape[0]), row_map(y, yr.shape[0])
+    ops = _ops()
+    if ops is not None:
+        return ops.fftconvolve(xr, yr, xmap, ymap, rows, start, out_len).view(tuple(lead) + (out_len,))
     out = torch.empty((rows, out_len), dtype=torch.float32, device=x.device)
     if out.numel():
         L = _lib.lib()

@@ -345,6 +345,7 @@ class MelSpectrogram(torch.nn.Module):
                                  sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode, db=db)
 
     def forward(self, waveform: Tensor) -> Tensor:
+        F._reject_param_grad(window=self.spectrogram.window, fb=self.mel_scale.fb)
         if torch.is_grad_enabled() and waveform.requires_grad:
             # training mode: the same fused forward launch; backward = filterbank transpose, spectrum cotangent and
             # STFT adjoint, all HIP kernels (F._MelSpectrogramFunction)
@@ -396,6 +397,9 @@ class MFCC(torch.nn.Module):
         self.group_max_hook: Optional[Callable[[Tensor], None]] = None
 
     def forward(self, waveform: Tensor) -> Tensor:
+        F._reject_param_grad(window=self.MelSpectrogram.spectrogram.window, fb=self.MelSpectrogram.mel_scale.fb)
+        if not waveform.requires_grad:
+            F._reject_param_grad(dct_mat=self.dct_mat)     # (the differentiable path below does propagate into it)
         if torch.is_grad_enabled() and waveform.requires_grad:
             # differentiable path (reference composition, _transforms.py:692-709, on top of the
             # differentiable mel spectrogram): the dB / top_db / DCT tail is cheap and torch's autograd

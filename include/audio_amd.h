@@ -98,6 +98,16 @@ typedef struct aamd_mel_bands {
   const int32_t* lane_order;
 } aamd_mel_bands;
 
+/* Kernel-selection switches for tests and A/B measurements (never needed in production): a process-wide bit mask,
+ * initialised once from the environment variables AAMD_FORCE_GENERIC / AAMD_MEL400_WIDE / AAMD_ISTFT_ATOMIC.
+ * aamd_set_kernel_policy returns the previous mask; a negative argument only queries.  Results do not depend on the mask, only which kernel computes them. */
+enum {
+  AAMD_POLICY_FORCE_GENERIC = 1,  /* skip the shape-specialised kernels (radix-20x20, wave FFT, MFMA paths) */
+  AAMD_POLICY_MEL400_WIDE   = 2,  /* n_fft = 400 mel epilogue: 16-byte stores through an LDS stage */
+  AAMD_POLICY_ISTFT_ATOMIC  = 4   /* inverse STFT: one atomic per contribution instead of run-based overlap-add */
+};
+int         aamd_set_kernel_policy(int flags);
+
 int         aamd_abi_version(void);
 const char* aamd_last_error(void);
 /* "gfx950" when the current device is an MI355X-class part; fills name (<=63 chars). */

@@ -52,6 +52,16 @@ def test_against_reference_and_oracle(case):
     if orc is not None:
         e_orc = peak_rel_err(got, orc)
         assert e_orc <= tol, f"vs oracle: {e_orc}"
+        # SURVEY A9 asks for BOTH metrics: element-wise error relative to max(|ref|, floor x peak).  The float64
+        # oracle is the yardstick; the floor is where fp32 rounding of the LARGEST terms of a sum sits (a bin 1e-5 below
+        # the peak of its own frame carries ~1e-7 x peak of FFT rounding noise whatever computes it -- the reference's
+        # fp32 CPU path shows the same), so magnitudes use 1e-4 at a 1e-3 floor; dB / cepstral features are compared
+        # on an absolute scale already by the peak metric.
+        if case["op"] in ("Spectrogram", "MelSpectrogram", "MelScale", "F.resample", "T.Resample", "fftconvolve",
+                          "T.FFTConvolve") and not np.iscomplexobj(orc):
+            e_floor = floor_rel_err(got, orc, floor=1e-3)
+            e_floor_ref = floor_rel_err(exp, orc, floor=1e-3)
+            assert e_floor <= max(1e-4, 2.0 * e_floor_ref), f"element-wise vs oracle: {e_floor} (reference itself: {e_floor_ref})"
 
 
 def test_output_strides_match_reference():
@@ -92,7 +102,8 @@ def test_librosa_goldens_on_gpu(librosa_goldens):
         t = T.MFCC(sample_rate=16000, n_mfcc=n_mfcc, norm="ortho",
                    melkwargs={"hop_length": hop, "n_fft": n_fft, "n_mels": n_mels}).cuda()
         got = t(xw)[0].cpu().numpy()
-        np.testing.assert_allclose(got, librosa_goldens[f"mfcc_{i}"], atol=5e-3, rtol=1e-4)
+        # the reference's own tolerance for this comparison (librosa_compatibility_test_impl.py:114-134)
+        np.testing.assert_allclose(got, librosa_goldens[f"mfcc_{i}"], atol=5e-4, rtol=1e-5)
 
 
 def test_sox_golden_biquad_on_gpu(sox_goldens):
@@ -119,11 +130,7 @@ def test_mel400_fast_path_equals_generic(monkeypatch):
     for L in (401, 560, 961, 1600, 16000, 16001, 48017):
         x = torch.randn(3, L, device="cuda").clamp_(-1, 1)
         fast = t(x)
-        os.environ["AAMD_FORCE_GENERIC"] = "1"
-        try:
-            gen = t(x)
-        finally:
-            del os.environ["AAMD_FORCE_GENERIC"]
+        gen = _force_generic(lambda: t(x))
         assert fast.shape == gen.shape
         e = (fast - gen).abs().max() / gen.abs().max()
         assert float(e) <= 2e-6, (L, float(e))
@@ -175,12 +182,9 @@ def test_empty_and_error_behaviour():
 
 
 def _force_generic(fn):
-    import os
-    os.environ["AAMD_FORCE_GENERIC"] = "1"
-    try:
+    from audio_amd import _lib
+    with _lib.kernel_policy(_lib.POLICY_FORCE_GENERIC):
         return fn()
-    finally:
-        del os.environ["AAMD_FORCE_GENERIC"]
 
 
 @pytest.mark.parametrize("power", [2.0, 1.0, 0.5])

@@ -1,0 +1,218 @@
+"""Host-layer behaviour added in round 2 (VERDICT r1 "What's weak" 6-8):
+learnable window / filterbank refused loudly, plan caches thread-safe with LRU eviction, RNN-T features on shapes outside
+the radix-20x20 fast path, concurrent callers on separate streams, full-size rows against the float64 oracle, and the
+element-wise (floor-relative) error next to the peak-relative one."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import floor_rel_err, peak_rel_err
+
+
+# ------------------------------------------------------------------------------------------------------------- CPU
+
+
+def test_learnable_filterbank_window_and_dct_are_refused_loudly():
+    import audio_amd.transforms as T
+    x = torch.zeros(2, 4000)
+    m = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80)
+    m.mel_scale.fb.requires_grad_(True)
+    with pytest.raises(RuntimeError, match="`fb` requires grad"):
+        m(x)
+    m2 = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80)
+    m2.spectrogram.window.requires_grad_(True)
+    with pytest.raises(RuntimeError, match="`window` requires grad"):
+        m2(x)
+    s = T.Spectrogram(n_fft=400)
+    s.window.requires_grad_(True)
+    with pytest.raises(RuntimeError, match="`window` requires grad"):
+        s(x)
+    k = T.MFCC(sample_rate=16000, n_mfcc=13, melkwargs=dict(n_fft=400, hop_length=160, n_mels=40))
+    k.dct_mat.requires_grad_(True)
+    with pytest.raises(RuntimeError, match="`dct_mat` requires grad"):
+        k(x)
+    with torch.no_grad():                         # no autograd recording: nothing to refuse, falls through to the device check
+        with pytest.raises(RuntimeError, match="must be on an MI355X"):
+            m(x)
+
+
+def test_plan_caches_are_thread_safe_and_evict_lru():
+    import audio_amd.functional as F
+    made = []
+
+    def worker(base):
+        for i in range(400):
+            k = ("t", (base + i) % 300)
+            v = F._cached(k, lambda k=k: made.append(k) or ("v", k))
+            assert v == ("v", k)
+
+    ths = [threading.Thread(target=worker, args=(37 * j,)) for j in range(8)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert len(F._CACHE) <= F._CACHE_MAX
+    # LRU, not clear-all: the most recent keys survive a burst of new ones
+    F._cached(("keep", 0), lambda: "kept")
+    for i in range(F._CACHE_MAX - 1):
+        F._cached(("burst", i), lambda: i)
+        if i % 16 == 0:
+            assert F._cached(("keep", 0), lambda: "REBUILT") == "kept"
+    assert F._cached(("keep", 0), lambda: "REBUILT") == "kept"
+    t = torch.zeros(4)
+    a = F._tensor_cached(t, "k", lambda: object())
+    assert F._tensor_cached(t, "k", lambda: object()) is a
+    t.add_(1)                                                 # in-place mutation invalidates (version counter)
+    b = F._tensor_cached(t, "k", lambda: object())
+    assert b is not a
+    t.data = torch.ones(4)                                    # storage swap invalidates (data_ptr in the key)
+    assert F._tensor_cached(t, "k", lambda: object()) is not b
+
+
+def test_double_precision_complex_inputs_are_refused_not_downcast():
+    import audio_amd.functional as F
+    z = torch.zeros(1, 201, 10, dtype=torch.complex128)
+    with pytest.raises((TypeError, RuntimeError)):
+        F.phase_vocoder(z, 1.2, torch.zeros(201, 1))
+    with pytest.raises((TypeError, RuntimeError)):
+        F.inverse_spectrogram(z, None, 0, torch.hann_window(400), 400, 160, 400, False)
+
+
+# ------------------------------------------------------------------------------------------------------------- GPU
+
+
+def _rnnt_unfused(fe, x):
+    """The reference chain op by op on the device (pipelines/rnnt_pipeline.py:319-326)."""
+    from audio_amd.pipelines import piecewise_linear_log
+    mel = fe.mel(x).transpose(-1, -2)
+    y = piecewise_linear_log(mel * fe.gain)
+    y = (y - fe.mean) * fe.invstddev
+    return torch.nn.functional.pad(y, (0, 0, 0, fe.right_padding))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_fft,hop,length", [(400, 80, 4000), (400, 160, 400), (400, 160, 333), (400, 200, 201),
+                                              (400, 120, 1700), (512, 128, 3000), (400, 160, 4000)])
+def test_rnnt_features_outside_the_fast_path(n_fft, hop, length):
+    """RNNTFeatureExtractor raised for n_fft = 400 with another hop and for clips of <= 400 samples."""
+    from audio_amd.pipelines import RNNTFeatureExtractor
+    g = torch.Generator().manual_seed(length)
+    stats = {"mean": (torch.randn(80, generator=g) * 0.5 + 2).tolist(), "invstddev": (torch.rand(80, generator=g) + 0.5).tolist()}
+    fe = RNNTFeatureExtractor(stats, n_fft=n_fft, hop_length=hop).cuda()
+    x = (0.3 * torch.randn(3, length, generator=g)).cuda()
+    with torch.no_grad():
+        got = fe(x)
+        ref = _rnnt_unfused(fe, x)
+        pcm = (x * 32767).round().clamp(-32768, 32767).to(torch.int16)
+        got16 = fe(pcm)
+        ref16 = _rnnt_unfused(fe, pcm.float() / 32768.0)
+    assert got.shape == ref.shape and got16.shape == ref16.shape
+    # same kernels either way up to the log unit (v_log_f32 vs torch.log) amplified by invstddev <= 1.5
+    assert float((got - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+    assert float((got16 - ref16).abs().max()) <= 2e-4 * max(1.0, float(ref16.abs().max()))
+    assert float(got[:, -fe.right_padding:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_concurrent_callers_on_their_own_streams():
+    """Two host threads, each with its own stream and its own parameter sets, hammer the shared plan caches and the
+    library at the same time; every result equals the one computed alone."""
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(11)
+    x = (0.5 * torch.randn(6, 2, 12000, generator=g)).clamp_(-1, 1).cuda()
+    builders = [
+        lambda: T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80),
+        lambda: T.MelSpectrogram(sample_rate=16000, n_fft=512, hop_length=128, n_mels=64),
+        lambda: T.MFCC(sample_rate=16000, n_mfcc=20, melkwargs=dict(n_fft=400, hop_length=200, n_mels=40)),
+        lambda: T.Resample(16000, 8000),
+        lambda: T.Spectrogram(n_fft=320, hop_length=80),
+    ]
+    with torch.no_grad():
+        want = [b().cuda()(x) for b in builders]
+        want_l = F.lfilter(x, torch.tensor([1.0, -0.5], device="cuda"), torch.tensor([0.3, 0.2], device="cuda"))
+        torch.cuda.synchronize()
+        errors = []
+
+        def worker(tid):
+            try:
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    for it in range(12):
+                        order = range(len(builders)) if tid == 0 else reversed(range(len(builders)))
+                        for i in order:
+                            m = builders[i]().cuda()              # fresh module: fresh buffers -> cache inserts race
+                            y = m(x)
+                            if not torch.equal(y, want[i]):
+                                errors.append((tid, it, i))
+                        yl = F.lfilter(x, torch.tensor([1.0, -0.5], device="cuda"), torch.tensor([0.3, 0.2], device="cuda"))
+                        if not torch.equal(yl, want_l):
+                            errors.append((tid, it, "lfilter"))
+                s.synchronize()
+            except Exception as e:   # noqa: BLE001
+                errors.append((tid, repr(e)))
+
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+    assert not errors, errors[:5]
+
+
+@pytest.mark.gpu
+def test_headline_full_size_rows_against_the_oracle():
+    """BASELINE configs[1] at FULL size (256 x 160 000): rows 0, 17 and 255 of the batched launch against the float64
+    oracle (full-size parity was property-based only), peak-relative AND element-wise."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    x = (0.5 * torch.randn(256, 160000, device="cuda", generator=g)).clamp_(-1, 1)
+    mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).cuda()
+    with torch.no_grad():
+        y = mel(x)
+    assert y.shape == (256, 80, 1001)
+    fb = O.melscale_fbanks(201, 0.0, 8000.0, 80, 16000)
+    for row in (0, 17, 255):
+        want = O.mel_spectrogram(x[row].cpu().numpy().astype(np.float64), O.hann_window(400), fb, 400, 160)
+        got = y[row].cpu().numpy()
+        assert peak_rel_err(got, want) <= 2e-6, row
+        # element-wise: every mel bin of every frame, relative to max(|ref|, 1e-6 peak) -- north-star tolerance 1e-4
+        assert floor_rel_err(got, want, floor=1e-6) <= 1e-4, row
+
+
+@pytest.mark.gpu
+def test_resample_and_lfilter_full_size_rows_against_the_oracle():
+    """configs[2] / configs[4] per-GPU shards at full length, a few rows each against the float64 oracle."""
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = (0.5 * torch.randn(128, 2, 30 * 44100, device="cuda", generator=g)).clamp_(-1, 1)        # cfg3 shard
+    rs = T.Resample(44100, 16000, resampling_method="sinc_interp_kaiser", lowpass_filter_width=64,
+                    rolloff=0.9475937167399596, beta=14.769656459379492).cuda()
+    with torch.no_grad():
+        y = rs(x)
+    assert y.shape == (128, 2, 30 * 16000)
+    for (b, c) in ((0, 0), (77, 1), (127, 1)):
+        seg = x[b, c, : 3 * 44100].cpu().numpy().astype(np.float64)       # the oracle is O(N taps): first 3 s, interior compared
+        want = O.resample(seg, 44100, 16000, lowpass_filter_width=64, rolloff=0.9475937167399596,
+                          resampling_method="sinc_interp_kaiser", beta=14.769656459379492)
+        n = 2 * 16000
+        got = y[b, c, :n].cpu().numpy()
+        assert peak_rel_err(got, want[:n]) <= 1e-5, (b, c)
+    del x, y
+    x = (0.25 * torch.randn(32, 8, 480000, device="cuda", generator=g)).clamp_(-1, 1)            # cfg5 shard
+    a = torch.tensor([1.0, -1.8, 0.81], device="cuda")
+    bb = torch.tensor([0.1, 0.05, 0.02], device="cuda")
+    with torch.no_grad():
+        y = F.lfilter(x, a, bb, clamp=True)
+    import scipy.signal
+    for (b, c) in ((0, 0), (31, 7)):
+        xr = x[b, c].cpu().numpy().astype(np.float64)
+        got = y[b, c].cpu().numpy()
+        # the recursion is causal: the oracle (a python loop) checks the first 20 000 samples, scipy's float64 direct form
+        # (an independent implementation) the whole 10 s; without clamping |y| stays < 1 here, so clamp is the identity
+        n = 20000
+        want = O.lfilter(xr[None, :n], a.cpu().numpy().astype(np.float64), bb.cpu().numpy().astype(np.float64), clamp=True)[0]
+        assert peak_rel_err(got[:n], want) <= 1e-4, (b, c)
+        full = np.clip(scipy.signal.lfilter(bb.cpu().numpy().astype(np.float64), a.cpu().numpy().astype(np.float64), xr), -1, 1)
+        assert peak_rel_err(got, full) <= 1e-4, (b, c)

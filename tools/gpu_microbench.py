@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import audio_amd.functional as F
+from audio_amd import _lib
 import audio_amd.transforms as T
 
 
@@ -70,9 +71,9 @@ def main():
                     os.environ["AAMD_MEL400_VARIANT"] = v
                     us = timeit(lambda: mel(x), 10, 100)
                     print(f"mel400 var {v}: {us:9.1f} us  frac {by / us / 1e3 / 8000:.3f}", flush=True)
-            os.environ["AAMD_FORCE_GENERIC"] = "1"
+            _lib.lib().aamd_set_kernel_policy(1)
             us = timeit(lambda: mel(x), 2, 5)
-            del os.environ["AAMD_FORCE_GENERIC"]
+            _lib.lib().aamd_set_kernel_policy(0)
             print(f"mel generic : {us:9.1f} us")
         if "spec" in what:
             x = (0.5 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
@@ -80,9 +81,9 @@ def main():
             us = timeit(lambda: sp(x), 5, 50)
             by = 256 * 160000 * 4 + 256 * 1001 * 201 * 4
             print(f"spectrogram400 fast: {us:9.1f} us  {by / us / 1e3:8.1f} GB/s  frac {by / us / 1e3 / 8000:.3f}")
-            os.environ["AAMD_FORCE_GENERIC"] = "1"
+            _lib.lib().aamd_set_kernel_policy(1)
             print(f"spectrogram generic 400/160: {timeit(lambda: sp(x), 2, 5):9.1f} us")
-            del os.environ["AAMD_FORCE_GENERIC"]
+            _lib.lib().aamd_set_kernel_policy(0)
         if "mfcc" in what:
             x = (0.5 * torch.randn(512, 160000, device=dev)).clamp_(-1, 1)
             m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).to(dev)
@@ -102,9 +103,9 @@ def main():
             by = x.numel() * 4 + 128 * 2 * 480000 * 4
             print(f"resample kaiser_best 128x2x30s (MFMA): {us:9.1f} us  ({128 * 30 / (us * 1e-6):.0f} clip-s/s) "
                   f"{fl / us / 1e6:.1f} algorithmic TFLOP/s (frac {fl / us / 1e6 / 157.3:.3f})  {by / us / 1e3:.0f} GB/s")
-            os.environ["AAMD_FORCE_GENERIC"] = "1"
+            _lib.lib().aamd_set_kernel_policy(1)
             us = timeit(lambda: r(x[:16]), 1, 3)
-            del os.environ["AAMD_FORCE_GENERIC"]
+            _lib.lib().aamd_set_kernel_policy(0)
             print(f"resample kaiser_best 16x2x30s scalar kernel: {us:9.1f} us")
         if "lfilter" in what:
             x = (torch.rand(32, 8, 480000, device=dev) - 0.5)
@@ -117,9 +118,9 @@ def main():
             us = timeit(lambda: F.biquad_cascade(x, a4, b4), 2, 10)
             print(f"4-biquad cascade fused 32x8x10s@48k (cfg5a shard): {us:9.1f} us  {2 * x.numel() * 4 / us / 1e3:.1f} GB/s "
                   f"(frac {2 * x.numel() * 4 / us / 1e3 / 8000:.3f})")
-            os.environ["AAMD_FORCE_GENERIC"] = "1"
+            _lib.lib().aamd_set_kernel_policy(1)
             us = timeit(lambda: F.biquad_cascade(x, a4, b4), 1, 3)
-            del os.environ["AAMD_FORCE_GENERIC"]
+            _lib.lib().aamd_set_kernel_policy(0)
             print(f"  same, workgroup-scan kernel: {us:9.1f} us")
         if "fftconv" in what:
             x = torch.rand(32, 8, 480000, device=dev) - 0.5                       # cfg5b per-GPU shard (1/8)
@@ -130,9 +131,9 @@ def main():
                   f"algorithmic {by / us / 1e3:.0f} GB/s (frac {by / us / 1e3 / 8000:.3f})")
             x1, y1 = torch.randn(4, 8, 48000, device=dev), torch.randn(1, 1, 2400, device=dev)
             print(f"fftconvolve 4x8x1s * 2400 taps: {timeit(lambda: F.fftconvolve(x1, y1), 1, 3):9.1f} us")
-            os.environ["AAMD_FORCE_GENERIC"] = "1"
+            _lib.lib().aamd_set_kernel_policy(1)
             print(f"  same, time-domain kernel: {timeit(lambda: F.fftconvolve(x1, y1), 1, 3):9.1f} us")
-            del os.environ["AAMD_FORCE_GENERIC"]
+            _lib.lib().aamd_set_kernel_policy(0)
     if "standalone" in what:
         x = (0.5 * torch.randn(256, 160000, device=dev)).clamp_(-1, 1)
         with torch.no_grad():
