@@ -30,6 +30,7 @@ class MelBands(C.Structure):
     _fields_ = [
         ("n_mels", C.c_int32), ("max_width", C.c_int32),
         ("lo", C.c_void_p), ("width", C.c_void_p), ("weights", C.c_void_p), ("lane_order", C.c_void_p),
+        ("table400", C.c_void_p),
     ]
 
 
@@ -62,6 +63,8 @@ _SIGS = {
     "aamd_abi_version": (C.c_int, []),
     "aamd_last_error": (C.c_char_p, []),
     "aamd_set_kernel_policy": (C.c_int, [C.c_int]),
+    "aamd_mel400_table_dwords": (C.c_int64, [C.c_int32, C.c_int32]),
+    "aamd_mel400_table_build": (C.c_int, [C.POINTER(MelBands), _P, _P]),
     "aamd_device_info": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "aamd_spectrogram_f32": (C.c_int, [_P, _P, _P, _P, C.POINTER(StftDesc), _P]),
     "aamd_melspectrogram_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), _P]),
@@ -114,7 +117,7 @@ def lib():
                 fn = getattr(h, name)   # AttributeError if the ABI symbol is missing
                 fn.restype = res
                 fn.argtypes = args
-            if h.aamd_abi_version() != 2:
+            if h.aamd_abi_version() != 3:
                 raise RuntimeError("audio_amd: ABI version mismatch between _lib.py and libaudio_amd.so")
             _lib = h
     return _lib

@@ -166,6 +166,7 @@ int validate_bands(const aamd_mel_bands* b, int n_freq, MelBandsDev& mb) {
   AAMD_CHECK_ARG(b->lo && b->width && b->weights, "null mel band pointers");
   mb.n_mels = b->n_mels; mb.max_width = b->max_width;
   mb.lo = b->lo; mb.width = b->width; mb.weights = b->weights; mb.order = b->lane_order;
+  mb.table400 = b->table400;
   return AAMD_OK;
 }
 
@@ -321,6 +322,25 @@ int aamd_set_kernel_policy(int flags) {
 }
 
 const char* aamd_last_error(void) { return g_err.c_str(); }
+
+int64_t aamd_mel400_table_dwords(int32_t n_mels, int32_t max_width) {
+  if (n_mels < 1 || max_width < 1) return 0;
+  if (m400::mel_ws(max_width) > m400::kMelMaxTaps + 4 || m400::mel_rounds(n_mels) > m400::kMelMaxRounds) return 0;
+  return m400::mel_tab_dwords(n_mels, max_width);
+}
+
+int aamd_mel400_table_build(const aamd_mel_bands* bands, float* table_out, void* stream) {
+  DeviceScope dev_scope_(table_out);
+  MelBandsDev mb{};
+  int rc = validate_bands(bands, 201, mb);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(table_out != nullptr, "null table buffer");
+  if (aamd_mel400_table_dwords(mb.n_mels, mb.max_width) == 0)
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: filterbank outside the radix-20x20 kernel (n_mels > 160 or band > 62 bins)");
+  mb.table400 = nullptr;
+  hipLaunchKernelGGL(m400::mel_tab_build_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mb, table_out);
+  return launch_check();
+}
 
 int aamd_device_info(char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes) {
   int dev = 0;

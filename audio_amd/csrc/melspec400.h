@@ -168,6 +168,19 @@ AAMD_HD int row_to_mel(const MelBandsDev& mb, int row) {
   return (m >= 0 && m < mb.n_mels) ? m : -1;
 }
 
+// pointers of the table image that starts at `base` (no memory access)
+AAMD_HD void mel_tab_layout(const MelBandsDev& mb, float* base, MelTab& mt) {
+  mt.n_mels = mb.n_mels;
+  mt.ws = mel_ws(mb.max_width);
+  mt.n_rounds = mel_rounds(mb.n_mels);
+  const int rows = mel_rows(mb.n_mels);
+  mt.w = base;
+  int* lo2 = reinterpret_cast<int*>(base + rows * mt.ws);
+  mt.lo2 = lo2;
+  mt.row_mel = lo2 + rows;
+  mt.rc = lo2 + 2 * rows;
+}
+
 // phase 1 (then a workgroup barrier): per-round chunk counts; phase 2: weights and band starts
 AAMD_HD void mel_tab_rounds(int tid, int nthr, const MelBandsDev& mb, float* base, MelTab& mt) {
   mt.n_mels = mb.n_mels;
@@ -737,6 +750,14 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
+// One workgroup lays out the band table image in global memory (once per filterbank; aamd_mel400_table_build).
+__global__ void __launch_bounds__(256) mel_tab_build_kernel(MelBandsDev mb, float* __restrict__ out) {
+  MelTab mt{};
+  mel_tab_rounds(threadIdx.x, blockDim.x, mb, out, mt);
+  __syncthreads();   // the chunk counts written above are read below by other threads of this workgroup
+  mel_tab_fill(threadIdx.x, blockDim.x, mb, out, mt);
+}
+
 template <int LAB, int EPI, int H = 8, typename TIn = float>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, AAMD_M400_MINWAVES)
 melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
@@ -757,14 +778,23 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   float* const_tab = smem400 + kWavesPerBlock * HC::lds_dwords;
   const_tab_build(threadIdx.x, blockDim.x, window, tw400, scale, const_tab);
   MelTab mt{};
-  if (EPI != EPI400_SPEC) mel_tab_rounds(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
-  // tile queue of this workgroup: the next unclaimed tile (waves start on tiles 0 .. W-1)
   const int tab_dwords = (EPI != EPI400_SPEC) ? mel_tab_dwords(mb.n_mels, mb.max_width) : 0;
+  // tile queue of this workgroup: the next unclaimed tile (waves start on tiles 0 .. W-1)
   int* queue = reinterpret_cast<int*>(const_tab + kConstDwords + tab_dwords);
   if (threadIdx.x == 0) *queue = kWavesPerBlock;
-  __syncthreads();
-  if (EPI != EPI400_SPEC) mel_tab_fill(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
-  __syncthreads();
+  if (EPI != EPI400_SPEC && mb.table400 != nullptr) {
+    // the band table was laid out once per filterbank (mel_tab_build_kernel): one round of independent loads here
+    // instead of the three dependent ones (lane order -> band start -> weight) of the in-kernel build
+    float* dst = const_tab + kConstDwords;
+    for (int i = threadIdx.x; i < tab_dwords; i += blockDim.x) dst[i] = mb.table400[i];
+    mel_tab_layout(mb, dst, mt);
+    __syncthreads();
+  } else {
+    if (EPI != EPI400_SPEC) mel_tab_rounds(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
+    __syncthreads();
+    if (EPI != EPI400_SPEC) mel_tab_fill(threadIdx.x, blockDim.x, mb, const_tab + kConstDwords, mt);
+    __syncthreads();
+  }
 
   long long lab_t1 = 0;
   if (LAB & 1024) lab_t1 = wall_clock64();

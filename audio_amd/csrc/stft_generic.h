@@ -33,6 +33,7 @@ struct MelBandsDev {
   const int32_t* width;
   const float* weights;
   const int32_t* order;   // mel400 only: table row -> mel (lane assignment), -1 = unused row; null = identity
+  const float* table400;  // mel400 only: prebuilt LDS image of the band table (m400::mel_tab_dwords dwords), or null
 };
 
 // ---- geometry of one workgroup: PB frame PAIRS (2 PB consecutive frames of one waveform) ------------

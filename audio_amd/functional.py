@@ -172,7 +172,18 @@ class MelBandsOnDevice:
         self.lane_order = torch.from_numpy(_host.mel_lane_order(lo, width)).to(device) if use_order else None
         self.struct = _lib.MelBands(self.n_mels, max_width, self.lo.data_ptr(), self.width.data_ptr(),
                                     self.weights.data_ptr(),
-                                    self.lane_order.data_ptr() if self.lane_order is not None else None)
+                                    self.lane_order.data_ptr() if self.lane_order is not None else None, None)
+        # the radix-20x20 kernel's LDS image of the table, laid out once per filterbank (aamd_mel400_table_build)
+        self.table400 = None
+        if self.n_freq == 201 and self.lo.is_cuda:
+            L = _lib.lib()
+            n = L.aamd_mel400_table_dwords(self.n_mels, max_width)
+            if n > 0:
+                self.table400 = torch.zeros(n, dtype=torch.float32, device=device)
+                with torch.cuda.device(device):
+                    _lib.check(L.aamd_mel400_table_build(C.byref(self.struct), self.table400.data_ptr(),
+                                                         _lib.current_stream(device)))
+                self.struct.table400 = self.table400.data_ptr()
 
 
 def _mel_bands(fb: Tensor, device) -> MelBandsOnDevice:
@@ -652,7 +663,7 @@ def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_ff
     ops = _ops()
     if ops is not None:
         targs = (x2, _padded_window(window, n_fft), _twiddles(n_fft, waveform.device), bands.lo, bands.width,
-                 bands.weights, bands.lane_order, n_fft, hop_length, pad, bool(center), desc.pad_mode, desc.n_frames,
+                 bands.weights, bands.lane_order, bands.table400, n_fft, hop_length, pad, bool(center), desc.pad_mode, desc.n_frames,
                  desc.scale, desc.power)
         if db is None:
             return ops.mel_spectrogram(*targs)

@@ -104,6 +104,41 @@ def pmc_child():
     torch.cuda.synchronize()
 
 
+def selftest_cpu(args, world, rank, launched):
+    """The multi-process plumbing of main() with gloo and a CPU stand-in for the step (no product code involved)."""
+    import torch
+    dist = None
+    ranks = 1
+    if launched:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        ranks = int(one.item())
+        assert ranks == world
+    x = torch.randn(4, 16000)
+    w = torch.hann_window(N_FFT)
+    for _ in range(args.warmup):
+        torch.stft(x, N_FFT, HOP, window=w, return_complex=True)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        torch.stft(x, N_FFT, HOP, window=w, return_complex=True)
+    if dist is not None:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "selftest (CPU plumbing only, not a measurement)", "value": 0.0, "unit": "none",
+                          "n_gpus": world, "rccl_ranks": ranks, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": float(t.item()) / max(args.steps, 1) * 1e3, "data": "selftest"}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -122,6 +157,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="plumbing self-test WITHOUT GPUs (tests/test_bench_cli.py): same launch / rendezvous / barrier / "
+                         "MAX-reduce / JSON path over gloo, the step replaced by a tiny CPU STFT; the line says "
+                         "data=selftest and is never a measurement")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child()
@@ -144,6 +183,8 @@ def main():
                  "number for a different GPU count than asked for")
 
     import torch
+    if args.selftest_cpu:
+        return selftest_cpu(args, world, rank, launched)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     assert torch.cuda.device_count() > local_rank, \
         f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPUs visible"

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define AAMD_ABI_VERSION 2
+#define AAMD_ABI_VERSION 3
 
 enum {
   AAMD_OK = 0,
@@ -96,7 +96,18 @@ typedef struct aamd_mel_bands {
    * (every mel exactly once, -1 = unused).  Results do not depend on it; it only decides which
    * LDS banks the band reads of a wavefront hit (audio_amd/_host.py: mel_lane_order). */
   const int32_t* lane_order;
+  /* Optional (may be NULL): the radix-20x20 kernel's band table laid out once per filterbank by
+   * aamd_mel400_table_build (device float[aamd_mel400_table_dwords(n_mels, max_width)]).  With it every workgroup of a
+   * launch copies the table into LDS with one round of loads; without it each workgroup derives it from lo / width /
+   * weights / lane_order (three dependent rounds, ~3 us per launch).  Results are identical. */
+  const float* table400;
 } aamd_mel_bands;
+
+/* Size (in 4-byte words) of the prebuilt band table for a filterbank, 0 if the filterbank is outside what the
+ * radix-20x20 kernel serves (more than 160 mels or a band wider than 62 bins). */
+int64_t aamd_mel400_table_dwords(int32_t n_mels, int32_t max_width);
+/* Lay the table out (one small launch; once per filterbank and lane order, not per call).  bands->table400 is ignored. */
+int aamd_mel400_table_build(const aamd_mel_bands* bands, float* table_out, void* stream);
 
 /* Kernel-selection switches for tests and A/B measurements (never needed in production): a process-wide bit mask,
  * initialised once from the environment variables AAMD_FORCE_GENERIC / AAMD_MEL400_WIDE / AAMD_ISTFT_ATOMIC.

@@ -1,0 +1,52 @@
+"""bench.py's launch contract (`--gpus` was parsed and ignored).  No GPU here: --selftest-cpu runs the
+same self-spawn / rendezvous / barrier / MAX-reduce / one-JSON-line path over gloo with a CPU stand-in for the step."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=240):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True,
+                          timeout=timeout, cwd=ROOT)
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def test_gpus_2_self_spawns_two_ranks_and_reports_n_gpus_2():
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout                      # exactly one JSON line, from rank 0
+    assert lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2 and lines[0]["steps"] == 3
+
+
+def test_under_the_drivers_own_torchrun_launch():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--selftest-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+
+
+def test_world_size_that_disagrees_with_gpus_is_an_error_not_n_gpus_1():
+    r = _run(["--gpus", "1", "--selftest-cpu"], env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    assert not _json_lines(r.stdout)
+
+
+def test_default_invocation_is_one_rank():
+    r = _run(["--steps", "2", "--warmup", "1", "--selftest-cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1

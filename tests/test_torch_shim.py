@@ -16,7 +16,7 @@ SCHEMAS = {
     "spectrogram": "aamd::spectrogram(Tensor wav, Tensor window, Tensor twiddle, int n_fft, int hop, int pad, bool center, "
                    "int pad_mode, bool onesided, int n_frames, float scale, float power) -> Tensor",
     "mel_spectrogram": "aamd::mel_spectrogram(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, "
-                       "Tensor band_weights, Tensor? lane_order, int n_fft, int hop, int pad, bool center, int pad_mode, "
+                       "Tensor band_weights, Tensor? lane_order, Tensor? table400, int n_fft, int hop, int pad, bool center, int pad_mode, "
                        "int n_frames, float scale, float power) -> Tensor",
     "mfcc_dct": "aamd::mfcc_dct(Tensor mel, Tensor dct_mat, int log_mode, Tensor? group_max, int vec_per_group, "
                 "float top_db) -> Tensor",
