@@ -236,9 +236,23 @@ bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
          m400::mel_rounds(mb.n_mels) <= m400::kMelMaxRounds;
 }
 
+template <int EPI, int H, typename TIn, int NR>
+int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, const float* window,
+                     const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s);
+
+// NR = 4 (n_mels <= 80: band-table control words in registers) or 8 (up to 160 mels); the spectrogram epilogue has
+// no mel phase and uses one instantiation
 template <int EPI, int H, typename TIn = float>
 int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, const float* window,
                     const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s) {
+  if (EPI != m400::EPI400_SPEC && m400::mel_rounds(mb.n_mels) <= 4)
+    return launch_fft400_nr<EPI, H, TIn, 4>(g, mb, wav, window, twiddle, out, epi, s);
+  return launch_fft400_nr<EPI, H, TIn, m400::kMelMaxRounds>(g, mb, wav, window, twiddle, out, epi, s);
+}
+
+template <int EPI, int H, typename TIn, int NR>
+int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, const float* window,
+                     const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
   const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
   const int64_t n_tiles = g.rows * tiles_per_row;
@@ -248,7 +262,7 @@ int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, co
   const size_t lds = (EPI == m400::EPI400_SPEC) ? m400::lds_bytes(0, 1, wdw) : m400::lds_bytes(mb.n_mels, mb.max_width, wdw);
   if (lds > dev_props().lds_per_block_optin)
     return fail(AAMD_EUNSUPPORTED, "audio_amd: mel filterbank too large for the LDS of this device");
-  auto kern = m400::melspec400_kernel<0, EPI, H, TIn>;
+  auto kern = m400::melspec400_kernel<0, EPI, H, TIn, NR>;
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -46,7 +46,18 @@ constexpr int kFramesPerWave = 6;
 constexpr int kWavesPerBlock = AAMD_M400_WAVES;              // 768 threads = 3 waves per SIMD: ONE block per CU (a second block of a
                                                // smaller size is not admitted: its waves land on the same SIMDs)
 // LDS strides picked with tools/lds_conflicts.py (bank model of MI355X_MICROARCH.md):
-constexpr int kTRow = 44;                      // dwords per transposition row: 20 complex + pad, 16-B aligned
+// Transposition buffer, round-2 layout: one ROW per transposed value and one COLUMN per writer lane.
+//   row (s, re) at dword kTOff[s], row (s, im) at kTOff[s] + 64; element of writer lane l at row + l.
+// A wave writes a value with ds_write_addtid_b32 (LDS address = M0 + offset + 4 * lane: no address VGPR, 2 LDS cycles per
+// wave-instruction against 6 for the ds_write_b64 of the first layout: 80 instead of 120 cycles per tile), and the reader
+// lane (pair p, column c) fetches the 20 values of its column from lanes 20 p .. 20 p + 19 as 5 + 5 ds_read_b128 at
+// kTOff[c] + 20 p (+ 64).  The row starts are 64 * rank + 4 * a(c) with slots a(c) found by tools/lds_conflicts.py-style
+// search so that every b128 read of a wave touches 16 distinct 4-bank slots in each of its lane groups (40 cycles for
+// the 10 reads = the conflict-free minimum; a uniform row stride cannot do better than 90).
+constexpr int kTOff[20] = {0, 260, 520, 652, 784, 916, 1444, 1576, 128, 388,
+                           2104, 2232, 2364, 1708, 1840, 1048, 1180, 1312, 1972, 2492};
+constexpr int kTBufDwords = 2492 + 128;        // 2620
+constexpr int kTRow = 44;                      // (first layout; still sizes the wave's region: 3 * 20 * 44 = 2640 >= 2620)
                                                // rows -> conflict-free ds_read_b128; column writes 6 array
                                                // cycles = the ds_write_b64 issue cost
 constexpr int kTPair = 20 * kTRow;             // 880 dwords per pair
@@ -105,6 +116,7 @@ constexpr int kMelMaxRounds = 8;               // n_mels <= 160
 constexpr int kMelMaxTaps = 64;                // widest padded band (taps)
 
 static_assert(3 * kPPair <= kLdsDwordsPerWave && 2 * kPK <= kPPair, "P rows must fit in the transposition buffer");
+static_assert(kTBufDwords <= kLdsDwordsPerWave, "transposition rows must fit in the wave's region");
 static_assert(3 * (kPK - 201) <= 64, "one lane per tail bin");
 static_assert(Hop<8>::lds_dwords == kLdsDwordsPerWave && Hop<8>::ndma == 5 && Hop<8>::pad == 20, "headline geometry");
 
@@ -256,6 +268,7 @@ struct LaneConst {
   const float* win;        // this lane's window row
   int p, pi, col;          // pair 0..2, position in the 20-lane group, pass-2 column
   int active;              // lanes 60..63 shadow lanes 40..43 but never store
+  int troff;               // kTOff[col] + 20 p: where this lane's column starts in the transposition buffer (dwords)
 };
 
 AAMD_HD void lane_init(int lane, const float* const_tab, LaneConst& c) {
@@ -266,6 +279,10 @@ AAMD_HD void lane_init(int lane, const float* const_tab, LaneConst& c) {
   c.col = col_of_pos(c.pi);
   c.tw = const_tab + kTwRow * c.pi;
   c.win = const_tab + 20 * kTwRow + 20 * c.pi;
+  int toff = 0;
+#pragma unroll
+  for (int k = 0; k < 20; ++k) toff = (c.col == k) ? kTOff[k] : toff;   // once per launch: selects, no table in memory
+  c.troff = toff + 20 * c.p;
 }
 
 // ---- in-register DFT-20, forward (e^{-2 pi i nk/20}), natural order in and out -----------
@@ -371,29 +388,99 @@ AAMD_HD void gather_global(const LaneConst& c, const TIn* wav_row, int64_t lengt
 
 // DFT-20 over q of the lane's 20 complex inputs, twiddle by W400^(b s), transposed write (shared by the forward
 // kernel and the inverse / adjoint kernel of istft400.h, whose inputs are spectrum bins instead of windowed samples)
+#if defined(__HIP_DEVICE_COMPILE__)
+// five transposed complex values (columns S0 .. S0 + 4) of every lane -> their rows; M0 = LDS byte address of the
+// wave's region for the duration (saved / restored: the compiler treats M0 as reserved)
+template <int S0>
+__device__ __forceinline__ void tr_store5(unsigned lds_base, const float (&wr)[5], const float (&wi)[5]) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %[k], m0\n\t"
+      "s_mov_b32 m0, %[b]\n\t"
+      "s_nop 0\n\t"
+      "ds_write_addtid_b32 %[r0] offset:%[o0]\n\t"
+      "ds_write_addtid_b32 %[i0] offset:%[q0]\n\t"
+      "ds_write_addtid_b32 %[r1] offset:%[o1]\n\t"
+      "ds_write_addtid_b32 %[i1] offset:%[q1]\n\t"
+      "ds_write_addtid_b32 %[r2] offset:%[o2]\n\t"
+      "ds_write_addtid_b32 %[i2] offset:%[q2]\n\t"
+      "ds_write_addtid_b32 %[r3] offset:%[o3]\n\t"
+      "ds_write_addtid_b32 %[i3] offset:%[q3]\n\t"
+      "ds_write_addtid_b32 %[r4] offset:%[o4]\n\t"
+      "ds_write_addtid_b32 %[i4] offset:%[q4]\n\t"
+      "s_mov_b32 m0, %[k]"
+      : [k] "=&s"(keep)
+      : [b] "s"(lds_base), [r0] "v"(wr[0]), [i0] "v"(wi[0]), [r1] "v"(wr[1]), [i1] "v"(wi[1]), [r2] "v"(wr[2]),
+        [i2] "v"(wi[2]), [r3] "v"(wr[3]), [i3] "v"(wi[3]), [r4] "v"(wr[4]), [i4] "v"(wi[4]),
+        [o0] "i"(4 * kTOff[S0]), [q0] "i"(4 * kTOff[S0] + 256), [o1] "i"(4 * kTOff[S0 + 1]), [q1] "i"(4 * kTOff[S0 + 1] + 256),
+        [o2] "i"(4 * kTOff[S0 + 2]), [q2] "i"(4 * kTOff[S0 + 2] + 256), [o3] "i"(4 * kTOff[S0 + 3]),
+        [q3] "i"(4 * kTOff[S0 + 3] + 256), [o4] "i"(4 * kTOff[S0 + 4]), [q4] "i"(4 * kTOff[S0 + 4] + 256)
+      : "memory");
+}
+#endif
+
+// DFT-20 over q of the lane's 20 complex inputs, twiddle by W400^(b s), transposed write (shared by the forward
+// kernel and the inverse / adjoint kernel of istft400.h, whose inputs are spectrum bins instead of windowed samples)
 template <bool TREG = false>
-AAMD_HD void phase_a_core(const LaneConst& c, const float (&xr)[20], const float (&xi)[20], float* lds,
+AAMD_HD void phase_a_core(const LaneConst& c, const float (&xr)[20], const float (&xi)[20], float* __restrict__ lds,
                           const float* twr = nullptr) {
+  // The twiddle table and the transposition rows live in the same LDS array but never overlap.  The reads of batch
+  // k + 1 are issued BEFORE the multiplies and row writes of batch k (the row writes are asm volatile with a memory
+  // clobber, which nothing can be hoisted across), and batch 0's before the DFT: one LDS round trip per tile is
+  // exposed here instead of ten in the first version (round-2 ISA review: read -> wait -> multiply -> write, ten times).
+  // Batches of five columns (10 VGPRs, double buffered) keep this inside the 168-register budget of 3 waves per SIMD.
+  const float* __restrict__ twp = c.tw;
+  float twn[10];
+  auto tw_load = [&](int blk) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const F2 t = *reinterpret_cast<const F2*>(twp + 2 * (5 * blk + j));   // 8-byte aligned (row start is 16-B aligned)
+      twn[2 * j] = t.x;
+      twn[2 * j + 1] = t.y;
+    }
+  };
+  if (!TREG) tw_load(0);
   float yr[20], yi[20];
   dft20(xr, xi, yr, yi);
-  float* colp = lds + kTPair * c.p + 2 * c.pi;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;      // wave-uniform LDS byte address
+#endif
 #pragma unroll
-  for (int s2 = 0; s2 < 10; ++s2) {
-    F4 t;
-    if (TREG) { t.x = twr[4 * s2]; t.y = twr[4 * s2 + 1]; t.z = twr[4 * s2 + 2]; t.w = twr[4 * s2 + 3]; }
-    else t = *reinterpret_cast<const F4*>(c.tw + 4 * s2);   // W^(b * 2 s2), W^(b * (2 s2 + 1))
-    const int s = 2 * s2;
-    float v0r = yr[s], v0i = yi[s];
-    if (s != 0) {
-      v0r = yr[s] * t.x - yi[s] * t.y;
-      v0i = yr[s] * t.y + yi[s] * t.x;
+  for (int blk = 0; blk < 4; ++blk) {
+    float tw[10];      // W^(b s) for s = 5 blk .. 5 blk + 4 as (re, im) pairs
+    if (!TREG) {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) tw[j] = twn[j];
+      if (blk < 3) tw_load(blk + 1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) tw[j] = twr[10 * blk + j];
     }
-    const float v1r = yr[s + 1] * t.z - yi[s + 1] * t.w;
-    const float v1i = yr[s + 1] * t.w + yi[s + 1] * t.z;
-    if (c.active) {
-      *reinterpret_cast<F2*>(colp + kTRow * pos_of_col(s)) = F2{v0r, v0i};
-      *reinterpret_cast<F2*>(colp + kTRow * pos_of_col(s + 1)) = F2{v1r, v1i};
+    float wr[5], wi[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int s = 5 * blk + j;
+      if (s == 0) {
+        wr[j] = yr[0];
+        wi[j] = yi[0];
+      } else {
+        wr[j] = yr[s] * tw[2 * j] - yi[s] * tw[2 * j + 1];
+        wi[j] = yr[s] * tw[2 * j + 1] + yi[s] * tw[2 * j];
+      }
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (blk == 0) tr_store5<0>(lds_base, wr, wi);
+    else if (blk == 1) tr_store5<5>(lds_base, wr, wi);
+    else if (blk == 2) tr_store5<10>(lds_base, wr, wi);
+    else tr_store5<15>(lds_base, wr, wi);
+#else
+    const int l = 20 * c.p + c.pi;       // CPU replay: lanes 60..63 rewrite what lanes 40..43 wrote (same values)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      lds[kTOff[5 * blk + j] + l] = wr[j];
+      lds[kTOff[5 * blk + j] + 64 + l] = wi[j];
+    }
+#endif
   }
 }
 
@@ -425,14 +512,13 @@ AAMD_HD void phase_a(const LaneConst& c, const float (&X)[Hop<H>::nx], float* ld
 
 // ---- phase B1: read own row (then DFT-20 over b  ->  Z[col + 20 d] in registers) ----------
 AAMD_HD void phase_b1_load(const LaneConst& c, const float* lds, float (&vr)[20], float (&vi)[20]) {
-  const float* row = lds + kTPair * c.p + kTRow * c.pi;
+  const float* col = lds + c.troff;      // row (column c, re) at the pair's 20 writer lanes; (c, im) 64 dwords on
 #pragma unroll
-  for (int j = 0; j < 10; ++j) {
-    const F4 v = *reinterpret_cast<const F4*>(row + 4 * j);
-    vr[2 * j] = v.x;
-    vi[2 * j] = v.y;
-    vr[2 * j + 1] = v.z;
-    vi[2 * j + 1] = v.w;
+  for (int j = 0; j < 5; ++j) {
+    const F4 r = *reinterpret_cast<const F4*>(col + 4 * j);
+    const F4 i = *reinterpret_cast<const F4*>(col + 64 + 4 * j);
+    vr[4 * j] = r.x; vr[4 * j + 1] = r.y; vr[4 * j + 2] = r.z; vr[4 * j + 3] = r.w;
+    vi[4 * j] = i.x; vi[4 * j + 1] = i.y; vi[4 * j + 2] = i.z; vi[4 * j + 3] = i.w;
   }
 }
 
@@ -605,17 +691,47 @@ AAMD_HD void mel_chunks(const float* wt, const float* P, float& sa, float& sb) {
   }
 }
 
-AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
-                     float (&acc_a)[kMelMaxRounds], float (&acc_b)[kMelMaxRounds]) {
-  const float* Pp = lds + kPPair * c.p;
+// Per-lane copies of the table's control words, read ONCE per launch (round-2 ISA review: per round and tile the kernel
+// re-read chunk count, band start and mel index from LDS and waited for each -- 12 dependent LDS round trips per tile):
+//   nc[r]   chunks of round r (wave-uniform, an SGPR)      poff[r]  dword offset of the lane's band start in a P row pair
+//   mel[r]  the mel the lane evaluates in round r, -1 = none
+template <int NR>
+struct MelRegs {
+  int nc[NR];     // wave-uniform
+  int pm[NR];     // poff | (mel & 0xffff) << 16: one VGPR per round (the 168-register budget of 3 waves/SIMD is tight)
+  AAMD_HD int poff(int r) const { return pm[r] & 0xffff; }
+  AAMD_HD int mel(int r) const { return pm[r] >> 16; }      // arithmetic shift: 0xffff.... -> -1
+};
+
+template <int NR>
+AAMD_HD void mel_regs_load(const LaneConst& c, const MelTab& mt, MelRegs<NR>& h) {
 #pragma unroll
-  for (int r = 0; r < kMelMaxRounds; ++r) {
+  for (int r = 0; r < NR; ++r) {
+    const bool on = r < mt.n_rounds;
+    const int row = r * kMelSlots + c.pi;
+#if defined(__HIP_DEVICE_COMPILE__)
+    h.nc[r] = on ? __builtin_amdgcn_readfirstlane(mt.rc[r]) : 0;
+#else
+    h.nc[r] = on ? mt.rc[r] : 0;
+#endif
+    const int poff = on ? 2 * mt.lo2[row] : 0;
+    const int mel = on ? mt.row_mel[row] : -1;
+    h.pm[r] = (int)(((unsigned)mel << 16) | (unsigned)poff);
+  }
+}
+
+template <int NR = kMelMaxRounds>
+AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
+                     float (&acc_a)[NR], float (&acc_b)[NR], const MelRegs<NR>* h = nullptr) {
+  const float* Pp = lds + kPPair * c.p;
+  const float* wt0 = mt.w + c.pi * mt.ws;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
     float sa = 0.0f, sb = 0.0f;
     if (r < mt.n_rounds) {
-      const int row = r * kMelSlots + c.pi;
-      const float* wt = mt.w + row * mt.ws;
-      const float* P = Pp + 2 * mt.lo2[row];
-      const int nc = mt.rc[r];
+      const float* wt = wt0 + r * kMelSlots * mt.ws;
+      const float* P = Pp + (h ? h->poff(r) : 2 * mt.lo2[r * kMelSlots + c.pi]);
+      const int nc = h ? h->nc[r] : mt.rc[r];
       switch (nc) {
         case 1: mel_chunks<1>(wt, P, sa, sb); break;
         case 2: mel_chunks<2>(wt, P, sa, sb); break;
@@ -633,16 +749,18 @@ AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
 // narrow store path (any n_mels / alignment): 4-byte stores straight from the accumulators
 //   Addressing: ONE wave-uniform tile pointer (SGPRs) + a small per-lane 32-bit offset, so every
 //   store is `global_store_dword voffset, data, s[base]` with one v_add -- no per-lane 64-bit pointers.
-AAMD_HD void store_direct(const LaneConst& c, const MelTab& mt, const float (&acc_a)[kMelMaxRounds],
-                          const float (&acc_b)[kMelMaxRounds], float* out_row, int64_t t0, int n_frames) {
+template <int NR = kMelMaxRounds>
+AAMD_HD void store_direct(const LaneConst& c, const MelTab& mt, const float (&acc_a)[NR],
+                          const float (&acc_b)[NR], float* out_row, int64_t t0, int n_frames,
+                          const MelRegs<NR>* h = nullptr) {
   const int left = (int)(n_frames - t0);               // frames of this tile inside the clip (wave-uniform)
   const bool va = c.active && 2 * c.p < left, vb = c.active && 2 * c.p + 1 < left;
   float* out_tile = out_row + t0 * (int64_t)mt.n_mels;   // wave-uniform
   const unsigned oa = 2u * (unsigned)c.p * (unsigned)mt.n_mels;
 #pragma unroll
-  for (int r = 0; r < kMelMaxRounds; ++r) {
+  for (int r = 0; r < NR; ++r) {
     if (r < mt.n_rounds) {
-      const int m = mt.row_mel[r * kMelSlots + c.pi];
+      const int m = h ? h->mel(r) : mt.row_mel[r * kMelSlots + c.pi];
       if (m >= 0) {
         if (va) out_tile[oa + (unsigned)m] = acc_a[r];
         if (vb) out_tile[oa + (unsigned)mt.n_mels + (unsigned)m] = acc_b[r];
@@ -653,14 +771,15 @@ AAMD_HD void store_direct(const LaneConst& c, const MelTab& mt, const float (&ac
 
 // wide store path (n_mels % 4 == 0, 16-B aligned output): the tile's 6 x n_mels outputs are
 // contiguous in memory; stage them in LDS (over the dead P rows) and write 16 B per lane.
-AAMD_HD void store_stage(const LaneConst& c, const MelTab& mt, const float (&acc_a)[kMelMaxRounds],
-                         const float (&acc_b)[kMelMaxRounds], float* lds) {
+template <int NR = kMelMaxRounds>
+AAMD_HD void store_stage(const LaneConst& c, const MelTab& mt, const float (&acc_a)[NR],
+                         const float (&acc_b)[NR], float* lds, const MelRegs<NR>* h = nullptr) {
   if (!c.active) return;
   float* oa = lds + 2 * c.p * mt.n_mels;
 #pragma unroll
-  for (int r = 0; r < kMelMaxRounds; ++r) {
+  for (int r = 0; r < NR; ++r) {
     if (r < mt.n_rounds) {
-      const int m = mt.row_mel[r * kMelSlots + c.pi];
+      const int m = h ? h->mel(r) : mt.row_mel[r * kMelSlots + c.pi];
       if (m >= 0) {
         oa[m] = acc_a[r];
         oa[mt.n_mels + m] = acc_b[r];
@@ -744,6 +863,10 @@ struct TileInfo {
 // LAB != 0 builds profiling variants for tools/ubench/mel400_lab.hip (wrong results by design):
 //   bit 0: no wait for the staged tile   bit 1: no global stores   bit 2: no phase C
 //   bit 3: no LDS-DMA issue              bit 4: no phase B (second DFT, separation, P rows)
+//   bit 15 (32768): interior tiles gather their samples with plain global loads, the NEXT tile's 28 samples per lane
+//                   prefetched into registers right after phase A (no LDS staging at all)
+//   bit 17 (131072): tiles handed out chip-wide in chunks of kLabChunk from ONE global counter (epi.group_max, zeroed by
+//                   the lab before each launch) instead of static per-workgroup ranges
 // float max through integer atomics (target initialised to -inf or any float)
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
@@ -758,7 +881,9 @@ __global__ void __launch_bounds__(256) mel_tab_build_kernel(MelBandsDev mb, floa
   mel_tab_fill(threadIdx.x, blockDim.x, mb, out, mt);
 }
 
-template <int LAB, int EPI, int H = 8, typename TIn = float>
+// NR = rounds of 20 mels the per-lane arrays are sized for: 4 (n_mels <= 80, the common front-ends: the control words of
+// the band table then live in registers, MelRegs) or kMelMaxRounds (up to 160 mels, control words re-read from LDS).
+template <int LAB, int EPI, int H = 8, typename TIn = float, int NR = kMelMaxRounds>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, AAMD_M400_MINWAVES)
 melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
                   const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
@@ -800,8 +925,12 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   if (LAB & 1024) lab_t1 = wall_clock64();
   LaneConst c;
   lane_init(lane, const_tab, c);
-  float winr[20], twr[40];             // lab bits 8192 / 16384: constants in registers instead of LDS reads
-  if (LAB & 8192) {
+  // The 20 window taps of this lane live in registers for the whole launch (round 2: -5 us on the headline batch once
+  // the buffers rotate over more than the 256 MiB Infinity Cache; 5 b128 LDS reads per tile less).  Lab bit 8192 forces
+  // it on, bit 262144 forces the LDS table; the twiddles (38 more registers) stay in LDS (bit 16384: spills at 3 waves/SIMD).
+  constexpr bool kWinRegs = ((LAB & 8192) != 0) || !(LAB & 262144);
+  float winr[20], twr[40];
+  if (kWinRegs) {
 #pragma unroll
     for (int q = 0; q < 20; ++q) winr[q] = c.win[q];
   }
@@ -809,10 +938,17 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 #pragma unroll
     for (int q = 0; q < 40; ++q) twr[q] = c.tw[q];
   }
-  float nrm_mean[kMelMaxRounds], nrm_inv[kMelMaxRounds];   // MEL_NORM: statistics of this lane's mels
+  constexpr bool kHoist = NR <= 4;
+  MelRegs<NR> mregs;
+  const MelRegs<NR>* mh = nullptr;
+  if (EPI != EPI400_SPEC && kHoist) {
+    mel_regs_load<NR>(c, mt, mregs);
+    mh = &mregs;
+  }
+  float nrm_mean[NR], nrm_inv[NR];   // MEL_NORM: statistics of this lane's mels
   if (EPI == EPI400_MEL_NORM) {
 #pragma unroll
-    for (int r = 0; r < kMelMaxRounds; ++r) {
+    for (int r = 0; r < NR; ++r) {
       const int m = r < mt.n_rounds ? mt.row_mel[r * kMelSlots + c.pi] : -1;
       nrm_mean[r] = m >= 0 ? epi.mean[m] : 0.0f;
       nrm_inv[r] = m >= 0 ? epi.invstd[m] : 0.0f;
@@ -843,10 +979,32 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     if (lane == 0) v = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return (unsigned)__builtin_amdgcn_readfirstlane(v);
   };
+  // lab bit 17: chip-wide queue.  A wave owns a chunk of kLabChunk consecutive tiles; the ticket of its NEXT chunk is
+  // requested when a chunk starts and read when it ends (the atomic's round trip hides behind kLabChunk tiles).
+  constexpr unsigned kLabChunk = 8;
+  unsigned* gq = reinterpret_cast<unsigned*>(epi.group_max);
+  int g_pending = 0;            // lane 0: ticket of the next chunk (in flight)
+  unsigned g_base = 0, g_pos = 0;
+  auto g_request = [&]() {
+    if (lane == 0) g_pending = (int)__hip_atomic_fetch_add(gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (LAB & 131072) {
+    blk_count = (unsigned)n_tiles;                       // indices below are global tile numbers
+    g_request();
+    g_base = (unsigned)__builtin_amdgcn_readfirstlane(g_pending) * kLabChunk;
+    g_request();
+  }
+  auto g_next = [&]() {          // global index of the tile after the current one
+    if (++g_pos < kLabChunk) return g_base + g_pos;
+    g_base = (unsigned)__builtin_amdgcn_readfirstlane(g_pending) * kLabChunk;
+    g_pos = 0;
+    g_request();
+    return g_base;
+  };
 
   auto tile_info = [&](unsigned idx) {
     TileInfo ti;
-    const unsigned t = blk_first + idx;
+    const unsigned t = ((LAB & 131072) ? 0u : blk_first) + idx;
     const unsigned row = t / (unsigned)tiles_per_row;
     ti.row = row;
     ti.t0 = (int64_t)(t - row * (unsigned)tiles_per_row) * kFramesPerWave;
@@ -876,7 +1034,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     wmax = -INFINITY;
   };
 
-  unsigned cur_idx = (unsigned)wave;
+  unsigned cur_idx = (LAB & 131072) ? g_base : (unsigned)wave;
   TileInfo cur = tile_info(cur_idx);
   if (LAB & 128) {   // lab: stagger the waves of a SIMD by thirds of a tile time.  Interleaved A/B runs
     // (tools/ubench/mel400_lab) put it within noise of the lock-step start (74-78 us either way): off.
@@ -891,15 +1049,30 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     const int k = 4 * ((wave >> 2) % 3) + (wave & 3);
     for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(17);
   }
-  if (cur.staged && !(LAB & 8)) stage_issue(cur);
+  float Xn[HC::nx];   // lab bit 15: the next tile's samples, in flight
+  auto gload = [&](const TileInfo& ti) {
+    const TIn* src = wav + ti.row * row_stride + (ti.t0 * kHop - kPad) + (HC::pair_stride * c.p + c.pi);
+#pragma unroll
+    for (int q = 0; q < HC::nx; ++q) Xn[q] = (float)src[20 * q];
+  };
+  if (LAB & 32768) {
+#pragma unroll
+    for (int q = 0; q < HC::nx; ++q) Xn[q] = 0.0f;
+    if (cur.staged) gload(cur);
+  } else if (cur.staged && !(LAB & 8)) {
+    stage_issue(cur);
+  }
 
   while (cur_idx < blk_count) {
     // claim the tile after this one now: it is prefetched while this one is in its second half
-    const unsigned nxt_idx = claim();
+    const unsigned nxt_idx = (LAB & 131072) ? g_next() : claim();
     TileInfo nxt = tile_info(nxt_idx);
 
     float X[HC::nx];
-    if (cur.staged) {
+    if ((LAB & 32768) && cur.staged) {
+#pragma unroll
+      for (int q = 0; q < HC::nx; ++q) X[q] = Xn[q];
+    } else if (cur.staged) {
       if (!(LAB & 1)) stage_wait();
       if (LAB & 256) {   // lab: no gather (samples from a register expression)
 #pragma unroll
@@ -910,13 +1083,16 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     } else {
       gather_global<H, TIn>(c, wav + cur.row * row_stride, length, cur.t0, n_frames, X);
     }
-    phase_a<H, (LAB & 8192) != 0, (LAB & 16384) != 0>(c, X, lds, winr, twr);
+    phase_a<H, kWinRegs, (LAB & 16384) != 0>(c, X, lds, winr, twr);
+    if ((LAB & 32768) && nxt.staged) gload(nxt);        // X is dead: the next tile's samples fly during phases B and C
     wave_lds_fence();
     float vr[20], vi[20], zr[20], zi[20], qr[10], qi[10];
     phase_b1_load(c, lds, vr, vi);
-    // every transposition row has been read: the staging area (it aliases rows) is free again
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (nxt.staged && !(LAB & 8)) stage_issue(nxt);
+    if (!(LAB & 32768)) {
+      // every transposition row has been read: the staging area (it aliases rows) is free again
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (nxt.staged && !(LAB & 8)) stage_issue(nxt);
+    }
     if (LAB & 16) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
     dft20(vr, vi, zr, zi);
     phase_b2_send(c, zr, zi, qr, qi);
@@ -949,9 +1125,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     phase_b2(c, zr, zi, qr, qi, lds);
     phase_b2_pad(lane, lds);
     wave_lds_fence();
-    float acc_a[kMelMaxRounds], acc_b[kMelMaxRounds];
+    float acc_a[NR], acc_b[NR];
     if (LAB & 4) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
-    phase_c(c, mt, lds, acc_a, acc_b);
+    phase_c<NR>(c, mt, lds, acc_a, acc_b, mh);
     if (EPI == EPI400_MEL_DB) {
       const int64_t g = cur.row / epi.rows_per_group;   // wave-uniform
       if (g != wgroup) {
@@ -961,7 +1137,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       // frames past the end of the clip hold garbage (phase_a): keep them out of the maximum
       const bool va_ok = cur.t0 + 2 * c.p < n_frames, vb_ok = cur.t0 + 2 * c.p + 1 < n_frames;
 #pragma unroll
-      for (int r = 0; r < kMelMaxRounds; ++r) {
+      for (int r = 0; r < NR; ++r) {
         if (r < mt.n_rounds) {
           acc_a[r] = epi_db(acc_a[r], epi);
           acc_b[r] = epi_db(acc_b[r], epi);
@@ -971,7 +1147,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     }
     if (EPI == EPI400_MEL_NORM) {
 #pragma unroll
-      for (int r = 0; r < kMelMaxRounds; ++r) {
+      for (int r = 0; r < NR; ++r) {
         if (r < mt.n_rounds) {
           acc_a[r] = (epi_plog(acc_a[r] * epi.gain) - nrm_mean[r]) * nrm_inv[r];
           acc_b[r] = (epi_plog(acc_b[r] * epi.gain) - nrm_mean[r]) * nrm_inv[r];
@@ -981,11 +1157,11 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     float* out_row = out + cur.row * (EPI == EPI400_MEL_NORM ? epi.out_frames : (int64_t)n_frames) * (int64_t)mb.n_mels;
     if (out_wide) {
       wave_lds_fence();
-      store_stage(c, mt, acc_a, acc_b, lds);
+      store_stage<NR>(c, mt, acc_a, acc_b, lds, mh);
       wave_lds_fence();
       if (!(LAB & 2)) store_wide(lane, mt, lds, out_row, cur.t0, n_frames);
     } else {
-      if (!(LAB & 2)) store_direct(c, mt, acc_a, acc_b, out_row, cur.t0, n_frames);
+      if (!(LAB & 2)) store_direct<NR>(c, mt, acc_a, acc_b, out_row, cur.t0, n_frames, mh);
     }
     wave_lds_fence();
     cur = nxt;

@@ -126,12 +126,17 @@ def test_reference_lfilter_core_loop_lands_in_the_hip_kernel(n_order):
     g = torch.Generator().manual_seed(n_order)
     n_batch, n_channel, n_sample = 3, 2, 5000
     waveform = (0.3 * torch.randn(n_batch, n_channel, n_sample, generator=g)).cuda()
-    # stable per-channel denominators: poles well inside the unit circle
-    r = 0.5 + 0.4 * torch.rand(n_channel, n_order - 1, generator=g)
+    # stable per-channel denominators: conjugate pole pairs (and one real pole for an odd count) inside the unit circle
+    rs = np.random.default_rng(100 + n_order)
     poly = []
     for c in range(n_channel):
-        p = np.poly(np.asarray(r[c]) * np.exp(1j * np.linspace(0.3, 2.5, n_order - 1))).real
-        poly.append(p / p[0])
+        roots = []
+        for _ in range((n_order - 1) // 2):
+            z = rs.uniform(0.3, 0.85) * np.exp(1j * rs.uniform(0.2, 2.9))
+            roots += [z, np.conj(z)]
+        if (n_order - 1) % 2:
+            roots.append(rs.uniform(-0.8, 0.8))
+        poly.append(np.poly(roots).real)
     a_coeffs_normalized = torch.tensor(np.stack(poly), dtype=torch.float32).cuda()
     n_sample_padded = n_sample + n_order - 1
     a_coeff_flipped = a_coeffs_normalized.flip(1).contiguous()

@@ -1,4 +1,4 @@
-// Design lab for the headline kernel (NOT product): ablation variants of melspec400_kernel<LAB, 0> built
+// Design lab for the headline kernel (NOT product): ablation variants of melspec400_kernel<LAB, 0, 8, float, NR> built
 // from the same phase functions, timed with HIP events on one MI355X, plus a float64 host check.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -fno-slp-vectorize mel400_lab.hip -o mel400_lab
 #include <hip/hip_runtime.h>
@@ -58,20 +58,28 @@ static void htk_bands(int n_mels, std::vector<int>& lo, std::vector<int>& width,
   for (int m = 0; m < n_mels; ++m) for (int j = 0; j < width[m]; ++j) w[(size_t)m * maxw + j] = fb[m][lo[m] + j];
 }
 
-template <int LAB>
+static int g_rotate = 1;
+
+template <int LAB, int NR = kMelMaxRounds>
 static float run(const char* name, int blocks, size_t lds, const float* wav, const float* win, const float* tw,
                  MelBandsDev mb, float* out, int64_t rows, int64_t L, int T, int iters, int in_aligned, int out_wide) {
   const int tiles_per_row = (T + kFramesPerWave - 1) / kFramesPerWave;
   const int64_t n_tiles = rows * tiles_per_row;
   const int tpw = (int)((n_tiles + blocks - 1) / blocks);   // tiles per block
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(melspec400_kernel<LAB, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(melspec400_kernel<LAB, 0, 8, float, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  static unsigned* ctr = nullptr;          // one zeroed ticket counter per launch (chip-wide queue variants)
+  if (!ctr) CK(hipMalloc(&ctr, 4096 * 64));
+  if (LAB & 131072) CK(hipMemset(ctr, 0, 4096 * 64));
+  int nl = 0;
+  auto epi_for = [&]() { Epi400 e{}; if (LAB & 131072) e.group_max = reinterpret_cast<float*>(ctr + 16 * (nl++ % 4096)); return e; };
+  const int wout = g_rotate ? 4 : 1;       // rotate over 4 input / output buffer pairs (working set > 256 MiB L3)
   for (int i = 0; i < (name[0] ? 10 : 3); ++i)
-    hipLaunchKernelGGL((melspec400_kernel<LAB, 0>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, 0, wav, win, tw, mb, out, rows, L, L, T, 1.0f, tiles_per_row, n_tiles, tpw, in_aligned, out_wide, Epi400{});
+    hipLaunchKernelGGL((melspec400_kernel<LAB, 0, 8, float, NR>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, 0, wav + (size_t)(i % wout) * rows * L, win, tw, mb, out + (size_t)(i % wout) * rows * T * 80, rows, L, L, T, 1.0f, tiles_per_row, n_tiles, tpw, in_aligned, out_wide, epi_for());
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL((melspec400_kernel<LAB, 0>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, 0, wav, win, tw, mb, out, rows, L, L, T, 1.0f, tiles_per_row, n_tiles, tpw, in_aligned, out_wide, Epi400{});
+    hipLaunchKernelGGL((melspec400_kernel<LAB, 0, 8, float, NR>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, 0, wav + (size_t)(i % wout) * rows * L, win, tw, mb, out + (size_t)(i % wout) * rows * T * 80, rows, L, L, T, 1.0f, tiles_per_row, n_tiles, tpw, in_aligned, out_wide, epi_for());
   CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   if (name[0]) printf("%-44s %8.1f us\n", name, ms * 1e3f / iters);
@@ -90,10 +98,10 @@ int main(int argc, char** argv) {
   std::vector<int> lo, wd; std::vector<float> ww; int maxw;
   htk_bands(M, lo, wd, ww, maxw);
   float *dx, *dwin, *dtw, *dw, *dout; int *dlo, *dwd;
-  CK(hipMalloc(&dx, hx.size() * 4)); CK(hipMalloc(&dwin, 1600)); CK(hipMalloc(&dtw, 4096 + 24 * 4096));
+  CK(hipMalloc(&dx, hx.size() * 4 * 4)); CK(hipMalloc(&dwin, 1600)); CK(hipMalloc(&dtw, 4096 + 24 * 4096));
   CK(hipMalloc(&dw, ww.size() * 4)); CK(hipMalloc(&dlo, M * 4)); CK(hipMalloc(&dwd, M * 4));
-  CK(hipMalloc(&dout, (size_t)rows * T * M * 4));
-  CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMalloc(&dout, (size_t)rows * T * M * 4 * 4));
+  for (int r = 0; r < 4; ++r) CK(hipMemcpy(dx + (size_t)r * hx.size(), hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dwin, hwin.data(), 1600, hipMemcpyHostToDevice)); CK(hipMemcpy(dtw, htw.data(), 3200, hipMemcpyHostToDevice));
   CK(hipMemcpy(dw, ww.data(), ww.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dlo, lo.data(), M * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dwd, wd.data(), M * 4, hipMemcpyHostToDevice));
@@ -130,6 +138,110 @@ int main(int argc, char** argv) {
     printf("float64 check: peak-rel err %.3e\n", worst / peak);
   }
   run<0>("product: staged in + narrow out", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 0);
+  if (getenv("LAB_R3")) {   // round-2, second batch: everything with the prebuilt table; NR = 4 = control words in registers
+    MelBandsDev mbt = mb;
+    float* dtab; CK(hipMalloc(&dtab, (size_t)mel_tab_dwords(M, maxw) * 4));
+    CK(hipMemset(dtab, 0, (size_t)mel_tab_dwords(M, maxw) * 4));
+    hipLaunchKernelGGL(mel_tab_build_kernel, dim3(1), dim3(256), 0, 0, mb, dtab);
+    CK(hipDeviceSynchronize());
+    mbt.table400 = dtab;
+    // warm the clocks: ~60 ms of launches
+    for (int i = 0; i < 6; ++i) run<0>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 120, 1, 0);
+    const int NV = 8;
+    std::vector<float> r[NV];
+    const char* nm[NV] = {"NR8 window regs", "NR8 window in LDS (262144)", "NR4 window regs (candidate product)",
+                          "NR4 window in LDS", "NR4 + no stage wait (LAB1)", "NR4 + no stores (LAB2)",
+                          "NR4 no DMA/wait/stores (LAB11)", "NR4 WIDE stores"};
+    for (int rep = 0; rep < 9; ++rep) {
+      r[0].push_back(run<0>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0));
+      r[1].push_back(run<262144>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0));
+      r[2].push_back(run<0, 4>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0));
+      r[3].push_back(run<262144, 4>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0));
+      r[4].push_back(run<1, 4>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0));
+      r[5].push_back(run<2, 4>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0));
+      r[6].push_back(run<11, 4>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0));
+      r[7].push_back(run<0, 4>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 1));
+    }
+    for (int i = 0; i < NV; ++i) { std::sort(r[i].begin(), r[i].end()); printf("R3 A/B median %-40s %7.1f us (min %.1f max %.1f)\n", nm[i], r[i][4], r[i].front(), r[i].back()); }
+    std::vector<float> ref((size_t)rows * T * M), got((size_t)rows * T * M);
+    g_rotate = 0;
+    run<262144>("", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, 1, 1, 0);
+    CK(hipMemcpy(ref.data(), dout, ref.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemset(dout, 0, ref.size() * 4)); run<0, 4>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 1, 1, 0);
+    CK(hipMemcpy(got.data(), dout, got.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0; double worst = 0; for (size_t i = 0; i < ref.size(); ++i) { bad += (ref[i] != got[i]); worst = std::fmax(worst, std::fabs((double)ref[i] - got[i])); }
+    printf("R3 check NR4 + window regs + prebuilt table vs LDS-window in-kernel-table NR8: %zu of %zu values differ, max abs %.3e\n", bad, ref.size(), worst);
+    g_rotate = 1;
+    { // census of the candidate
+      CK(hipMemset(dtw + 1024, 0, 24 * 4096));
+      run<1024, 4>("census run (NR4)", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 1, 1, 0);
+      const int nw = blocks * kWavesPerBlock;
+      std::vector<long long> rec(3 * nw);
+      CK(hipMemcpy(rec.data(), dtw + 1024, rec.size() * 8, hipMemcpyDeviceToHost));
+      long long tmin = rec[0], tmax = rec[2];
+      for (int w = 0; w < nw; ++w) if (rec[3 * w + 2] >= rec[0]) { tmin = std::min(tmin, rec[3 * w]); tmax = std::max(tmax, rec[3 * w + 2]); }
+      double e = 0, rr = 0, d = 0, emax = 0, rmax = 0, dmin = 1e30; int used = 0;
+      std::vector<double> blk_done(blocks, 0.0);
+      for (int w = 0; w < nw; ++w) {
+        if (rec[3 * w + 2] < rec[0]) continue;
+        ++used;
+        const double a = (rec[3 * w] - tmin) * 0.01, bb = (rec[3 * w + 1] - tmin) * 0.01, c = (rec[3 * w + 2] - tmin) * 0.01;
+        e += a; rr += bb; d += c; emax = std::max(emax, a); rmax = std::max(rmax, bb); dmin = std::min(dmin, c);
+        blk_done[w / kWavesPerBlock] = std::max(blk_done[w / kWavesPerBlock], c);
+      }
+      printf("R3 census (us from first wave entry): entry mean %.1f max %.1f | tables ready mean %.1f max %.1f | done mean %.1f min %.1f max %.1f\n",
+             e / used, emax, rr / used, rmax, d / used, dmin, (tmax - tmin) * 0.01);
+      // per-XCD finishing times (block b runs on XCD b % 8)
+      for (int x = 0; x < 8; ++x) { double mx = 0, mn = 1e30, sm = 0; int n = 0; for (int b = x; b < blocks; b += 8) { mx = std::max(mx, blk_done[b]); mn = std::min(mn, blk_done[b]); sm += blk_done[b]; ++n; }
+        printf("R3 census XCD %d: block done min %.1f mean %.1f max %.1f\n", x, mn, sm / n, mx); }
+    }
+    fflush(stdout);
+    if (getenv("LAB_R3_ONLY")) return 0;
+  }
+  if (getenv("LAB_R2")) {   // round-2 experiments: interleaved A/B medians, buffers rotating over > L3
+    MelBandsDev mbt = mb;
+    float* dtab; CK(hipMalloc(&dtab, (size_t)mel_tab_dwords(M, maxw) * 4));
+    CK(hipMemset(dtab, 0, (size_t)mel_tab_dwords(M, maxw) * 4));
+    hipLaunchKernelGGL(mel_tab_build_kernel, dim3(1), dim3(256), 0, 0, mb, dtab);
+    CK(hipDeviceSynchronize());
+    mbt.table400 = dtab;
+    const int NV = 10;
+    std::vector<float> r[NV];
+    const char* nm[NV] = {"product (in-kernel table build)", "prebuilt table", "prebuilt + direct global gather",
+                          "prebuilt + chip-wide queue", "prebuilt + gather + queue", "prebuilt + window regs",
+                          "prebuilt + gather + window regs", "prebuilt + gather + queue + window regs",
+                          "prebuilt, no stage wait (LAB1)", "prebuilt + gather + queue, WIDE stores"};
+    for (int rep = 0; rep < 7; ++rep) {
+      r[0].push_back(run<0>("", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, 24, 1, 0));
+      r[1].push_back(run<0>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 24, 1, 0));
+      r[2].push_back(run<32768>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 24, 1, 0));
+      r[3].push_back(run<131072>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 24, 1, 0));
+      r[4].push_back(run<32768 + 131072>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 24, 1, 0));
+      r[5].push_back(run<8192>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 24, 1, 0));
+      r[6].push_back(run<32768 + 8192>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 24, 1, 0));
+      r[7].push_back(run<32768 + 131072 + 8192>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 24, 1, 0));
+      r[8].push_back(run<1>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 24, 1, 0));
+      r[9].push_back(run<32768 + 131072>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 24, 1, 1));
+    }
+    for (int i = 0; i < NV; ++i) { std::sort(r[i].begin(), r[i].end()); printf("R2 A/B median %-44s %7.1f us (min %.1f max %.1f)\n", nm[i], r[i][3], r[i].front(), r[i].back()); }
+    // correctness of the variants against the product output (bit-identical expected: same arithmetic, other data path)
+    std::vector<float> ref((size_t)rows * T * M), got((size_t)rows * T * M);
+    run<0>("", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, 1, 1, 0);
+    CK(hipMemcpy(ref.data(), dout, ref.size() * 4, hipMemcpyDeviceToHost));
+    auto cmp = [&](const char* what) {
+      CK(hipMemcpy(got.data(), dout, got.size() * 4, hipMemcpyDeviceToHost));
+      size_t bad = 0; for (size_t i = 0; i < ref.size(); ++i) bad += (ref[i] != got[i]);
+      printf("R2 check %-40s %zu of %zu values differ\n", what, bad, ref.size());
+    };
+    g_rotate = 0;
+    CK(hipMemset(dout, 0, ref.size() * 4)); run<0>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 1, 1, 0); cmp("prebuilt table");
+    CK(hipMemset(dout, 0, ref.size() * 4)); run<32768>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 1, 1, 0); cmp("direct global gather");
+    CK(hipMemset(dout, 0, ref.size() * 4)); run<131072>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 1, 1, 0); cmp("chip-wide queue");
+    CK(hipMemset(dout, 0, ref.size() * 4)); run<32768 + 131072 + 8192>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 1, 1, 0); cmp("gather + queue + window regs");
+    g_rotate = 1;
+    fflush(stdout);
+    if (getenv("LAB_R2_ONLY")) return 0;
+  }
   {  // interleaved A/B (medians of 7 x 30 launches each): stagger on/off x lane order on/off, narrow stores
     MelBandsDev mbo = mb;
     std::vector<int> ord;
