@@ -4,8 +4,10 @@
 (DC removal, log-energy, pre-emphasis, window, zero padding), the FFT, the mel banks and the logs run in ONE HIP kernel
 (`p2::kaldi_pow2_kernel`, csrc/stft_pow2.h, through `aamd_kaldi_features_f32`); `mfcc` adds the DCT on the matrix-core kernel
 of the MFCC path.  Constants (window function, mel banks, DCT matrix, lifter) are built on the host exactly as the reference
-builds them.  Limits, raised loudly: the padded window must be 256, 512, 1024 or 2048 samples (8 / 16 / 22.05 / 32 / 44.1 / 48 kHz at
-the usual 25 ms), and `dither` must be 0 (the reference draws fresh noise per call; its own tests run with dither = 0).
+builds them.  Padded windows of 256 / 512 / 1024 / 2048 samples run on the register FFT; every other even size
+(`round_to_power_of_two=False`: 400 at 16 kHz, 200 at 8 kHz, 1102 at 44.1 kHz ...) on the mixed-radix LDS kernel
+(csrc/kaldi_generic.h).  `dither` draws its Gaussian noise exactly as the reference does -- `torch.randn(frames.shape)` on
+the waveform's device (kaldi.py:180-183) -- so a seeded run reproduces the reference's run on the same device.
 """
 from __future__ import annotations
 
@@ -35,6 +37,11 @@ mel_scale = _host.kaldi_mel_scale
 vtln_warp_freq = _host.kaldi_vtln_warp_freq
 vtln_warp_mel_freq = _host.kaldi_vtln_warp_mel_freq
 get_mel_banks = _host.kaldi_get_mel_banks
+
+
+def _randn(shape, device, dtype) -> Tensor:
+    """The reference's dither draw (tests substitute a recorded draw here)."""
+    return torch.randn(shape, device=device, dtype=dtype)
 
 
 def _next_power_of_2(x: int) -> int:
@@ -70,10 +77,8 @@ def _features(waveform: Tensor, window_shift: int, window_size: int, padded: int
               snip_edges: bool, raw_energy: bool, energy_floor: float, dither: float, remove_dc_offset: bool,
               preemphasis_coefficient: float, bands, use_power: bool, use_log: bool, energy_col: int, first_col: int,
               n_cols: int) -> Tensor:
-    if dither != 0.0:
-        raise NotImplementedError("audio_amd: kaldi features run with dither = 0 only (fresh noise per call is not reproduced)")
-    if padded not in (256, 512, 1024, 2048):
-        raise NotImplementedError(f"audio_amd: the padded window must be 256, 512, 1024 or 2048 samples, got {padded}")
+    if padded > 8192:
+        raise NotImplementedError(f"audio_amd: padded windows above 8192 samples are not supported, got {padded}")
     if not waveform.is_cuda:
         raise RuntimeError(f"audio_amd: waveform must be on an MI355X (ROCm) device, got {waveform.device}. "
                            "The HIP kernels have no CPU fallback.")
@@ -87,10 +92,14 @@ def _features(waveform: Tensor, window_shift: int, window_size: int, padded: int
     key = ("kaldi_win", window_type, window_size, padded, blackman_coeff, str(dev))
     win = F._cached(key, lambda: torch.nn.functional.pad(
         _host.kaldi_window(window_type, window_size, blackman_coeff), (0, padded - window_size)).to(dev).contiguous())
+    noise = None
+    if dither != 0.0:
+        # kaldi.py:180-183: rand_gauss = torch.randn(strided_input.shape, device, dtype); frames += rand_gauss * dither
+        noise = _randn((m, window_size), device=dev, dtype=torch.float32).contiguous()
     out = torch.empty((m, n_cols), dtype=torch.float32, device=dev)
     d = _lib.KaldiDesc(x.numel(), m, padded, window_shift, window_size, int(snip_edges), float(preemphasis_coefficient),
                        int(remove_dc_offset), int(raw_energy), float(energy_floor), int(use_power), int(use_log),
-                       energy_col, first_col, n_cols)
+                       energy_col, first_col, n_cols, float(dither), None if noise is None else noise.data_ptr())
     L = _lib.lib()
     _lib.check(L.aamd_kaldi_features_f32(x.data_ptr(), win.data_ptr(), F._twiddles(padded, dev).data_ptr(),
                                          None if bands is None else C.byref(bands.struct), out.data_ptr(), C.byref(d),

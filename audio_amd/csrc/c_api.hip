@@ -16,6 +16,7 @@
 #include "fftconv.h"
 #include "fftconv_os.h"
 #include "istft.h"
+#include "kaldi_generic.h"
 #include "vocoder.h"
 #include "stft_pow2.h"
 #include "istft400.h"
@@ -522,8 +523,8 @@ int aamd_kaldi_features_f32(const float* wav, const float* window, const float* 
   AAMD_CHECK_ARG(d->n_samples >= 0 && d->n_frames >= 0, "negative sizes");
   AAMD_CHECK_ARG(d->shift >= 1 && d->win >= 2 && d->win <= d->n_fft, "need shift >= 1 and 2 <= win <= n_fft");
   AAMD_CHECK_ARG(d->preemphasis >= 0.0f && d->preemphasis <= 1.0f, "preemphasis must be in [0, 1]");
-  if (d->n_fft != 256 && d->n_fft != 512 && d->n_fft != 1024 && d->n_fft != 2048)
-    return fail(AAMD_EUNSUPPORTED, "audio_amd: the Kaldi front-end needs a padded window of 256, 512, 1024 or 2048 samples");
+  AAMD_CHECK_ARG(d->n_fft % 2 == 0, "the padded window must be even (compliance/kaldi.py:139-141)");
+  AAMD_CHECK_ARG(d->dither == 0.0f || d->noise != nullptr, "dither needs the noise buffer");
   if (d->n_frames == 0) return AAMD_OK;
   MelBandsDev mb{};
   if (bands != nullptr) {
@@ -540,6 +541,37 @@ int aamd_kaldi_features_f32(const float* wav, const float* window, const float* 
   kg.eps = 1.1920928955078125e-07f;
   kg.use_power = d->use_power; kg.use_log = d->use_log;
   kg.energy_col = d->energy_col; kg.first_col = d->first_col; kg.n_cols = d->n_cols;
+  kg.noise = d->dither != 0.0f ? d->noise : nullptr; kg.dither = d->dither;
+  const bool pow2 = d->n_fft == 256 || d->n_fft == 512 || d->n_fft == 1024 || d->n_fft == 2048;
+  if (!pow2 || force_generic()) {
+    // any even padded window: mixed-radix Stockham stages in LDS (csrc/kaldi_generic.h)
+    kgen::Plan plan{};
+    plan.n_fft = d->n_fft;
+    plan.n_stages = plan_radices(d->n_fft, plan.radix);
+    if (plan.n_stages < 0 || d->n_fft > 8192)
+      return fail(AAMD_EUNSUPPORTED, "audio_amd: padded window too long / too many prime factors for the Kaldi front-end");
+    const int pb = kgen::pairs_per_block(d->n_fft);
+    const size_t lds = kgen::lds_floats(d->n_fft, pb) * sizeof(float);
+    if (lds > dev_props().lds_per_block_optin)
+      return fail(AAMD_EUNSUPPORTED, "audio_amd: padded window too long for the LDS");
+    const int64_t nblk = (d->n_frames + 2 * pb - 1) / (2 * pb);
+    AAMD_CHECK_ARG(nblk < (1ll << 31), "too many frames for one launch");
+    const auto* twg = reinterpret_cast<const cplx<float>*>(twiddle);
+    if (bands == nullptr) {
+      auto kk = kgen::kaldi_generic_kernel<0>;
+      if (lds > 48 * 1024)
+        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kk, dim3((unsigned)nblk), dim3(kgen::kThreads), lds, (hipStream_t)stream, kg, plan, pb, wav, window,
+                         twg, mb, out);
+    } else {
+      auto kk = kgen::kaldi_generic_kernel<1>;
+      if (lds > 48 * 1024)
+        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kk, dim3((unsigned)nblk), dim3(kgen::kThreads), lds, (hipStream_t)stream, kg, plan, pb, wav, window,
+                         twg, mb, out);
+    }
+    return launch_check();
+  }
   const int64_t n_pairs = (d->n_frames + 1) / 2;
   int64_t blocks = (int64_t)dev_props().cu_count * 4;
   const int64_t need = (n_pairs + p2::kWaves - 1) / p2::kWaves;

@@ -488,6 +488,8 @@ struct KaldiGeom {
   float eps;                          // torch.finfo(float32).eps
   int32_t use_power, use_log;
   int32_t energy_col, first_col, n_cols;   // output row: [n_cols]; energy_col < 0: no energy column
+  const float* noise;                 // dither: unit Gaussian noise [n_frames][win] (kaldi.py:180-183), or null
+  float dither;
 };
 
 // sample j of frame t (kaldi.py:44-83 _get_strided): snip_edges reads the signal as is; otherwise the signal is
@@ -496,7 +498,9 @@ AAMD_HD float kaldi_sample(const KaldiGeom& kg, const float* x, int64_t t, int j
   int64_t i = t * (int64_t)kg.shift + j - (kg.snip_edges ? 0 : kg.pad_left);
   if (i < 0) i = -1 - i;
   if (i >= kg.n_samples) i = 2 * kg.n_samples - 1 - i;
-  return (i >= 0 && i < kg.n_samples) ? x[i] : 0.0f;
+  const float v = (i >= 0 && i < kg.n_samples) ? x[i] : 0.0f;
+  // dither is added to the FRAMED signal (one independent draw per frame and tap, also where frames overlap)
+  return kg.noise != nullptr ? v + kg.dither * kg.noise[t * (int64_t)kg.win + j] : v;
 }
 
 // raw samples of the frame and their predecessors (for the pre-emphasis), this lane's E taps; taps >= win are 0

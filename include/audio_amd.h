@@ -194,8 +194,10 @@ int aamd_melspectrogram_grad_f32(float* spec_inout, const float* dmel, const aam
  *   bands == NULL: rows float[n_frames][n_fft/2 + 1] = log(max(|X|^2, eps)), column 0 = log energy   (kaldi.spectrogram)
  *   bands != NULL: rows float[n_frames][n_cols]: column first_col + m = mel-bank energy m (log(max(., eps)) if use_log),
  *                  column energy_col (if >= 0) = log energy                                        (kaldi.fbank)
- * window: float[n_fft], the window function in the first `win` entries, zero after.  n_fft in {512, 1024, 2048}.
- * Dither is not applied (the reference's tests run with dither = 0). */
+ * window: float[n_fft], the window function in the first `win` entries, zero after.  n_fft = 256 / 512 / 1024 / 2048 run on
+ * the register FFT; any other EVEN n_fft (round_to_power_of_two = False: 400 at 16 kHz, 200 at 8 kHz, 1102 at 44.1 kHz ...)
+ * on the mixed-radix LDS kernel of csrc/kaldi_generic.h.  Dither: the caller draws the Gaussian noise (as the reference
+ * does with torch.randn) and passes it in desc->noise. */
 typedef struct aamd_kaldi_desc {
   int64_t n_samples, n_frames;
   int32_t n_fft, shift, win;
@@ -205,6 +207,8 @@ typedef struct aamd_kaldi_desc {
   float energy_floor;                  /* 0: no floor */
   int32_t use_power, use_log;
   int32_t energy_col, first_col, n_cols;
+  float dither;                        /* 0: off; else frames += dither * noise (kaldi.py:180-183) */
+  const float* noise;                  /* device float[n_frames][win] unit Gaussian draws (the caller's RNG), NULL if dither == 0 */
 } aamd_kaldi_desc;
 int aamd_kaldi_features_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
                             float* out, const aamd_kaldi_desc* desc, void* stream);

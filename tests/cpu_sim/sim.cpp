@@ -17,6 +17,7 @@
 #include "../../audio_amd/csrc/vocoder.h"
 #include "../../audio_amd/csrc/stft_pow2.h"
 #include "../../audio_amd/csrc/istft400.h"
+#include "../../audio_amd/csrc/kaldi_generic.h"
 #include "../../audio_amd/csrc/lfilter.h"
 #include "../../audio_amd/csrc/lfilter_wave.h"
 #include "../../audio_amd/csrc/melspec400.h"
@@ -85,6 +86,7 @@ static int sim_pow2_e(const float* wav, const float* window, const float* tw, co
 // atomic adds hit it.  A sequential replay cannot show a store/atomic race by its value; the counts can.
 static int32_t* g_trace_store = nullptr;
 static int32_t* g_trace_add = nullptr;
+static int g_force_generic = 0;   // sim_kaldi_features: replay the generic (any even size) kernel also for 256 ... 2048
 static const float* g_trace_base = nullptr;
 
 template <int E>
@@ -350,6 +352,8 @@ int sim_istft400(const float* spec, const float* window, const float* tw, const 
   return -2;
 }
 
+void sim_set_force_generic(int v) { g_force_generic = v; }
+
 int sim_kaldi_features(const float* wav, const float* window, const float* tw, const aamd_mel_bands* bands, float* out,
                        const aamd_kaldi_desc* d) {
   p2::KaldiGeom kg{};
@@ -362,7 +366,46 @@ int sim_kaldi_features(const float* wav, const float* window, const float* tw, c
   kg.energy_col = d->energy_col; kg.first_col = d->first_col; kg.n_cols = d->n_cols;
   MelBandsDev mb{};
   if (bands) { mb.n_mels = bands->n_mels; mb.max_width = bands->max_width; mb.lo = bands->lo; mb.width = bands->width; mb.weights = bands->weights; }
+  kg.noise = d->dither != 0.0f ? d->noise : nullptr; kg.dither = d->dither;
   const int mode = bands ? 1 : 0;
+  const bool pow2 = d->n_fft == 256 || d->n_fft == 512 || d->n_fft == 1024 || d->n_fft == 2048;
+  if (!pow2 || g_force_generic) {   // replay of kgen::kaldi_generic_kernel, phase by phase
+    using namespace kgen;
+    Plan plan{};
+    plan.n_fft = d->n_fft;
+    plan.n_stages = plan_radices(d->n_fft, plan.radix);
+    if (plan.n_stages < 0) return -1;
+    const int N = d->n_fft, pb = pairs_per_block(N), nf = 2 * pb, nthr = kThreads;
+    std::vector<float> mem(lds_floats(N, pb) + 16);
+    const Lds l = carve(mem.data(), N, pb);
+    const cplx<float>* twc = reinterpret_cast<const cplx<float>*>(tw);
+    for (int i = 0; i < N; ++i) l.twl[i] = twc[i];
+    for (int64_t t0 = 0; t0 < kg.n_frames; t0 += nf) {
+      for (int tid = 0; tid < nthr; ++tid) pass_sum(tid, nthr, nf, kg, wav, t0, l.red);
+      for (int tid = 0; tid < nthr; ++tid) fold_mean(tid, nthr, nf, kg, l.red, l.stat);
+      if (kg.raw_energy) {
+        for (int tid = 0; tid < nthr; ++tid) pass_sumsq(tid, nthr, nf, kg, wav, t0, l.stat, l.red);
+        for (int tid = 0; tid < nthr; ++tid) fold_energy(tid, nthr, nf, kg, l.red, l.stat);
+      }
+      for (int tid = 0; tid < nthr; ++tid) pass_shape(tid, nthr, nf, N, kg, wav, window, t0, l.stat, l.bufA, l.red);
+      if (!kg.raw_energy)
+        for (int tid = 0; tid < nthr; ++tid) fold_energy(tid, nthr, nf, kg, l.red, l.stat);
+      cplx<float>* x = l.bufA; cplx<float>* y = l.bufB;
+      int sstride = 1;
+      for (int st = 0; st < plan.n_stages; ++st) {
+        for (int tid = 0; tid < nthr; ++tid) gen_stage<float>(tid, nthr, N, plan.radix[st], sstride, pb, x, y, l.twl);
+        sstride *= plan.radix[st];
+        std::swap(x, y);
+      }
+      if (mode == 0) {
+        for (int tid = 0; tid < nthr; ++tid) store_spec(tid, nthr, nf, N, kg, x, t0, l.stat, out);
+      } else {
+        for (int tid = 0; tid < nthr; ++tid) power_rows(tid, nthr, nf, N, kg, x, l.P);
+        for (int tid = 0; tid < nthr; ++tid) fbank_rows(tid, nthr, nf, N, kg, mb, l.P, t0, l.stat, out);
+      }
+    }
+    return 0;
+  }
   if (d->n_fft == 256) return sim_kaldi_e<4>(wav, window, tw, mb, out, kg, mode);
   if (d->n_fft == 512) return sim_kaldi_e<8>(wav, window, tw, mb, out, kg, mode);
   if (d->n_fft == 1024) return sim_kaldi_e<16>(wav, window, tw, mb, out, kg, mode);

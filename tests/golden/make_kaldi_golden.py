@@ -33,13 +33,45 @@ cases = {
     "mfcc_default": ("mfcc", dict()),
     "mfcc_energy_htk": ("mfcc", dict(use_energy=True, htk_compat=True, num_ceps=20, num_mel_bins=40, cepstral_lifter=0.0)),
     "mfcc_htk_noenergy": ("mfcc", dict(htk_compat=True, channel=1, subtract_mean=True)),
+    # round 2: padded window = frame length (round_to_power_of_two=False), any even size
+    "fbank_np2_16k_400": ("fbank", dict(round_to_power_of_two=False, num_mel_bins=40, use_energy=True)),
+    "spec_np2_16k_400": ("spectrogram", dict(round_to_power_of_two=False, snip_edges=False)),
+    "mfcc_np2_8k_200": ("mfcc", dict(round_to_power_of_two=False, sample_frequency=8000.0, channel=1)),
+    "fbank_np2_44k_1102": ("fbank", dict(round_to_power_of_two=False, sample_frequency=44100.0, num_mel_bins=64,
+                                         raw_energy=False, use_energy=True, window_type="hamming")),
+    "fbank_np2_22k_551pad": ("fbank", dict(round_to_power_of_two=False, sample_frequency=22050.0, frame_length=25.04,
+                                           num_mel_bins=30)),        # 552 samples = 2^3 * 3 * 23: a prime radix stage
 }
+# dither: the reference draws torch.randn(frames.shape); the recorded draw is stored so that the device path can be fed the
+# SAME noise (audio_amd.compliance.kaldi._randn is the substitution point)
+DITHER = {"fbank_dither": ("fbank", dict(dither=1.0, num_mel_bins=40)),
+          "spec_dither_np2": ("spectrogram", dict(dither=0.5, round_to_power_of_two=False, snip_edges=False)),
+          "mfcc_dither": ("mfcc", dict(dither=2.0, use_energy=True))}
 meta = {}
 for name, (fn, kw) in cases.items():
     y = getattr(K, fn)(wav, **kw)
     out[name] = y.numpy()
     meta[name] = {"fn": fn, "kw": kw}
     print(name, tuple(y.shape), float(y.abs().max()))
+_real_randn = torch.randn
+for name, (fn, kw) in DITHER.items():
+    drawn = []
+
+    def recording_randn(*a, **k):
+        r = _real_randn(*a, **k)
+        drawn.append(r.clone())
+        return r
+    torch.manual_seed(1234)
+    torch.randn = recording_randn
+    try:
+        y = getattr(K, fn)(wav, **kw)
+    finally:
+        torch.randn = _real_randn
+    assert len(drawn) == 1
+    out[name] = y.numpy()
+    out[f"noise/{name}"] = drawn[0].numpy()
+    meta[name] = {"fn": fn, "kw": kw, "noise": f"noise/{name}"}
+    print(name, tuple(y.shape), tuple(drawn[0].shape))
 # host-side constants of the reference, for bit-exact comparison with audio_amd/_host.py
 for tag, args in {"banks_default": (23, 512, 16000.0, 20.0, 0.0, 100.0, -500.0, 1.0),
                   "banks_80": (80, 512, 16000.0, 20.0, -400.0, 100.0, -500.0, 1.0),

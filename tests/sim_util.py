@@ -323,8 +323,10 @@ def sim_stft_pow2(x, window_padded, desc, bands=None):
 
 
 def sim_kaldi_features(x, window_padded, n_fft, shift, win, snip_edges=True, preemph=0.97, remove_dc=True, raw_energy=True,
-                       energy_floor=1.0, use_power=True, use_log=True, bands=None, energy_col=-1, first_col=0, n_cols=None):
-    """kaldi_pow2_kernel replay for ONE waveform.  Returns (n_frames, n_cols)."""
+                       energy_floor=1.0, use_power=True, use_log=True, bands=None, energy_col=-1, first_col=0, n_cols=None,
+                       dither=0.0, noise=None, force_generic=False):
+    """Replay for ONE waveform of kaldi_pow2_kernel (n_fft 256 ... 2048) or kgen::kaldi_generic_kernel (any other even
+    size, or force_generic).  Returns (n_frames, n_cols)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     n = x.shape[0]
     m = (0 if n < win else 1 + (n - win) // shift) if snip_edges else (n + shift // 2) // shift
@@ -333,10 +335,18 @@ def sim_kaldi_features(x, window_padded, n_fft, shift, win, snip_edges=True, pre
     out = np.zeros((m, n_cols), dtype=np.float32)
     w = np.ascontiguousarray(window_padded, dtype=np.float32)
     tw = np.ascontiguousarray(_host.twiddle_table(n_fft))
+    if noise is not None:
+        noise = np.ascontiguousarray(noise, dtype=np.float32)
+        assert noise.shape == (m, win)
     d = _lib.KaldiDesc(n, m, n_fft, shift, win, int(snip_edges), preemph, int(remove_dc), int(raw_energy), energy_floor,
-                       int(use_power), int(use_log), energy_col, first_col, n_cols)
+                       int(use_power), int(use_log), energy_col, first_col, n_cols, float(dither),
+                       None if noise is None else noise.ctypes.data)
     f = sim().sim_kaldi_features
     f.argtypes = [C.c_void_p] * 3 + [C.c_void_p, C.c_void_p, C.POINTER(_lib.KaldiDesc)]
-    assert f(fptr(x), fptr(w), fptr(tw), None if bands is None else C.cast(C.byref(bands.struct), C.c_void_p), fptr(out),
-             C.byref(d)) == 0
+    sim().sim_set_force_generic(int(force_generic))
+    try:
+        assert f(fptr(x), fptr(w), fptr(tw), None if bands is None else C.cast(C.byref(bands.struct), C.c_void_p), fptr(out),
+                 C.byref(d)) == 0
+    finally:
+        sim().sim_set_force_generic(0)
     return out

@@ -19,7 +19,7 @@ DEFAULTS = dict(blackman_coeff=0.42, channel=-1, energy_floor=1.0, frame_length=
                 htk_compat=False, low_freq=20.0, num_mel_bins=23, preemphasis_coefficient=0.97, raw_energy=True,
                 remove_dc_offset=True, sample_frequency=16000.0, snip_edges=True, subtract_mean=False, use_energy=False,
                 use_log_fbank=True, use_power=True, vtln_high=-500.0, vtln_low=100.0, vtln_warp=1.0, window_type="povey",
-                num_ceps=13, cepstral_lifter=22.0)
+                num_ceps=13, cepstral_lifter=22.0, round_to_power_of_two=True, dither=0.0)
 
 
 def _close(got, ref, linear=False):
@@ -30,16 +30,17 @@ def _close(got, ref, linear=False):
         assert np.abs(got - ref).max() <= 2e-3
 
 
-def _sim(name):
+def _sim(name, force_generic=False):
     fn, kw = META[name]["fn"], dict(DEFAULTS, **META[name]["kw"])
     x = G["wav"][max(kw["channel"], 0)]
     sr = kw["sample_frequency"]
     shift, win = int(sr * kw["frame_shift"] * 0.001), int(sr * kw["frame_length"] * 0.001)
-    n_fft = 2 ** (win - 1).bit_length()
+    n_fft = 2 ** (win - 1).bit_length() if kw["round_to_power_of_two"] else win
     w = np.zeros(n_fft, dtype=np.float32)
     w[:win] = _host.kaldi_window(kw["window_type"], win, kw["blackman_coeff"]).numpy()
     common = dict(snip_edges=kw["snip_edges"], preemph=kw["preemphasis_coefficient"], remove_dc=kw["remove_dc_offset"],
-                  raw_energy=kw["raw_energy"], energy_floor=kw["energy_floor"])
+                  raw_energy=kw["raw_energy"], energy_floor=kw["energy_floor"], dither=kw["dither"],
+                  noise=G[META[name]["noise"]] if "noise" in META[name] else None, force_generic=force_generic)
     if fn == "spectrogram":
         out = S.sim_kaldi_features(x, w, n_fft, shift, win, **common)
     else:
@@ -79,6 +80,13 @@ def test_sim_kaldi_vs_reference(name):
     _close(out, G[name], linear=(fn == "fbank" and not kw["use_log_fbank"]))
 
 
+@pytest.mark.parametrize("name", ["fbank_default", "fbank_44k", "spec_rect_nosnip", "mfcc_energy_htk", "fbank_dither"])
+def test_sim_generic_kaldi_kernel_also_serves_power_of_two_sizes(name):
+    """kgen::kaldi_generic_kernel (any even padded window) replayed on fixtures the register-FFT kernel normally serves."""
+    out, fn, kw = _sim(name, force_generic=True)
+    _close(out, G[name], linear=(fn == "fbank" and not kw["use_log_fbank"]))
+
+
 def test_kaldi_mel_banks_match_reference_formula():
     """Host constants: the triangles are linear in mel, sum to <= 1 per bin pair, and the warped variant keeps them ordered."""
     bins, centers = _host.kaldi_get_mel_banks(23, 512, 16000.0, 20.0, 0.0, 100.0, -500.0, 1.0)
@@ -92,23 +100,55 @@ def test_kaldi_mel_banks_match_reference_formula():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(META))
-def test_gpu_kaldi_vs_reference(name):
+def test_gpu_kaldi_vs_reference(name, monkeypatch):
     import audio_amd.compliance.kaldi as K
     fn, kw = META[name]["fn"], META[name]["kw"]
     wav = torch.tensor(G["wav"]).cuda()
+    if "noise" in META[name]:       # feed the reference's recorded dither draw
+        rec = torch.tensor(G[META[name]["noise"]])
+        monkeypatch.setattr(K, "_randn", lambda shape, device, dtype: rec.to(device=device, dtype=dtype).reshape(shape))
     with torch.no_grad():
         y = getattr(K, fn)(wav, **kw)
     _close(y.cpu().numpy(), G[name], linear=(fn == "fbank" and kw.get("use_log_fbank") is False))
 
 
 @pytest.mark.gpu
+def test_gpu_kaldi_dither_draws_like_the_reference():
+    """dither != 0: the noise is torch.randn(frames.shape) on the waveform's device, as in kaldi.py:180-183 -- a seeded call
+    is reproducible, two calls differ, and the features move by about what unit-variance noise on 16-bit audio does."""
+    import audio_amd.compliance.kaldi as K
+    wav = torch.tensor(G["wav"]).cuda()
+    torch.manual_seed(3)
+    a = K.fbank(wav, dither=1.0)
+    torch.manual_seed(3)
+    b = K.fbank(wav, dither=1.0)
+    c = K.fbank(wav, dither=1.0)
+    clean = K.fbank(wav, dither=0.0)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert 0.0 < float((a - clean).abs().max()) < 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["fbank_default", "fbank_44k", "spec_rect_nosnip", "mfcc_energy_htk"])
+def test_gpu_generic_kaldi_kernel_equals_register_fft_kernel(name):
+    import audio_amd.compliance.kaldi as K
+    from audio_amd import _lib
+    fn, kw = META[name]["fn"], META[name]["kw"]
+    wav = torch.tensor(G["wav"]).cuda()
+    fast = getattr(K, fn)(wav, **kw)
+    with _lib.kernel_policy(_lib.POLICY_FORCE_GENERIC):
+        gen = getattr(K, fn)(wav, **kw)
+    _close(gen.cpu().numpy(), G[name], linear=(fn == "fbank" and kw.get("use_log_fbank") is False))
+    assert float((gen - fast).abs().max()) <= 2e-3
+
+
+@pytest.mark.gpu
 def test_gpu_kaldi_errors_and_edges():
     import audio_amd.compliance.kaldi as K
     wav = torch.randn(1, 8000).cuda() * 1000
-    with pytest.raises(NotImplementedError):
-        K.fbank(wav, dither=1.0)
-    with pytest.raises(NotImplementedError):
-        K.fbank(wav, sample_frequency=4000.0)               # 100 -> 128: outside the register-FFT sizes
+    assert K.fbank(wav, sample_frequency=4000.0).shape == (198, 23)        # 100 -> 128: the generic kernel serves it
+    with pytest.raises(AssertionError):
+        K.fbank(wav, frame_length=25.06, round_to_power_of_two=False)      # 401 samples: odd padded window (reference assertion)
     with pytest.raises(AssertionError):
         K.fbank(wav[:, :300])                               # shorter than a window (reference assertion)
     with pytest.raises(RuntimeError):
