@@ -1,0 +1,140 @@
+"""Arbitrarily-often differentiable, dtype-generic (float32 / float64) building blocks on the HIP kernels.
+
+The reference guarantees ``gradcheck`` AND ``gradgradcheck`` of its filtering and spectral ops and runs them in float64
+(test/torchaudio_unittest/functional/autograd_impl.py:21-35, transforms/autograd_test_impl.py:30-45).  Its own autograd
+Functions get there by writing every ``backward`` out of differentiable pieces (functional/filtering.py:941-1024:
+``DifferentiableIIR.backward`` calls ``DifferentiableIIR.apply`` on the flipped gradient).  The same construction here:
+
+* each LINEAR operator of the path is a ``torch.autograd.Function`` whose backward is the ``apply`` of its adjoint
+  operator, itself such a Function -- the complex STFT and its adjoint (``aamd_spectrogram_* power <= 0`` /
+  ``aamd_istft_*(adjoint=1)``) differentiate into each other for ever;
+* everything non-linear around them (|X|^p, the filterbank product, dB, clamp) is ordinary torch arithmetic on the
+  kernels' outputs, so autograd differentiates it to any order.
+
+The fused float32 Functions of functional.py (one launch forward, three backward) stay the fast first-order path; their
+``backward`` switches to these blocks when it runs under ``create_graph=True``.  float64 inputs take these blocks in the
+forward pass too: float64 is the precision path (generic kernels, csrc/f64_paths.h), not the throughput path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import _host, _lib
+
+FLOATS = (torch.float32, torch.float64)
+
+
+def _suffix(dtype) -> str:
+    return "f64" if dtype == torch.float64 else "f32"
+
+
+def twiddles(n_fft: int, device, dtype) -> Tensor:
+    from . import functional as F
+    if dtype == torch.float32:
+        return F._twiddles(n_fft, device)
+
+    def make():
+        t = np.arange(n_fft, dtype=np.float64)
+        ang = 2.0 * np.pi * t / n_fft
+        return torch.from_numpy(np.stack([np.cos(ang), -np.sin(ang)], axis=1)).to(device).contiguous()
+    return F._cached(("tw64", n_fft, str(device)), make)
+
+
+Cfg = Tuple[int, int, int, bool, str]     # n_fft, hop, pad, center, pad_mode
+
+
+def _desc(rows: int, length: int, cfg: Cfg, n_frames: int, scale: float = 1.0):
+    n_fft, hop, pad, center, pad_mode = cfg
+    return _lib.StftDesc(rows, length, max(length, 1), n_fft, hop, pad, int(center), _lib.PAD_MODES[pad_mode], 1, n_frames,
+                         scale, 0.0)
+
+
+def n_frames_of(length: int, cfg: Cfg) -> int:
+    n_fft, hop, pad, center, _ = cfg
+    return _host.frame_count(length, n_fft, hop, center, pad)
+
+
+class Stft(torch.autograd.Function):
+    """x (rows, L) -> X (rows, T, F, 2): the onesided complex STFT with unit scale.  Linear; backward = StftAdjoint."""
+
+    @staticmethod
+    def forward(ctx, x2: Tensor, wp: Tensor, cfg: Cfg):
+        x2 = x2.contiguous()
+        rows, length = x2.shape
+        T = n_frames_of(length, cfg)
+        n_freq = cfg[0] // 2 + 1
+        out = torch.empty((rows, T, n_freq, 2), dtype=x2.dtype, device=x2.device)
+        if out.numel():
+            entry = getattr(_lib.lib(), "aamd_spectrogram_" + _suffix(x2.dtype))
+            d = _desc(rows, length, cfg, T)
+            with torch.cuda.device(x2.device):
+                _lib.check(entry(x2.data_ptr(), wp.data_ptr(), twiddles(cfg[0], x2.device, x2.dtype).data_ptr(),
+                                 out.data_ptr(), C.byref(d), _lib.current_stream(x2.device)))
+        ctx.save_for_backward(wp)
+        ctx.cfg, ctx.length = cfg, length
+        return out
+
+    @staticmethod
+    def backward(ctx, dX):
+        (wp,) = ctx.saved_tensors
+        return StftAdjoint.apply(dX, wp, ctx.cfg, ctx.length), None, None
+
+
+class StftAdjoint(torch.autograd.Function):
+    """G (rows, T, F, 2) -> x (rows, L): the exact adjoint of Stft (padding map run backwards).  backward = Stft."""
+
+    @staticmethod
+    def forward(ctx, G: Tensor, wp: Tensor, cfg: Cfg, length: int):
+        G = G.contiguous()
+        rows, T = G.shape[0], G.shape[1]
+        out = torch.zeros((rows, length), dtype=G.dtype, device=G.device)
+        if out.numel() and T:
+            entry = getattr(_lib.lib(), "aamd_istft_" + _suffix(G.dtype))
+            d = _desc(rows, length, cfg, T)
+            with torch.cuda.device(G.device):
+                _lib.check(entry(G.data_ptr(), wp.data_ptr(), twiddles(cfg[0], G.device, G.dtype).data_ptr(), None,
+                                 out.data_ptr(), C.byref(d), 1, _lib.current_stream(G.device)))
+        ctx.save_for_backward(wp)
+        ctx.cfg = cfg
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        (wp,) = ctx.saved_tensors
+        return Stft.apply(dx, wp, ctx.cfg), None, None, None
+
+
+def stft_complex(x2: Tensor, wp: Tensor, cfg: Cfg) -> Tensor:
+    """(rows, L) -> complex (rows, T, F), differentiable to any order."""
+    return torch.view_as_complex(Stft.apply(x2, wp, cfg))
+
+
+def spectrogram(waveform: Tensor, pad: int, window: Tensor, n_fft: int, hop_length: int, win_length: int, power,
+                normalized, center: bool, pad_mode: str) -> Tensor:
+    """The reference composition (functional/functional.py:112-145) with torch.stft replaced by `Stft`:
+    (..., L) -> (..., F, T) in the waveform's dtype (float32 or float64)."""
+    from . import functional as F
+    frame_length_norm, window_norm = F._get_spec_norms(normalized)
+    shape = waveform.size()
+    x2 = waveform.reshape(-1, shape[-1])
+    w = window.to(device=waveform.device, dtype=waveform.dtype)
+    wp = _host.center_pad_window(w.detach(), n_fft).contiguous()
+    if pad_mode not in _lib.PAD_MODES:
+        raise NotImplementedError(f"audio_amd: pad_mode {pad_mode!r} is not supported")
+    spec_f = stft_complex(x2, wp, (n_fft, hop_length, pad, bool(center), pad_mode))       # (rows, T, F)
+    if frame_length_norm:
+        spec_f = spec_f * (float(n_fft) ** -0.5)
+    if window_norm:
+        spec_f = spec_f / w.pow(2.0).sum().sqrt()
+    spec_f = spec_f.transpose(-1, -2)
+    spec_f = spec_f.reshape(tuple(shape[:-1]) + spec_f.shape[-2:])
+    if power is not None:
+        if power == 1.0:
+            return spec_f.abs()
+        return spec_f.abs().pow(power)
+    return spec_f

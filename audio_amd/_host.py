@@ -288,13 +288,16 @@ def resample_adjoint_table(kernel: np.ndarray, orig: int, new: int, width: int):
         W' = A new,  A = ceil(width / orig),  k' = (A - d) new + p  <->  h[p][d orig + r + width]
     (d = q' - q is the block offset between the input sample and the output block it contributed to).
     Returns (h' float32[orig][2 W' + new], W')."""
-    h = np.asarray(kernel, dtype=np.float32).reshape(new, -1)
+    h = np.asarray(kernel)
+    if h.dtype not in (np.float32, np.float64):
+        h = h.astype(np.float32)
+    h = h.reshape(new, -1)
     taps = h.shape[1]
     assert taps == 2 * width + orig
     A = -(-width // orig)
     Wp = A * new
     tp = 2 * Wp + new
-    out = np.zeros((orig, tp), dtype=np.float32)
+    out = np.zeros((orig, tp), dtype=h.dtype)
     r = np.arange(orig)[:, None]
     kp = np.arange(tp)[None, :]
     d = A - kp // new

@@ -93,6 +93,14 @@ _SIGS = {
                                            C.c_int32, C.c_int64, C.POINTER(ResampleBands), _P]),
     "aamd_lfilter_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, _P]),
+    "aamd_spectrogram_f64": (C.c_int, [_P, _P, _P, _P, C.POINTER(StftDesc), _P]),
+    "aamd_istft_f64": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(StftDesc), C.c_int32, _P]),
+    "aamd_lfilter_f64": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, _P]),
+    "aamd_resample_f64": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int64, _P]),
+    "aamd_fftconvolve_f64": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
+                                       C.c_int64, C.c_int64, _P]),
     "aamd_fftconvolve_workspace": (C.c_int64, [C.c_int64] * 5),
     "aamd_fftconvolve_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
                                        C.c_int64, C.c_int64, _P, _P]),

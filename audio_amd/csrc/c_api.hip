@@ -13,6 +13,7 @@
 
 #include "../../include/audio_amd.h"
 #include "db_mfcc.h"
+#include "f64_paths.h"
 #include "fftconv.h"
 #include "fftconv_os.h"
 #include "istft.h"
@@ -695,6 +696,121 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGenThreads), lds, (hipStream_t)stream, og, spec, window,
                      reinterpret_cast<const cplx<float>*>(twiddle), inv_envelope, out, pb, bpr);
+  return launch_check();
+}
+
+// ---- float64 entry points (csrc/f64_paths.h): autograd / gradcheck precision, not throughput ------------------------
+
+int aamd_spectrogram_f64(const double* wav, const double* window, const double* twiddle, double* out,
+                         const aamd_stft_desc* desc, void* stream) {
+  DeviceScope dev_scope_(wav);
+  StftGeom g;
+  int rc = validate_desc(desc, g);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(wav && window && twiddle && out, "null buffer");
+  if (g.rows == 0) return AAMD_OK;
+  int pb = gen_pairs_per_block(g.n_fft);
+  const int pairs_per_row = (g.n_frames + 1) / 2;
+  if (pb > pairs_per_row) pb = pairs_per_row;
+  size_t lds = gen_lds_floats(g.n_fft, g.n_freq, pb) * sizeof(double);
+  while (lds > dev_props().lds_per_block_optin && pb > 1) {
+    pb /= 2;
+    lds = gen_lds_floats(g.n_fft, g.n_freq, pb) * sizeof(double);
+  }
+  if (lds > dev_props().lds_per_block_optin) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft too large for the LDS (float64)");
+  const int bpr = (pairs_per_row + pb - 1) / pb;
+  const int64_t blocks = g.rows * bpr;
+  AAMD_CHECK_ARG(blocks < (1ll << 31), "too many frames for one launch");
+  auto kern = stft_generic_kernel<double, EPI_SPEC>;
+  if (lds > 48 * 1024)
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  MelBandsDev mb{};
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGenThreads), lds, (hipStream_t)stream, g, wav, window,
+                     reinterpret_cast<const cplx<double>*>(twiddle), mb, out, pb, bpr);
+  return launch_check();
+}
+
+int aamd_istft_f64(const double* spec, const double* window, const double* twiddle, const double* inv_envelope,
+                   double* out, const aamd_stft_desc* desc, int32_t adjoint, void* stream) {
+  DeviceScope dev_scope_(spec);
+  AAMD_CHECK_ARG(desc != nullptr && spec && window && twiddle && out, "null buffer");
+  AAMD_CHECK_ARG(desc->rows >= 0 && desc->length >= 0 && desc->n_frames >= 0, "negative sizes");
+  AAMD_CHECK_ARG(desc->n_fft >= 2 && desc->hop >= 1 && desc->pad >= 0, "n_fft must be >= 2, hop >= 1, pad >= 0");
+  AAMD_CHECK_ARG(desc->pad_mode >= 0 && desc->pad_mode <= 3, "bad pad_mode");
+  if (!desc->onesided) return fail(AAMD_EUNSUPPORTED, "audio_amd: inverse STFT needs a onesided spectrum");
+  if (desc->rows == 0 || desc->length == 0 || desc->n_frames == 0) return AAMD_OK;
+  OlaGeom og{};
+  StftGeom& g = og.g;
+  g.rows = desc->rows; g.length = desc->length; g.row_stride = desc->length;
+  g.n_fft = desc->n_fft; g.hop = desc->hop; g.pad = desc->pad; g.center = desc->center;
+  g.pad_mode = desc->pad_mode; g.onesided = 1; g.n_frames = desc->n_frames;
+  g.n_freq = desc->n_fft / 2 + 1;
+  g.scale = 1.0f; g.power = 0.0f;
+  g.n_stages = plan_radices(desc->n_fft, g.radix);
+  if (g.n_stages < 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft has too many prime factors");
+  og.interior = adjoint ? 0.5f : 1.0f;
+  og.scale = desc->scale * (adjoint ? 1.0f : 1.0f / (float)desc->n_fft);
+  int pb = gen_pairs_per_block(g.n_fft);
+  const int pairs_per_row = (g.n_frames + 1) / 2;
+  if (pb > pairs_per_row) pb = pairs_per_row;
+  size_t lds = ((size_t)2 * g.n_fft + (size_t)4 * pb * gen_seq_len(g.n_fft)) * sizeof(double);
+  while (lds > dev_props().lds_per_block_optin && pb > 1) {
+    pb /= 2;
+    lds = ((size_t)2 * g.n_fft + (size_t)4 * pb * gen_seq_len(g.n_fft)) * sizeof(double);
+  }
+  if (lds > dev_props().lds_per_block_optin) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft too large for the LDS (float64)");
+  const int bpr = (pairs_per_row + pb - 1) / pb;
+  const int64_t blocks = g.rows * bpr;
+  AAMD_CHECK_ARG(blocks < (1ll << 31), "too many frames for one launch");
+  auto kern = ola_kernel<double>;
+  if (lds > 48 * 1024)
+    AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kGenThreads), lds, (hipStream_t)stream, og, spec, window,
+                     reinterpret_cast<const cplx<double>*>(twiddle), inv_envelope, out, pb, bpr);
+  return launch_check();
+}
+
+int aamd_lfilter_f64(const double* x, const double* a, const double* b, double* y, int64_t batch, int32_t channels,
+                     int64_t length, int32_t n_order, int32_t n_coeff_rows, int32_t n_stages, int32_t clamp, void* stream) {
+  DeviceScope dev_scope_(x);
+  AAMD_CHECK_ARG(x && a && b && y, "null buffer");
+  AAMD_CHECK_ARG(batch >= 0 && channels >= 1 && length >= 0 && n_order >= 1, "bad sizes");
+  AAMD_CHECK_ARG(n_coeff_rows == 1 || n_coeff_rows == channels, "coefficient rows must be 1 or channels");
+  if (n_stages != 1) return fail(AAMD_EUNSUPPORTED, "audio_amd: float64 lfilter runs one stage per call");
+  const int64_t n_seq = batch * channels;
+  if (n_seq == 0 || length == 0) return AAMD_OK;
+  AAMD_CHECK_ARG((n_seq + 63) / 64 < (1ll << 31), "too many sequences for one launch");
+  hipLaunchKernelGGL(f64::lfilter_kernel, dim3((unsigned)((n_seq + 63) / 64)), dim3(64), 0, (hipStream_t)stream, x, a, b, y,
+                     n_seq, channels, length, n_order, n_coeff_rows, clamp);
+  return launch_check();
+}
+
+int aamd_resample_f64(const double* wav, const double* kernel, double* out, int64_t rows, int64_t length,
+                      int64_t row_stride, int32_t orig, int32_t new_, int32_t width, int64_t out_len, void* stream) {
+  DeviceScope dev_scope_(wav);
+  AAMD_CHECK_ARG(wav && kernel && out, "null buffer");
+  AAMD_CHECK_ARG(rows >= 0 && length >= 0 && orig >= 1 && new_ >= 1 && width >= 0 && out_len >= 0 && row_stride >= length,
+                 "bad sizes");
+  const int64_t n = rows * out_len;
+  if (n == 0) return AAMD_OK;
+  AAMD_CHECK_ARG((n + 255) / 256 < (1ll << 31), "too many samples for one launch");
+  hipLaunchKernelGGL(f64::resample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wav, kernel,
+                     out, rows, length, row_stride, orig, new_, width, out_len);
+  return launch_check();
+}
+
+int aamd_fftconvolve_f64(const double* x, const double* y, double* out, int64_t rows, int64_t n_x_rows, int64_t n_y_rows,
+                         int64_t nx, int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of, int64_t start,
+                         int64_t out_len, void* stream) {
+  DeviceScope dev_scope_(x);
+  AAMD_CHECK_ARG(x && y && out, "null buffer");
+  AAMD_CHECK_ARG(rows >= 0 && nx >= 1 && ny >= 1 && start >= 0 && out_len >= 0 && start + out_len <= nx + ny - 1, "bad sizes");
+  AAMD_CHECK_ARG((x_row_of != nullptr || n_x_rows == rows) && (y_row_of != nullptr || n_y_rows == rows), "row maps missing");
+  const int64_t n = rows * out_len;
+  if (n == 0) return AAMD_OK;
+  AAMD_CHECK_ARG((n + 255) / 256 < (1ll << 31), "too many samples for one launch");
+  hipLaunchKernelGGL(f64::conv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, out, rows,
+                     nx, ny, x_row_of, y_row_of, start, out_len);
   return launch_check();
 }
 

@@ -23,6 +23,7 @@ from torch import Tensor
 from . import _host
 from . import _lib
 from . import _shim
+from . import _diff
 from ._host import create_dct, melscale_fbanks  # noqa: F401  (re-exported, host-side constants)
 
 __all__ = [
@@ -37,13 +38,16 @@ __all__ = [
 # --------------------------------------------------------------------------- #
 
 
-def _require_device(t: Tensor, what: str, allow_grad: bool = False) -> None:
+def _require_device(t: Tensor, what: str, allow_grad: bool = False, allow_f64: bool = False) -> None:
     if not t.is_cuda:
         raise RuntimeError(
             f"audio_amd: {what} must be on an MI355X (ROCm) device, got {t.device}. "
             "The HIP kernels have no CPU fallback.")
-    if t.dtype != torch.float32:
-        raise TypeError(f"audio_amd: {what} must be float32 (got {t.dtype}); kernels compute in fp32.")
+    if t.dtype == torch.float64 and allow_f64:
+        pass       # precision path: generic float64 kernels (csrc/f64_paths.h), differentiable to any order (_diff.py)
+    elif t.dtype != torch.float32:
+        raise TypeError(f"audio_amd: {what} must be float32{' or float64' if allow_f64 else ''} (got {t.dtype}); "
+                        "kernels compute in fp32.")
     if t.requires_grad and torch.is_grad_enabled() and not allow_grad:
         raise RuntimeError("audio_amd: this op is forward-only (autograd: spectrogram family, lfilter / biquad, fftconvolve, resample); "
                            "wrap the call in torch.no_grad().")
@@ -268,13 +272,19 @@ def spectrogram(
             "complex dtype. Please remove the argument in the function call."
         )
     _reject_param_grad(window=window)
-    _require_device(waveform, "waveform", allow_grad=True)
+    _require_device(waveform, "waveform", allow_grad=True, allow_f64=True)
     if window.shape[0] != win_length:
         raise RuntimeError(
             f"stft: expected a 1D window tensor of size equal to win_length={win_length}, "
             f"but got window with size {list(window.shape)}")
     if not 0 < win_length <= n_fft:
         raise RuntimeError(f"stft: expected 0 < win_length <= n_fft, but got win_length={win_length}")
+    if waveform.dtype == torch.float64:
+        if not onesided:
+            raise NotImplementedError("audio_amd: float64 spectrograms are onesided only")
+        _stft_desc(_rows2d(waveform), pad, window.to(waveform.device), n_fft, hop_length, power, normalized, center, pad_mode,
+                   True)                       # the reference's argument checks and error messages
+        return _diff.spectrogram(waveform, pad, window, n_fft, hop_length, win_length, power, normalized, center, pad_mode)
     window = window.to(device=waveform.device, dtype=torch.float32)
     shape = waveform.size()
     x2 = _rows2d(waveform)
@@ -361,6 +371,14 @@ class _MelSpectrogramFunction(torch.autograd.Function):
         x2, window, fb = ctx.saved_tensors
         pad, n_fft, hop_length, win_length, power, normalized, center, pad_mode = ctx.args
         dev = x2.device
+        if torch.is_grad_enabled():
+            # create_graph=True (gradgradcheck, higher-order use): the same gradient out of differentiable pieces --
+            # d/dx of  mel = |scale * Stft(x)|^p . fb  through autograd over `_diff.Stft` (reference composition)
+            with torch.enable_grad():
+                spec = _diff.spectrogram(x2, pad, window, n_fft, hop_length, win_length, power, normalized, center, pad_mode)
+                mel = torch.matmul(spec.transpose(-1, -2), fb.to(dev))            # (rows, T, n_mels)
+                (dx,) = torch.autograd.grad(mel, x2, dy, create_graph=True)
+            return dx, None, None, None
         window = window.to(device=dev, dtype=torch.float32)
         desc = _stft_desc(x2, pad, window, n_fft, hop_length, power, normalized, center, pad_mode, True)
         wp = _padded_window(window, n_fft)
@@ -395,6 +413,17 @@ class _SpectrogramFunction(torch.autograd.Function):
         x2, window_padded = ctx.saved_tensors
         desc, power = ctx.desc, ctx.power
         n_freq = desc.n_fft // 2 + 1
+        if torch.is_grad_enabled():
+            # create_graph=True: differentiate the differentiable composition instead (see _MelSpectrogramFunction)
+            pm = [k for k, v in _lib.PAD_MODES.items() if v == desc.pad_mode][0]
+            with torch.enable_grad():
+                X = _diff.stft_complex(x2, window_padded, (desc.n_fft, desc.hop, desc.pad, bool(desc.center), pm)) * desc.scale
+                if power is None:
+                    Y = torch.view_as_real(X).reshape(X.shape[0], X.shape[1], -1)
+                else:
+                    Y = X.abs() if power == 1.0 else X.abs().pow(power)
+                (dx,) = torch.autograd.grad(Y, x2, dy, create_graph=True)
+            return dx, None, None, None
         dy = dy.contiguous()
         if power is None:
             G = dy                                             # (rows, T, n_freq * 2): dL/dRe, dL/dIm interleaved
@@ -807,6 +836,11 @@ def _dct_rows(x: Tensor, dct: Tensor) -> Tensor:
 
 def mel_scale(specgram: Tensor, fb: Tensor) -> Tensor:
     """MelScale.forward (transforms/_transforms.py:403-415): (..., freq, time) -> (..., n_mels, time)."""
+    if specgram.is_cuda and (specgram.dtype == torch.float64 or (torch.is_grad_enabled() and specgram.requires_grad)):
+        # precision / training path of this thin caller: the reference's own product, differentiable to any order
+        # (the fused MelSpectrogram kernel is the throughput path; test: transforms/autograd_test_impl.py test_melscale)
+        _reject_param_grad(fb=fb)
+        return torch.matmul(specgram.transpose(-1, -2), fb.to(device=specgram.device, dtype=specgram.dtype)).transpose(-1, -2)
     _require_device(specgram, "specgram")
     shape = specgram.shape
     n_freq, T = shape[-2], shape[-1]
@@ -834,6 +868,18 @@ def amplitude_to_DB(x: Tensor, multiplier: float, amin: float, db_multiplier: fl
                     top_db: Optional[float] = None) -> Tensor:
     r"""Power/amplitude -> decibel (functional/functional.py:356-404).  With ``top_db`` the cut-off
     is per leading item of the ``(-1, C, F, T)`` view, ``C = shape[-3]`` if ``x.dim() > 2`` else 1."""
+    if x.is_cuda and (x.dtype == torch.float64 or (torch.is_grad_enabled() and x.requires_grad)):
+        # precision / training path: the reference's element-wise formula (functional.py:390-402), so that autograd
+        # reproduces its clamp / amax sub-gradients to any order (test: autograd_test_impl.py test_amplitude_to_db)
+        x_db = multiplier * torch.log10(torch.clamp(x, min=amin))
+        x_db = x_db - multiplier * db_multiplier
+        if top_db is not None:
+            shape = x_db.size()
+            packed_channels = shape[-3] if x_db.dim() > 2 else 1
+            x_db = x_db.reshape(-1, packed_channels, shape[-2], shape[-1])
+            x_db = torch.max(x_db, (x_db.amax(dim=(-3, -2, -1)) - top_db).view(-1, 1, 1, 1))
+            x_db = x_db.reshape(shape)
+        return x_db
     _require_device(x, "x")
     # The op is element-wise plus a maximum over whole (C, F, T) blocks, so it runs in MEMORY order: the frame-major
     # tensors Spectrogram / MelSpectrogram / MelScale return ((..., F, T) views of (..., T, F) storage) are processed
@@ -874,6 +920,15 @@ def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new
     """(rows, L) -> (rows, ceil(new L / orig)) through aamd_resample_banded_f32; band table cached per tensor."""
     rows, length = x2.shape
     out_len = int(math.ceil(new * length / orig))
+    if x2.dtype == torch.float64:
+        x2 = x2.contiguous()
+        out = torch.empty((rows, out_len), dtype=torch.float64, device=x2.device)
+        if out.numel():
+            with torch.cuda.device(x2.device):
+                _lib.check(_lib.lib().aamd_resample_f64(x2.data_ptr(), kern.data_ptr(), out.data_ptr(), rows, length,
+                                                       max(length, 1), orig, new, width, out_len,
+                                                       _lib.current_stream(x2.device)))
+        return out
     # band table of the taps (host, once per kernel tensor): the matrix-core kernel skips the
     # ~1e-20-sized window tails outside each phase tile's band
     tap_lo, span = _tensor_cached(key_tensor, ("rs_bands", key, new),
@@ -912,7 +967,10 @@ class _ResampleFunction(torch.autograd.Function):
             (torch.from_numpy(t).to(dy.device) if isinstance(t, np.ndarray) else t)
             for t in _host.resample_adjoint_table(ctx.kern.cpu().numpy(), orig, new, width)))
         kern_adj, width_adj = adj
-        dx = _polyphase(dy.contiguous(), kern_adj, kern_adj, "adj", new, orig, int(width_adj))
+        if torch.is_grad_enabled():      # create_graph=True: the adjoint is the same kind of operator -- apply it differentiably
+            dx = _ResampleFunction.apply(dy.contiguous(), kern_adj, kern_adj, new, orig, int(width_adj))
+        else:
+            dx = _polyphase(dy.contiguous(), kern_adj, kern_adj, "adj", new, orig, int(width_adj))
         return dx[:, :ctx.length], None, None, None, None, None
 
 
@@ -921,12 +979,12 @@ def _apply_sinc_resample_kernel(waveform: Tensor, orig_freq: int, new_freq: int,
     """functional/functional.py:1405-1432 as one polyphase HIP kernel (differentiable in the waveform)."""
     if not waveform.is_floating_point():
         raise TypeError(f"Expected floating point type for waveform tensor, but received {waveform.dtype}.")
-    _require_device(waveform, "waveform", allow_grad=True)
+    _require_device(waveform, "waveform", allow_grad=True, allow_f64=True)
     orig = int(orig_freq) // gcd
     new = int(new_freq) // gcd
     shape = waveform.size()
     x2 = _rows2d(waveform)
-    kern = kernel.to(device=waveform.device, dtype=torch.float32).reshape(new, -1).contiguous()
+    kern = kernel.to(device=waveform.device, dtype=waveform.dtype).reshape(new, -1).contiguous()
     if kern.shape[1] != 2 * width + orig:
         raise RuntimeError("audio_amd: resample kernel shape does not match (new, 2*width+orig)")
     if torch.is_grad_enabled() and waveform.requires_grad:
@@ -972,6 +1030,16 @@ def resample(
 def _lfilter_launch(x3: Tensor, a: Tensor, b: Tensor, clamp: bool, n_stages: int = 1) -> Tensor:
     """x3: (batch, channels, L) contiguous; a, b: (n_stages, rows, n_order)."""
     batch, channels, length = x3.shape
+    if x3.dtype == torch.float64:
+        if n_stages != 1:
+            raise NotImplementedError("audio_amd: float64 lfilter runs one stage per call")
+        y = torch.empty_like(x3)
+        if y.numel():
+            with torch.cuda.device(x3.device):
+                _lib.check(_lib.lib().aamd_lfilter_f64(x3.data_ptr(), a.data_ptr(), b.data_ptr(), y.data_ptr(), batch,
+                                                      channels, length, a.shape[-1], a.shape[-2], 1, int(clamp),
+                                                      _lib.current_stream(x3.device)))
+        return y
     ops = _ops()
     if ops is not None:
         return ops.lfilter(x3, a.reshape(n_stages, -1, a.shape[-1]), b.reshape(n_stages, -1, b.shape[-1]), n_stages,
@@ -1009,13 +1077,21 @@ class _LFilterFunction(torch.autograd.Function):
         if ctx.clamp:
             g = g * ((y >= -1.0) & (y <= 1.0)).to(g.dtype)
         gf = g.flip(-1).contiguous()
+        # Under create_graph=True (gradgradcheck) every piece below must itself be differentiable: the adjoint filters are
+        # then applied through this very Function (as the reference's DifferentiableIIR.backward calls
+        # DifferentiableIIR.apply, filtering.py:1000-1017) and `y` is the graph-connected output it saved.
+        if torch.is_grad_enabled():
+            run = lambda t, aa, bb: _LFilterFunction.apply(t, aa, bb, False)                      # noqa: E731
+            y = run(x3, a_n, b_n)        # graph-connected copy of the unclamped output (da below depends on it)
+        else:
+            run = lambda t, aa, bb: _lfilter_launch(t, aa.unsqueeze(0), bb.unsqueeze(0), False)   # noqa: E731
         dx = da = db = None
         if ctx.needs_input_grad[0]:
-            dx = _lfilter_launch(gf, a_n.unsqueeze(0), b_n.unsqueeze(0), False).flip(-1)
+            dx = run(gf, a_n, b_n).flip(-1)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             one = torch.zeros_like(b_n)
             one[:, 0] = 1.0
-            dw = _lfilter_launch(gf, a_n.unsqueeze(0), one.unsqueeze(0), False).flip(-1)
+            dw = run(gf, a_n, one).flip(-1)
             n_order, L = a_n.shape[1], x3.shape[-1]
             if ctx.needs_input_grad[2]:
                 db = torch.stack([(dw[..., k:] * x3[..., :L - k]).sum((0, 2)) for k in range(n_order)], 1)
@@ -1051,12 +1127,12 @@ def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = 
         a_coeffs = a_coeffs.unsqueeze(0)
         b_coeffs = b_coeffs.unsqueeze(0)
     needs_grad = torch.is_grad_enabled() and (waveform.requires_grad or a_coeffs.requires_grad or b_coeffs.requires_grad)
-    _require_device(waveform, "waveform", allow_grad=True)
+    _require_device(waveform, "waveform", allow_grad=True, allow_f64=True)
     shape = waveform.size()
     n_filt = a_coeffs.shape[0]
     x3 = waveform.reshape(-1, n_filt, shape[-1]).contiguous()
-    a = a_coeffs.to(device=waveform.device, dtype=torch.float32).contiguous()
-    b = b_coeffs.to(device=waveform.device, dtype=torch.float32).contiguous()
+    a = a_coeffs.to(device=waveform.device, dtype=waveform.dtype).contiguous()
+    b = b_coeffs.to(device=waveform.device, dtype=waveform.dtype).contiguous()
     if needs_grad:
         # differentiable path (functional/filtering.py:941-1029): normalise by a0 with torch ops so that
         # autograd sees the division, the recursion and its adjoint run in the HIP kernel
@@ -1091,6 +1167,8 @@ def _cpu_scalar(v, dtype) -> Tensor:
     """0-dim CPU tensor of the waveform dtype (the reference builds its coefficients with
     ``torch.as_tensor(v, dtype=waveform.dtype)`` scalars; doing it on the host avoids launches)."""
     if isinstance(v, Tensor):
+        if v.requires_grad and torch.is_grad_enabled():
+            return v.to(device="cpu", dtype=dtype).reshape(())     # a learnable filter parameter: stay on the graph
         return v.detach().to(device="cpu", dtype=dtype).reshape(())
     return torch.as_tensor(v, dtype=dtype)
 
@@ -1258,6 +1336,15 @@ def _conv_slice(x: Tensor, y: Tensor, start: int, out_len: int) -> Tensor:
         return idx.expand(lead).reshape(-1).contiguous()
 
     xmap, ymap = row_map(x, xr.shape[0]), row_map(y, yr.shape[0])
+    if x.dtype == torch.float64:
+        out = torch.empty((rows, out_len), dtype=torch.float64, device=x.device)
+        if out.numel():
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.lib().aamd_fftconvolve_f64(
+                    xr.data_ptr(), yr.data_ptr(), out.data_ptr(), rows, xr.shape[0], yr.shape[0], nx, ny,
+                    xmap.data_ptr() if xmap is not None else None, ymap.data_ptr() if ymap is not None else None,
+                    start, out_len, _lib.current_stream(x.device)))
+        return out.view(tuple(lead) + (out_len,))
     ops = _ops()
     if ops is not None:
         return ops.fftconvolve(xr, yr, xmap, ymap, rows, start, out_len).view(tuple(lead) + (out_len,))
@@ -1290,13 +1377,14 @@ class _FFTConvolveFunction(torch.autograd.Function):
     def backward(ctx, dz):
         x, y = ctx.saved_tensors
         nx, ny = x.size(-1), y.size(-1)
-        full = torch.zeros(tuple(dz.shape[:-1]) + (nx + ny - 1,), dtype=dz.dtype, device=dz.device)
-        full[..., ctx.start:ctx.start + ctx.out_len] = dz
+        full = torch.nn.functional.pad(dz, (ctx.start, nx + ny - 1 - ctx.start - ctx.out_len))   # dz at offset `start`
+        # create_graph=True: both adjoints are convolutions again -- apply them through this Function
+        conv = _FFTConvolveFunction.apply if torch.is_grad_enabled() else _conv_slice
         dx = dy = None
         if ctx.needs_input_grad[0]:
-            dx = _conv_slice(full, y.flip(-1), ny - 1, nx).sum_to_size(x.shape)
+            dx = conv(full, y.flip(-1), ny - 1, nx).sum_to_size(x.shape)
         if ctx.needs_input_grad[1]:
-            dy = _conv_slice(full, x.flip(-1), nx - 1, ny).sum_to_size(y.shape)
+            dy = conv(full, x.flip(-1), nx - 1, ny).sum_to_size(y.shape)
         return dx, dy, None, None
 
 
@@ -1309,8 +1397,10 @@ def fftconvolve(x: Tensor, y: Tensor, mode: str = "full") -> Tensor:
         x = x.float()
     if not y.is_floating_point():
         y = y.float()
-    _require_device(x, "x", allow_grad=True)
-    _require_device(y, "y", allow_grad=True)
+    _require_device(x, "x", allow_grad=True, allow_f64=True)
+    _require_device(y, "y", allow_grad=True, allow_f64=True)
+    if x.dtype != y.dtype:
+        raise TypeError(f"audio_amd: fftconvolve operands must share a dtype (got {x.dtype} and {y.dtype})")
     nx, ny = x.size(-1), y.size(-1)
     n_full = nx + ny - 1
     if mode == "full":

@@ -346,6 +346,9 @@ class MelSpectrogram(torch.nn.Module):
 
     def forward(self, waveform: Tensor) -> Tensor:
         F._reject_param_grad(window=self.spectrogram.window, fb=self.mel_scale.fb)
+        if waveform.dtype == torch.float64 and waveform.is_cuda:
+            # precision path: the reference composition (_transforms.py:612-622) over the float64 STFT kernels
+            return self.mel_scale(self.spectrogram(waveform))
         if torch.is_grad_enabled() and waveform.requires_grad:
             # training mode: the same fused forward launch; backward = filterbank transpose, spectrum cotangent and
             # STFT adjoint, all HIP kernels (F._MelSpectrogramFunction)
@@ -400,8 +403,8 @@ class MFCC(torch.nn.Module):
         F._reject_param_grad(window=self.MelSpectrogram.spectrogram.window, fb=self.MelSpectrogram.mel_scale.fb)
         if not waveform.requires_grad:
             F._reject_param_grad(dct_mat=self.dct_mat)     # (the differentiable path below does propagate into it)
-        if torch.is_grad_enabled() and waveform.requires_grad:
-            # differentiable path (reference composition, _transforms.py:692-709, on top of the
+        if (torch.is_grad_enabled() and waveform.requires_grad) or (waveform.dtype == torch.float64 and waveform.is_cuda):
+            # differentiable / float64 path (reference composition, _transforms.py:692-709, on top of the
             # differentiable mel spectrogram): the dB / top_db / DCT tail is cheap and torch's autograd
             # reproduces the reference's sub-gradients (clamp, amax) exactly
             mel = self.MelSpectrogram(waveform)
@@ -415,7 +418,7 @@ class MFCC(torch.nn.Module):
                 x_db = x_db.reshape(-1, packed, shp[-2], shp[-1])
                 x_db = torch.max(x_db, (x_db.amax(dim=(-3, -2, -1)) - self.top_db).view(-1, 1, 1, 1))
                 mel = x_db.reshape(shp)
-            return torch.matmul(mel.transpose(-1, -2), self.dct_mat.to(mel.device)).transpose(-1, -2)
+            return torch.matmul(mel.transpose(-1, -2), self.dct_mat.to(device=mel.device, dtype=mel.dtype)).transpose(-1, -2)
         sp = self.MelSpectrogram.spectrogram
         a2db = self.amplitude_to_DB
         return F._mfcc(waveform, sp.pad, sp.window, self.MelSpectrogram.mel_scale.fb, self.dct_mat, sp.n_fft,

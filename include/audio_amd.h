@@ -334,6 +334,26 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
                          const int64_t* y_row_of, int64_t start, int64_t out_len, void* workspace,
                          void* stream);
 
+/* ---- float64 ------------------------------------------------------------------------------ */
+
+/* The reference guarantees first- AND second-order gradients of this path and checks them in float64
+ * (test/torchaudio_unittest/functional/autograd_impl.py:21-35, transforms/autograd_test_impl.py:30-45); its native IIR
+ * loop dispatches on double too (libtorchaudio/lfilter.cpp:62-68).  These entries have the semantics of their _f32
+ * namesakes on double buffers.  They are the generic kernels (no shape-specialised fast paths): precision, not
+ * throughput.  aamd_spectrogram_f64: twiddle is double[2 * n_fft]; desc->power <= 0 (complex) or > 0.
+ * aamd_lfilter_f64: n_stages must be 1.  aamd_fftconvolve_f64: direct evaluation, no workspace. */
+int aamd_spectrogram_f64(const double* wav, const double* window, const double* twiddle, double* out,
+                         const aamd_stft_desc* desc, void* stream);
+int aamd_istft_f64(const double* spec, const double* window, const double* twiddle, const double* inv_envelope,
+                   double* out, const aamd_stft_desc* desc, int32_t adjoint, void* stream);
+int aamd_lfilter_f64(const double* x, const double* a, const double* b, double* y, int64_t batch, int32_t channels,
+                     int64_t length, int32_t n_order, int32_t n_coeff_rows, int32_t n_stages, int32_t clamp, void* stream);
+int aamd_resample_f64(const double* wav, const double* kernel, double* out, int64_t rows, int64_t length,
+                      int64_t row_stride, int32_t orig, int32_t new_, int32_t width, int64_t out_len, void* stream);
+int aamd_fftconvolve_f64(const double* x, const double* y, double* out, int64_t rows, int64_t n_x_rows, int64_t n_y_rows,
+                         int64_t nx, int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of, int64_t start,
+                         int64_t out_len, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,183 @@
+"""gradcheck AND gradgradcheck in float64 on the device -- what the reference guarantees for this path and how it tests it
+(test/torchaudio_unittest/functional/autograd_impl.py:21-120, transforms/autograd_test_impl.py:24-135, 183-200, 320-333):
+same inputs (white noise of the same length), same transforms moved to float64 with `.to(dtype=torch.float64)`, default
+gradcheck tolerances.  The float64 kernels are csrc/f64_paths.h + the generic STFT / inverse-STFT kernels instantiated on
+double; every backward is built from differentiable pieces (audio_amd/_diff.py), so the second-order check passes too.
+`nondet_tol` as in the reference: its replication-pad backward, and here the atomic overlap-add of the STFT adjoint, sum in
+a run-dependent order (differences ~1e-17)."""
+from functools import partial
+
+import pytest
+import torch
+from torch.autograd import gradcheck, gradgradcheck
+
+pytestmark = pytest.mark.gpu
+
+
+def _noise(n_channels, n, seed=0, scale=0.3):
+    g = torch.Generator().manual_seed(seed)
+    return (scale * torch.randn(n_channels, n, generator=g)).clamp_(-1, 1)
+
+
+def _assert_grad(fn, inputs, enable_all_grad=True, nondet_tol=0.0):
+    ins = []
+    for i in inputs:
+        if torch.is_tensor(i):
+            req = i.requires_grad
+            i = i.detach().to(dtype=torch.float64, device="cuda")
+            i.requires_grad = True if enable_all_grad else req
+        ins.append(i)
+    assert gradcheck(fn, ins, nondet_tol=nondet_tol)
+    assert gradgradcheck(fn, ins, nondet_tol=nondet_tol)
+
+
+# ---------------------------------------------------------------------------------------------------- lfilter family
+
+A = torch.tensor([0.7, 0.2, 0.6])
+B = torch.tensor([0.4, 0.2, 0.9])
+
+
+@pytest.mark.parametrize("which", ["x", "a", "b", "all"])
+def test_lfilter(which):
+    import audio_amd.functional as F
+    x = _noise(2, 220)           # 22050 Hz x 0.01 s, as the reference
+    a, b = A.clone(), B.clone()
+    if which != "all":
+        {"x": x, "a": a, "b": b}[which].requires_grad = True
+    _assert_grad(F.lfilter, (x, a, b), enable_all_grad=(which == "all"))
+
+
+def test_lfilter_filterbanks_and_batching():
+    import audio_amd.functional as F
+    a = torch.tensor([[0.7, 0.2, 0.6], [0.8, 0.2, 0.9]])
+    b = torch.tensor([[0.4, 0.2, 0.9], [0.7, 0.2, 0.6]])
+    _assert_grad(partial(F.lfilter, batching=False), (_noise(3, 220), a, b))
+    _assert_grad(F.lfilter, (_noise(2, 220), a, b))
+
+
+def test_lfilter_without_clamp_and_float32_second_order_runs():
+    import audio_amd.functional as F
+    _assert_grad(partial(F.lfilter, clamp=False), (_noise(2, 120), A.clone(), B.clone()))
+    # float32: the same differentiable-backward construction (too coarse for gradgradcheck's tolerances, so: it runs and
+    # agrees with the float64 second derivative)
+    x32 = _noise(2, 120).cuda().requires_grad_()
+    a32, b32 = A.cuda().requires_grad_(), B.cuda().requires_grad_()
+    y = F.lfilter(x32, a32, b32)
+    (gx,) = torch.autograd.grad(y.pow(2).sum(), x32, create_graph=True)
+    (ga,) = torch.autograd.grad(gx.pow(2).sum(), a32)
+    x64 = x32.detach().double().requires_grad_()
+    a64, b64 = A.cuda().double().requires_grad_(), B.cuda().double().requires_grad_()
+    y64 = F.lfilter(x64, a64, b64)
+    (gx64,) = torch.autograd.grad(y64.pow(2).sum(), x64, create_graph=True)
+    (ga64,) = torch.autograd.grad(gx64.pow(2).sum(), a64)
+    assert torch.allclose(ga.double(), ga64, rtol=2e-3, atol=1e-4 * float(ga64.abs().max()))
+
+
+@pytest.mark.parametrize("which", ["a", "b", "all"])
+def test_filtfilt(which):
+    import audio_amd.functional as F
+    x = _noise(2, 220)
+    a, b = A.clone(), B.clone()
+    if which != "all":
+        {"a": a, "b": b}[which].requires_grad = True
+    _assert_grad(F.filtfilt, (x, a, b), enable_all_grad=(which == "all"))
+
+
+def test_biquad_and_designers():
+    import audio_amd.functional as F
+    x = _noise(1, 220)
+    _assert_grad(F.biquad, (x, B[0], B[1], B[2], A[0], A[1], A[2]))
+    sr = 22050
+    _assert_grad(lambda w, f, q: F.lowpass_biquad(w, sr, f, q), (x, torch.tensor(4000.0), torch.tensor(0.7)))
+    _assert_grad(lambda w, f, q: F.band_biquad(w, sr, f, q, True), (x, torch.tensor(800.0), torch.tensor(0.7)))
+    _assert_grad(lambda w, g, f, q: F.equalizer_biquad(w, sr, f, g, q), (x, torch.tensor(-6.0), torch.tensor(800.0), torch.tensor(0.7)))
+
+
+# --------------------------------------------------------------------------------------------------------- STFT family
+
+
+@pytest.mark.parametrize("kwargs", [
+    {"pad": 0, "normalized": False, "power": None}, {"pad": 3, "normalized": True, "power": None},
+    {"pad": 0, "normalized": False, "power": 1.0}, {"pad": 3, "normalized": True, "power": 1.0},
+    {"pad": 0, "normalized": False, "power": 2.0}, {"pad": 3, "normalized": False, "power": 2.0},
+    {"pad": 0, "normalized": True, "power": 2.0}, {"pad": 3, "normalized": True, "power": 2.0},
+], ids=str)
+def test_spectrogram(kwargs):
+    import audio_amd.transforms as T
+    t = T.Spectrogram(**kwargs).to(dtype=torch.float64, device="cuda")
+    _assert_grad(t, [_noise(2, 400)], nondet_tol=1e-10)           # 8000 Hz x 0.05 s, default n_fft = 400
+
+
+def test_spectrogram_small_n_fft_and_other_pad_modes():
+    import audio_amd.transforms as T
+    for pm in ("reflect", "constant", "replicate", "circular"):
+        t = T.Spectrogram(n_fft=64, hop_length=16, win_length=48, pad_mode=pm).to(dtype=torch.float64, device="cuda")
+        _assert_grad(t, [_noise(1, 150, seed=3)], nondet_tol=1e-10)
+
+
+def test_melspectrogram_and_melscale():
+    import audio_amd.transforms as T
+    t = T.MelSpectrogram(sample_rate=8000).to(dtype=torch.float64, device="cuda")
+    _assert_grad(t, [_noise(2, 400)], nondet_tol=1e-10)
+    ms = T.MelScale(sample_rate=8000, n_stft=201).to(dtype=torch.float64, device="cuda")
+    _assert_grad(ms, [torch.rand(2, 201, 6, generator=torch.Generator().manual_seed(1))])
+
+
+@pytest.mark.parametrize("log_mels", [False, True])
+def test_mfcc(log_mels):
+    import audio_amd.transforms as T
+    t = T.MFCC(sample_rate=8000, log_mels=log_mels).to(dtype=torch.float64, device="cuda")
+    _assert_grad(t, [_noise(2, 400)], nondet_tol=1e-10)
+
+
+def test_amplitude_to_db():
+    import audio_amd.transforms as T
+    spec = torch.rand(2, 30, 8, generator=torch.Generator().manual_seed(2)) + 0.1
+    _assert_grad(T.AmplitudeToDB().to(dtype=torch.float64, device="cuda"), [spec])
+    _assert_grad(T.AmplitudeToDB("magnitude", top_db=20.0).to(dtype=torch.float64, device="cuda"), [spec])
+
+
+# ---------------------------------------------------------------------------------------------- resample / fftconvolve
+
+
+@pytest.mark.parametrize("orig_freq,new_freq", [(8000, 8000), (8000, 4000), (4000, 8000), (8000, 6000)])
+def test_resample(orig_freq, new_freq):
+    import audio_amd.transforms as T
+    t = T.Resample(orig_freq=orig_freq, new_freq=new_freq).to(dtype=torch.float64, device="cuda")
+    _assert_grad(t, [_noise(2, 400)])
+
+
+@pytest.mark.parametrize("mode", ["full", "valid", "same"])
+def test_fftconvolve(mode):
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 25, generator=g)
+    y = torch.rand(1, 3, 11, generator=g)
+    _assert_grad(T.FFTConvolve(mode=mode), [x, y])
+
+
+def test_float64_forward_matches_float32_kernels_and_oracle():
+    """float64 entry points against the fp32 fast kernels (1e-6) and the float64 oracle (1e-12)."""
+    import numpy as np
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    x = _noise(2, 3000, seed=9).cuda()
+    mel32 = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=40).cuda()
+    mel64 = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=40).to(dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        y32, y64 = mel32(x), mel64(x.double())
+    assert y64.dtype == torch.float64 and float((y32.double() - y64).abs().max() / y64.abs().max()) <= 2e-6
+    want = O.mel_spectrogram(x.cpu().numpy().astype(np.float64), mel64.spectrogram.window.cpu().numpy(),
+                             mel64.mel_scale.fb.cpu().numpy(), 400, 160)
+    assert float(np.abs(y64.cpu().numpy() - want).max() / np.abs(want).max()) <= 1e-12
+    a = torch.tensor([1.0, -1.5, 0.7], dtype=torch.float64).cuda()
+    b = torch.tensor([0.3, 0.1, 0.2], dtype=torch.float64).cuda()
+    with torch.no_grad():
+        z = F.lfilter(x.double(), a, b)
+    wz = O.lfilter(x.cpu().numpy().astype(np.float64), a.cpu().numpy(), b.cpu().numpy())
+    assert float(np.abs(z.cpu().numpy() - wz).max()) <= 1e-12
+    with torch.no_grad():
+        r = F.resample(x.double(), 16000, 11025)
+    wr = O.resample(x.cpu().numpy().astype(np.float64), 16000, 11025)
+    assert float(np.abs(r.cpu().numpy() - wr).max()) <= 1e-12
