@@ -243,7 +243,7 @@ AAMD_HD void mel_tab_fill(int tid, int nthr, const MelBandsDev& mb, float* base,
 // 58 live registers -> one more wave per SIMD):
 //   twiddles  [20 b][44]: W400^(b c) as (re, im) pairs, c = 0..19, row padded to 44 dwords
 //   window    [20 b][20]: 0.5 * scale * window[b + 20 q]
-constexpr int kTwRow = 44;
+constexpr int kTwRow = 42;    // 42 b mod 64 is distinct (and even) for the 20 rows: conflict-free ds_read_b64 of the twiddle pairs (44 made rows 16..19 collide with 0..3)
 constexpr int kConstDwords = 20 * kTwRow + 20 * 20;   // 1280
 
 AAMD_HD void const_tab_build(int tid, int nthr, const float* window, const float* tw400, float scale,
