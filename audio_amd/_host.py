@@ -217,6 +217,26 @@ def resample_band_table(kernel: np.ndarray, rel_threshold: float = 2.0 ** -40):
     return lo, span
 
 
+def resample_sparse_table(kernel: np.ndarray, rel_threshold: float = 2.0 ** -40):
+    """Compact form of a polyphase table whose rows are almost empty (huge reduced rates, e.g. PitchShift's
+    8000 x 10095): per phase the first non-negligible tap and the common span, and the taps of that window.
+    Same negligibility rule as resample_band_table.  Returns (compact float32[new][span], tap_lo int32[new], span)."""
+    h = np.asarray(kernel, dtype=np.float32)
+    new, taps = h.shape
+    k = np.abs(h.astype(np.float64))
+    thr = rel_threshold * (k.max() if k.size else 0.0)
+    mask = k > thr
+    any_row = mask.any(axis=1)
+    first = np.where(any_row, mask.argmax(axis=1), 0)
+    last = np.where(any_row, taps - 1 - mask[:, ::-1].argmax(axis=1), 0)
+    span = int((last - first + 1).max()) if new else 1
+    lo = np.minimum(first, max(taps - span, 0)).astype(np.int32)
+    idx = lo[:, None].astype(np.int64) + np.arange(span)[None, :]
+    compact = np.take_along_axis(h, np.minimum(idx, taps - 1), axis=1)
+    compact[idx >= taps] = 0.0
+    return np.ascontiguousarray(compact, dtype=np.float32), lo, span
+
+
 # --------------------------------------------------------------------------- #
 # lane assignment of the radix-20x20 mel kernel (audio_amd/csrc/melspec400.h)   #
 # --------------------------------------------------------------------------- #

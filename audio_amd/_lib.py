@@ -91,6 +91,8 @@ _SIGS = {
                                     C.c_int32, C.c_int64, _P]),
     "aamd_resample_banded_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int64, C.POINTER(ResampleBands), _P]),
+    "aamd_resample_sparse_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_int64, _P]),
     "aamd_lfilter_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, _P]),
     "aamd_spectrogram_f64": (C.c_int, [_P, _P, _P, _P, C.POINTER(StftDesc), _P]),

@@ -1080,6 +1080,22 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
   return AAMD_OK;
 }
 
+int aamd_resample_sparse_f32(const float* wav, const float* taps_compact, const int32_t* tap_lo, float* out, int64_t rows,
+                             int64_t length, int64_t row_stride, int32_t orig, int32_t new_, int32_t width, int32_t span,
+                             int64_t out_len, void* stream) {
+  DeviceScope dev_scope_(wav);
+  AAMD_CHECK_ARG(wav && taps_compact && tap_lo && out, "null buffer");
+  AAMD_CHECK_ARG(rows >= 0 && length >= 0 && orig >= 1 && new_ >= 1 && width >= 0 && span >= 1, "bad sizes");
+  AAMD_CHECK_ARG(row_stride >= length, "row_stride < length");
+  AAMD_CHECK_ARG(out_len == ((int64_t)new_ * length + orig - 1) / orig, "out_len must be ceil(new*length/orig)");
+  const int64_t n = rows * out_len;
+  if (n == 0) return AAMD_OK;
+  AAMD_CHECK_ARG((n + 255) / 256 < (1ll << 31), "too many samples for one launch");
+  hipLaunchKernelGGL(resample_sparse_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wav,
+                     taps_compact, tap_lo, out, rows, length, row_stride, orig, new_, width, span, out_len);
+  return launch_check();
+}
+
 int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, int64_t batch,
                      int32_t channels, int64_t length, int32_t n_order, int32_t n_coeff_rows,
                      int32_t n_stages, int32_t clamp, void* stream) {

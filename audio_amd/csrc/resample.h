@@ -54,7 +54,36 @@ AAMD_HD void resample_compute(int tid, int nthr, const ResampleGeom& g, const fl
   }
 }
 
+// Sparse evaluation for ratios whose reduced rates are huge (PitchShift: 20158 -> 16000 Hz = 10079 : 8000, a tap table of
+// 8000 x 10095 of which ~36 taps per phase are non-zero; functional/functional.py:1790-1840 builds exactly that table).
+// The host compacts the table once: hb[p][span] = kernel[p][lo[p] .. lo[p] + span), lo[p] = first non-negligible tap of
+// phase p.  One thread per output sample:
+//   y[q new + p] = sum_{j < span} hb[p][j] * xpad[q orig + lo[p] + j]
+AAMD_HD float resample_sparse_one(const float* row, int64_t length, const float* hb, const int32_t* lo, int orig, int new_,
+                                  int width, int span, int64_t i) {
+  const int64_t q = i / new_;
+  const int p = (int)(i - q * new_);
+  const float* h = hb + (int64_t)p * span;
+  const int64_t s0 = q * orig + lo[p] - width;      // signal index of the band's first tap
+  float acc = 0.0f;
+  for (int j = 0; j < span; ++j) {
+    const int64_t s = s0 + j;
+    if (s >= 0 && s < length) acc += h[j] * row[s];
+  }
+  return acc;
+}
+
 #if defined(__HIPCC__)
+__global__ void __launch_bounds__(256)
+resample_sparse_kernel(const float* __restrict__ wav, const float* __restrict__ hb, const int32_t* __restrict__ lo,
+                       float* __restrict__ out, int64_t rows, int64_t length, int64_t row_stride, int orig, int new_,
+                       int width, int span, int64_t out_len) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * out_len) return;
+  const int64_t row = idx / out_len, i = idx - row * out_len;
+  out[idx] = resample_sparse_one(wav + row * row_stride, length, hb, lo, orig, new_, width, span, i);
+}
+
 __global__ void __launch_bounds__(256)
 resample_kernel(ResampleGeom g, const float* __restrict__ wav, const float* __restrict__ kern,
                 float* __restrict__ out) {

@@ -713,6 +713,29 @@ def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_ff
     return out
 
 
+def _melspectrogram_plan(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_fft: int, hop_length: int,
+                         win_length: int, power: float, normalized, center: bool, pad_mode: str):
+    """Everything of `_melspectrogram` that depends only on (shape, dtype, device, parameters): validated once, then the
+    module replays it per call (transforms.MelSpectrogram keeps the plans; host issue cost per call ~20 us -> a dict
+    lookup + one boxed op).  Returns None when the call cannot take the compiled route."""
+    ops = _ops()
+    if ops is None or power is None:
+        return None
+    _require_device(waveform, "waveform")
+    window = window.to(device=waveform.device, dtype=torch.float32)
+    x2 = _rows2d(waveform)
+    if x2.data_ptr() != waveform.data_ptr():
+        return None                               # needed a copy: no stable view recipe
+    desc = _stft_desc(x2, pad, window, n_fft, hop_length, power, normalized, center, pad_mode, True)
+    bands = _mel_bands(fb, waveform.device)
+    if bands.n_freq != n_fft // 2 + 1:
+        return None
+    args = (_padded_window(window, n_fft), _twiddles(n_fft, waveform.device), bands.lo, bands.width, bands.weights,
+            bands.lane_order, bands.table400, n_fft, hop_length, pad, bool(center), desc.pad_mode, desc.n_frames,
+            desc.scale, desc.power)
+    return ops.mel_spectrogram, (x2.shape[0], x2.shape[1]), args, (bands, window)      # keep-alives last
+
+
 def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_length: int, gain: float,
                  mean: Tensor, invstddev: Tensor, right_padding: int,
                  bands: Optional[MelBandsOnDevice] = None) -> Tensor:
@@ -916,6 +939,9 @@ def amplitude_to_DB(x: Tensor, multiplier: float, amin: float, db_multiplier: fl
 # --------------------------------------------------------------------------- #
 
 
+_SPARSE_TAPS = 4096      # polyphase tables with longer rows are evaluated sparsely (they are > 99 % zeros)
+
+
 def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new: int, width: int) -> Tensor:
     """(rows, L) -> (rows, ceil(new L / orig)) through aamd_resample_banded_f32; band table cached per tensor."""
     rows, length = x2.shape
@@ -928,6 +954,21 @@ def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new
                 _lib.check(_lib.lib().aamd_resample_f64(x2.data_ptr(), kern.data_ptr(), out.data_ptr(), rows, length,
                                                        max(length, 1), orig, new, width, out_len,
                                                        _lib.current_stream(x2.device)))
+        return out
+    if kern.shape[1] > _SPARSE_TAPS:
+        # huge reduced rates (PitchShift: 10079 : 8000 -> a 8000 x 10095 table with ~36 live taps per phase): the
+        # compacted table (host, once per kernel tensor) through the sparse kernel instead of 10 095 taps per sample
+        hb, lo, span = _tensor_cached(key_tensor, ("rs_sparse", key, new), lambda: tuple(
+            (torch.from_numpy(t).to(x2.device) if isinstance(t, np.ndarray) else t)
+            for t in _host.resample_sparse_table(kern.cpu().numpy())))
+        if x2.stride(0) != length and rows > 1:
+            x2 = x2.contiguous()
+        out = torch.empty((rows, out_len), dtype=torch.float32, device=x2.device)
+        if out.numel():
+            with torch.cuda.device(x2.device):
+                _lib.check(_lib.lib().aamd_resample_sparse_f32(
+                    x2.data_ptr(), hb.data_ptr(), lo.data_ptr(), out.data_ptr(), rows, length, max(length, 1), orig, new,
+                    width, int(span), out_len, _lib.current_stream(x2.device)))
         return out
     # band table of the taps (host, once per kernel tensor): the matrix-core kernel skips the
     # ~1e-20-sized window tails outside each phase tile's band

@@ -338,6 +338,12 @@ class MelSpectrogram(torch.nn.Module):
         )
         self.mel_scale = MelScale(self.n_mels, self.sample_rate, self.f_min, self.f_max, self.n_fft // 2 + 1,
                                   norm, mel_scale)
+        self._plans: dict = {}      # per-(shape, device, buffer version) launch plans of the inference path
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_plans"] = {}            # launch plans hold op handles and device tensors: rebuilt on first use
+        return state
 
     def _frame_major(self, waveform: Tensor, db=None) -> Tensor:
         sp = self.spectrogram
@@ -359,7 +365,22 @@ class MelSpectrogram(torch.nn.Module):
                 F._rows2d(waveform), sp.window, self.mel_scale.fb,
                 (sp.pad, sp.n_fft, sp.hop_length, sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode))
             return out.view(tuple(waveform.shape[:-1]) + out.shape[-2:]).transpose(-1, -2)
-        out = self._frame_major(waveform)                       # (rows, T, n_mels)
+        # steady-state serving: the argument tuple of the boxed op is a function of (shape, strides, device, buffers) only
+        sp, fb = self.spectrogram, self.mel_scale.fb
+        key = (waveform.shape, waveform.stride(), waveform.dtype, waveform.device, sp.window.data_ptr(), sp.window._version,
+               fb.data_ptr(), fb._version, F._ROUTE["ops"] is not None)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = F._melspectrogram_plan(waveform, sp.pad, sp.window, fb, sp.n_fft, sp.hop_length, sp.win_length, sp.power,
+                                          sp.normalized, sp.center, sp.pad_mode) or False
+            if len(self._plans) > 64:
+                self._plans.clear()
+            self._plans[key] = plan
+        if plan:
+            op, shape2, args, _keep = plan
+            out = op(waveform.view(shape2), *args)
+        else:
+            out = self._frame_major(waveform)                       # (rows, T, n_mels)
         lead = tuple(waveform.shape[:-1])
         return out.view(lead + out.shape[-2:]).transpose(-1, -2)
 

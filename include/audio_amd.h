@@ -307,6 +307,14 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
                              int32_t width, int64_t out_len, const aamd_resample_bands* bands,
                              void* stream);
 
+/* Sparse evaluation for ratios whose REDUCED rates are huge (F.pitch_shift / T.PitchShift: 20158 -> 16000 Hz is
+ * 10079 : 8000, a tap table of 8000 x 10095 with ~36 non-negligible taps per phase; functional/functional.py:1790-1840):
+ * taps_compact: device float[new][span] = kernel[p][tap_lo[p] .. tap_lo[p] + span), tap_lo: device int32[new], compacted
+ * once by the host.  Same result as aamd_resample_f32 up to the taps the caller dropped. */
+int aamd_resample_sparse_f32(const float* wav, const float* taps_compact, const int32_t* tap_lo, float* out, int64_t rows,
+                             int64_t length, int64_t row_stride, int32_t orig, int32_t new_, int32_t width, int32_t span,
+                             int64_t out_len, void* stream);
+
 /* ---- lfilter ---------------------------------------------------------------------------- */
 
 /* x, y: float[batch][channels][length]; a, b: device float[n_coeff_rows][n_order] with

@@ -688,6 +688,15 @@ int sim_resample(const float* wav, const float* kern, float* out, int64_t rows, 
   return 0;
 }
 
+// Replay of resample_sparse_kernel (one thread per output sample over the compacted tap table)
+int sim_resample_sparse(const float* wav, const float* hb, const int32_t* lo, float* out, int64_t rows, int64_t length,
+                        int64_t row_stride, int orig, int new_, int width, int span, int64_t out_len) {
+  for (int64_t row = 0; row < rows; ++row)
+    for (int64_t i = 0; i < out_len; ++i)
+      out[row * out_len + i] = resample_sparse_one(wav + row * row_stride, length, hb, lo, orig, new_, width, span, i);
+  return 0;
+}
+
 // Replay of rsm::resample_mfma_kernel: same Geom set-up as aamd_resample_banded_f32, the loader's
 // piece copies into a chunk buffer, and the MFMA fragment maps (A: lane m + 16 k, B: lane n + 16 k,
 // C: lane n + 16 (m / 4), element m % 4) applied to a_frag / b_base / store_c.

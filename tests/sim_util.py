@@ -159,6 +159,21 @@ def sim_resample(x, kernel, orig, new, width, qt=None, use_lds=1):
     return out
 
 
+def sim_resample_sparse(x, kernel, orig, new, width):
+    """resample_sparse_kernel replay over the host-compacted table (_host.resample_sparse_table)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, length = x.shape
+    k = np.ascontiguousarray(kernel, dtype=np.float32).reshape(new, -1)
+    hb, lo, span = _host.resample_sparse_table(k)
+    out_len = -(-new * length // orig)
+    out = np.full((rows, out_len), np.nan, dtype=np.float32)
+    f = sim().sim_resample_sparse
+    f.argtypes = [C.c_void_p] * 4 + [C.c_int64] * 3 + [C.c_int] * 4 + [C.c_int64]
+    assert f(fptr(x), fptr(hb), fptr(np.ascontiguousarray(lo, dtype=np.int32)), fptr(out), rows, length, length, orig, new,
+             width, span, out_len) == 0
+    return out, span
+
+
 def sim_resample_mfma(x, kernel, orig, new, width, vec_ok=1):
     x = np.ascontiguousarray(x, dtype=np.float32)
     rows, length = x.shape

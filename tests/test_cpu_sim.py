@@ -629,3 +629,23 @@ def test_inverse_kernels_plain_stores_are_exclusive(seed):
     assert np.abs(got - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-6)
     if st.sum() == 0 and L > 8 * n_fft and hop <= n_fft // 2 and (fast400 or run_len == 16):
         pytest.fail("no plain stores at all: the fast write path is not exercised")
+
+
+def test_sim_resample_sparse_pitch_shift_ratio():
+    """The reduced rates of F.pitch_shift (16 kHz, +4 semitones: 20158 -> 16000 Hz = 10079 : 8000): a 8000 x 10095 tap
+    table with 16 live taps per phase, evaluated by resample_sparse_kernel over the host-compacted table, against the
+    float64 oracle applied to the full table, and for an ordinary ratio against the dense kernel replay."""
+    o, n, g = 20158, 16000, 2
+    k, width = _host.sinc_resample_kernel(o, n, g)
+    kn = k.numpy().reshape(n // g, -1)
+    x = np.random.default_rng(4).standard_normal((2, 30000)).astype(np.float32) * 0.3
+    got, span = S.sim_resample_sparse(x, kn, o // g, n // g, width)
+    assert span <= 32
+    exp = O.apply_sinc_resample_kernel(x.astype(np.float64), o, n, g, kn.astype(np.float64), width)
+    assert got.shape == exp.shape
+    assert np.abs(got - exp).max() <= 1e-5 * max(1.0, np.abs(exp).max())
+    k2, w2 = _host.sinc_resample_kernel(44100, 16000, 100)
+    x2 = np.random.default_rng(5).standard_normal((1, 5000)).astype(np.float32)
+    a, _ = S.sim_resample_sparse(x2, k2.numpy(), 441, 160, w2)
+    b = S.sim_resample(x2, k2.numpy(), 441, 160, w2)
+    assert np.abs(a - b).max() <= 1e-5
