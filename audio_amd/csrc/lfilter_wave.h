@@ -132,14 +132,27 @@ AAMD_HD void scan_step(const float* tab, int k, bool active, float n0, float n1,
 
 // ---- phase 3: true state E_w entering wave w: fold the published wave-end states ----------------
 //   E_0 = carry (true state entering the block);  E_{i+1} = S_i + M^(64 chunks) E_i
+//   The published states are fetched in two batches of 8 BEFORE the serial chain (round 2: with the LDS read inside the
+//   loop the last wave paid 15 dependent LDS round trips per stage and block while 15 others waited at barrier 2 for it).
 AAMD_HD void fold_entering(const float* tab, const float* S, int w, float c0, float c1, float& e0, float& e1) {
   e0 = c0;
   e1 = c1;
-  for (int i = 0; i < w; ++i) {
-    float p0, p1;
-    mat_apply(tab + kTabM + 4 * kScanSteps, e0, e1, p0, p1);
-    e0 = S[xch_S(i)] + p0;
-    e1 = S[xch_S(i) + 1] + p1;
+  const float m00 = tab[kTabM + 4 * kScanSteps], m01 = tab[kTabM + 4 * kScanSteps + 1];
+  const float m10 = tab[kTabM + 4 * kScanSteps + 2], m11 = tab[kTabM + 4 * kScanSteps + 3];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (8 * half >= w) break;
+    F2 sr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sr[i] = *reinterpret_cast<const F2*>(S + xch_S(8 * half + i));   // S[i] for i >= W is unused
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (8 * half + i < w) {
+        const float p0 = m00 * e0 + m01 * e1, p1 = m10 * e0 + m11 * e1;
+        e0 = sr[i].x + p0;
+        e1 = sr[i].y + p1;
+      }
+    }
   }
 }
 
