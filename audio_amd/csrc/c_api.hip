@@ -1116,13 +1116,25 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
     while (W > 1 && lfw::lds_bytes(W, n_stages) > cap) W /= 2;
     const size_t lds = lfw::lds_bytes(W, n_stages);
     if (lds <= cap) {
-      AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lfw::lfilter_wave_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const int blocks = grid_for(n_seq, 1, dev_props().cu_count * 8);
       const int vec_ok = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0) &&
                          (length % 4 == 0);
-      hipLaunchKernelGGL(lfw::lfilter_wave_kernel, dim3(blocks), dim3(64 * W), lds, s, x, a, b, y, n_seq, channels,
-                         length, n_order, n_coeff_rows, n_stages, clamp, vec_ok);
+      static const int lab = [] { const char* e = std::getenv("AAMD_LFW_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
+#define AAMD_LFW(LL)                                                                                               \
+      {                                                                                                            \
+        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lfw::lfilter_wave_kernel<LL>),                  \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+        hipLaunchKernelGGL(lfw::lfilter_wave_kernel<LL>, dim3(blocks), dim3(64 * W), lds, s, x, a, b, y, n_seq,    \
+                           channels, length, n_order, n_coeff_rows, n_stages, clamp, vec_ok);                      \
+      }
+      switch (lab) {
+        case 1: AAMD_LFW(1) break;
+        case 3: AAMD_LFW(3) break;
+        case 7: AAMD_LFW(7) break;
+        case 15: AAMD_LFW(15) break;
+        default: AAMD_LFW(0)
+      }
+#undef AAMD_LFW
       return launch_check();
     }
   }

@@ -186,6 +186,9 @@ __device__ __attribute__((noinline)) void build_stage_call(const float* a_row, c
   build_stage(a_row, b_row, n_order, tab);
 }
 
+// LAB != 0: profiling variants (wrong results by design) -- bit 0: no barrier 2, bit 1: no barrier 1, bit 2: no scan,
+// bit 3: no fold / correction.  Selected by the hidden AAMD_LFW_LAB environment value (tools only).
+template <int LAB = 0>
 __global__ void __launch_bounds__(1024)
 lfilter_wave_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
                     float* __restrict__ y, int64_t n_seq, int channels, int64_t length, int n_order,
@@ -274,26 +277,30 @@ lfilter_wave_kernel(const float* __restrict__ x, const float* __restrict__ a, co
         }
         float s0, s1;
         chunk_pass(tab, v, hu0, hu1, s0, s1);
+        if (!(LAB & 4)) {
 #pragma unroll
-        for (int k = 0; k < kScanSteps; ++k) {
-          const float n0s = __shfl_up(s0, 1 << k, 64), n1s = __shfl_up(s1, 1 << k, 64);
-          scan_step(tab, k, lane >= (1 << k), n0s, n1s, s0, s1);
+          for (int k = 0; k < kScanSteps; ++k) {
+            const float n0s = __shfl_up(s0, 1 << k, 64), n1s = __shfl_up(s1, 1 << k, 64);
+            scan_step(tab, k, lane >= (1 << k), n0s, n1s, s0, s1);
+          }
         }
         if (lane == 63) {
           xch[xch_S(wave)] = s0;
           xch[xch_S(wave) + 1] = s1;
         }
-        __syncthreads();                                          // barrier 1: wave-end states visible
+        if (!(LAB & 2)) __syncthreads();                          // barrier 1: wave-end states visible
         const int cin = xch_carry(W, n_stages, parity, st);
-        float e0, e1;
-        fold_entering(tab, xch, wave, xch[cin], xch[cin + 1], e0, e1);
-        float p0, p1;
-        mat_apply(tab + kTabPow + 4 * lane, e0, e1, p0, p1);      // M^(l+1) E_w
-        s0 += p0;
-        s1 += p1;                                                 // true state after chunk l
-        float t0 = __shfl_up(s0, 1, 64), t1 = __shfl_up(s1, 1, 64);
-        if (lane == 0) { t0 = e0; t1 = e1; }
-        correct_clamp(tab, t0, t1, clamp, v);
+        float e0 = 0.0f, e1 = 0.0f;
+        if (!(LAB & 8)) {
+          fold_entering(tab, xch, wave, xch[cin], xch[cin + 1], e0, e1);
+          float p0, p1;
+          mat_apply(tab + kTabPow + 4 * lane, e0, e1, p0, p1);      // M^(l+1) E_w
+          s0 += p0;
+          s1 += p1;                                                 // true state after chunk l
+          float t0 = __shfl_up(s0, 1, 64), t1 = __shfl_up(s1, 1, 64);
+          if (lane == 0) { t0 = e0; t1 = e1; }
+          correct_clamp(tab, t0, t1, clamp, v);
+        }
         if (lane == 63) {
           if (wave == W - 1) {   // true (unclamped) state leaving the block -> next block's carry
             const int cout = xch_carry(W, n_stages, parity ^ 1, st);
@@ -304,7 +311,7 @@ lfilter_wave_kernel(const float* __restrict__ x, const float* __restrict__ a, co
           xch[xch_tail(W, n_stages, parity, st + 1, wave)] = v[kCh - 1];
           xch[xch_tail(W, n_stages, parity, st + 1, wave) + 1] = v[kCh - 2];
         }
-        __syncthreads();                                          // barrier 2: tails / carries visible
+        if (!(LAB & 1)) __syncthreads();                          // barrier 2: tails / carries visible
       }
       // 4. chunk -> tile -> row-major pieces -> global
 #pragma unroll
