@@ -304,7 +304,9 @@ def main():
             from oracle import torch_cpu_ref
             n_clips = BATCH
             v, cores, calls = torch_cpu_ref.time_mel_baseline(n_clips, SECONDS, SR, N_FFT, HOP, N_MELS)
+            v1 = torch_cpu_ref.time_mel_baseline_single_thread(16, SECONDS, SR, N_FFT, HOP, N_MELS)
             out["cpu_baseline"] = {"value": v, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+                                   "value_1_thread": v1, "sample_1_thread": "16 of the 256 clips on one host thread",
                                    "sample": f"all {n_clips} clips x 10 s of one batch, best of {calls} calls; a port, not "
                                              "torchaudio itself (the GPU box has no /root/reference): the same ATen ops "
                                              "torchaudio's CPU path issues (torch.stft + abs().pow(2) + matmul)"}

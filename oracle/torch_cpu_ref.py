@@ -76,3 +76,15 @@ def time_mel_baseline(n_clips: int, seconds: float, sample_rate: int = 16000, n_
         if t_total > 2.5 * budget_s:
             break
     return n_clips * seconds / t_best, torch.get_num_threads(), calls
+
+
+def time_mel_baseline_single_thread(n_clips: int, seconds: float, sample_rate: int = 16000, n_fft: int = 400, hop: int = 160,
+                                    n_mels: int = 80, budget_s: float = 6.0, seed: int = 1234):
+    """The same composition on ONE host thread (report n in {1, all cores}); returns audio_sec_per_sec."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        v, _, _ = time_mel_baseline(n_clips, seconds, sample_rate, n_fft, hop, n_mels, budget_s=budget_s, seed=seed)
+    finally:
+        torch.set_num_threads(n)
+    return v

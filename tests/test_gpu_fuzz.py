@@ -226,3 +226,85 @@ def test_fuzz_fftconvolve_vs_fft(seed):
         ref = full[..., s0:s0 + m]
     assert got.shape == ref.shape, (xs, ys, mode)
     assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (xs, ys, mode)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_float64_spectrogram_vs_aten(seed):
+    """The float64 entry points (generic Stockham on double) against torch.stft in float64 on the same GPU: every pad mode,
+    odd / prime n_fft, win_length < n_fft, pad > 0 -- to float64 round-off."""
+    import audio_amd.transforms as T
+    r = _rng(5000 + seed)
+    n_fft = int(r.choice([400, 512, 64, 96, 200, 97, 320, 1000, 250]))
+    win_length = n_fft if r.random() < 0.6 else int(r.integers(max(2, n_fft // 3), n_fft + 1))
+    hop = max(1, int(r.choice([n_fft // 4, n_fft // 2, 160, 100, int(r.integers(1, n_fft + 1))])))
+    hop = min(hop, n_fft)
+    pad_mode = str(r.choice(["reflect", "constant", "replicate", "circular"]))
+    pad = int(r.choice([0, 0, 7]))
+    power = [2.0, 1.0, None][int(r.integers(0, 3))]
+    L = int(r.integers(n_fft + 1, 5 * n_fft + 50))
+    g = torch.Generator().manual_seed(seed)
+    x = (0.5 * torch.randn(2, L, generator=g, dtype=torch.float64)).cuda()
+    t = T.Spectrogram(n_fft=n_fft, win_length=win_length, hop_length=hop, pad=pad, power=power, pad_mode=pad_mode)
+    t = t.to(dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        got = t(x)
+    assert got.dtype == (torch.complex128 if power is None else torch.float64)
+    xd = torch.nn.functional.pad(x, (pad, pad)) if pad else x
+    ref = torch.stft(xd, n_fft, hop, win_length, t.window, True, pad_mode, False, True, return_complex=True)
+    if power is not None:
+        ref = ref.abs().pow(power)
+    assert got.shape == ref.shape
+    assert float((got - ref).abs().max() / ref.abs().max()) <= 1e-12, (n_fft, win_length, hop, pad_mode, pad, power, L)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_kaldi_generic_sizes_vs_cpu_replay(seed):
+    """kgen::kaldi_generic_kernel on random EVEN window sizes (mixed radices, prime factors) against the CPU replay of the
+    same phase functions (tests/cpu_sim), which tests/test_kaldi.py pins on the reference's fixtures."""
+    import sim_util as S
+    from audio_amd import _host
+    import audio_amd.compliance.kaldi as K
+    r = _rng(6000 + seed)
+    sr = float(r.choice([8000.0, 16000.0, 22050.0, 11025.0]))
+    frame_length = float(r.choice([25.0, 20.0, 32.0, 17.5, 12.5]))
+    win = int(sr * frame_length * 0.001)
+    if win % 2:
+        frame_length += 1000.0 / sr
+        win = int(sr * frame_length * 0.001)
+    if win % 2:
+        pytest.skip("odd window after adjustment")
+    shift = int(sr * 10.0 * 0.001)
+    snip = bool(r.random() < 0.5)
+    nb = int(r.choice([23, 40]))
+    g = torch.Generator().manual_seed(seed)
+    wav = (torch.randn(1, int(sr * 0.6), generator=g) * 3000.0)
+    kw = dict(sample_frequency=sr, frame_length=frame_length, round_to_power_of_two=False, snip_edges=snip, num_mel_bins=nb,
+              use_energy=True)
+    with torch.no_grad():
+        got = K.fbank(wav.cuda(), **kw).cpu().numpy()
+    w = _host.kaldi_window("povey", win, 0.42).numpy()
+    bins, _ = _host.kaldi_get_mel_banks(nb, win, sr, 20.0, 0.0, 100.0, -500.0, 1.0)
+    fb = torch.nn.functional.pad(bins.float(), (0, 1)).T.contiguous().numpy()
+    sim = S.sim_kaldi_features(wav[0].numpy(), w, win, shift, win, snip_edges=snip, bands=S.HostBands(fb), energy_col=0,
+                               first_col=1, n_cols=nb + 1, force_generic=True)
+    assert got.shape == sim.shape
+    assert np.abs(got - sim).max() <= 2e-3, (sr, frame_length, win, snip)
+
+
+@pytest.mark.parametrize("n_steps", [-5, 3, 7])
+def test_fuzz_pitch_shift_sparse_path_vs_dense_kernel(n_steps):
+    """F.pitch_shift's resampling step has huge reduced rates: the sparse kernel over the host-compacted table must agree
+    with the dense polyphase kernel applied to the full table."""
+    import audio_amd.functional as F
+    from audio_amd import _lib
+    x = (0.3 * torch.randn(3, 12000, generator=torch.Generator().manual_seed(n_steps))).cuda()
+    with torch.no_grad():
+        got = F.pitch_shift(x, 16000, n_steps)
+        old = F._SPARSE_TAPS
+        try:
+            F._SPARSE_TAPS = 1 << 30                      # dense route (banded MFMA or scalar fallback)
+            ref = F.pitch_shift(x, 16000, n_steps)
+        finally:
+            F._SPARSE_TAPS = old
+    assert got.shape == ref.shape == x.shape
+    assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
