@@ -305,8 +305,11 @@ def main():
             n_clips = BATCH
             v, cores, calls = torch_cpu_ref.time_mel_baseline(n_clips, SECONDS, SR, N_FFT, HOP, N_MELS)
             v1 = torch_cpu_ref.time_mel_baseline_single_thread(16, SECONDS, SR, N_FFT, HOP, N_MELS)
-            out["cpu_baseline"] = {"value": v, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
-                                   "value_1_thread": v1, "sample_1_thread": "16 of the 256 clips on one host thread",
+            # n in {1, all host cores}, report the best and state the thread count it was measured with
+            best, best_cores = (v, cores) if v >= v1 else (v1, 1)
+            out["cpu_baseline"] = {"value": best, "unit": "audio-sec/sec", "cores": best_cores, "kind": "port",
+                                   "value_all_threads": v, "threads_all": cores, "value_1_thread": v1,
+                                   "sample_1_thread": "16 of the 256 clips on one host thread",
                                    "sample": f"all {n_clips} clips x 10 s of one batch, best of {calls} calls; a port, not "
                                              "torchaudio itself (the GPU box has no /root/reference): the same ATen ops "
                                              "torchaudio's CPU path issues (torch.stft + abs().pow(2) + matmul)"}
