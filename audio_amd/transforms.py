@@ -368,7 +368,8 @@ class MelSpectrogram(torch.nn.Module):
         # steady-state serving: the argument tuple of the boxed op is a function of (shape, strides, device, buffers) only
         sp, fb = self.spectrogram, self.mel_scale.fb
         key = (waveform.shape, waveform.stride(), waveform.dtype, waveform.device, sp.window.data_ptr(), sp.window._version,
-               fb.data_ptr(), fb._version, F._ROUTE["ops"] is not None)
+               fb.data_ptr(), fb._version, F._ROUTE["ops"] is not None,
+               sp.n_fft, sp.hop_length, sp.win_length, sp.pad, sp.power, sp.normalized, sp.center, sp.pad_mode)
         plan = self._plans.get(key)
         if plan is None:
             plan = F._melspectrogram_plan(waveform, sp.pad, sp.window, fb, sp.n_fft, sp.hop_length, sp.win_length, sp.power,
