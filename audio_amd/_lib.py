@@ -56,7 +56,8 @@ class KaldiDesc(C.Structure):
                 ("win", C.c_int32), ("snip_edges", C.c_int32), ("preemphasis", C.c_float),
                 ("remove_dc_offset", C.c_int32), ("raw_energy", C.c_int32), ("energy_floor", C.c_float),
                 ("use_power", C.c_int32), ("use_log", C.c_int32), ("energy_col", C.c_int32), ("first_col", C.c_int32),
-                ("n_cols", C.c_int32), ("dither", C.c_float), ("noise", C.c_void_p)]
+                ("n_cols", C.c_int32), ("dither", C.c_float), ("noise", C.c_void_p), ("n_utt", C.c_int64),
+                ("utt_stride", C.c_int64)]
 
 
 _SIGS = {

@@ -8,6 +8,10 @@ builds them.  Padded windows of 256 / 512 / 1024 / 2048 samples run on the regis
 (`round_to_power_of_two=False`: 400 at 16 kHz, 200 at 8 kHz, 1102 at 44.1 kHz ...) on the mixed-radix LDS kernel
 (csrc/kaldi_generic.h).  `dither` draws its Gaussian noise exactly as the reference does -- `torch.randn(frames.shape)` on
 the waveform's device (kaldi.py:180-183) -- so a seeded run reproduces the reference's run on the same device.
+
+EXTENSION (not in the reference, which takes one channel of one utterance per call): `spectrogram_batch`, `fbank_batch` and
+`mfcc_batch` take (B, n) equal-length utterances and return (B, m, cols) from ONE launch; row b is bit-identical to the
+single-utterance call on `waveforms[b]` (`subtract_mean` is per utterance).
 """
 from __future__ import annotations
 
@@ -22,7 +26,7 @@ from .. import _host, _lib
 from .. import functional as F
 
 __all__ = ["get_mel_banks", "inverse_mel_scale", "inverse_mel_scale_scalar", "mel_scale", "mel_scale_scalar", "spectrogram",
-           "fbank", "mfcc", "vtln_warp_freq", "vtln_warp_mel_freq"]
+           "fbank", "mfcc", "vtln_warp_freq", "vtln_warp_mel_freq", "spectrogram_batch", "fbank_batch", "mfcc_batch"]
 
 EPSILON = torch.tensor(torch.finfo(torch.float).eps)
 MILLISECONDS_TO_SECONDS = 0.001
@@ -37,6 +41,9 @@ mel_scale = _host.kaldi_mel_scale
 vtln_warp_freq = _host.kaldi_vtln_warp_freq
 vtln_warp_mel_freq = _host.kaldi_vtln_warp_mel_freq
 get_mel_banks = _host.kaldi_get_mel_banks
+
+
+_ALL = object()        # `channel` sentinel of the *_batch functions
 
 
 def _randn(shape, device, dtype) -> Tensor:
@@ -58,13 +65,16 @@ def _num_frames(num_samples: int, window_size: int, window_shift: int, snip_edge
 def _properties(waveform: Tensor, channel: int, sample_frequency: float, frame_shift: float, frame_length: float,
                 round_to_power_of_two: bool, preemphasis_coefficient: float) -> Tuple[Tensor, int, int, int]:
     """kaldi.py:125-151 with the reference's assertions."""
-    channel = max(channel, 0)
-    assert channel < waveform.size(0), "Invalid channel {} for size {}".format(channel, waveform.size(0))
-    waveform = waveform[channel, :]
+    if channel is _ALL:                       # the *_batch extension: every row is an utterance
+        assert waveform.dim() == 2, "waveforms must be (B, n)"
+    else:
+        channel = max(channel, 0)
+        assert channel < waveform.size(0), "Invalid channel {} for size {}".format(channel, waveform.size(0))
+        waveform = waveform[channel, :]
     window_shift = int(sample_frequency * frame_shift * MILLISECONDS_TO_SECONDS)
     window_size = int(sample_frequency * frame_length * MILLISECONDS_TO_SECONDS)
     padded_window_size = _next_power_of_2(window_size) if round_to_power_of_two else window_size
-    assert 2 <= window_size <= len(waveform), "choose a window size {} that is [2, {}]".format(window_size, len(waveform))
+    assert 2 <= window_size <= waveform.size(-1), "choose a window size {} that is [2, {}]".format(window_size, waveform.size(-1))
     assert 0 < window_shift, "`window_shift` must be greater than 0"
     assert padded_window_size % 2 == 0, (
         "the padded `window_size` must be divisible by two." " use `round_to_power_of_two` or change `frame_length`")
@@ -85,31 +95,38 @@ def _features(waveform: Tensor, window_shift: int, window_size: int, padded: int
     if waveform.dtype != torch.float32:
         raise TypeError(f"audio_amd: kaldi features need float32 waveforms, got {waveform.dtype}")
     dev = waveform.device
-    x = waveform.contiguous()
-    m = _num_frames(x.numel(), window_size, window_shift, snip_edges)
-    if m == 0:
-        return torch.empty((0, 0), dtype=torch.float32, device=dev)
+    x = waveform if waveform.stride(-1) == 1 else waveform.contiguous()
+    batch = x.dim() == 2
+    n_utt = x.size(0) if batch else 1
+    n = x.size(-1)
+    if batch and n_utt > 1 and x.stride(0) < n:
+        x = x.contiguous()
+    m = _num_frames(n, window_size, window_shift, snip_edges)
+    if m == 0 or n_utt == 0:
+        return torch.empty((n_utt, 0, 0) if batch else (0, 0), dtype=torch.float32, device=dev)
     key = ("kaldi_win", window_type, window_size, padded, blackman_coeff, str(dev))
     win = F._cached(key, lambda: torch.nn.functional.pad(
         _host.kaldi_window(window_type, window_size, blackman_coeff), (0, padded - window_size)).to(dev).contiguous())
     noise = None
     if dither != 0.0:
         # kaldi.py:180-183: rand_gauss = torch.randn(strided_input.shape, device, dtype); frames += rand_gauss * dither
-        noise = _randn((m, window_size), device=dev, dtype=torch.float32).contiguous()
-    out = torch.empty((m, n_cols), dtype=torch.float32, device=dev)
-    d = _lib.KaldiDesc(x.numel(), m, padded, window_shift, window_size, int(snip_edges), float(preemphasis_coefficient),
+        noise = _randn((n_utt, m, window_size) if batch else (m, window_size), device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty((n_utt, m, n_cols) if batch else (m, n_cols), dtype=torch.float32, device=dev)
+    d = _lib.KaldiDesc(n, m, padded, window_shift, window_size, int(snip_edges), float(preemphasis_coefficient),
                        int(remove_dc_offset), int(raw_energy), float(energy_floor), int(use_power), int(use_log),
-                       energy_col, first_col, n_cols, float(dither), None if noise is None else noise.data_ptr())
+                       energy_col, first_col, n_cols, float(dither), None if noise is None else noise.data_ptr(),
+                       n_utt, x.stride(0) if batch and n_utt > 1 else n)
     L = _lib.lib()
-    _lib.check(L.aamd_kaldi_features_f32(x.data_ptr(), win.data_ptr(), F._twiddles(padded, dev).data_ptr(),
-                                         None if bands is None else C.byref(bands.struct), out.data_ptr(), C.byref(d),
-                                         _lib.current_stream(dev)))
+    with torch.cuda.device(dev):
+        _lib.check(L.aamd_kaldi_features_f32(x.data_ptr(), win.data_ptr(), F._twiddles(padded, dev).data_ptr(),
+                                             None if bands is None else C.byref(bands.struct), out.data_ptr(), C.byref(d),
+                                             _lib.current_stream(dev)))
     return out
 
 
 def _subtract_column_mean(tensor: Tensor, subtract_mean: bool) -> Tensor:
     if subtract_mean:
-        tensor = tensor - torch.mean(tensor, dim=0).unsqueeze(0)
+        tensor = tensor - torch.mean(tensor, dim=-2, keepdim=True)
     return tensor
 
 
@@ -123,7 +140,7 @@ def spectrogram(
     r"""Kaldi's compute-spectrogram-feats (reference: compliance/kaldi.py:229-315): (m, padded_window_size // 2 + 1)."""
     waveform, window_shift, window_size, padded = _properties(
         waveform, channel, sample_frequency, frame_shift, frame_length, round_to_power_of_two, preemphasis_coefficient)
-    if len(waveform) < min_duration * sample_frequency:
+    if waveform.size(-1) < min_duration * sample_frequency:
         return torch.empty(0)
     out = _features(waveform, window_shift, window_size, padded, window_type, blackman_coeff, snip_edges, raw_energy,
                     energy_floor, dither, remove_dc_offset, preemphasis_coefficient, None, True, True, -1, 0, padded // 2 + 1)
@@ -143,7 +160,7 @@ def fbank(
     device, dtype = waveform.device, waveform.dtype
     waveform, window_shift, window_size, padded = _properties(
         waveform, channel, sample_frequency, frame_shift, frame_length, round_to_power_of_two, preemphasis_coefficient)
-    if len(waveform) < min_duration * sample_frequency:
+    if waveform.size(-1) < min_duration * sample_frequency:
         return torch.empty(0, device=device, dtype=dtype)
     key = ("kaldi_banks", num_mel_bins, padded, sample_frequency, low_freq, high_freq, vtln_low, vtln_high, vtln_warp,
            str(device))
@@ -199,21 +216,41 @@ def mfcc(
     if feature.numel() == 0:
         return feature
     if use_energy:
-        signal_log_energy = feature[:, num_mel_bins if htk_compat else 0]
+        signal_log_energy = feature[..., num_mel_bins if htk_compat else 0]
         mel_offset = int(not htk_compat)
-        feature = feature[:, mel_offset:(num_mel_bins + mel_offset)]
+        feature = feature[..., mel_offset:(num_mel_bins + mel_offset)]
     dct_matrix = F._cached(("kaldi_dct", num_ceps, num_mel_bins, str(device)),
                            lambda: _get_dct_matrix(num_ceps, num_mel_bins).to(dtype=torch.float32, device=device).contiguous())
     # (m, num_mel_bins) @ (num_mel_bins, num_ceps) on the MFCC path's DCT kernel (log_mode 0: plain product)
-    feature = F._dct_rows(feature.contiguous(), dct_matrix)
+    lead = feature.shape[:-1]
+    feature = F._dct_rows(feature.reshape(-1, num_mel_bins).contiguous(), dct_matrix).reshape(lead + (num_ceps,))
     if cepstral_lifter != 0.0:
-        feature = feature * _get_lifter_coeffs(num_ceps, cepstral_lifter).unsqueeze(0).to(device=device, dtype=torch.float32)
+        feature = feature * _get_lifter_coeffs(num_ceps, cepstral_lifter).to(device=device, dtype=torch.float32)
     if use_energy:
-        feature[:, 0] = signal_log_energy
+        feature[..., 0] = signal_log_energy
     if htk_compat:
-        energy = feature[:, 0].unsqueeze(1)
-        feature = feature[:, 1:]
+        energy = feature[..., 0].unsqueeze(-1)
+        feature = feature[..., 1:]
         if not use_energy:
             energy = energy * math.sqrt(2)
-        feature = torch.cat((feature, energy), dim=1)
+        feature = torch.cat((feature, energy), dim=-1)
     return _subtract_column_mean(feature, subtract_mean)
+
+
+def spectrogram_batch(waveforms: Tensor, **kwargs) -> Tensor:
+    """EXTENSION: `spectrogram` of B equal-length utterances (B, n) -> (B, m, padded // 2 + 1) in one launch; keyword
+    arguments as `spectrogram` (without `channel`)."""
+    assert "channel" not in kwargs, "the batch functions take every row as an utterance"
+    return spectrogram(waveforms, channel=_ALL, **kwargs)
+
+
+def fbank_batch(waveforms: Tensor, **kwargs) -> Tensor:
+    """EXTENSION: `fbank` of B equal-length utterances (B, n) -> (B, m, num_mel_bins + use_energy) in one launch."""
+    assert "channel" not in kwargs, "the batch functions take every row as an utterance"
+    return fbank(waveforms, channel=_ALL, **kwargs)
+
+
+def mfcc_batch(waveforms: Tensor, **kwargs) -> Tensor:
+    """EXTENSION: `mfcc` of B equal-length utterances (B, n) -> (B, m, num_ceps): one feature launch + one DCT launch."""
+    assert "channel" not in kwargs, "the batch functions take every row as an utterance"
+    return mfcc(waveforms, channel=_ALL, **kwargs)

@@ -543,6 +543,9 @@ int aamd_kaldi_features_f32(const float* wav, const float* window, const float* 
   kg.use_power = d->use_power; kg.use_log = d->use_log;
   kg.energy_col = d->energy_col; kg.first_col = d->first_col; kg.n_cols = d->n_cols;
   kg.noise = d->dither != 0.0f ? d->noise : nullptr; kg.dither = d->dither;
+  kg.n_utt = d->n_utt > 1 ? d->n_utt : 1;
+  kg.utt_stride = d->n_utt > 1 ? d->utt_stride : d->n_samples;
+  AAMD_CHECK_ARG(kg.utt_stride >= d->n_samples, "utt_stride < n_samples");
   const bool pow2 = d->n_fft == 256 || d->n_fft == 512 || d->n_fft == 1024 || d->n_fft == 2048;
   if (!pow2 || force_generic()) {
     // any even padded window: mixed-radix Stockham stages in LDS (csrc/kaldi_generic.h)
@@ -555,25 +558,26 @@ int aamd_kaldi_features_f32(const float* wav, const float* window, const float* 
     const size_t lds = kgen::lds_floats(d->n_fft, pb) * sizeof(float);
     if (lds > dev_props().lds_per_block_optin)
       return fail(AAMD_EUNSUPPORTED, "audio_amd: padded window too long for the LDS");
-    const int64_t nblk = (d->n_frames + 2 * pb - 1) / (2 * pb);
+    const int64_t bpu = (d->n_frames + 2 * pb - 1) / (2 * pb);
+    const int64_t nblk = bpu * kg.n_utt;
     AAMD_CHECK_ARG(nblk < (1ll << 31), "too many frames for one launch");
     const auto* twg = reinterpret_cast<const cplx<float>*>(twiddle);
     if (bands == nullptr) {
       auto kk = kgen::kaldi_generic_kernel<0>;
       if (lds > 48 * 1024)
         AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kk, dim3((unsigned)nblk), dim3(kgen::kThreads), lds, (hipStream_t)stream, kg, plan, pb, wav, window,
-                         twg, mb, out);
+      hipLaunchKernelGGL(kk, dim3((unsigned)nblk), dim3(kgen::kThreads), lds, (hipStream_t)stream, kg, plan, pb, (int)bpu, wav,
+                         window, twg, mb, out);
     } else {
       auto kk = kgen::kaldi_generic_kernel<1>;
       if (lds > 48 * 1024)
         AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kk, dim3((unsigned)nblk), dim3(kgen::kThreads), lds, (hipStream_t)stream, kg, plan, pb, wav, window,
-                         twg, mb, out);
+      hipLaunchKernelGGL(kk, dim3((unsigned)nblk), dim3(kgen::kThreads), lds, (hipStream_t)stream, kg, plan, pb, (int)bpu, wav,
+                         window, twg, mb, out);
     }
     return launch_check();
   }
-  const int64_t n_pairs = (d->n_frames + 1) / 2;
+  const int64_t n_pairs = (d->n_frames + 1) / 2 * kg.n_utt;
   int64_t blocks = (int64_t)dev_props().cu_count * 4;
   const int64_t need = (n_pairs + p2::kWaves - 1) / p2::kWaves;
   if (blocks > need) blocks = need;
@@ -1113,27 +1117,87 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
     int W = 1;
     while (W < lfw::kMaxWaves && n_seq * (2 * W) <= 8192 && (int64_t)W * lfw::kWaveBlock < length) W *= 2;
     const size_t cap = dev_props().lds_per_block_optin ? dev_props().lds_per_block_optin : 64 * 1024;
+    static const int lab_w = [] { const char* e = std::getenv("AAMD_LFW_W"); return e ? std::atoi(e) : 0; }();    // tools only
+    if (lab_w >= 1 && lab_w <= lfw::kMaxWaves && (lab_w & (lab_w - 1)) == 0) W = lab_w;
     while (W > 1 && lfw::lds_bytes(W, n_stages) > cap) W /= 2;
     const size_t lds = lfw::lds_bytes(W, n_stages);
     if (lds <= cap) {
       const int blocks = grid_for(n_seq, 1, dev_props().cu_count * 8);
-      const int vec_ok = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0) &&
-                         (length % 4 == 0);
       static const int lab = [] { const char* e = std::getenv("AAMD_LFW_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
-#define AAMD_LFW(LL)                                                                                               \
+      const int vec_ok = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0) &&
+                         (length % 4 == 0) && lab != 64;      // lab 64: the dword copies also for aligned rows
+#define AAMD_LFW(LL, MW, VV)                                                                                       \
       {                                                                                                            \
-        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lfw::lfilter_wave_kernel<LL>),                  \
+        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lfw::lfilter_wave_kernel<LL, MW, VV>),          \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
-        hipLaunchKernelGGL(lfw::lfilter_wave_kernel<LL>, dim3(blocks), dim3(64 * W), lds, s, x, a, b, y, n_seq,    \
-                           channels, length, n_order, n_coeff_rows, n_stages, clamp, vec_ok);                      \
+        hipLaunchKernelGGL((lfw::lfilter_wave_kernel<LL, MW, VV>), dim3(blocks), dim3(64 * W), lds, s, x, a, b, y, \
+                           n_seq, channels, length, n_order, n_coeff_rows, n_stages, clamp);                       \
       }
-      switch (lab) {
-        case 1: AAMD_LFW(1) break;
-        case 3: AAMD_LFW(3) break;
-        case 7: AAMD_LFW(7) break;
-        case 15: AAMD_LFW(15) break;
-        default: AAMD_LFW(0)
+#define AAMD_LFW_LABS(MW)                                                                                          \
+      switch (vec_ok ? lab : 0) {                                                                                  \
+        case 1: AAMD_LFW(1, MW, true) break;                                                                       \
+        case 2: AAMD_LFW(2, MW, true) break;                                                                       \
+        case 4: AAMD_LFW(4, MW, true) break;                                                                       \
+        case 8: AAMD_LFW(8, MW, true) break;                                                                       \
+        case 15: AAMD_LFW(15, MW, true) break;                                                                     \
+        case 16: AAMD_LFW(16, MW, true) break;                                                                     \
+        case 32: AAMD_LFW(32, MW, true) break;                                                                     \
+        case 63: AAMD_LFW(63, MW, true) break;                                                                     \
+        case 128: AAMD_LFW(128, MW, true) break;                                                                   \
+        case 256: AAMD_LFW(256, MW, true) break;                                                                   \
+        case 512: AAMD_LFW(512, MW, true) break;                                                                   \
+        case 896: AAMD_LFW(896, MW, true) break;                                                                   \
+        default:                                                                                                   \
+          if (vec_ok) AAMD_LFW(0, MW, true) else AAMD_LFW(0, MW, false)                                            \
       }
+      static const int lab_pipe = [] { const char* e = std::getenv("AAMD_LFW_PIPE"); return e ? std::atoi(e) : -1; }();   // tools only
+      const bool pipe = vec_ok && W >= 8 && lab_pipe != 0 && lfw::pipe_lds_bytes(8, n_stages) <= cap;
+      if (pipe && n_stages >= 3 && lab_pipe != 1) {   // + 4 mover waves that own the copies and the stores
+        const size_t plds = lfw::pipe_lds_bytes(8, n_stages);
+#define AAMD_LFWM(LL)                                                                                              \
+        {                                                                                                          \
+          AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lfw::lfilter_wave_mover_kernel<LL>),          \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));                    \
+          hipLaunchKernelGGL((lfw::lfilter_wave_mover_kernel<LL>), dim3(blocks), dim3(64 * (8 + lfw::kMovers)),    \
+                             plds, s, x, a, b, y, n_seq, channels, length, n_order, n_coeff_rows, n_stages, clamp);\
+        }
+        switch (lab) {
+          case 1: AAMD_LFWM(1) break;
+          case 16: AAMD_LFWM(16) break;
+          case 32: AAMD_LFWM(32) break;
+          case 48: AAMD_LFWM(48) break;
+          default: AAMD_LFWM(0)
+        }
+#undef AAMD_LFWM
+      } else if (pipe) {        // two tiles per wave, copies and stores spread over the stages (8 waves)
+        W = 8;
+        const size_t plds = lfw::pipe_lds_bytes(8, n_stages);
+#define AAMD_LFWP(LL)                                                                                              \
+        {                                                                                                          \
+          AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lfw::lfilter_wave_pipe_kernel<LL>),           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));                    \
+          hipLaunchKernelGGL((lfw::lfilter_wave_pipe_kernel<LL>), dim3(blocks), dim3(512), plds, s, x, a, b, y,    \
+                             n_seq, channels, length, n_order, n_coeff_rows, n_stages, clamp);                     \
+        }
+        switch (lab) {
+          case 1: AAMD_LFWP(1) break;
+          case 15: AAMD_LFWP(15) break;
+          case 16: AAMD_LFWP(16) break;
+          case 32: AAMD_LFWP(32) break;
+          case 48: AAMD_LFWP(48) break;
+          case 50: AAMD_LFWP(50) break;
+          case 52: AAMD_LFWP(52) break;
+          case 56: AAMD_LFWP(56) break;
+          case 63: AAMD_LFWP(63) break;
+          default: AAMD_LFWP(0)
+        }
+#undef AAMD_LFWP
+      } else if (W <= 8) {      // 512 threads: the 256-register instantiation
+        AAMD_LFW_LABS(8)
+      } else {
+        AAMD_LFW_LABS(16)
+      }
+#undef AAMD_LFW_LABS
 #undef AAMD_LFW
       return launch_check();
     }

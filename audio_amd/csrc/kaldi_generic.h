@@ -187,14 +187,18 @@ struct Plan {
 // MODE 0: kaldi.spectrogram rows [N/2 + 1]; MODE 1: kaldi.fbank rows [n_cols]
 template <int MODE>
 __global__ void __launch_bounds__(kThreads)
-kaldi_generic_kernel(KaldiGeom kg, Plan plan, int pb, const float* __restrict__ wav,
+kaldi_generic_kernel(KaldiGeom kg, Plan plan, int pb, int blocks_per_utt, const float* wav,
                      const float* __restrict__ window /* [N], 0 past win */, const cplx<float>* __restrict__ tw,
-                     MelBandsDev mb, float* __restrict__ out) {
+                     MelBandsDev mb, float* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_kg[];
   const int N = plan.n_fft, nf = 2 * pb;
   const Lds l = carve(reinterpret_cast<float*>(smem_kg), N, pb);
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int64_t t0 = (int64_t)blockIdx.x * nf;
+  const int64_t utt = blockIdx.x / blocks_per_utt;            // batch extension: one utterance per group of workgroups
+  const int64_t t0 = (int64_t)(blockIdx.x - utt * blocks_per_utt) * nf;
+  wav += utt * kg.utt_stride;
+  out += utt * kg.n_frames * (MODE == 0 ? (int64_t)(N / 2 + 1) : (int64_t)kg.n_cols);
+  if (kg.noise != nullptr) kg.noise += utt * kg.n_frames * kg.win;
   for (int i = tid; i < N; i += nthr) l.twl[i] = tw[i];
   pass_sum(tid, nthr, nf, kg, wav, t0, l.red);
   __syncthreads();

@@ -490,6 +490,7 @@ struct KaldiGeom {
   int32_t energy_col, first_col, n_cols;   // output row: [n_cols]; energy_col < 0: no energy column
   const float* noise;                 // dither: unit Gaussian noise [n_frames][win] (kaldi.py:180-183), or null
   float dither;
+  int64_t n_utt, utt_stride;          // batch extension: n_utt waveforms of n_samples each, utt_stride apart; outputs / noise per utterance
 };
 
 // sample j of frame t (kaldi.py:44-83 _get_strided): snip_edges reads the signal as is; otherwise the signal is
@@ -798,19 +799,28 @@ AAMD_D float wave_sum(float v) {
 // MODE 0: kaldi.spectrogram rows [N/2 + 1]; MODE 1: kaldi.fbank rows [n_cols]
 template <int E, int MODE>
 __global__ void __launch_bounds__(64 * kWaves)
-kaldi_pow2_kernel(KaldiGeom kg, const float* __restrict__ wav, const float* __restrict__ window /* [N], 0 past win */,
-                  const C32* __restrict__ tw, MelBandsDev mb, float* __restrict__ out) {
+kaldi_pow2_kernel(KaldiGeom kg, const float* wav, const float* __restrict__ window /* [N], 0 past win */,
+                  const C32* __restrict__ tw, MelBandsDev mb, float* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_p2[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   C32* lds = reinterpret_cast<C32*>(smem_p2) + wave * Cfg<E>::lds_complex;
   LaneTab<E> lt;
   lane_tab<E>(lane, window, tw, 2.0f, lt);                   // win = window (lane_tab folds 0.5 * scale)
-  const int64_t n_pairs = (kg.n_frames + 1) / 2;
+  const int64_t ppu = (kg.n_frames + 1) / 2;                  // frame pairs per utterance
+  const int64_t n_pairs = ppu * kg.n_utt;
   const int64_t n_waves = (int64_t)gridDim.x * kWaves;
   const float inv_win = 1.0f / (float)kg.win;
+  const float* const wav0 = wav;
+  float* const out0 = out;
+  const float* const noise0 = kg.noise;
+  const int64_t out_row = MODE == 0 ? (Cfg<E>::N / 2 + 1) : kg.n_cols;
 #pragma unroll 1
-  for (int64_t pair = (int64_t)blockIdx.x * kWaves + wave; pair < n_pairs; pair += n_waves) {
+  for (int64_t gp = (int64_t)blockIdx.x * kWaves + wave; gp < n_pairs; gp += n_waves) {
+    const int64_t utt = gp / ppu, pair = gp - utt * ppu;
+    wav = wav0 + utt * kg.utt_stride;                         // this utterance's samples, rows and dither draws
+    out = out0 + utt * kg.n_frames * out_row;
+    kg.noise = noise0 ? noise0 + utt * kg.n_frames * kg.win : nullptr;
     const int64_t ta = 2 * pair;
     float ra[E], rpa[E], rb[E], rpb[E], ya[E], yb[E];
     kaldi_load<E>(lane, kg, wav, ta, ra, rpa);

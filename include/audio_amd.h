@@ -208,7 +208,9 @@ typedef struct aamd_kaldi_desc {
   int32_t use_power, use_log;
   int32_t energy_col, first_col, n_cols;
   float dither;                        /* 0: off; else frames += dither * noise (kaldi.py:180-183) */
-  const float* noise;                  /* device float[n_frames][win] unit Gaussian draws (the caller's RNG), NULL if dither == 0 */
+  const float* noise;                  /* device float[n_utt][n_frames][win] unit Gaussian draws (the caller's RNG), NULL if dither == 0 */
+  int64_t n_utt;                       /* 0 or 1: one waveform (the reference's API); > 1: a batch of equal-length utterances */
+  int64_t utt_stride;                  /* samples between utterances (>= n_samples); out is float[n_utt][n_frames][row] */
 } aamd_kaldi_desc;
 int aamd_kaldi_features_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
                             float* out, const aamd_kaldi_desc* desc, void* stream);

@@ -367,6 +367,7 @@ int sim_kaldi_features(const float* wav, const float* window, const float* tw, c
   MelBandsDev mb{};
   if (bands) { mb.n_mels = bands->n_mels; mb.max_width = bands->max_width; mb.lo = bands->lo; mb.width = bands->width; mb.weights = bands->weights; }
   kg.noise = d->dither != 0.0f ? d->noise : nullptr; kg.dither = d->dither;
+  kg.n_utt = 1; kg.utt_stride = d->n_samples;
   const int mode = bands ? 1 : 0;
   const bool pow2 = d->n_fft == 256 || d->n_fft == 512 || d->n_fft == 1024 || d->n_fft == 2048;
   if (!pow2 || g_force_generic) {   // replay of kgen::kaldi_generic_kernel, phase by phase
@@ -811,8 +812,8 @@ static int sim_lfilter_d(const float* x, const float* a, const float* b, float* 
   return 0;
 }
 
-// Replay of lfw::lfilter_wave_kernel: W waves x 64 lanes per sequence, shuffles as array reads,
-// phases cut where the kernel has workgroup barriers.
+// Replay of lfw::lfilter_wave_kernel: W waves x 64 lanes per sequence, DPP moves as array reads (lfw::scan_src is the
+// lane map of both), phases cut where the kernel has its workgroup barrier.
 extern "C" int sim_lfilter_wave(const float* x, const float* a, const float* b, float* y, int64_t batch, int channels,
                                 int64_t length, int n_order, int n_rows, int n_stages, int clamp, int W) {
   using namespace lfw;
@@ -821,8 +822,18 @@ extern "C" int sim_lfilter_wave(const float* x, const float* a, const float* b, 
   const int64_t block_len = (int64_t)W * kWaveBlock;
   std::vector<float> tiles((size_t)W * kTile), tabs((size_t)n_stages * kTabFloats), xch(xch_floats(W, n_stages));
   std::vector<std::vector<float>> v(W * 64, std::vector<float>(kCh)), z(W * 64, std::vector<float>(kCh));
-  std::vector<float> s0(W * 64), s1(W * 64), t0(W * 64), t1(W * 64);
+  std::vector<float> s0(W * 64), s1(W * 64), t0(64), t1(64), hin0(W), hin1(W), e0(W), e1(W);
   auto arr = [](std::vector<float>& r) -> float(&)[kCh] { return *reinterpret_cast<float(*)[kCh]>(r.data()); };
+  // one DPP step over 64 lanes: lane l adds M_l . (value of lane src(l)), zeros without a source
+  auto dpp_step = [&](float* p0, float* p1, int step, const float* tab, bool fold) {
+    for (int lane = 0; lane < 64; ++lane) {
+      const int src = scan_src(step, lane);
+      t0[lane] = src >= 0 ? p0[src] : 0.0f;
+      t1[lane] = src >= 0 ? p1[src] : 0.0f;
+    }
+    for (int lane = 0; lane < 64; ++lane)
+      mat_acc(fold ? fold_mat(tab, step) : scan_mat(tab, step, lane), t0[lane], t1[lane], p0[lane], p1[lane]);
+  };
   for (int64_t seq = 0; seq < n_seq; ++seq) {
     const int crow = (n_rows == 1) ? 0 : (int)(seq % channels);
     for (int st = 0; st < n_stages; ++st) {
@@ -832,63 +843,57 @@ extern "C" int sim_lfilter_wave(const float* x, const float* a, const float* b, 
     std::fill(xch.begin(), xch.end(), 0.0f);
     const float* xs = x + seq * length;
     float* ys = y + seq * length;
-    int parity = 0;
+    int parity = 0, sbuf = 0;
     for (int64_t n0 = 0; n0 < length; n0 += block_len, parity ^= 1) {
-      for (int w = 0; w < W; ++w) {
+      for (int w = 0; w < W; ++w) {   // the block's samples and the 64 before them, through the tile
         float* tile = tiles.data() + (size_t)w * kTile;
         const int64_t nw = n0 + (int64_t)w * kWaveBlock;
-        for (int sidx = 0; sidx < kWaveBlock; ++sidx) tile[tile_idx(sidx)] = (nw + sidx < length) ? xs[nw + sidx] : 0.0f;
+        for (int sidx = -64; sidx < kWaveBlock; ++sidx)
+          tile[tile_idx(sidx)] = (nw + sidx >= 0 && nw + sidx < length) ? xs[nw + sidx] : 0.0f;
         for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < kCh; ++j) v[w * 64 + lane][j] = tile[lane * kRow + j];
-        xch[xch_tail(W, n_stages, parity, 0, w)] = v[w * 64 + 63][kCh - 1];
-        xch[xch_tail(W, n_stages, parity, 0, w) + 1] = v[w * 64 + 63][kCh - 2];
+          for (int j = 0; j < kCh; ++j) v[w * 64 + lane][j] = tile[tile_idx(kCh * lane + j)];
+        hin0[w] = nw > 0 ? tile[tile_idx(-1)] : 0.0f;
+        hin1[w] = nw > 0 ? tile[tile_idx(-2)] : 0.0f;
       }
-      for (int st = 0; st < n_stages; ++st) {
+      for (int st = 0; st < n_stages; ++st, sbuf ^= 1) {
         const float* tab = tabs.data() + st * kTabFloats;
         for (int w = 0; w < W; ++w) {
           for (int lane = 0; lane < 64; ++lane) {
-            float hu0, hu1;
+            float hu0 = hin0[w], hu1 = hin1[w];
             if (lane > 0) { hu0 = v[w * 64 + lane - 1][kCh - 1]; hu1 = v[w * 64 + lane - 1][kCh - 2]; }
-            else {
-              const int src = (w > 0) ? xch_tail(W, n_stages, parity, st, w - 1) : xch_tail(W, n_stages, parity ^ 1, st, W - 1);
-              hu0 = xch[src]; hu1 = xch[src + 1];
-            }
             z[w * 64 + lane] = v[w * 64 + lane];   // the kernel filters in place; keep v for the neighbour's history
             chunk_pass(tab, arr(z[w * 64 + lane]), hu0, hu1, s0[w * 64 + lane], s1[w * 64 + lane]);
           }
-          for (int k = 0; k < kScanSteps; ++k) {
-            for (int lane = 0; lane < 64; ++lane) {
-              const int src = lane >= (1 << k) ? lane - (1 << k) : lane;
-              t0[w * 64 + lane] = s0[w * 64 + src]; t1[w * 64 + lane] = s1[w * 64 + src];
-            }
-            for (int lane = 0; lane < 64; ++lane)
-              scan_step(tab, k, lane >= (1 << k), t0[w * 64 + lane], t1[w * 64 + lane], s0[w * 64 + lane], s1[w * 64 + lane]);
-          }
-          xch[xch_S(w)] = s0[w * 64 + 63];
-          xch[xch_S(w) + 1] = s1[w * 64 + 63];
+          for (int k = 0; k < 6; ++k) dpp_step(&s0[w * 64], &s1[w * 64], k, tab, false);
+          xch[xch_S(W, sbuf, w)] = s0[w * 64 + 63];
+          xch[xch_S(W, sbuf, w) + 1] = s1[w * 64 + 63];
         }
-        // barrier 1
+        // the barrier
         const int cin = xch_carry(W, n_stages, parity, st);
         for (int w = 0; w < W; ++w) {
-          float e0, e1;
-          fold_entering(tab, xch.data(), w, xch[cin], xch[cin + 1], e0, e1);
+          float f0[64], f1[64];
           for (int lane = 0; lane < 64; ++lane) {
-            float p0, p1;
-            mat_apply(tab + kTabPow + 4 * lane, e0, e1, p0, p1);
-            s0[w * 64 + lane] += p0; s1[w * 64 + lane] += p1;
+            const bool on = (lane & 15) < W;
+            f0[lane] = on ? xch[xch_S(W, sbuf, lane & 15)] : 0.0f;
+            f1[lane] = on ? xch[xch_S(W, sbuf, lane & 15) + 1] : 0.0f;
           }
+          for (int k = 0; k < 4; ++k) dpp_step(f0, f1, k, tab, true);
+          const int from = w > 0 ? w - 1 : 0;
+          fold_finish(tab, w, f0[from], f1[from], xch[cin], xch[cin + 1], e0[w], e1[w]);
+          for (int lane = 0; lane < 64; ++lane)
+            mat_acc(tab + kTabPow + 4 * lane, e0[w], e1[w], s0[w * 64 + lane], s1[w * 64 + lane]);
           for (int lane = 0; lane < 64; ++lane) {
-            const float tt0 = lane ? s0[w * 64 + lane - 1] : e0, tt1 = lane ? s1[w * 64 + lane - 1] : e1;
+            const float tt0 = lane ? s0[w * 64 + lane - 1] : e0[w], tt1 = lane ? s1[w * 64 + lane - 1] : e1[w];
             correct_clamp(tab, tt0, tt1, clamp, arr(z[w * 64 + lane]));
           }
         }
-        for (int w = 0; w < W; ++w) {   // writes that the kernel does before barrier 2
+        for (int w = 0; w < W; ++w) {
           if (w == W - 1) {
             const int cout = xch_carry(W, n_stages, parity ^ 1, st);
             xch[cout] = s0[w * 64 + 63]; xch[cout + 1] = s1[w * 64 + 63];
           }
-          xch[xch_tail(W, n_stages, parity, st + 1, w)] = z[w * 64 + 63][kCh - 1];
-          xch[xch_tail(W, n_stages, parity, st + 1, w) + 1] = z[w * 64 + 63][kCh - 2];
+          hin0[w] = clamp1(e0[w], clamp);
+          hin1[w] = clamp1(e1[w], clamp);
           for (int lane = 0; lane < 64; ++lane) v[w * 64 + lane] = z[w * 64 + lane];
         }
       }
@@ -896,7 +901,7 @@ extern "C" int sim_lfilter_wave(const float* x, const float* a, const float* b, 
         float* tile = tiles.data() + (size_t)w * kTile;
         const int64_t nw = n0 + (int64_t)w * kWaveBlock;
         for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < kCh; ++j) tile[lane * kRow + j] = v[w * 64 + lane][j];
+          for (int j = 0; j < kCh; ++j) tile[tile_idx(kCh * lane + j)] = v[w * 64 + lane][j];
         for (int sidx = 0; sidx < kWaveBlock; ++sidx)
           if (nw + sidx < length) ys[nw + sidx] = tile[tile_idx(sidx)];
       }

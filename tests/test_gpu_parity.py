@@ -505,6 +505,31 @@ def test_lfilter_wave_kernel_shape_edges():
     assert peak_rel_err(got.cpu().numpy(), exp) <= 1e-4
 
 
+@pytest.mark.parametrize("n_stages,length", [(1, 70004), (2, 40964), (3, 16384 + 8), (4, 65536), (8, 20000)])
+def test_lfilter_pipelined_kernel_against_oracle(n_stages, length):
+    """Long, 16-byte aligned rows take the two-tile kernel (copies and stores issued a few pieces per stage): whole blocks,
+    a ragged last block (waves partly / wholly past the end), a length that is an exact multiple of the block, every
+    piece-per-stage split (1, 2, 3, 4, 8 stages) -- against the sequential float64 cascade, clamped per stage."""
+    import audio_amd.functional as F
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(100 + n_stages)
+    x = (0.6 * torch.randn(3, 2, length, generator=g)).clamp_(-1, 1)
+    A, B = [], []
+    for s in range(n_stages):
+        w0 = 2 * math.pi * (300.0 + 700.0 * s) / 16000
+        alpha = math.sin(w0) / 2 / (0.6 + 0.1 * s)
+        A.append([1 + alpha, -2 * math.cos(w0), 1 - alpha])
+        B.append([1.3 * (1 - math.cos(w0)) / 2, 1.3 * (1 - math.cos(w0)), 1.3 * (1 - math.cos(w0)) / 2])   # gain > 1: clamps
+    a, b = torch.tensor(A), torch.tensor(B)
+    got = F.biquad_cascade(x.cuda(), a.cuda(), b.cuda()) if n_stages > 1 else F.lfilter(x.cuda(), a[0].cuda(), b[0].cuda())
+    exp = x.numpy().astype(np.float64)
+    for s in range(n_stages):
+        exp = O.lfilter(exp, a[s].numpy().astype(np.float64), b[s].numpy().astype(np.float64), True)
+    assert got.shape == x.shape
+    assert peak_rel_err(got.cpu().numpy(), exp) <= 2e-4, (n_stages, length)
+    assert float(np.abs(got.cpu().numpy()[..., -5:] - exp[..., -5:]).max()) <= 2e-4          # the ragged tail is written
+
+
 def test_resample_matrix_core_layout_edges():
     """Unaligned / strided inputs (scalar loader path) and a length shorter than one chunk."""
     import audio_amd.transforms as T

@@ -145,6 +145,54 @@ def test_gpu_generic_kaldi_kernel_equals_register_fft_kernel(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fn,kw", [
+    ("fbank", dict(num_mel_bins=80, use_energy=True)),
+    ("fbank", dict(round_to_power_of_two=False, num_mel_bins=40, subtract_mean=True)),
+    ("fbank", dict(sample_frequency=44100.0, num_mel_bins=40, snip_edges=False)),
+    ("spectrogram", dict(snip_edges=False, raw_energy=False)),
+    ("spectrogram", dict(round_to_power_of_two=False, sample_frequency=8000.0)),
+    ("mfcc", dict(use_energy=True, htk_compat=True, num_ceps=20, num_mel_bins=40, subtract_mean=True)),
+    ("mfcc", dict(round_to_power_of_two=False)),
+], ids=str)
+def test_gpu_kaldi_batch_extension_equals_the_per_utterance_calls(fn, kw):
+    """`*_batch` (one launch for B utterances) is bit-identical, row by row, to the reference-shaped single-utterance
+    call -- also from a strided (B, n) view, whose rows are not adjacent in memory."""
+    import audio_amd.compliance.kaldi as K
+    g = torch.Generator().manual_seed(11)
+    base = (torch.randn(5, 9000, generator=g) * 3000 + 40).cuda()
+    for wavs in (base[:, :7311], base[::2, 100:6100]):
+        y = getattr(K, fn + "_batch")(wavs, **kw)
+        assert y.dim() == 3 and y.size(0) == wavs.size(0)
+        for b in range(wavs.size(0)):
+            want = getattr(K, fn)(wavs, channel=b, **kw)
+            assert torch.equal(y[b], want), (fn, kw, b)
+
+
+@pytest.mark.gpu
+def test_gpu_kaldi_batch_extension_dither_and_edges(monkeypatch):
+    import audio_amd.compliance.kaldi as K
+    g = torch.Generator().manual_seed(12)
+    wavs = (torch.randn(3, 5000, generator=g) * 2000).cuda()
+    rec = torch.randn(3, 29, 400, generator=g)
+    for kw in (dict(), dict(round_to_power_of_two=False)):
+        monkeypatch.setattr(K, "_randn", lambda shape, device, dtype: rec.to(device=device, dtype=dtype).reshape(shape))
+        y = K.fbank_batch(wavs, dither=1.5, **kw)
+        for b in range(3):
+            monkeypatch.setattr(K, "_randn", lambda shape, device, dtype, b=b: rec[b].to(device=device, dtype=dtype).reshape(shape))
+            assert torch.equal(y[b], K.fbank(wavs, channel=b, dither=1.5, **kw))
+    monkeypatch.undo()
+    assert K.fbank_batch(wavs[:0]).shape == (0, 0, 0)
+    assert K.fbank_batch(wavs[:1]).shape == (1, 29, 23)
+    assert K.mfcc_batch(wavs, min_duration=10.0).numel() == 0
+    with pytest.raises(AssertionError):
+        K.fbank_batch(wavs, channel=0)
+    with pytest.raises(AssertionError):
+        K.fbank_batch(wavs[0])
+    with pytest.raises(AssertionError):
+        K.fbank_batch(wavs[:, :300])
+
+
+@pytest.mark.gpu
 def test_gpu_kaldi_errors_and_edges():
     import audio_amd.compliance.kaldi as K
     wav = torch.randn(1, 8000).cuda() * 1000
