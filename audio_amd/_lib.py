@@ -34,6 +34,13 @@ class MelBands(C.Structure):
     ]
 
 
+class MfccFused(C.Structure):
+    """aamd_mfcc_fused (include/audio_amd.h)."""
+    _fields_ = [("dct_frag", C.c_void_p), ("n_mfcc", C.c_int32), ("pass_", C.c_int32), ("multiplier", C.c_float),
+                ("amin", C.c_float), ("db_multiplier", C.c_float), ("top_db", C.c_float), ("group_max", C.c_void_p),
+                ("rows_per_group", C.c_int64), ("tile_min", C.c_void_p), ("fix_count", C.c_void_p)]
+
+
 class ResampleBands(C.Structure):
     _fields_ = [("n_tiles", C.c_int32), ("tap_span", C.c_int32), ("tap_lo", C.POINTER(C.c_int32))]
 
@@ -88,6 +95,11 @@ _SIGS = {
     "aamd_db_clamp_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, C.c_float, _P]),
     "aamd_mfcc_dct_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64,
                                     C.c_float, _P]),
+    "aamd_mfcc_frag_floats": (C.c_int32, []),
+    "aamd_mfcc_fused_tiles": (C.c_int64, [C.POINTER(StftDesc)]),
+    "aamd_mfcc_fused_supported": (C.c_int, [C.POINTER(StftDesc), C.POINTER(MelBands), C.c_int32]),
+    "aamd_mfcc_frag_build": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    "aamd_mfcc_fused_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.POINTER(MfccFused), _P]),
     "aamd_resample_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int64, _P]),
     "aamd_resample_banded_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,

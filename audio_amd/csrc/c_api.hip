@@ -405,6 +405,70 @@ int aamd_melspectrogram_f32(const float* wav, const float* window, const float* 
   return launch_generic<EPI_MEL>(g, mb, wav, window, twiddle, out, (hipStream_t)stream);
 }
 
+// ---- MFCC in one kernel (+ a fix-up launch for clamped tiles) --------------------------------------------------------
+namespace {
+bool mfcc_fused_ok(const StftGeom& g, const MelBandsDev& mb, int n_mfcc) {
+  return mel400_eligible(g, mb) && mb.n_mels == m400::kMfccMels && n_mfcc >= 4 && n_mfcc <= 16 * m400::kMfccMT &&
+         n_mfcc % 4 == 0;
+}
+}  // namespace
+
+int32_t aamd_mfcc_frag_floats(void) { return m400::kMfccFragFloats; }
+
+int64_t aamd_mfcc_fused_tiles(const aamd_stft_desc* desc) {
+  StftGeom g;
+  if (validate_desc(desc, g) != AAMD_OK) return -1;
+  return g.rows * ((g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave);
+}
+
+int aamd_mfcc_fused_supported(const aamd_stft_desc* desc, const aamd_mel_bands* bands, int32_t n_mfcc) {
+  StftGeom g;
+  if (validate_desc(desc, g) != AAMD_OK) return 0;
+  MelBandsDev mb;
+  if (validate_bands(bands, g.n_freq, mb) != AAMD_OK) return 0;
+  return mfcc_fused_ok(g, mb, n_mfcc) ? 1 : 0;
+}
+
+int aamd_mfcc_frag_build(const float* dct, int32_t n_mels, int32_t n_mfcc, float* frag, void* stream) {
+  DeviceScope dev_scope_(dct);
+  AAMD_CHECK_ARG(dct && frag, "null buffer");
+  AAMD_CHECK_ARG(n_mels >= 1 && n_mels <= m400::kMfccMels && n_mfcc >= 1 && n_mfcc <= 16 * m400::kMfccMT, "bad sizes");
+  hipLaunchKernelGGL(m400::mfcc_frag_build_kernel, dim3(15), dim3(256), 0, (hipStream_t)stream, dct, n_mels, n_mfcc, frag);
+  return launch_check();
+}
+
+int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
+                        float* out, const aamd_stft_desc* desc, const aamd_mfcc_fused* f, void* stream) {
+  DeviceScope dev_scope_(wav);
+  StftGeom g;
+  int rc = validate_desc(desc, g);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(wav && window && twiddle && out && f, "null buffer");
+  AAMD_CHECK_ARG(f->dct_frag && f->group_max && f->tile_min, "the fused MFCC needs dct_frag, group_max and tile_min");
+  AAMD_CHECK_ARG(f->rows_per_group >= 1 && (f->pass == 0 || f->pass == 1), "bad rows_per_group / pass");
+  AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(f->dct_frag) % 16 == 0,
+                 "out and dct_frag must be 16-byte aligned");
+  MelBandsDev mb;
+  rc = validate_bands(bands, g.n_freq, mb);
+  if (rc != AAMD_OK) return rc;
+  if (!mfcc_fused_ok(g, mb, f->n_mfcc))
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: the fused MFCC serves n_fft 400 / hop 100, 160, 200 / 80 mels / n_mfcc <= 48 "
+                                   "(multiple of 4); use aamd_melspectrogram_db_f32 + aamd_mfcc_dct_f32");
+  m400::Epi400 epi{};
+  epi.multiplier = f->multiplier; epi.amin = f->amin; epi.db_sub = f->multiplier * f->db_multiplier;
+  epi.group_max = f->group_max; epi.rows_per_group = f->rows_per_group;
+  epi.dct_frag = f->dct_frag; epi.n_mfcc = f->n_mfcc; epi.top_db = f->top_db; epi.tile_min = f->tile_min;
+  epi.fix_count = f->fix_count; epi.fixup = f->pass;
+  static const int mfcc_lab = [] { const char* e = std::getenv("AAMD_MFCC_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
+  epi.lab = mfcc_lab;
+  hipStream_t s = (hipStream_t)stream;
+  switch (g.hop) {
+    case 100: return launch_fft400_nr<m400::EPI400_MFCC, 5, float, 4>(g, mb, wav, window, twiddle, out, epi, s);
+    case 200: return launch_fft400_nr<m400::EPI400_MFCC, 10, float, 4>(g, mb, wav, window, twiddle, out, epi, s);
+    default: return launch_fft400_nr<m400::EPI400_MFCC, 8, float, 4>(g, mb, wav, window, twiddle, out, epi, s);
+  }
+}
+
 int aamd_melspectrogram_db_f32(const float* wav, const float* window, const float* twiddle,
                                const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
                                float multiplier, float amin, float db_multiplier, float* group_max,

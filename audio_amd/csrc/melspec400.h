@@ -127,7 +127,10 @@ static_assert(Hop<8>::lds_dwords == kLdsDwordsPerWave && Hop<8>::ndma == 5 && Ho
 //   EPI400_SPEC    no mel: |X|^power for the 201 one-sided bins -> out[rows][T][201]
 //   EPI400_MEL_NORM  the RNN-T front-end's feature post-processing fused (pipelines/rnnt_pipeline.py:16-47, 319-326):
 //                  y = piecewise_linear_log(mel * gain), (y - mean[m]) * invstddev[m], rows of out_frames >= T frames
-enum { EPI400_MEL = 0, EPI400_MEL_DB = 1, EPI400_SPEC = 2, EPI400_MEL_NORM = 3 };
+//   EPI400_MFCC    MEL_DB + the DCT-II product on the matrix cores: out[rows][T][n_mfcc] WITHOUT the top_db cut-off, the
+//                  group maximum and the minimum of every tile's dB values on the side; a second launch (`fixup`) redoes
+//                  only the tiles whose minimum lies under the cut-off, clamped (transforms/_transforms.py:692-709)
+enum { EPI400_MEL = 0, EPI400_MEL_DB = 1, EPI400_SPEC = 2, EPI400_MEL_NORM = 3, EPI400_MFCC = 4 };
 struct Epi400 {
   float multiplier, amin, db_sub;   // MEL_DB: y = multiplier * log10(max(x, amin)) - db_sub
   float* group_max;                 // MEL_DB: [n_groups] running max of y (float bit pattern), may be null
@@ -137,6 +140,13 @@ struct Epi400 {
   const float* mean;                // MEL_NORM: [n_mels]
   const float* invstd;              // MEL_NORM: [n_mels]
   int64_t out_frames;               // MEL_NORM: frames per clip in `out` (>= n_frames; the tail is the caller's)
+  const float* dct_frag;            // MFCC: the DCT matrix as MFMA A fragments (mfcc_frag_index), [kMfccFragFloats]
+  int n_mfcc;                       // MFCC: coefficients (<= 48, multiple of 4)
+  float top_db;                     // MFCC fix-up: cut-off = group_max[g] - top_db
+  float* tile_min;                  // MFCC: [n_tiles] minimum dB value of each tile (written by pass 0, read by the fix-up)
+  int* fix_count;                   // MFCC fix-up: number of tiles redone (atomic), may be null
+  int fixup;                        // MFCC: 0 = first pass, 1 = fix-up pass
+  int lab;                          // MFCC (tools only): 1 no fragment loads, 2 no MFMA, 4 no tile minimum, 8 no stores
 };
 constexpr int kSpecBins = 201;
 static_assert(kFramesPerWave * kSpecBins + 3 <= kSOff && 3 * 2 * kSpecBins + 3 <= kSOff, "SPEC rows must fit below the staging area");
@@ -148,6 +158,24 @@ AAMD_HD constexpr int col_of_pos(int pi) {
 }
 AAMD_HD constexpr int pos_of_col(int c) {
   return c == 0 ? 0 : c == 10 ? 1 : c < 10 ? 2 * c : 2 * (20 - c) + 1;
+}
+
+// ---- MFCC epilogue: the DCT product on v_mfma_f32_16x16x4_f32 ------------------------------------------------------
+//   out[f][c] = sum_m Y[f][m] D[m][c]:  A = D^T tile (16 coefficients x 4 mels), B = Y^T (4 mels x 16 frames, 6 live),
+//   C row 4 (l >> 4) + r = coefficient, column l & 15 = frame: a lane ends with 4 consecutive coefficients of one frame.
+//   Contraction slot (step s, lane group kk = l >> 4) <-> mel 20 kk + s, so that a lane's 20 B values are contiguous in its
+//   frame's staged dB row (5 b128 LDS reads).  n_mels = 80 exactly (every slot is a real mel), n_mfcc <= 48.
+constexpr int kMfccKS = 20, kMfccMT = 3, kMfccMels = kMfccKS * 4;
+constexpr int kMfccFragFloats = kMfccMT * kMfccKS * 64;      // 3840: [t][s / 4][lane][s % 4]
+AAMD_HD int mfcc_frag_index(int t, int s, int lane) { return (((t * (kMfccKS / 4) + (s >> 2)) * 64 + lane) << 2) + (s & 3); }
+AAMD_HD float mfcc_frag_value(const float* dct, int n_mels, int n_mfcc, int t, int s, int lane) {
+  const int mel = kMfccKS * (lane >> 4) + s, coef = 16 * t + (lane & 15);
+  return (mel < n_mels && coef < n_mfcc) ? dct[mel * n_mfcc + coef] : 0.0f;
+}
+// float index of the lane's B values of steps 4 u .. 4 u + 3 in the staged rows (frames >= 6: any live row)
+AAMD_HD int mfcc_b_index(int lane, int u) {
+  const int j = (lane & 15) < kFramesPerWave ? (lane & 15) : kFramesPerWave - 1;
+  return j * kMfccMels + kMfccKS * (lane >> 4) + 4 * u;
 }
 
 // ---- banded filterbank in LDS (built once per launch by every workgroup) ------------------
@@ -874,6 +902,14 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
 }
 
 // One workgroup lays out the band table image in global memory (once per filterbank; aamd_mel400_table_build).
+__global__ void __launch_bounds__(256) mfcc_frag_build_kernel(const float* __restrict__ dct, int n_mels, int n_mfcc,
+                                                              float* __restrict__ frag) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kMfccFragFloats; i += gridDim.x * blockDim.x) {
+    const int comp = i & 3, lane = (i >> 2) & 63, g = i >> 8;          // g = t * 5 + u
+    frag[i] = mfcc_frag_value(dct, n_mels, n_mfcc, g / (kMfccKS / 4), 4 * (g % (kMfccKS / 4)) + comp, lane);
+  }
+}
+
 __global__ void __launch_bounds__(256) mel_tab_build_kernel(MelBandsDev mb, float* __restrict__ out) {
   MelTab mt{};
   mel_tab_rounds(threadIdx.x, blockDim.x, mb, out, mt);
@@ -1024,8 +1060,10 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // MEL_DB: running maximum of this wave's dB values, flushed whenever the cut-off group changes
   float wmax = -INFINITY;
   int64_t wgroup = -1;
+  constexpr bool kDb = (EPI == EPI400_MEL_DB) || (EPI == EPI400_MFCC);
+  const bool fix = (EPI == EPI400_MFCC) && epi.fixup != 0;      // kernel-uniform: the fix-up pass of the fused MFCC
   auto flush_max = [&]() {
-    if (EPI == EPI400_MEL_DB && epi.group_max != nullptr && wgroup >= 0) {
+    if (kDb && !fix && epi.group_max != nullptr && wgroup >= 0) {
       float m = wmax;
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -1059,7 +1097,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 #pragma unroll
     for (int q = 0; q < HC::nx; ++q) Xn[q] = 0.0f;
     if (cur.staged) gload(cur);
-  } else if (cur.staged && !(LAB & 8)) {
+  } else if (cur.staged && !(LAB & 8) && !fix) {
     stage_issue(cur);
   }
 
@@ -1067,6 +1105,19 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     // claim the tile after this one now: it is prefetched while this one is in its second half
     const unsigned nxt_idx = (LAB & 131072) ? g_next() : claim();
     TileInfo nxt = tile_info(nxt_idx);
+    float fix_cut = -INFINITY;
+    if (fix) {
+      // fix-up pass: only tiles whose smallest dB value lies under the cut-off are redone (their samples are staged now,
+      // without prefetch: flagged tiles are the exception)
+      fix_cut = epi.group_max[cur.row / epi.rows_per_group] - epi.top_db;
+      if (!(epi.tile_min[blk_first + cur_idx] < fix_cut)) {
+        cur = nxt;
+        cur_idx = nxt_idx;
+        continue;
+      }
+      if (lane == 0 && epi.fix_count != nullptr) atomicAdd(epi.fix_count, 1);
+      if (cur.staged) stage_issue(cur);
+    }
 
     float X[HC::nx];
     if ((LAB & 32768) && cur.staged) {
@@ -1091,7 +1142,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     if (!(LAB & 32768)) {
       // every transposition row has been read: the staging area (it aliases rows) is free again
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (nxt.staged && !(LAB & 8)) stage_issue(nxt);
+      if (nxt.staged && !(LAB & 8) && !fix) stage_issue(nxt);
     }
     if (LAB & 16) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
     dft20(vr, vi, zr, zi);
@@ -1128,7 +1179,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     float acc_a[NR], acc_b[NR];
     if (LAB & 4) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
     phase_c<NR>(c, mt, lds, acc_a, acc_b, mh);
-    if (EPI == EPI400_MEL_DB) {
+    if (kDb) {
       const int64_t g = cur.row / epi.rows_per_group;   // wave-uniform
       if (g != wgroup) {
         flush_max();
@@ -1136,14 +1187,80 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       }
       // frames past the end of the clip hold garbage (phase_a): keep them out of the maximum
       const bool va_ok = cur.t0 + 2 * c.p < n_frames, vb_ok = cur.t0 + 2 * c.p + 1 < n_frames;
+      float tmin = INFINITY;
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         if (r < mt.n_rounds) {
           acc_a[r] = epi_db(acc_a[r], epi);
           acc_b[r] = epi_db(acc_b[r], epi);
           wmax = fmaxf(wmax, fmaxf(va_ok ? acc_a[r] : -INFINITY, vb_ok ? acc_b[r] : -INFINITY));
+          if (EPI == EPI400_MFCC) {
+            const bool real = (mh ? mh->mel(r) : mt.row_mel[r * kMelSlots + c.pi]) >= 0;
+            tmin = fminf(tmin, fminf(va_ok && real ? acc_a[r] : INFINITY, vb_ok && real ? acc_b[r] : INFINITY));
+            acc_a[r] = fmaxf(acc_a[r], fix_cut);       // first pass: fix_cut = -inf
+            acc_b[r] = fmaxf(acc_b[r], fix_cut);
+          }
         }
       }
+      if (EPI == EPI400_MFCC && !fix && !(epi.lab & 4)) {
+        // min-scan by DPP moves (VALU; a butterfly of __shfl_xor would be 6 LDS round trips): lane 63 ends with the minimum
+#define AAMD_MIN_STEP(CTRL, ROWS)                                                                                  \
+        tmin = fminf(tmin, __int_as_float(__builtin_amdgcn_update_dpp(0x7f800000, __float_as_int(tmin), CTRL, ROWS, 0xf, false)));
+        AAMD_MIN_STEP(0x111, 0xf) AAMD_MIN_STEP(0x112, 0xf) AAMD_MIN_STEP(0x114, 0xf) AAMD_MIN_STEP(0x118, 0xf)
+        AAMD_MIN_STEP(0x142, 0xa) AAMD_MIN_STEP(0x143, 0xc)
+#undef AAMD_MIN_STEP
+        if (lane == 63) epi.tile_min[blk_first + cur_idx] = tmin;
+      }
+    }
+    if (EPI == EPI400_MFCC) {
+      // the DCT product: A fragments from the (cache-resident) table, B from the staged dB rows
+      using f32x4 = __attribute__((ext_vector_type(4))) float;
+      // A fragments: 3 x 16 bytes per lane and k-step group, fetched one group ahead of the MFMAs that use them (the whole
+      // table in registers would be 60 VGPRs: the kernel spills at 3 waves / SIMD)
+      auto frag_load = [&](int u, F4 (&a)[kMfccMT]) {
+#pragma unroll
+        for (int t = 0; t < kMfccMT; ++t) {
+          a[t] = F4{1.0f, 0.5f, 0.25f, 0.125f};
+          if (!(epi.lab & 1)) a[t] = *reinterpret_cast<const F4*>(epi.dct_frag + (((t * (kMfccKS / 4) + u) * 64 + lane) << 2));
+        }
+      };
+      F4 a0[kMfccMT], a1[kMfccMT];
+      frag_load(0, a0);
+      wave_lds_fence();
+      store_stage<NR>(c, mt, acc_a, acc_b, lds, mh);
+      wave_lds_fence();
+      f32x4 cf[kMfccMT];
+#pragma unroll
+      for (int t = 0; t < kMfccMT; ++t) cf[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (!(epi.lab & 2)) {
+        // consecutive MFMAs go to different accumulators (a dependent one would wait out the 8 passes of its predecessor)
+#define AAMD_MFCC_STEP(A, COMP)                                                                                    \
+        _Pragma("unroll") for (int t = 0; t < kMfccMT; ++t)                                                        \
+          cf[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t].COMP, b4.COMP, cf[t], 0, 0, 0);
+#define AAMD_MFCC_GROUP(U, A, ANEXT)                                                                               \
+        {                                                                                                          \
+          const F4 b4 = *reinterpret_cast<const F4*>(lds + mfcc_b_index(lane, U));                                \
+          if (U + 1 < kMfccKS / 4) frag_load(U + 1, ANEXT);                                                        \
+          AAMD_MFCC_STEP(A, x) AAMD_MFCC_STEP(A, y) AAMD_MFCC_STEP(A, z) AAMD_MFCC_STEP(A, w)                      \
+        }
+        AAMD_MFCC_GROUP(0, a0, a1) AAMD_MFCC_GROUP(1, a1, a0) AAMD_MFCC_GROUP(2, a0, a1) AAMD_MFCC_GROUP(3, a1, a0)
+        AAMD_MFCC_GROUP(4, a0, a1)
+#undef AAMD_MFCC_GROUP
+#undef AAMD_MFCC_STEP
+      }
+      const int j = lane & 15;
+      if (!(LAB & 2) && !(epi.lab & 8) && cur.t0 + j < n_frames && j < kFramesPerWave) {
+        float* orow = out + (cur.row * (int64_t)n_frames + cur.t0 + j) * (int64_t)epi.n_mfcc;
+#pragma unroll
+        for (int t = 0; t < kMfccMT; ++t) {
+          const int k0 = 16 * t + 4 * (lane >> 4);
+          if (k0 < epi.n_mfcc) *reinterpret_cast<F4*>(orow + k0) = F4{cf[t][0], cf[t][1], cf[t][2], cf[t][3]};
+        }
+      }
+      wave_lds_fence();
+      cur = nxt;
+      cur_idx = nxt_idx;
+      continue;
     }
     if (EPI == EPI400_MEL_NORM) {
 #pragma unroll
@@ -1167,7 +1284,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     cur = nxt;
     cur_idx = nxt_idx;
   }
-  if (EPI == EPI400_MEL_DB && epi.group_max != nullptr) {
+  if (kDb && !fix && epi.group_max != nullptr) {
     // final flush through LDS: one atomic per workgroup and group instead of one per wave
     // (thousands of same-address atomics from every XCD serialise at one L2 channel)
     float m = wmax;

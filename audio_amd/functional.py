@@ -816,9 +816,93 @@ def _mfcc_dct_launch(mel2: Tensor, dct: Tensor, log_mode: int, gmax: Optional[Te
     return out
 
 
+class MfccFusedState:
+    """What the module keeps between calls of the one-kernel MFCC: the DCT matrix in the kernel's operand layout, and
+    the counter of the last call's fix-up pass -- read WITHOUT synchronising (through a pinned copy and an event that is
+    only polled), it drives the choice between the fused path and the two-kernel path:
+
+    * nothing clamped (loud, unpadded batches): pass 0 + an empty fix-up launch, ~25 % faster than two kernels;
+    * most tiles clamped (zero-padded batches, top_db reached everywhere): every tile would be computed twice, so the
+      two-kernel path is taken as long as the last observed share of redone tiles exceeds `max_share`; every
+      `retry_every` calls the fused path is probed again.
+    `path` / `last_share` report what ran (`MFCC.fused_report()`)."""
+
+    def __init__(self, max_share: float = 0.3, retry_every: int = 64):
+        self.frag = None
+        self.frag_key = None
+        self.max_share = max_share
+        self.retry_every = retry_every
+        self.pending = None           # (pinned int32 tensor, event, n_tiles)
+        self.last_share = None
+        self.avoid = 0                # calls left on the two-kernel path
+        self.path = None
+        self.calls_fused = 0
+        self.calls_two_kernel = 0
+
+    def poll(self):
+        if self.pending is not None and self.pending[1].query():
+            host, _, n_tiles = self.pending
+            self.last_share = float(host.item()) / max(n_tiles, 1)
+            self.pending = None
+            if self.last_share > self.max_share:
+                self.avoid = self.retry_every
+
+    def want_fused(self) -> bool:
+        self.poll()
+        if self.avoid > 0:
+            self.avoid -= 1
+            return False
+        return True
+
+
+def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft: int, hop_length: int, pad: int,
+                normalized, center: bool, pad_mode: str, top_db: float, db, packed: int, n_groups: int,
+                group_max_hook, state: MfccFusedState) -> Optional[Tensor]:
+    """MFCC.forward in one kernel + a fix-up launch (aamd_mfcc_fused_f32).  None when the shape is not served."""
+    dev = waveform.device
+    window = window.to(device=dev, dtype=torch.float32)
+    x2 = _rows2d(waveform)
+    desc = _stft_desc(x2, pad, window, n_fft, hop_length, 2.0, normalized, center, pad_mode, True)
+    bands = _mel_bands(fb, dev)
+    n_mfcc = dct.shape[1]
+    L = _lib.lib()
+    if bands.n_freq != n_fft // 2 + 1 or not L.aamd_mfcc_fused_supported(C.byref(desc), C.byref(bands.struct), n_mfcc):
+        return None
+    key = (dct.data_ptr(), dct._version, str(dev), n_mfcc)
+    stream = _lib.current_stream(dev)
+    with torch.cuda.device(dev):
+        if state.frag is None or state.frag_key != key:
+            frag = torch.empty((L.aamd_mfcc_frag_floats(),), dtype=torch.float32, device=dev)
+            _lib.check(L.aamd_mfcc_frag_build(dct.data_ptr(), bands.n_mels, n_mfcc, frag.data_ptr(), stream))
+            state.frag, state.frag_key = frag, key
+        n_tiles = int(L.aamd_mfcc_fused_tiles(C.byref(desc)))
+        out = torch.empty((desc.rows, desc.n_frames, n_mfcc), dtype=torch.float32, device=dev)
+        if out.numel() == 0:
+            return out
+        gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
+        tile_min = torch.empty((n_tiles,), dtype=torch.float32, device=dev)
+        count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        f = _lib.MfccFused(state.frag.data_ptr(), n_mfcc, 0, float(db[0]), float(db[1]), float(db[2]), float(top_db),
+                           gmax.data_ptr(), max(packed, 1), tile_min.data_ptr(), count.data_ptr())
+        args = (x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),
+                C.byref(bands.struct), out.data_ptr(), C.byref(desc))
+        _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))
+        if group_max_hook is not None:
+            group_max_hook(gmax)
+        f.pass_ = 1
+        _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))
+        if state.pending is None:                 # share of redone tiles, for the next calls' choice (never waited for)
+            host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+            host.copy_(count, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            state.pending = (host, ev, n_tiles)
+    return out
+
+
 def _mfcc(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, dct_mat: Tensor, n_fft: int, hop_length: int,
           win_length: int, power: float, normalized, center: bool, pad_mode: str, log_mels: bool, top_db: float,
-          db=(10.0, 1e-10, 0.0), group_max_hook=None) -> Tensor:
+          db=(10.0, 1e-10, 0.0), group_max_hook=None, fused_state: Optional[MfccFusedState] = None) -> Tensor:
     """MFCC.forward (transforms/_transforms.py:692-709) in two kernels: the mel kernel with
     amplitude_to_DB and the per-cut-off-group maximum fused into its epilogue, then clamp + DCT-II
     on the matrix cores.  ``group_max_hook(gmax)`` runs between them (audio_amd.distributed installs
@@ -841,6 +925,17 @@ def _mfcc(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, dct_mat: Tenso
         for d in lead:
             n_rows *= d
         n_groups = max(n_rows // max(packed, 1), 1)
+        if (fused_state is not None and power == 2.0 and waveform.is_cuda
+                and waveform.dtype == torch.float32 and fused_state.want_fused()):
+            out = _mfcc_fused(waveform, window, fb, dct, n_fft, hop_length, pad, normalized, center, pad_mode, top_db, db,
+                              packed, n_groups, group_max_hook, fused_state)
+            if out is not None:
+                fused_state.path = "fused"
+                fused_state.calls_fused += 1
+                return out.view(lead + (out.shape[1], n_mfcc)).transpose(-1, -2)
+        if fused_state is not None:
+            fused_state.path = "two-kernel"
+            fused_state.calls_two_kernel += 1
         gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
         mel = _melspectrogram(waveform, pad, window, fb, n_fft, hop_length, win_length, power, normalized, center,
                               pad_mode, db=(db[0], db[1], db[2], gmax, max(packed, 1)))

@@ -420,6 +420,25 @@ class MFCC(torch.nn.Module):
         #: optional hook ``fn(group_max: Tensor) -> None`` run between the dB pass and the clamp;
         #: audio_amd.distributed installs an all-reduce(MAX) here when a batch is sharded.
         self.group_max_hook: Optional[Callable[[Tensor], None]] = None
+        #: EXTENSION: False (default) = the exact two-kernel path.  True = the one-kernel MFCC (DCT in the mel kernel's epilogue
+        #: + a fix-up launch for the tiles the top_db cut-off reaches); "auto" = the one-kernel path unless the last observed
+        #: share of such tiles was large.  Same results either way.  Measured (profiles/r02_u_mfcc_paths.txt): the fp32 MFMA
+        #: product is NOT free beside the FFT arithmetic -- it runs on the same fp32 pipe -- so the one-kernel path is
+        #: 267 us against 224 us on the cfg4 batch and stays opt-in.
+        self.fused = False
+        self._fused_state = F.MfccFusedState()
+
+    def fused_report(self) -> dict:
+        """EXTENSION: which MFCC path ran last, and what the fix-up pass last had to redo."""
+        st = self._fused_state
+        st.poll()
+        return {"path": st.path, "redone_share": st.last_share, "calls_fused": st.calls_fused,
+                "calls_two_kernel": st.calls_two_kernel}
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_fused_state"] = F.MfccFusedState()
+        return d
 
     def forward(self, waveform: Tensor) -> Tensor:
         F._reject_param_grad(window=self.MelSpectrogram.spectrogram.window, fb=self.MelSpectrogram.mel_scale.fb)
@@ -446,7 +465,16 @@ class MFCC(torch.nn.Module):
         return F._mfcc(waveform, sp.pad, sp.window, self.MelSpectrogram.mel_scale.fb, self.dct_mat, sp.n_fft,
                        sp.hop_length, sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode, self.log_mels,
                        self.top_db, db=(a2db.multiplier, a2db.amin, a2db.db_multiplier),
-                       group_max_hook=self.group_max_hook)
+                       group_max_hook=self.group_max_hook, fused_state=self._fused_state_for_call())
+
+    def _fused_state_for_call(self):
+        st = getattr(self, "_fused_state", None)
+        fused = getattr(self, "fused", "auto")
+        if st is None or fused is False:
+            return None
+        if fused is True:
+            st.avoid = 0
+        return st
 
 
 class Resample(torch.nn.Module):

@@ -155,6 +155,33 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
                                float multiplier, float amin, float db_multiplier, float* group_max,
                                int64_t rows_per_group, void* stream);
 
+/* MFCC.forward (transforms/_transforms.py:692-709: MelSpectrogram -> amplitude_to_DB(top_db) -> DCT matmul) in ONE kernel
+ * for the headline front-end (n_fft 400, hop 100 / 160 / 200, 80 mels, n_mfcc <= 48 and a multiple of 4), plus a fix-up launch:
+ *   pass 0  writes out[rows][n_frames][n_mfcc] WITHOUT the top_db cut-off, max-reduces the dB values of each cut-off group
+ *           into group_max (caller pre-fills with -inf) and records the smallest dB value of every 6-frame tile in tile_min;
+ *   (multi-GPU: all-reduce group_max with MAX here)
+ *   pass 1  redoes, clamped at group_max[g] - top_db, exactly the tiles whose minimum lies under that cut-off and counts
+ *           them in fix_count (optional).  Batches in which nothing reaches the cut-off pay ~2 us for it; batches in which
+ *           most tiles do should take aamd_melspectrogram_db_f32 + aamd_mfcc_dct_f32 (the caller's choice).
+ * Results equal the two-kernel path's up to the rounding of the fp32 contraction order. */
+typedef struct aamd_mfcc_fused {
+  const float* dct_frag;   /* device float[aamd_mfcc_frag_floats()], from aamd_mfcc_frag_build */
+  int32_t n_mfcc;
+  int32_t pass;            /* 0 or 1 */
+  float multiplier, amin, db_multiplier, top_db;   /* F.amplitude_to_DB's (functional.py:356-404) */
+  float* group_max;        /* device float[ceil(rows / rows_per_group)] */
+  int64_t rows_per_group;
+  float* tile_min;         /* device float[aamd_mfcc_fused_tiles(desc)] */
+  int32_t* fix_count;      /* device int32 (caller zeroes it), or NULL */
+} aamd_mfcc_fused;
+int32_t aamd_mfcc_frag_floats(void);
+int64_t aamd_mfcc_fused_tiles(const aamd_stft_desc* desc);
+int aamd_mfcc_fused_supported(const aamd_stft_desc* desc, const aamd_mel_bands* bands, int32_t n_mfcc);   /* 1 / 0 */
+/* dct: device float[n_mels][n_mfcc] (F.create_dct, functional.py:636-667) -> the MFMA operand layout of the fused kernel */
+int aamd_mfcc_frag_build(const float* dct, int32_t n_mels, int32_t n_mfcc, float* frag, void* stream);
+int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
+                        float* out, const aamd_stft_desc* desc, const aamd_mfcc_fused* f, void* stream);
+
 /* MelSpectrogram with the RNN-T front-end's feature post-processing fused into the epilogue
  * (pipelines/rnnt_pipeline.py:16-47, 319-326: x * gain -> _piecewise_linear_log -> (x - mean) * invstddev):
  *   out[row][t][m] = (plog(mel[row][t][m] * gain) - mean[m]) * invstddev[m]

@@ -471,6 +471,18 @@ int sim_istft(const float* spec, const float* window, const float* tw, const flo
 
 // epi: 0 mel, 1 mel + dB (db = {multiplier, amin, db_sub}; gmax[rows / rows_per_group] max-reduced),
 //      2 spectrogram |X|^power (bands unused)
+// fused MFCC (EPI400_MFCC): the extra operands of the epilogue, set before sim_melspec400(epi_mode = 4)
+static struct { std::vector<float> frag; int n_mfcc = 0; float top_db = 0.f; float* tile_min = nullptr; int fixup = 0; int fix_count = 0; } g_mfcc;
+int sim_mfcc_fused_setup(const float* dct, int n_mels, int n_mfcc, float top_db, float* tile_min, int fixup) {
+  g_mfcc.frag.assign(m400::kMfccFragFloats, 0.f);
+  for (int t = 0; t < m400::kMfccMT; ++t)
+    for (int sidx = 0; sidx < m400::kMfccKS; ++sidx)
+      for (int lane = 0; lane < 64; ++lane)
+        g_mfcc.frag[m400::mfcc_frag_index(t, sidx, lane)] = m400::mfcc_frag_value(dct, n_mels, n_mfcc, t, sidx, lane);
+  g_mfcc.n_mfcc = n_mfcc; g_mfcc.top_db = top_db; g_mfcc.tile_min = tile_min; g_mfcc.fixup = fixup; g_mfcc.fix_count = 0;
+  return 0;
+}
+int sim_mfcc_fused_fix_count() { return g_mfcc.fix_count; }
 }  // extern "C" (pause: template)
 template <int H, typename TIn>
 static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw400, const aamd_mel_bands* bands,
@@ -486,7 +498,8 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
     if (mel_ws(mb.max_width) > kMelMaxTaps + 4 || mel_rounds(mb.n_mels) > kMelMaxRounds) return -2;
   }
   Epi400 epi{};
-  if (epi_mode == EPI400_MEL_DB) { epi.multiplier = db[0]; epi.amin = db[1]; epi.db_sub = db[2]; }
+  if (epi_mode == EPI400_MEL_DB || epi_mode == EPI400_MFCC) { epi.multiplier = db[0]; epi.amin = db[1]; epi.db_sub = db[2]; }
+  if (epi_mode == EPI400_MFCC && (mb.n_mels != kMfccMels || g_mfcc.n_mfcc <= 0 || g_mfcc.n_mfcc % 4 || g_mfcc.n_mfcc > 48)) return -5;
   // MEL_NORM: db = {gain, out_frames}; gmax = [mean(n_mels) | invstddev(n_mels)]
   if (epi_mode == EPI400_MEL_NORM) { epi.gain = db[0]; epi.out_frames = (int64_t)db[1]; epi.mean = gmax; epi.invstd = gmax + bands->n_mels; }
   epi.power = power;
@@ -523,10 +536,19 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
   const int64_t n_tiles = rows * tiles_per_row;
   bool cur_staged = n_tiles > 0 && staged(0);
   if (cur_staged) stage(0, 0);
+  const bool fix = epi_mode == EPI400_MFCC && g_mfcc.fixup;
   for (int64_t tile = 0; tile < n_tiles; ++tile) {
     const int64_t row = tile / tiles_per_row, t0 = (tile % tiles_per_row) * kFramesPerWave;
     const int64_t nrow = (tile + 1) / tiles_per_row, nt0 = ((tile + 1) % tiles_per_row) * kFramesPerWave;
     const bool nxt_staged = (tile + 1 < n_tiles) && staged(nt0);
+    float fix_cut = -INFINITY;
+    if (fix) {   // the fix-up pass redoes flagged tiles only, staging their samples on the spot
+      fix_cut = gmax[row / rows_per_group] - g_mfcc.top_db;
+      cur_staged = staged(t0);
+      if (!(g_mfcc.tile_min[tile] < fix_cut)) continue;
+      ++g_mfcc.fix_count;
+      if (cur_staged) stage(row, t0);
+    }
     const TIn* wr = wav + row * row_stride;
     for (int l = 0; l < 64; ++l) {
       if (cur_staged) gather_lds<H, TIn>(c[l], reinterpret_cast<const TIn*>(lds + kSOff), X[l]);
@@ -534,7 +556,7 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
     }
     for (int l = 0; l < 64; ++l) phase_a<H>(c[l], X[l], lds);
     for (int l = 0; l < 64; ++l) phase_b1_load(c[l], lds, vr[l], vi[l]);
-    if (nxt_staged) stage(nrow, nt0);
+    if (nxt_staged && !fix) stage(nrow, nt0);
     for (int l = 0; l < 64; ++l) dft20(vr[l], vi[l], zr[l], zi[l]);
     for (int l = 0; l < 64; ++l) phase_b2_send(c[l], zr[l], zi[l], qr[l], qi[l]);
     // exchange_partner(): in-place DPP swap with lane ^ 1, self-paired columns (0 and 10) keep their own
@@ -566,16 +588,46 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
     for (int l = 0; l < 64; ++l) phase_b2(c[l], zr[l], zi[l], xr[l], xi[l], lds);
     for (int l = 0; l < 64; ++l) phase_b2_pad(l, lds);
     for (int l = 0; l < 64; ++l) phase_c(c[l], mt, lds, acc_a[l], acc_b[l]);
-    if (epi_mode == EPI400_MEL_DB) {
-      float m = -INFINITY;
+    if (epi_mode == EPI400_MEL_DB || epi_mode == EPI400_MFCC) {
+      float m = -INFINITY, tmin = INFINITY;
       for (int l = 0; l < 64; ++l)
         for (int r = 0; r < mt.n_rounds; ++r) {
           acc_a[l][r] = epi_db(acc_a[l][r], epi);
           acc_b[l][r] = epi_db(acc_b[l][r], epi);
-          if (t0 + 2 * c[l].p < n_frames) m = std::fmax(m, acc_a[l][r]);
-          if (t0 + 2 * c[l].p + 1 < n_frames) m = std::fmax(m, acc_b[l][r]);
+          const bool real = mt.row_mel[r * kMelSlots + c[l].pi] >= 0;
+          if (t0 + 2 * c[l].p < n_frames) { m = std::fmax(m, acc_a[l][r]); if (real) tmin = std::fmin(tmin, acc_a[l][r]); }
+          if (t0 + 2 * c[l].p + 1 < n_frames) { m = std::fmax(m, acc_b[l][r]); if (real) tmin = std::fmin(tmin, acc_b[l][r]); }
+          if (epi_mode == EPI400_MFCC) { acc_a[l][r] = std::fmax(acc_a[l][r], fix_cut); acc_b[l][r] = std::fmax(acc_b[l][r], fix_cut); }
         }
-      if (gmax) { float& g = gmax[row / rows_per_group]; g = std::fmax(g, m); }
+      if (gmax && !fix) { float& g = gmax[row / rows_per_group]; g = std::fmax(g, m); }
+      if (epi_mode == EPI400_MFCC && !fix) g_mfcc.tile_min[tile] = tmin;
+    }
+    if (epi_mode == EPI400_MFCC) {
+      // store_stage + the fragment maps of v_mfma_f32_16x16x4_f32 (A[l & 15][l >> 4], B[l >> 4][l & 15], C row 4 (l >> 4) + r)
+      for (int l = 0; l < 64; ++l) store_stage(c[l], mt, acc_a[l], acc_b[l], lds);
+      static float C3[kMfccMT][16][16];
+      std::memset(C3, 0, sizeof(C3));
+      for (int sidx = 0; sidx < kMfccKS; ++sidx)
+        for (int t = 0; t < kMfccMT; ++t)
+          for (int i = 0; i < 16; ++i)
+            for (int j = 0; j < 16; ++j)
+              for (int k = 0; k < 4; ++k) {
+                const float a = g_mfcc.frag[mfcc_frag_index(t, sidx, i + 16 * k)];
+                const float b = lds[mfcc_b_index(j + 16 * k, sidx >> 2) + (sidx & 3)];
+                C3[t][i][j] += a * b;
+              }
+      for (int l = 0; l < 64; ++l) {
+        const int j = l & 15;
+        if (j >= kFramesPerWave || t0 + j >= n_frames) continue;
+        float* orow = out + (row * (int64_t)n_frames + t0 + j) * (int64_t)g_mfcc.n_mfcc;
+        for (int t = 0; t < kMfccMT; ++t)
+          for (int r = 0; r < 4; ++r) {
+            const int k0 = 16 * t + 4 * (l >> 4);
+            if (k0 < g_mfcc.n_mfcc) orow[k0 + r] = C3[t][4 * (l >> 4) + r][j];
+          }
+      }
+      cur_staged = nxt_staged;
+      continue;
     }
     if (epi_mode == EPI400_MEL_NORM) {
       for (int l = 0; l < 64; ++l)

@@ -112,6 +112,34 @@ def sim_mel400_db(x, window, bands, multiplier, amin, db_multiplier, gmax, rows_
                        rows_per_group=rows_per_group, out_width=bands.n_mels)
 
 
+def sim_mfcc_fused(x, window, bands, dct, multiplier, amin, db_multiplier, top_db, rows_per_group, hop=160):
+    """The fused MFCC kernel's two launches: pass 0 (unclamped MFCC + group maxima + tile minima), pass 1 (fix-up of the
+    tiles under the cut-off).  Returns (mfcc (rows, n_mfcc, T), group_max, tiles redone)."""
+    dct = np.ascontiguousarray(dct, dtype=np.float32)
+    n_mels, n_mfcc = dct.shape
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rows, length = x.shape
+    T = _host.frame_count(length, 400, hop, True)
+    n_groups = -(-rows // rows_per_group)
+    gmax = np.full(n_groups, -np.inf, dtype=np.float32)
+    tmin = np.zeros(rows * (-(-T // 6)), dtype=np.float32)
+    setup = sim().sim_mfcc_fused_setup
+    setup.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int]
+    w = np.ascontiguousarray(window, dtype=np.float32)
+    tw = np.ascontiguousarray(_host.twiddle_table(400))
+    out = np.zeros((rows, T, n_mfcc), dtype=np.float32)
+    f = sim().sim_melspec400
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                  C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_int]
+    dbv = np.ascontiguousarray([multiplier, amin, multiplier * db_multiplier], dtype=np.float32)
+    for fixup in (0, 1):
+        assert setup(fptr(dct), n_mels, n_mfcc, top_db, fptr(tmin), fixup) == 0
+        rc = f(x.ctypes.data_as(C.c_void_p), fptr(w), fptr(tw), C.cast(C.byref(bands.struct), C.c_void_p), fptr(out), rows,
+               length, length, T, 1.0, 4, fptr(dbv), fptr(gmax), rows_per_group, 2.0, 0, hop, 0)
+        assert rc == 0, rc
+    return np.swapaxes(out, -1, -2), gmax, sim().sim_mfcc_fused_fix_count()
+
+
 def sim_mel400_norm(x, window, bands, gain, mean, invstddev, right_padding=0, hop=160, i16=False, scale=1.0):
     """Fused RNN-T feature epilogue: ((plog(mel * gain)) - mean) * invstddev, rows of T + right_padding frames
     (the padding rows stay zero).  Returns frame-major (rows, T + right_padding, n_mels)."""

@@ -266,6 +266,33 @@ def test_sim_mel400_db_epilogue_and_group_max():
     np.testing.assert_allclose(gmax, exp.reshape(2, -1).max(-1), atol=2e-4)
 
 
+@pytest.mark.parametrize("n_mfcc,top_db,hop", [(40, 80.0, 160), (40, 25.0, 160), (13 + 3, 30.0, 200), (48, 10.0, 100)])
+def test_sim_mfcc_fused_epilogue_and_fixup(n_mfcc, top_db, hop):
+    """EPI400_MFCC: dB rows staged in LDS, the DCT product with the MFMA fragment maps, unclamped first pass + group maxima
+    + tile minima, then the fix-up pass over exactly the tiles under the cut-off -- against the float64 composition
+    MelSpectrogram -> amplitude_to_DB(top_db) -> DCT (transforms/_transforms.py:692-709), ragged tails, two groups."""
+    x, w, fb = _headline_setup(rows=4, L=2537)
+    x[1] *= 1e-3                      # a quiet clip: with a small top_db its tiles (and only they) are clamped
+    x[3, 900:] = 0.0                  # digital silence: -100 dB
+    bands = S.HostBands(fb)
+    dct = O.create_dct(n_mfcc, 80, "ortho").astype(np.float32)
+    got, gmax, n_fixed = S.sim_mfcc_fused(x, w, bands, dct, 10.0, 1e-10, 0.0, top_db, rows_per_group=2, hop=hop)
+    mel = O.mel_spectrogram(x.astype(np.float64), w.astype(np.float64), fb.astype(np.float64), 400, hop)
+    db = O.amplitude_to_db(mel, 10.0, 1e-10, 0.0)                       # (rows, n_mels, T)
+    want_max = db.reshape(2, -1).max(-1)
+    np.testing.assert_allclose(gmax, want_max, atol=2e-4)
+    cut = (want_max - top_db).repeat(2)[:, None, None]
+    clamped = np.maximum(db, cut)
+    exp = np.einsum("rmt,mc->rct", clamped, dct.astype(np.float64))
+    assert got.shape == exp.shape
+    assert np.abs(got - exp).max() <= 2e-3 * max(1.0, np.abs(exp).max() / 100)
+    T = db.shape[-1]
+    flagged = sum(int((db[r, :, 6 * t:6 * t + 6] < cut[r]).any()) for r in range(4) for t in range(-(-T // 6)))
+    assert n_fixed == flagged and flagged > 0
+    if top_db >= 80.0:
+        assert flagged < 4 * (-(-T // 6))          # only the silent tail is redone
+
+
 @pytest.mark.parametrize("n_mels,n_mfcc,log_mode", [(80, 40, 2), (80, 40, 0), (64, 13, 1), (128, 64, 2), (40, 40, 2), (36, 20, 0)])
 def test_sim_mfcc_dct_mfma_fragments(n_mels, n_mfcc, log_mode):
     """Index math of the matrix-core DCT (fragment tables, permuted contraction order, C layout)."""

@@ -530,6 +530,65 @@ def test_lfilter_pipelined_kernel_against_oracle(n_stages, length):
     assert float(np.abs(got.cpu().numpy()[..., -5:] - exp[..., -5:]).max()) <= 2e-4          # the ragged tail is written
 
 
+@pytest.mark.parametrize("hop,n_mfcc,shape", [(160, 40, (6, 48000)), (200, 40, (2, 3, 30011)), (100, 16, (5, 12345)),
+                                               (160, 48, (3, 16000))])
+def test_mfcc_one_kernel_path_equals_two_kernel_path_and_oracle(hop, n_mfcc, shape):
+    """The fused MFCC (mel -> dB -> DCT in the radix-20x20 kernel's epilogue + the fix-up launch for the tiles the top_db
+    cut-off reaches) against the exact two-kernel path and the float64 oracle: loud noise (nothing clamped), a quiet clip and
+    digital silence (clamped tiles), 2-D input (ONE batch-global cut-off) and 3-D input (one per batch item), ragged tails."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(hop + n_mfcc)
+    x = (0.4 * torch.randn(*shape, generator=g)).clamp_(-1, 1)
+    xs = x.clone()
+    xs.view(-1, shape[-1])[1] *= 1e-4
+    xs.view(-1, shape[-1])[0, shape[-1] // 2:] = 0.0
+    kw = dict(sample_rate=16000, n_mfcc=n_mfcc, melkwargs=dict(n_fft=400, hop_length=hop, n_mels=80))
+    fused, exact = T.MFCC(**kw).cuda(), T.MFCC(**kw).cuda()
+    fused.fused, exact.fused = True, False
+    for inp, clamps in ((x, False), (xs, True)):
+        with torch.no_grad():
+            a, b = fused(inp.cuda()), exact(inp.cuda())
+        assert fused.fused_report()["path"] == "fused" and exact._fused_state.path is None
+        assert a.shape == b.shape == tuple(shape[:-1]) + (n_mfcc, shape[-1] // hop + 1)
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * scale + 2e-4, (hop, n_mfcc, clamps)
+        torch.cuda.synchronize()
+        share = fused.fused_report()["redone_share"]
+        assert share is not None and ((share > 0) if clamps else (share == 0.0)), share
+        exp = O.mfcc(inp.numpy().astype(np.float64), fused.MelSpectrogram.spectrogram.window.cpu().numpy().astype(np.float64),
+                     fused.MelSpectrogram.mel_scale.fb.cpu().numpy().astype(np.float64),
+                     fused.dct_mat.cpu().numpy().astype(np.float64), 400, hop)
+        assert float(np.abs(a.cpu().numpy() - exp).max()) <= 2e-6 * float(np.abs(exp).max()) + 5e-4      # MFCC absolute (dB scale)
+
+
+def test_mfcc_path_choice_follows_the_share_of_clamped_tiles():
+    """`fused="auto"`: a batch in which most tiles reach the cut-off (zero padding) moves the module to the two-kernel
+    path for the following calls; shapes the fused kernel does not serve (n_mels != 80, n_mfcc % 4) take it directly."""
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(5)
+    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
+    assert m.fused is False                      # the default is the exact two-kernel path
+    m.fused = "auto"
+    loud = (0.4 * torch.randn(8, 32000, generator=g)).clamp_(-1, 1).cuda()
+    padded = loud.clone()
+    padded[:, 4000:] = 0.0
+    with torch.no_grad():
+        m(loud); torch.cuda.synchronize(); m(loud)
+        assert m.fused_report()["path"] == "fused" and m.fused_report()["redone_share"] == 0.0
+        y1 = m(padded); torch.cuda.synchronize()
+        assert m.fused_report()["redone_share"] > 0.5
+        y2 = m(padded)
+        assert m.fused_report()["path"] == "two-kernel"
+        assert float((y1 - y2).abs().max()) <= 2e-6 * float(y2.abs().max()) + 2e-4
+        for kw in (dict(n_mfcc=13, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)),
+                   dict(n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=64))):
+            mm = T.MFCC(sample_rate=16000, **kw).cuda()
+            mm.fused = "auto"
+            mm(loud)
+            assert mm.fused_report()["path"] == "two-kernel"
+
+
 def test_resample_matrix_core_layout_edges():
     """Unaligned / strided inputs (scalar loader path) and a length shorter than one chunk."""
     import audio_amd.transforms as T
