@@ -146,7 +146,7 @@ def lib():
     return _lib
 
 
-POLICY_FORCE_GENERIC, POLICY_MEL400_WIDE, POLICY_ISTFT_ATOMIC = 1, 2, 4
+POLICY_FORCE_GENERIC, POLICY_MEL400_WIDE, POLICY_ISTFT_ATOMIC, POLICY_RESAMPLE_FP32 = 1, 2, 4, 8
 
 
 class kernel_policy:

@@ -68,6 +68,7 @@ int policy() {
     if (std::getenv("AAMD_FORCE_GENERIC") != nullptr) p |= AAMD_POLICY_FORCE_GENERIC;
     if (std::getenv("AAMD_MEL400_WIDE") != nullptr) p |= AAMD_POLICY_MEL400_WIDE;
     if (std::getenv("AAMD_ISTFT_ATOMIC") != nullptr) p |= AAMD_POLICY_ISTFT_ATOMIC;
+    if (std::getenv("AAMD_RESAMPLE_FP32") != nullptr) p |= AAMD_POLICY_RESAMPLE_FP32;
     int expected = -1;
     g_policy.compare_exchange_strong(expected, p);
     p = g_policy.load(std::memory_order_relaxed);
@@ -333,7 +334,8 @@ int aamd_abi_version(void) { return AAMD_ABI_VERSION; }
 
 int aamd_set_kernel_policy(int flags) {
   const int prev = policy();
-  if (flags >= 0) g_policy.store(flags & (AAMD_POLICY_FORCE_GENERIC | AAMD_POLICY_MEL400_WIDE | AAMD_POLICY_ISTFT_ATOMIC));
+  if (flags >= 0) g_policy.store(flags & (AAMD_POLICY_FORCE_GENERIC | AAMD_POLICY_MEL400_WIDE | AAMD_POLICY_ISTFT_ATOMIC |
+                                          AAMD_POLICY_RESAMPLE_FP32));
   return prev;
 }
 
@@ -1093,6 +1095,8 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
   for (int t = 0; t < n_tiles; ++t)
     AAMD_CHECK_ARG(bands->tap_lo[t] >= 0 && bands->tap_lo[t] < taps, "tap_lo outside the tap table");
   rsm::Geom g{};
+  static const int rsm_lab = [] { const char* e = std::getenv("AAMD_RSM_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
+  g.lab = rsm_lab;
   g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
   g.orig = orig; g.new_ = new_; g.width = width; g.taps = taps;
   g.vec_in = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (row_stride % 4 == 0);
@@ -1111,16 +1115,18 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
     // q-groups: fill the workgroup with compute waves, bounded by the LDS double buffer and the row
     int qg = max_cw / g.n_pt;
     while (qg > 1 && ((int64_t)rsm::kQPerGroup * (qg - 1) >= nq ||
-                      2 * (size_t)rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) * sizeof(float) > lds_cap))
+                      2 * (size_t)rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) * sizeof(float) + 32 > lds_cap))
       --qg;
     g.qg = qg;
     const int qc = rsm::kQPerGroup * qg;
     g.buf_floats = rsm::buf_floats_needed(qc, orig, taps, max_lo, ks);
-    const size_t lds = 2 * (size_t)g.buf_floats * sizeof(float);
+    const bool f16 = (policy() & AAMD_POLICY_RESAMPLE_FP32) == 0;
+    const size_t lds = 2 * (size_t)g.buf_floats * sizeof(float) + (f16 ? 32 : 0);       // + the chunk-maximum slots and arrival counters
     if (lds > lds_cap)   // a single q-group does not fit (huge orig): scalar kernel
       return aamd_resample_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, stream);
     g.chunks_per_row = (int)((nq + qc - 1) / qc);
     g.n_chunks = rows * g.chunks_per_row;
+    AAMD_CHECK_ARG(g.n_chunks < (1ll << 31), "too many chunks for one launch");
     int64_t blocks = dev_props().cu_count;
     if (blocks > g.n_chunks) blocks = g.n_chunks;
     g.chunks_per_block = (int)((g.n_chunks + blocks - 1) / blocks);
@@ -1128,7 +1134,7 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
     const int threads = 64 * (g.n_pt * qg + rsm::kLoaderWaves);
 #define AAMD_RSM(KS)                                                                                  \
   do {                                                                                                \
-    auto kern = rsm::resample_mfma_kernel<KS>;                                                        \
+    auto kern = f16 ? rsm::resample_f16_kernel<KS> : rsm::resample_mfma_kernel<KS>;                   \
     if (lds > 48 * 1024)                                                                              \
       AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \

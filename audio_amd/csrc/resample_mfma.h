@@ -21,6 +21,8 @@
 //   * C layout gives each lane 4 consecutive phases of one q = one 16-B store.
 // fp32 MFMA is an exact fp32 FMA chain (same numerics class as the reference's conv1d).
 #pragma once
+#include <cstring>
+#include <cstdint>
 #include "hd.h"
 
 namespace aamd {
@@ -41,6 +43,7 @@ struct Geom {
   int buf_floats;            // floats per LDS chunk buffer (multiple of 4)
   int vec_in, vec_out;       // 16-B global loads / stores are legal
   int tap_lo[kMaxPhaseTiles];
+  int lab;                   // tools only (AAMD_RSM_LAB): 1 no conversion, 2 no MFMA, 4 no LDS operand reads, 8 no global loads, 16 no tap fragments, 32 no stores
 };
 
 // k-steps needed for a band of `span` taps, from the supported set (all = 16 mod 32); 0 = too wide
@@ -105,6 +108,102 @@ AAMD_HD void store_c(const Geom& g, float* out_row, int64_t qc0, int qt, int pt,
   const float c[4] = {c0, c1, c2, c3};
   for (int i = 0; i < 4; ++i)
     if (p0 + i < g.new_ && oi + i < g.out_len) out_row[oi + i] = c[i];
+}
+
+// ---- the f16 matrix-pipe variant: fp32-class accuracy from three f16 MFMAs per product --------------------------------
+// v_mfma_f32_16x16x4_f32 runs at 1/16 of the f16 rate of the matrix cores (157 against 2 500 TFLOP/s), and cfg3 is bound by
+// exactly that.  Every operand is therefore split into two binary16 numbers, v = hi + lo with hi = f16(v), lo = f16(v - hi)
+// (22 significant bits together), and a product of sums is evaluated as  hi*hi + hi*lo + lo*hi  on
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation (the dropped lo*lo is 2^-22 of the product): three instructions that do
+// 8 x the contraction depth of one fp32 instruction in half its time.
+//   * range: binary16 ends at 65504 and loses precision under 6e-5, so operands are scaled by powers of two (exact): taps by
+//     2^15 (|h| <= 1), the samples of a chunk by 2^(14 - e) with e the binary exponent of the chunk's LARGEST |sample| --
+//     found by the loader waves (LDS atomic max) while they fetch the chunk; the result is scaled back by 2^(e - 29).
+//     A low part that falls under the binary16 normal range is worth < 2^-31 of the chunk's peak.
+//   * the chunk sits in LDS as one dword per sample, (lo << 16) | hi: same footprint and the same conflict-free addresses as
+//     the float image; the loaders store raw floats, ALL waves convert the buffer in place between two barriers.
+//   * contraction slot (step s, lane group g, element e) <-> tap tap_lo + KS g + 8 s + e: a lane reads 8 consecutive dwords
+//     per step and q-tile and regroups them with v_perm_b32 into the hi and the lo operand.
+AAMD_HD uint16_t f16_bits(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(uint16_t, static_cast<_Float16>(f));
+#else
+  uint32_t u;                                   // round to nearest even, subnormals kept (what v_cvt_f16_f32 does)
+  std::memcpy(&u, &f, 4);
+  const uint32_t sign = u & 0x80000000u;
+  u ^= sign;
+  uint16_t o;
+  if (u >= ((127u + 16u) << 23)) {
+    o = (u > (255u << 23)) ? 0x7e00 : 0x7c00;
+  } else if (u < (113u << 23)) {
+    const uint32_t magic = ((127u - 15u) + (23u - 10u) + 1u) << 23;
+    float t, mf;
+    std::memcpy(&t, &u, 4);
+    std::memcpy(&mf, &magic, 4);
+    t += mf;
+    uint32_t tu;
+    std::memcpy(&tu, &t, 4);
+    o = (uint16_t)(tu - magic);
+  } else {
+    const uint32_t odd = (u >> 13) & 1u;
+    u += ((15u - 127u) << 23) + 0xfffu;
+    u += odd;
+    o = (uint16_t)(u >> 13);
+  }
+  return (uint16_t)(o | (sign >> 16));
+#endif
+}
+AAMD_HD float f16_value(uint16_t h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return static_cast<float>(__builtin_bit_cast(_Float16, h));
+#else
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t e = (h >> 10) & 31u, m = h & 1023u, u;
+  if (e == 0) {
+    if (m == 0) { u = sign; }
+    else {
+      int sh = 0;
+      while (!(m & 1024u)) { m <<= 1; ++sh; }
+      u = sign | ((uint32_t)(113 - sh) << 23) | ((m & 1023u) << 13);
+    }
+  } else if (e == 31) {
+    u = sign | 0x7f800000u | (m << 13);
+  } else {
+    u = sign | ((e + 112u) << 23) | (m << 13);
+  }
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+#endif
+}
+// (lo << 16) | hi of an already scaled value
+AAMD_HD uint32_t pack_hl(float xs) {
+  const uint16_t hi = f16_bits(xs);
+  const uint16_t lo = f16_bits(xs - f16_value(hi));
+  return (uint32_t)hi | ((uint32_t)lo << 16);
+}
+constexpr int kTapShift = 15;                       // taps are scaled by 2^15
+// scale of a chunk from the bits of its largest |sample|: the largest scaled sample lies in [2^14, 2^15)
+AAMD_HD void chunk_scale(uint32_t max_bits, float& scale, float& inv) {
+  int e = (int)(max_bits >> 23) - 127;
+  if (max_bits == 0 || e > 90 || e < -90) e = 14;   // silence, inf / nan, absurd magnitudes: unit scale
+  const uint32_t su = (uint32_t)(127 + 14 - e) << 23, iu = (uint32_t)(127 + e - 14 - kTapShift) << 23;
+  std::memcpy(&scale, &su, 4);
+  std::memcpy(&inv, &iu, 4);
+}
+// A operand dword d (elements 2 d, 2 d + 1) of step s: the hi parts and the lo parts
+AAMD_HD void a_pack16(const Geom& g, const float* kern, int pt, int tap_lo, int ks, int s, int d, int lane,
+                      uint32_t& hi, uint32_t& lo) {
+  const int p = 16 * pt + (lane & 15), tap = tap_lo + ks * (lane >> 4) + 8 * s + 2 * d;
+  // unconditional loads from clamped indices, zeroed by select: the 2 x 112 loads of a lane are then issued back to back
+  // (behind a branch each they were serialised: 0.08 ms per launch on the cfg3 shard)
+  const float* row = kern + (int64_t)(p < g.new_ ? p : 0) * g.taps;
+  const float r0 = row[tap < g.taps ? tap : g.taps - 1], r1 = row[tap + 1 < g.taps ? tap + 1 : g.taps - 1];
+  const float h0 = (p < g.new_ && tap < g.taps) ? r0 : 0.0f;
+  const float h1 = (p < g.new_ && tap + 1 < g.taps) ? r1 : 0.0f;
+  const uint32_t a = pack_hl(h0 * (float)(1 << kTapShift)), b = pack_hl(h1 * (float)(1 << kTapShift));
+  hi = (a & 0xffffu) | (b << 16);
+  lo = (a >> 16) | (b & 0xffff0000u);
 }
 
 #if defined(__HIPCC__)
@@ -197,6 +296,192 @@ resample_mfma_kernel(Geom g, const float* __restrict__ wav, const float* __restr
     store_c(g, out_row, qc0, qt0, pt, lane, acc0[0], acc0[1], acc0[2], acc0[3]);
     store_c(g, out_row, qc0, qt1, pt, lane, acc1[0], acc1[1], acc1[2], acc1[3]);
     __syncthreads();
+  }
+}
+
+// the f16 variant (see the block comment above a_pack16): same geometry, same band tables, same LDS addresses
+template <int KS>
+__global__ void __launch_bounds__(KS >= 80 ? 768 : 1024)
+resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restrict__ kern, float* __restrict__ out) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  using h8 = __attribute__((ext_vector_type(8))) _Float16;
+  using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+  constexpr int NS = KS / 8;                       // MFMA steps: 8 taps per lane group and step
+  extern __shared__ __attribute__((aligned(16))) float smem_rsm[];
+  unsigned* mx = reinterpret_cast<unsigned*>(smem_rsm + 2 * g.buf_floats);     // [3]: largest |sample| bits, chunk k -> slot k % 3
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ncw = g.n_pt * g.qg;
+  const bool loader = wave >= ncw;
+  const int pt_l = loader ? 0 : wave % g.n_pt;
+  const int qgi = loader ? 0 : wave / g.n_pt;
+  const int pt = g.pt0 + pt_l;
+  const int tap_lo = g.tap_lo[pt_l];
+  const int qc = chunk_q(g);
+  const int pieces = g.buf_floats >> 2;
+
+  const int64_t first = (int64_t)blockIdx.x * g.chunks_per_block;
+  int64_t end = first + g.chunks_per_block;
+  if (end > g.n_chunks) end = g.n_chunks;
+  if (threadIdx.x < 6) mx[threadIdx.x] = 0u;          // 3 maxima + 3 arrival counters
+  __syncthreads();
+
+  // Timeline (one barrier per chunk):
+  //   loaders   fetch(f) store(f) fetch(f+1) A0 | store(f+1) fetch(f+2) A(f) | store(f+2) fetch(f+3) A(f+1) | ...
+  //   the rest  tap fragments                A0 | compute(f)            A(f) | compute(f+1)          A(f+1) | ...
+  // fetch = the chunk's global loads into registers: issued a whole chunk period before the LDS buffer they go to is free
+  // (two chunks in LDS + one in the loaders' registers = the HBM latency of a 60 KB burst per CU is off the critical path);
+  // store = wait for the data, publish the largest |sample| (LDS atomic max), meet the other loader wave (LDS counter: both
+  // are always resident), convert the registers with the chunk's scale and write the packed dwords.  The compute waves
+  // never touch raw samples (round-2 lab: the in-place conversion by all waves between two barriers cost 0.10 of 0.80 ms).
+  unsigned* cnt = mx + 3;                              // [3]: loader waves that have published their maximum, monotonic
+  if (loader) {
+    const int lt = threadIdx.x - 64 * ncw;          // loader thread id
+    // the whole chunk in flight at once (U x 16 B per lane; 120 registers that only this branch owns): with the fp32
+    // kernel's 16 the two loader waves needed two HBM round trips per chunk and the f16 compute waves waited for them
+    constexpr int U = 30;
+    F4 v[U];
+    const float* wrow = wav;
+    int64_t a0 = 0;
+    bool interior = false;
+    auto chunk_src = [&](int64_t cid) {
+      const int64_t row = (int64_t)((uint32_t)cid / (uint32_t)g.chunks_per_row);   // n_chunks < 2^31 (checked by the launcher)
+      const int64_t qc0 = (cid - row * g.chunks_per_row) * qc;
+      wrow = wav + row * g.row_stride;
+      a0 = chunk_a0(g, qc0);
+      interior = g.vec_in && a0 >= 0 && a0 + g.buf_floats <= g.length && pieces <= 64 * kLoaderWaves * U && !(g.lab & 8);
+    };
+    auto absmax = [](unsigned m, const F4& t) {
+      const unsigned a = __float_as_uint(t.x) & 0x7fffffffu, bb = __float_as_uint(t.y) & 0x7fffffffu;
+      const unsigned cc = __float_as_uint(t.z) & 0x7fffffffu, d = __float_as_uint(t.w) & 0x7fffffffu;
+      return max(max(m, max(a, bb)), max(cc, d));
+    };
+    auto pack4 = [](const F4& t, float scale) {
+      u32x4 o;
+      o.x = pack_hl(t.x * scale); o.y = pack_hl(t.y * scale); o.z = pack_hl(t.z * scale); o.w = pack_hl(t.w * scale);
+      return o;
+    };
+    // both loader waves have published their maximum of chunk k (slot k % 3 is used for the (k / 3 + 1)-th time)
+    auto meet = [&](int k) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);                                   // lgkmcnt(0): this wave's atomic max is done
+      if (lane == 0) atomicAdd(&cnt[k % 3], 1u);
+      const unsigned want = (unsigned)kLoaderWaves * (unsigned)(k / 3 + 1);
+      while (__atomic_load_n(&cnt[k % 3], __ATOMIC_RELAXED) < want) __builtin_amdgcn_s_sleep(1);
+      return mx[k % 3];
+    };
+#define AAMD_RSM_FETCH(CID)                                                                                        \
+    {                                                                                                              \
+      chunk_src(CID);                                                                                              \
+      if (interior) {   /* wave-uniform base + one 32-bit lane offset per load; edge chunks are fetched in STORE */ \
+        const F4* base4 = reinterpret_cast<const F4*>(wrow + a0);                                                  \
+        int lt_ = lt;                                                                                              \
+        asm volatile("" : "+v"(lt_));   /* offsets recomputed here: hoisted out of the chunk loop they get spilled */ \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                            \
+          const int j = lt_ + 64 * kLoaderWaves * u;                                                               \
+          v[u] = base4[(unsigned)(j < pieces ? j : pieces - 1)];                                                   \
+        }                                                                                                          \
+      }                                                                                                            \
+    }
+#define AAMD_RSM_STORE(CID)                                                                                        \
+    {                                                                                                              \
+      const int k_ = (int)((CID) - first);                                                                         \
+      float* buf_ = smem_rsm + (k_ & 1) * g.buf_floats;                                                            \
+      unsigned m_ = 0u;                                                                                            \
+      float scale_, inv_;                                                                                          \
+      if (interior) {   /* from the registers: no raw image in LDS at all */                                        \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) m_ = absmax(m_, v[u]);   /* (clamped duplicates: same maximum) */ \
+        atomicMax(&mx[k_ % 3], m_);                                                                                \
+        chunk_scale(meet(k_), scale_, inv_);                                                                       \
+        int lt_ = lt;                                                                                              \
+        asm volatile("" : "+v"(lt_));   /* as in FETCH: nothing of this hoisted out of the chunk loop */            \
+        u32x4* dst_ = reinterpret_cast<u32x4*>(buf_) + lt_;                                                        \
+        const int left_ = pieces - lt_;                                                                            \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                                              \
+          if (64 * kLoaderWaves * u < left_) dst_[64 * kLoaderWaves * u] = pack4(v[u], scale_);                    \
+      } else {          /* edge chunks, very long chunks: raw image first, converted in place by its writers */     \
+        if (!(g.lab & 8))                                                                                          \
+          _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * kLoaderWaves) {                               \
+            const F4 t = load_piece(g, wrow, a0, j);                                                               \
+            *reinterpret_cast<F4*>(buf_ + 4 * j) = t;                                                              \
+            m_ = absmax(m_, t);                                                                                    \
+          }                                                                                                        \
+        atomicMax(&mx[k_ % 3], m_);                                                                                \
+        chunk_scale(meet(k_), scale_, inv_);                                                                       \
+        _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * kLoaderWaves) {                                 \
+          const F4 t = *reinterpret_cast<const F4*>(buf_ + 4 * j);                                                 \
+          *reinterpret_cast<u32x4*>(buf_ + 4 * j) = pack4(t, scale_);                                              \
+        }                                                                                                          \
+      }                                                                                                            \
+    }
+    if (first < end) {
+      AAMD_RSM_FETCH(first)
+      AAMD_RSM_STORE(first)
+    }
+    if (first + 1 < end) AAMD_RSM_FETCH(first + 1)
+    __syncthreads();                                     // A0
+    for (int64_t cid = first; cid < end; ++cid) {
+      if (cid + 1 < end) AAMD_RSM_STORE(cid + 1)          // fetched a whole chunk period ago; its buffer is free since A(cid - 1)
+      if (cid + 2 < end) AAMD_RSM_FETCH(cid + 2)          // stays in registers until the next round
+      __syncthreads();                                   // A(cid)
+    }
+#undef AAMD_RSM_FETCH
+#undef AAMD_RSM_STORE
+    return;
+  }
+
+  uint32_t ah[NS * 4], al[NS * 4];
+#pragma unroll
+  for (int i = 0; i < NS * 4; ++i) {
+    ah[i] = 0x3c003c00u; al[i] = 0x1c001c00u + i;
+    if (!(g.lab & 16)) a_pack16(g, kern, pt, tap_lo, KS, i >> 2, i & 3, lane, ah[i], al[i]);
+  }
+  __syncthreads();                                       // A0
+  for (int64_t cid = first; cid < end; ++cid) {
+    const int k = (int)(cid - first);
+    const uint32_t* buf = reinterpret_cast<const uint32_t*>(smem_rsm + (k & 1) * g.buf_floats);
+    float scale, inv;
+    chunk_scale(mx[k % 3], scale, inv);
+    const int64_t row = (int64_t)((uint32_t)cid / (uint32_t)g.chunks_per_row);   // n_chunks < 2^31 (checked by the launcher)
+    const int64_t qc0 = (cid - row * g.chunks_per_row) * qc;
+    const int shift = (int)((qc0 * g.orig - g.width) - chunk_a0(g, qc0));
+    const int qt0 = 2 * qgi, qt1 = 2 * qgi + 1;
+    const uint32_t* b0 = buf + b_base(g, qt0, tap_lo, KS, shift, lane);
+    const uint32_t* b1 = buf + b_base(g, qt1, tap_lo, KS, shift, lane);
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const h8 ahv = __builtin_bit_cast(h8, u32x4{ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]});
+      const h8 alv = __builtin_bit_cast(h8, u32x4{al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]});
+      // one q-tile after the other (both tiles' operands at once do not fit the 168 registers beside the 112 of the taps);
+      // small terms first
+#define AAMD_RSM_TILE(BP, ACC)                                                                                     \
+      {                                                                                                            \
+        u32x4 hv, lv;                                                                                              \
+        _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                            \
+          uint32_t x0 = 0x3c003c00u + d, x1 = 0x3c003c00u + s;                                                     \
+          if (!(g.lab & 4)) { x0 = BP[8 * s + 2 * d]; x1 = BP[8 * s + 2 * d + 1]; }                                \
+          hv[d] = __builtin_amdgcn_perm(x1, x0, 0x05040100u);                                                      \
+          lv[d] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);                                                      \
+        }                                                                                                          \
+        if (g.lab & 2) {                                                                                           \
+          ACC[0] += __uint_as_float(hv[0] ^ lv[1]); ACC[1] += __uint_as_float(hv[2] ^ lv[3]);                      \
+        } else {                                                                                                   \
+          ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, __builtin_bit_cast(h8, hv), ACC, 0, 0, 0);             \
+          ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, lv), ACC, 0, 0, 0);             \
+          ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, hv), ACC, 0, 0, 0);             \
+        }                                                                                                          \
+      }
+      AAMD_RSM_TILE(b0, acc0)
+      AAMD_RSM_TILE(b1, acc1)
+#undef AAMD_RSM_TILE
+    }
+    float* out_row = out + row * g.out_len;
+    if (!(g.lab & 32) || acc0[0] == 12345.0f) {
+      store_c(g, out_row, qc0, qt0, pt, lane, acc0[0] * inv, acc0[1] * inv, acc0[2] * inv, acc0[3] * inv);
+      store_c(g, out_row, qc0, qt1, pt, lane, acc1[0] * inv, acc1[1] * inv, acc1[2] * inv, acc1[3] * inv);
+    }
+    __syncthreads();                                     // A(cid): chunk cid is consumed, chunk cid + 1 is in LDS
+    if (threadIdx.x == 0) mx[k % 3] = 0u;                // read by everybody before A(cid); next written behind A(cid + 1)
   }
 }
 #endif  // __HIPCC__

@@ -115,7 +115,8 @@ int aamd_mel400_table_build(const aamd_mel_bands* bands, float* table_out, void*
 enum {
   AAMD_POLICY_FORCE_GENERIC = 1,  /* skip the shape-specialised kernels (radix-20x20, wave FFT, MFMA paths) */
   AAMD_POLICY_MEL400_WIDE   = 2,  /* n_fft = 400 mel epilogue: 16-byte stores through an LDS stage */
-  AAMD_POLICY_ISTFT_ATOMIC  = 4   /* inverse STFT: one atomic per contribution instead of run-based overlap-add */
+  AAMD_POLICY_ISTFT_ATOMIC  = 4,  /* inverse STFT: one atomic per contribution instead of run-based overlap-add */
+  AAMD_POLICY_RESAMPLE_FP32 = 8   /* banded resampling on v_mfma_f32_16x16x4_f32 instead of the f16 hi/lo-split MFMAs (16 x slower pipe) */
 };
 int         aamd_set_kernel_policy(int flags);
 

@@ -753,9 +753,11 @@ int sim_resample_sparse(const float* wav, const float* hb, const int32_t* lo, fl
 // Replay of rsm::resample_mfma_kernel: same Geom set-up as aamd_resample_banded_f32, the loader's
 // piece copies into a chunk buffer, and the MFMA fragment maps (A: lane m + 16 k, B: lane n + 16 k,
 // C: lane n + 16 (m / 4), element m % 4) applied to a_frag / b_base / store_c.
+// f16 = 1: replay of rsm::resample_f16_kernel (chunk maximum -> power-of-two scale, samples and taps split into two
+// binary16 numbers, hi*hi + hi*lo + lo*hi with the 16x16x32 fragment maps); f16 = 0: rsm::resample_mfma_kernel
 int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t rows, int64_t length,
                       int64_t row_stride, int orig, int new_, int width, int64_t out_len,
-                      const int32_t* tap_lo, int tap_span, int vec_ok) {
+                      const int32_t* tap_lo, int tap_span, int vec_ok, int f16) {
   using namespace rsm;
   const int n_tiles = (new_ + 15) / 16;
   const int ks = pick_ks(tap_span);
@@ -791,11 +793,44 @@ int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t r
         buf[4 * j] = v.x; buf[4 * j + 1] = v.y; buf[4 * j + 2] = v.z; buf[4 * j + 3] = v.w;
       }
       const int shift = (int)((qc0 * orig - width) - a0);
+      float sc = 1.0f, inv = 1.0f;
+      std::vector<uint32_t> pk;
+      if (f16) {
+        uint32_t mxb = 0;
+        for (float v : buf) { uint32_t u; std::memcpy(&u, &v, 4); u &= 0x7fffffffu; if (u > mxb) mxb = u; }
+        chunk_scale(mxb, sc, inv);
+        pk.resize(buf.size());
+        for (size_t i = 0; i < buf.size(); ++i) pk[i] = pack_hl(buf[i] * sc);
+      }
       for (int w = 0; w < g.n_pt * qg; ++w) {
         const int pt_l = w % g.n_pt, qgi = w / g.n_pt, pt = pt0 + pt_l, lo = g.tap_lo[pt_l];
         for (int half = 0; half < 2; ++half) {
           const int qt = 2 * qgi + half;
           float Cm[16][16] = {};
+          if (f16) {
+            // lane (row m / column n, group k4): A elements 8 s + e of its group, B the 8 consecutive samples
+            for (int sidx = 0; sidx < ks / 8; ++sidx)
+              for (int term = 0; term < 3; ++term)          // lo*hi, hi*lo, hi*hi
+                for (int m = 0; m < 16; ++m)
+                  for (int n = 0; n < 16; ++n)
+                    for (int k4 = 0; k4 < 4; ++k4)
+                      for (int e = 0; e < 8; ++e) {
+                        uint32_t ahi, alo;
+                        a_pack16(g, kern, pt, lo, ks, sidx, e >> 1, m + 16 * k4, ahi, alo);
+                        const uint16_t a_h = (uint16_t)(ahi >> (16 * (e & 1))), a_l = (uint16_t)(alo >> (16 * (e & 1)));
+                        const int bidx = b_base(g, qt, lo, ks, shift, n + 16 * k4) + 8 * sidx + e;
+                        if (bidx < 0 || bidx >= g.buf_floats) return -3;
+                        const uint16_t b_h = (uint16_t)(pk[bidx] & 0xffffu), b_l = (uint16_t)(pk[bidx] >> 16);
+                        const float a = f16_value(term == 0 ? a_l : a_h), b = f16_value(term == 1 ? b_l : b_h);
+                        Cm[m][n] += a * b;
+                      }
+            for (int lane = 0; lane < 64; ++lane) {
+              const int n = lane & 15, gq = lane >> 4;
+              store_c(g, out + row * out_len, qc0, qt, pt, lane, Cm[4 * gq][n] * inv, Cm[4 * gq + 1][n] * inv,
+                      Cm[4 * gq + 2][n] * inv, Cm[4 * gq + 3][n] * inv);
+            }
+            continue;
+          }
           for (int kk = 0; kk < ks; ++kk)
             for (int m = 0; m < 16; ++m)
               for (int n = 0; n < 16; ++n)

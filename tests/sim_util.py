@@ -202,7 +202,7 @@ def sim_resample_sparse(x, kernel, orig, new, width):
     return out, span
 
 
-def sim_resample_mfma(x, kernel, orig, new, width, vec_ok=1):
+def sim_resample_mfma(x, kernel, orig, new, width, vec_ok=1, f16=0):
     x = np.ascontiguousarray(x, dtype=np.float32)
     rows, length = x.shape
     k = np.ascontiguousarray(kernel, dtype=np.float32).reshape(new, -1)
@@ -211,8 +211,8 @@ def sim_resample_mfma(x, kernel, orig, new, width, vec_ok=1):
     lo, span = _host.resample_band_table(k)
     lo = np.ascontiguousarray(lo, dtype=np.int32)
     f = sim().sim_resample_mfma
-    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_int] * 3 + [C.c_int64, C.c_void_p, C.c_int, C.c_int]
-    rc = f(fptr(x), fptr(k), fptr(out), rows, length, length, orig, new, width, out_len, fptr(lo), span, vec_ok)
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 3 + [C.c_int] * 3 + [C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    rc = f(fptr(x), fptr(k), fptr(out), rows, length, length, orig, new, width, out_len, fptr(lo), span, vec_ok, f16)
     return rc, out
 
 

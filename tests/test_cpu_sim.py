@@ -128,8 +128,8 @@ def test_sim_resample(case):
     got2 = S.sim_resample(x2, k.numpy(), o // g, n // g, width, qt=3, use_lds=0).reshape(exp.shape)
     assert peak_rel_err(got2, exp) <= 1e-5
     # matrix-core kernel (banded taps, permuted contraction order, double-buffered chunks)
-    for vec_ok in (1, 0):
-        rc, got3 = S.sim_resample_mfma(x2, k.numpy(), o // g, n // g, width, vec_ok)
+    for vec_ok, f16 in ((1, 0), (0, 0), (1, 1), (0, 1)):      # f16: the hi / lo-split binary16 MFMA variant (the default)
+        rc, got3 = S.sim_resample_mfma(x2, k.numpy(), o // g, n // g, width, vec_ok, f16)
         if rc == -2:
             continue          # band wider than 448 taps: the scalar kernel serves it
         assert rc == 0
@@ -329,6 +329,20 @@ def test_sim_resample_mfma_kaiser_best_headline():
     exp = O.apply_sinc_resample_kernel(x.astype(np.float64), o, n, g, k.numpy().astype(np.float64).reshape(n // g, -1), width)
     assert got.shape == exp.shape
     assert peak_rel_err(got, exp) <= 5e-6
+    # the binary16 hi / lo split on the same shape: loud, quiet (1e-4 x) and very loud (3e4 x: Kaldi-style 16-bit range)
+    # clips go through the per-chunk power-of-two scale, a silent row through the unit scale
+    for gain in (1.0, 1e-4, 3e4, 0.0):
+        xs = (x * np.float32(gain)).astype(np.float32)
+        xs[1, 5000:] *= np.float32(1e-3)             # a chunk whose largest sample is small
+        rc, got = S.sim_resample_mfma(xs, k.numpy(), o // g, n // g, width, 1, 1)
+        assert rc == 0 and not np.isnan(got).any()
+        exp = O.apply_sinc_resample_kernel(xs.astype(np.float64), o, n, g, k.numpy().astype(np.float64).reshape(n // g, -1), width)
+        if gain == 0.0:
+            assert np.abs(got).max() == 0.0
+        else:
+            assert peak_rel_err(got, exp) <= 5e-6, gain
+            tail = slice(3000, None)                  # the quiet part of row 1, relative to ITS peak
+            assert np.abs(got[1, tail] - exp[1, tail]).max() <= 2e-5 * np.abs(exp[1, tail]).max(), gain
 
 
 @pytest.mark.parametrize("nx,ny,mode", [(40000, 9000, "full"), (20000, 700, "same"), (30000, 17000, "valid"),

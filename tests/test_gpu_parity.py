@@ -605,6 +605,34 @@ def test_resample_matrix_core_layout_edges():
         assert got.shape == exp.shape and peak_rel_err(got.cpu().numpy(), exp) <= 1e-5
 
 
+@pytest.mark.parametrize("gain", [1.0, 1e-4, 3e4])
+def test_resample_binary16_split_kernel_against_fp32_kernel_and_oracle(gain):
+    """cfg3's filter (44.1k -> 16k kaiser_best) on the f16 matrix pipe (operands split into two binary16 numbers, chunk-wise
+    power-of-two scaling) against the fp32-MFMA kernel (policy switch) and the float64 oracle: normal, very quiet and
+    16-bit-range amplitudes, a clip that falls silent, ragged length."""
+    import audio_amd.transforms as T
+    from audio_amd import _lib
+    from oracle import dsp_oracle as O
+    kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=64, rolloff=0.9475937167399596,
+              beta=14.769656459379492)
+    r = T.Resample(44100, 16000, **kw).cuda()
+    g = torch.Generator().manual_seed(23)
+    x = (0.5 * torch.randn(3, 2, 70013, generator=g)).clamp_(-1, 1) * gain
+    x[1, :, 30000:] *= 1e-3
+    x[2, 1, 20000:] = 0.0
+    with torch.no_grad():
+        got = r(x.cuda())
+        with _lib.kernel_policy(_lib.POLICY_RESAMPLE_FP32):
+            ref32 = r(x.cuda())
+    exp = O.resample(x.numpy().astype(np.float64), 44100, 16000, **kw)
+    assert got.shape == exp.shape
+    assert peak_rel_err(got.cpu().numpy(), exp) <= 1e-5 and peak_rel_err(ref32.cpu().numpy(), exp) <= 1e-5     # (fp32 taps vs the oracle's float64 taps)
+    assert float((got - ref32).abs().max()) <= 2e-6 * float(ref32.abs().max())                  # measured: see profiles/r02_v_resample_f16.txt
+    q = got[1, :, 12000:].cpu().numpy(), exp[1, :, 12000:]                       # the quiet part, against ITS peak
+    assert float(np.abs(q[0] - q[1]).max()) <= 2e-5 * float(np.abs(q[1]).max())
+    assert float(got[2, 1, 7400:].abs().max()) == 0.0                             # silence stays silence
+
+
 @pytest.mark.parametrize("hop", [100, 200])
 def test_fft400_other_hops_fast_path(hop):
     """hop = 100 and 200 (torchaudio's default n_fft // 2) also take the radix-20x20 kernel: mel, MFCC and
