@@ -77,7 +77,8 @@ def main():
                         rolloff=0.9475937167399596, beta=14.769656459379492).to(dev)
         emit("cfg3 Resample 44.1k->16k kaiser_best, per-GPU shard 128 x stereo x 30 s",
              timed(lambda: rs(x), 10, 30), 128 * 30.0, x.numel() * 4 + 128 * 2 * 480000 * 4,
-             flops=128 * 2 * 480000 * 373 * 2, note="FMA-bound; 373 effective taps per output")
+             flops=128 * 2 * 480000 * 373 * 2,
+             note="binary16 hi/lo-split MFMA kernel (default); 373 effective taps per output")
         del x
         x = torch.rand(32, 8, 480000, device=dev, generator=g) - 0.5
         A, B = [], []

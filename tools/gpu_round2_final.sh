@@ -12,3 +12,5 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -
 cd $R
 python tools/prof_summary.py $O/prof > $O/prof_summary.txt
 tail -3 $O/pytest.log; tail -2 $O/smoke.log; cat $O/bench.json; cat $O/bench_driver_flags.json; head -8 $O/prof_summary.txt
+timeout 400 python tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.err; cat $O/configs.jsonl | cut -c1-260
+rm -rf $O/prof/*/ 2>/dev/null; find $O/prof -name "*.csv" -size +2M -delete 2>/dev/null
