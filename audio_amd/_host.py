@@ -301,6 +301,97 @@ def mel_lane_order(lo: np.ndarray, width: np.ndarray, iters: int = 4000, seed: i
     return order
 
 
+def _m400_cost_fast(l2_of_pos) -> int:
+    """`_m400_round_cost` on plain ints (the search below calls it tens of thousands of times)."""
+    cost = 0
+    for grp in _B128_LANES:
+        seen = {}
+        for pair, pos in grp:
+            addr = _M400_PAIR_DWORDS * pair + 2 * l2_of_pos[pos]
+            seen.setdefault((addr >> 2) & 15, set()).add(addr)
+        cost += max(len(v) for v in seen.values())
+    return cost
+
+
+_B128_LANES = [[divmod(l if l < 60 else l - 20, 20) for l in g] for g in _B128_GROUPS]
+
+
+def mel400_table_image(lo: np.ndarray, width: np.ndarray, weights: np.ndarray, max_width: int, iters: int = 6000,
+                       seed: int = 0):
+    """The LDS image of the band table of the (n_fft, hop) = (400, *) kernel (`m400::mel_tab_layout` in csrc/melspec400.h:
+    [rows][ws] weights | lo2[rows] | row_mel[rows] | rc[8]) built on the host, with the two freedoms the kernel's results do
+    not depend on used against LDS bank conflicts of the power-row reads (one b128 per lane, chunk and frame pair, serviced in
+    the four 16-lane groups of MI355X_MICROARCH.md "LDS"):
+      * which lane position of a round evaluates which mel (as `mel_lane_order`), and
+      * the even bin a row's band read STARTS at: any even start <= the band's first bin that still covers the band inside
+        the round's chunk count (the weights of the skipped bins are zero).
+    HTK 80-mel bank: 104 LDS cycles per tile for the power-row reads with the order alone, 76-84 with both, floor 72.
+    Returns (image float32[rows * (ws + 2) + 8], order int32[rows])."""
+    lo = np.asarray(lo, dtype=np.int64)
+    width = np.asarray(width, dtype=np.int64)
+    n_mels = lo.shape[0]
+    n_rounds = (n_mels + 19) // 20
+    rows = n_rounds * 20
+    w4 = (int(max_width) + 1 + 3) & ~3
+    ws = w4 if (w4 >> 2) & 1 else w4 + 4
+    img = np.zeros(rows * (ws + 2) + 8, dtype=np.float32)
+    ints = img.view(np.int32)
+    lo2_o, mel_o, rc_o = rows * ws, rows * ws + rows, rows * ws + 2 * rows
+    order = np.full(rows, -1, dtype=np.int32)
+    rng = np.random.default_rng(seed)
+    for r in range(n_rounds):
+        mels = list(range(20 * r, min(20 * r + 20, n_mels)))
+        rw = max([4] + [int((width[m] + (lo[m] & 1) + 3) & ~3) for m in mels])
+        opts = {}
+        for m in mels:
+            l2 = min(int(lo[m]) & ~1, _M400_PK - rw)
+            opts[m] = []
+            while l2 >= 0 and int(lo[m]) + int(width[m]) <= l2 + rw:
+                opts[m].append(l2)
+                l2 -= 2
+        opts[-1] = [0]
+        best = None
+        for restart in range(3):
+            perm = mels + [-1] * (20 - len(mels))
+            if restart:
+                rng.shuffle(perm)
+            start = {m: opts[m][0] for m in set(perm)}
+            c = _m400_cost_fast([start[m] for m in perm])
+            for _ in range(iters):
+                if c <= len(_B128_LANES):
+                    break
+                if rng.random() < 0.5:
+                    i, j = rng.choice(20, size=2, replace=False)
+                    cand, st = list(perm), start
+                    cand[i], cand[j] = cand[j], cand[i]
+                else:
+                    m = perm[int(rng.integers(20))]
+                    st = dict(start)
+                    st[m] = opts[m][int(rng.integers(len(opts[m])))]
+                    cand = perm
+                cc = _m400_cost_fast([st[m] for m in cand])
+                if cc <= c:
+                    perm, start, c = cand, st, cc
+            if best is None or c < best[0]:
+                best = (c, perm, start)
+            if c <= len(_B128_LANES):
+                break
+        _, perm, start = best
+        ints[rc_o + r] = rw >> 2
+        for i, m in enumerate(perm):
+            row = 20 * r + i
+            order[row] = m
+            ints[mel_o + row] = m
+            if m < 0:
+                ints[lo2_o + row] = 0
+                continue
+            l2 = start[m]
+            ints[lo2_o + row] = l2
+            off = int(lo[m]) - l2
+            img[row * ws + off: row * ws + off + int(width[m])] = weights[m, :int(width[m])]
+    return img, order
+
+
 def resample_adjoint_table(kernel: np.ndarray, orig: int, new: int, width: int):
     """Tap table of the ADJOINT of `y[q new + p] = sum_k h[p][k] xpad[q orig + k]` written as the same kind of
     polyphase operator with the rates swapped (orig' = new, new' = orig):

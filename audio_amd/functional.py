@@ -171,22 +171,32 @@ class MelBandsOnDevice:
         self.width = torch.from_numpy(width).to(device)
         self.weights = torch.from_numpy(weights).to(device).contiguous()
         self.max_width = max_width
-        # lane assignment of the radix-20x20 kernel (bank-conflict optimised, results independent of it)
+        # lane assignment and band-read starts of the radix-20x20 kernel (chosen against LDS bank conflicts; the kernel's
+        # results do not depend on them): the table's LDS image is laid out once per filterbank, on the host
         use_order = self.n_freq == 201 and os.environ.get("AAMD_MEL400_NO_LANE_ORDER") is None   # env: A/B experiments
-        self.lane_order = torch.from_numpy(_host.mel_lane_order(lo, width)).to(device) if use_order else None
+        image = None
+        if use_order:
+            image, order = _host.mel400_table_image(lo, width, weights, max_width)
+            if os.environ.get("AAMD_MEL400_ORDER_ONLY") is not None:                              # env: A/B experiments
+                image, order = None, _host.mel_lane_order(lo, width)
+            self.lane_order = torch.from_numpy(order).to(device)
+        else:
+            self.lane_order = None
         self.struct = _lib.MelBands(self.n_mels, max_width, self.lo.data_ptr(), self.width.data_ptr(),
                                     self.weights.data_ptr(),
                                     self.lane_order.data_ptr() if self.lane_order is not None else None, None)
-        # the radix-20x20 kernel's LDS image of the table, laid out once per filterbank (aamd_mel400_table_build)
         self.table400 = None
         if self.n_freq == 201 and self.lo.is_cuda:
             L = _lib.lib()
             n = L.aamd_mel400_table_dwords(self.n_mels, max_width)
             if n > 0:
-                self.table400 = torch.zeros(n, dtype=torch.float32, device=device)
-                with torch.cuda.device(device):
-                    _lib.check(L.aamd_mel400_table_build(C.byref(self.struct), self.table400.data_ptr(),
-                                                         _lib.current_stream(device)))
+                if image is not None and image.shape[0] == n:
+                    self.table400 = torch.from_numpy(image).to(device)
+                else:       # the device builder (band starts at the band's first even bin)
+                    self.table400 = torch.zeros(n, dtype=torch.float32, device=device)
+                    with torch.cuda.device(device):
+                        _lib.check(L.aamd_mel400_table_build(C.byref(self.struct), self.table400.data_ptr(),
+                                                             _lib.current_stream(device)))
                 self.struct.table400 = self.table400.data_ptr()
 
 

@@ -508,7 +508,10 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
   alignas(16) static float ctab[kConstDwords];
   for (int tid = 0; tid < 256; ++tid) const_tab_build(tid, 256, window, tw400, scale, ctab);
   MelTab mt{};
-  if (epi_mode != EPI400_SPEC) {
+  if (epi_mode != EPI400_SPEC && bands->table400 != nullptr) {   // the prebuilt image (host or device builder), as the kernel copies it
+    std::memcpy(tab, bands->table400, (size_t)mel_tab_dwords(mb.n_mels, mb.max_width) * 4);
+    mel_tab_layout(mb, tab, mt);
+  } else if (epi_mode != EPI400_SPEC) {
     for (int tid = 0; tid < 256; ++tid) mel_tab_rounds(tid, 256, mb, tab, mt);
     for (int tid = 0; tid < 256; ++tid) mel_tab_fill(tid, 256, mb, tab, mt);
   }

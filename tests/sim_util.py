@@ -38,16 +38,22 @@ def fptr(a):
 
 
 class HostBands:
-    def __init__(self, fb, permute=False):
+    def __init__(self, fb, permute=False, image=False):
         self.lo, self.width, self.weights, self.max_width = _host.mel_band_table(np.asarray(fb))
         self.lo = np.ascontiguousarray(self.lo)
         self.width = np.ascontiguousarray(self.width)
         self.weights = np.ascontiguousarray(self.weights)
         self.n_mels = self.lo.shape[0]
         self.lane_order = np.ascontiguousarray(_host.mel_lane_order(self.lo, self.width)) if permute else None
+        self.image = None
+        if image:       # the host-built LDS image (order + shifted band starts), as audio_amd.functional uploads it
+            self.image, order = _host.mel400_table_image(self.lo, self.width, self.weights, self.max_width)
+            self.image = np.ascontiguousarray(self.image)
+            self.lane_order = np.ascontiguousarray(order)
         self.struct = _lib.MelBands(self.n_mels, self.max_width, self.lo.ctypes.data, self.width.ctypes.data,
                                     self.weights.ctypes.data,
-                                    self.lane_order.ctypes.data if self.lane_order is not None else None)
+                                    self.lane_order.ctypes.data if self.lane_order is not None else None,
+                                    self.image.ctypes.data if self.image is not None else None)
 
 
 def make_desc(rows, length, n_fft, hop, pad=0, center=True, pad_mode="reflect", onesided=True, scale=1.0,

@@ -94,6 +94,11 @@ def test_sim_melspectrogram(case):
         for wide in (0, 1):
             got4p = S.sim_mel400(x2, wp, perm, scale, wide=wide).reshape(exp.shape)
             assert np.array_equal(got4p, got4)
+        # the host-built table image (lane order + band reads started at an earlier even bin where that avoids a bank
+        # conflict: the extra taps have zero weight): still bit-identical
+        img = S.HostBands(fb, image=True)
+        assert sorted(m for m in img.lane_order if m >= 0) == list(range(img.n_mels))
+        assert np.array_equal(S.sim_mel400(x2, wp, img, scale).reshape(exp.shape), got4)
 
 
 def test_sim_mel400_framing_exact():

@@ -24,12 +24,12 @@ for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recu
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "melspec400_kernel" not in k: continue
-        lab = k.split("melspec400_kernel<")[1].split(">")[0]
+        lab = k.split("melspec400_kernel<")[1].split(">")[0].split(",")[0].strip() + "/" + k.split("melspec400_kernel<")[1].split(">")[0].split(",")[-1].strip()
         per[(lab, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (lab, disp, name), v in per.items():
         acc[lab][name].append(v)
 names = sorted({n for lab in acc for n in acc[lab]})
-labs = sorted(acc, key=lambda x: int(x))
+labs = sorted(acc, key=lambda x: (int(x.split("/")[0]), x))
 print("%-26s" % "counter (avg/dispatch)" + "".join("%14s" % ("LAB" + l) for l in labs))
 for n in names:
     print("%-26s" % n + "".join("%14.3g" % (sum(acc[l][n][1:]) / max(1, len(acc[l][n][1:]))) if acc[l][n] else "%14s" % "-" for l in labs))

@@ -138,6 +138,21 @@ int main(int argc, char** argv) {
     printf("float64 check: peak-rel err %.3e\n", worst / peak);
   }
   run<0>("product: staged in + narrow out", blocks, lds, dx, dwin, dtw, mb, dout, rows, L, T, it, 1, 0);
+  if (getenv("LAB_R4")) {   // round-2, third batch: where do the LDS bank conflicts come from?  (PMC per variant: tools/pmc_lab.sh)
+    MelBandsDev mbt = mb;
+    float* dtab; CK(hipMalloc(&dtab, (size_t)mel_tab_dwords(M, maxw) * 4));
+    CK(hipMemset(dtab, 0, (size_t)mel_tab_dwords(M, maxw) * 4));
+    hipLaunchKernelGGL(mel_tab_build_kernel, dim3(1), dim3(256), 0, 0, mb, dtab);
+    CK(hipDeviceSynchronize());
+    mbt.table400 = dtab;
+    for (int i = 0; i < 3; ++i) run<0, 4>("", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 120, 1, 0);
+    run<0, 4>("R4 product (NR4, prebuilt table)", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0);
+    run<11, 4>("R4 LAB11 no DMA / wait / stores", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0);
+    run<15, 4>("R4 LAB15 ... and no phase C", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0);
+    run<31, 4>("R4 LAB31 ... and no phase B", blocks, lds, dx, dwin, dtw, mbt, dout, rows, L, T, 40, 1, 0);
+    fflush(stdout);
+    if (getenv("LAB_R4_ONLY")) return 0;
+  }
   if (getenv("LAB_R3")) {   // round-2, second batch: everything with the prebuilt table; NR = 4 = control words in registers
     MelBandsDev mbt = mb;
     float* dtab; CK(hipMalloc(&dtab, (size_t)mel_tab_dwords(M, maxw) * 4));
