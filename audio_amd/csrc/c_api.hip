@@ -1076,6 +1076,11 @@ int aamd_resample_f32(const float* wav, const float* kernel, float* out, int64_t
   return launch_check();
 }
 
+// tools only (tools/rsm_census.py): the time stamps the f16 resampler records under AAMD_RSM_LAB=64
+extern "C" __attribute__((visibility("default"))) int aamd_debug_rsm_census(long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(rsm::g_rsm_census), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+
 int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, int64_t rows,
                              int64_t length, int64_t row_stride, int32_t orig, int32_t new_, int32_t width,
                              int64_t out_len, const aamd_resample_bands* bands, void* stream) {
@@ -1134,7 +1139,9 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
     const int threads = 64 * (g.n_pt * qg + rsm::kLoaderWaves);
 #define AAMD_RSM(KS)                                                                                  \
   do {                                                                                                \
-    auto kern = f16 ? rsm::resample_f16_kernel<KS> : rsm::resample_mfma_kernel<KS>;                   \
+    auto kern = !f16 ? rsm::resample_mfma_kernel<KS>                                                  \
+                : g.lab == 0 ? rsm::resample_f16_kernel<KS, 0>                                         \
+                : g.lab == 64 ? rsm::resample_f16_kernel<KS, 1> : rsm::resample_f16_kernel<KS, 2>;    \
     if (lds > 48 * 1024)                                                                              \
       AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \

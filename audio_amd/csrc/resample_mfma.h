@@ -299,10 +299,19 @@ resample_mfma_kernel(Geom g, const float* __restrict__ wav, const float* __restr
   }
 }
 
+// lab bit 64: timestamps (100 MHz wall clock) of workgroup 0, chunks 8 .. 39: [wave 16][chunk 32][stamp 8] (tools only)
+__device__ long long g_rsm_census[16 * 32 * 8];
+#define AAMD_RSM_STAMP(K, I)                                                                                       \
+  if ((lab & 64) && blockIdx.x == 0 && lane == 0 && (K) >= 8 && (K) < 40)                                        \
+    g_rsm_census[(wave * 32 + ((K) - 8)) * 8 + (I)] = wall_clock64();
 // the f16 variant (see the block comment above a_pack16): same geometry, same band tables, same LDS addresses
-template <int KS>
+// LABM: the tools-only switches live in instantiations of their own -- 1 = the time stamps (AAMD_RSM_LAB=64), 2 = every lab
+// switch (their branches inside the MFMA loop cut it into basic blocks the scheduler cannot move the LDS reads across:
+// the product kernel carried them until the round-2 census, profiles/r02_v)
+template <int KS, int LABM>
 __global__ void __launch_bounds__(KS >= 80 ? 768 : 1024)
 resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restrict__ kern, float* __restrict__ out) {
+  const int lab = LABM ? g.lab : 0;
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   using h8 = __attribute__((ext_vector_type(8))) _Float16;
   using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
@@ -336,6 +345,8 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   // never touch raw samples (round-2 lab: the in-place conversion by all waves between two barriers cost 0.10 of 0.80 ms).
   unsigned* cnt = mx + 3;                              // [3]: loader waves that have published their maximum, monotonic
   if (loader) {
+    // the two loader waves are the critical path of every chunk (round-2 census): first pick of the issue slots of their SIMDs
+    __builtin_amdgcn_s_setprio(3);
     const int lt = threadIdx.x - 64 * ncw;          // loader thread id
     // the whole chunk in flight at once (U x 16 B per lane; 120 registers that only this branch owns): with the fp32
     // kernel's 16 the two loader waves needed two HBM round trips per chunk and the f16 compute waves waited for them
@@ -349,7 +360,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       const int64_t qc0 = (cid - row * g.chunks_per_row) * qc;
       wrow = wav + row * g.row_stride;
       a0 = chunk_a0(g, qc0);
-      interior = g.vec_in && a0 >= 0 && a0 + g.buf_floats <= g.length && pieces <= 64 * kLoaderWaves * U && !(g.lab & 8);
+      interior = g.vec_in && a0 >= 0 && a0 + g.buf_floats <= g.length && pieces <= 64 * kLoaderWaves * U && !(lab & 8);
     };
     auto absmax = [](unsigned m, const F4& t) {
       const unsigned a = __float_as_uint(t.x) & 0x7fffffffu, bb = __float_as_uint(t.y) & 0x7fffffffu;
@@ -362,9 +373,18 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       return o;
     };
     // both loader waves have published their maximum of chunk k (slot k % 3 is used for the (k / 3 + 1)-th time)
+    // the wave's maximum by DPP moves, ONE LDS atomic per wave (round-2 census: 64 same-address LDS atomics per wave made
+    // this hand-shake 3.4 us of a 9 us chunk period)
+    auto publish = [&](int k, unsigned m) {
+#define AAMD_RSM_MAX_STEP(CTRL, ROWS) m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, CTRL, ROWS, 0xf, false));
+      AAMD_RSM_MAX_STEP(0x111, 0xf) AAMD_RSM_MAX_STEP(0x112, 0xf) AAMD_RSM_MAX_STEP(0x114, 0xf) AAMD_RSM_MAX_STEP(0x118, 0xf)
+      AAMD_RSM_MAX_STEP(0x142, 0xa) AAMD_RSM_MAX_STEP(0x143, 0xc)
+#undef AAMD_RSM_MAX_STEP
+      if (lane == 63) atomicMax(&mx[k % 3], m);
+    };
     auto meet = [&](int k) {
       __builtin_amdgcn_s_waitcnt(0xc07f);                                   // lgkmcnt(0): this wave's atomic max is done
-      if (lane == 0) atomicAdd(&cnt[k % 3], 1u);
+      if (lane == 63) atomicAdd(&cnt[k % 3], 1u);
       const unsigned want = (unsigned)kLoaderWaves * (unsigned)(k / 3 + 1);
       while (__atomic_load_n(&cnt[k % 3], __ATOMIC_RELAXED) < want) __builtin_amdgcn_s_sleep(1);
       return mx[k % 3];
@@ -389,23 +409,29 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       unsigned m_ = 0u;                                                                                            \
       float scale_, inv_;                                                                                          \
       if (interior) {   /* from the registers: no raw image in LDS at all */                                        \
+        AAMD_RSM_STAMP(k_, 0)                                                                                        \
         _Pragma("unroll") for (int u = 0; u < U; ++u) m_ = absmax(m_, v[u]);   /* (clamped duplicates: same maximum) */ \
-        atomicMax(&mx[k_ % 3], m_);                                                                                \
+        asm volatile("" : "+v"(m_));                                                                                \
+        AAMD_RSM_STAMP(k_, 1)                                                                                        \
+        publish(k_, m_);                                                                                           \
         chunk_scale(meet(k_), scale_, inv_);                                                                       \
+        AAMD_RSM_STAMP(k_, 2)                                                                                        \
         int lt_ = lt;                                                                                              \
         asm volatile("" : "+v"(lt_));   /* as in FETCH: nothing of this hoisted out of the chunk loop */            \
         u32x4* dst_ = reinterpret_cast<u32x4*>(buf_) + lt_;                                                        \
         const int left_ = pieces - lt_;                                                                            \
         _Pragma("unroll") for (int u = 0; u < U; ++u)                                                              \
           if (64 * kLoaderWaves * u < left_) dst_[64 * kLoaderWaves * u] = pack4(v[u], scale_);                    \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                                                        \
+        AAMD_RSM_STAMP(k_, 3)                                                                                        \
       } else {          /* edge chunks, very long chunks: raw image first, converted in place by its writers */     \
-        if (!(g.lab & 8))                                                                                          \
+        if (!(lab & 8))                                                                                          \
           _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * kLoaderWaves) {                               \
             const F4 t = load_piece(g, wrow, a0, j);                                                               \
             *reinterpret_cast<F4*>(buf_ + 4 * j) = t;                                                              \
             m_ = absmax(m_, t);                                                                                    \
           }                                                                                                        \
-        atomicMax(&mx[k_ % 3], m_);                                                                                \
+        publish(k_, m_);                                                                                           \
         chunk_scale(meet(k_), scale_, inv_);                                                                       \
         _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * kLoaderWaves) {                                 \
           const F4 t = *reinterpret_cast<const F4*>(buf_ + 4 * j);                                                 \
@@ -422,7 +448,9 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     for (int64_t cid = first; cid < end; ++cid) {
       if (cid + 1 < end) AAMD_RSM_STORE(cid + 1)          // fetched a whole chunk period ago; its buffer is free since A(cid - 1)
       if (cid + 2 < end) AAMD_RSM_FETCH(cid + 2)          // stays in registers until the next round
+      AAMD_RSM_STAMP((int)(cid + 1 - first), 4)
       __syncthreads();                                   // A(cid)
+      AAMD_RSM_STAMP((int)(cid + 1 - first), 5)
     }
 #undef AAMD_RSM_FETCH
 #undef AAMD_RSM_STORE
@@ -433,11 +461,12 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #pragma unroll
   for (int i = 0; i < NS * 4; ++i) {
     ah[i] = 0x3c003c00u; al[i] = 0x1c001c00u + i;
-    if (!(g.lab & 16)) a_pack16(g, kern, pt, tap_lo, KS, i >> 2, i & 3, lane, ah[i], al[i]);
+    if (!(lab & 16)) a_pack16(g, kern, pt, tap_lo, KS, i >> 2, i & 3, lane, ah[i], al[i]);
   }
   __syncthreads();                                       // A0
   for (int64_t cid = first; cid < end; ++cid) {
     const int k = (int)(cid - first);
+    AAMD_RSM_STAMP(k, 0)
     const uint32_t* buf = reinterpret_cast<const uint32_t*>(smem_rsm + (k & 1) * g.buf_floats);
     float scale, inv;
     chunk_scale(mx[k % 3], scale, inv);
@@ -448,39 +477,56 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     const uint32_t* b0 = buf + b_base(g, qt0, tap_lo, KS, shift, lane);
     const uint32_t* b1 = buf + b_base(g, qt1, tap_lo, KS, shift, lane);
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    // 2 NS operand tiles (step s = t >> 1, q-tile t & 1), one after the other (both tiles' operands at once do not fit the
+    // 168 registers beside the 112 of the taps).  The 8 packed dwords of tile t + 2 are requested before tile t is
+    // regrouped and multiplied: with three waves per SIMD a look-ahead of ONE tile (what the scheduler does on its own)
+    // is shorter than the LDS round trip and every tile stalled on its reads (round-2 census, profiles/r02_v).
+    uint32_t raw[3][8];
+#define AAMD_RSM_READ(T, R)                                                                                        \
+    {                                                                                                              \
+      const uint32_t* bp_ = ((T) & 1) ? b1 : b0;                                                                   \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                              \
+        R[j] = 0x3c003c00u + j;                                                                                    \
+        if (!(LABM == 2 && (lab & 4))) R[j] = bp_[8 * ((T) >> 1) + j];                                                  \
+      }                                                                                                            \
+    }
+    AAMD_RSM_READ(0, raw[0])
+    AAMD_RSM_READ(1, raw[1])
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int t = 0; t < 2 * NS; ++t) {
+      const int s = t >> 1;
       const h8 ahv = __builtin_bit_cast(h8, u32x4{ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]});
       const h8 alv = __builtin_bit_cast(h8, u32x4{al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]});
-      // one q-tile after the other (both tiles' operands at once do not fit the 168 registers beside the 112 of the taps);
-      // small terms first
-#define AAMD_RSM_TILE(BP, ACC)                                                                                     \
-      {                                                                                                            \
-        u32x4 hv, lv;                                                                                              \
-        _Pragma("unroll") for (int d = 0; d < 4; ++d) {                                                            \
-          uint32_t x0 = 0x3c003c00u + d, x1 = 0x3c003c00u + s;                                                     \
-          if (!(g.lab & 4)) { x0 = BP[8 * s + 2 * d]; x1 = BP[8 * s + 2 * d + 1]; }                                \
-          hv[d] = __builtin_amdgcn_perm(x1, x0, 0x05040100u);                                                      \
-          lv[d] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);                                                      \
-        }                                                                                                          \
-        if (g.lab & 2) {                                                                                           \
-          ACC[0] += __uint_as_float(hv[0] ^ lv[1]); ACC[1] += __uint_as_float(hv[2] ^ lv[3]);                      \
-        } else {                                                                                                   \
-          ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, __builtin_bit_cast(h8, hv), ACC, 0, 0, 0);             \
-          ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, lv), ACC, 0, 0, 0);             \
-          ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, hv), ACC, 0, 0, 0);             \
-        }                                                                                                          \
+      if (t + 2 < 2 * NS) AAMD_RSM_READ(t + 2, raw[(t + 2) % 3])
+      __builtin_amdgcn_sched_barrier(0);                 // (sched_group_barrier pipelines picked the reads of tile t itself)
+      u32x4 hv, lv;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        hv[d] = __builtin_amdgcn_perm(raw[t % 3][2 * d + 1], raw[t % 3][2 * d], 0x05040100u);
+        lv[d] = __builtin_amdgcn_perm(raw[t % 3][2 * d + 1], raw[t % 3][2 * d], 0x07060302u);
       }
-      AAMD_RSM_TILE(b0, acc0)
-      AAMD_RSM_TILE(b1, acc1)
-#undef AAMD_RSM_TILE
+      f32x4& acc = (t & 1) ? acc1 : acc0;
+      if (LABM == 2 && (lab & 2)) {
+        acc[0] += __uint_as_float(hv[0] ^ lv[1]); acc[1] += __uint_as_float(hv[2] ^ lv[3]);
+      } else {                                          // small terms first
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, __builtin_bit_cast(h8, hv), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, lv), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, hv), acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
+#undef AAMD_RSM_READ
+    asm volatile("" : "+v"(acc0), "+v"(acc1));
+    AAMD_RSM_STAMP(k, 1)
     float* out_row = out + row * g.out_len;
-    if (!(g.lab & 32) || acc0[0] == 12345.0f) {
+    if (!(lab & 32) || acc0[0] == 12345.0f) {
       store_c(g, out_row, qc0, qt0, pt, lane, acc0[0] * inv, acc0[1] * inv, acc0[2] * inv, acc0[3] * inv);
       store_c(g, out_row, qc0, qt1, pt, lane, acc1[0] * inv, acc1[1] * inv, acc1[2] * inv, acc1[3] * inv);
     }
+    AAMD_RSM_STAMP(k, 2)
     __syncthreads();                                     // A(cid): chunk cid is consumed, chunk cid + 1 is in LDS
+    AAMD_RSM_STAMP(k, 3)
     if (threadIdx.x == 0) mx[k % 3] = 0u;                // read by everybody before A(cid); next written behind A(cid + 1)
   }
 }
