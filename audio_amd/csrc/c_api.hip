@@ -1120,13 +1120,13 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
     // q-groups: fill the workgroup with compute waves, bounded by the LDS double buffer and the row
     int qg = max_cw / g.n_pt;
     while (qg > 1 && ((int64_t)rsm::kQPerGroup * (qg - 1) >= nq ||
-                      2 * (size_t)rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) * sizeof(float) + 32 > lds_cap))
+                      2 * (size_t)rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) * sizeof(float) + 48 > lds_cap))
       --qg;
     g.qg = qg;
     const int qc = rsm::kQPerGroup * qg;
     g.buf_floats = rsm::buf_floats_needed(qc, orig, taps, max_lo, ks);
     const bool f16 = (policy() & AAMD_POLICY_RESAMPLE_FP32) == 0;
-    const size_t lds = 2 * (size_t)g.buf_floats * sizeof(float) + (f16 ? 32 : 0);       // + the chunk-maximum slots and arrival counters
+    const size_t lds = 2 * (size_t)g.buf_floats * sizeof(float) + (f16 ? 48 : 0);       // + the chunk-maximum slots and arrival counters
     if (lds > lds_cap)   // a single q-group does not fit (huge orig): scalar kernel
       return aamd_resample_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, stream);
     g.chunks_per_row = (int)((nq + qc - 1) / qc);

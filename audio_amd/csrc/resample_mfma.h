@@ -121,7 +121,8 @@ AAMD_HD void store_c(const Geom& g, float* out_row, int64_t qc0, int qt, int pt,
 //     found by the loader waves (LDS atomic max) while they fetch the chunk; the result is scaled back by 2^(e - 29).
 //     A low part that falls under the binary16 normal range is worth < 2^-31 of the chunk's peak.
 //   * the chunk sits in LDS as one dword per sample, (lo << 16) | hi: same footprint and the same conflict-free addresses as
-//     the float image; the loaders store raw floats, ALL waves convert the buffer in place between two barriers.
+//     the float image; the loaders store raw floats, and whichever wave is free converts the buffer in place, batch by
+//     batch (LDS counters; one barrier per chunk -- see the timeline in the kernel).
 //   * contraction slot (step s, lane group g, element e) <-> tap tap_lo + KS g + 8 s + e: a lane reads 8 consecutive dwords
 //     per step and q-tile and regroups them with v_perm_b32 into the hi and the lo operand.
 AAMD_HD uint16_t f16_bits(float f) {
@@ -332,21 +333,56 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   const int64_t first = (int64_t)blockIdx.x * g.chunks_per_block;
   int64_t end = first + g.chunks_per_block;
   if (end > g.n_chunks) end = g.n_chunks;
-  if (threadIdx.x < 6) mx[threadIdx.x] = 0u;          // 3 maxima + 3 arrival counters
+  if (threadIdx.x < 9) mx[threadIdx.x] = 0u;          // 3 maxima + 3 arrival counters + 3 batch counters
   __syncthreads();
 
   // Timeline (one barrier per chunk):
-  //   loaders   fetch(f) store(f) fetch(f+1) A0 | store(f+1) fetch(f+2) A(f) | store(f+2) fetch(f+3) A(f+1) | ...
-  //   the rest  tap fragments                A0 | compute(f)            A(f) | compute(f+1)          A(f+1) | ...
+  //   loaders   fetch(f) stage(f) fetch(f+1)      A0 | stage(f+1) fetch(f+2)               A(f) | stage(f+2) fetch(f+3) ...
+  //   the rest  tap fragments, convert(f)         A0 | compute(f), stores, convert(f+1)    A(f) | compute(f+1) ...
   // fetch = the chunk's global loads into registers: issued a whole chunk period before the LDS buffer they go to is free
   // (two chunks in LDS + one in the loaders' registers = the HBM latency of a 60 KB burst per CU is off the critical path);
-  // store = wait for the data, publish the largest |sample| (LDS atomic max), meet the other loader wave (LDS counter: both
-  // are always resident), convert the registers with the chunk's scale and write the packed dwords.  The compute waves
-  // never touch raw samples (round-2 lab: the in-place conversion by all waves between two barriers cost 0.10 of 0.80 ms).
-  unsigned* cnt = mx + 3;                              // [3]: loader waves that have published their maximum, monotonic
+  // stage = wait for the data, publish the wave's largest |sample| (DPP reduction + one LDS atomic max), write the RAW
+  // floats to the free buffer, count the wave as arrived (LDS counter, after its writes).  convert = the compute waves, once
+  // their MFMA loop is done and both loaders have arrived, turn their share of the raw image into packed (lo << 16 | hi)
+  // dwords in place.  Round-2 census (profiles/r02_v): with the conversion in the two loader waves they were the critical
+  // path of every chunk (6.8 of 7.5 us) while the ten compute waves idled 2.3 - 3.9 us at the barrier.
+  unsigned* cnt = mx + 3;                              // [3]: loader waves whose raw samples and maximum are in LDS, monotonic
+  auto pack4 = [](const F4& t, float scale) {
+    u32x4 o;
+    o.x = pack_hl(t.x * scale); o.y = pack_hl(t.y * scale); o.z = pack_hl(t.z * scale); o.w = pack_hl(t.w * scale);
+    return o;
+  };
+  // convert(k): raw image of chunk k -> packed dwords, in batches of kGrab x 64 pieces handed out by an LDS counter to whichever
+  // wave is free (the early finishers of the MFMA loop and the loaders behind their fetches take most of them; the last
+  // compute waves of a period find nothing left), once both loader waves have counted themselves in (slot k % 3 is used for
+  // the (k / 3 + 1)-th time; every wave of the workgroup is resident, so the wait is bounded)
+  unsigned* grab = cnt + 3;                            // [3]: batches handed out
+  constexpr int kGrab = 3;
+  auto convert = [&](int k) {
+    const unsigned want = (unsigned)kLoaderWaves * (unsigned)(k / 3 + 1);
+    while (__atomic_load_n(&cnt[k % 3], __ATOMIC_RELAXED) < want) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (!loader) { AAMD_RSM_STAMP(k - 1, 3) }
+    if (lab & 1) return;
+    float scale, inv;
+    chunk_scale(__atomic_load_n(&mx[k % 3], __ATOMIC_RELAXED), scale, inv);
+    float* buf = smem_rsm + (k & 1) * g.buf_floats;
+    for (;;) {
+      unsigned b = 0u;
+      if (lane == 0) b = atomicAdd(&grab[k % 3], 1u);
+      const int j0 = (int)__builtin_amdgcn_readfirstlane(b) * (64 * kGrab) + lane;
+      if (j0 - lane >= pieces) break;
+      F4 t[kGrab];
+#pragma unroll
+      for (int i = 0; i < kGrab; ++i)
+        if (j0 + 64 * i < pieces) t[i] = *reinterpret_cast<const F4*>(buf + 4 * (j0 + 64 * i));
+#pragma unroll
+      for (int i = 0; i < kGrab; ++i)
+        if (j0 + 64 * i < pieces) *reinterpret_cast<u32x4*>(buf + 4 * (j0 + 64 * i)) = pack4(t[i], scale);
+    }
+  };
   if (loader) {
-    // the two loader waves are the critical path of every chunk (round-2 census): first pick of the issue slots of their SIMDs
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(3);                  // the producers: first pick of the issue slots of their SIMDs
     const int lt = threadIdx.x - 64 * ncw;          // loader thread id
     // the whole chunk in flight at once (U x 16 B per lane; 120 registers that only this branch owns): with the fp32
     // kernel's 16 the two loader waves needed two HBM round trips per chunk and the f16 compute waves waited for them
@@ -367,32 +403,23 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       const unsigned cc = __float_as_uint(t.z) & 0x7fffffffu, d = __float_as_uint(t.w) & 0x7fffffffu;
       return max(max(m, max(a, bb)), max(cc, d));
     };
-    auto pack4 = [](const F4& t, float scale) {
-      u32x4 o;
-      o.x = pack_hl(t.x * scale); o.y = pack_hl(t.y * scale); o.z = pack_hl(t.z * scale); o.w = pack_hl(t.w * scale);
-      return o;
-    };
-    // both loader waves have published their maximum of chunk k (slot k % 3 is used for the (k / 3 + 1)-th time)
-    // the wave's maximum by DPP moves, ONE LDS atomic per wave (round-2 census: 64 same-address LDS atomics per wave made
-    // this hand-shake 3.4 us of a 9 us chunk period)
+    // the wave's maximum by DPP moves, ONE LDS atomic per wave (64 same-address LDS atomics per wave cost 3.4 us per chunk),
+    // then -- behind the wave's own LDS writes, which the LDS executes in order -- the arrival count
     auto publish = [&](int k, unsigned m) {
 #define AAMD_RSM_MAX_STEP(CTRL, ROWS) m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, CTRL, ROWS, 0xf, false));
       AAMD_RSM_MAX_STEP(0x111, 0xf) AAMD_RSM_MAX_STEP(0x112, 0xf) AAMD_RSM_MAX_STEP(0x114, 0xf) AAMD_RSM_MAX_STEP(0x118, 0xf)
       AAMD_RSM_MAX_STEP(0x142, 0xa) AAMD_RSM_MAX_STEP(0x143, 0xc)
 #undef AAMD_RSM_MAX_STEP
-      if (lane == 63) atomicMax(&mx[k % 3], m);
-    };
-    auto meet = [&](int k) {
-      __builtin_amdgcn_s_waitcnt(0xc07f);                                   // lgkmcnt(0): this wave's atomic max is done
-      if (lane == 63) atomicAdd(&cnt[k % 3], 1u);
-      const unsigned want = (unsigned)kLoaderWaves * (unsigned)(k / 3 + 1);
-      while (__atomic_load_n(&cnt[k % 3], __ATOMIC_RELAXED) < want) __builtin_amdgcn_s_sleep(1);
-      return mx[k % 3];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 63) {
+        atomicMax(&mx[k % 3], m);
+        atomicAdd(&cnt[k % 3], 1u);
+      }
     };
 #define AAMD_RSM_FETCH(CID)                                                                                        \
     {                                                                                                              \
       chunk_src(CID);                                                                                              \
-      if (interior) {   /* wave-uniform base + one 32-bit lane offset per load; edge chunks are fetched in STORE */ \
+      if (interior) {   /* wave-uniform base + one 32-bit lane offset per load; edge chunks are fetched in STAGE */ \
         const F4* base4 = reinterpret_cast<const F4*>(wrow + a0);                                                  \
         int lt_ = lt;                                                                                              \
         asm volatile("" : "+v"(lt_));   /* offsets recomputed here: hoisted out of the chunk loop they get spilled */ \
@@ -402,58 +429,50 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         }                                                                                                          \
       }                                                                                                            \
     }
-#define AAMD_RSM_STORE(CID)                                                                                        \
+#define AAMD_RSM_STAGE(CID)                                                                                        \
     {                                                                                                              \
       const int k_ = (int)((CID) - first);                                                                         \
       float* buf_ = smem_rsm + (k_ & 1) * g.buf_floats;                                                            \
       unsigned m_ = 0u;                                                                                            \
-      float scale_, inv_;                                                                                          \
-      if (interior) {   /* from the registers: no raw image in LDS at all */                                        \
-        AAMD_RSM_STAMP(k_, 0)                                                                                        \
-        _Pragma("unroll") for (int u = 0; u < U; ++u) m_ = absmax(m_, v[u]);   /* (clamped duplicates: same maximum) */ \
-        asm volatile("" : "+v"(m_));                                                                                \
-        AAMD_RSM_STAMP(k_, 1)                                                                                        \
-        publish(k_, m_);                                                                                           \
-        chunk_scale(meet(k_), scale_, inv_);                                                                       \
-        AAMD_RSM_STAMP(k_, 2)                                                                                        \
+      AAMD_RSM_STAMP(k_, 0)                                                                                        \
+      if (interior) {   /* from the registers; a lane past the end holds a copy of the last piece and rewrites it */ \
         int lt_ = lt;                                                                                              \
         asm volatile("" : "+v"(lt_));   /* as in FETCH: nothing of this hoisted out of the chunk loop */            \
-        u32x4* dst_ = reinterpret_cast<u32x4*>(buf_) + lt_;                                                        \
-        const int left_ = pieces - lt_;                                                                            \
-        _Pragma("unroll") for (int u = 0; u < U; ++u)                                                              \
-          if (64 * kLoaderWaves * u < left_) dst_[64 * kLoaderWaves * u] = pack4(v[u], scale_);                    \
-        __builtin_amdgcn_s_waitcnt(0xc07f);                                                                        \
-        AAMD_RSM_STAMP(k_, 3)                                                                                        \
-      } else {          /* edge chunks, very long chunks: raw image first, converted in place by its writers */     \
-        if (!(lab & 8))                                                                                          \
-          _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * kLoaderWaves) {                               \
-            const F4 t = load_piece(g, wrow, a0, j);                                                               \
-            *reinterpret_cast<F4*>(buf_ + 4 * j) = t;                                                              \
-            m_ = absmax(m_, t);                                                                                    \
-          }                                                                                                        \
-        publish(k_, m_);                                                                                           \
-        chunk_scale(meet(k_), scale_, inv_);                                                                       \
+        F4* dst_ = reinterpret_cast<F4*>(buf_);                                                                    \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                            \
+          const int j = lt_ + 64 * kLoaderWaves * u;                                                               \
+          dst_[j < pieces ? j : pieces - 1] = v[u];                                                                \
+          m_ = absmax(m_, v[u]);                                                                                   \
+        }                                                                                                          \
+      } else if (!(lab & 8)) {   /* edge chunks, very long chunks */                                               \
         _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * kLoaderWaves) {                                 \
-          const F4 t = *reinterpret_cast<const F4*>(buf_ + 4 * j);                                                 \
-          *reinterpret_cast<u32x4*>(buf_ + 4 * j) = pack4(t, scale_);                                              \
+          const F4 t = load_piece(g, wrow, a0, j);                                                                 \
+          *reinterpret_cast<F4*>(buf_ + 4 * j) = t;                                                                \
+          m_ = absmax(m_, t);                                                                                      \
         }                                                                                                          \
       }                                                                                                            \
+      AAMD_RSM_STAMP(k_, 1)                                                                                        \
+      publish(k_, m_);                                                                                             \
+      AAMD_RSM_STAMP(k_, 2)                                                                                        \
     }
     if (first < end) {
       AAMD_RSM_FETCH(first)
-      AAMD_RSM_STORE(first)
+      AAMD_RSM_STAGE(first)
     }
     if (first + 1 < end) AAMD_RSM_FETCH(first + 1)
+    if (first < end) convert(0);
     __syncthreads();                                     // A0
     for (int64_t cid = first; cid < end; ++cid) {
-      if (cid + 1 < end) AAMD_RSM_STORE(cid + 1)          // fetched a whole chunk period ago; its buffer is free since A(cid - 1)
+      if (cid + 1 < end) AAMD_RSM_STAGE(cid + 1)          // fetched a whole chunk period ago; its buffer is free since A(cid - 1)
       if (cid + 2 < end) AAMD_RSM_FETCH(cid + 2)          // stays in registers until the next round
+      AAMD_RSM_STAMP((int)(cid + 1 - first), 3)
+      if (cid + 1 < end) convert((int)(cid + 1 - first));
       AAMD_RSM_STAMP((int)(cid + 1 - first), 4)
       __syncthreads();                                   // A(cid)
       AAMD_RSM_STAMP((int)(cid + 1 - first), 5)
     }
 #undef AAMD_RSM_FETCH
-#undef AAMD_RSM_STORE
+#undef AAMD_RSM_STAGE
     return;
   }
 
@@ -463,6 +482,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     ah[i] = 0x3c003c00u; al[i] = 0x1c001c00u + i;
     if (!(lab & 16)) a_pack16(g, kern, pt, tap_lo, KS, i >> 2, i & 3, lane, ah[i], al[i]);
   }
+  if (first < end) convert(0);
   __syncthreads();                                       // A0
   for (int64_t cid = first; cid < end; ++cid) {
     const int k = (int)(cid - first);
@@ -525,9 +545,11 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       store_c(g, out_row, qc0, qt1, pt, lane, acc1[0] * inv, acc1[1] * inv, acc1[2] * inv, acc1[3] * inv);
     }
     AAMD_RSM_STAMP(k, 2)
+    if (cid + 1 < end) convert(k + 1);                   // (stamp 3 inside: both loaders have arrived)
+    AAMD_RSM_STAMP(k, 4)
     __syncthreads();                                     // A(cid): chunk cid is consumed, chunk cid + 1 is in LDS
-    AAMD_RSM_STAMP(k, 3)
-    if (threadIdx.x == 0) mx[k % 3] = 0u;                // read by everybody before A(cid); next written behind A(cid + 1)
+    AAMD_RSM_STAMP(k, 5)
+    if (threadIdx.x == 0) { mx[k % 3] = 0u; grab[k % 3] = 0u; }                // read by everybody before A(cid); next written behind A(cid + 1)
   }
 }
 #endif  // __HIPCC__

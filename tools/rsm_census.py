@@ -20,13 +20,15 @@ assert h.aamd_debug_rsm_census(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
 t = buf.reshape(16, 32, 8).astype(np.float64) * 0.01     # us (100 MHz)
 base = t[0, :, 0]
 print("chunk period (compute wave 0, stamp 0 -> next stamp 0): mean %.2f us" % np.diff(t[0, :, 0]).mean())
-print("compute waves (0..9): MFMA loop = s1 - s0, stores = s2 - s1, barrier wait = s3 - s2   [us, mean over 32 chunks]")
+print("compute waves (0..9): MFMA loop = s1 - s0, stores = s2 - s1, wait for the loaders = s3 - s2, convert = s4 - s3, "
+      "barrier = s5 - s4   [us, mean over 32 chunks]")
 for w in range(10):
     a = t[w]
-    print("  wave %2d: loop %5.2f  stores %5.2f  barrier %5.2f" % (w, (a[:, 1] - a[:, 0]).mean(), (a[:, 2] - a[:, 1]).mean(), (a[:, 3] - a[:, 2]).mean()))
-print("loader waves (10, 11): data wait + max = s1 - s0, hand-shake = s2 - s1, convert + LDS stores = s3 - s2, fetch issue = s4 - s3, barrier = s5 - s4")
+    d = [(a[:, i + 1] - a[:, i]).mean() for i in range(5)]
+    print("  wave %2d: loop %5.2f  stores %5.2f  wait %5.2f  convert %5.2f  barrier %5.2f" % (w, *d))
+print("loader waves (10, 11): data wait + raw LDS stores + max = s1 - s0, publish = s2 - s1, fetch issue = s3 - s2, convert = s4 - s3, barrier = s5 - s4")
 for w in (10, 11):
     a = t[w]
-    print("  wave %2d: max %5.2f  meet %5.2f  convert %5.2f  fetch %5.2f  barrier %5.2f   | s0 relative to compute wave 0's chunk start: %5.2f" % (
-        w, (a[:, 1] - a[:, 0]).mean(), (a[:, 2] - a[:, 1]).mean(), (a[:, 3] - a[:, 2]).mean(), (a[:, 4] - a[:, 3]).mean(),
-        (a[:, 5] - a[:, 4]).mean(), (a[:, 0] - t[0, :, 0]).mean()))
+    d = [(a[:, i + 1] - a[:, i]).mean() for i in range(5)]
+    print("  wave %2d: stage %5.2f  publish %5.2f  fetch %5.2f  convert %5.2f  barrier %5.2f   | s0 relative to compute wave 0's chunk start: %5.2f" % (
+        w, *d, (a[:, 0] - t[0, :, 0]).mean()))
