@@ -117,6 +117,7 @@ _SIGS = {
     "aamd_fftconvolve_f64": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
                                        C.c_int64, C.c_int64, _P]),
     "aamd_fftconvolve_workspace": (C.c_int64, [C.c_int64] * 5),
+    "aamd_fftconvolve_plan": (C.c_int, [C.c_int64] * 4),
     "aamd_fftconvolve_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
                                        C.c_int64, C.c_int64, _P, _P]),
 }
@@ -147,6 +148,7 @@ def lib():
 
 
 POLICY_FORCE_GENERIC, POLICY_MEL400_WIDE, POLICY_ISTFT_ATOMIC, POLICY_RESAMPLE_FP32 = 1, 2, 4, 8
+POLICY_FFTCONV_NO_FDL, POLICY_FFTCONV_FDL = 16, 32
 
 
 class kernel_policy:

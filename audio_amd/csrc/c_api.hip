@@ -69,6 +69,8 @@ int policy() {
     if (std::getenv("AAMD_MEL400_WIDE") != nullptr) p |= AAMD_POLICY_MEL400_WIDE;
     if (std::getenv("AAMD_ISTFT_ATOMIC") != nullptr) p |= AAMD_POLICY_ISTFT_ATOMIC;
     if (std::getenv("AAMD_RESAMPLE_FP32") != nullptr) p |= AAMD_POLICY_RESAMPLE_FP32;
+    if (std::getenv("AAMD_FFTCONV_NO_FDL") != nullptr) p |= AAMD_POLICY_FFTCONV_NO_FDL;
+    if (std::getenv("AAMD_FFTCONV_FDL") != nullptr) p |= AAMD_POLICY_FFTCONV_FDL;
     int expected = -1;
     g_policy.compare_exchange_strong(expected, p);
     p = g_policy.load(std::memory_order_relaxed);
@@ -266,6 +268,7 @@ int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, c
   if (lds > dev_props().lds_per_block_optin)
     return fail(AAMD_EUNSUPPORTED, "audio_amd: mel filterbank too large for the LDS of this device");
   auto kern = m400::melspec400_kernel<0, EPI, H, TIn, NR>;
+  if (EPI == m400::EPI400_MFCC && epi.lab != 0) kern = m400::melspec400_kernel<(EPI == m400::EPI400_MFCC ? 524288 : 0), EPI, H, TIn, NR>;
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -335,7 +338,7 @@ int aamd_abi_version(void) { return AAMD_ABI_VERSION; }
 int aamd_set_kernel_policy(int flags) {
   const int prev = policy();
   if (flags >= 0) g_policy.store(flags & (AAMD_POLICY_FORCE_GENERIC | AAMD_POLICY_MEL400_WIDE | AAMD_POLICY_ISTFT_ATOMIC |
-                                          AAMD_POLICY_RESAMPLE_FP32));
+                                          AAMD_POLICY_RESAMPLE_FP32 | AAMD_POLICY_FFTCONV_NO_FDL | AAMD_POLICY_FFTCONV_FDL));
   return prev;
 }
 
@@ -1299,6 +1302,18 @@ static bool fftconv_use_fft(int64_t n_taps) {
   return n_taps > kFftConvMinTaps && !force_generic();
 }
 
+// partitions of the delay-line plan, 0 when the tap count (or the policy) rules it out
+static int64_t fftconv_fdl_parts(int64_t n_taps) {
+  const int64_t np = (n_taps + fco::kHop - 1) / fco::kHop;
+  return ((policy() & AAMD_POLICY_FFTCONV_NO_FDL) || np < 2 || np > fco::kMaxFdlParts) ? 0 : np;
+}
+// the plan of one call: the cost model of fco::plan_fdl, or (policy, tests) the delay line whenever it is possible at all
+static bool fftconv_pick_fdl(int64_t rows, int64_t taps, int64_t out_len, fco::FdlGeom& f) {
+  if (!fftconv_fdl_parts(taps)) return false;
+  const bool cheaper = fco::plan_fdl(rows, taps, out_len, dev_props().cu_count, f);
+  return cheaper || ((policy() & AAMD_POLICY_FFTCONV_FDL) && f.n_blocks >= 2);
+}
+
 int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_rows, int64_t nx, int64_t ny) {
   (void)rows;
   const bool swap = ny > nx;
@@ -1307,7 +1322,17 @@ int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_r
   if (!fftconv_use_fft(taps)) return 0;
   fco::Geom g{};
   fco::plan(taps, 1, g);
-  return (int64_t)sizeof(fco::C32) * fco::kN * (1 + tap_rows * g.n_part);
+  // twiddles | tap spectra (of whichever plan runs) | delay-line rings, one per workgroup (the slice is not known here)
+  const int64_t np_fdl = fftconv_fdl_parts(taps);
+  const int64_t n_spec = tap_rows * (np_fdl > g.n_part ? np_fdl : g.n_part);
+  return (int64_t)sizeof(fco::C32) * fco::kN * (1 + n_spec + (np_fdl > 2 ? np_fdl - 2 : 0) * dev_props().cu_count);
+}
+
+int aamd_fftconvolve_plan(int64_t rows, int64_t nx, int64_t ny, int64_t out_len) {
+  const int64_t taps = ny > nx ? nx : ny;
+  if (!fftconv_use_fft(taps)) return 0;
+  fco::FdlGeom f{};
+  return fftconv_pick_fdl(rows, taps, out_len, f) ? 2 : 1;
 }
 
 int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows,
@@ -1342,6 +1367,34 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fco::overlap_save_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fco::twiddle_kernel, dim3(fco::kN / 256), dim3(256), 0, s, tw);
+    fco::FdlGeom f{};
+    f.rows = rows; f.nx = nxa; f.ny = nya; f.start = start; f.out_len = out_len;
+    if (fftconv_pick_fdl(rows, nya, out_len, f)) {
+      // frequency-domain delay line: one forward + one inverse FFT per block step
+      fco::Geom gs = g;
+      gs.n_part = f.n_part; gs.part_taps = fco::kHop;
+      AAMD_CHECK_ARG(tap_rows * f.n_part < (1ll << 31), "too many tap rows");
+      hipLaunchKernelGGL(fco::spectrum_kernel, dim3((unsigned)(tap_rows * f.n_part)), dim3(fco::kThreads), lds, s, gs,
+                         ya, tw, H);
+      const int64_t n_spec = tap_rows * (f.n_part > g.n_part ? f.n_part : g.n_part);
+      fco::C32* ring = H + n_spec * fco::kN;
+      int64_t blocks = dev_props().cu_count;
+      if (blocks > rows * f.segs) blocks = rows * f.segs;
+#define AAMD_FDL(NP)                                                                                          \
+      do {                                                                                                    \
+        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fco::overlap_save_fdl_kernel<NP>),         \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+        hipLaunchKernelGGL(fco::overlap_save_fdl_kernel<NP>, dim3((unsigned)blocks), dim3(fco::kPhys), lds, s, \
+                           f, xa, tw, H, ring, xmap, ymap, out);                                              \
+      } while (0)
+      switch (f.n_part) {
+        case 2: AAMD_FDL(2); break;
+        case 3: AAMD_FDL(3); break;
+        default: AAMD_FDL(4); break;
+      }
+#undef AAMD_FDL
+      return launch_check();
+    }
     AAMD_CHECK_ARG(tap_rows * g.n_part < (1ll << 31), "too many tap rows");
     hipLaunchKernelGGL(fco::spectrum_kernel, dim3((unsigned)(tap_rows * g.n_part)), dim3(fco::kThreads), lds, s, g,
                        ya, tw, H);

@@ -148,28 +148,35 @@ AAMD_HD void mul_twiddles(C32 (&v)[16], const C32* tl, int e) {
 template <int LC, bool inv>
 AAMD_HD void pass16(int tid, C32* lds, const C32* tw) {
   constexpr int m = LC / 16;
+  // pad_idx(base + t m) = pad_idx(base) + t ms, ms = m + 4 (m >> 6): exact for m = 1024 and 64 (multiples of 64) and for m = 4
+  // (base % 64 = j < 4, so base + 4 t stays inside its group of 64).  ONE address per pass, the rest immediate offsets; with
+  // the 16 padded indices computed separately the compiler kept every one of them live across the step loop and spilled --
+  // and each reload of a spilled LDS address is an s_waitcnt vmcnt(0) that also waits for the prefetched inputs.
+  constexpr int ms = m + 4 * (m >> 6);
+  tid = opaque(tid);
   const int blk = tid / m, j = tid - blk * m;
   const int base = blk * LC + j;
+  C32* cell = lds + pad_idx(base);
   C32 v[16];
 #pragma unroll
-  for (int t = 0; t < 16; ++t) v[t] = lds[pad_idx(base + t * m)];
+  for (int t = 0; t < 16; ++t) v[t] = cell[t * ms];
   // inner passes read their 15 twiddles from the LDS tables (no products to form the powers)
-  const C32* tab = tw + (LC == 1024 ? kTwB : kTwC) + opaque(j);
+  const C32* tab = tw + (LC == 1024 ? kTwB : kTwC) + j;
   if (inv && (LC == 1024 || LC == 64)) {
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmulc<true>(v[k], tab[(k - 1) * m]);
   } else if (inv && m > 1) {
-    mul_twiddles<true>(v, tw, opaque(j * (kN / LC)));
+    mul_twiddles<true>(v, tw, j * (kN / LC));
   }
   dft16<inv>(v);
   if (!inv && (LC == 1024 || LC == 64)) {
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmulc<false>(v[k], tab[(k - 1) * m]);
   } else if (!inv && m > 1) {
-    mul_twiddles<false>(v, tw, opaque(j * (kN / LC)));
+    mul_twiddles<false>(v, tw, j * (kN / LC));
   }
 #pragma unroll
-  for (int t = 0; t < 16; ++t) lds[pad_idx(base + t * m)] = v[t];
+  for (int t = 0; t < 16; ++t) cell[t * ms] = v[t];
 }
 
 // Middle step = last forward pass (radix 4 on sub-transforms of length 4: no twiddles), product with the
@@ -194,7 +201,7 @@ AAMD_HD void middle_spectrum(int tid, const C32* lds, C32* H, float scale) {
     const int e0 = middle_e0(tid, q);
     C32 v[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0 + t)];
+    for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0) + t];
     dft4<false>(v[0], v[1], v[2], v[3]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) H[e0 + t] = C32{v[t].x * scale, v[t].y * scale};
@@ -213,36 +220,38 @@ AAMD_HD int64_t block_s0(const Geom& g, int p, int64_t j) {
 // global load / store of the block gives it.
 AAMD_HD void first_pass_from_regs(int tid, C32 (&v)[16], C32* lds, const C32* tw) {
   dft16<false>(v);
-  mul_twiddles<false>(v, tw, opaque(tid));
+  tid = opaque(tid);
+  mul_twiddles<false>(v, tw, tid);
+  C32* cell = lds + pad_idx(tid);               // pad_idx(tid + 1024 t) = pad_idx(tid) + 1088 t
 #pragma unroll
-  for (int t = 0; t < 16; ++t) lds[pad_idx(tid + t * 1024)] = v[t];
+  for (int t = 0; t < 16; ++t) cell[t * 1088] = v[t];
 }
 
 AAMD_HD void last_pass_to_regs(int tid, const C32* lds, const C32* tw, C32 (&v)[16]) {
+  tid = opaque(tid);
+  const C32* cell = lds + pad_idx(tid);
 #pragma unroll
-  for (int t = 0; t < 16; ++t) v[t] = lds[pad_idx(tid + t * 1024)];
-  mul_twiddles<true>(v, tw, opaque(tid));
+  for (int t = 0; t < 16; ++t) v[t] = cell[t * 1088];
+  mul_twiddles<true>(v, tw, tid);
   dft16<true>(v);
 }
 
-// inputs of the block pair (j0, j0 + 1) of partition p, element tid + 1024 t -> v[t] = a + i b
-AAMD_HD void load_pair_regs(int tid, const Geom& g, const float* xr, int p, int64_t j0, C32 (&v)[16]) {
-  const int64_t sa = block_s0(g, p, j0), sb = block_s0(g, p, j0 + 1);
-  const bool has_b = j0 + 1 < g.n_blocks;
+// inputs of two blocks starting at x[sa], x[sb] (either may reach outside [0, nx): zeros), element tid + 1024 t -> v[t] = a + i b
+AAMD_HD void load_blocks(int tid, int64_t nx, const float* xr, int64_t sa, int64_t sb, bool has_b, C32 (&v)[16]) {
   // uniform block bases + one 32-bit lane offset (opaque: keeps the address arithmetic out of the prologue)
   const float* pa = xr + sa;
   const float* pb = xr + sb;
   const unsigned lane = (unsigned)opaque(tid);
-  if (has_b && sa >= 0 && sb + kN <= g.nx) {            // interior pair (uniform branch): no bounds checks
+  if (has_b && sa >= 0 && sb >= 0 && sa + kN <= nx && sb + kN <= nx) {   // interior pair (uniform branch): no bounds checks
 #pragma unroll
     for (int t = 0; t < 16; ++t) v[t] = C32{(pa + 1024 * t)[lane], (pb + 1024 * t)[lane]};
     return;
   }
   // edge pair: valid element ranges [lo, hi) of the two blocks as 32-bit block-local indices
   const int lo_a = (int)(sa < 0 ? (-sa < kN ? -sa : kN) : 0);
-  const int hi_a = (int)(g.nx - sa < kN ? (g.nx - sa > 0 ? g.nx - sa : 0) : kN);
+  const int hi_a = (int)(nx - sa < kN ? (nx - sa > 0 ? nx - sa : 0) : kN);
   const int lo_b = (int)(sb < 0 ? (-sb < kN ? -sb : kN) : 0);
-  const int hi_b = !has_b ? 0 : (int)(g.nx - sb < kN ? (g.nx - sb > 0 ? g.nx - sb : 0) : kN);
+  const int hi_b = !has_b ? 0 : (int)(nx - sb < kN ? (nx - sb > 0 ? nx - sb : 0) : kN);
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int i = (int)lane + 1024 * t;
@@ -251,22 +260,30 @@ AAMD_HD void load_pair_regs(int tid, const Geom& g, const float* xr, int p, int6
   }
 }
 
-AAMD_HD void store_pair_regs(int tid, const Geom& g, const C32 (&v)[16], int64_t j0, float* out_row) {
-  const bool has_b = j0 + 1 < g.n_blocks;
-  const int skip = g.part_taps - 1;                       // wrapped-around samples
-  float* oa = out_row + (j0 * g.v - skip);                // uniform bases; element i of block a -> oa[i]
-  float* ob = oa + g.v;
+// inputs of the block pair (j0, j0 + 1) of partition p
+AAMD_HD void load_pair_regs(int tid, const Geom& g, const float* xr, int p, int64_t j0, C32 (&v)[16]) {
+  load_blocks(tid, g.nx, xr, block_s0(g, p, j0), block_s0(g, p, j0 + 1), j0 + 1 < g.n_blocks, v);
+}
+
+// element i of block a -> oa[i] for skip <= i < hi_a (b likewise): uniform bases and limits
+AAMD_HD void store_blocks(int tid, const C32 (&v)[16], float* oa, float* ob, int skip, int hi_a, int hi_b) {
   const unsigned lane = (unsigned)opaque(tid);
-  // valid i: skip <= i < hi (32-bit, uniform limits)
-  const int64_t left_a = g.out_len - (j0 * g.v - skip), left_b = left_a - g.v;
-  const int hi_a = (int)(left_a < kN ? (left_a > 0 ? left_a : 0) : kN);
-  const int hi_b = !has_b ? 0 : (int)(left_b < kN ? (left_b > 0 ? left_b : 0) : kN);
 #pragma unroll
   for (int t = 0; t < 16; ++t) {
     const int i = (int)lane + 1024 * t;
     if (i >= skip && i < hi_a) (oa + 1024 * t)[lane] = v[t].x;
     if (i >= skip && i < hi_b) (ob + 1024 * t)[lane] = v[t].y;
   }
+}
+
+AAMD_HD void store_pair_regs(int tid, const Geom& g, const C32 (&v)[16], int64_t j0, float* out_row) {
+  const bool has_b = j0 + 1 < g.n_blocks;
+  const int skip = g.part_taps - 1;                       // wrapped-around samples
+  float* oa = out_row + (j0 * g.v - skip);                // element i of block a -> oa[i]
+  const int64_t left_a = g.out_len - (j0 * g.v - skip), left_b = left_a - g.v;
+  const int hi_a = (int)(left_a < kN ? (left_a > 0 ? left_a : 0) : kN);
+  const int hi_b = !has_b ? 0 : (int)(left_b < kN ? (left_b > 0 ? left_b : 0) : kN);
+  store_blocks(tid, v, oa, oa + g.v, skip, hi_a, hi_b);
 }
 
 // middle step with the partitions accumulated in registers: acc[4 q + t] += DFT4(lds[4 (tid + 1024 q) + .])[t] * H
@@ -276,7 +293,7 @@ AAMD_HD void middle_accumulate(int tid, const C32* lds, const C32* H, C32 (&acc)
     const int e0 = middle_e0(tid, q);
     C32 v[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0 + t)];
+    for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0) + t];
     dft4<false>(v[0], v[1], v[2], v[3]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -294,7 +311,7 @@ AAMD_HD void middle_finish(int tid, C32 (&acc)[16], C32* lds) {
     const int e0 = middle_e0(tid, q);
     dft4<true>(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) lds[pad_idx(e0 + t)] = acc[4 * q + t];
+    for (int t = 0; t < 4; ++t) lds[pad_idx(e0) + t] = acc[4 * q + t];
   }
 }
 
@@ -307,6 +324,111 @@ AAMD_HD void load_taps(int tid, const Geom& g, const float* yr, int p, C32* lds)
     const int64_t k = t0 + i;
     lds[pad_idx(i)] = C32{(i < g.part_taps && k < g.ny) ? yr[k] : 0.0f, 0.0f};
   }
+}
+
+// ---- frequency-domain delay line (uniform partitions) ---------------------------------------------------------------
+// With block hop = partition length = kHop = kN / 2 the spectrum Z_j of the input segment x[start + (j - 1) kHop .. + kN) serves
+// n_part consecutive output blocks:  Y_j = sum_p H_p Z_(j - p)  (H_p = spectrum of taps [p kHop, (p + 1) kHop)).  A workgroup
+// walks consecutive blocks of one row segment and keeps the last n_part - 1 spectra -- the latest in registers, the older
+// ones in a ring in global memory (each thread re-reads exactly the 32 elements it wrote: thread-private, coalesced, no
+// synchronisation): ONE forward and one inverse FFT per step instead of n_part + 1.  The two real sequences packed into the complex FFT are the two halves of the segment
+// (blocks j and j + hn), so both see the same delay.  A segment starts with n_part - 1 forward-only steps that fill the ring.
+constexpr int kHop = kN / 2;
+constexpr int kMaxFdlParts = 4;
+
+struct FdlGeom {
+  int64_t rows, nx, ny, start, out_len;
+  int n_part;              // ceil(ny / kHop)
+  int segs;                // segments per row: one work item each
+  int64_t n_blocks;        // ceil(out_len / kHop)
+  int64_t seg_blocks;      // blocks per segment (the last one may be shorter)
+};
+
+// cost in FFTs on the critical path of the busiest workgroup; returns true when the delay line is the cheaper plan
+AAMD_HD bool plan_fdl(int64_t rows, int64_t ny, int64_t out_len, int cu_count, FdlGeom& f) {
+  f.n_part = (int)((ny + kHop - 1) / kHop);
+  f.n_blocks = (out_len + kHop - 1) / kHop;
+  f.segs = 1;
+  f.seg_blocks = f.n_blocks;
+  if (f.n_part < 2 || f.n_part > kMaxFdlParts || rows < 1 || f.n_blocks < 2 || cu_count < 1) return false;
+  Geom g{};
+  plan(ny, out_len, g);
+  const int64_t old_cost = ((rows * g.n_pairs + cu_count - 1) / cu_count) * (g.n_part + 1);
+  int64_t best = -1;
+  for (int segs = 1; segs <= 64 && segs * 2 <= f.n_blocks; ++segs) {
+    const int64_t sb = (f.n_blocks + segs - 1) / segs, hn = (sb + 1) / 2;
+    const int64_t used = (f.n_blocks + sb - 1) / sb;                      // segments that own blocks
+    const int64_t cost = ((rows * used + cu_count - 1) / cu_count) * (2 * hn + f.n_part - 1);
+    if (best < 0 || cost < best) { best = cost; f.segs = (int)used; f.seg_blocks = sb; }
+  }
+  return best > 0 && best * 10 <= old_cost * 9;
+}
+
+// the middle step of one delay-line step for logical thread tid: Z = radix-4 of the LDS data; with `produce`,
+// Y = sum_p H_p Z_(-p) and the first inverse radix-4 back into LDS.  Z_(-1) stays in registers (zprev: the thread's own 16
+// elements); Z_(-2) .. Z_(-(NP-1)) come from the ring (NP - 2 slots; Z_(-1) goes to `wslot`, the slot of the oldest, after
+// that one has been read).  Ring traffic per step: one spectrum written, NP - 2 read (none at all for NP = 2).
+template <int NP>
+AAMD_HD void middle_fdl(int tid, C32* lds, const C32* H, C32* ring, int wslot, bool produce, C32 (&zprev)[16]) {
+  constexpr int R = NP - 2;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // (opaque: the 2 x 4 x (2 NP - 2) element addresses are loop invariants of the step loop; hoisted, they were spilled)
+    const int e0 = middle_e0(opaque(tid), q);
+    C32 v[4], h[NP][4], zr[NP][4];
+    if (produce) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[p][t] = H[(int64_t)p * kN + e0 + t];
+        if (p >= 2) {
+          int sp = wslot - (p - 1);
+          if (sp < 0) sp += R;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) zr[p][t] = ring[(int64_t)sp * kN + e0 + t];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0) + t];
+    dft4<false>(v[0], v[1], v[2], v[3]);
+    if (produce) {
+      C32 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const C32 z1 = zprev[4 * q + t];
+        acc[t] = C32{v[t].x * h[0][t].x - v[t].y * h[0][t].y, v[t].x * h[0][t].y + v[t].y * h[0][t].x};
+        acc[t].x += z1.x * h[1][t].x - z1.y * h[1][t].y;
+        acc[t].y += z1.x * h[1][t].y + z1.y * h[1][t].x;
+#pragma unroll
+        for (int p = 2; p < NP; ++p) {
+          acc[t].x += zr[p][t].x * h[p][t].x - zr[p][t].y * h[p][t].y;
+          acc[t].y += zr[p][t].x * h[p][t].y + zr[p][t].y * h[p][t].x;
+        }
+      }
+      dft4<true>(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) lds[pad_idx(e0) + t] = acc[t];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (R > 0) ring[(int64_t)wslot * kN + e0 + t] = zprev[4 * q + t];
+      zprev[4 * q + t] = v[t];
+    }
+  }
+}
+
+// blocks of step s of an item: a = j_lo + s, b = j_lo + hn + s
+AAMD_HD int64_t fdl_seg_start(const FdlGeom& f, int64_t j) { return f.start + (j - 1) * (int64_t)kHop; }
+AAMD_HD void fdl_load(int tid, const FdlGeom& f, const float* xr, int64_t ja, int64_t jb, C32 (&v)[16]) {
+  load_blocks(tid, f.nx, xr, fdl_seg_start(f, ja), fdl_seg_start(f, jb), true, v);
+}
+AAMD_HD void fdl_store(int tid, const FdlGeom& f, const C32 (&v)[16], int64_t ja, int64_t jb, int64_t j_hi, float* out_row) {
+  // element i >= kHop of block j is output j kHop + i - kHop
+  const int64_t left_a = f.out_len - (ja - 1) * (int64_t)kHop, left_b = f.out_len - (jb - 1) * (int64_t)kHop;
+  const int hi_a = (int)(left_a < kN ? (left_a > 0 ? left_a : 0) : kN);
+  const int hi_b = jb >= j_hi ? 0 : (int)(left_b < kN ? (left_b > 0 ? left_b : 0) : kN);
+  store_blocks(tid, v, out_row + (ja - 1) * (int64_t)kHop, out_row + (jb - 1) * (int64_t)kHop, kHop, hi_a, hi_b);
 }
 
 #if defined(__HIPCC__)
@@ -421,6 +543,80 @@ overlap_save_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__
     store_pair_regs(t1, g, w, j0, out + row * g.out_len);
     if (nitem < n_items) load_pair_regs(t1, g, nxr, 0, 2 * (nitem - nrow * g.n_pairs), v1);
     __syncthreads();
+  }
+}
+// the delay-line variant of overlap_save_kernel: one item = one row segment, walked block by block (see above)
+template <int NP>
+__global__ void __launch_bounds__(kPhys)
+overlap_save_fdl_kernel(FdlGeom f, const float* __restrict__ x, const C32* __restrict__ tw,
+                        const C32* __restrict__ H, C32* __restrict__ ring, const int64_t* __restrict__ x_row_of,
+                        const int64_t* __restrict__ y_row_of, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_fco[];
+  C32* lds = reinterpret_cast<C32*>(smem_fco);
+  const int t0 = threadIdx.x, t1 = threadIdx.x + kPhys;
+  const int64_t n_items = f.rows * f.segs;
+  C32* tl = lds + kLdsData;
+  twiddle_tables(t0, tw, tl);
+  twiddle_tables(t1, tw, tl);
+  __syncthreads();
+  constexpr int R = NP - 2;
+  C32* my_ring = ring + (int64_t)blockIdx.x * (R > 0 ? R : 1) * kN;
+  C32 v0[16], v1[16], zp0[16], zp1[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) zp0[t] = zp1[t] = C32{0.0f, 0.0f};
+#pragma unroll 1
+  for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int64_t row = item / f.segs;
+    const int64_t j_lo = (item - row * f.segs) * f.seg_blocks;
+    const int64_t j_hi = j_lo + f.seg_blocks < f.n_blocks ? j_lo + f.seg_blocks : f.n_blocks;
+    const int64_t hn = (j_hi - j_lo + 1) / 2;
+    const float* xr = x + (x_row_of ? x_row_of[row] : row) * f.nx;
+    const C32* Hr = H + (y_row_of ? y_row_of[row] : row) * NP * (int64_t)kN;
+    float* out_row = out + row * f.out_len;
+    int wslot = 0;
+    fdl_load(t0, f, xr, j_lo - (NP - 1), j_lo + hn - (NP - 1), v0);
+    fdl_load(t1, f, xr, j_lo - (NP - 1), j_lo + hn - (NP - 1), v1);
+#pragma unroll 1
+    for (int64_t s = -(NP - 1); s < hn; ++s) {
+      const bool produce = s >= 0;
+      first_pass_from_regs(t0, v0, lds, tl);
+      first_pass_from_regs(t1, v1, lds, tl);
+      __syncthreads();
+#define AAMD_FDL_FWD(T, ZP)                                                                          \
+      pass16<1024, false>(T, lds, tl);                                                               \
+      wave_sync();                                                                                   \
+      pass16<64, false>(T, lds, tl);                                                                 \
+      wave_sync();                                                                                   \
+      middle_fdl<NP>(T, lds, Hr, my_ring, wslot, produce, ZP);
+#define AAMD_FDL_INV(T)                                                                              \
+      if (produce) {                                                                                 \
+        wave_sync();                                                                                 \
+        pass16<64, true>(T, lds, tl);                                                                \
+        wave_sync();                                                                                 \
+        pass16<1024, true>(T, lds, tl);                                                              \
+      }
+      AAMD_FDL_FWD(t0, zp0)
+      AAMD_FDL_INV(t0)
+      AAMD_FDL_FWD(t1, zp1)
+      if (s + 1 < hn) {   // the next step's inputs: in flight during the inverse passes and the stores (their 64 registers
+                          // are the ones the middle step's operands have just left)
+        fdl_load(t0, f, xr, j_lo + s + 1, j_lo + hn + s + 1, v0);
+        fdl_load(t1, f, xr, j_lo + s + 1, j_lo + hn + s + 1, v1);
+      }
+      AAMD_FDL_INV(t1)
+#undef AAMD_FDL_FWD
+#undef AAMD_FDL_INV
+      __syncthreads();
+      if (produce) {
+        C32 w[16];
+        last_pass_to_regs(t0, lds, tl, w);
+        fdl_store(t0, f, w, j_lo + s, j_lo + hn + s, j_hi, out_row);
+        last_pass_to_regs(t1, lds, tl, w);
+        fdl_store(t1, f, w, j_lo + s, j_lo + hn + s, j_hi, out_row);
+        __syncthreads();
+      }
+      if (R > 0) wslot = wslot + 1 == R ? 0 : wslot + 1;
+    }
   }
 }
 #endif  // __HIPCC__

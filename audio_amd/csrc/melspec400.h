@@ -927,6 +927,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
                   int tiles_per_row, int64_t n_tiles, int tiles_per_block, int in_aligned,
                   int out_wide, Epi400 epi) {
   extern __shared__ __attribute__((aligned(16))) float smem400[];
+  // the tools-only switches of the MFCC epilogue (AAMD_MFCC_LAB) are honoured by an instantiation of their own: as run-time
+  // branches in the product kernel they cut its MFMA section into basic blocks (the lesson of the resampler's census)
+  const int elab = (LAB & 524288) ? epi.lab : 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   long long lab_t0 = 0;
@@ -1202,7 +1205,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
           }
         }
       }
-      if (EPI == EPI400_MFCC && !fix && !(epi.lab & 4)) {
+      if (EPI == EPI400_MFCC && !fix && !(elab & 4)) {
         // min-scan by DPP moves (VALU; a butterfly of __shfl_xor would be 6 LDS round trips): lane 63 ends with the minimum
 #define AAMD_MIN_STEP(CTRL, ROWS)                                                                                  \
         tmin = fminf(tmin, __int_as_float(__builtin_amdgcn_update_dpp(0x7f800000, __float_as_int(tmin), CTRL, ROWS, 0xf, false)));
@@ -1221,7 +1224,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 #pragma unroll
         for (int t = 0; t < kMfccMT; ++t) {
           a[t] = F4{1.0f, 0.5f, 0.25f, 0.125f};
-          if (!(epi.lab & 1)) a[t] = *reinterpret_cast<const F4*>(epi.dct_frag + (((t * (kMfccKS / 4) + u) * 64 + lane) << 2));
+          if (!(elab & 1)) a[t] = *reinterpret_cast<const F4*>(epi.dct_frag + (((t * (kMfccKS / 4) + u) * 64 + lane) << 2));
         }
       };
       F4 a0[kMfccMT], a1[kMfccMT];
@@ -1232,7 +1235,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       f32x4 cf[kMfccMT];
 #pragma unroll
       for (int t = 0; t < kMfccMT; ++t) cf[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (!(epi.lab & 2)) {
+      if (!(elab & 2)) {
         // consecutive MFMAs go to different accumulators (a dependent one would wait out the 8 passes of its predecessor)
 #define AAMD_MFCC_STEP(A, COMP)                                                                                    \
         _Pragma("unroll") for (int t = 0; t < kMfccMT; ++t)                                                        \
@@ -1249,7 +1252,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 #undef AAMD_MFCC_STEP
       }
       const int j = lane & 15;
-      if (!(LAB & 2) && !(epi.lab & 8) && cur.t0 + j < n_frames && j < kFramesPerWave) {
+      if (!(LAB & 2) && !(elab & 8) && cur.t0 + j < n_frames && j < kFramesPerWave) {
         float* orow = out + (cur.row * (int64_t)n_frames + cur.t0 + j) * (int64_t)epi.n_mfcc;
 #pragma unroll
         for (int t = 0; t < kMfccMT; ++t) {

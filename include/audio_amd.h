@@ -110,13 +110,16 @@ int64_t aamd_mel400_table_dwords(int32_t n_mels, int32_t max_width);
 int aamd_mel400_table_build(const aamd_mel_bands* bands, float* table_out, void* stream);
 
 /* Kernel-selection switches for tests and A/B measurements (never needed in production): a process-wide bit mask,
- * initialised once from the environment variables AAMD_FORCE_GENERIC / AAMD_MEL400_WIDE / AAMD_ISTFT_ATOMIC.
+ * initialised once from the environment variables AAMD_FORCE_GENERIC / AAMD_MEL400_WIDE / AAMD_ISTFT_ATOMIC /
+ * AAMD_RESAMPLE_FP32 / AAMD_FFTCONV_NO_FDL / AAMD_FFTCONV_FDL.
  * aamd_set_kernel_policy returns the previous mask; a negative argument only queries.  Results do not depend on the mask, only which kernel computes them. */
 enum {
   AAMD_POLICY_FORCE_GENERIC = 1,  /* skip the shape-specialised kernels (radix-20x20, wave FFT, MFMA paths) */
   AAMD_POLICY_MEL400_WIDE   = 2,  /* n_fft = 400 mel epilogue: 16-byte stores through an LDS stage */
   AAMD_POLICY_ISTFT_ATOMIC  = 4,  /* inverse STFT: one atomic per contribution instead of run-based overlap-add */
-  AAMD_POLICY_RESAMPLE_FP32 = 8   /* banded resampling on v_mfma_f32_16x16x4_f32 instead of the f16 hi/lo-split MFMAs (16 x slower pipe) */
+  AAMD_POLICY_RESAMPLE_FP32 = 8,  /* banded resampling on v_mfma_f32_16x16x4_f32 instead of the f16 hi/lo-split MFMAs (16 x slower pipe) */
+  AAMD_POLICY_FFTCONV_NO_FDL = 16, /* overlap-save: never the frequency-domain delay-line plan */
+  AAMD_POLICY_FFTCONV_FDL   = 32  /* overlap-save: the delay-line plan whenever the tap count allows it (cost model ignored) */
 };
 int         aamd_set_kernel_policy(int flags);
 
@@ -364,9 +367,14 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
  * from output row to input row (broadcasting); NULL means identity.
  * The shorter operand is treated as the taps.  <= 192 taps: tiled time-domain evaluation.  More:
  * overlap-save on a 16384-point complex FFT held in LDS (two real blocks per complex FFT, taps
- * in partitions of <= 8192; tap spectra and the twiddle table live in `workspace`, which must hold
- * aamd_fftconvolve_workspace() bytes, 8-byte aligned; it may be NULL when that is 0). */
+ * in partitions of <= 8192; tap spectra, the twiddle table and -- for 8193 .. 32768 taps -- the
+ * frequency-domain delay lines of the workgroups live in `workspace`, which must hold
+ * aamd_fftconvolve_workspace() bytes, 8-byte aligned; it may be NULL when that is 0).
+ * aamd_fftconvolve_plan reports what a call of that shape runs on the current device: 0 time domain, 1 overlap-save
+ * with the input spectrum recomputed per tap partition, 2 overlap-save with a frequency-domain delay line (uniform
+ * 8192-tap partitions, one forward + one inverse FFT per block; chosen by a cost model over rows, blocks and CUs). */
 int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_rows, int64_t nx, int64_t ny);
+int aamd_fftconvolve_plan(int64_t rows, int64_t nx, int64_t ny, int64_t out_len);
 int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows,
                          int64_t n_y_rows, int64_t nx, int64_t ny, const int64_t* x_row_of,
                          const int64_t* y_row_of, int64_t start, int64_t out_len, void* workspace,

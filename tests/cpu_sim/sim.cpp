@@ -1022,7 +1022,7 @@ int sim_lfilter(const float* x, const float* a, const float* b, float* y, int64_
 // kernel has barriers.  Twiddles as the device twiddle_kernel computes them (fp64 -> fp32).
 int sim_fftconv_os(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows, int64_t n_y_rows,
                    int64_t nx, int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of, int64_t start,
-                   int64_t out_len) {
+                   int64_t out_len, int cu_count) {   // cu_count <= 0: never the delay-line plan; returns 1 when it ran
   using namespace fco;
   const bool swap = ny > nx;
   const float* xa = swap ? y : x; const float* ya = swap ? x : y;
@@ -1052,6 +1052,55 @@ int sim_fftconv_os(const float* x, const float* y, float* out, int64_t rows, int
   }
   std::vector<std::array<C32, 16>> v(kThreads), acc(kThreads);
   auto arr = [](std::array<C32, 16>& a) -> C32 (&)[16] { return *reinterpret_cast<C32 (*)[16]>(a.data()); };
+  FdlGeom f{};
+  f.rows = rows; f.nx = nxa; f.ny = nya; f.start = start; f.out_len = out_len;
+  if (cu_count > 0 && plan_fdl(rows, nya, out_len, cu_count, f)) {
+    // the delay-line plan (fco::overlap_save_fdl_kernel): spectra of kHop-tap partitions, a ring of NP spectra per item
+    const int NP = f.n_part;
+    Geom gs = g;
+    gs.n_part = NP; gs.part_taps = kHop;
+    std::vector<C32> Hf((size_t)tap_rows * NP * kN), ring((size_t)(NP > 2 ? NP - 2 : 1) * kN);
+    std::vector<std::array<C32, 16>> zprev(kThreads);
+    for (int64_t b = 0; b < tap_rows * NP; ++b) {
+      const int64_t yrow = b / NP; const int p = (int)(b - yrow * NP);
+      for (int t = 0; t < kThreads; ++t) load_taps(t, gs, ya + yrow * gs.ny, p, lds.data());
+      fwd();
+      for (int t = 0; t < kThreads; ++t) middle_spectrum(t, lds.data(), Hf.data() + b * kN, 1.0f / (float)kN);
+    }
+    for (int64_t item = 0; item < rows * f.segs; ++item) {
+      const int64_t row = item / f.segs, j_lo = (item - row * f.segs) * f.seg_blocks;
+      const int64_t j_hi = j_lo + f.seg_blocks < f.n_blocks ? j_lo + f.seg_blocks : f.n_blocks;
+      const int64_t hn = (j_hi - j_lo + 1) / 2;
+      const int64_t rx = xmap ? xmap[row] : row, ry = ymap ? ymap[row] : row;
+      const float* xr = xa + rx * f.nx;
+      const C32* Hr = Hf.data() + ry * NP * (int64_t)kN;
+      int wslot = 0;
+      for (int64_t s = -(NP - 1); s < hn; ++s) {
+        const bool produce = s >= 0;
+        for (int t = 0; t < kThreads; ++t) {
+          fdl_load(t, f, xr, j_lo + s, j_lo + hn + s, arr(v[t]));
+          first_pass_from_regs(t, arr(v[t]), lds.data(), tl);
+        }
+        for (int t = 0; t < kThreads; ++t) pass16<1024, false>(t, lds.data(), tl);
+        for (int t = 0; t < kThreads; ++t) pass16<64, false>(t, lds.data(), tl);
+        for (int t = 0; t < kThreads; ++t) {
+          if (NP == 2) middle_fdl<2>(t, lds.data(), Hr, ring.data(), wslot, produce, arr(zprev[t]));
+          else if (NP == 3) middle_fdl<3>(t, lds.data(), Hr, ring.data(), wslot, produce, arr(zprev[t]));
+          else middle_fdl<4>(t, lds.data(), Hr, ring.data(), wslot, produce, arr(zprev[t]));
+        }
+        if (produce) {
+          for (int t = 0; t < kThreads; ++t) pass16<64, true>(t, lds.data(), tl);
+          for (int t = 0; t < kThreads; ++t) pass16<1024, true>(t, lds.data(), tl);
+          for (int t = 0; t < kThreads; ++t) {
+            last_pass_to_regs(t, lds.data(), tl, arr(v[t]));
+            fdl_store(t, f, arr(v[t]), j_lo + s, j_lo + hn + s, j_hi, out + row * out_len);
+          }
+        }
+        if (NP > 2) wslot = wslot + 1 == NP - 2 ? 0 : wslot + 1;
+      }
+    }
+    return 1;
+  }
   for (int64_t item = 0; item < rows * g.n_pairs; ++item) {
     const int64_t row = item / g.n_pairs, j0 = 2 * (item - row * g.n_pairs);
     const int64_t rx = xmap ? xmap[row] : row, ry = ymap ? ymap[row] : row;

@@ -262,18 +262,23 @@ def sim_fftconv(x, y, start, out_len, xmap=None, ymap=None, rows=None):
     return out
 
 
-def sim_fftconv_os(x, y, start, out_len, xmap=None, ymap=None, rows=None):
-    """Overlap-save path (16384-point LDS FFT).  x: (n_x_rows, nx), y: (n_y_rows, ny)."""
+def sim_fftconv_os(x, y, start, out_len, xmap=None, ymap=None, rows=None, cu_count=0, plan=None):
+    """Overlap-save path (16384-point LDS FFT).  x: (n_x_rows, nx), y: (n_y_rows, ny).  cu_count > 0 lets the launcher's
+    cost model pick the frequency-domain delay-line plan as it would on a device with that many CUs; `plan`, a list, receives
+    "fdl" or "recompute"."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.ascontiguousarray(y, dtype=np.float32)
     nx, ny = x.shape[-1], y.shape[-1]
     rows = rows if rows is not None else x.shape[0]
     out = np.full((rows, out_len), np.nan, dtype=np.float32)
     f = sim().sim_fftconv_os
-    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 5 + [C.c_void_p] * 2 + [C.c_int64] * 2
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 5 + [C.c_void_p] * 2 + [C.c_int64] * 2 + [C.c_int]
     xm = None if xmap is None else fptr(np.ascontiguousarray(xmap, dtype=np.int64))
     ym = None if ymap is None else fptr(np.ascontiguousarray(ymap, dtype=np.int64))
-    assert f(fptr(x), fptr(y), fptr(out), rows, x.shape[0], y.shape[0], nx, ny, xm, ym, start, out_len) == 0
+    rc = f(fptr(x), fptr(y), fptr(out), rows, x.shape[0], y.shape[0], nx, ny, xm, ym, start, out_len, cu_count)
+    assert rc in (0, 1)
+    if plan is not None:
+        plan.append("fdl" if rc == 1 else "recompute")
     return out
 
 

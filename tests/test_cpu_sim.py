@@ -367,6 +367,30 @@ def test_sim_fftconvolve_overlap_save(nx, ny, mode):
     assert peak_rel_err(got, exp) <= 2e-6
 
 
+@pytest.mark.parametrize("nx,ny,mode,cus,fdl", [
+    (70000, 16000, "full", 2, True), (60000, 24000, "full", 2, True), (50000, 17000, "same", 1, True),
+    (90000, 30000, "valid", 4, True), (150000, 24000, "full", 16, True),
+    # barely more than one partition of taps (the non-uniform plan has the longer hop) / 5 blocks on 256 CUs: recompute
+    (70000, 9000, "full", 2, False), (40000, 20000, "full", 256, False)])
+def test_sim_fftconvolve_delay_line_plan(nx, ny, mode, cus, fdl):
+    """The frequency-domain delay-line plan of the overlap-save path (fco::overlap_save_fdl_kernel: uniform 8192-tap
+    partitions, one forward + one inverse FFT per block step, the last n_part - 1 spectra in a ring, the two halves of a row
+    segment packed into one complex FFT, forward-only warm-up steps) vs the float64 oracle: 2, 3 and 4 partitions, row
+    segments (more CUs than rows), slices that start inside the convolution, a last segment with an odd block count."""
+    rng = np.random.default_rng(nx + ny)
+    x = rng.standard_normal((2, nx)).astype(np.float32)
+    y = (rng.standard_normal((1, ny)) * np.exp(-np.arange(ny) / (0.3 * ny))).astype(np.float32)
+    exp = O.fftconvolve(x.astype(np.float64), np.broadcast_to(y, (2, ny)).astype(np.float64), mode)
+    n_full = nx + ny - 1
+    out_len = exp.shape[-1]
+    start = 0 if mode == "full" else (n_full - out_len) // 2
+    plan = []
+    got = S.sim_fftconv_os(x, y, start, out_len, ymap=np.zeros(2, dtype=np.int64), rows=2, cu_count=cus, plan=plan)
+    assert plan == ["fdl" if fdl else "recompute"], plan
+    assert not np.isnan(got).any()
+    assert peak_rel_err(got, exp) <= 2e-6
+
+
 def test_mel_lane_order_reduces_modelled_bank_conflicts():
     """Host optimiser of the lane assignment: a permutation inside each round, cheaper than identity under
     the b128 bank model of MI355X_MICROARCH.md for the headline filterbank; ragged n_mels keep -1 rows."""

@@ -351,6 +351,42 @@ def test_fftconvolve_overlap_save_equals_direct_and_oracle(case):
     assert peak_rel_err(fast.cpu().numpy(), exp) <= 1e-5
 
 
+@pytest.mark.parametrize("case", [((6, 700000), (1, 24000), "full"), ((3, 2, 300000), (3, 2, 16000), "same"),
+                                  ((2, 900000), (2, 30000), "valid"), ((300, 70000), (1, 20000), "full"),
+                                  ((4, 60000), (1, 20000), "full"), ((5, 40000), (5, 9000), "same")])
+def test_fftconvolve_delay_line_plan_against_oracle(case):
+    """The frequency-domain delay-line plan of the overlap-save path (2 / 3 / 4 uniform partitions, row segments when there
+    are fewer rows than CUs, per-row taps, slices that start inside the convolution, rows of only 5 blocks) vs the float64
+    oracle -- forced by policy, so every shape runs it whatever the cost model says -- and against the plan the cost model
+    picks itself; the plan query agrees with the policy."""
+    import audio_amd.functional as F
+    from audio_amd import _lib
+    from oracle import dsp_oracle as O
+    xs, ys, mode = case
+    g = torch.Generator().manual_seed(xs[-1] + ys[-1])
+    x = torch.randn(*xs, generator=g)
+    y = torch.randn(*ys, generator=g) * torch.exp(-torch.arange(ys[-1]) / (0.3 * ys[-1]))
+    lead = np.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    xe = np.broadcast_to(x.numpy().astype(np.float64), lead + x.shape[-1:])
+    ye = np.broadcast_to(y.numpy().astype(np.float64), lead + y.shape[-1:])
+    exp = O.fftconvolve(xe, ye, mode)
+    rows = int(np.prod(lead))
+    xd, yd = x.cuda(), y.cuda()
+    with _lib.kernel_policy(_lib.POLICY_FFTCONV_FDL):
+        assert _lib.lib().aamd_fftconvolve_plan(rows, xs[-1], ys[-1], exp.shape[-1]) == 2
+        fdl = F.fftconvolve(xd, yd, mode)
+    with _lib.kernel_policy(_lib.POLICY_FFTCONV_NO_FDL):
+        assert _lib.lib().aamd_fftconvolve_plan(rows, xs[-1], ys[-1], exp.shape[-1]) == 1
+        rec = F.fftconvolve(xd, yd, mode)
+    own = F.fftconvolve(xd, yd, mode)
+    plan = _lib.lib().aamd_fftconvolve_plan(rows, xs[-1], ys[-1], exp.shape[-1])
+    assert plan in (1, 2)
+    assert fdl.shape == exp.shape
+    assert peak_rel_err(fdl.cpu().numpy(), exp) <= 1e-5
+    assert peak_rel_err(rec.cpu().numpy(), exp) <= 1e-5
+    assert torch.equal(own, fdl if plan == 2 else rec)
+
+
 def test_fftconvolve_headline_shape_properties():
     """BASELINE config 5b shape at 1/8 of the batch (32 x 8 ch x 10 s @48 kHz, 0.5 s RIR = 24000 taps,
     shared RIR): length, linearity, and an impulse RIR reproduces the (delayed) input exactly."""
@@ -359,6 +395,8 @@ def test_fftconvolve_headline_shape_properties():
     x = torch.rand(32, 8, 480000, device="cuda", generator=g) - 0.5
     t = torch.arange(24000, device="cuda") / 48000.0
     rir = (torch.randn(1, 1, 24000, device="cuda", generator=g) * torch.exp(-t / 0.1) * 0.05)
+    from audio_amd import _lib
+    assert _lib.lib().aamd_fftconvolve_plan(256, 480000, 24000, 503999) == 2      # the delay-line plan serves this shape
     y = F.fftconvolve(x, rir)
     assert y.shape == (32, 8, 503999) and torch.isfinite(y).all()
     y2 = F.fftconvolve(0.5 * x[:2], rir)
