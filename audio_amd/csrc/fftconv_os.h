@@ -368,54 +368,71 @@ AAMD_HD bool plan_fdl(int64_t rows, int64_t ny, int64_t out_len, int cu_count, F
 // Y = sum_p H_p Z_(-p) and the first inverse radix-4 back into LDS.  Z_(-1) stays in registers (zprev: the thread's own 16
 // elements); Z_(-2) .. Z_(-(NP-1)) come from the ring (NP - 2 slots; Z_(-1) goes to `wslot`, the slot of the oldest, after
 // that one has been read).  Ring traffic per step: one spectrum written, NP - 2 read (none at all for NP = 2).
+// ... in two halves per q so that the kernel can request the operands of q + 1 before it works on q:
+// fdl_fetch = the tap spectra H_0 .. H_(NP-1) and the ring spectra Z_(-2) .. of the 4 elements of q
 template <int NP>
-AAMD_HD void middle_fdl(int tid, C32* lds, const C32* H, C32* ring, int wslot, bool produce, C32 (&zprev)[16]) {
+AAMD_HD void fdl_fetch(int tid, const C32* H, const C32* ring, int wslot, int q, C32 (&h)[NP][4], C32 (&zr)[NP][4]) {
   constexpr int R = NP - 2;
+  // (opaque: the 2 x 4 x (2 NP - 2) element addresses are loop invariants of the step loop; hoisted, they were spilled)
+  const int e0 = middle_e0(opaque(tid), q);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    // (opaque: the 2 x 4 x (2 NP - 2) element addresses are loop invariants of the step loop; hoisted, they were spilled)
-    const int e0 = middle_e0(opaque(tid), q);
-    C32 v[4], h[NP][4], zr[NP][4];
-    if (produce) {
+  for (int p = 0; p < NP; ++p) {
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
+    for (int t = 0; t < 4; ++t) h[p][t] = H[(int64_t)p * kN + e0 + t];
+    if (p >= 2) {
+      int sp = wslot - (p - 1);
+      if (sp < 0) sp += R;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h[p][t] = H[(int64_t)p * kN + e0 + t];
-        if (p >= 2) {
-          int sp = wslot - (p - 1);
-          if (sp < 0) sp += R;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) zr[p][t] = ring[(int64_t)sp * kN + e0 + t];
-        }
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0) + t];
-    dft4<false>(v[0], v[1], v[2], v[3]);
-    if (produce) {
-      C32 acc[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const C32 z1 = zprev[4 * q + t];
-        acc[t] = C32{v[t].x * h[0][t].x - v[t].y * h[0][t].y, v[t].x * h[0][t].y + v[t].y * h[0][t].x};
-        acc[t].x += z1.x * h[1][t].x - z1.y * h[1][t].y;
-        acc[t].y += z1.x * h[1][t].y + z1.y * h[1][t].x;
-#pragma unroll
-        for (int p = 2; p < NP; ++p) {
-          acc[t].x += zr[p][t].x * h[p][t].x - zr[p][t].y * h[p][t].y;
-          acc[t].y += zr[p][t].x * h[p][t].y + zr[p][t].y * h[p][t].x;
-        }
-      }
-      dft4<true>(acc[0], acc[1], acc[2], acc[3]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) lds[pad_idx(e0) + t] = acc[t];
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (R > 0) ring[(int64_t)wslot * kN + e0 + t] = zprev[4 * q + t];
-      zprev[4 * q + t] = v[t];
+      for (int t = 0; t < 4; ++t) zr[p][t] = ring[(int64_t)sp * kN + e0 + t];
     }
   }
+}
+template <int NP>
+AAMD_HD void fdl_apply(int tid, C32* lds, C32* ring, int wslot, bool produce, int q, const C32 (&h)[NP][4],
+                       const C32 (&zr)[NP][4], C32 (&zprev)[16]) {
+  constexpr int R = NP - 2;
+  const int e0 = middle_e0(opaque(tid), q);
+  C32 v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = lds[pad_idx(e0) + t];
+  dft4<false>(v[0], v[1], v[2], v[3]);
+  if (produce) {
+    C32 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const C32 z1 = zprev[4 * q + t];
+      acc[t] = C32{v[t].x * h[0][t].x - v[t].y * h[0][t].y, v[t].x * h[0][t].y + v[t].y * h[0][t].x};
+      acc[t].x += z1.x * h[1][t].x - z1.y * h[1][t].y;
+      acc[t].y += z1.x * h[1][t].y + z1.y * h[1][t].x;
+#pragma unroll
+      for (int p = 2; p < NP; ++p) {
+        acc[t].x += zr[p][t].x * h[p][t].x - zr[p][t].y * h[p][t].y;
+        acc[t].y += zr[p][t].x * h[p][t].y + zr[p][t].y * h[p][t].x;
+      }
+    }
+    dft4<true>(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) lds[pad_idx(e0) + t] = acc[t];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (R > 0) ring[(int64_t)wslot * kN + e0 + t] = zprev[4 * q + t];
+    zprev[4 * q + t] = v[t];
+  }
+}
+// the whole middle step; the operands of q + 1 are requested before q is worked on (the ring comes from HBM / the
+// Infinity Cache: with the requests at the head of each q the step waited four round trips per half)
+template <int NP>
+AAMD_HD void middle_fdl(int tid, C32* lds, const C32* H, C32* ring, int wslot, bool produce, C32 (&zprev)[16]) {
+  C32 ha[NP][4], za[NP][4], hb[NP][4], zb[NP][4];
+  if (produce) fdl_fetch<NP>(tid, H, ring, wslot, 0, ha, za);
+  if (produce) fdl_fetch<NP>(tid, H, ring, wslot, 1, hb, zb);
+  fdl_apply<NP>(tid, lds, ring, wslot, produce, 0, ha, za, zprev);
+  if (produce) fdl_fetch<NP>(tid, H, ring, wslot, 2, ha, za);
+  fdl_apply<NP>(tid, lds, ring, wslot, produce, 1, hb, zb, zprev);
+  if (produce) fdl_fetch<NP>(tid, H, ring, wslot, 3, hb, zb);
+  fdl_apply<NP>(tid, lds, ring, wslot, produce, 2, ha, za, zprev);
+  fdl_apply<NP>(tid, lds, ring, wslot, produce, 3, hb, zb, zprev);
 }
 
 // blocks of step s of an item: a = j_lo + s, b = j_lo + hn + s
