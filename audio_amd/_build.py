@@ -15,6 +15,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fno-slp-vectorize"]
 
 
+def _tmp_suffix() -> str:
+    """Per-process temporary name: concurrent builders (pytest-xdist workers) each write their own file and rename it into
+    place atomically instead of writing into one shared .tmp."""
+    return ".tmp.%d" % os.getpid()
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -44,13 +50,13 @@ def build_shim(force: bool = False, verbose: bool = False) -> str:
     cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-DUSE_ROCM",
            "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", os.path.join(tp, "include"),
-           SHIM_SRC, "-o", SHIM_OUT + ".tmp", "-L", os.path.dirname(OUT), "-laudio_amd",
+           SHIM_SRC, "-o", SHIM_OUT + _tmp_suffix(), "-L", os.path.dirname(OUT), "-laudio_amd",
            "-L", os.path.join(tp, "lib"), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10",
            "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(tp, "lib")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(SHIM_OUT + ".tmp", SHIM_OUT)
+    os.replace(SHIM_OUT + _tmp_suffix(), SHIM_OUT)
     return SHIM_OUT
 
 
@@ -68,12 +74,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
+    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + _tmp_suffix()]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    os.replace(OUT + ".tmp", OUT)
+    os.replace(OUT + _tmp_suffix(), OUT)
     return OUT
 
 

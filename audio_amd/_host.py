@@ -217,6 +217,47 @@ def resample_band_table(kernel: np.ndarray, rel_threshold: float = 2.0 ** -40):
     return lo, span
 
 
+def _rs_pick_ks(span: int) -> int:
+    """rsm::pick_ks (csrc/resample_mfma.h): k-steps of the narrowest kernel instantiation that covers a band of `span` taps."""
+    need = (span + 3) // 4
+    for ks in (16, 48, 80, 112):
+        if need <= ks:
+            return ks
+    return 0
+
+
+def resample_fill_phase_tiles(kernel: np.ndarray, orig: int, new: int, width: int):
+    """The matrix-core resampler works on tiles of 16 output phases; for a reduced rate pair with few phases (48 k -> 16 k is
+    3 : 1 -- ONE phase) fifteen sixteenths of every MFMA are padding.  The same filter written for the pair (m orig : m new)
+    has m new phases -- phase j new + p of the expanded table is phase p delayed by j orig samples:
+        kernel'[j new + p][k] = kernel[p][k - j orig],   taps' = taps + (m - 1) orig = 2 width + m orig
+    -- the outputs, their order and out_len = ceil(new L / orig) are unchanged, only the tiling of the same sums differs.
+    Picks m by the MFMA work per output sample, (tiles x k-steps of the band) / (m new), from the real band table of each
+    candidate, and returns (kernel', m); m = 1 returns the table as it is."""
+    kernel = np.asarray(kernel)
+    taps = kernel.shape[1]
+    best = None
+    for m in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
+        if m > 1 and (m * new > 256 or new % 16 == 0):
+            break
+        if m == 1:
+            kp = kernel
+        else:
+            kp = np.zeros((m * new, taps + (m - 1) * orig), dtype=kernel.dtype)
+            for j in range(m):
+                kp[j * new:(j + 1) * new, j * orig:j * orig + taps] = kernel
+        _, span = resample_band_table(kp)
+        ks = _rs_pick_ks(span)
+        if ks == 0:
+            if m == 1:
+                return kernel, 1
+            break
+        cost = ((m * new + 15) // 16) * ks / float(m * new)
+        if best is None or cost < 0.85 * best[0]:
+            best = (cost, m, kp)
+    return best[2], best[1]
+
+
 def resample_sparse_table(kernel: np.ndarray, rel_threshold: float = 2.0 ** -40):
     """Compact form of a polyphase table whose rows are almost empty (huge reduced rates, e.g. PitchShift's
     8000 x 10095): per phase the first non-negligible tap and the common span, and the taps of that window.

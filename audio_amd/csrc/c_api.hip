@@ -1121,21 +1121,30 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
       if (g.tap_lo[t] > max_lo) max_lo = g.tap_lo[t];
     }
     // q-groups: fill the workgroup with compute waves, bounded by the LDS double buffer and the row
+    const bool f16 = (policy() & AAMD_POLICY_RESAMPLE_FP32) == 0;
+    // ... and (f16 kernel) by what its two loader waves hold in registers: a longer chunk would take the staged path
+    const int64_t max_floats = f16 ? 4ll * 64 * rsm::kLoaderWaves * rsm::loader_pieces_per_lane(ks) : (1ll << 40);
     int qg = max_cw / g.n_pt;
     while (qg > 1 && ((int64_t)rsm::kQPerGroup * (qg - 1) >= nq ||
-                      2 * (size_t)rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) * sizeof(float) + 48 > lds_cap))
+                      2 * (size_t)rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) * sizeof(float) + 48 > lds_cap ||
+                      rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) > max_floats))
       --qg;
     g.qg = qg;
     const int qc = rsm::kQPerGroup * qg;
     g.buf_floats = rsm::buf_floats_needed(qc, orig, taps, max_lo, ks);
-    const bool f16 = (policy() & AAMD_POLICY_RESAMPLE_FP32) == 0;
     const size_t lds = 2 * (size_t)g.buf_floats * sizeof(float) + (f16 ? 48 : 0);       // + the chunk-maximum slots and arrival counters
     if (lds > lds_cap)   // a single q-group does not fit (huge orig): scalar kernel
       return aamd_resample_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, stream);
     g.chunks_per_row = (int)((nq + qc - 1) / qc);
     g.n_chunks = rows * g.chunks_per_row;
     AAMD_CHECK_ARG(g.n_chunks < (1ll << 31), "too many chunks for one launch");
-    int64_t blocks = dev_props().cu_count;
+    // persistent workgroups: as many per CU as the 16 wave slots (128 registers) and the LDS hold -- a one-tile rate pair
+    // has only a handful of compute waves per workgroup
+    const int wg_waves = g.n_pt * qg + rsm::kLoaderWaves;
+    int per_cu = ks >= 80 ? 1 : 16 / wg_waves;
+    if (per_cu > (int)(lds_cap / lds)) per_cu = (int)(lds_cap / lds);
+    if (per_cu < 1) per_cu = 1;
+    int64_t blocks = (int64_t)dev_props().cu_count * per_cu;
     if (blocks > g.n_chunks) blocks = g.n_chunks;
     g.chunks_per_block = (int)((g.n_chunks + blocks - 1) / blocks);
     blocks = (g.n_chunks + g.chunks_per_block - 1) / g.chunks_per_block;

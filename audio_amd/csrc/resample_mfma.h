@@ -56,6 +56,9 @@ AAMD_HD int pick_ks(int span) {
   return 0;
 }
 AAMD_HD int max_compute_waves(int ks) { return ks >= 80 ? 10 : 14; }
+// 16-byte pieces per lane that a loader wave of the f16 kernel keeps in flight in registers (a whole chunk: the launcher
+// sizes the chunk to at most 128 of these); the 16-wave instantiations (KS < 80) have 128 registers per thread
+AAMD_HD constexpr int loader_pieces_per_lane(int ks) { return ks >= 80 ? 30 : 20; }
 
 AAMD_HD int chunk_q(const Geom& g) { return kQPerGroup * g.qg; }
 
@@ -386,7 +389,10 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     const int lt = threadIdx.x - 64 * ncw;          // loader thread id
     // the whole chunk in flight at once (U x 16 B per lane; 120 registers that only this branch owns): with the fp32
     // kernel's 16 the two loader waves needed two HBM round trips per chunk and the f16 compute waves waited for them
-    constexpr int U = 30;
+    // (the 16-wave instantiations, KS < 80, have 128 registers: 30 x 16 B there spilled 536 B per thread, and a scratch
+    // reload waits for every load in flight -- the default-quality rate pairs ran 4-5 x slower than they do now;
+    // a chunk of more than 128 U pieces takes the staged path)
+    constexpr int U = loader_pieces_per_lane(KS);
     F4 v[U];
     const float* wrow = wav;
     int64_t a0 = 0;

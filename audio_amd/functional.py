@@ -1075,6 +1075,15 @@ def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new
                     x2.data_ptr(), hb.data_ptr(), lo.data_ptr(), out.data_ptr(), rows, length, max(length, 1), orig, new,
                     width, int(span), out_len, _lib.current_stream(x2.device)))
         return out
+    # few output phases (48 k -> 16 k has ONE): the same filter for the pair (m orig : m new), whose m new phases fill the
+    # 16-phase tiles of the matrix-core kernel (host, once per kernel tensor; same outputs in the same order)
+    def _fill():
+        kp, mm = _host.resample_fill_phase_tiles(kern.cpu().numpy(), orig, new, width)
+        return (kern if mm == 1 else torch.from_numpy(np.ascontiguousarray(kp)).to(x2.device)), mm
+
+    kern_m, m = _tensor_cached(key_tensor, ("rs_fill", key, orig, new, width), _fill)
+    if m > 1:
+        kern, orig, new = kern_m, m * orig, m * new
     # band table of the taps (host, once per kernel tensor): the matrix-core kernel skips the
     # ~1e-20-sized window tails outside each phase tile's band
     tap_lo, span = _tensor_cached(key_tensor, ("rs_bands", key, new),

@@ -28,7 +28,9 @@ def sim():
     if _sim is None:
         if _stale():
             os.makedirs(os.path.dirname(OUT), exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT])
+            tmp = "%s.tmp.%d" % (OUT, os.getpid())     # xdist workers build side by side: each its own file, renamed into place
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", tmp])
+            os.replace(tmp, OUT)
         _sim = C.CDLL(OUT)
     return _sim
 

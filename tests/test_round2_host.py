@@ -260,3 +260,39 @@ def test_mel400_table_image_invariants_and_conflict_cost():
             ref = [min(int(lo[m]) & ~1, 208 - rw) if m >= 0 else 0 for m in plain[20 * r:20 * r + 20]]
             cost_ord += _host._m400_cost_fast(ref) * int(rc[r])
         assert cost_img <= cost_ord
+
+
+@pytest.mark.parametrize("rates", [(48000, 16000), (16000, 8000), (8000, 16000), (16000, 24000), (24000, 16000), (44100, 48000),
+                                   (44100, 16000)])
+def test_resample_phase_tile_filling_is_the_same_filter(rates):
+    """_host.resample_fill_phase_tiles: the polyphase table rewritten for (m orig : m new) gives the same outputs in the same
+    order (float64 evaluation of both tables on a random waveform: equal to rounding, the extra taps are zeros); pairs with few
+    phases get m > 1 and phase tiles filled to 10 / 16 or better (48 k -> 16 k: m = 10 keeps the band inside the narrowest kernel,
+    which beats 16 phases on the next wider one), pairs that fill their tiles already keep m = 1."""
+    import math
+    from audio_amd import _host
+    o, n = rates
+    g = math.gcd(o, n)
+    kern, width = _host.sinc_resample_kernel(o, n, g)
+    orig, new = o // g, n // g
+    k = kern.reshape(new, -1).numpy().astype(np.float64)
+    kp, m = _host.resample_fill_phase_tiles(k, orig, new, width)
+    assert kp.shape == (m * new, 2 * width + m * orig)
+    if new % 16 == 0 or new >= 147:
+        assert m == 1 and kp is k
+    else:
+        assert m > 1 and (m * new) / (16 * ((m * new + 15) // 16)) >= 0.6
+
+    def polyphase(table, orig_, new_, x, out_len):
+        taps = table.shape[1]
+        nq = (out_len + new_ - 1) // new_
+        xp = np.concatenate([np.zeros(width), x, np.zeros(nq * orig_ + taps)])
+        out = np.empty(nq * new_)
+        for q in range(nq):
+            out[q * new_:(q + 1) * new_] = table @ xp[q * orig_:q * orig_ + taps]
+        return out[:out_len]
+
+    x = np.random.default_rng(o + n).standard_normal(1000)
+    out_len = -(-new * x.size // orig)
+    a, b = polyphase(k, orig, new, x, out_len), polyphase(kp, m * orig, m * new, x, out_len)
+    assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()      # same products; BLAS sums the longer rows in another order
