@@ -1120,27 +1120,18 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
       g.tap_lo[t] = bands->tap_lo[pt0 + t];
       if (g.tap_lo[t] > max_lo) max_lo = g.tap_lo[t];
     }
-    // q-groups: fill the workgroup with compute waves, bounded by the LDS double buffer and the row
     const bool f16 = (policy() & AAMD_POLICY_RESAMPLE_FP32) == 0;
-    // ... and (f16 kernel) by what its two loader waves hold in registers: a longer chunk would take the staged path
-    const int64_t max_floats = f16 ? 4ll * 64 * rsm::kLoaderWaves * rsm::loader_pieces_per_lane(ks) : (1ll << 40);
-    int qg = max_cw / g.n_pt;
-    while (qg > 1 && ((int64_t)rsm::kQPerGroup * (qg - 1) >= nq ||
-                      2 * (size_t)rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) * sizeof(float) + 48 > lds_cap ||
-                      rsm::buf_floats_needed(rsm::kQPerGroup * qg, orig, taps, max_lo, ks) > max_floats))
-      --qg;
-    g.qg = qg;
-    const int qc = rsm::kQPerGroup * qg;
-    g.buf_floats = rsm::buf_floats_needed(qc, orig, taps, max_lo, ks);
-    const size_t lds = 2 * (size_t)g.buf_floats * sizeof(float) + (f16 ? 48 : 0);       // + the chunk-maximum slots and arrival counters
-    if (lds > lds_cap)   // a single q-group does not fit (huge orig): scalar kernel
+    if (!rsm::plan_chunk(g, ks, f16, nq, max_lo, lds_cap))   // a single q-group does not fit (huge orig): scalar kernel
       return aamd_resample_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, stream);
+    const int qg = g.qg;
+    const int qc = rsm::chunk_q(g);
+    const size_t lds = 2 * (size_t)g.buf_floats * sizeof(float) + (f16 ? 48 : 0);       // + the chunk-maximum slots and arrival counters
     g.chunks_per_row = (int)((nq + qc - 1) / qc);
     g.n_chunks = rows * g.chunks_per_row;
     AAMD_CHECK_ARG(g.n_chunks < (1ll << 31), "too many chunks for one launch");
     // persistent workgroups: as many per CU as the 16 wave slots (128 registers) and the LDS hold -- a one-tile rate pair
     // has only a handful of compute waves per workgroup
-    const int wg_waves = g.n_pt * qg + rsm::kLoaderWaves;
+    const int wg_waves = g.n_pt * qg + g.n_loaders;
     int per_cu = ks >= 80 ? 1 : 16 / wg_waves;
     if (per_cu > (int)(lds_cap / lds)) per_cu = (int)(lds_cap / lds);
     if (per_cu < 1) per_cu = 1;
@@ -1148,7 +1139,7 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
     if (blocks > g.n_chunks) blocks = g.n_chunks;
     g.chunks_per_block = (int)((g.n_chunks + blocks - 1) / blocks);
     blocks = (g.n_chunks + g.chunks_per_block - 1) / g.chunks_per_block;
-    const int threads = 64 * (g.n_pt * qg + rsm::kLoaderWaves);
+    const int threads = 64 * wg_waves;
 #define AAMD_RSM(KS)                                                                                  \
   do {                                                                                                \
     auto kern = !f16 ? rsm::resample_mfma_kernel<KS>                                                  \

@@ -37,6 +37,8 @@ struct Geom {
   int orig, new_, width, taps;
   int pt0, n_pt;             // phase tiles [pt0, pt0 + n_pt) are produced by this launch
   int qg;                    // q-groups per workgroup; compute waves = n_pt * qg
+  int rounds;                // q-groups a compute wave works through per chunk (f16 kernel; 1 for the fp32 kernel)
+  int n_loaders;             // loader waves (f16 kernel: 2 or 4; the fp32 kernel has kLoaderWaves)
   int chunks_per_row;
   int64_t n_chunks;
   int chunks_per_block;
@@ -60,13 +62,39 @@ AAMD_HD int max_compute_waves(int ks) { return ks >= 80 ? 10 : 14; }
 // sizes the chunk to at most 128 of these); the 16-wave instantiations (KS < 80) have 128 registers per thread
 AAMD_HD constexpr int loader_pieces_per_lane(int ks) { return ks >= 80 ? 30 : 20; }
 
-AAMD_HD int chunk_q(const Geom& g) { return kQPerGroup * g.qg; }
+AAMD_HD int chunk_q(const Geom& g) { return kQPerGroup * g.qg * g.rounds; }
 
 // floats one chunk buffer must hold: every index a compute wave can read, + 3 for the 16-B phase
 AAMD_HD int buf_floats_needed(int qc, int orig, int taps, int max_tap_lo, int ks) {
   int reach = max_tap_lo + 4 * ks;
   if (reach < taps) reach = taps;
   return (((qc - 1) * orig + reach + 3) + 3) & ~3;
+}
+
+// Chunk geometry of one launch over g.n_pt phase tiles: q-groups (compute waves = n_pt * qg fill the workgroup, bounded by the
+// row), and for the f16 kernel the loader waves and the rounds -- a chunk is as long as the LDS double buffer and the
+// registers of the loader waves (64 x loader_pieces_per_lane pieces each: the whole chunk is in flight) allow, because a
+// chunk period costs ~4 us of fetch / stage / barrier whatever its length: the 10-tile 160 : 147 pair (48 k -> 44.1 k) with
+// 32 q per chunk spent 5.6 us per chunk on 12 MFMAs per wave.  Four loader waves when the 16 wave slots have room.
+// Returns false when not even one q-group fits the LDS (huge orig: scalar kernel).
+AAMD_HD bool plan_chunk(Geom& g, int ks, bool f16, int64_t nq, int max_lo, size_t lds_cap) {
+  const int max_cw = max_compute_waves(ks);
+  int qg = max_cw / g.n_pt;
+  while (qg > 1 && (int64_t)kQPerGroup * (qg - 1) >= nq) --qg;
+  g.rounds = 1;
+  g.n_loaders = kLoaderWaves;
+  if (f16 && ks < 80 && g.n_pt * qg + 4 <= 16) g.n_loaders = 4;
+  auto fits = [&](int q_groups) {
+    const int64_t fl = buf_floats_needed(kQPerGroup * q_groups, g.orig, g.taps, max_lo, ks);
+    if (2 * (size_t)fl * sizeof(float) + 48 > lds_cap) return false;
+    return !f16 || fl <= 4ll * 64 * g.n_loaders * loader_pieces_per_lane(ks);
+  };
+  while (qg > 1 && !fits(qg)) --qg;
+  if (f16)
+    while (g.rounds < 8 && (int64_t)kQPerGroup * qg * g.rounds < nq && fits(qg * (g.rounds + 1))) ++g.rounds;
+  g.qg = qg;
+  g.buf_floats = buf_floats_needed(chunk_q(g), g.orig, g.taps, max_lo, ks);
+  return 2 * (size_t)g.buf_floats * sizeof(float) + (f16 ? 48 : 0) <= lds_cap;
 }
 
 // sample index of LDS float 0 of chunk (qc0): 16-B phase aligned with global memory when vec_in
@@ -108,6 +136,8 @@ AAMD_HD void store_c(const Geom& g, float* out_row, int64_t qc0, int qt, int pt,
     *reinterpret_cast<F4*>(out_row + oi) = F4{c0, c1, c2, c3};
     return;
   }
+  // (a 4-byte-aligned dwordx4 store for odd `new` -- q new + p0 is not 16-byte aligned then -- aborts the process on this
+  // stack with a memory fault: measured in round 2; the four guarded dword stores stay)
   const float c[4] = {c0, c1, c2, c3};
   for (int i = 0; i < 4; ++i)
     if (p0 + i < g.new_ && oi + i < g.out_len) out_row[oi + i] = c[i];
@@ -325,6 +355,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ncw = g.n_pt * g.qg;
+  const int nld = g.n_loaders;
   const bool loader = wave >= ncw;
   const int pt_l = loader ? 0 : wave % g.n_pt;
   const int qgi = loader ? 0 : wave / g.n_pt;
@@ -362,7 +393,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   unsigned* grab = cnt + 3;                            // [3]: batches handed out
   constexpr int kGrab = 3;
   auto convert = [&](int k) {
-    const unsigned want = (unsigned)kLoaderWaves * (unsigned)(k / 3 + 1);
+    const unsigned want = (unsigned)nld * (unsigned)(k / 3 + 1);
     while (__atomic_load_n(&cnt[k % 3], __ATOMIC_RELAXED) < want) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (!loader) { AAMD_RSM_STAMP(k - 1, 3) }
@@ -402,7 +433,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       const int64_t qc0 = (cid - row * g.chunks_per_row) * qc;
       wrow = wav + row * g.row_stride;
       a0 = chunk_a0(g, qc0);
-      interior = g.vec_in && a0 >= 0 && a0 + g.buf_floats <= g.length && pieces <= 64 * kLoaderWaves * U && !(lab & 8);
+      interior = g.vec_in && a0 >= 0 && a0 + g.buf_floats <= g.length && pieces <= 64 * nld * U && !(lab & 8);
     };
     auto absmax = [](unsigned m, const F4& t) {
       const unsigned a = __float_as_uint(t.x) & 0x7fffffffu, bb = __float_as_uint(t.y) & 0x7fffffffu;
@@ -430,7 +461,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         int lt_ = lt;                                                                                              \
         asm volatile("" : "+v"(lt_));   /* offsets recomputed here: hoisted out of the chunk loop they get spilled */ \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                            \
-          const int j = lt_ + 64 * kLoaderWaves * u;                                                               \
+          const int j = lt_ + 64 * nld * u;                                                               \
           v[u] = base4[(unsigned)(j < pieces ? j : pieces - 1)];                                                   \
         }                                                                                                          \
       }                                                                                                            \
@@ -446,12 +477,12 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         asm volatile("" : "+v"(lt_));   /* as in FETCH: nothing of this hoisted out of the chunk loop */            \
         F4* dst_ = reinterpret_cast<F4*>(buf_);                                                                    \
         _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                            \
-          const int j = lt_ + 64 * kLoaderWaves * u;                                                               \
+          const int j = lt_ + 64 * nld * u;                                                               \
           dst_[j < pieces ? j : pieces - 1] = v[u];                                                                \
           m_ = absmax(m_, v[u]);                                                                                   \
         }                                                                                                          \
       } else if (!(lab & 8)) {   /* edge chunks, very long chunks */                                               \
-        _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * kLoaderWaves) {                                 \
+        _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * nld) {                                 \
           const F4 t = load_piece(g, wrow, a0, j);                                                                 \
           *reinterpret_cast<F4*>(buf_ + 4 * j) = t;                                                                \
           m_ = absmax(m_, t);                                                                                      \
@@ -499,7 +530,10 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     const int64_t row = (int64_t)((uint32_t)cid / (uint32_t)g.chunks_per_row);   // n_chunks < 2^31 (checked by the launcher)
     const int64_t qc0 = (cid - row * g.chunks_per_row) * qc;
     const int shift = (int)((qc0 * g.orig - g.width) - chunk_a0(g, qc0));
-    const int qt0 = 2 * qgi, qt1 = 2 * qgi + 1;
+    float* out_row = out + row * g.out_len;
+#pragma unroll 1
+    for (int r = 0; r < g.rounds; ++r) {                 // (indentation of the body kept: one more level would not fit the lines)
+    const int qt0 = 2 * (qgi + g.qg * r), qt1 = qt0 + 1;
     const uint32_t* b0 = buf + b_base(g, qt0, tap_lo, KS, shift, lane);
     const uint32_t* b1 = buf + b_base(g, qt1, tap_lo, KS, shift, lane);
     f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -544,12 +578,12 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     }
 #undef AAMD_RSM_READ
     asm volatile("" : "+v"(acc0), "+v"(acc1));
-    AAMD_RSM_STAMP(k, 1)
-    float* out_row = out + row * g.out_len;
     if (!(lab & 32) || acc0[0] == 12345.0f) {
       store_c(g, out_row, qc0, qt0, pt, lane, acc0[0] * inv, acc0[1] * inv, acc0[2] * inv, acc0[3] * inv);
       store_c(g, out_row, qc0, qt1, pt, lane, acc1[0] * inv, acc1[1] * inv, acc1[2] * inv, acc1[3] * inv);
     }
+    }
+    AAMD_RSM_STAMP(k, 1)                                 // (the MFMA loops and the stores of all rounds)
     AAMD_RSM_STAMP(k, 2)
     if (cid + 1 < end) convert(k + 1);                   // (stamp 3 inside: both loaders have arrived)
     AAMD_RSM_STAMP(k, 4)

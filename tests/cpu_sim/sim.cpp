@@ -777,12 +777,9 @@ int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t r
     g.n_pt = n_tiles - pt0 < max_cw ? n_tiles - pt0 : max_cw;
     int max_lo = 0;
     for (int t = 0; t < g.n_pt; ++t) { g.tap_lo[t] = tap_lo[pt0 + t]; if (g.tap_lo[t] > max_lo) max_lo = g.tap_lo[t]; }
-    int qg = max_cw / g.n_pt;
-    while (qg > 1 && ((int64_t)kQPerGroup * (qg - 1) >= nq ||
-                      2 * (size_t)buf_floats_needed(kQPerGroup * qg, orig, g.taps, max_lo, ks) * 4 > 160 * 1024)) --qg;
-    g.qg = qg;
-    const int qc = kQPerGroup * qg;
-    g.buf_floats = buf_floats_needed(qc, orig, g.taps, max_lo, ks);
+    if (!plan_chunk(g, ks, f16 != 0, nq, max_lo, 160 * 1024)) return -3;   // the launcher's own chunk geometry
+    const int qg = g.qg;
+    const int qc = chunk_q(g);
     g.chunks_per_row = (int)((nq + qc - 1) / qc);
     g.n_chunks = rows * g.chunks_per_row;
     std::vector<float> buf(g.buf_floats);
@@ -805,7 +802,7 @@ int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t r
         pk.resize(buf.size());
         for (size_t i = 0; i < buf.size(); ++i) pk[i] = pack_hl(buf[i] * sc);
       }
-      for (int w = 0; w < g.n_pt * qg; ++w) {
+      for (int w = 0; w < g.n_pt * qg * g.rounds; ++w) {      // (rounds: the same wave, its next q-group)
         const int pt_l = w % g.n_pt, qgi = w / g.n_pt, pt = pt0 + pt_l, lo = g.tap_lo[pt_l];
         for (int half = 0; half < 2; ++half) {
           const int qt = 2 * qgi + half;
