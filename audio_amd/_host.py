@@ -572,3 +572,120 @@ def kaldi_get_mel_banks(num_bins: int, window_length_padded: int, sample_freq: f
         bins[rising] = up[rising]
         bins[falling] = down[falling]
     return bins, center_freqs
+
+
+# --------------------------------------------------------------------------- #
+# lfilter: orders 3 .. 8 as second-order sections                             #
+# --------------------------------------------------------------------------- #
+
+
+def _real_factors(roots: np.ndarray, tol: float = 1e-9):
+    """Roots of a real polynomial -> real factor polynomials in z^-1: [1, -2 Re r, |r|^2] per conjugate pair and
+    [1, -r] per real root (lower delays first).  None when the roots do not pair up."""
+    roots = list(roots)
+    quad, lin = [], []
+    while roots:
+        r = roots.pop()
+        if abs(r.imag) <= tol * max(1.0, abs(r)):
+            lin.append((np.array([1.0, -r.real]), abs(r.real)))
+            continue
+        j = int(np.argmin([abs(q - np.conj(r)) for q in roots])) if roots else -1
+        if j < 0 or abs(roots[j] - np.conj(r)) > 1e-6 * max(1.0, abs(r)):
+            return None
+        roots.pop(j)
+        quad.append((np.array([1.0, -2.0 * r.real, abs(r) ** 2]), abs(r)))
+    return quad, lin
+
+
+def _pack_quadratics(quad, lin):
+    """Linear factors two at a time into quadratics (largest radii together), every polynomial padded to 3 coefficients."""
+    lin = sorted(lin, key=lambda t: -t[1])
+    out = list(quad)
+    for i in range(0, len(lin) - 1, 2):
+        out.append((np.convolve(lin[i][0], lin[i + 1][0]), max(lin[i][1], lin[i + 1][1])))
+    if len(lin) % 2:
+        out.append((np.array([lin[-1][0][0], lin[-1][0][1], 0.0]), lin[-1][1]))
+    return out
+
+
+def _direct_form(b, a, x):
+    """float64 difference equation (host check only)."""
+    try:
+        from scipy.signal import lfilter as _sl
+        return _sl(b, a, x)
+    except Exception:  # pragma: no cover - scipy is part of the image
+        y = np.zeros_like(x)
+        for n in range(x.size):
+            acc = sum(b[k] * x[n - k] for k in range(len(b)) if n >= k)
+            acc -= sum(a[k] * y[n - k] for k in range(1, len(a)) if n >= k)
+            y[n] = acc / a[0]
+        return y
+
+
+def lfilter_sos(a: np.ndarray, b: np.ndarray, max_pole_radius: float = 0.99, rel_tol: float = 2e-6):
+    """(rows, n_order) float32 coefficient rows of filters of order 3 .. 8 -> second-order sections
+    (a_s, b_s) float32 (n_sections, rows, 3) for the cascade kernels (clamp mode 2), or None.
+
+    Poles and zeros from the float64 companion matrices, conjugates kept together, every pole section paired with the
+    nearest remaining zero section, sections ordered by pole radius (the sharpest resonance last, as scipy's zpk2sos
+    does).  The factorisation is only used when it REPRODUCES the filter: the float64 impulse response of the cascade of
+    the float32-rounded sections must equal that of the direct form to rel_tol (in l1 over 8192 samples), and no pole may
+    lie outside max_pole_radius (beyond it float32 section coefficients move the resonance noticeably).  Anything else --
+    unstable, near-unstable, clustered roots -- keeps the general-order kernel."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    rows, n_order = a.shape
+    if not (4 <= n_order <= 9):
+        return None
+    n_sec = n_order // 2            # ceil(order / 2), order = n_order - 1
+    a_s = np.zeros((n_sec, rows, 3))
+    b_s = np.zeros((n_sec, rows, 3))
+    imp = np.zeros(8192)
+    imp[0] = 1.0
+    for r in range(rows):
+        if a[r, 0] == 0.0 or not np.all(np.isfinite(a[r])) or not np.all(np.isfinite(b[r])):
+            return None
+        an, bn = a[r] / a[r, 0], b[r] / a[r, 0]
+        nz = np.nonzero(bn)[0]
+        if nz.size == 0:
+            return None
+        d = int(nz[0])                                   # leading zeros of b: a pure delay
+        bt = np.trim_zeros(bn[d:], "b")
+        at = np.trim_zeros(an, "b")
+        poles = np.roots(at) if at.size > 1 else np.array([])
+        zeros = np.roots(bt) if bt.size > 1 else np.array([])
+        if poles.size and np.abs(poles).max() > max_pole_radius:
+            return None
+        pf, zf = _real_factors(poles), _real_factors(zeros)
+        if pf is None or zf is None:
+            return None
+        den = _pack_quadratics(*pf)
+        zq, zl = zf
+        zl = zl + [(np.array([0.0, 1.0]), 0.0)] * d      # z^-1 factors of the delay
+        num = _pack_quadratics(zq, zl)
+        if len(den) > n_sec or len(num) > n_sec:
+            return None
+        den += [(np.array([1.0, 0.0, 0.0]), 0.0)] * (n_sec - len(den))
+        num += [(np.array([1.0, 0.0, 0.0]), -1.0)] * (n_sec - len(num))
+        den.sort(key=lambda t: t[1])                     # sharpest resonance last
+        # nearest zero section for the sharpest poles first (root radius as the distance: conjugates share it)
+        order = sorted(range(n_sec), key=lambda i: -den[i][1])
+        left = list(range(n_sec))
+        pick = [None] * n_sec
+        for i in order:
+            j = min(left, key=lambda k: abs(num[k][1] - den[i][1]))
+            left.remove(j)
+            pick[i] = j
+        gain = bt[0]
+        for i in range(n_sec):
+            a_s[i, r] = den[i][0]
+            b_s[i, r] = num[pick[i]][0] * (gain if i == 0 else 1.0)
+        # the check: cascade of the float32-ROUNDED sections against the direct form, both in float64
+        y = imp
+        for i in range(n_sec):
+            y = _direct_form(b_s[i, r].astype(np.float32).astype(np.float64), a_s[i, r].astype(np.float32).astype(np.float64), y)
+        ref = _direct_form(bn, an, imp)
+        scale = np.abs(ref).sum()
+        if not np.isfinite(scale) or scale == 0.0 or np.abs(y - ref).sum() > rel_tol * scale:
+            return None
+    return a_s.astype(np.float32), b_s.astype(np.float32)

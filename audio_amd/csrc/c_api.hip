@@ -1187,6 +1187,7 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
   AAMD_CHECK_ARG(x && a && b && y, "null buffer");
   AAMD_CHECK_ARG(batch >= 0 && channels >= 1 && length >= 0, "bad sizes");
   AAMD_CHECK_ARG(n_order >= 1 && n_stages >= 1, "n_order and n_stages must be >= 1");
+  AAMD_CHECK_ARG(clamp >= 0 && clamp <= 2, "clamp must be 0, 1 (after every stage) or 2 (after the last stage only)");
   AAMD_CHECK_ARG(n_coeff_rows == 1 || n_coeff_rows == channels, "n_coeff_rows must be 1 or channels");
   const int64_t n_seq = batch * channels;
   if (n_seq == 0 || length == 0) return AAMD_OK;

@@ -247,7 +247,7 @@ lfilter_kernel(const float* __restrict__ x, const float* __restrict__ a,
           __syncthreads();
           src_is_a = !src_is_a;
         }
-        lf_correct_store<D>(tid, lds, th, src_is_a, clamp);
+        lf_correct_store<D>(tid, lds, th, src_is_a, clamp == 1 || (clamp == 2 && st == n_stages - 1));   // 2: last stage only
         if (tid == 0) lf_save_output_carry<D>(lds, src_is_a);
         __syncthreads();
         for (int i = tid; i < 2 * D; i += kLfThreads)   // persist the carries of this stage

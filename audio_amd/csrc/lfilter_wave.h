@@ -200,6 +200,9 @@ AAMD_HD void correct_clamp(const float* tab, float t0, float t1, int clamp, floa
   }
 }
 AAMD_HD float clamp1(float v, int clamp) { return clamp ? fmin(fmax(v, -1.0f), 1.0f) : v; }
+// clamp argument of the launch: 0 never, 1 after every stage (n sequential lfilter calls), 2 after the LAST stage only (one
+// higher-order filter factored into second-order sections)
+AAMD_HD int stage_clamp(int clamp, int st, int n_stages) { return clamp == 1 || (clamp == 2 && st == n_stages - 1); }
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -410,7 +413,7 @@ lfilter_wave_kernel(const float* __restrict__ x, const float* __restrict__ a, co
       // 2. stages
       float hin0 = xh0, hin1 = xh1;                             // history of lane 0: inputs before this wave
       for (int st = 0; st < n_stages; ++st, sbuf ^= 1)
-        stage_step<LAB>(tabs + st * kTabFloats, xch, W, n_stages, parity, st, sbuf, wave, lane, clamp, v, hin0, hin1);
+        stage_step<LAB>(tabs + st * kTabFloats, xch, W, n_stages, parity, st, sbuf, wave, lane, stage_clamp(clamp, st, n_stages), v, hin0, hin1);
       // 3. the next block's chunk -> registers (its copy has had all stages to land), then this block's chunk ->
       //    tile -> row-major pieces -> global
       float vn[kCh], nh0 = 0.0f, nh1 = 0.0f;
@@ -593,7 +596,7 @@ lfilter_wave_pipe_kernel(const float* __restrict__ x, const float* __restrict__ 
       for (int st = 0; st < n_stages; ++st, sbuf ^= 1) {
         if (next_whole && st < copy_stages) copy_pieces(nxt, 8 * st / copy_stages, 8 * (st + 1) / copy_stages);
         if (prev_whole) store_pieces(prv, 8 * st / n_stages, 8 * (st + 1) / n_stages);
-        stage_step<LAB>(tabs + st * kTabFloats, xch, W, n_stages, parity, st, sbuf, wave, lane, clamp, v, hin0, hin1);
+        stage_step<LAB>(tabs + st * kTabFloats, xch, W, n_stages, parity, st, sbuf, wave, lane, stage_clamp(clamp, st, n_stages), v, hin0, hin1);
       }
       // (the block before the last can only be ragged if this one is the last: nothing left to do for it)
       // this block's output -> OUT tile (its former content has been read: the loads of the stores are waited for at issue)
@@ -773,7 +776,7 @@ lfilter_wave_mover_kernel(const float* __restrict__ x, const float* __restrict__
       const int64_t nw = n0 + (int64_t)wave * kWaveBlock;
       nw_last = nw;
       for (int st = 0; st < n_stages; ++st, sbuf ^= 1)
-        stage_step<LAB>(tabs + st * kTabFloats, xch, W, n_stages, parity, st, sbuf, wave, lane, clamp, v, hin0, hin1);
+        stage_step<LAB>(tabs + st * kTabFloats, xch, W, n_stages, parity, st, sbuf, wave, lane, stage_clamp(clamp, st, n_stages), v, hin0, hin1);
       // behind barrier (i, n - 1): the movers have read block i - 1 out of the OUT tile and block i + 1 has landed in the IN tile
 #pragma unroll
       for (int q = 0; q < 8; ++q)

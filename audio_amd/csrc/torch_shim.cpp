@@ -232,7 +232,7 @@ Tensor resample(Tensor wav, Tensor kernel, int64_t orig, int64_t new_, int64_t w
 }
 
 // ---- aamd::lfilter  (functional/filtering.py:1027-1099; cascades fused) --------------------------------------------
-Tensor lfilter(Tensor x, Tensor a, Tensor b, int64_t n_stages, bool clamp) {
+Tensor lfilter(Tensor x, Tensor a, Tensor b, int64_t n_stages, int64_t clamp) {   // clamp: 0 / 1 every stage / 2 last stage
   want_f32(x, "waveform", 3);
   want_f32(a, "a_coeffs", 3);
   want_f32(b, "b_coeffs", 3);
@@ -241,11 +241,12 @@ Tensor lfilter(Tensor x, Tensor a, Tensor b, int64_t n_stages, bool clamp) {
   STD_TORCH_CHECK(a.size(0) == n_stages && b.size(0) == n_stages && a.size(1) == b.size(1) && a.size(2) == b.size(2),
                   "audio_amd: a / b must be (n_stages, rows, n_order)");
   STD_TORCH_CHECK(a.size(1) == 1 || a.size(1) == x.size(1), "audio_amd: coefficient rows must be 1 or channels");
+  STD_TORCH_CHECK(clamp >= 0 && clamp <= 2, "audio_amd: clamp must be 0, 1 (after every stage) or 2 (after the last stage)");
   const torch::stable::accelerator::DeviceGuard guard(x.get_device_index());
   Tensor y = torch::stable::empty_like(x);
   if (y.numel())
     check(aamd_lfilter_f32(fp(x), fp(a), fp(b), fpm(y), x.size(0), (int32_t)x.size(1), x.size(2), (int32_t)a.size(2),
-                           (int32_t)a.size(1), (int32_t)n_stages, clamp ? 1 : 0, current_stream(x)));
+                           (int32_t)a.size(1), (int32_t)n_stages, (int32_t)clamp, current_stream(x)));
   return y;
 }
 
@@ -340,7 +341,7 @@ STABLE_TORCH_LIBRARY(aamd, m) {
   m.def("mfcc_dct(Tensor mel, Tensor dct_mat, int log_mode, Tensor? group_max, int vec_per_group, float top_db) -> Tensor");
   m.def("resample(Tensor wav, Tensor kernel, int orig, int new, int width, int out_len, int[]? band_tap_lo, "
         "int tap_span) -> Tensor");
-  m.def("lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, int n_stages, bool clamp) -> Tensor");
+  m.def("lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, int n_stages, int clamp) -> Tensor");
   m.def("fftconvolve(Tensor x, Tensor y, Tensor? x_row_of, Tensor? y_row_of, int rows, int start, int out_len) -> Tensor");
 }
 

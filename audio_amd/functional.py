@@ -1198,7 +1198,7 @@ def _lfilter_launch(x3: Tensor, a: Tensor, b: Tensor, clamp: bool, n_stages: int
     ops = _ops()
     if ops is not None:
         return ops.lfilter(x3, a.reshape(n_stages, -1, a.shape[-1]), b.reshape(n_stages, -1, b.shape[-1]), n_stages,
-                           bool(clamp))
+                           int(clamp))
     y = torch.empty_like(x3)
     if y.numel():
         L = _lib.lib()
@@ -1257,6 +1257,35 @@ class _LFilterFunction(torch.autograd.Function):
         return dx, da, db, None
 
 
+_SOS_MIN_SAMPLES = 0            # every size: the sections are also the more ACCURATE form (the general-order scan carries the
+                                # direct form's float32 round-off: 2e-3 .. 8e-2 of the peak on 6th-order designs, tests)
+_SOS_BY_VALUE: dict = {}        # coefficient bytes -> sections (host arrays) or None: callers that rebuild their tensors per call
+
+
+def _lfilter_sections(a_key: Tensor, b_key: Tensor, a: Tensor, b: Tensor):
+    """Second-order sections (device tensors (n_sections, rows, 3)) of the order 3 .. 8 filter (a, b), or None when
+    `_host.lfilter_sos` does not vouch for the factorisation.  Cached per coefficient tensor (no host round trip on a hit)
+    and per coefficient values (one device-to-host copy, no root finding, for callers that rebuild the tensors)."""
+    def make():
+        ah, bh = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+        key = (ah.shape, ah.tobytes(), bh.tobytes())
+        with _CACHE_LOCK:
+            hit = key in _SOS_BY_VALUE
+            sec = _SOS_BY_VALUE.get(key)
+        if not hit:
+            sec = _host.lfilter_sos(ah, bh)
+            with _CACHE_LOCK:
+                if len(_SOS_BY_VALUE) > 256:
+                    _SOS_BY_VALUE.clear()
+                _SOS_BY_VALUE[key] = sec
+        if sec is None:
+            return (None,)
+        return (torch.from_numpy(sec[0]).to(a.device), torch.from_numpy(sec[1]).to(a.device))
+
+    got = _tensor_cached(a_key, ("lf_sos", id(b_key), b_key._version, b_key.data_ptr(), str(a.device)), make)
+    return None if got[0] is None else got
+
+
 def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = True, batching: bool = True) -> Tensor:
     r"""IIR filter by the difference equation (functional/filtering.py:1032-1099): FIR + recursion
     + clamp in one HIP kernel (chunked linear-recurrence scan, see csrc/lfilter.h)."""
@@ -1267,6 +1296,7 @@ def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = 
         )
     if a_coeffs.ndim > 2:
         raise ValueError(f"Expected coeffs to have greater than 1 dimension. Found: {a_coeffs.ndim}")
+    a_key, b_key = a_coeffs, b_coeffs            # the caller's tensor objects: cache slots for what is derived from them
     if a_coeffs.ndim > 1:
         if batching:
             if waveform.ndim <= 0:
@@ -1293,7 +1323,12 @@ def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = 
         # autograd sees the division, the recursion and its adjoint run in the HIP kernel
         y = _LFilterFunction.apply(x3, a / a[:, 0:1], b / a[:, 0:1], clamp)
     else:
-        y = _lfilter_launch(x3, a, b, clamp)
+        sos = _lfilter_sections(a_key, b_key, a, b) if (x3.dtype == torch.float32 and 4 <= a.shape[-1] <= 9
+                                                      and x3.numel() >= _SOS_MIN_SAMPLES) else None
+        if sos is not None:      # orders 3 .. 8 on the biquad-class kernels: second-order sections, clamped once at the end
+            y = _lfilter_launch(x3, sos[0], sos[1], 2 if clamp else 0, n_stages=sos[0].shape[0])
+        else:
+            y = _lfilter_launch(x3, a, b, clamp)
     return y.reshape(shape[:-1] + y.shape[-1:])
 
 

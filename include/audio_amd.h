@@ -354,7 +354,10 @@ int aamd_resample_sparse_f32(const float* wav, const float* taps_compact, const 
  * n_coeff_rows = 1 (shared) or channels (per channel), lower delays first, NOT yet normalised
  * by a0 (the kernel divides, like filtering.py:1028-1029).  clamp: 0/1 -> clamp(y,-1,1) after
  * the recursion.  n_stages > 1 applies a cascade: a, b are float[n_stages][n_coeff_rows][n_order]
- * and each stage's (clamped) output feeds the next -- equal to n_stages sequential F.lfilter calls. */
+ * and each stage's (clamped) output feeds the next -- equal to n_stages sequential F.lfilter calls.
+ * clamp = 2 clamps after the LAST stage only: one higher-order filter given as second-order sections
+ * (the host layer factors orders 3 .. 8 that way when the sections reproduce the filter, see
+ * audio_amd/_host.py lfilter_sos; the biquad-class kernels run ~6 x faster than the general-order scan). */
 int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, int64_t batch,
                      int32_t channels, int64_t length, int32_t n_order, int32_t n_coeff_rows,
                      int32_t n_stages, int32_t clamp, void* stream);

@@ -886,7 +886,7 @@ static int sim_lfilter_d(const float* x, const float* a, const float* b, float* 
           for (int tid = 0; tid < kLfThreads; ++tid) lf_scan_step<D>(tid, k, lds, th[tid], src_is_a);
           src_is_a = !src_is_a;
         }
-        for (int tid = 0; tid < kLfThreads; ++tid) lf_correct_store<D>(tid, lds, th[tid], src_is_a, clamp);
+        for (int tid = 0; tid < kLfThreads; ++tid) lf_correct_store<D>(tid, lds, th[tid], src_is_a, clamp == 1 || (clamp == 2 && st == n_stages - 1));
         lf_save_output_carry<D>(lds, src_is_a);
         for (int i = 0; i < 2 * D; ++i) stage_store[st * stage_floats + (L::cx - L::H) + i] = lds[L::cx + i];
       }
@@ -971,7 +971,7 @@ extern "C" int sim_lfilter_wave(const float* x, const float* a, const float* b, 
             mat_acc(tab + kTabPow + 4 * lane, e0[w], e1[w], s0[w * 64 + lane], s1[w * 64 + lane]);
           for (int lane = 0; lane < 64; ++lane) {
             const float tt0 = lane ? s0[w * 64 + lane - 1] : e0[w], tt1 = lane ? s1[w * 64 + lane - 1] : e1[w];
-            correct_clamp(tab, tt0, tt1, clamp, arr(z[w * 64 + lane]));
+            correct_clamp(tab, tt0, tt1, stage_clamp(clamp, st, n_stages), arr(z[w * 64 + lane]));
           }
         }
         for (int w = 0; w < W; ++w) {
@@ -979,8 +979,8 @@ extern "C" int sim_lfilter_wave(const float* x, const float* a, const float* b, 
             const int cout = xch_carry(W, n_stages, parity ^ 1, st);
             xch[cout] = s0[w * 64 + 63]; xch[cout + 1] = s1[w * 64 + 63];
           }
-          hin0[w] = clamp1(e0[w], clamp);
-          hin1[w] = clamp1(e1[w], clamp);
+          hin0[w] = clamp1(e0[w], stage_clamp(clamp, st, n_stages));
+          hin1[w] = clamp1(e1[w], stage_clamp(clamp, st, n_stages));
           for (int lane = 0; lane < 64; ++lane) v[w * 64 + lane] = z[w * 64 + lane];
         }
       }

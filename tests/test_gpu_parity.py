@@ -437,6 +437,56 @@ def test_lfilter_wave_kernel_equals_workgroup_kernel_and_oracle():
         assert peak_rel_err(fast.cpu().numpy(), exp) <= 1e-4
 
 
+@pytest.mark.parametrize("design", ["butter4", "butter6_high", "band4", "cheby6", "butter3", "per_channel", "delay"])
+def test_lfilter_orders_3_to_8_as_second_order_sections(design):
+    """F.lfilter of order 3 .. 8 on big batches runs as second-order sections on the biquad-class kernels (clamp after the
+    last section only): against the sequential float64 oracle of the DIRECT form and against the general-order kernel, with
+    an input loud enough that the clamp matters, clamp on and off, shared and per-channel coefficients."""
+    from scipy import signal
+    import audio_amd.functional as F
+    from audio_amd import _lib
+    from oracle import dsp_oracle as O
+    C = 4
+    if design == "per_channel":
+        ba = [signal.butter(4, w) for w in (0.1, 0.2, 0.3, 0.45)]
+        b = torch.tensor(np.stack([x[0] for x in ba]), dtype=torch.float32)
+        a = torch.tensor(np.stack([x[1] for x in ba]), dtype=torch.float32)
+    else:
+        bb, aa = {"butter4": signal.butter(4, 0.2), "butter6_high": signal.butter(6, 0.3, "high"),
+                  "band4": signal.butter(4, [0.1, 0.3], "band"), "cheby6": signal.cheby1(6, 1, 0.2),
+                  "butter3": signal.butter(3, 0.25),
+                  "delay": (np.array([0.0, 0.0, 0.3, 0.1]), np.array([1.0, -0.5, 0.2, -0.1]))}[design]
+        b, a = torch.tensor(bb, dtype=torch.float32), torch.tensor(aa, dtype=torch.float32)
+    g = torch.Generator().manual_seed(len(design))
+    x = (torch.rand(5, C, 220000, generator=g) - 0.5) * 6.0
+    xd, ad, bd = x.cuda(), a.cuda(), b.cuda()
+    assert F._lfilter_sections(ad, bd, ad.reshape(-1, a.shape[-1]), bd.reshape(-1, b.shape[-1])) is not None
+    for clamp in (True, False):
+        got = F.lfilter(xd, ad, bd, clamp=clamp)
+        with _lib.kernel_policy(_lib.POLICY_FORCE_GENERIC):
+            gen = F._lfilter_launch(xd[:1].contiguous(), ad.reshape(1, -1, a.shape[-1]), bd.reshape(1, -1, b.shape[-1]), clamp)
+        # float64 direct form: scipy over the whole length, the sequential oracle on a prefix (causal: the prefix of the
+        # output depends on the prefix of the input only)
+        a64, b64 = np.atleast_2d(a.numpy().astype(np.float64)), np.atleast_2d(b.numpy().astype(np.float64))
+        exp = np.stack([np.stack([signal.lfilter(b64[c % len(b64)], a64[c % len(a64)], x[n, c].numpy().astype(np.float64))
+                                  for c in range(C)]) for n in range(2)])
+        loud = np.abs(exp).max() > 1.05
+        if clamp:
+            exp = np.clip(exp, -1.0, 1.0)
+        pre = O.lfilter(x[:1, :, :3000].numpy().astype(np.float64), a.numpy().astype(np.float64),
+                        b.numpy().astype(np.float64), clamp)
+        assert np.abs(pre - exp[:1, :, :3000]).max() <= 1e-9
+        # (of the peak AFTER the clamp, i.e. of 1.0, while the recursion runs at the input's +-3: hence not 1e-5)
+        assert peak_rel_err(got[:2].cpu().numpy(), exp) <= (3e-5 if a.shape[-1] <= 5 else 5e-5)
+        # the general-order kernel carries the direct form's float32 round-off through its scan: 2e-3 (Butterworth 6) to 8e-2
+        # (Chebyshev 6) of the peak measured here -- the other reason the sections are preferred whenever they are vouched for
+        if a.shape[-1] <= 5:
+            assert peak_rel_err(gen.cpu().numpy(), exp[:1]) <= 1e-4
+        if clamp:
+            assert float(got.abs().max()) <= 1.0
+            assert not loud or float((got[:2].abs() == 1.0).float().mean()) > 0.0        # the clamp was hit where it must be
+
+
 def test_lfilter_cascade_headline_shape_properties():
     """BASELINE config 5a at 1/8 of the batch (32 x 8 ch x 10 s @48 kHz): the fused 4-biquad cascade
     equals four sequential F.lfilter calls (each clamped), and filtering is causal + time invariant."""

@@ -296,3 +296,36 @@ def test_resample_phase_tile_filling_is_the_same_filter(rates):
     out_len = -(-new * x.size // orig)
     a, b = polyphase(k, orig, new, x, out_len), polyphase(kp, m * orig, m * new, x, out_len)
     assert np.abs(a - b).max() <= 1e-13 * np.abs(a).max()      # same products; BLAS sums the longer rows in another order
+
+
+def test_lfilter_second_order_sections_reproduce_the_filter():
+    """_host.lfilter_sos: Butterworth / Chebyshev / elliptic designs of order 3 .. 8 (scipy.signal) factor into sections whose
+    float32-rounded cascade has the direct form's impulse response (float64, l1 over 8192 samples, 2e-6); a numerator that starts
+    with zeros becomes delay factors; near-unstable or ill-conditioned direct forms (order-8 Butterworth at 0.05: clustered
+    roots) and orders outside 3 .. 8 are refused -- the general-order kernel keeps those."""
+    from scipy import signal
+    from audio_amd import _host
+    designs = [signal.butter(4, 0.2), signal.butter(6, 0.3, "high"), signal.butter(4, [0.1, 0.3], "band"), signal.butter(3, 0.25),
+               signal.butter(5, 0.4), signal.cheby1(6, 1, 0.2), signal.ellip(4, 1, 60, 0.3),
+               (np.array([0.0, 0.0, 0.3, 0.1]), np.array([1.0, -0.5, 0.2, -0.1]))]
+    imp = np.zeros(8192)
+    imp[0] = 1.0
+    for b, a in designs:
+        sec = _host.lfilter_sos(np.asarray(a, np.float32)[None], np.asarray(b, np.float32)[None])
+        assert sec is not None, (a, b)
+        a_s, b_s = sec
+        assert a_s.shape == b_s.shape == ((len(a) - 1 + 1) // 2, 1, 3) and a_s.dtype == np.float32
+        y = imp
+        for i in range(a_s.shape[0]):
+            y = signal.lfilter(b_s[i, 0].astype(np.float64), a_s[i, 0].astype(np.float64), y)
+        an, bn = np.asarray(a, np.float32).astype(np.float64), np.asarray(b, np.float32).astype(np.float64)
+        ref = signal.lfilter(bn / an[0], an / an[0], imp)
+        assert np.abs(y - ref).sum() <= 2e-6 * np.abs(ref).sum()
+    b, a = signal.butter(8, 0.05)
+    assert _host.lfilter_sos(a.astype(np.float32)[None], b.astype(np.float32)[None]) is None            # clustered roots
+    assert _host.lfilter_sos(np.array([[1.0, -1.999, 0.9995, 0.0]], np.float32), np.array([[1.0, 0, 0, 0]], np.float32)) is None
+    assert _host.lfilter_sos(np.array([[1.0, -0.5, 0.1]], np.float32), np.array([[1.0, 0.2, 0.1]], np.float32)) is None  # order 2
+    rows = np.stack([np.asarray(signal.butter(4, w)[1], np.float32) for w in (0.1, 0.2, 0.3)])
+    rb = np.stack([np.asarray(signal.butter(4, w)[0], np.float32) for w in (0.1, 0.2, 0.3)])
+    sec = _host.lfilter_sos(rows, rb)
+    assert sec is not None and sec[0].shape == (2, 3, 3)                                                # per-channel rows

@@ -22,7 +22,7 @@ SCHEMAS = {
                 "float top_db) -> Tensor",
     "resample": "aamd::resample(Tensor wav, Tensor kernel, int orig, int new, int width, int out_len, int[]? band_tap_lo, "
                 "int tap_span) -> Tensor",
-    "lfilter": "aamd::lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, int n_stages, bool clamp) -> Tensor",
+    "lfilter": "aamd::lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, int n_stages, int clamp) -> Tensor",
     "fftconvolve": "aamd::fftconvolve(Tensor x, Tensor y, Tensor? x_row_of, Tensor? y_row_of, int rows, int start, "
                    "int out_len) -> Tensor",
 }
