@@ -1,1 +1,1 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_torch_shim.py tests/test_ops_registration.py tests/test_gpu_autograd_f64.py -m gpu -q -k "lfilter or shim or ops or biquad or filter" 2>&1 | grep -E "^E  *(Assert|assert)|passed|failed" | head
+timeout 600 python tools/bench_stft_shapes.py 2>&1 | grep "^{"
