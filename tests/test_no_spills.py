@@ -1,0 +1,76 @@
+"""The built gfx950 code object must not spill in the throughput kernels.
+
+Round 2 found two regressions by reading the ISA by hand: the narrow instantiations of the f16 resampler held 30 x 16 B per lane in
+a 128-register budget (536 B of scratch per thread; default-quality Resample pairs ran 4-5 x slower) and the overlap-save kernels
+spilled hoisted LDS addresses (every reload an s_waitcnt vmcnt(0) that waits for the prefetched inputs).  Neither changes a result,
+so no parity test sees it; this test reads the kernel descriptors of libaudio_amd.so (llvm-objdump --offloading + llvm-readelf
+--notes) and fails when a kernel outside the allow list uses scratch.  No GPU needed."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+# kernels that are allowed scratch, with the most they may use (bytes per thread): general-order IIR scans of order >= 8 (rare
+# shapes; orders 3 .. 8 run as second-order sections), the 2048-point Kaldi kernel, the one-tile biquad kernel's table builder
+ALLOW = [(r"aamd14lfilter_kernelILi(8|12|16)E", 4200), (r"aamd2p217kaldi_pow2_kernelILi32E", 128),
+         (r"aamd3lfw19lfilter_wave_kernel", 96), (r"aamd3lfw24lfilter_wave_pipe_kernel", 32),
+         (r"aamd3lfw25lfilter_wave_mover_kernel", 32), (r"aamd4m40015istft400_kernel", 16),
+         # lab instantiations of the f16 resampler (tools only: AAMD_RSM_LAB), never the product one (<KS, 0>)
+         (r"aamd3rsm19resample_f16_kernelILi\d+ELi[12]E", 64)]
+
+
+def _kernels():
+    from audio_amd import _build
+    so = _build.OUT
+    if not os.path.exists(so):
+        pytest.skip("libaudio_amd.so is not built")
+    if not (os.path.exists(os.path.join(LLVM, "llvm-objdump")) and os.path.exists(os.path.join(LLVM, "llvm-readelf"))):
+        pytest.skip("llvm-objdump / llvm-readelf not in this image")
+    with tempfile.TemporaryDirectory() as d:
+        local = os.path.join(d, "lib.so")
+        shutil.copy(so, local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, capture_output=True, cwd=d)
+        objs = [f for f in os.listdir(d) if "gfx950" in f]
+        assert len(objs) == 1, os.listdir(d)
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(d, objs[0])], check=True,
+                               capture_output=True, text=True).stdout
+    out, name = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s*\.name:\s+(\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+            continue
+        m = re.match(r"\s*\.(private_segment_fixed_size|vgpr_spill_count|sgpr_spill_count|vgpr_count):\s+(\d+)", line)
+        if m and name:
+            out[name][m.group(1)] = int(m.group(2))
+    return out
+
+
+def test_throughput_kernels_do_not_spill():
+    ks = _kernels()
+    assert len(ks) > 100, len(ks)                      # the library's kernels were found at all
+    bad = []
+    for name, k in ks.items():
+        scratch = k.get("private_segment_fixed_size", 0)
+        if scratch == 0 and k.get("vgpr_spill_count", 0) == 0:
+            continue
+        limit = max([lim for pat, lim in ALLOW if re.search(pat, name)] or [0])
+        if scratch > limit:
+            bad.append((name, scratch, k.get("vgpr_spill_count")))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("pattern", [r"aamd4m40017melspec400_kernel", r"aamd3rsm19resample_f16_kernelILi\d+ELi0E",
+                                     r"aamd3fco19overlap_save_kernel", r"aamd3fco23overlap_save_fdl_kernel",
+                                     r"aamd3lfw25lfilter_wave_mover_kernelILi0E", r"aamd2p216stft_pow2_kernel"])
+def test_headline_kernels_have_no_scratch_at_all(pattern):
+    """The kernels behind the BASELINE configs: zero bytes of scratch, zero spilled registers."""
+    ks = {n: k for n, k in _kernels().items() if re.search(pattern, n)}
+    assert ks, pattern
+    for n, k in ks.items():
+        assert k.get("private_segment_fixed_size", 0) == 0 and k.get("vgpr_spill_count", 0) == 0, (n, k)
