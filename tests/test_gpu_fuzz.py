@@ -226,6 +226,11 @@ def test_fuzz_fftconvolve_vs_fft(seed):
         ref = full[..., s0:s0 + m]
     assert got.shape == ref.shape, (xs, ys, mode)
     assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (xs, ys, mode)
+    if min(nx, ny) > 8192:      # long taps: also the frequency-domain delay-line plan, whatever the cost model picked above
+        from audio_amd import _lib
+        with _lib.kernel_policy(_lib.POLICY_FFTCONV_FDL), torch.no_grad():
+            fdl = F.fftconvolve(x.cuda(), y.cuda(), mode)
+        assert peak_rel_err(fdl.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (xs, ys, mode, "delay line")
 
 
 @pytest.mark.parametrize("seed", range(10))
