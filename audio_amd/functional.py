@@ -30,7 +30,7 @@ __all__ = [
     "spectrogram", "inverse_spectrogram", "griffinlim", "phase_vocoder", "pitch_shift", "speed", "amplitude_to_DB", "melscale_fbanks", "create_dct", "resample",
     "lfilter", "biquad", "fftconvolve", "mel_scale", "filtfilt",
     "lowpass_biquad", "highpass_biquad", "allpass_biquad", "bandpass_biquad",
-    "bandreject_biquad", "equalizer_biquad", "band_biquad", "treble_biquad", "bass_biquad",
+    "bandreject_biquad", "equalizer_biquad", "band_biquad", "treble_biquad", "bass_biquad", "deemph_biquad", "riaa_biquad",
 ]
 
 # --------------------------------------------------------------------------- #
@@ -1488,6 +1488,39 @@ def bass_biquad(waveform: Tensor, sample_rate: int, gain: float, central_freq: f
 # --------------------------------------------------------------------------- #
 # fftconvolve                                                                 #
 # --------------------------------------------------------------------------- #
+
+
+def deemph_biquad(waveform: Tensor, sample_rate: int) -> Tensor:
+    r"""ISO 908 CD de-emphasis (functional/filtering.py:417-462): a high shelf in SoX's slope parameterisation,
+    alpha = sin(w0) / 2 * sqrt((A + 1 / A) (1 / S - 1) + 2), at 44.1 kHz (5283 Hz, S 0.4845, -9.477 dB) or 48 kHz (5356 Hz,
+    S 0.479, -9.62 dB); any other rate raises like the reference."""
+    table = {44100: (5283.0, 0.4845, -9.477), 48000: (5356.0, 0.479, -9.62)}
+    if sample_rate not in table:
+        raise ValueError("Sample rate must be 44100 (audio-CD) or 48000 (DAT)")
+    freq, slope, gain = table[sample_rate]
+    w0 = 2.0 * math.pi * freq / sample_rate
+    A = math.exp(gain / 40.0 * math.log(10.0))
+    alpha = math.sin(w0) / 2.0 * math.sqrt((A + 1.0 / A) * (1.0 / slope - 1.0) + 2.0)
+    t1, t2, t3 = 2.0 * math.sqrt(A) * alpha, (A - 1.0) * math.cos(w0), (A + 1.0) * math.cos(w0)
+    return biquad(waveform, A * ((A + 1.0) + t2 + t1), -2.0 * A * ((A - 1.0) + t3), A * ((A + 1.0) + t2 - t1),
+                  (A + 1.0) - t2 + t1, 2.0 * ((A - 1.0) - t3), (A + 1.0) - t2 - t1)
+
+
+def riaa_biquad(waveform: Tensor, sample_rate: int) -> Tensor:
+    r"""RIAA vinyl playback equalisation (functional/filtering.py:1294-1360): SoX's zero / pole pairs for 44.1, 48, 88.2 and
+    96 kHz, normalised to 0 dB at 1 kHz; any other rate raises like the reference."""
+    table = {44100: ((-0.2014898, 0.9233820), (0.7083149, 0.9924091)), 48000: ((-0.1766069, 0.9321590), (0.7396325, 0.9931330)),
+             88200: ((-0.1168735, 0.9648312), (0.8590646, 0.9964002)), 96000: ((-0.1141486, 0.9676817), (0.8699137, 0.9966946))}
+    if sample_rate not in table:
+        raise ValueError("Sample rate must be 44.1k, 48k, 88.2k, or 96k")
+    (z0, z1), (p0, p1) = table[sample_rate]
+    b = [1.0, -(z0 + z1), z0 * z1]
+    a = [1.0, -(p0 + p1), p0 * p1]
+    y = 2.0 * math.pi * 1000.0 / sample_rate                       # |H| = 1 at 1 kHz
+    num = complex(b[0] + b[1] * math.cos(y) + b[2] * math.cos(2 * y), -(b[1] * math.sin(y) + b[2] * math.sin(2 * y)))
+    den = complex(a[0] + a[1] * math.cos(y) + a[2] * math.cos(2 * y), -(a[1] * math.sin(y) + a[2] * math.sin(2 * y)))
+    g = abs(den) / abs(num)
+    return biquad(waveform, b[0] * g, b[1] * g, b[2] * g, a[0], a[1], a[2])
 
 
 def _check_shape_compatible(x: Tensor, y: Tensor) -> None:

@@ -122,6 +122,18 @@ def test_sox_golden_biquad_on_gpu(sox_goldens):
         np.testing.assert_allclose(got, sox_goldens[name], atol=atol, rtol=1e-5)
 
 
+def test_table_driven_biquad_designers_against_reference_runs():
+    """deemph_biquad / riaa_biquad on the device vs the reference's CPU output on the same noise (fixture from
+    tests/golden/make_biquad_extra_golden.py), the tolerance of the other designer fixtures."""
+    import os
+    import audio_amd.functional as F
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "biquad_extra_goldens.npz"))
+    x = torch.from_numpy(gold["noise"]).cuda()
+    for name, fn, rates in (("deemph", F.deemph_biquad, (44100, 48000)), ("riaa", F.riaa_biquad, (44100, 48000, 88200, 96000))):
+        for sr in rates:
+            np.testing.assert_allclose(fn(x, sr).cpu().numpy(), gold[f"{name}_{sr}"], atol=1e-4, rtol=1e-5)
+
+
 def test_mel400_fast_path_equals_generic(monkeypatch):
     """Headline register-FFT kernel vs the generic LDS Stockham kernel on ragged / edge inputs."""
     import os

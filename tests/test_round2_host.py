@@ -2,6 +2,7 @@
 learnable window / filterbank refused loudly, plan caches thread-safe with LRU eviction, RNN-T features on shapes outside
 the radix-20x20 fast path, concurrent callers on separate streams, full-size rows against the float64 oracle, and the
 element-wise (floor-relative) error next to the peak-relative one."""
+import os
 import threading
 
 import numpy as np
@@ -329,3 +330,20 @@ def test_lfilter_second_order_sections_reproduce_the_filter():
     rb = np.stack([np.asarray(signal.butter(4, w)[0], np.float32) for w in (0.1, 0.2, 0.3)])
     sec = _host.lfilter_sos(rows, rb)
     assert sec is not None and sec[0].shape == (2, 3, 3)                                                # per-channel rows
+
+
+@pytest.mark.parametrize("name,rates", [("deemph", (44100, 48000)), ("riaa", (44100, 48000, 88200, 96000))])
+def test_table_driven_biquad_designers_hand_over_the_references_coefficients(name, rates, monkeypatch):
+    """deemph_biquad / riaa_biquad (functional/filtering.py:417-462, 1294-1360): the six coefficients they pass to `biquad` equal
+    the ones the reference passes to its own (captured from the reference by tests/golden/make_biquad_extra_golden.py), and an
+    unsupported sample rate raises the reference's ValueError."""
+    import audio_amd.functional as F
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "biquad_extra_goldens.npz"))
+    got = []
+    monkeypatch.setattr(F, "biquad", lambda w, b0, b1, b2, a0, a1, a2: got.append([float(v) for v in (b0, b1, b2, a0, a1, a2)]))
+    fn = getattr(F, name + "_biquad")
+    for sr in rates:
+        fn(torch.zeros(1, 8), sr)
+        np.testing.assert_allclose(got[-1], gold[f"{name}_{sr}_coeffs"], rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
+        fn(torch.zeros(1, 8), 32000)
