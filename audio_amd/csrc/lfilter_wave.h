@@ -333,17 +333,22 @@ lfilter_wave_kernel(const float* __restrict__ x, const float* __restrict__ a, co
   // row-major read of step 3 finds the piece; as a byte offset into the block it is the source of LDS slot 64 i + lane.
   auto piece = [](int l, int odd) { return 32 * (l >> 3) + 4 * ((l & 7) ^ (4 * odd + (l >> 4))); };
 
+  int built_crow = -1;                                  // coefficient row of the tables currently in LDS
   for (int64_t seq = blockIdx.x; seq < n_seq; seq += gridDim.x) {
     const int ch = (int)(seq % channels);
     const int crow = (n_coeff_rows == 1) ? 0 : ch;
     __syncthreads();
     if (wave == 0) {
-      if (lane < n_stages) {   // lane st builds the tables of stage st
+      // lane st builds the tables of stage st (fp64, one lane: ~10 us) -- only when the coefficient row differs from the one the
+      // tables in LDS were built for: with shared coefficients a workgroup builds them ONCE, not once per sequence (65 536
+      // sequences of 4 000 samples spent a quarter of their time here)
+      if (lane < n_stages && crow != built_crow) {
         const int64_t coff = ((int64_t)lane * n_coeff_rows + crow) * n_order;
         build_stage_call(a + coff, b + coff, n_order, tabs + lane * kTabFloats);
       }
       for (int i = lane; i < xch_floats(W, n_stages); i += 64) xch[i] = 0.0f;   // zero initial conditions
     }
+    built_crow = crow;
     __syncthreads();
     const float* xs = x + seq * length;
     float* ys = y + seq * length;
@@ -517,17 +522,19 @@ lfilter_wave_pipe_kernel(const float* __restrict__ x, const float* __restrict__ 
   float* own_out = otile + kCh * lane;
   const int own_r = swz(lane);
 
+  int built_crow = -1;                                  // coefficient row of the tables currently in LDS
   for (int64_t seq = blockIdx.x; seq < n_seq; seq += gridDim.x) {
     const int ch = (int)(seq % channels);
     const int crow = (n_coeff_rows == 1) ? 0 : ch;
     __syncthreads();
     if (wave == 0) {
-      if (lane < n_stages) {
+      if (lane < n_stages && crow != built_crow) {   // (once per coefficient row, not per sequence: see lfilter_wave_kernel)
         const int64_t coff = ((int64_t)lane * n_coeff_rows + crow) * n_order;
         build_stage_call(a + coff, b + coff, n_order, tabs + lane * kTabFloats);
       }
       for (int i = lane; i < xch_floats(W, n_stages); i += 64) xch[i] = 0.0f;
     }
+    built_crow = crow;
     __syncthreads();
     const float* xs = x + seq * length;
     float* ys = y + seq * length;
@@ -659,17 +666,19 @@ lfilter_wave_mover_kernel(const float* __restrict__ x, const float* __restrict__
   const int pc_e = piece(lane, 0), pc_o = piece(lane, 1);
   const int own_r = swz(lane);
 
+  int built_crow = -1;                                  // coefficient row of the tables currently in LDS
   for (int64_t seq = blockIdx.x; seq < n_seq; seq += gridDim.x) {
     const int ch = (int)(seq % channels);
     const int crow = (n_coeff_rows == 1) ? 0 : ch;
     __syncthreads();
     if (wave == 0) {
-      if (lane < n_stages) {
+      if (lane < n_stages && crow != built_crow) {   // (once per coefficient row, not per sequence: see lfilter_wave_kernel)
         const int64_t coff = ((int64_t)lane * n_coeff_rows + crow) * n_order;
         build_stage_call(a + coff, b + coff, n_order, tabs + lane * kTabFloats);
       }
       for (int i = lane; i < xch_floats(W, n_stages); i += 64) xch[i] = 0.0f;
     }
+    built_crow = crow;
     __syncthreads();
     const float* xs = x + seq * length;
     float* ys = y + seq * length;
