@@ -719,3 +719,36 @@ def test_sim_resample_sparse_pitch_shift_ratio():
     a, _ = S.sim_resample_sparse(x2, k2.numpy(), 441, 160, w2)
     b = S.sim_resample(x2, k2.numpy(), 441, 160, w2)
     assert np.abs(a - b).max() <= 1e-5
+
+
+@pytest.mark.parametrize("design", ["butter4", "cheby6", "per_channel"])
+def test_sim_lfilter_sections_with_clamp_after_the_last_stage(design):
+    """Orders 3 .. 8 as second-order sections (host factorisation `_host.lfilter_sos`) through the CPU replay of BOTH cascade
+    kernels (wave-per-sequence and workgroup scan) with clamp mode 2 = after the last section only, against the float64 direct
+    form clamped once, on an input loud enough that the final clamp bites; without any clamp (mode 0) the same sections give
+    the unclamped filter output."""
+    from scipy import signal
+    from audio_amd import _host
+    C_ = 3
+    if design == "per_channel":
+        ba = [signal.butter(4, w) for w in (0.1, 0.2, 0.35)]
+        b = np.stack([v[0] for v in ba]).astype(np.float32)
+        a = np.stack([v[1] for v in ba]).astype(np.float32)
+    else:
+        bb, aa = signal.butter(4, 0.2) if design == "butter4" else signal.cheby1(6, 1, 0.2)
+        b, a = np.asarray(bb, np.float32)[None], np.asarray(aa, np.float32)[None]
+    sec = _host.lfilter_sos(a, b)
+    assert sec is not None
+    a_s, b_s = sec
+    rng = np.random.default_rng(len(design))
+    x = ((rng.random((2, C_, 5000)) - 0.5) * 6.0).astype(np.float32)
+    exp = np.stack([np.stack([signal.lfilter(b[c % len(b)].astype(np.float64), a[c % len(a)].astype(np.float64),
+                                             x[n, c].astype(np.float64)) for c in range(C_)]) for n in range(2)])
+    assert np.abs(exp).max() > 1.2                       # the clamp matters
+    exp = np.clip(exp, -1.0, 1.0)
+    rc, wave = S.sim_lfilter_wave(x, a_s, b_s, clamp=2, waves=2)
+    assert rc == 0
+    gen = S.sim_lfilter(x, a_s, b_s, clamp=2)
+    assert np.abs(wave - exp).max() <= 3e-5 and np.abs(gen - exp).max() <= 3e-5
+    rc, none = S.sim_lfilter_wave(x, a_s, b_s, clamp=0, waves=2)
+    assert rc == 0 and np.abs(none).max() > 1.2 and np.abs(np.clip(none, -1, 1) - exp).max() <= 3e-5
