@@ -1014,6 +1014,23 @@ int sim_lfilter(const float* x, const float* a, const float* b, float* y, int64_
   return -1;
 }
 
+// The launcher's chunk geometry of the banded resampler for one set of phase tiles (rsm::plan_chunk), for property tests:
+// out = {qg, rounds, n_loaders, buf_floats, waves, chunk_q}; returns 0 when even one q-group does not fit.
+int sim_rsm_plan(int orig, int new_, int width, int tap_span, int max_lo, int64_t nq, int f16, int64_t lds_cap, int* out) {
+  using namespace rsm;
+  const int ks = pick_ks(tap_span);
+  if (ks == 0) return -2;
+  Geom g{};
+  g.orig = orig; g.new_ = new_; g.width = width; g.taps = 2 * width + orig;
+  const int n_tiles = (new_ + 15) / 16, max_cw = max_compute_waves(ks);
+  g.pt0 = 0;
+  g.n_pt = n_tiles < max_cw ? n_tiles : max_cw;
+  const bool ok = plan_chunk(g, ks, f16 != 0, nq, max_lo, (size_t)lds_cap);
+  out[0] = g.qg; out[1] = g.rounds; out[2] = g.n_loaders; out[3] = g.buf_floats;
+  out[4] = g.n_pt * g.qg + g.n_loaders; out[5] = chunk_q(g); out[6] = ks; out[7] = loader_pieces_per_lane(ks);
+  return ok ? 1 : 0;
+}
+
 // Replay of the overlap-save path (fco::spectrum_kernel + fco::overlap_save_kernel): the same
 // launcher logic as aamd_fftconvolve_f32, 1024 "threads" per phase, phases separated where the
 // kernel has barriers.  Twiddles as the device twiddle_kernel computes them (fp64 -> fp32).

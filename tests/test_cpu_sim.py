@@ -752,3 +752,36 @@ def test_sim_lfilter_sections_with_clamp_after_the_last_stage(design):
     assert np.abs(wave - exp).max() <= 3e-5 and np.abs(gen - exp).max() <= 3e-5
     rc, none = S.sim_lfilter_wave(x, a_s, b_s, clamp=0, waves=2)
     assert rc == 0 and np.abs(none).max() > 1.2 and np.abs(np.clip(none, -1, 1) - exp).max() <= 3e-5
+
+
+def test_resampler_chunk_plan_respects_the_hardware_limits():
+    """rsm::plan_chunk (shared by the launcher and the CPU replay) over a grid of rate pairs, band widths, row lengths and LDS
+    sizes: the workgroup has at most 16 waves (12 for the wide instantiations, which are compiled for 168 registers), the two
+    chunk buffers + counters fit the LDS, an f16 chunk is never longer than what its loader waves hold in registers (a longer
+    one would silently take the staged path), and neither a further q-group nor a further round starts past the end of the row."""
+    import ctypes as C
+    f = S.sim().sim_rsm_plan
+    f.argtypes = [C.c_int] * 5 + [C.c_int64, C.c_int, C.c_int64, C.c_void_p]
+    seen_rounds = seen_four = 0
+    for orig, new in [(3, 1), (30, 10), (2, 1), (1, 2), (147, 160), (160, 147), (441, 160), (441, 320), (80, 441), (640, 441)]:
+        for span in (13, 30, 64, 75, 190, 300, 416, 448):
+            for nq in (1, 5, 40, 500, 100000):
+                for f16 in (0, 1):
+                    for lds in (64 * 1024, 160 * 1024):
+                        width = max(1, span // 2)
+                        out = np.zeros(8, dtype=np.int32)
+                        rc = f(orig, new, width, span, min(span // 3, 2 * width + orig - 1), nq, f16, lds, out.ctypes.data_as(C.c_void_p))
+                        qg, rounds, nld, buf, waves, qc, ks, per_lane = (int(v) for v in out)
+                        assert rc in (0, 1) and qg >= 1 and rounds >= 1 and nld in (2, 4)
+                        assert waves <= (12 if ks >= 80 else 16), (orig, new, span, waves)
+                        assert qc == 32 * qg * rounds
+                        if not f16:
+                            assert rounds == 1 and nld == 2
+                        if rc == 1:
+                            assert 2 * buf * 4 + (48 if f16 else 0) <= lds
+                            if f16 and (qg > 1 or rounds > 1):
+                                assert buf <= 4 * 64 * nld * per_lane, (orig, new, span, nq, buf)
+                            assert (qg == 1 or 32 * (qg - 1) < nq) and (rounds == 1 or 32 * qg * (rounds - 1) < nq)
+                        seen_rounds += rounds > 1
+                        seen_four += nld == 4
+    assert seen_rounds > 20 and seen_four > 20          # both mechanisms are exercised by the grid
