@@ -371,14 +371,14 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   __syncthreads();
 
   // Timeline (one barrier per chunk):
-  //   loaders   fetch(f) stage(f) fetch(f+1)      A0 | stage(f+1) fetch(f+2)               A(f) | stage(f+2) fetch(f+3) ...
-  //   the rest  tap fragments, convert(f)         A0 | compute(f), stores, convert(f+1)    A(f) | compute(f+1) ...
+  //   loaders   fetch(f) stage(f) fetch(f+1) convert(f)   A0 | stage(f+1) fetch(f+2) convert(f+1)       A(f) | stage(f+2) ...
+  //   the rest  tap fragments, convert(f)                 A0 | compute(f) (all rounds), stores, convert(f+1) A(f) | compute(f+1) ...
   // fetch = the chunk's global loads into registers: issued a whole chunk period before the LDS buffer they go to is free
   // (two chunks in LDS + one in the loaders' registers = the HBM latency of a 60 KB burst per CU is off the critical path);
   // stage = wait for the data, publish the wave's largest |sample| (DPP reduction + one LDS atomic max), write the RAW
-  // floats to the free buffer, count the wave as arrived (LDS counter, after its writes).  convert = the compute waves, once
-  // their MFMA loop is done and both loaders have arrived, turn their share of the raw image into packed (lo << 16 | hi)
-  // dwords in place.  Round-2 census (profiles/r02_v): with the conversion in the two loader waves they were the critical
+  // floats to the free buffer, count the wave as arrived (LDS counter, after its writes).  convert = every wave that is free
+  // (compute waves behind their MFMA loops, loaders behind their fetches), once all loaders have arrived, takes batches of
+  // the raw image from an LDS counter and turns them into packed (lo << 16 | hi) dwords in place.  Round-2 census (profiles/r02_v): with the conversion in the two loader waves they were the critical
   // path of every chunk (6.8 of 7.5 us) while the ten compute waves idled 2.3 - 3.9 us at the barrier.
   unsigned* cnt = mx + 3;                              // [3]: loader waves whose raw samples and maximum are in LDS, monotonic
   auto pack4 = [](const F4& t, float scale) {
@@ -388,7 +388,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   };
   // convert(k): raw image of chunk k -> packed dwords, in batches of kGrab x 64 pieces handed out by an LDS counter to whichever
   // wave is free (the early finishers of the MFMA loop and the loaders behind their fetches take most of them; the last
-  // compute waves of a period find nothing left), once both loader waves have counted themselves in (slot k % 3 is used for
+  // compute waves of a period find nothing left), once all loader waves have counted themselves in (slot k % 3 is used for
   // the (k / 3 + 1)-th time; every wave of the workgroup is resident, so the wait is bounded)
   unsigned* grab = cnt + 3;                            // [3]: batches handed out
   constexpr int kGrab = 3;
