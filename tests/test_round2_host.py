@@ -347,3 +347,31 @@ def test_table_driven_biquad_designers_hand_over_the_references_coefficients(nam
         np.testing.assert_allclose(got[-1], gold[f"{name}_{sr}_coeffs"], rtol=1e-12, atol=0)
     with pytest.raises(ValueError):
         fn(torch.zeros(1, 8), 32000)
+
+
+def test_lfilter_sections_are_cached_per_tensor_and_per_values(monkeypatch):
+    """functional._lfilter_sections: one factorisation per coefficient VALUES (callers that rebuild their tensors every call
+    pay a host copy, not a root finding), no host work at all for the same tensor objects, None for filters the host does not
+    vouch for, and an in-place update of the coefficients invalidates the per-tensor slot."""
+    from scipy import signal
+    import audio_amd.functional as F
+    from audio_amd import _host
+    calls = []
+    real = _host.lfilter_sos
+    monkeypatch.setattr(_host, "lfilter_sos", lambda a, b: (calls.append(1), real(a, b))[1])
+    F._SOS_BY_VALUE.clear()
+    bb, aa = signal.butter(4, 0.2)
+    a, b = torch.tensor(aa, dtype=torch.float32), torch.tensor(bb, dtype=torch.float32)
+    s1 = F._lfilter_sections(a, b, a.reshape(1, -1), b.reshape(1, -1))
+    assert s1 is not None and s1[0].shape == (2, 1, 3) and len(calls) == 1
+    s2 = F._lfilter_sections(a, b, a.reshape(1, -1), b.reshape(1, -1))
+    assert s2[0] is s1[0] and len(calls) == 1                      # same tensors: the cached device tensors themselves
+    a2, b2 = a.clone(), b.clone()
+    s3 = F._lfilter_sections(a2, b2, a2.reshape(1, -1), b2.reshape(1, -1))
+    assert len(calls) == 1 and torch.equal(s3[0], s1[0])           # same values: no second factorisation
+    b.mul_(0.5)                                                    # in place: version counter moves
+    s4 = F._lfilter_sections(a, b, a.reshape(1, -1), b.reshape(1, -1))
+    assert len(calls) == 2 and torch.allclose(s4[1][0], 0.5 * s1[1][0])   # the gain sits in the first section
+    bad_a = torch.tensor([1.0, -1.999, 0.9995, 0.0])
+    bad_b = torch.tensor([1.0, 0.0, 0.0, 0.0])
+    assert F._lfilter_sections(bad_a, bad_b, bad_a.reshape(1, -1), bad_b.reshape(1, -1)) is None
