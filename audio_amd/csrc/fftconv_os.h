@@ -355,7 +355,7 @@ AAMD_HD bool plan_fdl(int64_t rows, int64_t ny, int64_t out_len, int cu_count, F
   plan(ny, out_len, g);
   const int64_t old_cost = ((rows * g.n_pairs + cu_count - 1) / cu_count) * (g.n_part + 1);
   int64_t best = -1;
-  for (int segs = 1; segs <= 64 && segs * 2 <= f.n_blocks; ++segs) {
+  for (int segs = 1; segs <= 1024 && segs * 2 <= f.n_blocks; ++segs) {   // (a single very long row still fills the chip)
     const int64_t sb = (f.n_blocks + segs - 1) / segs, hn = (sb + 1) / 2;
     const int64_t used = (f.n_blocks + sb - 1) / sb;                      // segments that own blocks
     const int64_t cost = ((rows * used + cu_count - 1) / cu_count) * (2 * hn + f.n_part - 1);

@@ -369,7 +369,7 @@ def test_sim_fftconvolve_overlap_save(nx, ny, mode):
 
 @pytest.mark.parametrize("nx,ny,mode,cus,fdl", [
     (70000, 16000, "full", 2, True), (60000, 24000, "full", 2, True), (50000, 17000, "same", 1, True),
-    (90000, 30000, "valid", 4, True), (150000, 24000, "full", 16, True),
+    (90000, 30000, "valid", 4, True), (150000, 24000, "full", 16, True), (70000, 24000, "full", 4, True),
     # barely more than one partition of taps (the non-uniform plan has the longer hop) / 5 blocks on 256 CUs: recompute
     (70000, 9000, "full", 2, False), (40000, 20000, "full", 256, False)])
 def test_sim_fftconvolve_delay_line_plan(nx, ny, mode, cus, fdl):
