@@ -623,7 +623,7 @@ def _direct_form(b, a, x):
 
 
 def lfilter_sos(a: np.ndarray, b: np.ndarray, max_pole_radius: float = 0.99, rel_tol: float = 2e-6):
-    """(rows, n_order) float32 coefficient rows of filters of order 3 .. 8 -> second-order sections
+    """(rows, n_order) float32 coefficient rows of filters of order 3 .. 16 -> second-order sections
     (a_s, b_s) float32 (n_sections, rows, 3) for the cascade kernels (clamp mode 2), or None.
 
     Poles and zeros from the float64 companion matrices, conjugates kept together, every pole section paired with the
@@ -635,7 +635,7 @@ def lfilter_sos(a: np.ndarray, b: np.ndarray, max_pole_radius: float = 0.99, rel
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     rows, n_order = a.shape
-    if not (4 <= n_order <= 9):
+    if not (4 <= n_order <= 17):      # <= 8 sections: what one launch of the cascade kernels takes (lfw::kMaxCascade)
         return None
     n_sec = n_order // 2            # ceil(order / 2), order = n_order - 1
     a_s = np.zeros((n_sec, rows, 3))

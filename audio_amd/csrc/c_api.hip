@@ -317,7 +317,7 @@ int launch_lfilter(const float* x, const float* a, const float* b, float* y, int
                    int channels, int64_t length, int n_order, int n_rows, int n_stages, int clamp,
                    hipStream_t s) {
   using L = LfLds<D>;
-  const size_t lds = ((size_t)L::total + (size_t)n_stages * (L::total - L::H)) * sizeof(float);
+  const size_t lds = L::bytes(n_stages);
   if (lds > 160 * 1024) return fail(AAMD_EUNSUPPORTED, "audio_amd: lfilter cascade too long for LDS");
   auto kern = lfilter_kernel<D>;
   if (lds > 48 * 1024)

@@ -18,6 +18,7 @@ using std::log;
 using std::log10;
 using std::fmax;
 using std::fmin;
+using std::fma;
 #endif
 
 namespace aamd {

@@ -123,7 +123,7 @@ def _cached(key, make):
     return v
 
 
-def _tensor_cached(t: Tensor, key, make):
+def _tensor_cached(t: Tensor, key, make, replace: bool = False):
     """Cache a constant derived from tensor `t` (window / fb buffers).  The slot is found by
     object id but is only trusted while its weak reference still resolves to `t` itself, so a
     new tensor that reuses a dead tensor's id can never hit a stale entry (finalizers of tensor
@@ -140,14 +140,17 @@ def _tensor_cached(t: Tensor, key, make):
                     del _TENSOR_CACHE[kk]
             slot = (weakref.ref(t), {})
             _TENSOR_CACHE[tid] = slot
-        v = slot[1].get(k)
+        v = None if replace else slot[1].get(k)
         if v is not None:
             return v
     v = make()
     with _CACHE_LOCK:
         if len(slot[1]) > 64:                    # a tensor mutated every step: keep only the newest derivations
             slot[1].clear()
-        v = slot[1].setdefault(k, v)
+        if replace:
+            slot[1][k] = v
+        else:
+            v = slot[1].setdefault(k, v)
     return v
 
 
@@ -176,10 +179,16 @@ class MelBandsOnDevice:
         use_order = self.n_freq == 201 and os.environ.get("AAMD_MEL400_NO_LANE_ORDER") is None   # env: A/B experiments
         image = None
         if use_order:
-            image, order = _host.mel400_table_image(lo, width, weights, max_width)
-            if os.environ.get("AAMD_MEL400_ORDER_ONLY") is not None:                              # env: A/B experiments
+            # the image exists only for filterbanks the radix-20x20 kernel serves (<= 8 rounds of 20 mels, bands <= 62 bins:
+            # aamd_mel400_table_dwords() > 0); anything wider keeps the plain lane order and runs on the generic kernel
+            fast = _lib.lib().aamd_mel400_table_dwords(int(self.n_mels), int(max_width)) > 0
+            if fast and os.environ.get("AAMD_MEL400_ORDER_ONLY") is None:                         # env: A/B experiments
+                image, order = _host.mel400_table_image(lo, width, weights, max_width)
+            elif fast:
                 image, order = None, _host.mel_lane_order(lo, width)
-            self.lane_order = torch.from_numpy(order).to(device)
+            else:
+                image, order = None, None
+            self.lane_order = torch.from_numpy(order).to(device) if order is not None else None
         else:
             self.lane_order = None
         self.struct = _lib.MelBands(self.n_mels, max_width, self.lo.data_ptr(), self.width.data_ptr(),
@@ -1063,7 +1072,7 @@ def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new
     if kern.shape[1] > _SPARSE_TAPS:
         # huge reduced rates (PitchShift: 10079 : 8000 -> a 8000 x 10095 table with ~36 live taps per phase): the
         # compacted table (host, once per kernel tensor) through the sparse kernel instead of 10 095 taps per sample
-        hb, lo, span = _tensor_cached(key_tensor, ("rs_sparse", key, new), lambda: tuple(
+        hb, lo, span = _tensor_cached(key_tensor, ("rs_sparse", key, new, str(x2.device)), lambda: tuple(
             (torch.from_numpy(t).to(x2.device) if isinstance(t, np.ndarray) else t)
             for t in _host.resample_sparse_table(kern.cpu().numpy())))
         if x2.stride(0) != length and rows > 1:
@@ -1081,7 +1090,7 @@ def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new
         kp, mm = _host.resample_fill_phase_tiles(kern.cpu().numpy(), orig, new, width)
         return (kern if mm == 1 else torch.from_numpy(np.ascontiguousarray(kp)).to(x2.device)), mm
 
-    kern_m, m = _tensor_cached(key_tensor, ("rs_fill", key, orig, new, width), _fill)
+    kern_m, m = _tensor_cached(key_tensor, ("rs_fill", key, orig, new, width, str(x2.device)), _fill)
     if m > 1:
         kern, orig, new = kern_m, m * orig, m * new
     # band table of the taps (host, once per kernel tensor): the matrix-core kernel skips the
@@ -1208,26 +1217,38 @@ def _lfilter_launch(x3: Tensor, a: Tensor, b: Tensor, clamp: bool, n_stages: int
     return y
 
 
+def _lfilter_any(x3: Tensor, a_n: Tensor, b_n: Tensor, sos) -> Tensor:
+    """Unclamped filter of (batch, rows, L) by the (rows, n_order) coefficients: the host-vouched second-order sections
+    `sos` on the cascade kernels when the caller has them, else the general-order kernel (float64 state, csrc/lfilter.h)."""
+    if sos is not None:
+        return _lfilter_launch(x3, sos[0], sos[1], 0, n_stages=sos[0].shape[0])
+    return _lfilter_launch(x3, a_n.unsqueeze(0), b_n.unsqueeze(0), False)
+
+
 class _LFilterFunction(torch.autograd.Function):
     """Autograd of lfilter on the HIP kernels (reference: DifferentiableFIR / DifferentiableIIR,
     functional/filtering.py:941-1024).  With w = FIR(x; b^) and y = IIR(w; a^), both LTI:
       dL/dx   = time-reversed lfilter(a^, b^) of the time-reversed dL/dy      (one kernel launch)
       dL/dw   = time-reversed all-pole filter 1/A of the time-reversed dL/dy  (one kernel launch)
       dL/db^k = sum_n dL/dw[n] x[n-k],   dL/da^k = -sum_n dL/dw[n] y[n-k]  (k >= 1; a^0 = 1 is not a parameter)
-    clamp(-1, 1) passes gradient where the unclamped output lies inside [-1, 1] (torch.clamp's rule)."""
+    clamp(-1, 1) passes gradient where the unclamped output lies inside [-1, 1] (torch.clamp's rule).
+    `sos`: second-order sections of (a^, b^) for a FIXED filter under a differentiable waveform (the forward and the dx
+    launch then run on the cascade kernels); learnable coefficients change every step and take the general-order kernel."""
 
     @staticmethod
-    def forward(ctx, x3, a_n, b_n, clamp):
+    def forward(ctx, x3, a_n, b_n, clamp, sos=None):
         a_n = a_n.contiguous()
         b_n = b_n.contiguous()
-        y_raw = _lfilter_launch(x3, a_n.unsqueeze(0), b_n.unsqueeze(0), False)
+        y_raw = _lfilter_any(x3, a_n, b_n, sos)
         ctx.save_for_backward(x3, a_n, b_n, y_raw)
         ctx.clamp = clamp
+        ctx.sos = sos
         return y_raw.clamp(-1.0, 1.0) if clamp else y_raw
 
     @staticmethod
     def backward(ctx, dy):
         x3, a_n, b_n, y = ctx.saved_tensors
+        sos = ctx.sos
         g = dy
         if ctx.clamp:
             g = g * ((y >= -1.0) & (y <= 1.0)).to(g.dtype)
@@ -1236,13 +1257,13 @@ class _LFilterFunction(torch.autograd.Function):
         # then applied through this very Function (as the reference's DifferentiableIIR.backward calls
         # DifferentiableIIR.apply, filtering.py:1000-1017) and `y` is the graph-connected output it saved.
         if torch.is_grad_enabled():
-            run = lambda t, aa, bb: _LFilterFunction.apply(t, aa, bb, False)                      # noqa: E731
-            y = run(x3, a_n, b_n)        # graph-connected copy of the unclamped output (da below depends on it)
+            run = lambda t, aa, bb, ss=None: _LFilterFunction.apply(t, aa, bb, False, ss)        # noqa: E731
+            y = run(x3, a_n, b_n, sos)   # graph-connected copy of the unclamped output (da below depends on it)
         else:
-            run = lambda t, aa, bb: _lfilter_launch(t, aa.unsqueeze(0), bb.unsqueeze(0), False)   # noqa: E731
+            run = lambda t, aa, bb, ss=None: _lfilter_any(t, aa, bb, ss)                         # noqa: E731
         dx = da = db = None
         if ctx.needs_input_grad[0]:
-            dx = run(gf, a_n, b_n).flip(-1)
+            dx = run(gf, a_n, b_n, sos).flip(-1)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             one = torch.zeros_like(b_n)
             one[:, 0] = 1.0
@@ -1254,16 +1275,28 @@ class _LFilterFunction(torch.autograd.Function):
                 cols = [torch.zeros(a_n.shape[0], dtype=a_n.dtype, device=a_n.device)]
                 cols += [-(dw[..., k:] * y[..., :L - k]).sum((0, 2)) for k in range(1, n_order)]
                 da = torch.stack(cols, 1)
-        return dx, da, db, None
+        return dx, da, db, None, None
 
 
-_SOS_MIN_SAMPLES = 0            # every size: the sections are also the more ACCURATE form (the general-order scan carries the
-                                # direct form's float32 round-off: 2e-3 .. 8e-2 of the peak on 6th-order designs, tests)
+_SOS_MIN_SAMPLES = 0            # every size: the sections are the FAST form (biquad-class kernels); accuracy no longer depends
+                                # on them -- the general-order kernel carries its state in float64 since round 3
+_SOS_MAX_COEFFS = 17            # order <= 16 = 8 sections, what one launch of the cascade kernels takes
 _SOS_BY_VALUE: dict = {}        # coefficient bytes -> sections (host arrays) or None: callers that rebuild their tensors per call
+_SOS_ENABLED = [os.environ.get("AAMD_LFILTER_NO_SECTIONS") is None]
+
+
+def set_lfilter_sections(enabled: bool) -> bool:
+    """Switch the host factorisation of orders 3 .. 16 into second-order sections on or off (returns the previous
+    setting).  Factoring needs the coefficient VALUES on the host: one blocking device-to-host copy per new coefficient
+    tensor pair (plus root finding on a value miss) -- callers that build coefficients on the device every call, or capture
+    HIP graphs, switch it off and stay on the general-order kernel, which needs nothing from the host."""
+    prev = _SOS_ENABLED[0]
+    _SOS_ENABLED[0] = bool(enabled)
+    return prev
 
 
 def _lfilter_sections(a_key: Tensor, b_key: Tensor, a: Tensor, b: Tensor):
-    """Second-order sections (device tensors (n_sections, rows, 3)) of the order 3 .. 8 filter (a, b), or None when
+    """Second-order sections (device tensors (n_sections, rows, 3)) of the order 3 .. 16 filter (a, b), or None when
     `_host.lfilter_sos` does not vouch for the factorisation.  Cached per coefficient tensor (no host round trip on a hit)
     and per coefficient values (one device-to-host copy, no root finding, for callers that rebuild the tensors)."""
     def make():
@@ -1279,11 +1312,16 @@ def _lfilter_sections(a_key: Tensor, b_key: Tensor, a: Tensor, b: Tensor):
                     _SOS_BY_VALUE.clear()
                 _SOS_BY_VALUE[key] = sec
         if sec is None:
-            return (None,)
-        return (torch.from_numpy(sec[0]).to(a.device), torch.from_numpy(sec[1]).to(a.device))
+            return (None, None, weakref.ref(b_key))
+        return (torch.from_numpy(sec[0]).to(a.device), torch.from_numpy(sec[1]).to(a.device), weakref.ref(b_key))
 
-    got = _tensor_cached(a_key, ("lf_sos", id(b_key), b_key._version, b_key.data_ptr(), str(a.device)), make)
-    return None if got[0] is None else got
+    # The slot lives on `a_key` (weakref-checked by _tensor_cached); `b_key` is identified by a weak reference stored IN the
+    # entry -- never by id() / data_ptr(), which CPython and the allocator reuse for a fresh tensor with other values.
+    k = ("lf_sos", b_key._version, b_key.data_ptr(), str(a.device))
+    got = _tensor_cached(a_key, k, make)
+    if got[2]() is not b_key:
+        got = _tensor_cached(a_key, k, make, replace=True)
+    return None if got[0] is None else got[:2]
 
 
 def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = True, batching: bool = True) -> Tensor:
@@ -1311,24 +1349,27 @@ def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = 
     else:
         a_coeffs = a_coeffs.unsqueeze(0)
         b_coeffs = b_coeffs.unsqueeze(0)
-    needs_grad = torch.is_grad_enabled() and (waveform.requires_grad or a_coeffs.requires_grad or b_coeffs.requires_grad)
+    coeff_grad = torch.is_grad_enabled() and (a_coeffs.requires_grad or b_coeffs.requires_grad)
+    needs_grad = coeff_grad or (torch.is_grad_enabled() and waveform.requires_grad)
     _require_device(waveform, "waveform", allow_grad=True, allow_f64=True)
     shape = waveform.size()
     n_filt = a_coeffs.shape[0]
     x3 = waveform.reshape(-1, n_filt, shape[-1]).contiguous()
     a = a_coeffs.to(device=waveform.device, dtype=waveform.dtype).contiguous()
     b = b_coeffs.to(device=waveform.device, dtype=waveform.dtype).contiguous()
+    # orders 3 .. 16 with FIXED coefficients: second-order sections on the biquad-class kernels, clamped once at the end
+    sos = None
+    if (x3.dtype == torch.float32 and 4 <= a.shape[-1] <= _SOS_MAX_COEFFS and x3.numel() >= _SOS_MIN_SAMPLES
+            and _SOS_ENABLED[0] and not coeff_grad):
+        sos = _lfilter_sections(a_key, b_key, a.detach(), b.detach())
     if needs_grad:
         # differentiable path (functional/filtering.py:941-1029): normalise by a0 with torch ops so that
-        # autograd sees the division, the recursion and its adjoint run in the HIP kernel
-        y = _LFilterFunction.apply(x3, a / a[:, 0:1], b / a[:, 0:1], clamp)
+        # autograd sees the division, the recursion and its adjoint run in the HIP kernels
+        y = _LFilterFunction.apply(x3, a / a[:, 0:1], b / a[:, 0:1], clamp, sos)
+    elif sos is not None:
+        y = _lfilter_launch(x3, sos[0], sos[1], 2 if clamp else 0, n_stages=sos[0].shape[0])
     else:
-        sos = _lfilter_sections(a_key, b_key, a, b) if (x3.dtype == torch.float32 and 4 <= a.shape[-1] <= 9
-                                                      and x3.numel() >= _SOS_MIN_SAMPLES) else None
-        if sos is not None:      # orders 3 .. 8 on the biquad-class kernels: second-order sections, clamped once at the end
-            y = _lfilter_launch(x3, sos[0], sos[1], 2 if clamp else 0, n_stages=sos[0].shape[0])
-        else:
-            y = _lfilter_launch(x3, a, b, clamp)
+        y = _lfilter_launch(x3, a, b, clamp)
     return y.reshape(shape[:-1] + y.shape[-1:])
 
 

@@ -856,43 +856,47 @@ template <int D>
 static int sim_lfilter_d(const float* x, const float* a, const float* b, float* y, int64_t n_seq, int channels,
                          int64_t length, int n_order, int n_rows, int n_stages, int clamp) {
   using L = LfLds<D>;
-  const int stage_floats = L::total - L::H;
-  std::vector<float> ldsv((size_t)L::total + (size_t)n_stages * stage_floats, 0.f);
-  float* lds = ldsv.data();
-  float* stage_store = lds + L::total;
+  std::vector<float> blkv((size_t)L::blk_floats, 0.f);
+  std::vector<double> tabv((size_t)L::total + (size_t)n_stages * L::stage_doubles, 0.0);
+  float* blk = blkv.data();
+  double* tab = tabv.data();
+  double* stage_store = tab + L::total;
   std::vector<LfThread<D>> th(kLfThreads);
   for (int64_t seq = 0; seq < n_seq; ++seq) {
     const int ch = (int)(seq % channels);
     const int crow = (n_rows == 1) ? 0 : ch;
     for (int st = 0; st < n_stages; ++st) {
       const int64_t coff = ((int64_t)st * n_rows + crow) * n_order;
-      lf_build_tables<D>(a + coff, b + coff, n_order, lds);
-      for (int e = 0; e < D; ++e) { lds[L::cx + e] = 0.f; lds[L::cy + e] = 0.f; }
-      for (int i = 0; i < stage_floats; ++i) stage_store[st * stage_floats + i] = lds[L::H + i];
+      for (int tid = 0; tid < kLfThreads; ++tid) lf_tables_coeffs<D>(tid, a + coff, b + coff, n_order, tab);
+      for (int e = 0; e < 2 * D; ++e) tab[L::cx + e] = 0.0;
+      for (int tid = 0; tid < kLfThreads; ++tid) lf_tables_response<D>(tid, tab);
+      for (int k = 1; k < kLfScanSteps; ++k)
+        for (int tid = 0; tid < kLfThreads; ++tid) lf_tables_square<D>(tid, k, tab);
+      for (int i = 0; i < L::stage_doubles; ++i) stage_store[st * L::stage_doubles + i] = tab[L::H + i];
     }
     const float* xs = x + seq * length;
     float* ys = y + seq * length;
     for (int64_t n0 = 0; n0 < length; n0 += kLfBlock) {
       for (int i = 0; i < kLfBlock; ++i) {
         const int64_t n = n0 + i;
-        lds[L::blk + (i / kLfChunk) * kLfChunkStride + (i % kLfChunk)] = (n < length) ? xs[n] : 0.f;
+        blk[(i / kLfChunk) * kLfChunkStride + (i % kLfChunk)] = (n < length) ? xs[n] : 0.f;
       }
       for (int st = 0; st < n_stages; ++st) {
-        for (int i = 0; i < stage_floats; ++i) lds[L::H + i] = stage_store[st * stage_floats + i];
-        for (int tid = 0; tid < kLfThreads; ++tid) lf_chunk_pass<D>(tid, lds, th[tid]);
-        lf_save_input_carry<D>(lds);
+        for (int i = 0; i < L::stage_doubles; ++i) tab[L::H + i] = stage_store[st * L::stage_doubles + i];
+        for (int tid = 0; tid < kLfThreads; ++tid) lf_chunk_pass<D>(tid, blk, tab, th[tid]);
+        lf_save_input_carry<D>(blk, tab);
         bool src_is_a = true;
         for (int k = 0; k < kLfScanSteps; ++k) {
-          for (int tid = 0; tid < kLfThreads; ++tid) lf_scan_step<D>(tid, k, lds, th[tid], src_is_a);
+          for (int tid = 0; tid < kLfThreads; ++tid) lf_scan_step<D>(tid, k, tab, th[tid], src_is_a);
           src_is_a = !src_is_a;
         }
-        for (int tid = 0; tid < kLfThreads; ++tid) lf_correct_store<D>(tid, lds, th[tid], src_is_a, clamp == 1 || (clamp == 2 && st == n_stages - 1));
-        lf_save_output_carry<D>(lds, src_is_a);
-        for (int i = 0; i < 2 * D; ++i) stage_store[st * stage_floats + (L::cx - L::H) + i] = lds[L::cx + i];
+        for (int tid = 0; tid < kLfThreads; ++tid) lf_correct_store<D>(tid, blk, tab, th[tid], src_is_a, clamp == 1 || (clamp == 2 && st == n_stages - 1));
+        lf_save_output_carry<D>(tab, src_is_a);
+        for (int i = 0; i < 2 * D; ++i) stage_store[st * L::stage_doubles + (L::cx - L::H) + i] = tab[L::cx + i];
       }
       for (int i = 0; i < kLfBlock; ++i) {
         const int64_t n = n0 + i;
-        if (n < length) ys[n] = lds[L::blk + (i / kLfChunk) * kLfChunkStride + (i % kLfChunk)];
+        if (n < length) ys[n] = blk[(i / kLfChunk) * kLfChunkStride + (i % kLfChunk)];
       }
     }
   }

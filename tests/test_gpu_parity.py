@@ -490,10 +490,9 @@ def test_lfilter_orders_3_to_8_as_second_order_sections(design):
         assert np.abs(pre - exp[:1, :, :3000]).max() <= 1e-9
         # (of the peak AFTER the clamp, i.e. of 1.0, while the recursion runs at the input's +-3: hence not 1e-5)
         assert peak_rel_err(got[:2].cpu().numpy(), exp) <= (3e-5 if a.shape[-1] <= 5 else 5e-5)
-        # the general-order kernel carries the direct form's float32 round-off through its scan: 2e-3 (Butterworth 6) to 8e-2
-        # (Chebyshev 6) of the peak measured here -- the other reason the sections are preferred whenever they are vouched for
-        if a.shape[-1] <= 5:
-            assert peak_rel_err(gen.cpu().numpy(), exp[:1]) <= 1e-4
+        # the general-order kernel carries its state in float64 (round 3; the float32 scan of round 2 lost 2e-3 .. 8e-2 of
+        # the peak on the 6th-order designs): every design, same bar
+        assert peak_rel_err(gen.cpu().numpy(), exp[:1]) <= 1e-4
         if clamp:
             assert float(got.abs().max()) <= 1.0
             assert not loud or float((got[:2].abs() == 1.0).float().mean()) > 0.0        # the clamp was hit where it must be
