@@ -893,6 +893,7 @@ struct TileInfo {
 //   bit 3: no LDS-DMA issue              bit 4: no phase B (second DFT, separation, P rows)
 //   bit 15 (32768): interior tiles gather their samples with plain global loads, the NEXT tile's 28 samples per lane
 //                   prefetched into registers right after phase A (no LDS staging at all)
+//   bit 20 (1048576): every wave records (cycle counter, 100 MHz wall clock) at entry and exit into epi.fix_count
 //   bit 17 (131072): tiles handed out chip-wide in chunks of kLabChunk from ONE global counter (epi.group_max, zeroed by
 //                   the lab before each launch) instead of static per-workgroup ranges
 // float max through integer atomics (target initialised to -inf or any float)
@@ -934,6 +935,12 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   long long lab_t0 = 0;
   if (LAB & 1024) lab_t0 = wall_clock64();
+  if ((LAB & 1048576) && lane == 0) {  // lab: ... and at its entry (shader clock of the launch = cycles / wall time)
+    long long* rec = reinterpret_cast<long long*>(epi.fix_count);
+    const int w = blockIdx.x * kWavesPerBlock + wave;
+    rec[4 * w] = (long long)clock64();
+    rec[4 * w + 1] = wall_clock64();
+  }
   using HC = Hop<H>;
   constexpr int kHop = HC::hop;
   float* lds = smem400 + wave * HC::lds_dwords;
@@ -1314,6 +1321,12 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       }
       if (g_run >= 0) atomic_max_f32(epi.group_max + g_run, m_run);
     }
+  }
+  if ((LAB & 1048576) && lane == 0) {  // lab (tools/mel400_lab.py): cycle counter and 100 MHz wall clock at the wave's exit
+    long long* rec = reinterpret_cast<long long*>(epi.fix_count);
+    const int w = blockIdx.x * kWavesPerBlock + wave;
+    rec[4 * w + 2] = (long long)clock64();
+    rec[4 * w + 3] = wall_clock64();
   }
   if ((LAB & 1024) && lane == 0) {   // lab census: per-wave entry / tables ready / done (100 MHz clock)
     long long* rec = reinterpret_cast<long long*>(const_cast<float*>(tw400) + 1024);

@@ -1,0 +1,61 @@
+// Lab build of the headline kernel (tools only): the SAME audio_amd/csrc/melspec400.h compiled alone, one shared library
+// per source variant (-D switches), so that A/B runs of kernel changes take 30 s to build instead of the whole product
+// library, and so that profiling variants (LAB bits of melspec400_kernel) can be launched from tools/mel400_lab.py.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/audio_amd.h"
+#include "../../audio_amd/csrc/melspec400.h"
+
+using namespace aamd;
+
+#ifndef LAB_BITS
+#define LAB_BITS 0
+#endif
+
+static long long* g_dbg = nullptr;
+extern "C" void lab_set_debug(void* p) { g_dbg = (long long*)p; }
+
+template <int LAB>
+static int launch(const float* wav, const float* window, const float* tw, const MelBandsDev& mb, float* out, int64_t rows,
+                  int64_t length, int64_t row_stride, int n_frames, float scale, int out_wide, int blocks_override,
+                  hipStream_t s) {
+  const int tiles_per_row = (n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
+  const int64_t n_tiles = rows * tiles_per_row;
+  const int wpb = m400::kWavesPerBlock;
+  const size_t lds = m400::lds_bytes(mb.n_mels, mb.max_width, m400::Hop<8>::lds_dwords);
+  auto kern = m400::melspec400_kernel<LAB, m400::EPI400_MEL, 8, float, 4>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+  hipDeviceProp_t dp;
+  int dev = 0;
+  hipGetDevice(&dev);
+  static int cus = 0;
+  if (!cus) { hipGetDeviceProperties(&dp, dev); cus = dp.multiProcessorCount; }
+  int64_t blocks = blocks_override > 0 ? blocks_override : cus;
+  const int64_t need = (n_tiles + wpb - 1) / wpb;
+  if (blocks > need) blocks = need;
+  if (blocks >= 8) blocks -= blocks % 8;
+  if (blocks < 1) blocks = 1;
+  const int tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
+  const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (row_stride % 4 == 0);
+  m400::Epi400 epi{};
+  epi.fix_count = reinterpret_cast<int*>(g_dbg);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, s, wav, window, tw, mb, out, rows, length, row_stride,
+                     n_frames, scale, tiles_per_row, n_tiles, tiles_per_block, in_aligned, out_wide, epi);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int lab_mel400(const float* wav, const float* window, const float* tw, const aamd_mel_bands* b, float* out,
+                          int64_t rows, int64_t length, int64_t row_stride, int n_frames, float scale, int out_wide,
+                          int blocks_override, void* stream) {
+  MelBandsDev mb{};
+  mb.n_mels = b->n_mels; mb.max_width = b->max_width; mb.lo = b->lo; mb.width = b->width; mb.weights = b->weights;
+  mb.order = b->lane_order; mb.table400 = b->table400;
+  return launch<LAB_BITS>(wav, window, tw, mb, out, rows, length, row_stride, n_frames, scale, out_wide, blocks_override,
+                          (hipStream_t)stream);
+}
+extern "C" int lab_info(int* waves, int* lds_per_wave_dwords) {
+  *waves = m400::kWavesPerBlock;
+  *lds_per_wave_dwords = m400::Hop<8>::lds_dwords;
+  return LAB_BITS;
+}
