@@ -82,6 +82,8 @@ _SIGS = {
                                                   _P, _P, C.c_int64, _P]),
     "aamd_melspectrogram_pcm16_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.c_float,
                                                 _P, _P, C.c_int64, _P]),
+    "aamd_melspectrogram_pcm16_interleaved_f32": (C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(MelBands), _P,
+                                                            C.POINTER(StftDesc), C.c_float, _P, _P, C.c_int64, _P]),
     "aamd_spectrogram_grad_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
     "aamd_melspectrogram_grad_f32": (C.c_int, [_P, _P, C.POINTER(MelBands), C.c_int64, C.c_int32, C.c_int32, C.c_float, _P]),
     "aamd_kaldi_features_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(KaldiDesc), _P]),
@@ -141,7 +143,7 @@ def lib():
                 fn = getattr(h, name)   # AttributeError if the ABI symbol is missing
                 fn.restype = res
                 fn.argtypes = args
-            if h.aamd_abi_version() != 3:
+            if h.aamd_abi_version() != 4:
                 raise RuntimeError("audio_amd: ABI version mismatch between _lib.py and libaudio_amd.so")
             _lib = h
     return _lib

@@ -560,6 +560,41 @@ int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const
                       : launch_fft400_h<m400::EPI400_MEL, 10, int16_t>(g, mb, wav, window, twiddle, out, m400::Epi400{}, s);
 }
 
+int aamd_melspectrogram_pcm16_interleaved_f32(const int16_t* pcm, int32_t channels, const float* window, const float* twiddle,
+                                              const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
+                                              float gain, const float* mean, const float* invstddev, int64_t out_frames,
+                                              void* stream) {
+  if (channels == 1)
+    return aamd_melspectrogram_pcm16_f32(pcm, window, twiddle, bands, out, desc, gain, mean, invstddev, out_frames, stream);
+  if (channels != 2)
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: interleaved PCM is read directly for 1 or 2 channels only (transpose first)");
+  DeviceScope dev_scope_(pcm);
+  StftGeom g;
+  int rc = validate_desc(desc, g);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(pcm && window && twiddle && out, "null buffer");
+  AAMD_CHECK_ARG(g.rows % 2 == 0, "rows must be clips * channels");
+  AAMD_CHECK_ARG((mean == nullptr) == (invstddev == nullptr), "mean and invstddev come together");
+  AAMD_CHECK_ARG(desc->power > 0.0f && desc->onesided, "mel spectrogram needs power > 0 and a onesided spectrum");
+  AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(pcm) % 4 == 0, "interleaved stereo PCM must be 4-byte aligned");
+  MelBandsDev mb;
+  rc = validate_bands(bands, g.n_freq, mb);
+  if (rc != AAMD_OK) return rc;
+  if (!mel400_eligible(g, mb) || (g.hop != 160 && g.hop != 200))
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: int16 PCM input is served by the n_fft = 400, hop 160 / 200 kernel only");
+  hipStream_t s = (hipStream_t)stream;
+  const m400::PcmStereo* w2 = reinterpret_cast<const m400::PcmStereo*>(pcm);      // one (L, R) word per sample time
+  if (mean != nullptr) {
+    AAMD_CHECK_ARG(out_frames >= desc->n_frames, "out_frames must be >= n_frames");
+    m400::Epi400 epi{};
+    epi.gain = gain; epi.mean = mean; epi.invstd = invstddev; epi.out_frames = out_frames;
+    return g.hop == 160 ? launch_fft400_h<m400::EPI400_MEL_NORM, 8, m400::PcmStereo>(g, mb, w2, window, twiddle, out, epi, s)
+                        : launch_fft400_h<m400::EPI400_MEL_NORM, 10, m400::PcmStereo>(g, mb, w2, window, twiddle, out, epi, s);
+  }
+  return g.hop == 160 ? launch_fft400_h<m400::EPI400_MEL, 8, m400::PcmStereo>(g, mb, w2, window, twiddle, out, m400::Epi400{}, s)
+                      : launch_fft400_h<m400::EPI400_MEL, 10, m400::PcmStereo>(g, mb, w2, window, twiddle, out, m400::Epi400{}, s);
+}
+
 int aamd_spectrogram_grad_f32(const float* spec, const float* dpower, float* out, int64_t n, float power, void* stream) {
   DeviceScope dev_scope_(spec);
   AAMD_CHECK_ARG(spec && dpower && out, "null buffer");

@@ -92,6 +92,22 @@ struct Hop {
 // dwords after every pair_stride samples put the three pairs' strided rows on disjoint banks:
 //   float: (pair dwords + pad) = 20 (mod 32);  int16: two lanes share a dword, a pair's row spans 10 dwords, and
 //   (pair dwords + pad) = 44 (mod 64) puts the three rows at banks 0.., 44.., 24..
+// Input element types.  float and int16_t are planar rows (one channel per row).  PcmStereo is one SAMPLE TIME of
+// interleaved 16-bit stereo, (L, R) in one dword -- what a decoder hands over before the reference transposes it to
+// (channel, time) (torchaudio/_torchcodec.py:150-152): the kernel's rows are then (clip, channel) pairs, both rows of a clip
+// stage the same dwords (the float layout: one dword per sample time, conflict-free as for float) and the gather
+// takes the row's half-word.  Channel de-interleave, int16 -> float and the 1/32768 (folded into the window) cost nothing
+// beyond the conversion the planar int16 path already does.
+struct PcmStereo { uint32_t lr; };
+template <typename TIn> struct InTraits {
+  static constexpr int chans = 1;
+  AAMD_HD static float get(const TIn* p, int) { return (float)*p; }
+};
+template <> struct InTraits<PcmStereo> {
+  static constexpr int chans = 2;
+  AAMD_HD static float get(const PcmStereo* p, int ch) { return (float)(int16_t)(uint16_t)(p->lr >> (16 * ch)); }
+};
+
 template <int H, typename TIn>
 struct Stage {
   using HC = Hop<H>;
@@ -110,6 +126,8 @@ static_assert(Stage<8, float>::blk_data == Hop<8>::blk_data && Stage<8, float>::
               Stage<8, float>::pieces == Hop<8>::pieces && Stage<8, float>::ndma == Hop<8>::ndma, "float staging = Hop");
 static_assert(Stage<8, int16_t>::ok && Stage<8, int16_t>::pad == 12 && Stage<8, int16_t>::ndma == 3, "int16 staging, hop 160");
 static_assert(Stage<10, int16_t>::ok && Stage<5, float>::ok && Stage<10, float>::ok, "staging geometry");
+static_assert(sizeof(PcmStereo) == 4 && Stage<8, PcmStereo>::ok && Stage<10, PcmStereo>::ok &&
+              Stage<8, PcmStereo>::pieces == Stage<8, float>::pieces, "interleaved stereo stages like float");
 
 constexpr int kMelSlots = 20;                  // mels per round
 constexpr int kMelMaxRounds = 8;               // n_mels <= 160
@@ -391,18 +409,18 @@ AAMD_HD int stage_src_piece(int u) {   // staging piece u (16 B) <- tile piece (
 }
 
 template <int H, typename TIn = float>
-AAMD_HD void gather_lds(const LaneConst& c, const TIn* S, float (&X)[Hop<H>::nx]) {
+AAMD_HD void gather_lds(const LaneConst& c, const TIn* S, float (&X)[Hop<H>::nx], int chan = 0) {
   using HC = Hop<H>;
   using SG = Stage<H, TIn>;
   const TIn* src = S + (HC::pair_stride + SG::pad_elems) * c.p + c.pi;
 #pragma unroll
-  for (int q = 0; q < HC::nx; ++q) X[q] = (float)src[20 * q + SG::pad_elems * (q / (2 * H))];
+  for (int q = 0; q < HC::nx; ++q) X[q] = InTraits<TIn>::get(src + 20 * q + SG::pad_elems * (q / (2 * H)), chan);
 }
 
 // Unstaged tiles (clip edges: reflect padding; or inputs that are not 16-B aligned): direct loads.
 template <int H, typename TIn = float>
 AAMD_HD void gather_global(const LaneConst& c, const TIn* wav_row, int64_t length, int64_t t0,
-                           int n_frames, float (&X)[Hop<H>::nx]) {
+                           int n_frames, float (&X)[Hop<H>::nx], int chan = 0) {
   const int64_t ta = t0 + 2 * c.p;
   const int64_t i0 = ta * Hop<H>::hop - kPad + c.pi;
 #pragma unroll
@@ -410,7 +428,7 @@ AAMD_HD void gather_global(const LaneConst& c, const TIn* wav_row, int64_t lengt
     const int64_t i = i0 + 20 * q;
     // q < 20 belongs to frame a (and to a + 1 when q >= H); q >= 20 only to frame a + 1
     const bool need = (q < 20) ? (ta < n_frames) : (ta + 1 < n_frames);
-    X[q] = need ? (float)wav_row[reflect_idx(i, length)] : 0.0f;
+    X[q] = need ? InTraits<TIn>::get(wav_row + reflect_idx(i, length), chan) : 0.0f;
   }
 }
 
@@ -1060,7 +1078,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     return ti;
   };
   auto stage_issue = [&](const TileInfo& ti) {
-    const TIn* src = wav + ti.row * row_stride + (ti.t0 * kHop - kPad);
+    const TIn* src = wav + (ti.row / InTraits<TIn>::chans) * row_stride + (ti.t0 * kHop - kPad);   // stereo: rows 2 i, 2 i + 1 = clip i
     if (LAB & 32) src = wav + 6 * kHop;                 // lab: always the same (cache-resident) tile
 #pragma unroll
     for (int k = 0; k < SG::ndma; ++k)
@@ -1099,9 +1117,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   }
   float Xn[HC::nx];   // lab bit 15: the next tile's samples, in flight
   auto gload = [&](const TileInfo& ti) {
-    const TIn* src = wav + ti.row * row_stride + (ti.t0 * kHop - kPad) + (HC::pair_stride * c.p + c.pi);
+    const TIn* src = wav + (ti.row / InTraits<TIn>::chans) * row_stride + (ti.t0 * kHop - kPad) + (HC::pair_stride * c.p + c.pi);
 #pragma unroll
-    for (int q = 0; q < HC::nx; ++q) Xn[q] = (float)src[20 * q];
+    for (int q = 0; q < HC::nx; ++q) Xn[q] = InTraits<TIn>::get(src + 20 * q, (int)(ti.row % InTraits<TIn>::chans));
   };
   if (LAB & 32768) {
 #pragma unroll
@@ -1139,10 +1157,11 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 #pragma unroll
         for (int q = 0; q < HC::nx; ++q) X[q] = (float)(q + lane) * scale;
       } else {
-        gather_lds<H, TIn>(c, reinterpret_cast<const TIn*>(lds + kSOff), X);
+        gather_lds<H, TIn>(c, reinterpret_cast<const TIn*>(lds + kSOff), X, (int)(cur.row % InTraits<TIn>::chans));
       }
     } else {
-      gather_global<H, TIn>(c, wav + cur.row * row_stride, length, cur.t0, n_frames, X);
+      gather_global<H, TIn>(c, wav + (cur.row / InTraits<TIn>::chans) * row_stride, length, cur.t0, n_frames, X,
+                            (int)(cur.row % InTraits<TIn>::chans));
     }
     phase_a<H, kWinRegs, (LAB & 16384) != 0>(c, X, lds, winr, twr);
     if ((LAB & 32768) && nxt.staged) gload(nxt);        // X is dead: the next tile's samples fly during phases B and C

@@ -757,13 +757,32 @@ def _melspectrogram_plan(waveform: Tensor, pad: int, window: Tensor, fb: Tensor,
 
 def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_length: int, gain: float,
                  mean: Tensor, invstddev: Tensor, right_padding: int,
-                 bands: Optional[MelBandsOnDevice] = None) -> Tensor:
+                 bands: Optional[MelBandsOnDevice] = None, interleaved_channels: int = 0) -> Tensor:
     """MelSpectrogram (power 2, centre / reflect) with the RNN-T feature post-processing fused
-    (pipelines/rnnt_pipeline.py:16-47, 319-326).  Returns (rows, T + right_padding, n_mels), the padding rows zero."""
-    pcm16 = waveform.dtype == torch.int16
+    (pipelines/rnnt_pipeline.py:16-47, 319-326).  Returns (rows, T + right_padding, n_mels), the padding rows zero.
+
+    `interleaved_channels` = C > 0: `waveform` is int16 PCM laid out (..., time, C) -- the decoder's interleaved order, which
+    the reference transposes to (channel, time) before any transform (torchaudio/_torchcodec.py:150-152).  Rows of the
+    result are then (clip, channel) pairs.  C = 1, 2 are read directly by the kernel (de-interleave in the load); any other
+    count is transposed first."""
     L0 = _lib.lib()
-    if pcm16 and not (n_fft == 400 and hop_length in (160, 200) and waveform.shape[-1] > 400
-                      and not (L0.aamd_set_kernel_policy(-1) & _lib.POLICY_FORCE_GENERIC)):
+    if interleaved_channels:
+        C_ = int(interleaved_channels)
+        if waveform.dtype != torch.int16 or waveform.shape[-1] != C_:
+            raise ValueError("audio_amd: interleaved PCM must be int16 with a trailing channel dimension")
+        n_time = waveform.shape[-2]
+        direct = (C_ in (1, 2) and waveform.is_cuda and n_fft == 400 and hop_length in (160, 200) and n_time > 400
+                  and not (L0.aamd_set_kernel_policy(-1) & _lib.POLICY_FORCE_GENERIC))
+        if direct:
+            bands_d = bands if bands is not None else _mel_bands(fb, waveform.device)
+            direct = bands_d.n_mels <= 160 and bands_d.max_width <= 62
+        if not direct:      # the planar path (which itself converts first when it has to)
+            planar = waveform.transpose(-1, -2).contiguous()
+            return _mel_lognorm(planar, window, fb, n_fft, hop_length, gain, mean, invstddev, right_padding, bands)
+    pcm16 = waveform.dtype == torch.int16
+    if pcm16 and not interleaved_channels and not (
+            n_fft == 400 and hop_length in (160, 200) and waveform.shape[-1] > 400
+            and not (L0.aamd_set_kernel_policy(-1) & _lib.POLICY_FORCE_GENERIC)):
         waveform, pcm16 = waveform.to(torch.float32) * (1.0 / 32768.0), False   # shapes the PCM kernel does not serve
     if pcm16:
         if not waveform.is_cuda:
@@ -773,8 +792,15 @@ def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_l
         _require_device(waveform, "waveform")
     dev = waveform.device
     window = window.to(device=dev, dtype=torch.float32)
-    x2 = _rows2d(waveform)
-    desc = _stft_desc(x2, 0, window, n_fft, hop_length, 2.0, False, True, "reflect", True)
+    if interleaved_channels:
+        clips = waveform.reshape(-1, waveform.shape[-2], interleaved_channels).contiguous()   # (clips, time, C)
+        # the geometry of (clips * C) planar rows of `time` samples; the entry below is told they are interleaved
+        probe = torch.empty((clips.shape[0] * interleaved_channels, clips.shape[1]), dtype=torch.float32, device="meta")
+        desc = _stft_desc(probe, 0, window, n_fft, hop_length, 2.0, False, True, "reflect", True)
+        x2 = clips
+    else:
+        x2 = _rows2d(waveform)
+        desc = _stft_desc(x2, 0, window, n_fft, hop_length, 2.0, False, True, "reflect", True)
     if pcm16:
         desc.scale = desc.scale / 32768.0          # float = int16 / 32768 (what the decoder's normalisation does)
     if bands is None:
@@ -783,17 +809,22 @@ def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_l
     invstddev = invstddev.to(device=dev, dtype=torch.float32).contiguous()
     if mean.numel() != bands.n_mels or invstddev.numel() != bands.n_mels:
         raise RuntimeError(f"audio_amd: global statistics must have n_mels = {bands.n_mels} entries")
-    if pcm16 and not (bands.n_mels <= 160 and bands.max_width <= 62):   # filterbank outside the radix-20x20 kernel
+    if pcm16 and not interleaved_channels and not (bands.n_mels <= 160 and bands.max_width <= 62):   # filterbank outside the radix-20x20 kernel
         return _mel_lognorm(waveform.to(torch.float32) * (1.0 / 32768.0), window, fb, n_fft, hop_length, gain, mean,
                             invstddev, right_padding, bands)
     T = desc.n_frames
     # Rows of T + right_padding frames come straight from the kernel only on the radix-20x20 fast path.  Its
     # eligibility (csrc/c_api.hip: mel400_eligible -- hop, clip length, filterbank geometry, kernel policy) is mirrored
     # here; every other shape writes T frames and is padded afterwards, as the reference does.
-    fused_pad = (right_padding > 0 and n_fft == 400 and hop_length in (100, 160, 200) and x2.shape[1] > 400
+    n_time = x2.shape[-2] if interleaved_channels else x2.shape[1]
+    fused_pad = (right_padding > 0 and n_fft == 400 and hop_length in (100, 160, 200) and n_time > 400
                  and bands.n_mels <= 160 and bands.max_width <= 62
                  and not (L0.aamd_set_kernel_policy(-1) & _lib.POLICY_FORCE_GENERIC))
-    entry = L0.aamd_melspectrogram_pcm16_f32 if pcm16 else L0.aamd_melspectrogram_lognorm_f32
+    if interleaved_channels:
+        def entry(wav, *rest):
+            return L0.aamd_melspectrogram_pcm16_interleaved_f32(wav, int(interleaved_channels), *rest)
+    else:
+        entry = L0.aamd_melspectrogram_pcm16_f32 if pcm16 else L0.aamd_melspectrogram_lognorm_f32
 
     def launch(frames: int) -> Tensor:
         out = torch.empty((desc.rows, frames, bands.n_mels), dtype=torch.float32, device=dev)
@@ -854,6 +885,7 @@ class MfccFusedState:
         self.pending = None           # (pinned int32 tensor, event, n_tiles)
         self.last_share = None
         self.avoid = 0                # calls left on the two-kernel path
+        self.force = False            # MFCC.fused = True: always the one-kernel path (the observed share is only reported)
         self.path = None
         self.calls_fused = 0
         self.calls_two_kernel = 0
@@ -868,6 +900,9 @@ class MfccFusedState:
 
     def want_fused(self) -> bool:
         self.poll()
+        if self.force:
+            self.avoid = 0
+            return True
         if self.avoid > 0:
             self.avoid -= 1
             return False

@@ -61,9 +61,19 @@ class RNNTFeatureExtractor(torch.nn.Module):
         self.right_padding = right_padding
         self.gain = gain
 
-    def features(self, waveform: Tensor) -> Tensor:
-        """(..., time) float32 in [-1, 1], or int16 PCM -> (..., frames + right_padding, n_mels)."""
+    def features(self, waveform: Tensor, channels_first: bool = True) -> Tensor:
+        """(..., time) float32 in [-1, 1], or int16 PCM -> (..., frames + right_padding, n_mels).
+
+        ``channels_first=False`` (EXTENSION; the flag name is the reference loader's, torchaudio/_torchcodec.py:150-152):
+        ``waveform`` is int16 PCM in the decoder's interleaved order ``(..., time, channels)``; the result is
+        ``(..., channels, frames + right_padding, n_mels)`` -- what the reference computes from the transposed, converted
+        tensor -- with the de-interleave done inside the kernel's load for mono and stereo."""
         sp = self.mel.spectrogram
+        if not channels_first:
+            chans = int(waveform.shape[-1])
+            out = F._mel_lognorm(waveform, sp.window, self.mel.mel_scale.fb, sp.n_fft, sp.hop_length, self.gain, self.mean,
+                                 self.invstddev, self.right_padding, interleaved_channels=chans)
+            return out.view(tuple(waveform.shape[:-2]) + (chans,) + out.shape[-2:])
         out = F._mel_lognorm(waveform, sp.window, self.mel.mel_scale.fb, sp.n_fft, sp.hop_length, self.gain, self.mean,
                              self.invstddev, self.right_padding)
         return out.view(tuple(waveform.shape[:-1]) + out.shape[-2:])

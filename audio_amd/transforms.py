@@ -18,6 +18,14 @@ from torch import Tensor
 
 from . import _host, _lib
 from . import functional as F
+from . import _ops  # noqa: F401  (registers torch.ops.audio_amd.* -- the opaque module-level ops torch.compile sees)
+
+
+def _norm_mode(normalized) -> int:
+    """`normalized` of the reference's Spectrogram as the op schema's integer: 0 none, 1 "frame_length", 2 "window" / True."""
+    if normalized == "frame_length":
+        return 1
+    return 2 if (normalized is True or normalized == "window") else 0
 
 __all__ = ["Spectrogram", "InverseSpectrogram", "GriffinLim", "TimeStretch", "PitchShift", "Speed", "SpeedPerturbation",
            "MelScale", "MelSpectrogram", "AmplitudeToDB", "MFCC", "Resample", "FFTConvolve"]
@@ -63,6 +71,10 @@ class Spectrogram(torch.nn.Module):
             )
 
     def forward(self, waveform: Tensor) -> Tensor:
+        if torch.compiler.is_compiling():          # one opaque op with a fake kernel (see MelSpectrogram.forward)
+            return torch.ops.audio_amd.spectrogram(waveform, self.window, self.pad, self.n_fft, self.hop_length,
+                                                   self.win_length, self.power, _norm_mode(self.normalized), self.center,
+                                                   self.pad_mode, self.onesided)
         return F.spectrogram(waveform, self.pad, self.window, self.n_fft, self.hop_length, self.win_length,
                              self.power, self.normalized, self.center, self.pad_mode, self.onesided)
 
@@ -351,6 +363,13 @@ class MelSpectrogram(torch.nn.Module):
                                  sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode, db=db)
 
     def forward(self, waveform: Tensor) -> Tensor:
+        if torch.compiler.is_compiling():
+            # torch.compile / torch.export: the module is ONE opaque op with a fake kernel (audio_amd/_ops.py); the host-side
+            # plan caches below (tensor identities, data pointers, ctypes) are not something a tracer should look into
+            sp = self.spectrogram
+            return torch.ops.audio_amd.mel_spectrogram(waveform, sp.window, self.mel_scale.fb, sp.pad, sp.n_fft,
+                                                       sp.hop_length, sp.win_length, float(sp.power),
+                                                       _norm_mode(sp.normalized), sp.center, sp.pad_mode)
         F._reject_param_grad(window=self.spectrogram.window, fb=self.mel_scale.fb)
         if waveform.dtype == torch.float64 and waveform.is_cuda:
             # precision path: the reference composition (_transforms.py:612-622) over the float64 STFT kernels
@@ -441,6 +460,11 @@ class MFCC(torch.nn.Module):
         return d
 
     def forward(self, waveform: Tensor) -> Tensor:
+        if torch.compiler.is_compiling():          # one opaque op with a fake kernel (see MelSpectrogram.forward)
+            sp = self.MelSpectrogram.spectrogram
+            return torch.ops.audio_amd.mfcc(waveform, sp.window, self.MelSpectrogram.mel_scale.fb, self.dct_mat, sp.pad,
+                                            sp.n_fft, sp.hop_length, sp.win_length, float(sp.power),
+                                            _norm_mode(sp.normalized), sp.center, sp.pad_mode, self.log_mels, self.top_db)
         F._reject_param_grad(window=self.MelSpectrogram.spectrogram.window, fb=self.MelSpectrogram.mel_scale.fb)
         if not waveform.requires_grad:
             F._reject_param_grad(dct_mat=self.dct_mat)     # (the differentiable path below does propagate into it)
@@ -472,7 +496,8 @@ class MFCC(torch.nn.Module):
         fused = getattr(self, "fused", "auto")
         if st is None or fused is False:
             return None
-        if fused is True:
+        st.force = fused is True      # True: always one kernel; "auto": follow the observed share of redone tiles
+        if st.force:
             st.avoid = 0
         return st
 

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define AAMD_ABI_VERSION 3
+#define AAMD_ABI_VERSION 4
 
 enum {
   AAMD_OK = 0,
@@ -206,6 +206,18 @@ int aamd_melspectrogram_lognorm_f32(const float* wav, const float* window, const
 int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const float* twiddle,
                                   const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, float gain,
                                   const float* mean, const float* invstddev, int64_t out_frames, void* stream);
+
+/* The same, reading INTERLEAVED 16-bit PCM: pcm = int16[clips][row_stride][channels] (time-major, channels adjacent: the
+ * decoder's native order, which the reference transposes to (channel, time) before any transform,
+ * torchaudio/_torchcodec.py:150-152).  desc->rows = clips * channels (row r = clip r / channels, channel r % channels:
+ * the output is laid out (clip, channel, frames, n_mels)); desc->length and desc->row_stride count SAMPLE TIMES per
+ * channel.  channels = 1 is aamd_melspectrogram_pcm16_f32; channels = 2 is served by the same kernel (both rows of a clip
+ * stage the same 32-bit (L, R) words and the gather takes the row's half-word: de-interleave, conversion and 1 / 32768 in
+ * the load); any other count: AAMD_EUNSUPPORTED (transpose first). */
+int aamd_melspectrogram_pcm16_interleaved_f32(const int16_t* pcm, int32_t channels, const float* window, const float* twiddle,
+                                              const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
+                                              float gain, const float* mean, const float* invstddev, int64_t out_frames,
+                                              void* stream);
 
 /* Backward of the |X|^p stage of F.spectrogram (functional.py:141-145), element-wise over n bins:
  *   out = dpower * p * |X|^(p-2) * X   (interleaved complex; 0 where X = 0 and p < 2)

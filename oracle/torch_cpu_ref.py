@@ -88,3 +88,45 @@ def time_mel_baseline_single_thread(n_clips: int, seconds: float, sample_rate: i
     finally:
         torch.set_num_threads(n)
     return v
+
+
+def sweep_mel_baseline(n_clips: int, seconds: float, sample_rate: int = 16000, n_fft: int = 400, hop: int = 160,
+                       n_mels: int = 80, budget_s: float = 3.0, seed: int = 1234, counts=None):
+    """the reference's CPU composition at its BEST over host thread counts.  One big call does not scale
+    with torch's intra-op pool (round 2: 128 threads = 1 thread), so the clips are dealt to `threads` Python threads,
+    each running the single-threaded composition on its contiguous share (the ops release the GIL).  Returns a list of
+    {"threads", "audio_sec_per_sec", "calls"} for threads in {1, 8, 16, 32, 64, all host cores}."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from audio_amd import _host
+    cores = os.cpu_count() or 1
+    counts = counts or sorted({c for c in (1, 8, 16, 32, 64, cores) if c <= cores})
+    g = torch.Generator().manual_seed(seed)
+    x = (0.5 * torch.randn(n_clips, int(seconds * sample_rate), generator=g)).clamp_(-1, 1)
+    window = torch.hann_window(n_fft)
+    fb = _host.melscale_fbanks(n_fft // 2 + 1, 0.0, float(sample_rate // 2), n_mels, sample_rate)
+    prev = torch.get_num_threads()
+    out = []
+    try:
+        torch.set_num_threads(1)
+        mel_spectrogram(x[:2], window, fb, n_fft, hop)      # warm-up
+        for th in counts:
+            use = min(th, n_clips)
+            bounds = [(n_clips * i // use, n_clips * (i + 1) // use) for i in range(use)]
+
+            def work(b):
+                return mel_spectrogram(x[b[0]:b[1]], window, fb, n_fft, hop).shape
+
+            with ThreadPoolExecutor(max_workers=use) as pool:
+                t_best, t_total, calls = float("inf"), 0.0, 0
+                while calls < 2 or (t_total < budget_s and calls < 40):
+                    t0 = time.perf_counter()
+                    list(pool.map(work, bounds))
+                    dt = time.perf_counter() - t0
+                    t_best, t_total, calls = min(t_best, dt), t_total + dt, calls + 1
+                    if t_total > 2.5 * budget_s:
+                        break
+            out.append({"threads": th, "audio_sec_per_sec": n_clips * seconds / t_best, "calls": calls})
+    finally:
+        torch.set_num_threads(prev)
+    return out

@@ -529,7 +529,7 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
   };
   // what the 5 LDS-DMA instructions of stage_issue() do: staging piece u <- tile piece stage_src_piece(u)
   auto stage = [&](int64_t row, int64_t t0) {
-    const TIn* src = wav + row * row_stride + (t0 * kHop - kPad);
+    const TIn* src = wav + (row / InTraits<TIn>::chans) * row_stride + (t0 * kHop - kPad);
     using SG = Stage<H, TIn>;
     for (int u = 0; u < 64 * SG::ndma; ++u)      // 16-B pieces, byte for byte
       std::memcpy(reinterpret_cast<char*>(lds + kSOff) + 16 * u,
@@ -552,10 +552,11 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
       ++g_mfcc.fix_count;
       if (cur_staged) stage(row, t0);
     }
-    const TIn* wr = wav + row * row_stride;
+    const TIn* wr = wav + (row / InTraits<TIn>::chans) * row_stride;
+    const int chan = (int)(row % InTraits<TIn>::chans);
     for (int l = 0; l < 64; ++l) {
-      if (cur_staged) gather_lds<H, TIn>(c[l], reinterpret_cast<const TIn*>(lds + kSOff), X[l]);
-      else gather_global<H, TIn>(c[l], wr, length, t0, n_frames, X[l]);
+      if (cur_staged) gather_lds<H, TIn>(c[l], reinterpret_cast<const TIn*>(lds + kSOff), X[l], chan);
+      else gather_global<H, TIn>(c[l], wr, length, t0, n_frames, X[l], chan);
     }
     for (int l = 0; l < 64; ++l) phase_a<H>(c[l], X[l], lds);
     for (int l = 0; l < 64; ++l) phase_b1_load(c[l], lds, vr[l], vi[l]);
@@ -662,6 +663,13 @@ int sim_melspec400(const void* wav, const float* window, const float* tw400, con
                                                row_stride, n_frames, scale, epi_mode, db, gmax, rows_per_group, power, want_wide)
 #define SIM_M400_I16(H) return sim_melspec400_h<H, int16_t>(static_cast<const int16_t*>(wav), window, tw400, bands, out, rows, \
                                                length, row_stride, n_frames, scale, epi_mode, db, gmax, rows_per_group, power, want_wide)
+#define SIM_M400_ST(H) return sim_melspec400_h<H, aamd::m400::PcmStereo>(static_cast<const aamd::m400::PcmStereo*>(wav), window, tw400, bands, out, rows, \
+                                               length, row_stride, n_frames, scale, epi_mode, db, gmax, rows_per_group, power, want_wide)
+  if (in_i16 == 2) {            // interleaved 16-bit stereo: rows = 2 x clips, row_stride in sample times
+    if (hop == 160) SIM_M400_ST(8);
+    if (hop == 200) SIM_M400_ST(10);
+    return -4;
+  }
   if (in_i16) {
     if (hop == 160) SIM_M400_I16(8);
     if (hop == 200) SIM_M400_I16(10);

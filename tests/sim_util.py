@@ -92,8 +92,14 @@ def sim_mel_generic(x, window_padded, bands, desc):
 
 def _sim_fft400(x, window, bands, scale, epi, db=None, gmax=None, rows_per_group=1, power=2.0, out_width=None,
                 wide=0, hop=160, out_frames=None, i16=False):
+    """i16: False = float rows, True = planar int16 rows, 2 = interleaved 16-bit stereo (clips, time, 2): the kernel's rows are
+    then (clip, channel) pairs."""
     x = np.ascontiguousarray(x, dtype=np.int16 if i16 else np.float32)
-    rows, length = x.shape
+    if i16 == 2:
+        assert x.ndim == 3 and x.shape[-1] == 2
+        rows, length = 2 * x.shape[0], x.shape[1]
+    else:
+        rows, length = x.shape
     w = np.ascontiguousarray(window, dtype=np.float32)
     tw = np.ascontiguousarray(_host.twiddle_table(400))
     T = _host.frame_count(length, 400, hop, True)
@@ -152,7 +158,7 @@ def sim_mel400_norm(x, window, bands, gain, mean, invstddev, right_padding=0, ho
     """Fused RNN-T feature epilogue: ((plog(mel * gain)) - mean) * invstddev, rows of T + right_padding frames
     (the padding rows stay zero).  Returns frame-major (rows, T + right_padding, n_mels)."""
     x = np.ascontiguousarray(x, dtype=np.int16 if i16 else np.float32)
-    T = _host.frame_count(x.shape[1], 400, hop, True)
+    T = _host.frame_count(x.shape[1], 400, hop, True)       # (clips, time, 2) for interleaved stereo: shape[1] is time
     stats = np.ascontiguousarray(np.concatenate([mean, invstddev]), dtype=np.float32)
     o = _sim_fft400(x, window, bands, scale, 3, db=[gain, float(T + right_padding)], gmax=stats, out_width=bands.n_mels,
                     hop=hop, out_frames=T + right_padding, i16=i16)

@@ -630,6 +630,29 @@ def test_sim_mel400_int16_pcm_input(hop):
     assert np.array_equal(got2, ref2)
 
 
+@pytest.mark.parametrize("hop", [160, 200])
+def test_sim_mel400_interleaved_stereo_pcm_input(hop):
+    """SURVEY 8(f) rank 4, upstream half: interleaved 16-bit stereo (time, channel) -- what the decoder
+    produces before the reference transposes it (torchaudio/_torchcodec.py:150-152) -- read straight by the kernel; rows
+    (clip, channel) come out bit-identical to the planar int16 path fed `pcm.transpose(-1, -2)`."""
+    rng = np.random.default_rng(hop + 1)
+    pcm = rng.integers(-20000, 20000, size=(2, 8000, 2), dtype=np.int16)      # (clip, time, channel)
+    pcm[0, :37, 1] = 32767
+    pcm[1, -5:, 0] = -32768
+    fb = _host.melscale_fbanks(201, 0.0, 8000.0, 80, 16000, None, "htk")
+    bands = S.HostBands(fb.numpy(), permute=True)
+    w = torch.hann_window(400).numpy()
+    planar = np.ascontiguousarray(np.swapaxes(pcm, -1, -2)).reshape(4, 8000)      # rows (clip, channel)
+    ref = S.sim_mel400(planar, w, bands, scale=1.0 / 32768.0, hop=hop, i16=True)
+    got = S.sim_mel400(pcm, w, bands, scale=1.0 / 32768.0, hop=hop, i16=2)
+    assert got.shape == ref.shape == (4, 80, 8000 // hop + 1)
+    assert np.array_equal(got, ref)
+    # a length whose rows are not 16-byte multiples: every tile takes the unstaged (direct-load) path
+    got2 = S.sim_mel400(np.ascontiguousarray(pcm[:, :7999]), w, bands, scale=1.0 / 32768.0, hop=hop, i16=2)
+    ref2 = S.sim_mel400(np.ascontiguousarray(planar[:, :7999]), w, bands, scale=1.0 / 32768.0, hop=hop, i16=True)
+    assert np.array_equal(got2, ref2)
+
+
 @pytest.mark.parametrize("hop,L", [(160, 4000), (160, 2403), (100, 2500), (200, 3100), (160, 500), (200, 3600), (160, 301),
                                    (100, 250), (200, 12000)])
 def test_sim_istft400_roundtrip_and_adjoint(hop, L):

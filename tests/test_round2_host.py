@@ -375,3 +375,85 @@ def test_lfilter_sections_are_cached_per_tensor_and_per_values(monkeypatch):
     bad_a = torch.tensor([1.0, -1.999, 0.9995, 0.0])
     bad_b = torch.tensor([1.0, 0.0, 0.0, 0.0])
     assert F._lfilter_sections(bad_a, bad_b, bad_a.reshape(1, -1), bad_b.reshape(1, -1)) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cutoff", ["batch_global_2d", "per_item_3d"])
+def test_mfcc_cfg4_full_size_rows_against_the_oracle(cutoff):
+    """BASELINE configs[3] at FULL size (512 x 160 000, n_mfcc = 40): rows 0, 5 and 511 against the float64 oracle
+    (the full-size check compared the product with itself).  2-D input: ONE top_db cut-off from the
+    maximum over the WHOLE batch (functional.py:393-402) -- that maximum is taken from an independent float64 evaluation
+    of all 512 rows (ATen CPU stft in double), the rows themselves from the numpy oracle.  Row 5 is 80 dB down, so in the
+    2-D case nearly all of it lies under the cut-off (the clamp decides), in the 3-D case (one cut-off per item) none."""
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = (0.5 * torch.randn(512, 160000, device="cuda", generator=g)).clamp_(-1, 1)
+    x[5] *= 1e-4
+    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
+    with torch.no_grad():
+        y = m(x) if cutoff == "batch_global_2d" else m(x[:, None, :])[:, 0]
+    assert y.shape == (512, 40, 1001)
+    fb = m.MelSpectrogram.mel_scale.fb.double().cpu()
+    win = m.MelSpectrogram.spectrogram.window.double().cpu()
+    dct = m.dct_mat.double().cpu().numpy()
+    xc = x.cpu()
+    gmax = None
+    if cutoff == "batch_global_2d":
+        best = -np.inf
+        for i in range(0, 512, 64):          # float64 dB maximum of the whole batch, independent of the product and of numpy
+            spec = torch.stft(xc[i:i + 64].double(), 400, 160, window=win, center=True, pad_mode="reflect",
+                              return_complex=True).abs().pow(2)
+            mel = torch.matmul(spec.transpose(-1, -2), fb)
+            best = max(best, float((10.0 * torch.log10(torch.clamp(mel, min=1e-10))).max()))
+        gmax = best
+    for row in (0, 5, 511):
+        mel = O.mel_spectrogram(xc[row].numpy().astype(np.float64), win.numpy(), fb.numpy(), 400, 160)
+        db = 10.0 * np.log10(np.maximum(mel, 1e-10))
+        cut = (gmax if gmax is not None else db.max()) - 80.0
+        want = (np.maximum(db, cut).T @ dct).T
+        got = y[row].cpu().numpy()
+        clamped = float((db < cut).mean())
+        assert (clamped > 0.9) if (row == 5 and gmax is not None) else (clamped < 0.01), (row, clamped)
+        # MFCC is on a dB scale (c0 ~ -600 .. 200): peak-relative AND absolute (the fused epilogue's hardware log2 is
+        # good to ~2e-5 dB, a coefficient sums 80 of them with |weights| <= 0.16)
+        assert peak_rel_err(got, want) <= 1e-5, (row, cutoff)
+        assert float(np.abs(got - want).max()) <= 1e-3, (row, cutoff)
+
+
+@pytest.mark.gpu
+def test_lfilter_cfg5a_fused_cascade_full_size_rows_against_float64_chain():
+    """BASELINE configs[4] (lfilter half), per-GPU shard 32 x 8 ch x 480 000 samples: two rows of the FUSED 4-biquad
+    cascade (one launch: every stage clamped, as four reference F.lfilter calls clamp) against a float64 chain of scipy
+    direct forms with the clamp after every stage -- not against four product calls.  The input is
+    loud enough that the first stages do clip."""
+    import math
+    import scipy.signal
+    import audio_amd.functional as F
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = (torch.rand(32, 8, 480000, device="cuda", generator=g) - 0.5) * 2.4
+    A, B = [], []
+    for fc in (8000.0, 6000.0, 4000.0, 3000.0):
+        w0 = 2 * math.pi * fc / 48000
+        alpha = math.sin(w0) / 2 / 0.707
+        A.append([1 + alpha, -2 * math.cos(w0), 1 - alpha])
+        B.append([(1 - math.cos(w0)) / 2, 1 - math.cos(w0), (1 - math.cos(w0)) / 2])
+    a = torch.tensor(A, dtype=torch.float32)
+    b = torch.tensor(B, dtype=torch.float32)
+    with torch.no_grad():
+        y = F.biquad_cascade(x, a.cuda(), b.cuda(), clamp=True)
+    assert y.shape == x.shape
+    for (n, c) in ((0, 0), (31, 7)):
+        ref = x[n, c].cpu().numpy().astype(np.float64)
+        clipped = []
+        for s in range(4):
+            # the kernel normalises by a0 in float32 exactly as the reference does (lfilter.cpp / filtering.py:1063-1064)
+            an = (a[s] / a[s, 0]).numpy().astype(np.float64)
+            bn = (b[s] / a[s, 0]).numpy().astype(np.float64)
+            ref = scipy.signal.lfilter(bn, an, ref)
+            clipped.append(float((np.abs(ref) > 1.0).mean()))
+            ref = np.clip(ref, -1.0, 1.0)
+        assert clipped[0] > 1e-4, clipped                 # the clamp of an inner stage matters in this test
+        got = y[n, c].cpu().numpy()
+        assert peak_rel_err(got, ref) <= 1e-4, (n, c)
+        assert float(np.abs(got - ref).max()) <= 5e-5, (n, c)

@@ -169,3 +169,19 @@ def test_boxed_op_uses_the_current_stream():
             y = mel(x * 1.0)                                      # producer and consumer on s: ordered only on s
         s.synchronize()
     assert torch.equal(y, ref)
+
+
+@pytest.mark.gpu
+def test_torch_compile_fullgraph_melspectrogram_equals_eager():
+    """`torch.compile(fullgraph=True)` over the headline module (eager backend: the captured graph is one audio_amd::* op,
+    tests/test_ops_registration.py) gives the eager result bit for bit, for MelSpectrogram and MFCC."""
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(0)
+    x = (0.3 * torch.randn(3, 16000, generator=g)).cuda()
+    for mod in (T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).cuda(),
+                T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()):
+        with torch.no_grad():
+            want = mod(x)
+            got = torch.compile(mod, fullgraph=True, backend="eager")(x)
+        assert got.shape == want.shape and got.stride() == want.stride()
+        assert torch.equal(got, want)
