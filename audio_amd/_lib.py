@@ -38,7 +38,8 @@ class MfccFused(C.Structure):
     """aamd_mfcc_fused (include/audio_amd.h)."""
     _fields_ = [("dct_frag", C.c_void_p), ("n_mfcc", C.c_int32), ("pass_", C.c_int32), ("multiplier", C.c_float),
                 ("amin", C.c_float), ("db_multiplier", C.c_float), ("top_db", C.c_float), ("group_max", C.c_void_p),
-                ("rows_per_group", C.c_int64), ("tile_min", C.c_void_p), ("fix_count", C.c_void_p)]
+                ("rows_per_group", C.c_int64), ("tile_min", C.c_void_p), ("fix_count", C.c_void_p),
+                ("tile_list", C.c_void_p)]
 
 
 class ResampleBands(C.Structure):

@@ -257,14 +257,19 @@ int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, co
 
 template <int EPI, int H, typename TIn, int NR>
 int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, const float* window,
-                     const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s) {
+                     const float* twiddle, float* out, const m400::Epi400& epi_in, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
   const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
   const int64_t n_tiles = g.rows * tiles_per_row;
   AAMD_CHECK_ARG(n_tiles < (1ll << 31), "too many frames for one launch");
   const int wpb = m400::kWavesPerBlock;
   const int wdw = m400::Hop<H>::lds_dwords;
-  const size_t lds = (EPI == m400::EPI400_SPEC) ? m400::lds_bytes(0, 1, wdw) : m400::lds_bytes(mb.n_mels, mb.max_width, wdw);
+  size_t lds = (EPI == m400::EPI400_SPEC) ? m400::lds_bytes(0, 1, wdw) : m400::lds_bytes(mb.n_mels, mb.max_width, wdw);
+  m400::Epi400 epi = epi_in;
+  if (EPI == m400::EPI400_MFCC && m400::lds_bytes(mb.n_mels, mb.max_width, wdw, true) <= dev_props().lds_per_block_optin) {
+    lds = m400::lds_bytes(mb.n_mels, mb.max_width, wdw, true);      // room for the DCT fragments next to the band table
+    epi.frag_in_lds = 1;
+  }
   if (lds > dev_props().lds_per_block_optin)
     return fail(AAMD_EUNSUPPORTED, "audio_amd: mel filterbank too large for the LDS of this device");
   auto kern = m400::melspec400_kernel<0, EPI, H, TIn, NR>;
@@ -463,7 +468,19 @@ int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twid
   epi.multiplier = f->multiplier; epi.amin = f->amin; epi.db_sub = f->multiplier * f->db_multiplier;
   epi.group_max = f->group_max; epi.rows_per_group = f->rows_per_group;
   epi.dct_frag = f->dct_frag; epi.n_mfcc = f->n_mfcc; epi.top_db = f->top_db; epi.tile_min = f->tile_min;
-  epi.fix_count = f->fix_count; epi.fixup = f->pass;
+  epi.fix_count = f->fix_count; epi.fixup = f->pass; epi.fix_list = f->tile_list;
+  if (f->pass == 1) {
+    // compact the tiles under their group's cut-off (known now: the caller reduced group_max over ranks between the passes)
+    AAMD_CHECK_ARG(f->fix_count && f->tile_list, "pass 1 of the fused MFCC needs fix_count and tile_list");
+    const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
+    const int64_t n_tiles = g.rows * tiles_per_row;
+    AAMD_HIP(hipMemsetAsync(f->fix_count, 0, sizeof(int32_t), (hipStream_t)stream));
+    hipLaunchKernelGGL(m400::mfcc_fix_list_kernel, dim3(grid_for(n_tiles, 256, dev_props().cu_count * 4)), dim3(256), 0,
+                       (hipStream_t)stream, f->tile_min, f->group_max, f->rows_per_group, tiles_per_row, n_tiles, f->top_db,
+                       f->tile_list, f->fix_count);
+    rc = launch_check();
+    if (rc != AAMD_OK) return rc;
+  }
   static const int mfcc_lab = [] { const char* e = std::getenv("AAMD_MFCC_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
   epi.lab = mfcc_lab;
   hipStream_t s = (hipStream_t)stream;
@@ -725,6 +742,7 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
   if (g.n_stages < 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft has too many prime factors");
   og.interior = adjoint ? 0.5f : 1.0f;
   og.scale = desc->scale * (adjoint ? 1.0f : 1.0f / (float)desc->n_fft);
+  og.scale_d = (double)desc->scale * (adjoint ? 1.0 : 1.0 / (double)desc->n_fft);
   if (g.n_fft == 400 && (g.hop == 100 || g.hop == 160 || g.hop == 200) && g.center && g.pad == 0 &&
       !force_generic()) {
     // radix-20x20 register FFT run backwards (istft400.h)
@@ -858,6 +876,7 @@ int aamd_istft_f64(const double* spec, const double* window, const double* twidd
   if (g.n_stages < 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft has too many prime factors");
   og.interior = adjoint ? 0.5f : 1.0f;
   og.scale = desc->scale * (adjoint ? 1.0f : 1.0f / (float)desc->n_fft);
+  og.scale_d = (double)desc->scale * (adjoint ? 1.0 : 1.0 / (double)desc->n_fft);
   int pb = gen_pairs_per_block(g.n_fft);
   const int pairs_per_row = (g.n_frames + 1) / 2;
   if (pb > pairs_per_row) pb = pairs_per_row;

@@ -32,6 +32,7 @@
 #pragma once
 #include "hd.h"
 #include "stft_generic.h"
+#include "resample_mfma.h"   // rsm::f16_bits / f16_value: binary16 conversion shared with the CPU replay
 
 namespace aamd {
 namespace m400 {
@@ -158,11 +159,13 @@ struct Epi400 {
   const float* mean;                // MEL_NORM: [n_mels]
   const float* invstd;              // MEL_NORM: [n_mels]
   int64_t out_frames;               // MEL_NORM: frames per clip in `out` (>= n_frames; the tail is the caller's)
-  const float* dct_frag;            // MFCC: the DCT matrix as MFMA A fragments (mfcc_frag_index), [kMfccFragFloats]
+  const float* dct_frag;            // MFCC: the DCT matrix as binary16 hi / lo MFMA A fragments (mfcc_frag_piece), [kMfccFragFloats]
   int n_mfcc;                       // MFCC: coefficients (<= 48, multiple of 4)
   float top_db;                     // MFCC fix-up: cut-off = group_max[g] - top_db
   float* tile_min;                  // MFCC: [n_tiles] minimum dB value of each tile (written by pass 0, read by the fix-up)
-  int* fix_count;                   // MFCC fix-up: number of tiles redone (atomic), may be null
+  int* fix_count;                   // MFCC fix-up: number of tiles to redo = entries of fix_list (written by mfcc_fix_list_kernel)
+  const int* fix_list;              // MFCC fix-up: the tiles under the cut-off, compacted (any order)
+  int frag_in_lds;                  // MFCC: the workgroup's LDS has room for the fragment table (hop 100 / 160; not hop 200)
   int fixup;                        // MFCC: 0 = first pass, 1 = fix-up pass
   int lab;                          // MFCC (tools only): 1 no fragment loads, 2 no MFMA, 4 no tile minimum, 8 no stores
 };
@@ -178,23 +181,38 @@ AAMD_HD constexpr int pos_of_col(int c) {
   return c == 0 ? 0 : c == 10 ? 1 : c < 10 ? 2 * c : 2 * (20 - c) + 1;
 }
 
-// ---- MFCC epilogue: the DCT product on v_mfma_f32_16x16x4_f32 ------------------------------------------------------
-//   out[f][c] = sum_m Y[f][m] D[m][c]:  A = D^T tile (16 coefficients x 4 mels), B = Y^T (4 mels x 16 frames, 6 live),
+// ---- MFCC epilogue: the DCT product on the f16 matrix pipe, operands split into two binary16 numbers ----------------------
+//   out[f][c] = sum_m Y[f][m] D[m][c]:  A = D^T tile (16 coefficients x K mels), B = Y^T (K mels x 16 frames, 6 live),
 //   C row 4 (l >> 4) + r = coefficient, column l & 15 = frame: a lane ends with 4 consecutive coefficients of one frame.
-//   Contraction slot (step s, lane group kk = l >> 4) <-> mel 20 kk + s, so that a lane's 20 B values are contiguous in its
-//   frame's staged dB row (5 b128 LDS reads).  n_mels = 80 exactly (every slot is a real mel), n_mfcc <= 48.
-constexpr int kMfccKS = 20, kMfccMT = 3, kMfccMels = kMfccKS * 4;
-constexpr int kMfccFragFloats = kMfccMT * kMfccKS * 64;      // 3840: [t][s / 4][lane][s % 4]
-AAMD_HD int mfcc_frag_index(int t, int s, int lane) { return (((t * (kMfccKS / 4) + (s >> 2)) * 64 + lane) << 2) + (s & 3); }
-AAMD_HD float mfcc_frag_value(const float* dct, int n_mels, int n_mfcc, int t, int s, int lane) {
-  const int mel = kMfccKS * (lane >> 4) + s, coef = 16 * t + (lane & 15);
-  return (mel < n_mels && coef < n_mfcc) ? dct[mel * n_mfcc + coef] : 0.0f;
+//   Round 2 ran this on v_mfma_f32_16x16x4_f32 (exact fp32 chains): 60 instructions per tile that hold the SIMD for 32
+//   cycles each IN SERIES with the kernel's fp32 VALU work -- 81 us on the cfg4 batch, which made the one-kernel MFCC slower
+//   than two kernels.  Now (round 3) every operand is v = hi + lo, hi = f16(v), lo = f16(v - hi) (22 significant bits), and
+//   a product of sums is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 / 16x16x16_f16 with fp32 accumulation (the
+//   dropped lo*lo is 2^-22 of the product): 80 mels = two K = 32 steps + one K = 16 step, 3 coefficient tiles, 3 terms =
+//   27 instructions of 8-16 cycles on a pipe the rest of the kernel does not use.  Ranges: dB values (|y| < 256 after the
+//   cut-off) are scaled by 2^-8, DCT weights (|d| <= 0.16 for "ortho", <= 2 unnormalised) by 2^-1; the result by 2^9: exact
+//   powers of two.  Absolute error of a dB value 256 * 2^-22 * |y / 256| <= 2.4e-5 dB, below the fused epilogue's log2.
+//   n_mels = 80 exactly (every K slot is a real mel), n_mfcc <= 48.
+constexpr int kMfccMT = 3, kMfccMels = 80, kMfccSteps = 3;
+constexpr float kMfccYScale = 1.0f / 256.0f, kMfccDScale = 0.5f, kMfccOutScale = 512.0f;
+// fragment table: [t][s][hi / lo][lane][8 halves] as 16-byte pieces -> floats
+constexpr int kMfccFragFloats = kMfccMT * kMfccSteps * 2 * 64 * 4;      // 4608 floats = 18 432 B
+AAMD_HD int mfcc_frag_piece(int t, int s, int hl, int lane) { return ((t * kMfccSteps + s) * 2 + hl) * 64 + lane; }   // 16-B pieces
+// mel of contraction slot j of lane `lane` in step s (steps 0, 1: K = 32, 8 per lane; step 2: K = 16, 4 per lane), -1 = none
+AAMD_HD int mfcc_slot_mel(int s, int lane, int j) {
+  if (s < 2) return 32 * s + 8 * (lane >> 4) + j;
+  return j < 4 ? 64 + 4 * (lane >> 4) + j : -1;
 }
-// float index of the lane's B values of steps 4 u .. 4 u + 3 in the staged rows (frames >= 6: any live row)
-AAMD_HD int mfcc_b_index(int lane, int u) {
+AAMD_HD float mfcc_frag_value(const float* dct, int n_mels, int n_mfcc, int t, int s, int lane, int j) {
+  const int mel = mfcc_slot_mel(s, lane, j), coef = 16 * t + (lane & 15);
+  return (mel >= 0 && mel < n_mels && coef < n_mfcc) ? dct[mel * n_mfcc + coef] * kMfccDScale : 0.0f;
+}
+// index (in halves) of the lane's B values of step s in the staged binary16 rows (frames >= 6: any live row)
+AAMD_HD int mfcc_b_index(int lane, int s) {
   const int j = (lane & 15) < kFramesPerWave ? (lane & 15) : kFramesPerWave - 1;
-  return j * kMfccMels + kMfccKS * (lane >> 4) + 4 * u;
+  return j * kMfccMels + (s < 2 ? 32 * s + 8 * (lane >> 4) : 64 + 4 * (lane >> 4));
 }
+constexpr int kMfccPlaneHalves = kFramesPerWave * kMfccMels;     // 480: the lo plane starts here (960 B, 16-B aligned)
 
 // ---- banded filterbank in LDS (built once per launch by every workgroup) ------------------
 //   Bands are processed in chunks of 4 taps = one b128 of weights + two b128 of P (2 bins x 2
@@ -304,9 +322,9 @@ AAMD_HD void const_tab_build(int tid, int nthr, const float* window, const float
 }
 
 // dynamic LDS of one workgroup: per-wave regions, constant tables, mel table, tile queue
-AAMD_HD size_t lds_bytes(int n_mels, int max_width, int wave_dwords = kLdsDwordsPerWave) {
-  return ((size_t)kWavesPerBlock * wave_dwords + kConstDwords + mel_tab_dwords(n_mels, max_width) + 4) *
-         sizeof(float);
+AAMD_HD size_t lds_bytes(int n_mels, int max_width, int wave_dwords = kLdsDwordsPerWave, bool mfcc = false) {
+  return ((size_t)kWavesPerBlock * wave_dwords + kConstDwords + mel_tab_dwords(n_mels, max_width) + 4 +
+          (mfcc ? kMfccFragFloats : 0)) * sizeof(float);
 }
 
 struct LaneConst {
@@ -920,15 +938,44 @@ __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 
-// One workgroup lays out the band table image in global memory (once per filterbank; aamd_mel400_table_build).
+// The DCT matrix as MFMA A fragments, split into binary16 hi / lo planes (once per DCT matrix; aamd_mfcc_frag_build).
 __global__ void __launch_bounds__(256) mfcc_frag_build_kernel(const float* __restrict__ dct, int n_mels, int n_mfcc,
                                                               float* __restrict__ frag) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kMfccFragFloats; i += gridDim.x * blockDim.x) {
-    const int comp = i & 3, lane = (i >> 2) & 63, g = i >> 8;          // g = t * 5 + u
-    frag[i] = mfcc_frag_value(dct, n_mels, n_mfcc, g / (kMfccKS / 4), 4 * (g % (kMfccKS / 4)) + comp, lane);
+  uint16_t* fh = reinterpret_cast<uint16_t*>(frag);
+  const int n = kMfccMT * kMfccSteps * 64 * 8;                        // (t, s, lane, j)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int j = i & 7, lane = (i >> 3) & 63, g = i >> 9, s = g % kMfccSteps, t = g / kMfccSteps;
+    const float v = mfcc_frag_value(dct, n_mels, n_mfcc, t, s, lane, j);
+    const uint16_t hi = rsm::f16_bits(v);
+    const uint16_t lo = rsm::f16_bits(v - rsm::f16_value(hi));
+    fh[mfcc_frag_piece(t, s, 0, lane) * 8 + j] = hi;
+    fh[mfcc_frag_piece(t, s, 1, lane) * 8 + j] = lo;
   }
 }
 
+// Between the two passes of the fused MFCC: the tiles whose smallest dB value lies under their group's cut-off, compacted
+// into `list` (one atomic per wave; `count` zeroed by the launcher).  The fix-up launch deals list entries out block by
+// block, so 5 % flagged tiles that all sit in a few clips cost 5 % of a pass, not the +100 us of static tile ranges.
+__global__ void __launch_bounds__(256) mfcc_fix_list_kernel(const float* __restrict__ tile_min, const float* __restrict__ group_max,
+                                                            int64_t rows_per_group, int tiles_per_row, int64_t n_tiles,
+                                                            float top_db, int* __restrict__ list, int* __restrict__ count) {
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n_tiles; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = base + threadIdx.x;
+    bool hit = false;
+    if (i < n_tiles) {
+      const int64_t row = i / tiles_per_row;
+      hit = tile_min[i] < group_max[row / rows_per_group] - top_db;
+    }
+    const unsigned long long m = __ballot(hit);
+    const int lane = threadIdx.x & 63;
+    int start = 0;
+    if (lane == 0 && m) start = atomicAdd(count, __popcll(m));
+    start = __shfl(start, 0, 64);
+    if (hit) list[start + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
+  }
+}
+
+// One workgroup lays out the band table image in global memory (once per filterbank; aamd_mel400_table_build).
 __global__ void __launch_bounds__(256) mel_tab_build_kernel(MelBandsDev mb, float* __restrict__ out) {
   MelTab mt{};
   mel_tab_rounds(threadIdx.x, blockDim.x, mb, out, mt);
@@ -946,6 +993,11 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
                   int tiles_per_row, int64_t n_tiles, int tiles_per_block, int in_aligned,
                   int out_wide, Epi400 epi) {
   extern __shared__ __attribute__((aligned(16))) float smem400[];
+  int fix_n = 0;      // fix-up pass of the fused MFCC: entries of the compacted tile list (kernel-uniform)
+  if (EPI == EPI400_MFCC && epi.fixup != 0) {
+    fix_n = *epi.fix_count;
+    if (fix_n <= (int)blockIdx.x) return;                 // nothing for this workgroup (nothing at all: the common case)
+  }
   // the tools-only switches of the MFCC epilogue (AAMD_MFCC_LAB) are honoured by an instantiation of their own: as run-time
   // branches in the product kernel they cut its MFMA section into basic blocks (the lesson of the resampler's census)
   const int elab = (LAB & 524288) ? epi.lab : 0;
@@ -971,6 +1023,12 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // tile queue of this workgroup: the next unclaimed tile (waves start on tiles 0 .. W-1)
   int* queue = reinterpret_cast<int*>(const_tab + kConstDwords + tab_dwords);
   if (threadIdx.x == 0) *queue = kWavesPerBlock;
+  // MFCC: the DCT fragments (18 KB) live in LDS behind the queue -- fetched from memory per tile they cost 18 global
+  // loads per lane whose registers (prefetch) pushed the kernel into scratch, and a scratch reload waits for the LDS-DMA in
+  // flight (one in-order vmcnt)
+  float* frag_lds = const_tab + kConstDwords + tab_dwords + 4;
+  if (EPI == EPI400_MFCC && epi.frag_in_lds)
+    for (int i = threadIdx.x; i < kMfccFragFloats; i += blockDim.x) frag_lds[i] = epi.dct_frag[i];
   if (EPI != EPI400_SPEC && mb.table400 != nullptr) {
     // the band table was laid out once per filterbank (mel_tab_build_kernel): one round of independent loads here
     // instead of the three dependent ones (lane order -> band start -> weight) of the in-kernel build
@@ -992,7 +1050,8 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // The 20 window taps of this lane live in registers for the whole launch (round 2: -5 us on the headline batch once
   // the buffers rotate over more than the 256 MiB Infinity Cache; 5 b128 LDS reads per tile less).  Lab bit 8192 forces
   // it on, bit 262144 forces the LDS table; the twiddles (38 more registers) stay in LDS (bit 16384: spills at 3 waves/SIMD).
-  constexpr bool kWinRegs = ((LAB & 8192) != 0) || !(LAB & 262144);
+  // (the MFCC epilogue's MFMA operands need the 20 registers more than the window does: its taps stay in the LDS table)
+  constexpr bool kWinRegs = (EPI != EPI400_MFCC) && (((LAB & 8192) != 0) || !(LAB & 262144));
   float winr[20], twr[40];
   if (kWinRegs) {
 #pragma unroll
@@ -1032,11 +1091,15 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   if ((nb & 7) == 0) lb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
   // this workgroup's run of tiles; its waves claim them one at a time from the LDS queue, so a
   // wave that the scheduler favours simply takes more tiles (static shares left 40 % idle tails)
-  const unsigned blk_first = (unsigned)lb * (unsigned)tiles_per_block;
+  unsigned blk_first = (unsigned)lb * (unsigned)tiles_per_block;
   unsigned blk_count = 0;
   if (blk_first < (unsigned)n_tiles) {
     blk_count = (unsigned)n_tiles - blk_first;
     if (blk_count > (unsigned)tiles_per_block) blk_count = (unsigned)tiles_per_block;
+  }
+  if (EPI == EPI400_MFCC && epi.fixup != 0) {             // list entries blockIdx, blockIdx + nb, ... belong to this workgroup
+    blk_first = 0;
+    blk_count = ((unsigned)fix_n - blockIdx.x + (unsigned)nb - 1u) / (unsigned)nb;
   }
   auto claim = [&]() {   // wave-uniform
     int v = 0;
@@ -1068,7 +1131,8 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 
   auto tile_info = [&](unsigned idx) {
     TileInfo ti;
-    const unsigned t = ((LAB & 131072) ? 0u : blk_first) + idx;
+    unsigned t = ((LAB & 131072) ? 0u : blk_first) + idx;
+    if (EPI == EPI400_MFCC && epi.fixup != 0) t = idx < blk_count ? (unsigned)epi.fix_list[blockIdx.x + idx * (unsigned)nb] : 0u;
     const unsigned row = t / (unsigned)tiles_per_row;
     ti.row = row;
     ti.t0 = (int64_t)(t - row * (unsigned)tiles_per_row) * kFramesPerWave;
@@ -1135,15 +1199,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     TileInfo nxt = tile_info(nxt_idx);
     float fix_cut = -INFINITY;
     if (fix) {
-      // fix-up pass: only tiles whose smallest dB value lies under the cut-off are redone (their samples are staged now,
-      // without prefetch: flagged tiles are the exception)
+      // fix-up pass: the tiles of the compacted list (smallest dB value under the cut-off) are redone, clamped; their samples
+      // are staged now, without prefetch: flagged tiles are the exception
       fix_cut = epi.group_max[cur.row / epi.rows_per_group] - epi.top_db;
-      if (!(epi.tile_min[blk_first + cur_idx] < fix_cut)) {
-        cur = nxt;
-        cur_idx = nxt_idx;
-        continue;
-      }
-      if (lane == 0 && epi.fix_count != nullptr) atomicAdd(epi.fix_count, 1);
       if (cur.staged) stage_issue(cur);
     }
 
@@ -1242,40 +1300,88 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       }
     }
     if (EPI == EPI400_MFCC) {
-      // the DCT product: A fragments from the (cache-resident) table, B from the staged dB rows
+      // the DCT product on the f16 matrix pipe: A fragments (hi / lo planes) from the cache-resident table, B from the
+      // staged dB rows, which are written as two binary16 planes (hi, lo) of 6 x 80 halves each
       using f32x4 = __attribute__((ext_vector_type(4))) float;
-      // A fragments: 3 x 16 bytes per lane and k-step group, fetched one group ahead of the MFMAs that use them (the whole
-      // table in registers would be 60 VGPRs: the kernel spills at 3 waves / SIMD)
-      auto frag_load = [&](int u, F4 (&a)[kMfccMT]) {
+      using h8 = __attribute__((ext_vector_type(8))) _Float16;
+      using h4 = __attribute__((ext_vector_type(4))) _Float16;
+      using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+      using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+      const u32x4* ftab = reinterpret_cast<const u32x4*>(epi.frag_in_lds ? frag_lds : epi.dct_frag);
+      auto frag_load = [&](int sidx, u32x4 (&a)[kMfccMT][2]) {      // step sidx: 3 coefficient tiles x (hi, lo), 16 B each (LDS)
 #pragma unroll
-        for (int t = 0; t < kMfccMT; ++t) {
-          a[t] = F4{1.0f, 0.5f, 0.25f, 0.125f};
-          if (!(elab & 1)) a[t] = *reinterpret_cast<const F4*>(epi.dct_frag + (((t * (kMfccKS / 4) + u) * 64 + lane) << 2));
-        }
+        for (int t = 0; t < kMfccMT; ++t)
+#pragma unroll
+          for (int hl = 0; hl < 2; ++hl) {
+            a[t][hl] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+            if (!(elab & 1)) a[t][hl] = ftab[mfcc_frag_piece(t, sidx, hl, lane)];
+          }
       };
-      F4 a0[kMfccMT], a1[kMfccMT];
-      frag_load(0, a0);
+      u32x4 a0[kMfccMT][2];
       wave_lds_fence();
-      store_stage<NR>(c, mt, acc_a, acc_b, lds, mh);
+      {   // stage: v = y * 2^-8 = hi + lo
+        uint16_t* hs = reinterpret_cast<uint16_t*>(lds);
+        uint16_t* ls = hs + kMfccPlaneHalves;
+        if (c.active) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            if (r < mt.n_rounds) {
+              const int m = mh ? mh->mel(r) : mt.row_mel[r * kMelSlots + c.pi];
+              if (m >= 0) {
+                const float va = acc_a[r] * kMfccYScale, vb = acc_b[r] * kMfccYScale;
+                const _Float16 ha = (_Float16)va, hb = (_Float16)vb;
+                const _Float16 la = (_Float16)(va - (float)ha), lb = (_Float16)(vb - (float)hb);
+                hs[2 * c.p * kMfccMels + m] = __builtin_bit_cast(uint16_t, ha);
+                ls[2 * c.p * kMfccMels + m] = __builtin_bit_cast(uint16_t, la);
+                hs[(2 * c.p + 1) * kMfccMels + m] = __builtin_bit_cast(uint16_t, hb);
+                ls[(2 * c.p + 1) * kMfccMels + m] = __builtin_bit_cast(uint16_t, lb);
+              }
+            }
+          }
+        }
+      }
       wave_lds_fence();
       f32x4 cf[kMfccMT];
 #pragma unroll
       for (int t = 0; t < kMfccMT; ++t) cf[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       if (!(elab & 2)) {
-        // consecutive MFMAs go to different accumulators (a dependent one would wait out the 8 passes of its predecessor)
-#define AAMD_MFCC_STEP(A, COMP)                                                                                    \
-        _Pragma("unroll") for (int t = 0; t < kMfccMT; ++t)                                                        \
-          cf[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[t].COMP, b4.COMP, cf[t], 0, 0, 0);
-#define AAMD_MFCC_GROUP(U, A, ANEXT)                                                                               \
+        const uint16_t* hs = reinterpret_cast<const uint16_t*>(lds);
+        // consecutive MFMAs go to different accumulators (a dependent one would wait out the passes of its predecessor)
+#define AAMD_MFCC_K32(A)                                                                                           \
         {                                                                                                          \
-          const F4 b4 = *reinterpret_cast<const F4*>(lds + mfcc_b_index(lane, U));                                \
-          if (U + 1 < kMfccKS / 4) frag_load(U + 1, ANEXT);                                                        \
-          AAMD_MFCC_STEP(A, x) AAMD_MFCC_STEP(A, y) AAMD_MFCC_STEP(A, z) AAMD_MFCC_STEP(A, w)                      \
+          _Pragma("unroll") for (int t = 0; t < kMfccMT; ++t)                                                      \
+            cf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, A[t][1]), bh, cf[t], 0, 0, 0);  \
+          _Pragma("unroll") for (int t = 0; t < kMfccMT; ++t)                                                      \
+            cf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, A[t][0]), bl, cf[t], 0, 0, 0);  \
+          _Pragma("unroll") for (int t = 0; t < kMfccMT; ++t)                                                      \
+            cf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, A[t][0]), bh, cf[t], 0, 0, 0);  \
         }
-        AAMD_MFCC_GROUP(0, a0, a1) AAMD_MFCC_GROUP(1, a1, a0) AAMD_MFCC_GROUP(2, a0, a1) AAMD_MFCC_GROUP(3, a1, a0)
-        AAMD_MFCC_GROUP(4, a0, a1)
-#undef AAMD_MFCC_GROUP
-#undef AAMD_MFCC_STEP
+        {
+          const h8 bh = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(hs + mfcc_b_index(lane, 0)));
+          const h8 bl = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(hs + kMfccPlaneHalves + mfcc_b_index(lane, 0)));
+          frag_load(0, a0);
+          AAMD_MFCC_K32(a0)
+        }
+        {
+          const h8 bh = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(hs + mfcc_b_index(lane, 1)));
+          const h8 bl = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(hs + kMfccPlaneHalves + mfcc_b_index(lane, 1)));
+          frag_load(1, a0);
+          AAMD_MFCC_K32(a0)
+        }
+#undef AAMD_MFCC_K32
+        {   // mels 64 .. 79: K = 16 (4 halves per lane: the low 8 bytes of the fragment pieces)
+          frag_load(2, a0);
+          const h4 bh = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(hs + mfcc_b_index(lane, 2)));
+          const h4 bl = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(hs + kMfccPlaneHalves + mfcc_b_index(lane, 2)));
+#define AAMD_A4(T, HL) __builtin_bit_cast(h4, u32x2{a0[T][HL][0], a0[T][HL][1]})
+#pragma unroll
+          for (int t = 0; t < kMfccMT; ++t) cf[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(AAMD_A4(t, 1), bh, cf[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < kMfccMT; ++t) cf[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(AAMD_A4(t, 0), bl, cf[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < kMfccMT; ++t) cf[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(AAMD_A4(t, 0), bh, cf[t], 0, 0, 0);
+#undef AAMD_A4
+        }
       }
       const int j = lane & 15;
       if (!(LAB & 2) && !(elab & 8) && cur.t0 + j < n_frames && j < kFramesPerWave) {
@@ -1283,7 +1389,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 #pragma unroll
         for (int t = 0; t < kMfccMT; ++t) {
           const int k0 = 16 * t + 4 * (lane >> 4);
-          if (k0 < epi.n_mfcc) *reinterpret_cast<F4*>(orow + k0) = F4{cf[t][0], cf[t][1], cf[t][2], cf[t][3]};
+          if (k0 < epi.n_mfcc)
+            *reinterpret_cast<F4*>(orow + k0) = F4{cf[t][0] * kMfccOutScale, cf[t][1] * kMfccOutScale,
+                                                   cf[t][2] * kMfccOutScale, cf[t][3] * kMfccOutScale};
         }
       }
       wave_lds_fence();

@@ -480,15 +480,17 @@ def inverse_spectrogram(
     if not onesided:
         raise NotImplementedError("audio_amd: inverse_spectrogram needs onesided=True")
     dev = spectrogram.device
-    window = window.to(device=dev, dtype=torch.float32)
+    f64 = spectrogram.dtype == torch.complex128          # the reference's tests run in float64 too: the float64 inverse kernel
+    rdt = torch.float64 if f64 else torch.float32
+    window = window.to(device=dev, dtype=rdt)
     wp = _padded_window(window, n_fft)
     shape = spectrogram.size()
     n_freq, T = shape[-2], shape[-1]
     if n_freq != n_fft // 2 + 1:
         raise RuntimeError(f"istft: expected the frequency dimension of the input to be n_fft / 2 + 1 = "
                            f"{n_fft // 2 + 1}, but got {n_freq}")
-    if spectrogram.dtype != torch.complex64:
-        raise TypeError(f"audio_amd: spectrogram must be complex64 (got {spectrogram.dtype}); kernels compute in fp32.")
+    if spectrogram.dtype not in (torch.complex64, torch.complex128):
+        raise TypeError(f"audio_amd: spectrogram must be complex64 or complex128 (got {spectrogram.dtype}).")
     fm = spectrogram.transpose(-1, -2).reshape(-1, T, n_freq)
     if not fm.is_contiguous():
         fm = fm.contiguous()
@@ -516,12 +518,23 @@ def inverse_spectrogram(
         covered = env[: max(min(out_len, expected - start), 0)]
         if covered.numel() and float(covered.abs().min()) < 1e-11:
             raise RuntimeError("istft(...) window overlap add min: 1")
-        return (1.0 / env).to(torch.float32).contiguous()
+        return (1.0 / env).to(rdt).contiguous()
 
     inv_env = _tensor_cached(window, ("istft_env", n_fft, hop_length, T, out_len, center), make_env)
     desc = _lib.StftDesc(rows, out_len, out_len, n_fft, hop_length, 0, int(center), _lib.PAD_MODES["constant"], 1, T,
-                         scale, 0.0)
-    out = _istft_launch(torch.view_as_real(fm).view(rows, T, 2 * n_freq), wp, desc, False, inv_env)
+                         1.0 if f64 else scale, 0.0)      # (the descriptor's scale is a float: float64 applies it below)
+    if f64:
+        from . import _diff
+        out = torch.zeros((rows, out_len), dtype=torch.float64, device=dev)
+        if out.numel() and T:
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().aamd_istft_f64(torch.view_as_real(fm).data_ptr(), wp.data_ptr(),
+                                                     _diff.twiddles(n_fft, dev, torch.float64).data_ptr(), inv_env.data_ptr(),
+                                                     out.data_ptr(), C.byref(desc), 0, _lib.current_stream(dev)))
+        if scale != 1.0:
+            out = out * scale
+    else:
+        out = _istft_launch(torch.view_as_real(fm).view(rows, T, 2 * n_freq), wp, desc, False, inv_env)
     if length is not None and pad > 0:
         out = out[:, pad:-pad]
     return out.reshape(tuple(shape[:-2]) + out.shape[-1:])
@@ -552,6 +565,23 @@ def _phase_vocoder_launch(spec: Tensor, rate: float, phase_advance: Tensor, fram
     return out.transpose(-1, -2) if frame_major_out else out
 
 
+def _phase_vocoder_f64(spec: Tensor, rate: float, phase_advance: Tensor) -> Tensor:
+    """complex128 precision path of this thin caller: the reference's formula (functional/functional.py:765-803) evaluated
+    with device tensor ops in float64 -- interpolated magnitudes, unwrapped phase increments, running phase sum."""
+    shape = spec.size()
+    z = torch.nn.functional.pad(spec.reshape((-1,) + tuple(shape[-2:])), [0, 2])
+    t = torch.arange(0, shape[-1], rate, device=spec.device, dtype=torch.float64)
+    frac = t % 1.0
+    i0 = t.long()
+    z0, z1 = z.index_select(-1, i0), z.index_select(-1, i0 + 1)
+    pa = phase_advance.to(device=spec.device, dtype=torch.float64)
+    step = z1.angle() - z0.angle() - pa
+    step = step - 2 * math.pi * torch.round(step / (2 * math.pi)) + pa
+    phase = torch.cumsum(torch.cat([z[..., :1].angle(), step[..., :-1]], dim=-1), -1)
+    out = torch.polar(frac * z1.abs() + (1 - frac) * z0.abs(), phase)
+    return out.reshape(tuple(shape[:-2]) + out.shape[1:])
+
+
 def phase_vocoder(complex_specgrams: Tensor, rate: float, phase_advance: Tensor) -> Tensor:
     r"""Stretch a complex spectrogram in time by ``rate`` without changing pitch
     (reference: functional/functional.py:732-803) -- one HIP kernel, a thread per (row, frequency) chain."""
@@ -563,9 +593,10 @@ def phase_vocoder(complex_specgrams: Tensor, rate: float, phase_advance: Tensor)
     if complex_specgrams.requires_grad and torch.is_grad_enabled():
         raise RuntimeError("audio_amd: phase_vocoder is forward-only; wrap the call in torch.no_grad().")
     shape = complex_specgrams.size()
+    if complex_specgrams.dtype == torch.complex128:
+        return _phase_vocoder_f64(complex_specgrams, rate, phase_advance)
     if complex_specgrams.dtype != torch.complex64:
-        raise TypeError(f"audio_amd: complex_specgrams must be complex64 (got {complex_specgrams.dtype}); "
-                        "kernels compute in fp32.")
+        raise TypeError(f"audio_amd: complex_specgrams must be complex64 or complex128 (got {complex_specgrams.dtype}).")
     spec = complex_specgrams.reshape((-1,) + tuple(shape[-2:]))
     out = _phase_vocoder_launch(spec, rate, phase_advance, frame_major_out=False)
     return out.reshape(tuple(shape[:-2]) + out.shape[1:])
@@ -871,13 +902,13 @@ class MfccFusedState:
     the counter of the last call's fix-up pass -- read WITHOUT synchronising (through a pinned copy and an event that is
     only polled), it drives the choice between the fused path and the two-kernel path:
 
-    * nothing clamped (loud, unpadded batches): pass 0 + an empty fix-up launch, ~25 % faster than two kernels;
+    * nothing clamped (loud, unpadded batches): pass 0 + an empty fix-up launch, ~8 % faster than two kernels;
     * most tiles clamped (zero-padded batches, top_db reached everywhere): every tile would be computed twice, so the
       two-kernel path is taken as long as the last observed share of redone tiles exceeds `max_share`; every
       `retry_every` calls the fused path is probed again.
     `path` / `last_share` report what ran (`MFCC.fused_report()`)."""
 
-    def __init__(self, max_share: float = 0.3, retry_every: int = 64):
+    def __init__(self, max_share: float = 0.12, retry_every: int = 64):
         self.frag = None
         self.frag_key = None
         self.max_share = max_share
@@ -935,9 +966,10 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
             return out
         gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
         tile_min = torch.empty((n_tiles,), dtype=torch.float32, device=dev)
-        count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        count = torch.empty((1,), dtype=torch.int32, device=dev)
+        tile_list = torch.empty((n_tiles,), dtype=torch.int32, device=dev)
         f = _lib.MfccFused(state.frag.data_ptr(), n_mfcc, 0, float(db[0]), float(db[1]), float(db[2]), float(top_db),
-                           gmax.data_ptr(), max(packed, 1), tile_min.data_ptr(), count.data_ptr())
+                           gmax.data_ptr(), max(packed, 1), tile_min.data_ptr(), count.data_ptr(), tile_list.data_ptr())
         args = (x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),
                 C.byref(bands.struct), out.data_ptr(), C.byref(desc))
         _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))

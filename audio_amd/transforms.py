@@ -439,12 +439,13 @@ class MFCC(torch.nn.Module):
         #: optional hook ``fn(group_max: Tensor) -> None`` run between the dB pass and the clamp;
         #: audio_amd.distributed installs an all-reduce(MAX) here when a batch is sharded.
         self.group_max_hook: Optional[Callable[[Tensor], None]] = None
-        #: EXTENSION: False (default) = the exact two-kernel path.  True = the one-kernel MFCC (DCT in the mel kernel's epilogue
-        #: + a fix-up launch for the tiles the top_db cut-off reaches); "auto" = the one-kernel path unless the last observed
-        #: share of such tiles was large.  Same results either way.  Measured (profiles/r02_u_mfcc_paths.txt): the fp32 MFMA
-        #: product is NOT free beside the FFT arithmetic -- it runs on the same fp32 pipe -- so the one-kernel path is
-        #: 267 us against 224 us on the cfg4 batch and stays opt-in.
-        self.fused = False
+        #: EXTENSION: which MFCC path runs.  "auto" (default since round 3) = the one-kernel MFCC (DCT on the f16 matrix pipe
+        #: in the mel kernel's epilogue, operands split into two binary16 numbers, + a fix-up launch over the compacted list of
+        #: tiles the top_db cut-off reaches) unless the last observed share of such tiles was above 12 %, where the exact
+        #: two-kernel path is cheaper; True / False force one or the other.  Same results within 3e-5 dB.  Measured on the cfg4
+        #: batch (profiles/r03_d_mfcc_paths.txt): 211 us against 229 us for two kernels on noise, 220 against 234 with 5 %
+        #: clamped tiles, 297 against 220 with 50 %.  (Round 2's fp32-MFMA epilogue was 267 us and opt-in.)
+        self.fused = "auto"
         self._fused_state = F.MfccFusedState()
 
     def fused_report(self) -> dict:

@@ -176,7 +176,9 @@ typedef struct aamd_mfcc_fused {
   float* group_max;        /* device float[ceil(rows / rows_per_group)] */
   int64_t rows_per_group;
   float* tile_min;         /* device float[aamd_mfcc_fused_tiles(desc)] */
-  int32_t* fix_count;      /* device int32 (caller zeroes it), or NULL */
+  int32_t* fix_count;      /* device int32: pass 1 writes the number of tiles it redoes here (no need to zero it) */
+  int32_t* tile_list;      /* device int32[aamd_mfcc_fused_tiles(desc)]: scratch of pass 1 -- the tiles under the cut-off,
+                              compacted, so that the fix-up launch deals them out evenly however they cluster by clip */
 } aamd_mfcc_fused;
 int32_t aamd_mfcc_frag_floats(void);
 int64_t aamd_mfcc_fused_tiles(const aamd_stft_desc* desc);

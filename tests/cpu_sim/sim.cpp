@@ -474,11 +474,18 @@ int sim_istft(const float* spec, const float* window, const float* tw, const flo
 // fused MFCC (EPI400_MFCC): the extra operands of the epilogue, set before sim_melspec400(epi_mode = 4)
 static struct { std::vector<float> frag; int n_mfcc = 0; float top_db = 0.f; float* tile_min = nullptr; int fixup = 0; int fix_count = 0; } g_mfcc;
 int sim_mfcc_fused_setup(const float* dct, int n_mels, int n_mfcc, float top_db, float* tile_min, int fixup) {
+  // what mfcc_frag_build_kernel writes: binary16 hi / lo planes of the scaled DCT weights, in 16-byte pieces
   g_mfcc.frag.assign(m400::kMfccFragFloats, 0.f);
+  uint16_t* fh = reinterpret_cast<uint16_t*>(g_mfcc.frag.data());
   for (int t = 0; t < m400::kMfccMT; ++t)
-    for (int sidx = 0; sidx < m400::kMfccKS; ++sidx)
+    for (int sidx = 0; sidx < m400::kMfccSteps; ++sidx)
       for (int lane = 0; lane < 64; ++lane)
-        g_mfcc.frag[m400::mfcc_frag_index(t, sidx, lane)] = m400::mfcc_frag_value(dct, n_mels, n_mfcc, t, sidx, lane);
+        for (int j = 0; j < 8; ++j) {
+          const float v = m400::mfcc_frag_value(dct, n_mels, n_mfcc, t, sidx, lane, j);
+          const uint16_t hi = rsm::f16_bits(v);
+          fh[m400::mfcc_frag_piece(t, sidx, 0, lane) * 8 + j] = hi;
+          fh[m400::mfcc_frag_piece(t, sidx, 1, lane) * 8 + j] = rsm::f16_bits(v - rsm::f16_value(hi));
+        }
   g_mfcc.n_mfcc = n_mfcc; g_mfcc.top_db = top_db; g_mfcc.tile_min = tile_min; g_mfcc.fixup = fixup; g_mfcc.fix_count = 0;
   return 0;
 }
@@ -607,19 +614,39 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
       if (epi_mode == EPI400_MFCC && !fix) g_mfcc.tile_min[tile] = tmin;
     }
     if (epi_mode == EPI400_MFCC) {
-      // store_stage + the fragment maps of v_mfma_f32_16x16x4_f32 (A[l & 15][l >> 4], B[l >> 4][l & 15], C row 4 (l >> 4) + r)
-      for (int l = 0; l < 64; ++l) store_stage(c[l], mt, acc_a[l], acc_b[l], lds);
+      // the staged binary16 planes + the fragment maps of v_mfma_f32_16x16x32_f16 / 16x16x16_f16 (A[l & 15][8 (l >> 4) + j],
+      // B[8 (l >> 4) + j][l & 15], C row 4 (l >> 4) + r): hi*hi + hi*lo + lo*hi in fp32
+      uint16_t* hs = reinterpret_cast<uint16_t*>(lds);
+      uint16_t* ls = hs + kMfccPlaneHalves;
+      for (int l = 0; l < 64; ++l) {
+        if (!c[l].active) continue;
+        for (int r = 0; r < mt.n_rounds; ++r) {
+          const int m = mt.row_mel[r * kMelSlots + c[l].pi];
+          if (m < 0) continue;
+          const float va = acc_a[l][r] * kMfccYScale, vb = acc_b[l][r] * kMfccYScale;
+          const uint16_t ha = rsm::f16_bits(va), hb = rsm::f16_bits(vb);
+          hs[2 * c[l].p * kMfccMels + m] = ha;
+          ls[2 * c[l].p * kMfccMels + m] = rsm::f16_bits(va - rsm::f16_value(ha));
+          hs[(2 * c[l].p + 1) * kMfccMels + m] = hb;
+          ls[(2 * c[l].p + 1) * kMfccMels + m] = rsm::f16_bits(vb - rsm::f16_value(hb));
+        }
+      }
       static float C3[kMfccMT][16][16];
       std::memset(C3, 0, sizeof(C3));
-      for (int sidx = 0; sidx < kMfccKS; ++sidx)
+      const uint16_t* fh = reinterpret_cast<const uint16_t*>(g_mfcc.frag.data());
+      for (int sidx = 0; sidx < kMfccSteps; ++sidx)
         for (int t = 0; t < kMfccMT; ++t)
           for (int i = 0; i < 16; ++i)
             for (int j = 0; j < 16; ++j)
-              for (int k = 0; k < 4; ++k) {
-                const float a = g_mfcc.frag[mfcc_frag_index(t, sidx, i + 16 * k)];
-                const float b = lds[mfcc_b_index(j + 16 * k, sidx >> 2) + (sidx & 3)];
-                C3[t][i][j] += a * b;
-              }
+              for (int g4 = 0; g4 < 4; ++g4)
+                for (int e = 0; e < (sidx < 2 ? 8 : 4); ++e) {
+                  const int la = i + 16 * g4, lb = j + 16 * g4;
+                  const float ah = rsm::f16_value(fh[mfcc_frag_piece(t, sidx, 0, la) * 8 + e]);
+                  const float al = rsm::f16_value(fh[mfcc_frag_piece(t, sidx, 1, la) * 8 + e]);
+                  const float bh = rsm::f16_value(hs[mfcc_b_index(lb, sidx) + e]);
+                  const float bl = rsm::f16_value(ls[mfcc_b_index(lb, sidx) + e]);
+                  C3[t][i][j] += al * bh + ah * bl + ah * bh;
+                }
       for (int l = 0; l < 64; ++l) {
         const int j = l & 15;
         if (j >= kFramesPerWave || t0 + j >= n_frames) continue;
@@ -627,7 +654,7 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
         for (int t = 0; t < kMfccMT; ++t)
           for (int r = 0; r < 4; ++r) {
             const int k0 = 16 * t + 4 * (l >> 4);
-            if (k0 < g_mfcc.n_mfcc) orow[k0 + r] = C3[t][4 * (l >> 4) + r][j];
+            if (k0 < g_mfcc.n_mfcc) orow[k0 + r] = C3[t][4 * (l >> 4) + r][j] * kMfccOutScale;
           }
       }
       cur_staged = nxt_staged;

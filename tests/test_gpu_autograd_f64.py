@@ -5,6 +5,7 @@ gradcheck tolerances.  The float64 kernels are csrc/f64_paths.h + the generic ST
 double; every backward is built from differentiable pieces (audio_amd/_diff.py), so the second-order check passes too.
 `nondet_tol` as in the reference: its replication-pad backward, and here the atomic overlap-add of the STFT adjoint, sum in
 a run-dependent order (differences ~1e-17)."""
+import math
 from functools import partial
 
 import pytest
@@ -181,3 +182,42 @@ def test_float64_forward_matches_float32_kernels_and_oracle():
         r = F.resample(x.double(), 16000, 11025)
     wr = O.resample(x.cpu().numpy().astype(np.float64), 16000, 11025)
     assert float(np.abs(r.cpu().numpy() - wr).max()) <= 1e-12
+
+
+# ---- float64 (complex128) through the two widening ops that used to be float32-only ------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(n_fft=400, hop=160, L=8000), dict(n_fft=512, hop=128, L=6000, length=6000),
+                                 dict(n_fft=200, hop=50, win_length=160, L=2222)])
+def test_inverse_spectrogram_complex128(cfg):
+    """complex128 spectrograms run on the float64 inverse-STFT kernel and return float64 (the reference accepts
+    complex128, and its tests run in float64): against torch.istft in float64 on the CPU, 1e-11 of the peak."""
+    import audio_amd.functional as F
+    n_fft, hop, L = cfg["n_fft"], cfg["hop"], cfg["L"]
+    wl = cfg.get("win_length", n_fft)
+    g = torch.Generator().manual_seed(n_fft)
+    x = 0.5 * torch.randn(3, L, generator=g, dtype=torch.float64)
+    w = torch.hann_window(wl, dtype=torch.float64)
+    X = torch.stft(x, n_fft, hop, wl, w, center=True, pad_mode="reflect", return_complex=True)
+    ref = torch.istft(X, n_fft, hop, wl, w, center=True, length=cfg.get("length"))
+    with torch.no_grad():
+        got = F.inverse_spectrogram(X.cuda(), cfg.get("length"), 0, w.cuda(), n_fft, hop, wl, False)
+    assert got.dtype == torch.float64 and got.shape == ref.shape
+    assert float((got.cpu() - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_phase_vocoder_complex128():
+    """complex128 input: the float64 precision path (reference formula on device tensors) -- equal to the same formula
+    evaluated on the CPU, and consistent with the float32 kernel on the same data at the float32 phase-sum noise level."""
+    import audio_amd.functional as F
+    g = torch.Generator().manual_seed(3)
+    spec = torch.randn(2, 201, 120, generator=g, dtype=torch.float64) + 1j * torch.randn(2, 201, 120, generator=g,
+                                                                                         dtype=torch.float64)
+    pa = torch.linspace(0, math.pi * 160, 201, dtype=torch.float64)[..., None]
+    with torch.no_grad():
+        got = F.phase_vocoder(spec.cuda(), 1.3, pa.cuda())
+        cpu = F._phase_vocoder_f64(spec, 1.3, pa)
+        f32 = F.phase_vocoder(spec.to(torch.complex64).cuda(), 1.3, pa.float().cuda())
+    assert got.dtype == torch.complex128 and got.shape == (2, 201, 93)
+    assert float((got.cpu() - cpu).abs().max()) <= 1e-9 * float(cpu.abs().max())
+    assert float((got.abs().float() - f32.abs()).abs().max()) <= 1e-5 * float(cpu.abs().max())

@@ -70,7 +70,9 @@ def test_plan_caches_are_thread_safe_and_evict_lru():
     assert F._tensor_cached(t, "k", lambda: object()) is not b
 
 
-def test_double_precision_complex_inputs_are_refused_not_downcast():
+def test_complex_inputs_on_the_cpu_are_refused_not_computed_elsewhere():
+    """(round 2 refused complex128 outright; round 3 serves it on the float64 kernels -- tests/test_gpu_autograd_f64.py --
+    so what is left to refuse here is the device: there is no CPU path)"""
     import audio_amd.functional as F
     z = torch.zeros(1, 201, 10, dtype=torch.complex128)
     with pytest.raises((TypeError, RuntimeError)):

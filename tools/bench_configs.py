@@ -15,7 +15,7 @@ import torch
 import audio_amd.functional as F
 import audio_amd.transforms as T
 
-HBM, FP32 = 8000.0, 157.3   # GB/s, TFLOP/s (MI355X_MICROARCH.md)
+HBM, FP32, F16 = 8000.0, 157.3, 2500.0   # GB/s, TFLOP/s fp32 vector / MFMA, TFLOP/s dense f16 MFMA (MI355X_MICROARCH.md)
 
 
 def timed(fn, warmup, steps):
@@ -42,12 +42,29 @@ def main():
     def noise(*shape):
         return (0.5 * torch.randn(*shape, device=dev, generator=g)).clamp_(-1, 1)
 
-    def emit(name, ms, clip_seconds, algo_bytes, flops=None, note=""):
+    def ring(fn, bufs):
+        """fn(buffer) over rotating input buffers (more than the 256 MiB Infinity Cache in total), as bench.py does"""
+        it = [0]
+
+        def step():
+            it[0] += 1
+            return fn(bufs[it[0] % len(bufs)])
+        return step
+
+    def emit(name, ms, clip_seconds, algo_bytes, flops=None, note="", f16_terms=0):
         rec = {"config": name, "ms_per_launch": ms, "clip_seconds_per_launch": clip_seconds,
                "value": clip_seconds / (ms * 1e-3), "unit": "audio-sec/sec (per GPU)",
                "roofline_hbm": {"algorithmic_bytes": algo_bytes, "achieved_GBs": algo_bytes / ms / 1e6,
                                 "frac": algo_bytes / ms / 1e6 / HBM}}
-        if flops:
+        if flops and f16_terms:
+            # the kernel runs on the f16 matrix pipe with `f16_terms` MFMA instructions per product (hi/lo-split operands):
+            # priced against THAT pipe's dense peak; the fp32 figure is what the same arithmetic would need on fp32 FMAs
+            rec["roofline_matrix_f16"] = {"algorithmic_flops": flops, "issued_flops": f16_terms * flops,
+                                          "achieved_TFLOPs_issued": f16_terms * flops / ms / 1e9, "peak_TFLOPs": F16,
+                                          "frac": f16_terms * flops / ms / 1e9 / F16}
+            rec["fp32_equivalent"] = {"achieved_TFLOPs": flops / ms / 1e9, "of_fp32_peak": flops / ms / 1e9 / FP32,
+                                      "note": "not a roofline of this kernel: no fp32 pipe executes these flops"}
+        elif flops:
             rec["roofline_fp32"] = {"algorithmic_flops": flops, "achieved_TFLOPs": flops / ms / 1e9,
                                     "frac": flops / ms / 1e9 / FP32}
         if note:
@@ -55,30 +72,32 @@ def main():
         print(json.dumps(rec), flush=True)
 
     with torch.no_grad():
-        x = noise(256, 160000)
+        xs = [noise(256, 160000) for _ in range(4)]
         mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).to(dev)
         emit("cfg2 MelSpectrogram n_fft=400 hop=160 n_mels=80, 256 x 10 s @16 kHz",
-             timed(lambda: mel(x), 5 * args.warmup, 5 * args.steps), 2560.0, 256 * 160000 * 4 + 256 * 1001 * 80 * 4)
+             timed(ring(mel, xs), 5 * args.warmup, 5 * args.steps), 2560.0, 256 * 160000 * 4 + 256 * 1001 * 80 * 4,
+             note="4 input batches rotate")
         sp = T.Spectrogram(n_fft=400, hop_length=160).to(dev)
         emit("cfg1-shaped Spectrogram n_fft=400 hop=160 (power 2), 256 x 10 s @16 kHz",
-             timed(lambda: sp(x), 5 * args.warmup, 5 * args.steps), 2560.0, 256 * 160000 * 4 + 256 * 1001 * 201 * 4)
-        del x
-        x = noise(512, 160000)
+             timed(ring(sp, xs), 5 * args.warmup, 5 * args.steps), 2560.0, 256 * 160000 * 4 + 256 * 1001 * 201 * 4,
+             note="4 input batches rotate")
+        del xs
+        xs = [noise(512, 160000) for _ in range(3)]
         mf = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).to(dev)
         emit("cfg4 MFCC n_mfcc=40, 512 x 10 s @16 kHz, (B, L) input = one batch-global top_db cut-off",
-             timed(lambda: mf(x), args.warmup, args.steps), 5120.0, 512 * 160000 * 4 + 512 * 1001 * 40 * 4,
-             note="two kernels (mel+dB+max, clamp+DCT on MFMA); exact path moves 737.6 MB")
-        x3 = x[:, None, :]
-        emit("cfg4 variant: (B, 1, L) input = per-item cut-offs", timed(lambda: mf(x3), args.warmup, args.steps),
+             timed(ring(mf, xs), args.warmup, args.steps), 5120.0, 512 * 160000 * 4 + 512 * 1001 * 40 * 4,
+             note="default path (MFCC.fused = %r; report %r); 3 input batches rotate" % (mf.fused, mf.fused_report()["path"]))
+        x3 = [x[:, None, :] for x in xs]
+        emit("cfg4 variant: (B, 1, L) input = per-item cut-offs", timed(ring(mf, x3), args.warmup, args.steps),
              5120.0, 512 * 160000 * 4 + 512 * 1001 * 40 * 4)
-        del x, x3
+        del xs, x3
         x = noise(128, 2, 1323000)
         rs = T.Resample(44100, 16000, resampling_method="sinc_interp_kaiser", lowpass_filter_width=64,
                         rolloff=0.9475937167399596, beta=14.769656459379492).to(dev)
         emit("cfg3 Resample 44.1k->16k kaiser_best, per-GPU shard 128 x stereo x 30 s",
              timed(lambda: rs(x), 10, 30), 128 * 30.0, x.numel() * 4 + 128 * 2 * 480000 * 4,
-             flops=128 * 2 * 480000 * 373 * 2,
-             note="binary16 hi/lo-split MFMA kernel (default); 373 effective taps per output")
+             flops=128 * 2 * 480000 * 373 * 2, f16_terms=3,
+             note="binary16 hi/lo-split MFMA kernel (default): 3 f16 MFMA terms per product; 373 effective taps per output")
         del x
         x = torch.rand(32, 8, 480000, device=dev, generator=g) - 0.5
         A, B = [], []

@@ -36,7 +36,13 @@ with torch.no_grad():
         for label, fused in (("fused", True), ("two_kernel", False), ("auto", "auto")):
             m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).to(dev)
             m.fused = fused
-            us = timed(lambda: m(inp))
+            ring = [inp, inp.clone(), inp.clone()]          # 3 x 328 MB in + outputs: beyond the 256 MiB Infinity Cache
+            it = [0]
+
+            def step():
+                it[0] += 1
+                return m(ring[it[0] % 3])
+            us = timed(step)
             rep = m.fused_report()
             rec[label] = {"us": round(us, 1), "frac_of_hbm_peak": round(ALGO / us / 8e6, 3), "path": rep["path"],
                           "redone_share": rep["redone_share"]}
