@@ -44,9 +44,13 @@ struct LfThread {   // per-thread registers that live across phases
 template <int D>
 struct LfLds {
   static constexpr int blk_floats = (kLfThreads * kLfChunkStride + 1) & ~1;   // even: the doubles behind stay 8-aligned
-  static constexpr int scanA = 0;                                   // kLfThreads*D
-  static constexpr int scanB = scanA + kLfThreads * D;
-  static constexpr int H = scanB + kLfThreads * D;                  // kLfChunk*D      | per-stage slots from here
+  // scan rows: D doubles per thread at a row stride of SD doubles with SD odd -- 2 SD dwords = 2 (mod 4), so the b64
+  // accesses of 32 consecutive threads land on 32 distinct bank pairs (a stride of D doubles is an 8-way (D = 4) to 32-way
+  // (D = 16) bank conflict on every read of a scan step)
+  static constexpr int SD = D + 1 + (D & 1);
+  static constexpr int scanA = 0;                                   // kLfThreads*SD
+  static constexpr int scanB = scanA + kLfThreads * SD;
+  static constexpr int H = scanB + kLfThreads * SD;                 // kLfChunk*D      | per-stage slots from here
   static constexpr int Mp = H + kLfChunk * D;                       // kLfScanSteps*D*D
   static constexpr int ah = Mp + kLfScanSteps * D * D;              // D+1 (a^)
   static constexpr int bh = ah + (D + 1);                           // D+1 (b^)
@@ -171,7 +175,7 @@ AAMD_HD void lf_chunk_pass(int tid, const float* blk, double* tab, LfThread<D>& 
 #pragma unroll
   for (int e = 0; e < D; ++e) {
     th.s[e] = hz[e];
-    tab[L::scanA + tid * D + e] = hz[e];
+    tab[L::scanA + tid * L::SD + e] = hz[e];
   }
 }
 
@@ -193,7 +197,7 @@ AAMD_HD void lf_scan_step(int tid, int k, double* tab, LfThread<D>& th, bool src
   double* dst = tab + (src_is_a ? L::scanB : L::scanA);
   if (tid >= off) {
     const double* Mk = tab + L::Mp + k * D * D;
-    const double* vp = src + (tid - off) * D;
+    const double* vp = src + (tid - off) * L::SD;
     double v[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) v[d] = vp[d];
@@ -206,7 +210,7 @@ AAMD_HD void lf_scan_step(int tid, int k, double* tab, LfThread<D>& th, bool src
     }
   }
 #pragma unroll
-  for (int e = 0; e < D; ++e) dst[tid * D + e] = th.s[e];
+  for (int e = 0; e < D; ++e) dst[tid * L::SD + e] = th.s[e];
 }
 
 // ---- phase 3: add the homogeneous response of the true entering state, clamp, write back ----
@@ -218,7 +222,7 @@ AAMD_HD void lf_correct_store(int tid, float* blk, const double* tab, LfThread<D
   float* mine = blk + tid * kLfChunkStride;
   double sp[D];
 #pragma unroll
-  for (int e = 0; e < D; ++e) sp[e] = (tid > 0) ? fin[(tid - 1) * D + e] : 0.0;
+  for (int e = 0; e < D; ++e) sp[e] = (tid > 0) ? fin[(tid - 1) * L::SD + e] : 0.0;
   const double* H = tab + L::H;
 #pragma unroll
   for (int j = 0; j < kLfChunk; ++j) {
@@ -238,7 +242,7 @@ template <int D>
 AAMD_HD void lf_save_output_carry(double* tab, bool fin_is_a) {
   using L = LfLds<D>;
   const double* fin = tab + (fin_is_a ? L::scanA : L::scanB);
-  for (int e = 0; e < D; ++e) tab[L::cy + e] = fin[(kLfThreads - 1) * D + e];
+  for (int e = 0; e < D; ++e) tab[L::cy + e] = fin[(kLfThreads - 1) * L::SD + e];
 }
 
 #if defined(__HIPCC__)
@@ -279,11 +283,33 @@ lfilter_kernel(const float* __restrict__ x, const float* __restrict__ a,
     __syncthreads();
     const float* xs = x + seq * length;
     float* ys = y + seq * length;
+    // The next block's samples travel while the current block is filtered: with one workgroup per sequence and (for the
+    // 256 sequences of a cfg5a shard) one wave per SIMD, nothing else hides the ~2 us of an HBM round trip per block.
+    // 32 registers per thread: orders <= 8 (the wider instantiations are at their register limit without it).
+    constexpr bool kPrefetch = D <= 8;
+    float pre[kPrefetch ? kLfChunk : 1];
+    auto fetch = [&](int64_t n0) {
+#pragma unroll
+      for (int k = 0; k < kLfChunk; ++k) {
+        const int64_t n = n0 + tid + (int64_t)k * kLfThreads;
+        pre[kPrefetch ? k : 0] = (n < length) ? xs[n] : 0.0f;
+      }
+    };
+    if (kPrefetch) fetch(0);
     for (int64_t n0 = 0; n0 < length; n0 += kLfBlock) {
       // stage the block (zero beyond the end)
-      for (int i = tid; i < kLfBlock; i += kLfThreads) {
-        const int64_t n = n0 + i;
-        blk[(i / kLfChunk) * kLfChunkStride + (i % kLfChunk)] = (n < length) ? xs[n] : 0.0f;
+      if (kPrefetch) {
+#pragma unroll
+        for (int k = 0; k < kLfChunk; ++k) {
+          const int i = tid + k * kLfThreads;
+          blk[(i / kLfChunk) * kLfChunkStride + (i % kLfChunk)] = pre[kPrefetch ? k : 0];
+        }
+        if (n0 + kLfBlock < length) fetch(n0 + kLfBlock);
+      } else {
+        for (int i = tid; i < kLfBlock; i += kLfThreads) {
+          const int64_t n = n0 + i;
+          blk[(i / kLfChunk) * kLfChunkStride + (i % kLfChunk)] = (n < length) ? xs[n] : 0.0f;
+        }
       }
       for (int st = 0; st < n_stages; ++st) {
         __syncthreads();
