@@ -357,6 +357,20 @@ def _m400_cost_fast(l2_of_pos) -> int:
 _B128_LANES = [[divmod(l if l < 60 else l - 20, 20) for l in g] for g in _B128_GROUPS]
 
 
+def mel400_table_signature(image: np.ndarray, n_mels: int, max_width: int) -> int:
+    """Shape of a table image for `aamd_mel_bands.table_sig`: chunk count of round r in nibble r when the filterbank has
+    exactly 4 rounds of 20 mels (n_mels = 80) and chunk counts below 16; else 0 (= unknown: the generic instantiation)."""
+    if n_mels != 80:
+        return 0
+    rows = 80
+    w4 = (int(max_width) + 1 + 3) & ~3
+    ws = w4 if (w4 >> 2) & 1 else w4 + 4
+    rc = image.view(np.int32)[rows * ws + 2 * rows: rows * ws + 2 * rows + 4]
+    if any(int(v) < 1 or int(v) > 15 for v in rc):
+        return 0
+    return int(rc[0]) | (int(rc[1]) << 4) | (int(rc[2]) << 8) | (int(rc[3]) << 12)
+
+
 def mel400_table_image(lo: np.ndarray, width: np.ndarray, weights: np.ndarray, max_width: int, iters: int = 6000,
                        seed: int = 0):
     """The LDS image of the band table of the (n_fft, hop) = (400, *) kernel (`m400::mel_tab_layout` in csrc/melspec400.h:

@@ -30,7 +30,7 @@ class MelBands(C.Structure):
     _fields_ = [
         ("n_mels", C.c_int32), ("max_width", C.c_int32),
         ("lo", C.c_void_p), ("width", C.c_void_p), ("weights", C.c_void_p), ("lane_order", C.c_void_p),
-        ("table400", C.c_void_p),
+        ("table400", C.c_void_p), ("table_sig", C.c_int32),
     ]
 
 

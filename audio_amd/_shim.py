@@ -61,12 +61,12 @@ def _register_fakes() -> None:
 
     @reg("aamd::mel_spectrogram")
     def _(wav, window, twiddle, band_lo, band_width, band_weights, lane_order, table400, n_fft, hop, pad, center, pad_mode,
-          n_frames, scale, power):
+          n_frames, scale, power, table_sig):
         return wav.new_empty((wav.shape[0], n_frames, band_lo.shape[0]), dtype=torch.float32)
 
     @reg("aamd::mel_spectrogram_db")
     def _(wav, window, twiddle, band_lo, band_width, band_weights, lane_order, table400, n_fft, hop, pad, center, pad_mode,
-          n_frames, scale, power, multiplier, amin, db_multiplier, group_max, rows_per_group):
+          n_frames, scale, power, multiplier, amin, db_multiplier, group_max, rows_per_group, table_sig):
         return wav.new_empty((wav.shape[0], n_frames, band_lo.shape[0]), dtype=torch.float32)
 
     @reg("aamd::mfcc_dct")

@@ -172,6 +172,7 @@ int validate_bands(const aamd_mel_bands* b, int n_freq, MelBandsDev& mb) {
   mb.n_mels = b->n_mels; mb.max_width = b->max_width;
   mb.lo = b->lo; mb.width = b->width; mb.weights = b->weights; mb.order = b->lane_order;
   mb.table400 = b->table400;
+  mb.table_sig = b->table400 ? b->table_sig : 0;
   return AAMD_OK;
 }
 
@@ -241,7 +242,7 @@ bool mel400_eligible(const StftGeom& g, const MelBandsDev& mb) {
          m400::mel_rounds(mb.n_mels) <= m400::kMelMaxRounds;
 }
 
-template <int EPI, int H, typename TIn, int NR>
+template <int EPI, int H, typename TIn, int NR, int SIG = 0>
 int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, const float* window,
                      const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s);
 
@@ -250,12 +251,21 @@ int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, c
 template <int EPI, int H, typename TIn = float>
 int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, const float* window,
                     const float* twiddle, float* out, const m400::Epi400& epi, hipStream_t s) {
-  if (EPI != m400::EPI400_SPEC && m400::mel_rounds(mb.n_mels) <= 4)
+  if (EPI != m400::EPI400_SPEC && m400::mel_rounds(mb.n_mels) <= 4) {
+    // the 80-mel HTK / Slaney banks of the 16 kHz front-ends (headline hop, float input): band reduction compiled for them
+    if constexpr (H == 8 && sizeof(TIn) == 4 && std::is_same<TIn, float>::value &&
+                  (EPI == m400::EPI400_MEL || EPI == m400::EPI400_MFCC)) {   // (MEL_DB: the straight-line form spills 4 registers)
+      if (mb.table_sig == m400::kSigHtk80 && mb.n_mels == 80)
+        return launch_fft400_nr<EPI, H, TIn, 4, m400::kSigHtk80>(g, mb, wav, window, twiddle, out, epi, s);
+      if (mb.table_sig == m400::kSigSlaney80 && mb.n_mels == 80)
+        return launch_fft400_nr<EPI, H, TIn, 4, m400::kSigSlaney80>(g, mb, wav, window, twiddle, out, epi, s);
+    }
     return launch_fft400_nr<EPI, H, TIn, 4>(g, mb, wav, window, twiddle, out, epi, s);
+  }
   return launch_fft400_nr<EPI, H, TIn, m400::kMelMaxRounds>(g, mb, wav, window, twiddle, out, epi, s);
 }
 
-template <int EPI, int H, typename TIn, int NR>
+template <int EPI, int H, typename TIn, int NR, int SIG>
 int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, const float* window,
                      const float* twiddle, float* out, const m400::Epi400& epi_in, hipStream_t s) {
   if (g.rows == 0) return AAMD_OK;
@@ -272,8 +282,8 @@ int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, c
   }
   if (lds > dev_props().lds_per_block_optin)
     return fail(AAMD_EUNSUPPORTED, "audio_amd: mel filterbank too large for the LDS of this device");
-  auto kern = m400::melspec400_kernel<0, EPI, H, TIn, NR>;
-  if (EPI == m400::EPI400_MFCC && epi.lab != 0) kern = m400::melspec400_kernel<(EPI == m400::EPI400_MFCC ? 524288 : 0), EPI, H, TIn, NR>;
+  auto kern = m400::melspec400_kernel<0, EPI, H, TIn, NR, SIG>;
+  if (EPI == m400::EPI400_MFCC && epi.lab != 0) kern = m400::melspec400_kernel<(EPI == m400::EPI400_MFCC ? 524288 : 0), EPI, H, TIn, NR, SIG>;
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -30,6 +30,7 @@
 // functional/functional.py:112-145, torch/functional.py:675-681; framing is bit-exact
 // (index reflection i<0 -> -i, i>=L -> 2(L-1)-i).
 #pragma once
+#include <type_traits>
 #include "hd.h"
 #include "stft_generic.h"
 #include "resample_mfma.h"   // rsm::f16_bits / f16_value: binary16 conversion shared with the CPU replay
@@ -784,7 +785,14 @@ AAMD_HD void mel_regs_load(const LaneConst& c, const MelTab& mt, MelRegs<NR>& h)
   }
 }
 
-template <int NR = kMelMaxRounds>
+// SIG != 0: the filterbank's shape is a compile-time constant -- nibble r = 4-tap chunks of round r, exactly NR rounds, every
+// table row holds a mel (n_mels = 20 NR).  The four rounds are then straight-line code (no switch on a chunk count, no
+// `round exists` / `row holds a mel` tests), so the reads of all rounds are in flight together: - 3 % on the headline batch
+// (profiles/r03_g_mel400_lab_rcsig.txt).  The launcher picks the instantiation when the band table's signature matches.
+AAMD_HD constexpr int sig_chunks(int sig, int r) { return (sig >> (4 * r)) & 15; }
+constexpr int kSigHtk80 = 0x4221, kSigSlaney80 = 0x4211;      // melscale_fbanks(201, 0, 8000, 80, 16000): htk / slaney
+
+template <int NR = kMelMaxRounds, int SIG = 0>
 AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
                      float (&acc_a)[NR], float (&acc_b)[NR], const MelRegs<NR>* h = nullptr) {
   const float* Pp = lds + kPPair * c.p;
@@ -792,10 +800,10 @@ AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     float sa = 0.0f, sb = 0.0f;
-    if (r < mt.n_rounds) {
+    if (SIG != 0 || r < mt.n_rounds) {
       const float* wt = wt0 + r * kMelSlots * mt.ws;
       const float* P = Pp + (h ? h->poff(r) : 2 * mt.lo2[r * kMelSlots + c.pi]);
-      const int nc = h ? h->nc[r] : mt.rc[r];
+      const int nc = SIG != 0 ? sig_chunks(SIG, r) : (h ? h->nc[r] : mt.rc[r]);
       switch (nc) {
         case 1: mel_chunks<1>(wt, P, sa, sb); break;
         case 2: mel_chunks<2>(wt, P, sa, sb); break;
@@ -813,7 +821,7 @@ AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
 // narrow store path (any n_mels / alignment): 4-byte stores straight from the accumulators
 //   Addressing: ONE wave-uniform tile pointer (SGPRs) + a small per-lane 32-bit offset, so every
 //   store is `global_store_dword voffset, data, s[base]` with one v_add -- no per-lane 64-bit pointers.
-template <int NR = kMelMaxRounds>
+template <int NR = kMelMaxRounds, int SIG = 0>
 AAMD_HD void store_direct(const LaneConst& c, const MelTab& mt, const float (&acc_a)[NR],
                           const float (&acc_b)[NR], float* out_row, int64_t t0, int n_frames,
                           const MelRegs<NR>* h = nullptr) {
@@ -821,6 +829,17 @@ AAMD_HD void store_direct(const LaneConst& c, const MelTab& mt, const float (&ac
   const bool va = c.active && 2 * c.p < left, vb = c.active && 2 * c.p + 1 < left;
   float* out_tile = out_row + t0 * (int64_t)mt.n_mels;   // wave-uniform
   const unsigned oa = 2u * (unsigned)c.p * (unsigned)mt.n_mels;
+  if (SIG != 0) {      // every round and every table row is live: one EXEC region per frame instead of one per store
+    if (va) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) out_tile[oa + (unsigned)h->mel(r)] = acc_a[r];
+    }
+    if (vb) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) out_tile[oa + (unsigned)mt.n_mels + (unsigned)h->mel(r)] = acc_b[r];
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     if (r < mt.n_rounds) {
@@ -985,7 +1004,7 @@ __global__ void __launch_bounds__(256) mel_tab_build_kernel(MelBandsDev mb, floa
 
 // NR = rounds of 20 mels the per-lane arrays are sized for: 4 (n_mels <= 80, the common front-ends: the control words of
 // the band table then live in registers, MelRegs) or kMelMaxRounds (up to 160 mels, control words re-read from LDS).
-template <int LAB, int EPI, int H = 8, typename TIn = float, int NR = kMelMaxRounds>
+template <int LAB, int EPI, int H = 8, typename TIn = float, int NR = kMelMaxRounds, int SIG = 0>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, AAMD_M400_MINWAVES)
 melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
                   const float* __restrict__ tw400, MelBandsDev mb, float* __restrict__ out,
@@ -1067,6 +1086,14 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   if (EPI != EPI400_SPEC && kHoist) {
     mel_regs_load<NR>(c, mt, mregs);
     mh = &mregs;
+  }
+  if (SIG != 0) {
+    // the launcher chose this instantiation from the caller's `table_sig`: it must describe the table that was just copied
+    // into LDS (exactly NR rounds, every row a mel, these chunk counts) -- anything else is a caller bug, and a wrong
+    // answer is the one thing this library does not return
+    static_assert(SIG == 0 || NR == 4, "filterbank signatures are 4 rounds of 20 mels");
+    const int sig_rt = mregs.nc[0] | (mregs.nc[1 % NR] << 4) | (mregs.nc[2 % NR] << 8) | (mregs.nc[3 % NR] << 12);
+    if (mt.n_rounds != NR || mt.n_mels != kMelSlots * NR || sig_rt != SIG) __builtin_trap();
   }
   float nrm_mean[NR], nrm_inv[NR];   // MEL_NORM: statistics of this lane's mels
   if (EPI == EPI400_MEL_NORM) {
@@ -1265,7 +1292,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     wave_lds_fence();
     float acc_a[NR], acc_b[NR];
     if (LAB & 4) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
-    phase_c<NR>(c, mt, lds, acc_a, acc_b, mh);
+    phase_c<NR, SIG>(c, mt, lds, acc_a, acc_b, mh);
     if (kDb) {
       const int64_t g = cur.row / epi.rows_per_group;   // wave-uniform
       if (g != wgroup) {
@@ -1415,7 +1442,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       wave_lds_fence();
       if (!(LAB & 2)) store_wide(lane, mt, lds, out_row, cur.t0, n_frames);
     } else {
-      if (!(LAB & 2)) store_direct<NR>(c, mt, acc_a, acc_b, out_row, cur.t0, n_frames, mh);
+      if (!(LAB & 2)) store_direct<NR, SIG>(c, mt, acc_a, acc_b, out_row, cur.t0, n_frames, mh);
     }
     wave_lds_fence();
     cur = nxt;

@@ -34,6 +34,7 @@ struct MelBandsDev {
   const float* weights;
   const int32_t* order;   // mel400 only: table row -> mel (lane assignment), -1 = unused row; null = identity
   const float* table400;  // mel400 only: prebuilt LDS image of the band table (m400::mel_tab_dwords dwords), or null
+  int table_sig;          // mel400 only: shape of that image (chunk counts per round as nibbles), 0 = unknown
 };
 
 // ---- geometry of one workgroup: PB frame PAIRS (2 PB consecutive frames of one waveform) ------------

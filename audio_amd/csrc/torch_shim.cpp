@@ -94,7 +94,7 @@ aamd_stft_desc make_desc(const Tensor& wav, int64_t n_fft, int64_t hop, int64_t 
 struct Bands {
   aamd_mel_bands b{};
   Bands(const Tensor& wav, const Tensor& lo, const Tensor& width, const Tensor& weights,
-        const std::optional<Tensor>& lane_order, const std::optional<Tensor>& table400) {
+        const std::optional<Tensor>& lane_order, const std::optional<Tensor>& table400, int64_t table_sig = 0) {
     want_i32(lo, "band_lo");
     want_i32(width, "band_width");
     want_f32(weights, "band_weights", 2);
@@ -121,6 +121,7 @@ struct Bands {
                       "audio_amd: table400 does not belong to this band table");
       b.table400 = fp(*table400);
     }
+    b.table_sig = b.table400 ? (int32_t)table_sig : 0;     // (the kernel verifies it against the table and traps on a mismatch)
   }
 };
 
@@ -143,14 +144,14 @@ Tensor spectrogram(Tensor wav, Tensor window, Tensor twiddle, int64_t n_fft, int
 // ---- aamd::mel_spectrogram  (transforms/_transforms.py:612-622) ---------------------------------------------------
 Tensor mel_spectrogram(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, Tensor band_weights,
                        std::optional<Tensor> lane_order, std::optional<Tensor> table400, int64_t n_fft, int64_t hop, int64_t pad, bool center,
-                       int64_t pad_mode, int64_t n_frames, double scale, double power) {
+                       int64_t pad_mode, int64_t n_frames, double scale, double power, int64_t table_sig) {
   aamd_stft_desc d = make_desc(wav, n_fft, hop, pad, center, pad_mode, true, n_frames, scale, power);
   want_f32(window, "window", 1);
   want_f32(twiddle, "twiddle");
   same_device(wav, window);
   same_device(wav, twiddle);
   STD_TORCH_CHECK(window.numel() == n_fft && twiddle.numel() == 2 * n_fft, "audio_amd: window / twiddle size");
-  Bands bands(wav, band_lo, band_width, band_weights, lane_order, table400);
+  Bands bands(wav, band_lo, band_width, band_weights, lane_order, table400, table_sig);
   const torch::stable::accelerator::DeviceGuard guard(wav.get_device_index());
   Tensor out = torch::stable::new_empty(wav, {d.rows, n_frames, (int64_t)bands.b.n_mels});
   if (out.numel())
@@ -162,13 +163,14 @@ Tensor mel_spectrogram(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo
 Tensor mel_spectrogram_db(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width,
                           Tensor band_weights, std::optional<Tensor> lane_order, std::optional<Tensor> table400, int64_t n_fft, int64_t hop, int64_t pad,
                           bool center, int64_t pad_mode, int64_t n_frames, double scale, double power, double multiplier,
-                          double amin, double db_multiplier, std::optional<Tensor> group_max, int64_t rows_per_group) {
+                          double amin, double db_multiplier, std::optional<Tensor> group_max, int64_t rows_per_group,
+                          int64_t table_sig) {
   aamd_stft_desc d = make_desc(wav, n_fft, hop, pad, center, pad_mode, true, n_frames, scale, power);
   want_f32(window, "window", 1);
   want_f32(twiddle, "twiddle");
   same_device(wav, window);
   same_device(wav, twiddle);
-  Bands bands(wav, band_lo, band_width, band_weights, lane_order, table400);
+  Bands bands(wav, band_lo, band_width, band_weights, lane_order, table400, table_sig);
   float* gmax = nullptr;
   if (group_max.has_value()) {
     want_f32(*group_max, "group_max", 1);
@@ -333,11 +335,11 @@ STABLE_TORCH_LIBRARY(aamd, m) {
         "bool onesided, int n_frames, float scale, float power) -> Tensor");
   m.def("mel_spectrogram(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, "
         "Tensor band_weights, Tensor? lane_order, Tensor? table400, int n_fft, int hop, int pad, bool center, int pad_mode, int n_frames, "
-        "float scale, float power) -> Tensor");
+        "float scale, float power, int table_sig) -> Tensor");
   m.def("mel_spectrogram_db(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, "
         "Tensor band_weights, Tensor? lane_order, Tensor? table400, int n_fft, int hop, int pad, bool center, int pad_mode, int n_frames, "
         "float scale, float power, float multiplier, float amin, float db_multiplier, Tensor(a!)? group_max, "
-        "int rows_per_group) -> Tensor");
+        "int rows_per_group, int table_sig) -> Tensor");
   m.def("mfcc_dct(Tensor mel, Tensor dct_mat, int log_mode, Tensor? group_max, int vec_per_group, float top_db) -> Tensor");
   m.def("resample(Tensor wav, Tensor kernel, int orig, int new, int width, int out_len, int[]? band_tap_lo, "
         "int tap_span) -> Tensor");

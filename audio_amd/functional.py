@@ -195,12 +195,15 @@ class MelBandsOnDevice:
                                     self.weights.data_ptr(),
                                     self.lane_order.data_ptr() if self.lane_order is not None else None, None)
         self.table400 = None
+        self.table_sig = 0
         if self.n_freq == 201 and self.lo.is_cuda:
             L = _lib.lib()
             n = L.aamd_mel400_table_dwords(self.n_mels, max_width)
             if n > 0:
                 if image is not None and image.shape[0] == n:
                     self.table400 = torch.from_numpy(image).to(device)
+                    self.table_sig = _host.mel400_table_signature(image, int(self.n_mels), int(max_width))
+                    self.struct.table_sig = self.table_sig
                 else:       # the device builder (band starts at the band's first even bin)
                     self.table400 = torch.zeros(n, dtype=torch.float32, device=device)
                     with torch.cuda.device(device):
@@ -744,10 +747,11 @@ def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_ff
         targs = (x2, _padded_window(window, n_fft), _twiddles(n_fft, waveform.device), bands.lo, bands.width,
                  bands.weights, bands.lane_order, bands.table400, n_fft, hop_length, pad, bool(center), desc.pad_mode, desc.n_frames,
                  desc.scale, desc.power)
+        sig = int(bands.table_sig)
         if db is None:
-            return ops.mel_spectrogram(*targs)
+            return ops.mel_spectrogram(*targs, sig)
         multiplier, amin, db_multiplier, group_max, rows_per_group = db
-        return ops.mel_spectrogram_db(*targs, multiplier, amin, db_multiplier, group_max, rows_per_group)
+        return ops.mel_spectrogram_db(*targs, multiplier, amin, db_multiplier, group_max, rows_per_group, sig)
     out = torch.empty((desc.rows, desc.n_frames, bands.n_mels), dtype=torch.float32, device=waveform.device)
     if out.numel():
         L = _lib.lib()
@@ -782,7 +786,7 @@ def _melspectrogram_plan(waveform: Tensor, pad: int, window: Tensor, fb: Tensor,
         return None
     args = (_padded_window(window, n_fft), _twiddles(n_fft, waveform.device), bands.lo, bands.width, bands.weights,
             bands.lane_order, bands.table400, n_fft, hop_length, pad, bool(center), desc.pad_mode, desc.n_frames,
-            desc.scale, desc.power)
+            desc.scale, desc.power, int(bands.table_sig))
     return ops.mel_spectrogram, (x2.shape[0], x2.shape[1]), args, (bands, window)      # keep-alives last
 
 

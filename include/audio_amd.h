@@ -101,6 +101,12 @@ typedef struct aamd_mel_bands {
    * launch copies the table into LDS with one round of loads; without it each workgroup derives it from lo / width /
    * weights / lane_order (three dependent rounds, ~3 us per launch).  Results are identical. */
   const float* table400;
+  /* Optional (0 = unknown): the shape of the table400 image -- 4-tap chunks of round r in nibble r, given ONLY when the
+   * filterbank has exactly 4 rounds of 20 mels and every table row holds a mel.  For the signatures the library was built
+   * for (HTK / Slaney 80 mels at 16 kHz: 0x4221 / 0x4211) the radix-20x20 kernel runs an instantiation whose band
+   * reduction is straight-line code (- 3 %).  A signature that does not describe table400 is a caller bug: the kernel
+   * checks it against the table and traps.  audio_amd/_host.py: mel400_table_signature. */
+  int32_t table_sig;
 } aamd_mel_bands;
 
 /* Size (in 4-byte words) of the prebuilt band table for a filterbank, 0 if the filterbank is outside what the

@@ -91,9 +91,9 @@ def test_compiled_aamd_ops_have_fake_kernels():
         lo, wd, wt = torch.empty(80, **i32), torch.empty(80, **i32), torch.empty(80, 30, device=dev)
         assert torch.ops.aamd.spectrogram(w, win, tw, 400, 160, 0, True, 0, True, 101, 1.0, 2.0).shape == (4, 101, 201)
         assert torch.ops.aamd.spectrogram(w, win, tw, 400, 160, 0, True, 0, True, 101, 1.0, 0.0).shape == (4, 101, 402)
-        assert torch.ops.aamd.mel_spectrogram(w, win, tw, lo, wd, wt, None, None, 400, 160, 0, True, 0, 101, 1.0, 2.0).shape == (4, 101, 80)
+        assert torch.ops.aamd.mel_spectrogram(w, win, tw, lo, wd, wt, None, None, 400, 160, 0, True, 0, 101, 1.0, 2.0, 0).shape == (4, 101, 80)
         assert torch.ops.aamd.mel_spectrogram_db(w, win, tw, lo, wd, wt, None, None, 400, 160, 0, True, 0, 101, 1.0, 2.0, 10.0,
-                                                 1e-10, 0.0, None, 1).shape == (4, 101, 80)
+                                                 1e-10, 0.0, None, 1, 0).shape == (4, 101, 80)
         assert torch.ops.aamd.mfcc_dct(torch.empty(404, 80, device=dev), torch.empty(80, 40, device=dev), 2, None, 1, 80.0).shape == (404, 40)
         assert torch.ops.aamd.resample(w, torch.empty(160, 815, device=dev), 441, 160, 187, 5805, None, 0).shape == (4, 5805)
         x3 = torch.empty(2, 3, 100, device=dev)

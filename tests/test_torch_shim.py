@@ -17,7 +17,7 @@ SCHEMAS = {
                    "int pad_mode, bool onesided, int n_frames, float scale, float power) -> Tensor",
     "mel_spectrogram": "aamd::mel_spectrogram(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, "
                        "Tensor band_weights, Tensor? lane_order, Tensor? table400, int n_fft, int hop, int pad, bool center, int pad_mode, "
-                       "int n_frames, float scale, float power) -> Tensor",
+                       "int n_frames, float scale, float power, int table_sig) -> Tensor",
     "mfcc_dct": "aamd::mfcc_dct(Tensor mel, Tensor dct_mat, int log_mode, Tensor? group_max, int vec_per_group, "
                 "float top_db) -> Tensor",
     "resample": "aamd::resample(Tensor wav, Tensor kernel, int orig, int new, int width, int out_len, int[]? band_tap_lo, "

@@ -24,7 +24,10 @@ static int launch(const float* wav, const float* window, const float* tw, const 
   const int64_t n_tiles = rows * tiles_per_row;
   const int wpb = m400::kWavesPerBlock;
   const size_t lds = m400::lds_bytes(mb.n_mels, mb.max_width, m400::Hop<8>::lds_dwords);
-  auto kern = m400::melspec400_kernel<LAB, m400::EPI400_MEL, 8, float, 4>;
+#ifndef LAB_SIG
+#define LAB_SIG 0
+#endif
+  auto kern = m400::melspec400_kernel<LAB, m400::EPI400_MEL, 8, float, 4, LAB_SIG>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
   hipDeviceProp_t dp;
   int dev = 0;
@@ -50,7 +53,7 @@ extern "C" int lab_mel400(const float* wav, const float* window, const float* tw
                           int blocks_override, void* stream) {
   MelBandsDev mb{};
   mb.n_mels = b->n_mels; mb.max_width = b->max_width; mb.lo = b->lo; mb.width = b->width; mb.weights = b->weights;
-  mb.order = b->lane_order; mb.table400 = b->table400;
+  mb.order = b->lane_order; mb.table400 = b->table400; mb.table_sig = b->table_sig;
   return launch<LAB_BITS>(wav, window, tw, mb, out, rows, length, row_stride, n_frames, scale, out_wide, blocks_override,
                           (hipStream_t)stream);
 }
