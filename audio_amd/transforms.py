@@ -268,6 +268,8 @@ class AmplitudeToDB(torch.nn.Module):
         self.db_multiplier = math.log10(max(self.amin, self.ref_value))
 
     def forward(self, x: Tensor) -> Tensor:
+        if torch.compiler.is_compiling():
+            return torch.ops.audio_amd.amplitude_to_DB(x, self.multiplier, self.amin, self.db_multiplier, self.top_db)
         return F.amplitude_to_DB(x, self.multiplier, self.amin, self.db_multiplier, self.top_db)
 
 
@@ -535,6 +537,9 @@ class Resample(torch.nn.Module):
     def forward(self, waveform: Tensor) -> Tensor:
         if self.orig_freq == self.new_freq:
             return waveform
+        if torch.compiler.is_compiling():          # one opaque op with a fake kernel (see MelSpectrogram.forward)
+            return torch.ops.audio_amd.resample_apply(waveform, self.kernel, self.orig_freq, self.new_freq, self.gcd,
+                                                      self.width)
         return F._apply_sinc_resample_kernel(waveform, self.orig_freq, self.new_freq, self.gcd, self.kernel,
                                              self.width)
 
@@ -548,4 +553,6 @@ class FFTConvolve(torch.nn.Module):
         self.mode = mode
 
     def forward(self, x: Tensor, y: Tensor) -> Tensor:
+        if torch.compiler.is_compiling():
+            return torch.ops.audio_amd.fftconvolve(x, y, self.mode)
         return F.fftconvolve(x, y, mode=self.mode)

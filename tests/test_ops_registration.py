@@ -73,6 +73,16 @@ def test_torch_compile_fullgraph_sees_each_module_as_one_op():
         assert tuple(y.shape) == shape and y.stride()[-2:] == (1, shape[1])
         calls = [str(n.target) for n in graphs[-1].graph.nodes if n.op == "call_function"]
         assert calls == [op], calls
+    rs = T.Resample(44100, 16000).to("meta")
+    y = torch.compile(rs, fullgraph=True, backend=backend)(torch.empty(2, 44100, device="meta"))
+    assert tuple(y.shape) == (2, 16000)
+    assert [str(n.target) for n in graphs[-1].graph.nodes if n.op == "call_function"] == ["audio_amd.resample_apply"]
+    fc = T.FFTConvolve("full")
+    y = torch.compile(fc, fullgraph=True, backend=backend)(torch.empty(3, 100, device="meta"), torch.empty(3, 7, device="meta"))
+    assert tuple(y.shape) == (3, 106)
+    db = T.AmplitudeToDB("power", 80.0)
+    y = torch.compile(db, fullgraph=True, backend=backend)(torch.empty(3, 80, 101, device="meta"))
+    assert tuple(y.shape) == (3, 80, 101)
 
 
 def test_compiled_aamd_ops_have_fake_kernels():
