@@ -948,6 +948,7 @@ struct TileInfo {
 //   bit 3: no LDS-DMA issue              bit 4: no phase B (second DFT, separation, P rows)
 //   bit 15 (32768): interior tiles gather their samples with plain global loads, the NEXT tile's 28 samples per lane
 //                   prefetched into registers right after phase A (no LDS staging at all)
+//   bit 22 (4194304): the stores of a wave always hit the same (cache-resident) 1920 bytes: store ISSUE cost without HBM writes
 //   bit 20 (1048576): every wave records (cycle counter, 100 MHz wall clock) at entry and exit into epi.fix_count
 //   bit 17 (131072): tiles handed out chip-wide in chunks of kLabChunk from ONE global counter (epi.group_max, zeroed by
 //                   the lab before each launch) instead of static per-workgroup ranges
@@ -1436,6 +1437,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       }
     }
     float* out_row = out + cur.row * (EPI == EPI400_MEL_NORM ? epi.out_frames : (int64_t)n_frames) * (int64_t)mb.n_mels;
+    if (LAB & 4194304) out_row = out + (int64_t)(wave + kWavesPerBlock * (blockIdx.x & 63)) * 6 * mb.n_mels - cur.t0 * (int64_t)mb.n_mels;   // lab bit 22: every store of a wave goes to one cache-resident tile
     if (out_wide) {
       wave_lds_fence();
       store_stage<NR>(c, mt, acc_a, acc_b, lds, mh);
