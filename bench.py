@@ -382,6 +382,20 @@ def main():
         wall = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / args.steps
     y = ys[(args.steps - 1) % ring] if args.steps else run(xs[0])
+    steady = None
+    if args.steps < 500:
+        # a short timed region (the driver's --steps 20 is 1.4 ms of GPU time) is a small sample: the same loop over 1000 more
+        # steps, OUTSIDE the timed K and never used for `value`, is reported beside it
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            for i in range(1000):
+                step(i)
+            s1.record()
+            torch.cuda.synchronize()
+        steady = {"steps": 1000, "ms_per_step": s0.elapsed_time(s1) / 1000.0,
+                  "note": "outside the timed region; not used for `value` / `ms_per_step`"}
 
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     per_rank = None
@@ -475,6 +489,9 @@ def main():
             out["per_rank_ms_min_max"] = [min(per_rank), max(per_rank)]
         if sg is not None:
             out["scatter_gather"] = sg
+        if steady is not None:
+            steady["frac_of_hbm_peak"] = algo_bytes / (steady["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["steady_state_1000_steps"] = steady
         if world == 1 and not args.no_cpu_baseline and args.op == "mel":
             from oracle import torch_cpu_ref
             sweep = torch_cpu_ref.sweep_mel_baseline(batch, SECONDS, SR, N_FFT, HOP, N_MELS)
