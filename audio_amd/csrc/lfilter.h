@@ -56,7 +56,8 @@ struct LfLds {
   static constexpr int bh = ah + (D + 1);                           // D+1 (b^)
   static constexpr int cx = bh + (D + 1);                           // carried inputs  [D]
   static constexpr int cy = cx + D;                                 // carried outputs [D] (true, unclamped)
-  static constexpr int total = cy + D;
+  static constexpr int neff = cy + D;                               // scan steps that matter (as a double), + kLfScanSteps flags
+  static constexpr int total = neff + 1 + kLfScanSteps;
   static constexpr int stage_doubles = total - H;
   // bytes for a cascade of n_stages: one working copy + (n_stages > 1) a parked copy per stage
   static constexpr size_t bytes(int n_stages) {
@@ -136,6 +137,28 @@ AAMD_HD void lf_tables_square(int tid, int k, double* tab) {
     acc = lf_dd_add(acc, lf_dd_mul(LfDD{Mk[e * D + f], lo_in[e * D + f]}, LfDD{Mk[f * D + d], lo_in[f * D + d]}));
   tab[L::Mp + k * D * D + tid] = acc.hi;
   lo_out[tid] = acc.lo;
+}
+
+// phase D (tid < kLfScanSteps, then tid 0): scan steps whose matrix is below 2^-70 everywhere add nothing a float32 output can
+// see, even through a homogeneous response of 1e6 (poles at radius r: |M^(2^k)| ~ r^(32 2^k); r = 0.95 -> steps 5, 6, 7).
+// Once a power is that small all higher ones are (they are its squares), so the scan simply stops early.
+template <int D>
+AAMD_HD void lf_tables_small(int tid, double* tab) {
+  using L = LfLds<D>;
+  if (tid >= kLfScanSteps) return;
+  double m = 0.0;
+  for (int i = 0; i < D * D; ++i) {
+    const double v = tab[L::Mp + tid * D * D + i];
+    m = fmax(m, v < 0.0 ? -v : v);
+  }
+  tab[L::neff + 1 + tid] = (m < 8.470329472543003e-22) ? 1.0 : 0.0;      // 2^-70
+}
+template <int D>
+AAMD_HD void lf_tables_neff(double* tab) {
+  using L = LfLds<D>;
+  int n = kLfScanSteps;
+  while (n > 0 && tab[L::neff + n] != 0.0) --n;        // flags at neff + 1 + k
+  tab[L::neff] = (double)n;
 }
 
 // ---- phase 1: chunk pass from zero state (chunk 0: from the carried state) ------------------
@@ -275,6 +298,10 @@ lfilter_kernel(const float* __restrict__ x, const float* __restrict__ a,
         __syncthreads();
         lf_tables_square<D>(tid, k, tab);
       }
+      __syncthreads();
+      lf_tables_small<D>(tid, tab);
+      __syncthreads();
+      if (tid == 0) lf_tables_neff<D>(tab);
       if (n_stages > 1) {
         __syncthreads();
         for (int i = tid; i < L::stage_doubles; i += kLfThreads) stage_store[st * L::stage_doubles + i] = tab[L::H + i];
@@ -321,7 +348,8 @@ lfilter_kernel(const float* __restrict__ x, const float* __restrict__ a,
         __syncthreads();
         if (tid == 0) lf_save_input_carry<D>(blk, tab);
         bool src_is_a = true;
-        for (int k = 0; k < kLfScanSteps; ++k) {
+        const int n_eff = (int)tab[L::neff];             // (workgroup-uniform; written before the barrier above)
+        for (int k = 0; k < n_eff; ++k) {
           lf_scan_step<D>(tid, k, tab, th, src_is_a);
           __syncthreads();
           src_is_a = !src_is_a;

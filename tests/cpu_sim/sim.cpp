@@ -907,6 +907,8 @@ static int sim_lfilter_d(const float* x, const float* a, const float* b, float* 
       for (int tid = 0; tid < kLfThreads; ++tid) lf_tables_response<D>(tid, tab);
       for (int k = 1; k < kLfScanSteps; ++k)
         for (int tid = 0; tid < kLfThreads; ++tid) lf_tables_square<D>(tid, k, tab);
+      for (int tid = 0; tid < kLfThreads; ++tid) lf_tables_small<D>(tid, tab);
+      lf_tables_neff<D>(tab);
       for (int i = 0; i < L::stage_doubles; ++i) stage_store[st * L::stage_doubles + i] = tab[L::H + i];
     }
     const float* xs = x + seq * length;
@@ -921,7 +923,8 @@ static int sim_lfilter_d(const float* x, const float* a, const float* b, float* 
         for (int tid = 0; tid < kLfThreads; ++tid) lf_chunk_pass<D>(tid, blk, tab, th[tid]);
         lf_save_input_carry<D>(blk, tab);
         bool src_is_a = true;
-        for (int k = 0; k < kLfScanSteps; ++k) {
+        const int n_eff = (int)tab[L::neff];
+        for (int k = 0; k < n_eff; ++k) {
           for (int tid = 0; tid < kLfThreads; ++tid) lf_scan_step<D>(tid, k, tab, th[tid], src_is_a);
           src_is_a = !src_is_a;
         }
