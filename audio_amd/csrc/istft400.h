@@ -172,7 +172,7 @@ istft400_kernel(Inv400Geom ig, const cplx<float>* __restrict__ spec, const float
     float xr[20], xi[20], vr[20], vi[20], zr[20], zi[20];
     inv400_load(c, ig, spec + row * ig.g.n_frames * (int64_t)kSpecBins, t0, xr, xi);
     wave_lds_fence();
-    phase_a_core<false>(c, xr, xi, lds);
+    phase_a_core<0>(c, xr, xi, lds);
     wave_lds_fence();
     phase_b1_load(c, lds, vr, vi);
     wave_lds_fence();

@@ -486,7 +486,7 @@ __device__ __forceinline__ void tr_store5(unsigned lds_base, const float (&wr)[5
 
 // DFT-20 over q of the lane's 20 complex inputs, twiddle by W400^(b s), transposed write (shared by the forward
 // kernel and the inverse / adjoint kernel of istft400.h, whose inputs are spectrum bins instead of windowed samples)
-template <bool TREG = false>
+template <int TREG = 0>      // leading batches of five columns whose twiddles are in registers (`twr`); the rest comes from the LDS table
 AAMD_HD void phase_a_core(const LaneConst& c, const float (&xr)[20], const float (&xi)[20], float* __restrict__ lds,
                           const float* twr = nullptr) {
   // The twiddle table and the transposition rows live in the same LDS array but never overlap.  The reads of batch
@@ -504,7 +504,7 @@ AAMD_HD void phase_a_core(const LaneConst& c, const float (&xr)[20], const float
       twn[2 * j + 1] = t.y;
     }
   };
-  if (!TREG) tw_load(0);
+  if (TREG < 4) tw_load(TREG);
   float yr[20], yi[20];
   dft20(xr, xi, yr, yi);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -513,7 +513,7 @@ AAMD_HD void phase_a_core(const LaneConst& c, const float (&xr)[20], const float
 #pragma unroll
   for (int blk = 0; blk < 4; ++blk) {
     float tw[10];      // W^(b s) for s = 5 blk .. 5 blk + 4 as (re, im) pairs
-    if (!TREG) {
+    if (blk >= TREG) {
 #pragma unroll
       for (int j = 0; j < 10; ++j) tw[j] = twn[j];
       if (blk < 3) tw_load(blk + 1);
@@ -552,7 +552,7 @@ AAMD_HD void phase_a_core(const LaneConst& c, const float (&xr)[20], const float
 //   A frame b beyond the end of the clip is NOT zeroed here (that cost 20 selects per tile): its
 //   spectrum is garbage that no store path writes (store_direct / store_wide / store_spec mask by
 //   frame) and that the dB epilogue excludes from the running maximum.
-template <int H, bool WREG = false, bool TREG = false>
+template <int H, bool WREG = false, int TREG = 0>
 AAMD_HD void phase_a(const LaneConst& c, const float (&X)[Hop<H>::nx], float* lds, const float* winr = nullptr,
                      const float* twr = nullptr) {
   float xr[20], xi[20];
@@ -1077,9 +1077,16 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 #pragma unroll
     for (int q = 0; q < 20; ++q) winr[q] = c.win[q];
   }
-  if (LAB & 16384) {
+#ifndef AAMD_M400_TWREG
+#define AAMD_M400_TWREG 3
+#endif
+  // Twiddle batches (of five columns) held in registers instead of re-read from the LDS table every tile: all four under lab
+  // bit 14 (spills).  The signature instantiation runs at 136 registers, so three batches fit its 168 (164; - 3.0 % on the
+  // headline batch, 67.3 -> 65.3 us, profiles/r03_i_mel400_lab_twiddle_regs.txt): 15 of the 20 ds_read_b64 per tile gone.
+  constexpr int kTwRegBatches = (LAB & 16384) ? 4 : ((SIG != 0 && EPI == EPI400_MEL) ? AAMD_M400_TWREG : 0);
+  if (kTwRegBatches > 0) {
 #pragma unroll
-    for (int q = 0; q < 40; ++q) twr[q] = c.tw[q];
+    for (int q = 0; q < 10 * kTwRegBatches; ++q) twr[q] = c.tw[q];
   }
   constexpr bool kHoist = NR <= 4;
   MelRegs<NR> mregs;
@@ -1249,7 +1256,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       gather_global<H, TIn>(c, wav + (cur.row / InTraits<TIn>::chans) * row_stride, length, cur.t0, n_frames, X,
                             (int)(cur.row % InTraits<TIn>::chans));
     }
-    phase_a<H, kWinRegs, (LAB & 16384) != 0>(c, X, lds, winr, twr);
+    phase_a<H, kWinRegs, kTwRegBatches>(c, X, lds, winr, twr);
     if ((LAB & 32768) && nxt.staged) gload(nxt);        // X is dead: the next tile's samples fly during phases B and C
     wave_lds_fence();
     float vr[20], vi[20], zr[20], zi[20], qr[10], qi[10];
