@@ -1083,7 +1083,15 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // Twiddle batches (of five columns) held in registers instead of re-read from the LDS table every tile: all four under lab
   // bit 14 (spills).  The signature instantiation runs at 136 registers, so three batches fit its 168 (164; - 3.0 % on the
   // headline batch, 67.3 -> 65.3 us, profiles/r03_i_mel400_lab_twiddle_regs.txt): 15 of the 20 ds_read_b64 per tile gone.
-  constexpr int kTwRegBatches = (LAB & 16384) ? 4 : ((SIG != 0 && EPI == EPI400_MEL) ? AAMD_M400_TWREG : 0);
+  // The other float-input hop-160 instantiations get what their register count leaves (tests/test_no_spills.py keeps every
+  // one of them out of scratch): Spectrogram 144 -> 2 batches, generic mel 149 / 135 (NR 4 / 8) -> 1 / 3, mel + dB 154 -> 1.
+  constexpr bool kPlain = H == 8 && std::is_same<TIn, float>::value && LAB == 0;
+  constexpr int kTwRegBatches = (LAB & 16384) ? 4
+                                : (SIG != 0 && EPI == EPI400_MEL) ? AAMD_M400_TWREG
+                                : !kPlain ? 0
+                                : EPI == EPI400_SPEC ? 2
+                                : (EPI == EPI400_MEL && SIG == 0) ? (NR <= 4 ? 1 : 3)
+                                : (EPI == EPI400_MEL_DB && NR <= 4) ? 1 : 0;
   if (kTwRegBatches > 0) {
 #pragma unroll
     for (int q = 0; q < 10 * kTwRegBatches; ++q) twr[q] = c.tw[q];
