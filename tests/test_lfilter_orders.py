@@ -265,3 +265,55 @@ class _nullcontext:
 
     def __exit__(self, *a):
         return False
+
+
+# ---- the headline kernel's filterbank-signature instantiations (round 3) ---------------------------------------------------
+def test_table_signatures_of_the_common_80_mel_banks():
+    """`aamd_mel_bands.table_sig` as the host derives it from the table image: the two banks the library carries an
+    instantiation for (HTK / Slaney, 80 mels, 0-8 kHz at 16 kHz), and 0 (= generic kernel) for everything else."""
+    from audio_amd import _host
+    import warnings
+    want = {(80, None, "htk"): 0x4221, (80, "slaney", "slaney"): 0x4211, (64, None, "htk"): 0, (128, None, "htk"): 0,
+            (40, None, "htk"): 0}
+    for (n_mels, norm, scale), sig in want.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fb = _host.melscale_fbanks(201, 0.0, 8000.0, n_mels, 16000, norm, scale).numpy()
+        lo, width, weights, mw = _host.mel_band_table(fb)
+        img, _ = _host.mel400_table_image(lo, width, weights, mw, iters=100)
+        assert _host.mel400_table_signature(img, n_mels, mw) == sig, (n_mels, norm, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bank", ["htk", "slaney"])
+def test_melspectrogram_signature_instantiations_against_the_oracle(bank):
+    """The 80-mel HTK and Slaney banks run `melspec400_kernel<..., SIG>` (band reduction compiled for the bank's chunk counts,
+    twiddles in registers; the kernel traps if the signature does not describe the table): against the float64 oracle on
+    interior tiles, clip edges (ragged length: unstaged tiles) and a clip shorter than one tile row, and bit-for-bit
+    against the generic instantiation of the same kernel fed the same table without a signature."""
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    from oracle import dsp_oracle as O
+    kw = dict(norm="slaney", mel_scale="slaney") if bank == "slaney" else {}
+    mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80, **kw).cuda()
+    bands = F._mel_bands(mel.mel_scale.fb, torch.device("cuda", 0))
+    assert bands.table_sig == (0x4211 if bank == "slaney" else 0x4221)
+    g = torch.Generator().manual_seed(5)
+    fb = mel.mel_scale.fb.double().cpu().numpy()
+    win = mel.spectrogram.window.double().cpu().numpy()
+    for shape in ((3, 16000), (2, 12345), (1, 700)):
+        x = (0.4 * torch.randn(*shape, generator=g)).clamp_(-1, 1)
+        with torch.no_grad():
+            got = mel(x.cuda())
+        want = O.mel_spectrogram(x.numpy().astype(np.float64), win, fb, 400, 160)
+        assert peak_rel_err(got.cpu().numpy(), want) <= 2e-6, (bank, shape)
+        # the generic instantiation: same table, signature withheld
+        sig, bands.struct.table_sig, bands.table_sig = bands.table_sig, 0, 0
+        try:
+            mel._plans.clear()
+            with torch.no_grad():
+                gen = mel(x.cuda())
+        finally:
+            bands.struct.table_sig, bands.table_sig = sig, sig
+            mel._plans.clear()
+        assert float((got - gen).abs().max()) <= 2e-7 * float(gen.abs().max()), (bank, shape)
