@@ -44,10 +44,21 @@ constexpr int kMaxCascade = 8;
 constexpr int kMaxWaves = 16;
 
 // per-stage table (floats): ah[3] bh[3] pad[2] | Mc^(2^k), k = 0..9 [10][4] | Mc^(l+1), l = 0..63 [64][4] |
-//                           Mc^(64 w), w = 0..15 [16][4]
+//                           Mc^(64 w), w = 0..15 [16][4] | Ms = state after kSub homogeneous steps [4]
 constexpr int kPow2 = 10;
 constexpr int kTabAB = 0, kTabM = 8, kTabPow = kTabM + 4 * kPow2, kTabPowW = kTabPow + 4 * 64;
-constexpr int kTabFloats = kTabPowW + 4 * kMaxWaves;           // 368
+constexpr int kTabSub = kTabPowW + 4 * kMaxWaves;              // 368
+constexpr int kTabFloats = kTabSub + 4;                        // 372
+// A lane's chunk is filtered as kNSub independent sub-chunks of kSub samples (each from zero recursion state; a 2 x 2
+// step with Ms chains their end states).  Why: every instruction of the plain 32-sample pass reads the result of the one
+// before it, and on gfx950 a wave issues dependent VALU instructions 8.5 cycles apart (independent ones 5; two waves per
+// SIMD: 4.26 against 2.76 cycles per instruction and SIMD with four chains -- tools/lab/valu_ubench.hip,
+// profiles/r03_zz_valu_issue.txt).
+#ifndef AAMD_LFW_NSUB
+#define AAMD_LFW_NSUB 1
+#endif
+constexpr int kNSub = AAMD_LFW_NSUB;
+constexpr int kSub = kCh / kNSub;
 // exchange area (floats): S[2 buffers][W][2] | carry[2 parity][stages][2]
 AAMD_HD int xch_S(int W, int buf, int w) { return (buf * W + w) * 2; }
 AAMD_HD int xch_carry(int W, int n_stages, int parity, int st) { return 4 * W + (parity * n_stages + st) * 2; }
@@ -104,6 +115,20 @@ AAMD_HD void build_stage(const float* a_row, const float* b_row, int n_order, fl
     M[0][d] = h0;   // y[31]
     M[1][d] = h1;   // y[30]
   }
+  {
+    double Ms[2][2];                                    // state after kSub homogeneous steps
+    for (int d = 0; d < 2; ++d) {
+      double h0 = (d == 0) ? 1.0 : 0.0, h1 = (d == 1) ? 1.0 : 0.0;
+      for (int j = 0; j < kSub; ++j) {
+        const double y = -(double)ah[1] * h0 - (double)ah[2] * h1;
+        h1 = h0;
+        h0 = y;
+      }
+      Ms[0][d] = h0;
+      Ms[1][d] = h1;
+    }
+    mat_put(tab + kTabSub, Ms);
+  }
   double P[2][2] = {{M[0][0], M[0][1]}, {M[1][0], M[1][1]}};       // Mc^(l+1)
   for (int l = 0; l < 64; ++l) {
     mat_put(tab + kTabPow + 4 * l, P);
@@ -125,25 +150,64 @@ AAMD_HD void build_stage(const float* a_row, const float* b_row, int n_order, fl
 
 // ---- phase 1: filter the lane's chunk from zero recursion state; (hu0, hu1) = x[-1], x[-2] -------
 //      x is overwritten by the zero-state response z (in place: one register array per lane)
-AAMD_HD void chunk_pass(const float* tab, float (&x)[kCh], float hu0, float hu1, float& s0, float& s1) {
-  const float a1 = tab[kTabAB + 1], a2 = tab[kTabAB + 2];
-  const float b0 = tab[kTabAB + 3], b1 = tab[kTabAB + 4], b2 = tab[kTabAB + 5];
-  float hz0 = 0.0f, hz1 = 0.0f;
+// the normalised coefficients of a stage and the kSub-step matrix, read from the table ONCE per stage and block
+struct StageCoef { float a1, a2, b0, b1, b2, ms[4]; };
+AAMD_HD StageCoef stage_coef(const float* tab) {
+  StageCoef c;
+  c.a1 = tab[kTabAB + 1]; c.a2 = tab[kTabAB + 2];
+  c.b0 = tab[kTabAB + 3]; c.b1 = tab[kTabAB + 4]; c.b2 = tab[kTabAB + 5];
+  for (int i = 0; i < 4; ++i) c.ms[i] = (kNSub > 1) ? tab[kTabSub + i] : 0.0f;
+  return c;
+}
+AAMD_HD void chunk_pass(const StageCoef& cf, float (&x)[kCh], float hu0, float hu1, float& s0, float& s1) {
+  const float a1 = cf.a1, a2 = cf.a2, b0 = cf.b0, b1 = cf.b1, b2 = cf.b2;
+  // kNSub chains side by side: sample j of every sub-chunk, then sample j + 1 of every sub-chunk, ...
+  float u0[kNSub], u1[kNSub], z0[kNSub], z1[kNSub];
 #pragma unroll
-  for (int j = 0; j < kCh; ++j) {
-    const float u = x[j];
-    float w = b2 * hu1;          // oldest tap first (lfilter.cpp:40-43)
-    w += b1 * hu0;
-    w += b0 * u;
-    float y = w;
-    y -= a2 * hz1;
-    y -= a1 * hz0;
-    hu1 = hu0; hu0 = u;
-    hz1 = hz0; hz0 = y;
-    x[j] = y;
+  for (int k = 0; k < kNSub; ++k) {
+    u0[k] = k ? x[kSub * k - 1] : hu0;      // true input history of the sub-chunk (read before sub-chunk k - 1 overwrites it)
+    u1[k] = k ? x[kSub * k - 2] : hu1;
+    z0[k] = 0.0f;
+    z1[k] = 0.0f;
   }
-  s0 = hz0;
-  s1 = hz1;
+#pragma unroll
+  for (int j = 0; j < kSub; ++j) {
+    // operation by operation across the chains (the five operations of one sample depend on each other in sequence)
+    float w[kNSub];
+#pragma unroll
+    for (int k = 0; k < kNSub; ++k) w[k] = b2 * u1[k];          // oldest tap first (lfilter.cpp:40-43)
+#pragma unroll
+    for (int k = 0; k < kNSub; ++k) w[k] += b1 * u0[k];
+#pragma unroll
+    for (int k = 0; k < kNSub; ++k) w[k] += b0 * x[kSub * k + j];
+    if (j >= 2) {                    // (zero recursion state: the first two samples of a sub-chunk have nothing to subtract)
+#pragma unroll
+      for (int k = 0; k < kNSub; ++k) w[k] -= a2 * z1[k];
+    }
+    if (j >= 1) {
+#pragma unroll
+      for (int k = 0; k < kNSub; ++k) w[k] -= a1 * z0[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kNSub; ++k) {
+      u1[k] = u0[k]; u0[k] = x[kSub * k + j];
+      z1[k] = z0[k]; z0[k] = w[k];
+      x[kSub * k + j] = w[k];
+    }
+  }
+  // end state of the whole chunk from zero state: e_(n-1) + Ms (e_(n-2) + Ms (... e_0))
+  s0 = z0[0];
+  s1 = z1[0];
+#pragma unroll
+  for (int k = 1; k < kNSub; ++k) {
+    const float r0 = cf.ms[0] * s0 + cf.ms[1] * s1 + z0[k];
+    const float r1 = cf.ms[2] * s0 + cf.ms[3] * s1 + z1[k];
+    s0 = r0;
+    s1 = r1;
+  }
+}
+AAMD_HD void chunk_pass(const float* tab, float (&x)[kCh], float hu0, float hu1, float& s0, float& s1) {
+  chunk_pass(stage_coef(tab), x, hu0, hu1, s0, s1);
 }
 
 // (r0, r1) = M . (n0, n1) for a 2x2 M stored row-major
@@ -185,19 +249,39 @@ AAMD_HD void fold_finish(const float* tab, int w, float i0, float i1, float c0, 
 }
 
 // ---- phase 4: homogeneous response started from the true state (t0, t1) entering the chunk, clamp ----
-AAMD_HD void correct_clamp(const float* tab, float t0, float t1, int clamp, float (&z)[kCh]) {
-  const float a1 = tab[kTabAB + 1], a2 = tab[kTabAB + 2];
-  float c0 = t0, c1 = t1;
+template <bool CLAMP>
+AAMD_HD void correct_clamp_t(const StageCoef& cf, float t0, float t1, float (&z)[kCh]) {
+  const float a1 = cf.a1, a2 = cf.a2;
+  // true state entering sub-chunk k: T_0 = (t0, t1), T_(k+1) = Ms T_k + e_k, with e_k = the zero-state end of sub-chunk k,
+  // i.e. the last two values of its zero-state response (still in z)
+  float c0[kNSub], c1[kNSub];
+  c0[0] = t0;
+  c1[0] = t1;
 #pragma unroll
-  for (int j = 0; j < kCh; ++j) {
-    float c = -(a2 * c1);
-    c -= a1 * c0;
-    c1 = c0;
-    c0 = c;
-    float y = z[j] + c;
-    if (clamp) y = fmin(fmax(y, -1.0f), 1.0f);
-    z[j] = y;
+  for (int k = 1; k < kNSub; ++k) {
+    c0[k] = cf.ms[0] * c0[k - 1] + cf.ms[1] * c1[k - 1] + z[kSub * k - 1];
+    c1[k] = cf.ms[2] * c0[k - 1] + cf.ms[3] * c1[k - 1] + z[kSub * k - 2];
   }
+#pragma unroll
+  for (int j = 0; j < kSub; ++j) {
+#pragma unroll
+    for (int k = 0; k < kNSub; ++k) {
+      float c = -(a2 * c1[k]);
+      c -= a1 * c0[k];
+      c1[k] = c0[k];
+      c0[k] = c;
+      float y = z[kSub * k + j] + c;
+      if (CLAMP) y = fmin(fmax(y, -1.0f), 1.0f);
+      z[kSub * k + j] = y;
+    }
+  }
+}
+AAMD_HD void correct_clamp(const StageCoef& cf, float t0, float t1, int clamp, float (&z)[kCh]) {
+  if (clamp) correct_clamp_t<true>(cf, t0, t1, z);      // (wave-uniform: two straight-line bodies instead of a select per sample)
+  else correct_clamp_t<false>(cf, t0, t1, z);
+}
+AAMD_HD void correct_clamp(const float* tab, float t0, float t1, int clamp, float (&z)[kCh]) {
+  correct_clamp(stage_coef(tab), t0, t1, clamp, z);
 }
 AAMD_HD float clamp1(float v, int clamp) { return clamp ? fmin(fmax(v, -1.0f), 1.0f) : v; }
 // clamp argument of the launch: 0 never, 1 after every stage (n sequential lfilter calls), 2 after the LAST stage only (one
@@ -254,42 +338,68 @@ __device__ __attribute__((noinline)) void build_stage_call(const float* a_row, c
 // One stage of the wave's 2048 samples (v: the lane's chunk, in place): chunk pass, wave scan, publication of the wave-end
 // state, the stage's ONE barrier, fold to the true entering state, correction and clamp.  (hin0, hin1): lane 0's input
 // history on entry, the next stage's on exit.
-template <int LAB>
+// One 2 x 2 table entry in registers
+struct Mat4 { float m[4]; };
+__device__ __forceinline__ Mat4 mat_load(const float* p) {
+  const F4 t = *reinterpret_cast<const F4*>(p);
+  return Mat4{{t.x, t.y, t.z, t.w}};
+}
+
+// PRE: the table entries of the scan are requested at the top of the stage (in flight during the chunk pass), those of the
+// fold and of the state update right before the barrier (they land while the wave waits): 6 + 6 x 16 bytes, 24 registers
+// at a time (the 12-wave kernels have them).  Without it the serial part of the
+// stage -- scan, barrier, fold, state update, about 110 dependent instructions -- stopped six times for an LDS round trip
+// (profiles/r03_zz_lfilter_issue.txt).
+template <int LAB, bool PRE = false>
 __device__ __forceinline__ void stage_step(const float* tab, float* xch, int W, int n_stages, int parity, int st, int sbuf,
                                            int wave, int lane, int clamp, float (&v)[kCh], float& hin0, float& hin1) {
   float hu0 = wave_shr1(v[kCh - 1]), hu1 = wave_shr1(v[kCh - 2]);
   if (lane == 0) { hu0 = hin0; hu1 = hin1; }
   float s0, s1;
+  const StageCoef cf = stage_coef(tab);
+  Mat4 ms[6], mf[4], mw, ml;
+  if (PRE) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ms[k] = mat_load(scan_mat(tab, k, lane));
+  }
   // scheduling fences between the phases: left alone, the scheduler interleaves the chunk pass with the table reads
   // of the later phases and needs 135 registers -- 7 more than 16 waves have, and ANY scratch reload inside the stage
   // loop would wait for the LDS-DMA in flight (vmcnt counts both)
   __builtin_amdgcn_sched_barrier(0);
-  chunk_pass(tab, v, hu0, hu1, s0, s1);
+  chunk_pass(cf, v, hu0, hu1, s0, s1);
   __builtin_amdgcn_sched_barrier(0);
   if (!(LAB & 4)) {
-#define AAMD_LFW_SCAN(STEP) mat_acc(scan_mat(tab, STEP, lane), scan_take<STEP>(s0), scan_take<STEP>(s1), s0, s1);
+#define AAMD_LFW_SCAN(STEP) mat_acc(PRE ? ms[STEP].m : scan_mat(tab, STEP, lane), scan_take<STEP>(s0), scan_take<STEP>(s1), s0, s1);
     AAMD_LFW_SCAN(0) AAMD_LFW_SCAN(1) AAMD_LFW_SCAN(2) AAMD_LFW_SCAN(3) AAMD_LFW_SCAN(4) AAMD_LFW_SCAN(5)
 #undef AAMD_LFW_SCAN
   }
   if (lane == 63) *reinterpret_cast<F2*>(xch + xch_S(W, sbuf, wave)) = F2{s0, s1};
+  if (PRE && !(LAB & 8)) {                                  // the tables of the fold and of the state update land while the wave waits
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mf[k] = mat_load(fold_mat(tab, k));
+    mw = mat_load(tab + kTabPowW + 4 * wave);
+    ml = mat_load(tab + kTabPow + 4 * lane);
+  }
   if (!(LAB & 2)) lds_barrier();                            // the wave-end states of this stage are visible
   float e0 = 0.0f, e1 = 0.0f;
   if (!(LAB & 8)) {
     const F2 cin = *reinterpret_cast<const F2*>(xch + xch_carry(W, n_stages, parity, st));
     const F2 sw = *reinterpret_cast<const F2*>(xch + xch_S(W, sbuf, (lane & 15) < W ? (lane & 15) : 0));
     float f0 = (lane & 15) < W ? sw.x : 0.0f, f1 = (lane & 15) < W ? sw.y : 0.0f;
-#define AAMD_LFW_FOLD(STEP) mat_acc(fold_mat(tab, STEP), scan_take<STEP>(f0), scan_take<STEP>(f1), f0, f1);
+#define AAMD_LFW_FOLD(STEP) mat_acc(PRE ? mf[STEP].m : fold_mat(tab, STEP), scan_take<STEP>(f0), scan_take<STEP>(f1), f0, f1);
     AAMD_LFW_FOLD(0) AAMD_LFW_FOLD(1) AAMD_LFW_FOLD(2) AAMD_LFW_FOLD(3)
 #undef AAMD_LFW_FOLD
     const int from = wave > 0 ? wave - 1 : 0;
     const float i0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f0), from));
     const float i1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f1), from));
-    fold_finish(tab, wave, i0, i1, cin.x, cin.y, e0, e1);
-    mat_acc(tab + kTabPow + 4 * lane, e0, e1, s0, s1);      // + Mc^(l+1) E_w: true state after chunk l
+    e0 = (wave > 0) ? i0 : 0.0f;                            // (fold_finish with the table entry in registers)
+    e1 = (wave > 0) ? i1 : 0.0f;
+    mat_acc(PRE ? mw.m : tab + kTabPowW + 4 * wave, cin.x, cin.y, e0, e1);
+    mat_acc(PRE ? ml.m : tab + kTabPow + 4 * lane, e0, e1, s0, s1);      // + Mc^(l+1) E_w: true state after chunk l
     float t0 = wave_shr1(s0), t1 = wave_shr1(s1);
     if (lane == 0) { t0 = e0; t1 = e1; }
     __builtin_amdgcn_sched_barrier(0);
-    correct_clamp(tab, t0, t1, clamp, v);
+    correct_clamp(cf, t0, t1, clamp, v);
   }
   if (lane == 63 && wave == W - 1)   // true (unclamped) state leaving the block -> next block's carry
     *reinterpret_cast<F2*>(xch + xch_carry(W, n_stages, parity ^ 1, st)) = F2{s0, s1};
@@ -648,6 +758,10 @@ lfilter_wave_pipe_kernel(const float* __restrict__ x, const float* __restrict__ 
 //   slots (i, 1 .. n - 2): the copies of block i + 1 into the IN tiles; slot (i, n - 1) starts with vmcnt(0), so the copies have
 //                landed when the filter waves pass barrier (i, n - 1) and read them.
 constexpr int kMovers = 4;
+#ifndef AAMD_LFW_PREFETCH
+#define AAMD_LFW_PREFETCH 1
+#endif
+constexpr bool kMoverPrefetch = AAMD_LFW_PREFETCH != 0;
 
 #if defined(__HIPCC__)
 template <int LAB = 0>
@@ -785,7 +899,7 @@ lfilter_wave_mover_kernel(const float* __restrict__ x, const float* __restrict__
       const int64_t nw = n0 + (int64_t)wave * kWaveBlock;
       nw_last = nw;
       for (int st = 0; st < n_stages; ++st, sbuf ^= 1)
-        stage_step<LAB>(tabs + st * kTabFloats, xch, W, n_stages, parity, st, sbuf, wave, lane, stage_clamp(clamp, st, n_stages), v, hin0, hin1);
+        stage_step<LAB, kMoverPrefetch>(tabs + st * kTabFloats, xch, W, n_stages, parity, st, sbuf, wave, lane, stage_clamp(clamp, st, n_stages), v, hin0, hin1);
       // behind barrier (i, n - 1): the movers have read block i - 1 out of the OUT tile and block i + 1 has landed in the IN tile
 #pragma unroll
       for (int q = 0; q < 8; ++q)

@@ -30,7 +30,12 @@ def build(specs):
     procs = []
     for spec in specs:
         name, _, flags = spec.partition(":")
-        fl = [f for f in flags.split(",") if f]
+        fl = []
+        for f in flags.split(","):
+            if f.startswith("-mllvm="):
+                fl += ["-mllvm", f[len("-mllvm="):]]
+            elif f:
+                fl.append(f)
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast",
                "-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"] + fl + [SRC, "-o", so_path(name)]
         log = open(os.path.join(OUT, name + ".log"), "w")
