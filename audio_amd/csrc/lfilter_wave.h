@@ -44,21 +44,10 @@ constexpr int kMaxCascade = 8;
 constexpr int kMaxWaves = 16;
 
 // per-stage table (floats): ah[3] bh[3] pad[2] | Mc^(2^k), k = 0..9 [10][4] | Mc^(l+1), l = 0..63 [64][4] |
-//                           Mc^(64 w), w = 0..15 [16][4] | Ms = state after kSub homogeneous steps [4]
+//                           Mc^(64 w), w = 0..15 [16][4]
 constexpr int kPow2 = 10;
 constexpr int kTabAB = 0, kTabM = 8, kTabPow = kTabM + 4 * kPow2, kTabPowW = kTabPow + 4 * 64;
-constexpr int kTabSub = kTabPowW + 4 * kMaxWaves;              // 368
-constexpr int kTabFloats = kTabSub + 4;                        // 372
-// A lane's chunk is filtered as kNSub independent sub-chunks of kSub samples (each from zero recursion state; a 2 x 2
-// step with Ms chains their end states).  Why: every instruction of the plain 32-sample pass reads the result of the one
-// before it, and on gfx950 a wave issues dependent VALU instructions 8.5 cycles apart (independent ones 5; two waves per
-// SIMD: 4.26 against 2.76 cycles per instruction and SIMD with four chains -- tools/lab/valu_ubench.hip,
-// profiles/r03_zz_valu_issue.txt).
-#ifndef AAMD_LFW_NSUB
-#define AAMD_LFW_NSUB 1
-#endif
-constexpr int kNSub = AAMD_LFW_NSUB;
-constexpr int kSub = kCh / kNSub;
+constexpr int kTabFloats = kTabPowW + 4 * kMaxWaves;           // 368
 // exchange area (floats): S[2 buffers][W][2] | carry[2 parity][stages][2]
 AAMD_HD int xch_S(int W, int buf, int w) { return (buf * W + w) * 2; }
 AAMD_HD int xch_carry(int W, int n_stages, int parity, int st) { return 4 * W + (parity * n_stages + st) * 2; }
@@ -115,20 +104,6 @@ AAMD_HD void build_stage(const float* a_row, const float* b_row, int n_order, fl
     M[0][d] = h0;   // y[31]
     M[1][d] = h1;   // y[30]
   }
-  {
-    double Ms[2][2];                                    // state after kSub homogeneous steps
-    for (int d = 0; d < 2; ++d) {
-      double h0 = (d == 0) ? 1.0 : 0.0, h1 = (d == 1) ? 1.0 : 0.0;
-      for (int j = 0; j < kSub; ++j) {
-        const double y = -(double)ah[1] * h0 - (double)ah[2] * h1;
-        h1 = h0;
-        h0 = y;
-      }
-      Ms[0][d] = h0;
-      Ms[1][d] = h1;
-    }
-    mat_put(tab + kTabSub, Ms);
-  }
   double P[2][2] = {{M[0][0], M[0][1]}, {M[1][0], M[1][1]}};       // Mc^(l+1)
   for (int l = 0; l < 64; ++l) {
     mat_put(tab + kTabPow + 4 * l, P);
@@ -150,61 +125,28 @@ AAMD_HD void build_stage(const float* a_row, const float* b_row, int n_order, fl
 
 // ---- phase 1: filter the lane's chunk from zero recursion state; (hu0, hu1) = x[-1], x[-2] -------
 //      x is overwritten by the zero-state response z (in place: one register array per lane)
-// the normalised coefficients of a stage and the kSub-step matrix, read from the table ONCE per stage and block
-struct StageCoef { float a1, a2, b0, b1, b2, ms[4]; };
+// the normalised coefficients of a stage, read from the table ONCE per stage and block
+struct StageCoef { float a1, a2, b0, b1, b2; };
 AAMD_HD StageCoef stage_coef(const float* tab) {
-  StageCoef c;
-  c.a1 = tab[kTabAB + 1]; c.a2 = tab[kTabAB + 2];
-  c.b0 = tab[kTabAB + 3]; c.b1 = tab[kTabAB + 4]; c.b2 = tab[kTabAB + 5];
-  for (int i = 0; i < 4; ++i) c.ms[i] = (kNSub > 1) ? tab[kTabSub + i] : 0.0f;
-  return c;
+  return StageCoef{tab[kTabAB + 1], tab[kTabAB + 2], tab[kTabAB + 3], tab[kTabAB + 4], tab[kTabAB + 5]};
 }
 AAMD_HD void chunk_pass(const StageCoef& cf, float (&x)[kCh], float hu0, float hu1, float& s0, float& s1) {
-  const float a1 = cf.a1, a2 = cf.a2, b0 = cf.b0, b1 = cf.b1, b2 = cf.b2;
-  // kNSub chains side by side: sample j of every sub-chunk, then sample j + 1 of every sub-chunk, ...
-  float u0[kNSub], u1[kNSub], z0[kNSub], z1[kNSub];
+  float hz0 = 0.0f, hz1 = 0.0f;
 #pragma unroll
-  for (int k = 0; k < kNSub; ++k) {
-    u0[k] = k ? x[kSub * k - 1] : hu0;      // true input history of the sub-chunk (read before sub-chunk k - 1 overwrites it)
-    u1[k] = k ? x[kSub * k - 2] : hu1;
-    z0[k] = 0.0f;
-    z1[k] = 0.0f;
+  for (int j = 0; j < kCh; ++j) {
+    const float u = x[j];
+    float w = cf.b2 * hu1;          // oldest tap first (lfilter.cpp:40-43)
+    w += cf.b1 * hu0;
+    w += cf.b0 * u;
+    float y = w;
+    if (j >= 2) y -= cf.a2 * hz1;   // (zero recursion state: the first two samples have nothing to subtract)
+    if (j >= 1) y -= cf.a1 * hz0;
+    hu1 = hu0; hu0 = u;
+    hz1 = hz0; hz0 = y;
+    x[j] = y;
   }
-#pragma unroll
-  for (int j = 0; j < kSub; ++j) {
-    // operation by operation across the chains (the five operations of one sample depend on each other in sequence)
-    float w[kNSub];
-#pragma unroll
-    for (int k = 0; k < kNSub; ++k) w[k] = b2 * u1[k];          // oldest tap first (lfilter.cpp:40-43)
-#pragma unroll
-    for (int k = 0; k < kNSub; ++k) w[k] += b1 * u0[k];
-#pragma unroll
-    for (int k = 0; k < kNSub; ++k) w[k] += b0 * x[kSub * k + j];
-    if (j >= 2) {                    // (zero recursion state: the first two samples of a sub-chunk have nothing to subtract)
-#pragma unroll
-      for (int k = 0; k < kNSub; ++k) w[k] -= a2 * z1[k];
-    }
-    if (j >= 1) {
-#pragma unroll
-      for (int k = 0; k < kNSub; ++k) w[k] -= a1 * z0[k];
-    }
-#pragma unroll
-    for (int k = 0; k < kNSub; ++k) {
-      u1[k] = u0[k]; u0[k] = x[kSub * k + j];
-      z1[k] = z0[k]; z0[k] = w[k];
-      x[kSub * k + j] = w[k];
-    }
-  }
-  // end state of the whole chunk from zero state: e_(n-1) + Ms (e_(n-2) + Ms (... e_0))
-  s0 = z0[0];
-  s1 = z1[0];
-#pragma unroll
-  for (int k = 1; k < kNSub; ++k) {
-    const float r0 = cf.ms[0] * s0 + cf.ms[1] * s1 + z0[k];
-    const float r1 = cf.ms[2] * s0 + cf.ms[3] * s1 + z1[k];
-    s0 = r0;
-    s1 = r1;
-  }
+  s0 = hz0;
+  s1 = hz1;
 }
 AAMD_HD void chunk_pass(const float* tab, float (&x)[kCh], float hu0, float hu1, float& s0, float& s1) {
   chunk_pass(stage_coef(tab), x, hu0, hu1, s0, s1);
@@ -251,29 +193,16 @@ AAMD_HD void fold_finish(const float* tab, int w, float i0, float i1, float c0, 
 // ---- phase 4: homogeneous response started from the true state (t0, t1) entering the chunk, clamp ----
 template <bool CLAMP>
 AAMD_HD void correct_clamp_t(const StageCoef& cf, float t0, float t1, float (&z)[kCh]) {
-  const float a1 = cf.a1, a2 = cf.a2;
-  // true state entering sub-chunk k: T_0 = (t0, t1), T_(k+1) = Ms T_k + e_k, with e_k = the zero-state end of sub-chunk k,
-  // i.e. the last two values of its zero-state response (still in z)
-  float c0[kNSub], c1[kNSub];
-  c0[0] = t0;
-  c1[0] = t1;
+  float c0 = t0, c1 = t1;
 #pragma unroll
-  for (int k = 1; k < kNSub; ++k) {
-    c0[k] = cf.ms[0] * c0[k - 1] + cf.ms[1] * c1[k - 1] + z[kSub * k - 1];
-    c1[k] = cf.ms[2] * c0[k - 1] + cf.ms[3] * c1[k - 1] + z[kSub * k - 2];
-  }
-#pragma unroll
-  for (int j = 0; j < kSub; ++j) {
-#pragma unroll
-    for (int k = 0; k < kNSub; ++k) {
-      float c = -(a2 * c1[k]);
-      c -= a1 * c0[k];
-      c1[k] = c0[k];
-      c0[k] = c;
-      float y = z[kSub * k + j] + c;
-      if (CLAMP) y = fmin(fmax(y, -1.0f), 1.0f);
-      z[kSub * k + j] = y;
-    }
+  for (int j = 0; j < kCh; ++j) {
+    float c = -(cf.a2 * c1);
+    c -= cf.a1 * c0;
+    c1 = c0;
+    c0 = c;
+    float y = z[j] + c;
+    if (CLAMP) y = fmin(fmax(y, -1.0f), 1.0f);
+    z[j] = y;
   }
 }
 AAMD_HD void correct_clamp(const StageCoef& cf, float t0, float t1, int clamp, float (&z)[kCh]) {
@@ -399,7 +328,8 @@ __device__ __forceinline__ void stage_step(const float* tab, float* xch, int W, 
     float t0 = wave_shr1(s0), t1 = wave_shr1(s1);
     if (lane == 0) { t0 = e0; t1 = e1; }
     __builtin_amdgcn_sched_barrier(0);
-    correct_clamp(cf, t0, t1, clamp, v);
+    if (PRE) correct_clamp(cf, t0, t1, clamp, v);
+    else correct_clamp(tab, t0, t1, clamp, v);             // (a1, a2 re-read: the 128-register instantiations have no room to keep them)
   }
   if (lane == 63 && wave == W - 1)   // true (unclamped) state leaving the block -> next block's carry
     *reinterpret_cast<F2*>(xch + xch_carry(W, n_stages, parity ^ 1, st)) = F2{s0, s1};

@@ -26,8 +26,3 @@ extern "C" int lab_lfw_mover(const float* x, const float* a, const float* b, flo
                      length, n_order, n_coeff_rows, n_stages, clamp);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-#ifdef LAB_LFW_HEADER
-extern "C" int lab_lfw_nsub() { return 0; }
-#else
-extern "C" int lab_lfw_nsub() { return lfw::kNSub; }
-#endif
