@@ -455,12 +455,11 @@ AAMD_HD void gather_global(const LaneConst& c, const TIn* wav_row, int64_t lengt
 // kernel and the inverse / adjoint kernel of istft400.h, whose inputs are spectrum bins instead of windowed samples)
 #if defined(__HIP_DEVICE_COMPILE__)
 // five transposed complex values (columns S0 .. S0 + 4) of every lane -> their rows; M0 = LDS byte address of the
-// wave's region for the duration (saved / restored: the compiler treats M0 as reserved)
+// wave's region (declared clobbered: the compiler keeps nothing in M0 here, so there is nothing to save and restore --
+// every scalar instruction costs the wave an issue slot of ~5 cycles, profiles/r03_zz_valu_issue.txt)
 template <int S0>
 __device__ __forceinline__ void tr_store5(unsigned lds_base, const float (&wr)[5], const float (&wi)[5]) {
-  unsigned keep;
   asm volatile(
-      "s_mov_b32 %[k], m0\n\t"
       "s_mov_b32 m0, %[b]\n\t"
       "s_nop 0\n\t"
       "ds_write_addtid_b32 %[r0] offset:%[o0]\n\t"
@@ -472,15 +471,14 @@ __device__ __forceinline__ void tr_store5(unsigned lds_base, const float (&wr)[5
       "ds_write_addtid_b32 %[r3] offset:%[o3]\n\t"
       "ds_write_addtid_b32 %[i3] offset:%[q3]\n\t"
       "ds_write_addtid_b32 %[r4] offset:%[o4]\n\t"
-      "ds_write_addtid_b32 %[i4] offset:%[q4]\n\t"
-      "s_mov_b32 m0, %[k]"
-      : [k] "=&s"(keep)
+      "ds_write_addtid_b32 %[i4] offset:%[q4]"
+      :
       : [b] "s"(lds_base), [r0] "v"(wr[0]), [i0] "v"(wi[0]), [r1] "v"(wr[1]), [i1] "v"(wi[1]), [r2] "v"(wr[2]),
         [i2] "v"(wi[2]), [r3] "v"(wr[3]), [i3] "v"(wi[3]), [r4] "v"(wr[4]), [i4] "v"(wi[4]),
         [o0] "i"(4 * kTOff[S0]), [q0] "i"(4 * kTOff[S0] + 256), [o1] "i"(4 * kTOff[S0 + 1]), [q1] "i"(4 * kTOff[S0 + 1] + 256),
         [o2] "i"(4 * kTOff[S0 + 2]), [q2] "i"(4 * kTOff[S0 + 2] + 256), [o3] "i"(4 * kTOff[S0 + 3]),
         [q3] "i"(4 * kTOff[S0 + 3] + 256), [o4] "i"(4 * kTOff[S0 + 4]), [q4] "i"(4 * kTOff[S0 + 4] + 256)
-      : "memory");
+      : "memory", "m0");
 }
 #endif
 
@@ -931,9 +929,7 @@ __device__ __forceinline__ void exchange_partner(float (&qr)[10], float (&qi)[10
 // LDS-DMA of one 16-B piece per lane: 64 lanes fill 1 KiB at LDS byte address `lds_dst`
 // (wave-uniform).  hipcc does not count this load: the consumer waits with stage_wait().
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 
 __device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1194,7 +1190,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 
   // MEL_DB: running maximum of this wave's dB values, flushed whenever the cut-off group changes
   float wmax = -INFINITY;
-  int64_t wgroup = -1;
+  int64_t wgroup = -1, wrow = -1;
   constexpr bool kDb = (EPI == EPI400_MEL_DB) || (EPI == EPI400_MFCC);
   const bool fix = (EPI == EPI400_MFCC) && epi.fixup != 0;      // kernel-uniform: the fix-up pass of the fused MFCC
   auto flush_max = [&]() {
@@ -1310,10 +1306,13 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     if (LAB & 4) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
     phase_c<NR, SIG>(c, mt, lds, acc_a, acc_b, mh);
     if (kDb) {
-      const int64_t g = cur.row / epi.rows_per_group;   // wave-uniform
-      if (g != wgroup) {
-        flush_max();
-        wgroup = g;
+      if (cur.row != wrow) {        // (a 64-bit division: once per row of the wave's run, not once per tile)
+        wrow = cur.row;
+        const int64_t g = cur.row / epi.rows_per_group;   // wave-uniform
+        if (g != wgroup) {
+          flush_max();
+          wgroup = g;
+        }
       }
       // frames past the end of the clip hold garbage (phase_a): keep them out of the maximum
       const bool va_ok = cur.t0 + 2 * c.p < n_frames, vb_ok = cur.t0 + 2 * c.p + 1 < n_frames;

@@ -18,6 +18,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # shapes; orders 3 .. 8 run as second-order sections), the 2048-point Kaldi kernel, the one-tile biquad kernel's table builder
 ALLOW = [(r"aamd14lfilter_kernelILi(8|12|16)E", 4200), (r"aamd2p217kaldi_pow2_kernelILi32E", 128),
          (r"aamd3lfw19lfilter_wave_kernel", 96), (r"aamd3lfw24lfilter_wave_pipe_kernel", 32),
+         # lab instantiations of the one-tile biquad kernel (tools only: AAMD_LFW_LAB copy-order / non-temporal variants)
+         (r"aamd3lfw19lfilter_wave_kernelILi(128|896)ELi16E", 128),
          (r"aamd3lfw25lfilter_wave_mover_kernel", 32), (r"aamd4m40015istft400_kernel", 16),
          # lab instantiations of the f16 resampler (tools only: AAMD_RSM_LAB), never the product one (<KS, 0>)
          (r"aamd3rsm19resample_f16_kernelILi\d+ELi[12]E", 64)]
