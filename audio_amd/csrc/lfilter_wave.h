@@ -181,9 +181,15 @@ AAMD_HD const float* scan_mat(const float* tab, int step, int lane) {
 }
 
 // ---- phase 3: true state E_w entering wave w from the published wave-end states S_0 .. S_{W-1} ---
-//   I_j = sum_{i <= j} Mw^(j - i) S_i (Mw = Mc^64) by a 4-step scan over 16 lanes (source lane l - 2^k, zeros below 0,
-//   matrix Mc^(64 . 2^k) = table entry 6 + k);  E_w = I_{w-1} + Mc^(64 w) . carry,  E_0 = carry.
-AAMD_HD const float* fold_mat(const float* tab, int step) { return tab + kTabM + 4 * (6 + step); }
+//   E_w = sum_{i < w} Mw^(w - 1 - i) S_i + Mw^w . carry   (Mw = Mc^64; E_0 = carry).
+//   Lane i (< W) of wave w multiplies S_i by the table entry Mc^(64 (w - 1 - i)) -- an entry that does not depend on the
+//   published states, so it is requested before the barrier -- and the contributions are summed by a plain 4-step prefix
+//   sum over the 16-lane row (source lane l - 2^k, zeros below 0); lane w - 1 holds the sum over i < w.  Round 3: the
+//   former matrix scan over the W states (Mc^(64 . 2^k) per step) cost 32 instructions per stage instead of 12.
+AAMD_HD int fold_entry(int w, int lane) {          // index into the Mc^(64 k) table for lane's contribution to wave w
+  const int k = w - 1 - (lane & 15);
+  return k > 0 ? k : 0;                            // (lanes >= w - 1 ... : only lanes < w enter the sum that is read)
+}
 AAMD_HD void fold_finish(const float* tab, int w, float i0, float i1, float c0, float c1, float& e0, float& e1) {
   e0 = (w > 0) ? i0 : 0.0f;
   e1 = (w > 0) ? i1 : 0.0f;
@@ -285,7 +291,7 @@ __device__ __forceinline__ void stage_step(const float* tab, float* xch, int W, 
   if (lane == 0) { hu0 = hin0; hu1 = hin1; }
   float s0, s1;
   const StageCoef cf = stage_coef(tab);
-  Mat4 ms[6], mf[4], mw, ml;
+  Mat4 ms[6], mf, mw, ml;
   if (PRE) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) ms[k] = mat_load(scan_mat(tab, k, lane));
@@ -303,8 +309,7 @@ __device__ __forceinline__ void stage_step(const float* tab, float* xch, int W, 
   }
   if (lane == 63) *reinterpret_cast<F2*>(xch + xch_S(W, sbuf, wave)) = F2{s0, s1};
   if (PRE && !(LAB & 8)) {                                  // the tables of the fold and of the state update land while the wave waits
-#pragma unroll
-    for (int k = 0; k < 4; ++k) mf[k] = mat_load(fold_mat(tab, k));
+    mf = mat_load(tab + kTabPowW + 4 * fold_entry(wave, lane));
     mw = mat_load(tab + kTabPowW + 4 * wave);
     ml = mat_load(tab + kTabPow + 4 * lane);
   }
@@ -314,7 +319,13 @@ __device__ __forceinline__ void stage_step(const float* tab, float* xch, int W, 
     const F2 cin = *reinterpret_cast<const F2*>(xch + xch_carry(W, n_stages, parity, st));
     const F2 sw = *reinterpret_cast<const F2*>(xch + xch_S(W, sbuf, (lane & 15) < W ? (lane & 15) : 0));
     float f0 = (lane & 15) < W ? sw.x : 0.0f, f1 = (lane & 15) < W ? sw.y : 0.0f;
-#define AAMD_LFW_FOLD(STEP) mat_acc(PRE ? mf[STEP].m : fold_mat(tab, STEP), scan_take<STEP>(f0), scan_take<STEP>(f1), f0, f1);
+    {
+      float g0, g1;
+      mat_apply(PRE ? mf.m : tab + kTabPowW + 4 * fold_entry(wave, lane), f0, f1, g0, g1);
+      f0 = g0;
+      f1 = g1;
+    }
+#define AAMD_LFW_FOLD(STEP) { const float a0_ = scan_take<STEP>(f0), a1_ = scan_take<STEP>(f1); f0 += a0_; f1 += a1_; }
     AAMD_LFW_FOLD(0) AAMD_LFW_FOLD(1) AAMD_LFW_FOLD(2) AAMD_LFW_FOLD(3)
 #undef AAMD_LFW_FOLD
     const int from = wave > 0 ? wave - 1 : 0;

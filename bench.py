@@ -397,6 +397,26 @@ def main():
         steady = {"steps": 1000, "ms_per_step": s0.elapsed_time(s1) / 1000.0,
                   "note": "outside the timed region; not used for `value` / `ms_per_step`"}
 
+    # box calibration, outside the timed region: a plain device-to-device copy of one input batch (read + write).  Boxes of
+    # this pool differ (the same kernel ran 66 us on most and 94 us on one, profiles/r03_zz_lfilter_issue.txt); the copy rate
+    # measured in the same process says which kind this run was on
+    with torch.no_grad():
+        dst = torch.empty_like(xs[0])
+        for i in range(10):
+            dst.copy_(xs[i % ring])
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for i in range(50):
+            dst.copy_(xs[i % ring])
+        c1.record()
+        torch.cuda.synchronize()
+        copy_ms = c0.elapsed_time(c1) / 50
+        calibration = {"hbm_copy_GBps": 2 * xs[0].numel() * 4 / (copy_ms * 1e-3) / 1e9, "copy_ms": copy_ms,
+                       "note": "torch copy_ of one input batch (read + write), 50 launches, outside the timed region; "
+                               "5.3 TB/s on the boxes the profiles/ numbers come from"}
+        del dst
+
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     per_rank = None
     if dist is not None:
@@ -484,6 +504,7 @@ def main():
                               "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
                               "read_only_frac": (batch * L * 4) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}, **tdetail, **pmc),
         }
+        out["box_calibration"] = calibration
         if per_rank is not None:
             out["per_rank_ms_per_step"] = per_rank
             out["per_rank_ms_min_max"] = [min(per_rank), max(per_rank)]

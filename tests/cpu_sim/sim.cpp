@@ -961,7 +961,7 @@ extern "C" int sim_lfilter_wave(const float* x, const float* a, const float* b, 
       t1[lane] = src >= 0 ? p1[src] : 0.0f;
     }
     for (int lane = 0; lane < 64; ++lane)
-      mat_acc(fold ? fold_mat(tab, step) : scan_mat(tab, step, lane), t0[lane], t1[lane], p0[lane], p1[lane]);
+      mat_acc(scan_mat(tab, step, lane), t0[lane], t1[lane], p0[lane], p1[lane]);
   };
   for (int64_t seq = 0; seq < n_seq; ++seq) {
     const int crow = (n_rows == 1) ? 0 : (int)(seq % channels);
@@ -1006,7 +1006,20 @@ extern "C" int sim_lfilter_wave(const float* x, const float* a, const float* b, 
             f0[lane] = on ? xch[xch_S(W, sbuf, lane & 15)] : 0.0f;
             f1[lane] = on ? xch[xch_S(W, sbuf, lane & 15) + 1] : 0.0f;
           }
-          for (int k = 0; k < 4; ++k) dpp_step(f0, f1, k, tab, true);
+          for (int lane = 0; lane < 64; ++lane) {   // contribution of S_(lane) to wave w, then a plain prefix sum over the row
+            float g0, g1;
+            mat_apply(tab + kTabPowW + 4 * fold_entry(w, lane), f0[lane], f1[lane], g0, g1);
+            f0[lane] = g0;
+            f1[lane] = g1;
+          }
+          for (int k = 0; k < 4; ++k) {
+            for (int lane = 0; lane < 64; ++lane) {
+              const int src = scan_src(k, lane);
+              t0[lane] = src >= 0 ? f0[src] : 0.0f;
+              t1[lane] = src >= 0 ? f1[src] : 0.0f;
+            }
+            for (int lane = 0; lane < 64; ++lane) { f0[lane] += t0[lane]; f1[lane] += t1[lane]; }
+          }
           const int from = w > 0 ? w - 1 : 0;
           fold_finish(tab, w, f0[from], f1[from], xch[cin], xch[cin + 1], e0[w], e1[w]);
           for (int lane = 0; lane < 64; ++lane)
