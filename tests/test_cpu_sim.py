@@ -808,3 +808,20 @@ def test_resampler_chunk_plan_respects_the_hardware_limits():
                         seen_rounds += rounds > 1
                         seen_four += nld == 4
     assert seen_rounds > 20 and seen_four > 20          # both mechanisms are exercised by the grid
+
+
+@pytest.mark.parametrize("r,theta", [(0.9995, 0.3), (0.999, 1.2), (0.99, 0.05), (0.9999, 2.0)])
+def test_sim_lfilter_wave_slowly_decaying_poles_across_waves(r, theta):
+    """Resonators whose impulse response outlives a wave's 2048 samples (|pole|^2048 = 0.36 at 0.9995, 0.81 at 0.9999): the
+    state entering wave w is a sum over ALL earlier waves of the block (table entries Mc^(64 k), k >= 1, and the prefix sum
+    of lfw::stage_step's fold) plus the carry of the block before -- the decaying designs of the other tests leave all of
+    that at zero."""
+    rng = np.random.default_rng(11)
+    a = np.array([1.0, -2 * r * np.cos(theta), r * r], dtype=np.float32)
+    b = np.array([1 - r, 0.0, 0.0], dtype=np.float32)
+    for waves in (2, 4, 8, 16):
+        L = waves * 2048 * 3 + 515
+        x = (0.1 * rng.standard_normal((1, 1, L))).astype(np.float32)
+        rc, got = S.sim_lfilter_wave(x, a[None, None], b[None, None], False, waves)
+        ref = O.lfilter(x[0, 0].astype(np.float64), a, b, False)
+        assert rc == 0 and peak_rel_err(got[0, 0], ref) <= 4e-5, (r, theta, waves)

@@ -317,3 +317,29 @@ def test_melspectrogram_signature_instantiations_against_the_oracle(bank):
             bands.struct.table_sig, bands.table_sig = sig, sig
             mel._plans.clear()
         assert float((got - gen).abs().max()) <= 2e-7 * float(gen.abs().max()), (bank, shape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,length", [(6, 16 * 2048 * 2 + 777), (640, 4 * 2048 * 3 + 515), (3000, 2048 * 3 + 99)])
+def test_biquad_kernels_with_poles_that_outlive_a_wave(rows, length):
+    """Resonators with |pole| = 0.9995 / 0.9999 (impulse response longer than the 2048 samples a wave owns) on shapes that run
+    the 16-, 8-, 4- and 1-wave instantiations and, as a 4-stage cascade, the mover kernel: the wave-entry fold and the block
+    carry of lfw::stage_step carry real state here (the low-pass designs of the other tests decay to zero inside a wave)."""
+    import audio_amd.functional as F
+    from oracle import dsp_oracle as O
+    g = torch.Generator().manual_seed(rows)
+    x = 0.1 * torch.randn(rows, length, generator=g)
+    designs = [(0.9995, 0.3), (0.9999, 2.0), (0.999, 1.2), (0.99, 0.05)]
+    A = torch.tensor([[1.0, -2 * r * np.cos(t), r * r] for r, t in designs], dtype=torch.float32)
+    B = torch.tensor([[1 - r, 0.0, 0.0] for r, _ in designs], dtype=torch.float32)
+    rows_checked = (0, rows // 2, rows - 1)
+    with torch.no_grad():
+        got1 = F.lfilter(x.cuda(), A[0].cuda(), B[0].cuda(), clamp=False).cpu().numpy()
+        got4 = F.biquad_cascade(x.cuda(), A.cuda(), B.cuda(), clamp=False).cpu().numpy()
+    for i in rows_checked:
+        ref = x[i].double().numpy()
+        ref1 = O.lfilter(ref, A[0].numpy(), B[0].numpy(), False)
+        assert peak_rel_err(got1[i], ref1) <= 4e-5, (rows, i)
+        for k in range(4):
+            ref = O.lfilter(ref, A[k].numpy(), B[k].numpy(), False)
+        assert peak_rel_err(got4[i], ref) <= 1e-4, (rows, i)
