@@ -1081,13 +1081,16 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // headline batch, 67.3 -> 65.3 us, profiles/r03_i_mel400_lab_twiddle_regs.txt): 15 of the 20 ds_read_b64 per tile gone.
   // The other float-input hop-160 instantiations get what their register count leaves (tests/test_no_spills.py keeps every
   // one of them out of scratch): Spectrogram 144 -> 2 batches, generic mel 149 / 135 (NR 4 / 8) -> 1 / 3, mel + dB 154 -> 1.
+#ifndef AAMD_M400_TWREG_DB
+#define AAMD_M400_TWREG_DB 1
+#endif
   constexpr bool kPlain = H == 8 && std::is_same<TIn, float>::value && LAB == 0;
   constexpr int kTwRegBatches = (LAB & 16384) ? 4
                                 : (SIG != 0 && EPI == EPI400_MEL) ? AAMD_M400_TWREG
                                 : !kPlain ? 0
                                 : EPI == EPI400_SPEC ? 2
                                 : (EPI == EPI400_MEL && SIG == 0) ? (NR <= 4 ? 1 : 3)
-                                : (EPI == EPI400_MEL_DB && NR <= 4) ? 1 : 0;
+                                : ((EPI == EPI400_MEL_DB || EPI == EPI400_MFCC) && NR <= 4) ? AAMD_M400_TWREG_DB : 0;
   if (kTwRegBatches > 0) {
 #pragma unroll
     for (int q = 0; q < 10 * kTwRegBatches; ++q) twr[q] = c.tw[q];
