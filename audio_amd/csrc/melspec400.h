@@ -1235,8 +1235,21 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     stage_issue(cur);
   }
 
+  // lab bit 23 (tools/mel400_lab.py phases): shader cycles per phase, summed over the wave's tiles.  The stamps sit where the
+  // kernel drains its LDS counter anyway (s_memtime returns through the same counter), so they move little.
+  long long ph_acc[6] = {0, 0, 0, 0, 0, 0}, ph_t = 0;
+  int ph_tiles = 0;
+#define AAMD_M400_STAMP(K)                                  \
+  if (LAB & 8388608) {                                      \
+    const long long now_ = (long long)clock64();            \
+    ph_acc[K] += now_ - ph_t;                               \
+    ph_t = now_;                                            \
+  }
   while (cur_idx < blk_count) {
+    if (LAB & 8388608) { ph_t = (long long)clock64(); ++ph_tiles; }
     // claim the tile after this one now: it is prefetched while this one is in its second half
+    // (issuing the LDS atomic here and reading its ticket behind the column reads' wait moved 70 cycles from phase A to
+    // phase B and nothing else: profiles/r03_zz_mel400_phase_census.txt)
     const unsigned nxt_idx = (LAB & 131072) ? g_next() : claim();
     TileInfo nxt = tile_info(nxt_idx);
     float fix_cut = -INFINITY;
@@ -1266,11 +1279,13 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     phase_a<H, kWinRegs, kTwRegBatches>(c, X, lds, winr, twr);
     if ((LAB & 32768) && nxt.staged) gload(nxt);        // X is dead: the next tile's samples fly during phases B and C
     wave_lds_fence();
+    AAMD_M400_STAMP(0)   // claim, gather, window, first DFT-20, twiddles, transposed writes
     float vr[20], vi[20], zr[20], zi[20], qr[10], qi[10];
     phase_b1_load(c, lds, vr, vi);
     if (!(LAB & 32768)) {
       // every transposition row has been read: the staging area (it aliases rows) is free again
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      AAMD_M400_STAMP(1)   // column reads
       if (nxt.staged && !(LAB & 8) && !fix) stage_issue(nxt);
     }
     if (LAB & 16) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
@@ -1278,6 +1293,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     phase_b2_send(c, zr, zi, qr, qi);
     exchange_partner(qr, qi, self_mask);
     wave_lds_fence();
+    AAMD_M400_STAMP(2)     // DMA issue, second DFT-20, partner exchange
     if (EPI == EPI400_SPEC) {
       const int64_t left = n_frames - cur.t0;
       const int n_valid = left < kFramesPerWave ? (int)left : kFramesPerWave;
@@ -1305,9 +1321,12 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     phase_b2(c, zr, zi, qr, qi, lds);
     phase_b2_pad(lane, lds);
     wave_lds_fence();
+    AAMD_M400_STAMP(3)     // power, P rows
     float acc_a[NR], acc_b[NR];
     if (LAB & 4) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
     phase_c<NR, SIG>(c, mt, lds, acc_a, acc_b, mh);
+    if (LAB & 8388608) { asm volatile("" : "+v"(acc_a[0]), "+v"(acc_b[NR - 1])); }
+    AAMD_M400_STAMP(4)     // band reduction
     if (kDb) {
       if (cur.row != wrow) {        // (a 64-bit division: once per row of the wave's run, not once per tile)
         wrow = cur.row;
@@ -1464,8 +1483,16 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       if (!(LAB & 2)) store_direct<NR, SIG>(c, mt, acc_a, acc_b, out_row, cur.t0, n_frames, mh);
     }
     wave_lds_fence();
+    AAMD_M400_STAMP(5)     // stores
     cur = nxt;
     cur_idx = nxt_idx;
+  }
+#undef AAMD_M400_STAMP
+  if ((LAB & 8388608) && lane == 0) {
+    long long* rec = reinterpret_cast<long long*>(epi.fix_count) + 4 * 12 * 256 + 8 * (blockIdx.x * kWavesPerBlock + wave);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rec[k] = ph_acc[k];
+    rec[6] = ph_tiles;
   }
   if (kDb && !fix && epi.group_max != nullptr) {
     // final flush through LDS: one atomic per workgroup and group instead of one per wave

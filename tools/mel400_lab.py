@@ -79,7 +79,7 @@ def run(names, launches, rounds, rows=256, seconds=10.0, wide=0, blocks=0):
         L.lab_mel400.argtypes = [C.c_void_p] * 5 + [C.c_int64] * 3 + [C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
         libs[n] = L
     stream = _lib.current_stream(dev)
-    dbg = torch.zeros(4 * 12 * 256, dtype=torch.int64, device=dev)
+    dbg = torch.zeros((4 + 8) * 12 * 256, dtype=torch.int64, device=dev)
     for L in libs.values():
         L.lab_set_debug.argtypes = [C.c_void_p]
         L.lab_set_debug(dbg.data_ptr())
@@ -109,13 +109,23 @@ def run(names, launches, rounds, rows=256, seconds=10.0, wide=0, blocks=0):
         launch(libs[names[0]], i)
     torch.cuda.synchronize()
     def clock_report(n):
-        if not (libs[n].lab_info(C.byref(C.c_int()), C.byref(C.c_int())) & 1048576):
+        bits = libs[n].lab_info(C.byref(C.c_int()), C.byref(C.c_int()))
+        if bits & 8388608:      # per-phase shader cycles, summed per wave over its tiles
+            ph = dbg.cpu().numpy()[4 * 12 * 256:].reshape(-1, 8).astype(float)
+            ph = ph[ph[:, 6] > 0]
+            per_tile = ph[:, :6] / ph[:, 6:7]
+            names6 = ["A: claim+gather+window+DFT+twiddle+transposed writes", "B1: column reads", "B: DMA issue+DFT+exchange",
+                      "B2: power+P rows", "C: band reduction", "stores"]
+            print(json.dumps({"variant": n, "waves": int(len(ph)), "tiles_per_wave_mean": round(float(ph[:, 6].mean()), 2),
+                              "cycles_per_tile_by_phase": {k: round(float(v), 0) for k, v in zip(names6, per_tile.mean(axis=0))},
+                              "cycles_per_tile_total": round(float(per_tile.sum(axis=1).mean()), 0)}))
+        if not (bits & 1048576):
             return
         if True:
-            d = dbg.cpu().numpy().reshape(-1, 4)
+            d = dbg.cpu().numpy()[:4 * 12 * 256].reshape(-1, 4)
             d = d[d[:, 1] != 0]
             cyc, wall = (d[:, 2] - d[:, 0]).astype(float), (d[:, 3] - d[:, 1]).astype(float)
-            full = dbg.cpu().numpy().reshape(-1, 12, 4)          # [block][wave][4]
+            full = dbg.cpu().numpy()[:4 * 12 * 256].reshape(-1, 12, 4)          # [block][wave][4]
             t00 = full[:, :, 1][full[:, :, 1] != 0].min()
             blk_end = (full[:, :, 3].max(axis=1) - t00) / 100.0
             blk_start = (full[:, :, 1].min(axis=1) - t00) / 100.0
