@@ -466,6 +466,7 @@ int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twid
   AAMD_CHECK_ARG(wav && window && twiddle && out && f, "null buffer");
   AAMD_CHECK_ARG(f->dct_frag && f->group_max && f->tile_min, "the fused MFCC needs dct_frag, group_max and tile_min");
   AAMD_CHECK_ARG(f->rows_per_group >= 1 && (f->pass == 0 || f->pass == 1), "bad rows_per_group / pass");
+  AAMD_CHECK_ARG(f->fix_count != nullptr, "the fused MFCC needs fix_count in both passes (pass 0 resets it)");
   AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(f->dct_frag) % 16 == 0,
                  "out and dct_frag must be 16-byte aligned");
   MelBandsDev mb;
@@ -484,7 +485,7 @@ int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twid
     AAMD_CHECK_ARG(f->fix_count && f->tile_list, "pass 1 of the fused MFCC needs fix_count and tile_list");
     const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
     const int64_t n_tiles = g.rows * tiles_per_row;
-    AAMD_HIP(hipMemsetAsync(f->fix_count, 0, sizeof(int32_t), (hipStream_t)stream));
+    // (fix_count was reset by pass 0 of this call -- the kernel's first workgroup does it)
     hipLaunchKernelGGL(m400::mfcc_fix_list_kernel, dim3(grid_for(n_tiles, 256, dev_props().cu_count * 4)), dim3(256), 0,
                        (hipStream_t)stream, f->tile_min, f->group_max, f->rows_per_group, tiles_per_row, n_tiles, f->top_db,
                        f->tile_list, f->fix_count);

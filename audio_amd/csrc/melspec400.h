@@ -1014,6 +1014,10 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     fix_n = *epi.fix_count;
     if (fix_n <= (int)blockIdx.x) return;                 // nothing for this workgroup (nothing at all: the common case)
   }
+  // pass 0 of the fused MFCC resets the counter of the compacted fix-up list that pass 1 fills (one launch less per call than a
+  // memset; nothing reads it before mfcc_fix_list_kernel, which is ordered behind this kernel on the stream)
+  if (EPI == EPI400_MFCC && LAB == 0 && epi.fixup == 0 && epi.fix_count != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    *epi.fix_count = 0;
   // the tools-only switches of the MFCC epilogue (AAMD_MFCC_LAB) are honoured by an instantiation of their own: as run-time
   // branches in the product kernel they cut its MFMA section into basic blocks (the lesson of the resampler's census)
   const int elab = (LAB & 524288) ? epi.lab : 0;
