@@ -343,3 +343,44 @@ def test_biquad_kernels_with_poles_that_outlive_a_wave(rows, length):
         for k in range(4):
             ref = O.lfilter(ref, A[k].numpy(), B[k].numpy(), False)
         assert peak_rel_err(got4[i], ref) <= 1e-4, (rows, i)
+
+
+def _long_goldens():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lfilter_long_goldens.npz"))
+
+
+def test_long_memory_biquads_oracle_and_cpu_replay_against_the_reference_run():
+    """tests/golden/lfilter_long_goldens.npz is the REFERENCE's own float32 output (compiled lfilter.cpp core loop) for
+    resonators with |pole| up to 0.9999: the float64 oracle and the CPU replay of the biquad kernels (4 waves per sequence,
+    two blocks: fold and block carry in use) against it."""
+    import sim_util as S
+    from oracle import dsp_oracle as O
+    gd = _long_goldens()
+    x, A, B = gd["noise"], gd["a"], gd["b"]
+    for i in range(4):
+        ref = gd[f"single_{i}"]
+        assert peak_rel_err(O.lfilter(x.astype(np.float64), A[i], B[i], False), ref) <= 2e-5, i
+        rc, got = S.sim_lfilter_wave(x[:, None, :], A[i][None, None], B[i][None, None], False, 4)
+        assert rc == 0 and peak_rel_err(got[:, 0], ref) <= 4e-5, i
+    rc, got = S.sim_lfilter_wave(x[:, None, :], A[:, None, :], B[:, None, :], True, 4)
+    assert rc == 0 and peak_rel_err(got[:, 0], gd["cascade_clamped"]) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_long_memory_biquads_against_the_reference_run():
+    """The same fixture through F.lfilter / F.biquad_cascade on the GPU."""
+    import audio_amd.functional as F
+    gd = _long_goldens()
+    x = torch.from_numpy(gd["noise"]).cuda()
+    A, B = torch.from_numpy(gd["a"]).cuda(), torch.from_numpy(gd["b"]).cuda()
+    with torch.no_grad():
+        for i in range(4):
+            got = F.lfilter(x, A[i], B[i], clamp=False).cpu().numpy()
+            assert peak_rel_err(got, gd[f"single_{i}"]) <= 4e-5, i
+        got = F.biquad_cascade(x, A, B, clamp=True).cpu().numpy()
+        y = x
+        for i in range(4):
+            y = F.lfilter(y, A[i], B[i], clamp=True)
+    assert peak_rel_err(got, gd["cascade_clamped"]) <= 1e-4
+    assert peak_rel_err(y.cpu().numpy(), gd["cascade_clamped"]) <= 1e-4
