@@ -776,6 +776,7 @@ def _melspectrogram_plan(waveform: Tensor, pad: int, window: Tensor, fb: Tensor,
     if ops is None or power is None:
         return None
     _require_device(waveform, "waveform")
+    window_in = window
     window = window.to(device=waveform.device, dtype=torch.float32)
     x2 = _rows2d(waveform)
     if x2.data_ptr() != waveform.data_ptr():
@@ -787,7 +788,9 @@ def _melspectrogram_plan(waveform: Tensor, pad: int, window: Tensor, fb: Tensor,
     args = (_padded_window(window, n_fft), _twiddles(n_fft, waveform.device), bands.lo, bands.width, bands.weights,
             bands.lane_order, bands.table400, n_fft, hop_length, pad, bool(center), desc.pad_mode, desc.n_frames,
             desc.scale, desc.power, int(bands.table_sig))
-    return ops.mel_spectrogram, (x2.shape[0], x2.shape[1]), args, (bands, window)      # keep-alives last
+    # keep-alives last -- including the caller's OWN window / fb tensors: the module finds this plan by their addresses and
+    # version counters, and an address can only be reused by another tensor once the old one is gone
+    return ops.mel_spectrogram, (x2.shape[0], x2.shape[1]), args, (bands, window, window_in, fb)
 
 
 def _mel_lognorm(waveform: Tensor, window: Tensor, fb: Tensor, n_fft: int, hop_length: int, gain: float,
@@ -915,6 +918,7 @@ class MfccFusedState:
     def __init__(self, max_share: float = 0.12, retry_every: int = 64):
         self.frag = None
         self.frag_key = None
+        self.frag_src = None          # weak reference to the DCT tensor the fragments were built from
         self.max_share = max_share
         self.retry_every = retry_every
         self.pending = None           # (pinned int32 tensor, event, n_tiles)
@@ -957,13 +961,15 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
     L = _lib.lib()
     if bands.n_freq != n_fft // 2 + 1 or not L.aamd_mfcc_fused_supported(C.byref(desc), C.byref(bands.struct), n_mfcc):
         return None
-    key = (dct.data_ptr(), dct._version, str(dev), n_mfcc)
+    # the fragments belong to the tensor OBJECT they were built from (weak reference) at its in-place version: an address
+    # and a version counter alone can be reused by a fresh tensor with other values (the lfilter sections)
+    key = (dct._version, dct.data_ptr(), str(dev), n_mfcc, bands.n_mels)
     stream = _lib.current_stream(dev)
     with torch.cuda.device(dev):
-        if state.frag is None or state.frag_key != key:
+        if state.frag is None or state.frag_key != key or state.frag_src is None or state.frag_src() is not dct:
             frag = torch.empty((L.aamd_mfcc_frag_floats(),), dtype=torch.float32, device=dev)
             _lib.check(L.aamd_mfcc_frag_build(dct.data_ptr(), bands.n_mels, n_mfcc, frag.data_ptr(), stream))
-            state.frag, state.frag_key = frag, key
+            state.frag, state.frag_key, state.frag_src = frag, key, weakref.ref(dct)
         n_tiles = int(L.aamd_mfcc_fused_tiles(C.byref(desc)))
         out = torch.empty((desc.rows, desc.n_frames, n_mfcc), dtype=torch.float32, device=dev)
         if out.numel() == 0:

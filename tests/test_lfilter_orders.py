@@ -384,3 +384,48 @@ def test_long_memory_biquads_against_the_reference_run():
             y = F.lfilter(y, A[i], B[i], clamp=True)
     assert peak_rel_err(got, gd["cascade_clamped"]) <= 1e-4
     assert peak_rel_err(y.cpu().numpy(), gd["cascade_clamped"]) <= 1e-4
+
+
+def test_launch_plans_keep_the_tensors_they_are_keyed_by_alive():
+    """MelSpectrogram's per-shape launch plans are found by the addresses and version counters of `window` and `fb`: the
+    plan must hold those tensors (an address can only be reused by another tensor once the old one is gone), and the DCT
+    fragments of the fused MFCC belong to the tensor object they were built from (weak reference), not to an address."""
+    import inspect
+    import audio_amd.functional as F
+    src = inspect.getsource(F._melspectrogram_plan)
+    assert "window_in, fb)" in src
+    st = F.MfccFusedState()
+    assert st.frag_src is None
+    src = inspect.getsource(F._mfcc_fused)
+    assert "state.frag_src() is not dct" in src
+
+
+@pytest.mark.gpu
+def test_replaced_filterbank_and_dct_buffers_are_never_served_stale():
+    """A module whose `fb` / `dct_mat` buffer is REPLACED by a fresh tensor (new values, possibly at the address the allocator
+    just freed, version counter 0 again) must compute with the new values: 12 replacements each, against a module built with
+    those values from the start."""
+    # (12 replacements: each builds two reference modules; the hazard needs one reuse of a freed address to show)
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(9)
+    x = (0.3 * torch.randn(4, 8000, generator=g)).cuda()
+    mel = T.MelSpectrogram(16000, n_fft=400, hop_length=160, n_mels=80).cuda()
+    mfcc = T.MFCC(16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
+    mfcc.fused = True
+    base_fb, base_dct = mel.mel_scale.fb.clone(), mfcc.dct_mat.clone()
+    with torch.no_grad():
+        for i in range(12):
+            scale = 1.0 + 0.25 * (i % 7)
+            mel.mel_scale.fb = base_fb * scale          # a NEW tensor object every time; the old one is freed
+            gc.collect()
+            got = mel(x)
+            want = T.MelSpectrogram(16000, n_fft=400, hop_length=160, n_mels=80).cuda()
+            want.mel_scale.fb.mul_(scale)
+            assert torch.allclose(got, want(x), rtol=1e-5, atol=1e-7), i
+            mfcc.dct_mat = base_dct * scale
+            gc.collect()
+            got = mfcc(x)
+            ref = T.MFCC(16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
+            ref.fused = False
+            ref.dct_mat.mul_(scale)
+            assert float((got - ref(x)).abs().max()) <= 2e-4 * float(ref(x).abs().max()), i
