@@ -1175,61 +1175,14 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     return g_base;
   };
 
-  // lab bit 25 (tools/mel400_lab.py, tail balancing): every workgroup keeps the last kPoolReserve tiles of its run out of
-  // its own queue; they form one pool per XCD (counter gq[xcd], device scope), drawn tile by tile by whichever wave runs out
-  // of work first.  A ticket is requested one tile ahead (during the wave's last tiles of static work) and read at the next
-  // claim; every wave draws exactly one ticket past the end of the pool, and the wave that draws the very last ticket of
-  // the launch (pool + waves - 1) resets the counter for the next launch.
-  constexpr unsigned kPoolReserve = 8, kPoolTag = 0x40000000u, kNoTile = 0xffffffffu;
-  constexpr bool kPool = (LAB & 33554432) != 0;
-  unsigned pool_n = 0, pool_waves = 0, pool_blk0 = 0;
-  unsigned* pool_ctr = nullptr;
-  int pool_pending = 0;            // lane 0: the ticket in flight
-  bool pool_have = false, pool_mode = false;
-  if (kPool) {
-    const unsigned per_xcd = (unsigned)nb >> 3;
-    pool_n = per_xcd * kPoolReserve;
-    pool_waves = per_xcd * kWavesPerBlock;
-    pool_blk0 = (blockIdx.x & 7) * per_xcd;
-    pool_ctr = reinterpret_cast<unsigned*>(epi.group_max) + 32 * (blockIdx.x & 7);   // one 128-byte line per counter
-    blk_count -= kPoolReserve;     // (lab: full blocks only -- the cfg2 batch)
-  }
-  auto pool_request = [&]() {
-    if (lane == 0) pool_pending = (int)__hip_atomic_fetch_add(pool_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pool_have = true;
-  };
-  auto pool_next = [&]() -> unsigned {      // wave-uniform: local index, tagged global tile, or kNoTile
-    if (!pool_mode) {
-      const unsigned idx = claim();
-      if (idx < blk_count) {
-        if (idx + kWavesPerBlock >= blk_count && !pool_have) pool_request();
-        return idx;
-      }
-      pool_mode = true;
-      if (!pool_have) pool_request();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = (unsigned)__builtin_amdgcn_readfirstlane(pool_pending);
-    pool_have = false;
-    if (t >= pool_n) {
-      if (t == pool_n + pool_waves - 1u && lane == 0) __hip_atomic_store(pool_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return kNoTile;
-    }
-    pool_request();
-    const unsigned j = t / kPoolReserve, r = t - j * kPoolReserve;
-    return kPoolTag | ((pool_blk0 + j) * (unsigned)tiles_per_block + ((unsigned)tiles_per_block - kPoolReserve) + r);
-  };
-
   auto tile_info = [&](unsigned idx) {
     TileInfo ti;
     unsigned t = ((LAB & 131072) ? 0u : blk_first) + idx;
-    if (kPool && (idx & kPoolTag) && idx != kNoTile) t = idx & ~kPoolTag;
-    if (kPool && idx == kNoTile) t = 0u;
     if (EPI == EPI400_MFCC && epi.fixup != 0) t = idx < blk_count ? (unsigned)epi.fix_list[blockIdx.x + idx * (unsigned)nb] : 0u;
     const unsigned row = t / (unsigned)tiles_per_row;
     ti.row = row;
     ti.t0 = (int64_t)(t - row * (unsigned)tiles_per_row) * kFramesPerWave;
-    ti.staged = (kPool ? idx != kNoTile : idx < blk_count) && in_aligned && (ti.t0 * kHop - kPad >= 0) &&
+    ti.staged = idx < blk_count && in_aligned && (ti.t0 * kHop - kPad >= 0) &&
                 ((ti.t0 + kFramesPerWave - 1) * kHop + (kN - kPad) <= length) &&
                 (ti.t0 + kFramesPerWave <= n_frames);
     return ti;
@@ -1296,12 +1249,12 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     ph_acc[K] += now_ - ph_t;                               \
     ph_t = now_;                                            \
   }
-  while (kPool ? cur_idx != kNoTile : cur_idx < blk_count) {
+  while (cur_idx < blk_count) {
     if (LAB & 8388608) { ph_t = (long long)clock64(); ++ph_tiles; }
     // claim the tile after this one now: it is prefetched while this one is in its second half
     // (issuing the LDS atomic here and reading its ticket behind the column reads' wait moved 70 cycles from phase A to
     // phase B and nothing else: profiles/r03_zz_mel400_phase_census.txt)
-    const unsigned nxt_idx = kPool ? pool_next() : (LAB & 131072) ? g_next() : claim();
+    const unsigned nxt_idx = (LAB & 131072) ? g_next() : claim();
     TileInfo nxt = tile_info(nxt_idx);
     float fix_cut = -INFINITY;
     if (fix) {

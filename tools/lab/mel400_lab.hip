@@ -14,9 +14,7 @@ using namespace aamd;
 #endif
 
 static long long* g_dbg = nullptr;
-static float* g_pool = nullptr;   // LAB bit 25: eight pool counters (one 128-byte line each), zero before the FIRST launch
 extern "C" void lab_set_debug(void* p) { g_dbg = (long long*)p; }
-extern "C" void lab_set_pool(void* p) { g_pool = (float*)p; }
 
 template <int LAB>
 static int launch(const float* wav, const float* window, const float* tw, const MelBandsDev& mb, float* out, int64_t rows,
@@ -45,7 +43,6 @@ static int launch(const float* wav, const float* window, const float* tw, const 
   const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (row_stride % 4 == 0);
   m400::Epi400 epi{};
   epi.fix_count = reinterpret_cast<int*>(g_dbg);
-  if (LAB & 33554432) epi.group_max = g_pool;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, s, wav, window, tw, mb, out, rows, length, row_stride,
                      n_frames, scale, tiles_per_row, n_tiles, tiles_per_block, in_aligned, out_wide, epi);
   return hipGetLastError() == hipSuccess ? 0 : -1;

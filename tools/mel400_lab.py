@@ -80,12 +80,9 @@ def run(names, launches, rounds, rows=256, seconds=10.0, wide=0, blocks=0):
         libs[n] = L
     stream = _lib.current_stream(dev)
     dbg = torch.zeros((4 + 8) * 12 * 256, dtype=torch.int64, device=dev)
-    pool = torch.zeros(8 * 32, dtype=torch.int32, device=dev)       # LAB bit 25: per-XCD pool counters (self-resetting)
     for L in libs.values():
         L.lab_set_debug.argtypes = [C.c_void_p]
         L.lab_set_debug(dbg.data_ptr())
-        L.lab_set_pool.argtypes = [C.c_void_p]
-        L.lab_set_pool(pool.data_ptr())
 
     def launch(L, i):
         x, o = xs[i % 4], outs[i % 5]
@@ -157,8 +154,6 @@ def run(names, launches, rounds, rows=256, seconds=10.0, wide=0, blocks=0):
             res[n].append(e0.elapsed_time(e1) / launches * 1e3)
             if r == rounds - 1:
                 clock_report(n)
-    torch.cuda.synchronize()
-    print(json.dumps({"pool_counters_after_the_run (0 = every launch reset them)": pool.cpu().numpy()[::32].tolist()}))
     for n in names:
         v = res[n]
         print(json.dumps({"variant": n, "us_per_launch": [round(t, 2) for t in v], "best": round(min(v), 2),
