@@ -313,3 +313,30 @@ def test_fuzz_pitch_shift_sparse_path_vs_dense_kernel(n_steps):
             F._SPARSE_TAPS = old
     assert got.shape == ref.shape == x.shape
     assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("power", [1.0, 2.0, 3.0])
+@pytest.mark.parametrize("normalized", [False, True, "frame_length"])
+@pytest.mark.parametrize("bank", ["htk", "slaney"])
+def test_signature_instantiations_serve_every_power_and_normalisation(power, normalized, bank):
+    """The 80-mel HTK / Slaney banks at n_fft 400 / hop 160 run the filterbank-signature instantiation of the headline
+    kernel whatever the `power` and `normalized` arguments are: each combination against the float64 ATen composition
+    (`torch.stft` -> abs().pow(p) -> normalisation -> matmul, _transforms.py:612-622)."""
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    kw = dict(norm="slaney", mel_scale="slaney") if bank == "slaney" else {}
+    m = T.MelSpectrogram(16000, n_fft=400, hop_length=160, n_mels=80, power=power, normalized=normalized, **kw).cuda()
+    assert F._mel_bands(m.mel_scale.fb, torch.device("cuda", 0)).table_sig in (0x4221, 0x4211)
+    g = torch.Generator().manual_seed(int(power * 10) + len(bank))
+    x = (0.5 * torch.randn(3, 12345, generator=g)).clamp_(-1, 1).cuda()
+    with torch.no_grad():
+        got = m(x)
+    w = torch.hann_window(400, dtype=torch.float64).cuda()
+    spec = torch.stft(x.double(), 400, 160, 400, w, True, "reflect", False, True, return_complex=True)
+    if normalized is True:
+        spec = spec / w.pow(2).sum().sqrt()
+    elif normalized == "frame_length":
+        spec = spec / math.sqrt(400)
+    ref = torch.matmul(spec.abs().pow(power).transpose(-1, -2), m.mel_scale.fb.double()).transpose(-1, -2)
+    assert got.shape == ref.shape
+    assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (power, normalized, bank)
