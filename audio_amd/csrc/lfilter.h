@@ -349,6 +349,11 @@ lfilter_kernel(const float* __restrict__ x, const float* __restrict__ a,
         if (tid == 0) lf_save_input_carry<D>(blk, tab);
         bool src_is_a = true;
         const int n_eff = (int)tab[L::neff];             // (workgroup-uniform; written before the barrier above)
+        // The carry save above READS the last chunk of the block (thread 0); lf_correct_store below WRITES it in place from
+        // another wave.  The scan steps used to separate the two with their barriers, but the early-stopping scan runs none
+        // of them for a stage whose memory dies within one chunk (an FIR through lfilter, poles with |r| < ~0.22): the
+        // carried FIR history then raced with the filtered samples.
+        if (n_eff == 0) __syncthreads();
         for (int k = 0; k < n_eff; ++k) {
           lf_scan_step<D>(tid, k, tab, th, src_is_a);
           __syncthreads();

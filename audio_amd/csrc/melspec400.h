@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(256) mfcc_frag_build_kernel(const float* __res
 }
 
 // Between the two passes of the fused MFCC: the tiles whose smallest dB value lies under their group's cut-off, compacted
-// into `list` (one atomic per wave; `count` zeroed by the launcher).  The fix-up launch deals list entries out block by
+// into `list` (one atomic per wave; `count` was zeroed by pass 0 of the same call, whose first workgroup resets it).  The fix-up launch deals list entries out block by
 // block, so 5 % flagged tiles that all sit in a few clips cost 5 % of a pass, not the +100 us of static tile ranges.
 __global__ void __launch_bounds__(256) mfcc_fix_list_kernel(const float* __restrict__ tile_min, const float* __restrict__ group_max,
                                                             int64_t rows_per_group, int tiles_per_row, int64_t n_tiles,
@@ -1016,7 +1016,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   }
   // pass 0 of the fused MFCC resets the counter of the compacted fix-up list that pass 1 fills (one launch less per call than a
   // memset; nothing reads it before mfcc_fix_list_kernel, which is ordered behind this kernel on the stream)
-  if (EPI == EPI400_MFCC && LAB == 0 && epi.fixup == 0 && epi.fix_count != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+  // (every instantiation does it, the tools-only ones included: the caller hands over an uninitialised counter -- ADVICE r3)
+  if (EPI == EPI400_MFCC && epi.fixup == 0 && epi.fix_count != nullptr && !(LAB & (1048576 | 8388608)) && blockIdx.x == 0 &&
+      threadIdx.x == 0)
     *epi.fix_count = 0;
   // the tools-only switches of the MFCC epilogue (AAMD_MFCC_LAB) are honoured by an instantiation of their own: as run-time
   // branches in the product kernel they cut its MFMA section into basic blocks (the lesson of the resampler's census)

@@ -441,21 +441,31 @@ class MFCC(torch.nn.Module):
         #: optional hook ``fn(group_max: Tensor) -> None`` run between the dB pass and the clamp;
         #: audio_amd.distributed installs an all-reduce(MAX) here when a batch is sharded.
         self.group_max_hook: Optional[Callable[[Tensor], None]] = None
-        #: EXTENSION: which MFCC path runs.  "auto" (default since round 3) = the one-kernel MFCC (DCT on the f16 matrix pipe
-        #: in the mel kernel's epilogue, operands split into two binary16 numbers, + a fix-up launch over the compacted list of
-        #: tiles the top_db cut-off reaches) unless the last observed share of such tiles was above 12 %, where the exact
-        #: two-kernel path is cheaper; True / False force one or the other.  Same results within 3e-5 dB.  Measured on the cfg4
-        #: batch (profiles/r03_d_mfcc_paths.txt): 211 us against 229 us for two kernels on noise, 220 against 234 with 5 %
-        #: clamped tiles, 297 against 220 with 50 %.  (Round 2's fp32-MFMA epilogue was 267 us and opt-in.)
+        #: EXTENSION: which MFCC path runs.  True = the one-kernel MFCC (DCT on the f16 matrix pipe in the mel kernel's epilogue,
+        #: operands split into two binary16 numbers, + a fix-up launch over the compacted list of tiles the top_db cut-off
+        #: reaches); False = the exact two-kernel path; both are bit-reproducible call to call.  "auto" (default) decides ONCE
+        #: per module, at its first eligible call, from the share of tiles that call had to redo (> 12 %: two kernels are
+        #: cheaper) and keeps that arithmetic for every later call (F.MfccFusedState; round 3 re-decided from a polled event,
+        #: so equal inputs could return different bits).  A group_max_hook (sharded batches) or a HIP-graph capture in
+        #: progress run the one-kernel path without deciding.  Same results within 3e-5 dB.  Measured on the cfg4 batch
+        #: (profiles/r03_d_mfcc_paths.txt): 211 us against 229 us for two kernels on noise, 220 against 234 with 5 % clamped
+        #: tiles, 297 against 220 with 50 %.
         self.fused = "auto"
         self._fused_state = F.MfccFusedState()
 
     def fused_report(self) -> dict:
-        """EXTENSION: which MFCC path ran last, and what the fix-up pass last had to redo."""
+        """EXTENSION: which MFCC path ran last, the module's "auto" decision, and what the last one-kernel call's fix-up pass
+        had to redo (this read synchronises with the device)."""
         st = self._fused_state
-        st.poll()
-        return {"path": st.path, "redone_share": st.last_share, "calls_fused": st.calls_fused,
-                "calls_two_kernel": st.calls_two_kernel}
+        share = None
+        if st.last_count is not None:
+            share = float(st.last_count.item()) / max(st.last_tiles, 1)
+        return {"path": st.path, "redone_share": share, "decided": st.decided, "decided_share": st.decided_share,
+                "calls_fused": st.calls_fused, "calls_two_kernel": st.calls_two_kernel}
+
+    def reset_fused_decision(self) -> None:
+        """EXTENSION: forget the "auto" decision (the next eligible call takes it again, e.g. after the kind of batch changed)."""
+        self._fused_state.reset()
 
     def __getstate__(self):
         d = dict(self.__dict__)
@@ -475,6 +485,11 @@ class MFCC(torch.nn.Module):
             # differentiable / float64 path (reference composition, _transforms.py:692-709, on top of the
             # differentiable mel spectrogram): the dB / top_db / DCT tail is cheap and torch's autograd
             # reproduces the reference's sub-gradients (clamp, amax) exactly
+            if waveform.numel() == 0 and self.group_max_hook is not None and not self.log_mels:
+                # an empty shard still joins the exchange of the batch-global cut-off (the other ranks wait in it)
+                self.group_max_hook(torch.full((1,), float("-inf"), dtype=waveform.dtype, device=waveform.device))
+                T_ = 1 + waveform.shape[-1] // self.MelSpectrogram.hop_length
+                return waveform.new_zeros(tuple(waveform.shape[:-1]) + (self.n_mfcc, T_))
             mel = self.MelSpectrogram(waveform)
             if self.log_mels:
                 mel = torch.log(mel + 1e-6)
@@ -484,7 +499,16 @@ class MFCC(torch.nn.Module):
                 shp = x_db.size()
                 packed = shp[-3] if x_db.dim() > 2 else 1
                 x_db = x_db.reshape(-1, packed, shp[-2], shp[-1])
-                x_db = torch.max(x_db, (x_db.amax(dim=(-3, -2, -1)) - self.top_db).view(-1, 1, 1, 1))
+                gmax = x_db.amax(dim=(-3, -2, -1))
+                if self.group_max_hook is not None:
+                    # sharded batch (audio_amd.distributed): the cut-off is the maximum over ALL ranks' shards.  The exchange
+                    # runs on a detached copy in the path's own dtype; where another rank holds the maximum it enters as a
+                    # constant -- its sub-gradient belongs to that rank's element -- and where this rank holds it the
+                    # reference's amax sub-gradient is kept (this branch used per-shard cut-offs)
+                    g_all = gmax.detach().clone()
+                    self.group_max_hook(g_all)
+                    gmax = torch.where(g_all > gmax, g_all, gmax)      # (a tie keeps the local amax and its whole sub-gradient)
+                x_db = torch.max(x_db, (gmax - self.top_db).view(-1, 1, 1, 1))
                 mel = x_db.reshape(shp)
             return torch.matmul(mel.transpose(-1, -2), self.dct_mat.to(device=mel.device, dtype=mel.dtype)).transpose(-1, -2)
         sp = self.MelSpectrogram.spectrogram
@@ -499,9 +523,7 @@ class MFCC(torch.nn.Module):
         fused = getattr(self, "fused", "auto")
         if st is None or fused is False:
             return None
-        st.force = fused is True      # True: always one kernel; "auto": follow the observed share of redone tiles
-        if st.force:
-            st.avoid = 0
+        st.force = fused is True      # True: always one kernel; "auto": the module's one-time decision (F.MfccFusedState)
         return st
 
 

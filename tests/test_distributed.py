@@ -155,7 +155,7 @@ import pytest
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "auto"])
 @pytest.mark.parametrize("split", [(5, 3), (7, 1), (8, 0)])
 def test_product_mfcc_hook_two_shards_on_one_gpu(fused, split, monkeypatch):
     import audio_amd.transforms as T
@@ -175,23 +175,149 @@ def test_product_mfcc_hook_two_shards_on_one_gpu(fused, split, monkeypatch):
     mod.group_max_hook = None
     shards = [xd[:split[0]], xd[split[0]:]]
     sharded = D.ShardedTransform(mod)
-    # pass 1: what each rank's kernel would hand to the all-reduce
+    # pass 1: what each rank's kernel would hand to the all-reduce.  EVERY rank calls it exactly once -- the rank whose
+    # shard is empty included (the one-kernel path returned before the hook and the job hung)
     local_max = []
     monkeypatch.setattr(D, "allreduce_group_max", lambda gm, group=None: local_max.append(gm.clone()))
     for s in shards:
-        if s.shape[0]:
-            sharded(s)
+        before = len(local_max)
+        out = sharded(s)
+        assert len(local_max) == before + 1, "a rank skipped the all-reduce"
+        assert out.shape == (s.shape[0], 40, 101)
+    if 0 in split:
+        assert float(local_max[-1].max()) == float("-inf")          # the empty shard contributes the identity of MAX
     combined = torch.stack(local_max).amax(0)
     assert torch.equal(combined, seen["full"])                      # MAX over the shards IS the unsharded maximum
-    assert len(local_max) < 2 or not torch.equal(local_max[0], local_max[1])
+    assert not torch.equal(local_max[0], local_max[1])
     # pass 2: every rank receives the combined maximum, as dist.all_reduce(MAX) delivers it
     monkeypatch.setattr(D, "allreduce_group_max", lambda gm, group=None: gm.copy_(combined))
-    parts = [sharded(s) for s in shards if s.shape[0]]
+    parts = [sharded(s) for s in shards]
     got = torch.cat(parts, 0)
     assert got.shape == full.shape
     assert torch.equal(got, full)                                   # bit for bit: clamp decisions included
+    if fused == "auto":
+        # under a hook "auto" never decides (every rank must run the same arithmetic): the one-kernel path ran every time
+        rep = mod.fused_report()
+        assert rep["decided"] is None and rep["calls_two_kernel"] == 0 and rep["path"] == "fused"
     # and WITHOUT the exchange the shard that does not hold the loudest clip clamps differently (the hook matters)
     lone = [mod(s) for s in shards if s.shape[0]]
     if len(lone) == 2:
         assert not torch.equal(torch.cat(lone, 0), full)
     assert mod.group_max_hook is None                               # ShardedTransform restored the caller's hook
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["float64", "grad"])
+def test_product_mfcc_hook_precision_and_training_branch(mode, monkeypatch):
+    """the float64 / differentiable MFCC branch honours the hook too -- a sharded float64 or training-mode
+    MFCC uses the batch-global cut-off, an empty shard joins the exchange, and the gradient of the sharded call equals the
+    unsharded one on the rows of each shard (the remote maximum enters as a constant)."""
+    import audio_amd.transforms as T
+    from audio_amd import distributed as D
+    g = torch.Generator().manual_seed(9)
+    dt = torch.float64 if mode == "float64" else torch.float32
+    x = (0.3 * torch.randn(6, 8000, generator=g)).clamp_(-1, 1).to(dt)
+    x[4] *= 1e-3
+    x[5, 3000:] = 0.0
+    xd = x.cuda()
+    mod = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs={"n_fft": 400, "hop_length": 160, "n_mels": 80}).cuda().to(dt)
+
+    def run(inp):
+        inp = inp.clone().requires_grad_(mode == "grad")
+        out = mod(inp)
+        grad = None
+        if mode == "grad" and inp.numel():
+            grad = torch.autograd.grad(out.square().sum(), inp)[0]
+        return out.detach(), grad
+
+    full, gfull = run(xd)
+    sharded = D.ShardedTransform(mod)
+    local_max = []
+    monkeypatch.setattr(D, "allreduce_group_max", lambda gm, group=None: local_max.append(gm.clone()))
+    shards = [xd[:4], xd[4:], xd[:0]]
+    for s in shards:
+        run_out = sharded(s.clone().requires_grad_(mode == "grad"))
+        assert run_out.shape[0] == s.shape[0]
+    assert len(local_max) == 3 and float(local_max[2].max()) == float("-inf")
+    combined = torch.stack([m.to(torch.float64) for m in local_max]).amax(0)
+    monkeypatch.setattr(D, "allreduce_group_max", lambda gm, group=None: gm.copy_(combined.to(gm.dtype)))
+    outs, grads = [], []
+    for s in shards[:2]:
+        inp = s.clone().requires_grad_(mode == "grad")
+        o = sharded(inp)
+        outs.append(o.detach())
+        if mode == "grad":
+            grads.append(torch.autograd.grad(o.square().sum(), inp)[0])
+    got = torch.cat(outs, 0)
+    tol = 1e-9 if mode == "float64" else 2e-5
+    assert float((got - full).abs().max()) <= tol * float(full.abs().max())
+    lone = torch.cat([mod(s) for s in shards[:2]], 0)
+    assert float((lone - full).abs().max()) > 1e-3 * float(full.abs().max())     # per-shard cut-offs would differ visibly
+    if mode == "grad":
+        gg = torch.cat(grads, 0)
+        # rows of the shard that holds the maximum carry the amax sub-gradient as in the unsharded call; for the other shard
+        # the cut-off is a constant, so only the single element that holds the batch maximum may differ
+        assert float((gg[4:] - gfull[4:]).abs().max()) <= 2e-5 * float(gfull[4:].abs().max()) + 1e-9
+        assert torch.isfinite(gg).all()
+        # ... and on the rank that holds the maximum only the samples under the arg-max frame can differ (the clamped
+        # elements of the OTHER shard send their sub-gradient there in the unsharded call; no backward collective here)
+        diff = (gg[:4] - gfull[:4]).abs().amax(0)
+        assert int((diff > 2e-5 * float(gfull.abs().max())).sum()) <= 400
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_and_allreduce_max_on_this_box():
+    """One-rank RCCL leg inside `pytest -m gpu`: the driver's GPU run proves, on its own box, that
+    backend "nccl" (= RCCL) creates a communicator, that all_reduce(MAX) runs on the stream the product uses, and that the
+    product's sharded MFCC goes through it (torch.distributed.run, one process, 127.0.0.1)."""
+    import subprocess
+    script = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from audio_amd import distributed as D
+import audio_amd.transforms as T
+rank, world, dev = D.init_from_env()
+assert world == 1 and dev.type == "cuda"
+if not dist.is_initialized():
+    dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl"
+t = torch.tensor([1.5, -3.0], device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+torch.cuda.synchronize()
+assert t.tolist() == [1.5, -3.0]
+g = torch.Generator().manual_seed(0)
+x = (0.3 * torch.randn(4, 16000, generator=g)).clamp_(-1, 1).to(dev)
+x[3, 4000:] = 0
+m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs={"n_fft": 400, "hop_length": 160, "n_mels": 80}).to(dev)
+calls = []
+def forced(gm, group=None):        # the collective itself, although one rank is the whole world
+    calls.append(gm.data_ptr())
+    dist.all_reduce(gm, op=dist.ReduceOp.MAX, group=group)
+D.allreduce_group_max = forced
+for fused in (True, False):
+    m.fused = fused
+    full = m(x)
+    y = D.ShardedTransform(m)(x)
+    assert torch.equal(y, full), fused
+    e = D.ShardedTransform(m)(x[:0])
+    assert e.shape[0] == 0
+torch.cuda.synchronize()
+assert len(calls) == 4, calls
+loc = D.scatter_batch(x, tuple(x.shape), dev)
+back = D.gather_batch(m(loc), x.shape[0])
+assert torch.equal(back, full)
+dist.destroy_process_group()
+print("RCCL_OK", torch.cuda.get_device_name(0))
+""" % ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-c", script]
+    # torch.distributed.run takes a script path, not -c: write it next to the test's temp dir
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "rccl_leg.py")
+        with open(path, "w") as fh:
+            fh.write(script)
+        cmd = cmd[:-2] + [path]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0 and "RCCL_OK" in res.stdout, (res.stdout[-2000:], res.stderr[-4000:])

@@ -662,30 +662,95 @@ def test_mfcc_one_kernel_path_equals_two_kernel_path_and_oracle(hop, n_mfcc, sha
         assert float(np.abs(a.cpu().numpy() - exp).max()) <= 2e-6 * float(np.abs(exp).max()) + 5e-4      # MFCC absolute (dB scale)
 
 
-def test_mfcc_path_choice_follows_the_share_of_clamped_tiles():
-    """`fused="auto"`: a batch in which most tiles reach the cut-off (zero padding) moves the module to the two-kernel
-    path for the following calls; shapes the fused kernel does not serve (n_mels != 80, n_mfcc % 4) take it directly."""
+def test_mfcc_path_choice_is_taken_once_per_module():
+    """`fused="auto"`: the module decides at its FIRST eligible call (synchronised) from the share of tiles that call had to
+    redo, and keeps that arithmetic; a zero-padded first batch puts it on the two-kernel path -- including for that first
+    call, so every call of a module is the same arithmetic; shapes the fused kernel does not serve (n_mels != 80,
+    n_mfcc % 4) take the two-kernel path directly."""
     import audio_amd.transforms as T
     g = torch.Generator().manual_seed(5)
-    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
-    assert m.fused == "auto"                     # the default since round 3 (the f16-pipe epilogue made one kernel the faster path)
+    kw0 = dict(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80))
+    m = T.MFCC(**kw0).cuda()
+    assert m.fused == "auto"
     loud = (0.4 * torch.randn(8, 32000, generator=g)).clamp_(-1, 1).cuda()
     padded = loud.clone()
     padded[:, 4000:] = 0.0
+    exact = T.MFCC(**kw0).cuda()
+    exact.fused = False
+    one = T.MFCC(**kw0).cuda()
+    one.fused = True
     with torch.no_grad():
-        m(loud); torch.cuda.synchronize(); m(loud)
-        assert m.fused_report()["path"] == "fused" and m.fused_report()["redone_share"] == 0.0
-        y1 = m(padded); torch.cuda.synchronize()
-        assert m.fused_report()["redone_share"] > 0.5
-        y2 = m(padded)
-        assert m.fused_report()["path"] == "two-kernel"
-        assert float((y1 - y2).abs().max()) <= 2e-6 * float(y2.abs().max()) + 2e-4
+        y0 = m(loud)
+        rep = m.fused_report()
+        assert rep["decided"] == "fused" and rep["decided_share"] == 0.0 and rep["path"] == "fused"
+        assert torch.equal(y0, one(loud))
+        y1 = m(padded)                          # the decision stands: still one kernel, bit-equal to fused=True
+        assert m.fused_report()["path"] == "fused" and m.fused_report()["redone_share"] > 0.5
+        assert torch.equal(y1, one(padded))
+        m2 = T.MFCC(**kw0).cuda()               # a module whose first batch is zero padded decides the other way ...
+        z1 = m2(padded)
+        rep = m2.fused_report()
+        assert rep["decided"] == "two-kernel" and rep["decided_share"] > 0.5 and rep["path"] == "two-kernel"
+        assert torch.equal(z1, exact(padded))   # ... and already that first call is the two-kernel arithmetic
+        assert torch.equal(m2(loud), exact(loud)) and m2.fused_report()["calls_fused"] == 0
+        m2.reset_fused_decision()
+        assert torch.equal(m2(loud), one(loud)) and m2.fused_report()["decided"] == "fused"
         for kw in (dict(n_mfcc=13, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)),
                    dict(n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=64))):
             mm = T.MFCC(sample_rate=16000, **kw).cuda()
-            mm.fused = "auto"
             mm(loud)
             assert mm.fused_report()["path"] == "two-kernel"
+
+
+@pytest.mark.parametrize("fused", [True, False, "auto"])
+def test_mfcc_repeated_calls_are_bit_identical(fused):
+    """50 calls on a half-silent batch return the same bits, whatever the path setting."""
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(12)
+    x = (0.4 * torch.randn(16, 24000, generator=g)).clamp_(-1, 1)
+    x[8:] = 0.0
+    x[3, 9000:] = 0.0
+    xd = x.cuda()
+    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
+    m.fused = fused
+    with torch.no_grad():
+        first = m(xd).clone()
+        other = (0.2 * torch.randn(5, 16000, generator=g)).cuda()
+        for i in range(50):
+            if i % 7 == 3:
+                m(other)                         # another batch in between does not move the path
+            assert torch.equal(m(xd), first), i
+    rep = m.fused_report()
+    assert (rep["calls_fused"] == 0) or (rep["calls_two_kernel"] == 0)
+
+
+def test_mfcc_default_module_under_hip_graph_capture():
+    """the default module is capture-safe -- while a capture is in progress "auto" takes no decision (no host
+    read, no pinned copy, no event) and runs the one-kernel path; the replayed graph returns the eager result."""
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(21)
+    x = (0.4 * torch.randn(4, 16000, generator=g)).clamp_(-1, 1).cuda()
+    x[2, 5000:] = 0.0
+    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
+    with torch.no_grad():
+        m.fused = True                           # warm the module's side tables (band image, DCT fragments) without deciding
+        want = m(x).clone()
+        m.fused = "auto"
+        assert m.fused_report()["decided"] is None
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m.fused = True
+            m(x)
+            m.fused = "auto"
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            y = m(x)
+        assert m._fused_state.decided is None and m._fused_state.path == "fused"
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
 
 
 def test_resample_matrix_core_layout_edges():
@@ -1273,5 +1338,13 @@ def test_rnnt_features_from_interleaved_pcm(hop):
             got2 = fe.features(odd.cuda(), channels_first=False)
             want2 = fe(odd.transpose(-1, -2).cuda().float() * (1.0 / 32768.0))
             assert torch.equal(got2, want2), chans
+    # a contiguous stereo VIEW that starts on an odd half-word (2-byte aligned) is served, not refused
+    flat = torch.randint(-20000, 20000, (2 * 48000 * 2 + 1,), generator=g, dtype=torch.int16).cuda()
+    view = flat[1:].view(2, 48000, 2)
+    assert view.data_ptr() % 4 == 2 and view.is_contiguous()
+    with torch.no_grad():
+        got3 = fe.features(view, channels_first=False)
+        want3 = fe(view.transpose(-1, -2).float() * (1.0 / 32768.0))
+    assert torch.equal(got3, want3)
     with pytest.raises(ValueError):
         fe.features(torch.zeros(2, 4800, 2).cuda(), channels_first=False)          # float input is not PCM

@@ -215,6 +215,46 @@ def test_lfilter_high_orders_learnable_coefficients(design):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fir5", "small_poles4", "fir_in_cascade"])
+def test_lfilter_general_order_short_memory_stages_across_blocks(kind):
+    """a stage whose memory dies inside one chunk (an FIR passed through lfilter, poles with |r| < 0.22) runs ZERO
+    scan steps, and the scan steps' barriers were the only thing between thread 0's read of the block's last chunk (the
+    carried FIR history) and the in-place store of the filtered samples by another wave.  Rows of many 8192-sample blocks, the
+    general-order kernel forced, every block boundary checked against the float64 direct form; repeated so that a race has
+    chances to show."""
+    import audio_amd.functional as F
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(6, 12 * 8192 + 77, generator=g) - 0.5) * 0.6
+    if kind == "fir5":
+        b = np.array([0.3, -0.2, 0.25, 0.1, -0.15], np.float32)
+        a = np.array([1.0, 0.0, 0.0, 0.0, 0.0], np.float32)
+    elif kind == "small_poles4":
+        a = np.poly([0.15, -0.1, 0.12 + 0.1j, 0.12 - 0.1j]).real.astype(np.float32)
+        b = np.array([0.4, 0.3, -0.2, 0.1, 0.05], np.float32)
+    else:
+        a = np.array([[1.0, 0.0, 0.0, 0.0], [1.0, -0.1, 0.02, 0.0]], np.float32)
+        b = np.array([[0.5, 0.25, -0.125, 0.3], [0.6, -0.3, 0.2, 0.1]], np.float32)
+    prev = F.set_lfilter_sections(False)
+    try:
+        xd = x.cuda()
+        for _ in range(5):
+            if kind == "fir_in_cascade":
+                got = F.biquad_cascade(xd, torch.tensor(a).cuda(), torch.tensor(b).cuda(), clamp=False).cpu().numpy()
+            else:
+                got = F.lfilter(xd, torch.tensor(a).cuda(), torch.tensor(b).cuda(), clamp=False).cpu().numpy()
+            if kind == "fir_in_cascade":
+                exp = x.numpy().astype(np.float64)
+                for s in range(2):
+                    exp = _f64_direct(exp, a[s], b[s])
+            else:
+                exp = _f64_direct(x.numpy(), a, b)
+            err = np.abs(got - exp)
+            assert err.max() <= 1e-5 * np.abs(exp).max(), (kind, np.unravel_index(err.argmax(), err.shape))
+    finally:
+        F.set_lfilter_sections(prev)
+
+
+@pytest.mark.gpu
 def test_lfilter_general_order_per_channel_cascade_and_long_rows():
     """The general-order kernel's other shapes: per-channel coefficient rows, a 2-stage cascade of order-4 filters through
     biquad_cascade (parked per-stage tables), and a row of 20 blocks (carried float64 state)."""
