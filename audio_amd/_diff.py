@@ -114,10 +114,25 @@ def stft_complex(x2: Tensor, wp: Tensor, cfg: Cfg) -> Tensor:
     return torch.view_as_complex(Stft.apply(x2, wp, cfg))
 
 
+def hermitian_extend(spec_f: Tensor, n_fft: int) -> Tensor:
+    """(rows, T, n_fft // 2 + 1) onesided spectrum of a REAL signal -> (rows, T, n_fft): X[N - k] = conj X[k]
+    (what aten::stft returns for onesided=False; plain tensor arithmetic, so autograd sees through it)."""
+    mirror = spec_f[..., 1:(n_fft + 1) // 2].flip(-1).conj()
+    return torch.cat([spec_f, mirror], dim=-1)
+
+
+def onesided_part(spec: Tensor, n_fft: int) -> Tensor:
+    """(..., n_fft, T) two-sided spectrum -> its first n_fft // 2 + 1 bins.  aten::istft with onesided=False does exactly
+    this before its Hermitian inverse FFT (the mirror half is ignored, not folded in -- checked against torch.istft:
+    tests/test_gpu_autograd_f64.py::test_inverse_spectrogram_gradcheck_other_shapes)."""
+    return spec[..., : n_fft // 2 + 1, :]
+
+
 def spectrogram(waveform: Tensor, pad: int, window: Tensor, n_fft: int, hop_length: int, win_length: int, power,
-                normalized, center: bool, pad_mode: str) -> Tensor:
+                normalized, center: bool, pad_mode: str, onesided: bool = True) -> Tensor:
     """The reference composition (functional/functional.py:112-145) with torch.stft replaced by `Stft`:
-    (..., L) -> (..., F, T) in the waveform's dtype (float32 or float64)."""
+    (..., L) -> (..., F, T) in the waveform's dtype (float32 or float64); onesided=False extends the spectrum of the real
+    signal by its Hermitian symmetry (functional.py:123-134 passes the flag to aten::stft for every dtype)."""
     from . import functional as F
     frame_length_norm, window_norm = F._get_spec_norms(normalized)
     shape = waveform.size()
@@ -131,6 +146,8 @@ def spectrogram(waveform: Tensor, pad: int, window: Tensor, n_fft: int, hop_leng
         spec_f = spec_f * (float(n_fft) ** -0.5)
     if window_norm:
         spec_f = spec_f / w.pow(2.0).sum().sqrt()
+    if not onesided:
+        spec_f = hermitian_extend(spec_f, n_fft)
     spec_f = spec_f.transpose(-1, -2)
     spec_f = spec_f.reshape(tuple(shape[:-1]) + spec_f.shape[-2:])
     if power is not None:
@@ -138,3 +155,55 @@ def spectrogram(waveform: Tensor, pad: int, window: Tensor, n_fft: int, hop_leng
             return spec_f.abs()
         return spec_f.abs().pow(power)
     return spec_f
+
+
+def istft(fm: Tensor, wp: Tensor, n_fft: int, hop_length: int, center: bool, out_len: int, inv_env: Tensor,
+          scale: float) -> Tensor:
+    """Differentiable inverse STFT: complex (rows, T, F) frame-major onesided spectrum -> (rows, out_len).
+
+    aten::istft is LINEAR in the spectrum: Hermitian inverse FFT of every frame (interior bins count twice, the imaginary
+    parts of DC / Nyquist are dropped), window, overlap-add, envelope division, centre trimming.  That is the adjoint of the
+    zero-padded onesided STFT applied to the spectrum with its interior bins doubled:
+        y = inv_env * (scale / N) * StftAdjoint_{constant padding}(c * S),   c = (1, 2, ..., 2, 1),
+    and `StftAdjoint` differentiates into `Stft` and back for ever (the module docstring), so this is differentiable to any
+    order in float32 and float64.  The pair is taken at the length the T frames COVER after the centre trim,
+    hop (T - 1) + n_fft / 2 (centre) or n_fft (not centre) -- torch.istft returns those samples when asked for a longer
+    `length` -- where the forward operator has T' >= T frames: the spectrum is extended by T' - T zero frames, which makes the
+    operator pair consistent and changes nothing else.  The caller's length then trims or zero-extends."""
+    rows, T, n_freq = fm.shape
+    c = torch.full((n_freq,), 2.0, dtype=wp.dtype, device=fm.device)
+    c[0] = 1.0
+    if n_fft % 2 == 0:
+        c[-1] = 1.0
+    G = torch.view_as_real(fm * c)
+    cfg = (n_fft, hop_length, 0, bool(center), "constant")
+    covered = hop_length * (T - 1) + (n_fft // 2 if center else n_fft)
+    t_op = n_frames_of(covered, cfg)
+    if t_op > T:
+        G = torch.nn.functional.pad(G, (0, 0, 0, 0, 0, t_op - T))
+    x = StftAdjoint.apply(G, wp, cfg, covered)
+    if out_len < covered:
+        x = x[:, :out_len]
+    elif out_len > covered:
+        x = torch.nn.functional.pad(x, (0, out_len - covered))
+    return x * (inv_env * (scale / n_fft))
+
+
+def phase_vocoder(spec: Tensor, rate: float, phase_advance: Tensor) -> Tensor:
+    """The phase vocoder as tensor arithmetic in the spectrum's own precision (functional/functional.py:765-803:
+    interpolated magnitudes, unwrapped phase increments, running phase sum) -- the differentiable / complex128 route of this
+    thin caller; the throughput route is the HIP kernel csrc/vocoder.h.  spec: complex (..., F, T)."""
+    import math
+    shape = spec.size()
+    rdt = torch.float64 if spec.dtype == torch.complex128 else torch.float32
+    z = torch.nn.functional.pad(spec.reshape((-1,) + tuple(shape[-2:])), [0, 2])
+    t = torch.arange(0, shape[-1], rate, device=spec.device, dtype=rdt)
+    frac = t % 1.0
+    i0 = t.long()
+    z0, z1 = z.index_select(-1, i0), z.index_select(-1, i0 + 1)
+    pa = phase_advance.to(device=spec.device, dtype=rdt)
+    step = z1.angle() - z0.angle() - pa
+    step = step - 2 * math.pi * torch.round(step / (2 * math.pi)) + pa
+    phase = torch.cumsum(torch.cat([z[..., :1].angle(), step[..., :-1]], dim=-1), -1)
+    out = torch.polar(frac * z1.abs() + (1 - frac) * z0.abs(), phase)
+    return out.reshape(tuple(shape[:-2]) + out.shape[1:])

@@ -75,6 +75,7 @@ _SIGS = {
     "aamd_mel400_table_dwords": (C.c_int64, [C.c_int32, C.c_int32]),
     "aamd_mel400_table_build": (C.c_int, [C.POINTER(MelBands), _P, _P]),
     "aamd_device_info": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "aamd_box_probe": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "aamd_spectrogram_f32": (C.c_int, [_P, _P, _P, _P, C.POINTER(StftDesc), _P]),
     "aamd_melspectrogram_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), _P]),
     "aamd_melspectrogram_db_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.c_float,

@@ -391,6 +391,39 @@ int aamd_device_info(char* name, int32_t name_len, int32_t* cu_count, int64_t* h
   return AAMD_OK;
 }
 
+// Box probe (bench.py `box_calibration`): every workgroup runs the same fixed chain of dependent fp32 FMAs in all of its
+// waves and records shader cycles (s_memtime), 100 MHz wall ticks (s_memrealtime) and the XCD it ran on.  cycles / ticks is
+// the shader clock this box sustains under vector-ALU load; the spread of the per-XCD means is the XCD skew.  Boxes of one
+// pool ran the same binary between 65.9 and 72.5 us: this is what the bench line reports beside its
+// number so that a slow box can be told from a slow kernel.
+__global__ void __launch_bounds__(256) box_probe_kernel(long long* __restrict__ rec, int iters) {
+  float a0 = 1.0f + threadIdx.x * 1e-6f, a1 = 0.5f, a2 = 0.25f, a3 = 0.125f;
+  const float m = 0.99999f, c = 1e-7f;
+  const long long c0 = (long long)clock64(), w0 = (long long)wall_clock64();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      a0 = fmaf(a0, m, c); a1 = fmaf(a1, m, c); a2 = fmaf(a2, m, c); a3 = fmaf(a3, m, c);
+    }
+  }
+  const long long c1 = (long long)clock64(), w1 = (long long)wall_clock64();
+  unsigned xcc = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (threadIdx.x == 0) {
+    long long* r = rec + 4 * (long long)blockIdx.x;
+    r[0] = c1 - c0; r[1] = w1 - w0; r[2] = (long long)(xcc & 15u); r[3] = w0;
+  }
+  if (a0 + a1 + a2 + a3 == 123456.0f) rec[0] = 0;       // keeps the chains alive
+}
+
+int aamd_box_probe(int64_t* rec, int32_t n_blocks, int32_t iters, void* stream) {
+  DeviceScope dev_scope_(rec);
+  AAMD_CHECK_ARG(rec != nullptr && n_blocks >= 1 && iters >= 1, "box probe: rec[4 * n_blocks], n_blocks >= 1, iters >= 1");
+  hipLaunchKernelGGL(box_probe_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<long long*>(rec), (int)iters);
+  return launch_check();
+}
+
 int aamd_spectrogram_f32(const float* wav, const float* window, const float* twiddle, float* out,
                          const aamd_stft_desc* desc, void* stream) {
   DeviceScope dev_scope_(wav);

@@ -301,12 +301,12 @@ def spectrogram(
             f"but got window with size {list(window.shape)}")
     if not 0 < win_length <= n_fft:
         raise RuntimeError(f"stft: expected 0 < win_length <= n_fft, but got win_length={win_length}")
-    if waveform.dtype == torch.float64:
-        if not onesided:
-            raise NotImplementedError("audio_amd: float64 spectrograms are onesided only")
+    if waveform.dtype == torch.float64 or (not onesided and torch.is_grad_enabled() and waveform.requires_grad):
+        # precision / two-sided training path: the differentiable blocks (onesided kernel + Hermitian extension)
         _stft_desc(_rows2d(waveform), pad, window.to(waveform.device), n_fft, hop_length, power, normalized, center, pad_mode,
                    True)                       # the reference's argument checks and error messages
-        return _diff.spectrogram(waveform, pad, window, n_fft, hop_length, win_length, power, normalized, center, pad_mode)
+        return _diff.spectrogram(waveform, pad, window, n_fft, hop_length, win_length, power, normalized, center, pad_mode,
+                                 onesided)
     window = window.to(device=waveform.device, dtype=torch.float32)
     shape = waveform.size()
     x2 = _rows2d(waveform)
@@ -315,8 +315,6 @@ def spectrogram(
     lead = tuple(shape[:-1])
     T = desc.n_frames
     if torch.is_grad_enabled() and waveform.requires_grad:
-        if not onesided:
-            raise RuntimeError("audio_amd: autograd of the spectrogram needs onesided=True")
         out = _SpectrogramFunction.apply(x2, _padded_window(window, n_fft), desc, power)
     else:
         out = _spectrogram_launch(x2, _padded_window(window, n_fft), desc, power)
@@ -478,10 +476,15 @@ def inverse_spectrogram(
     if not spectrogram.is_cuda:
         raise RuntimeError(f"audio_amd: spectrogram must be on an MI355X (ROCm) device, got {spectrogram.device}. "
                            "The HIP kernels have no CPU fallback.")
-    if spectrogram.requires_grad and torch.is_grad_enabled():
-        raise RuntimeError("audio_amd: inverse_spectrogram is forward-only; wrap the call in torch.no_grad().")
+    if spectrogram.dtype not in (torch.complex64, torch.complex128):
+        raise TypeError(f"audio_amd: spectrogram must be complex64 or complex128 (got {spectrogram.dtype}).")
     if not onesided:
-        raise NotImplementedError("audio_amd: inverse_spectrogram needs onesided=True")
+        if spectrogram.shape[-2] != n_fft:
+            raise RuntimeError(f"istft: expected the frequency dimension of the input to be n_fft = {n_fft} when "
+                               f"onesided=False, but got {spectrogram.shape[-2]}")
+        from . import _diff
+        spectrogram = _diff.onesided_part(spectrogram, n_fft)          # what aten::istft does with a two-sided input
+    want_grad = spectrogram.requires_grad and torch.is_grad_enabled()
     dev = spectrogram.device
     f64 = spectrogram.dtype == torch.complex128          # the reference's tests run in float64 too: the float64 inverse kernel
     rdt = torch.float64 if f64 else torch.float32
@@ -492,8 +495,6 @@ def inverse_spectrogram(
     if n_freq != n_fft // 2 + 1:
         raise RuntimeError(f"istft: expected the frequency dimension of the input to be n_fft / 2 + 1 = "
                            f"{n_fft // 2 + 1}, but got {n_freq}")
-    if spectrogram.dtype not in (torch.complex64, torch.complex128):
-        raise TypeError(f"audio_amd: spectrogram must be complex64 or complex128 (got {spectrogram.dtype}).")
     fm = spectrogram.transpose(-1, -2).reshape(-1, T, n_freq)
     if not fm.is_contiguous():
         fm = fm.contiguous()
@@ -526,7 +527,12 @@ def inverse_spectrogram(
     inv_env = _tensor_cached(window, ("istft_env", n_fft, hop_length, T, out_len, center), make_env)
     desc = _lib.StftDesc(rows, out_len, out_len, n_fft, hop_length, 0, int(center), _lib.PAD_MODES["constant"], 1, T,
                          1.0 if f64 else scale, 0.0)      # (the descriptor's scale is a float: float64 applies it below)
-    if f64:
+    if want_grad:
+        # training path (transforms/autograd_test_impl.py:76-83): the inverse STFT is linear in the spectrum, and its operator
+        # is the adjoint of the zero-padded STFT -- the Stft / StftAdjoint pair of _diff.py, differentiable to any order
+        from . import _diff
+        out = _diff.istft(fm, wp, n_fft, hop_length, bool(center), out_len, inv_env, scale)
+    elif f64:
         from . import _diff
         out = torch.zeros((rows, out_len), dtype=torch.float64, device=dev)
         if out.numel() and T:
@@ -568,23 +574,6 @@ def _phase_vocoder_launch(spec: Tensor, rate: float, phase_advance: Tensor, fram
     return out.transpose(-1, -2) if frame_major_out else out
 
 
-def _phase_vocoder_f64(spec: Tensor, rate: float, phase_advance: Tensor) -> Tensor:
-    """complex128 precision path of this thin caller: the reference's formula (functional/functional.py:765-803) evaluated
-    with device tensor ops in float64 -- interpolated magnitudes, unwrapped phase increments, running phase sum."""
-    shape = spec.size()
-    z = torch.nn.functional.pad(spec.reshape((-1,) + tuple(shape[-2:])), [0, 2])
-    t = torch.arange(0, shape[-1], rate, device=spec.device, dtype=torch.float64)
-    frac = t % 1.0
-    i0 = t.long()
-    z0, z1 = z.index_select(-1, i0), z.index_select(-1, i0 + 1)
-    pa = phase_advance.to(device=spec.device, dtype=torch.float64)
-    step = z1.angle() - z0.angle() - pa
-    step = step - 2 * math.pi * torch.round(step / (2 * math.pi)) + pa
-    phase = torch.cumsum(torch.cat([z[..., :1].angle(), step[..., :-1]], dim=-1), -1)
-    out = torch.polar(frac * z1.abs() + (1 - frac) * z0.abs(), phase)
-    return out.reshape(tuple(shape[:-2]) + out.shape[1:])
-
-
 def phase_vocoder(complex_specgrams: Tensor, rate: float, phase_advance: Tensor) -> Tensor:
     r"""Stretch a complex spectrogram in time by ``rate`` without changing pitch
     (reference: functional/functional.py:732-803) -- one HIP kernel, a thread per (row, frequency) chain."""
@@ -593,11 +582,13 @@ def phase_vocoder(complex_specgrams: Tensor, rate: float, phase_advance: Tensor)
     if not complex_specgrams.is_cuda:
         raise RuntimeError(f"audio_amd: complex_specgrams must be on an MI355X (ROCm) device, got "
                            f"{complex_specgrams.device}. The HIP kernels have no CPU fallback.")
-    if complex_specgrams.requires_grad and torch.is_grad_enabled():
-        raise RuntimeError("audio_amd: phase_vocoder is forward-only; wrap the call in torch.no_grad().")
     shape = complex_specgrams.size()
-    if complex_specgrams.dtype == torch.complex128:
-        return _phase_vocoder_f64(complex_specgrams, rate, phase_advance)
+    if complex_specgrams.dtype == torch.complex128 or (complex_specgrams.requires_grad and torch.is_grad_enabled()
+                                                       and complex_specgrams.dtype == torch.complex64):
+        # precision / training route of this thin caller: the reference's formula as device tensor arithmetic, which
+        # autograd differentiates (transforms/autograd_test_impl.py:225-262 TimeStretch)
+        from . import _diff
+        return _diff.phase_vocoder(complex_specgrams, rate, phase_advance)
     if complex_specgrams.dtype != torch.complex64:
         raise TypeError(f"audio_amd: complex_specgrams must be complex64 or complex128 (got {complex_specgrams.dtype}).")
     spec = complex_specgrams.reshape((-1,) + tuple(shape[-2:]))
@@ -622,6 +613,9 @@ def griffinlim(
     for n_fft = 400, the generic Stockham kernel otherwise) and the fused phase update (csrc/vocoder.h)."""
     if not 0 <= momentum < 1:
         raise ValueError("momentum must be in range [0, 1). Found: {}".format(momentum))
+    if specgram.is_cuda and (specgram.dtype == torch.float64 or (specgram.requires_grad and torch.is_grad_enabled())):
+        return _griffinlim_diff(specgram, window, n_fft, hop_length, win_length, power, n_iter, momentum / (1 + momentum),
+                                length, rand_init)
     _require_device(specgram, "specgram")
     momentum = momentum / (1 + momentum)
     shape = specgram.size()
@@ -657,6 +651,34 @@ def griffinlim(
             torch.view_as_real(nxt).data_ptr(), mag.numel(), float(momentum), _lib.current_stream(dev)))
         cur, nxt = nxt, cur
     waveform = invert(cur)
+    return waveform.reshape(tuple(shape[:-2]) + waveform.shape[-1:])
+
+
+def _griffinlim_diff(specgram: Tensor, window: Tensor, n_fft: int, hop_length: int, win_length: int, power: float,
+                     n_iter: int, momentum: float, length: Optional[int], rand_init: bool) -> Tensor:
+    """Griffin-Lim in training mode / float64 (transforms/autograd_test_impl.py:99-109 runs gradcheck + gradgradcheck on it):
+    the iteration of functional/functional.py:313-347 written on the differentiable blocks -- the inverse STFT as the adjoint
+    operator (`_diff.istft`), the rebuild as `_diff.Stft`, the phase normalisation as tensor arithmetic.  `momentum` arrives
+    already mapped to m / (1 + m)."""
+    shape = specgram.size()
+    mag = specgram.reshape((-1,) + tuple(shape[-2:])).pow(1 / power)
+    cdt = torch.complex128 if specgram.dtype == torch.float64 else torch.complex64
+    if rand_init:       # the reference draws in the COMPLEX dtype, on the spectrogram's device, in (rows, freq, time) order
+        angles = torch.rand(mag.size(), dtype=cdt, device=mag.device)
+    else:
+        angles = torch.full(mag.size(), 1, dtype=cdt, device=mag.device)
+    tprev = None
+    for _ in range(n_iter):
+        inverse = inverse_spectrogram(mag * angles, length, 0, window, n_fft, hop_length, win_length, False)
+        rebuilt = _diff.spectrogram(inverse, 0, window, n_fft, hop_length, win_length, None, False, True, "reflect")
+        if rebuilt.shape[-1] != mag.shape[-1]:
+            raise RuntimeError("audio_amd: griffinlim needs length consistent with the number of frames")
+        angles = rebuilt
+        if momentum and tprev is not None:
+            angles = angles - tprev * momentum
+        angles = angles / (angles.abs() + 1e-16)
+        tprev = rebuilt
+    waveform = inverse_spectrogram(mag * angles, length, 0, window, n_fft, hop_length, win_length, False)
     return waveform.reshape(tuple(shape[:-2]) + waveform.shape[-1:])
 
 

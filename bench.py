@@ -165,6 +165,49 @@ def measure_issue(kernel_ms, timeout_s=150):
     return res
 
 
+def box_probe(dev):
+    """What distinguishes a fast box from a slow one (the same binary ran 65.9 ... 72.5 us across the pool and
+    the copy rate did not predict it): the shader clock the chip sustains under a pure vector-ALU load and the skew between
+    its XCDs, from aamd_box_probe (every workgroup times the same FMA chain with the cycle counter and the 100 MHz clock)."""
+    import ctypes
+    import torch
+    from audio_amd import _lib
+    try:
+        L = _lib.lib()
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        n = 4 * cus                                            # 4 x 256 threads per CU: one wave per SIMD and then some
+        rec = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+        for iters in (2000, 20000, 20000):                     # warm-up, ramp, measured (~1.3 ms of dependent FMAs per wave)
+            _lib.check(L.aamd_box_probe(rec.data_ptr(), n, iters, _lib.current_stream(dev)))
+        torch.cuda.synchronize()
+        r = rec.cpu().double()
+        ghz = (r[:, 0] / (r[:, 1] * 10.0))                     # cycles per ns: 100 MHz ticks are 10 ns
+        per_xcd = {}
+        for x in range(8):
+            m = r[:, 2] == x
+            if m.any():
+                per_xcd[x] = {"blocks": int(m.sum()), "clock_GHz": round(float(ghz[m].mean()), 4),
+                              "mean_us": round(float((r[m, 1] * 0.01).mean()), 2)}
+        us = [v["mean_us"] for v in per_xcd.values()]
+        return {"alu_clock_GHz": round(float(ghz.mean()), 4), "alu_clock_GHz_min_max": [round(float(ghz.min()), 4), round(float(ghz.max()), 4)],
+                "xcd_skew": round((max(us) - min(us)) / (sum(us) / len(us)), 4) if us else None, "per_xcd": per_xcd,
+                "probe": "aamd_box_probe: 20000 x 64 dependent fp32 FMAs per lane, 4 workgroups of 256 per CU; cycles (s_memtime) "
+                         "/ 100 MHz ticks (s_memrealtime) per workgroup; xcd_skew = (max - min) / mean of the per-XCD mean durations"}
+    except Exception as e:                                     # a measurement aid must never break the bench line
+        return {"alu_clock_GHz": None, "probe_error": f"{type(e).__name__}: {e}"[:200]}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def pmc_child():
     """A few launches of the bench's own loop body for a rocprofv3 counter pass."""
     import torch
@@ -267,6 +310,9 @@ def main():
     ap.add_argument("--scatter-gather", action="store_true",
                     help="also time scatter_batch / gather_batch of a root-born batch (outside the K steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the other BASELINE configs (cfg3 / cfg4 / cfg5a / cfg5b shards, measured after the timed K steps "
+                         "at N = 1 and reported under `configs`)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 PMC passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--selftest-cpu", action="store_true",
@@ -416,6 +462,7 @@ def main():
                        "note": "torch copy_ of one input batch (read + write), 50 launches, outside the timed region; "
                                "5.3 TB/s on the boxes the profiles/ numbers come from"}
         del dst
+        calibration.update(box_probe(dev))
 
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
     per_rank = None
@@ -471,9 +518,27 @@ def main():
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         traffic, tdetail = (None, {"traffic_source": "committed", "why": "--no-traffic, --op mfcc or N > 1"})
         pmc = {}
+        mfcc_report = None
+        if args.op == "mfcc":
+            # the label says what was measured -- the module reports which path its calls took
+            mfcc_report = mod.fused_report()
+            if mfcc_report["calls_two_kernel"] == 0:
+                kernels = ["melspec400_kernel<EPI400_MFCC> pass 0 (mel + dB + DCT on the f16 matrix pipe + group max)",
+                           "mfcc_fix_list_kernel", "melspec400_kernel<EPI400_MFCC> fix-up pass"]
+        xs = ys = None
+        torch.cuda.empty_cache()
+        configs = None
+        if world == 1 and not args.no_configs:
+            # the other BASELINE configs (per-GPU shards), after and outside the timed K steps of the headline metric
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            try:
+                import bench_configs
+                which = ["spec", "cfg4", "cfg4_per_item", "cfg3", "cfg5a", "cfg5b"] if args.op == "mel" else \
+                        ["cfg2", "cfg3", "cfg5a", "cfg5b"]
+                configs = bench_configs.measure_configs(dev, steps=200, warmup=100, which=which)
+            except Exception as e:                            # never lose the headline line to a side measurement
+                configs = [{"error": f"{type(e).__name__}: {e}"[:400]}]
         if world == 1 and not args.no_traffic and args.op == "mel":
-            del xs, ys
-            torch.cuda.empty_cache()
             traffic, tdetail = measure_traffic()
             pmc = measure_issue(kernel_ms)
         if traffic is None and args.op == "mel":
@@ -501,10 +566,17 @@ def main():
                                       f"({ring * algo_bytes / 1e6:.0f} MB per cycle > 256 MiB Infinity Cache)"},
             "roofline": dict({"bound": "hbm", "kernel": " + ".join(kernels), "achieved": achieved, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "frac_on_wall_clock": algo_bytes / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
+                              "timing": "`achieved` / `frac` from HIP events around the K steps on the launch stream "
+                                        "(`kernel_ms`); `frac_on_wall_clock` from `ms_per_step` (host clock, barrier to barrier)",
                               "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
                               "read_only_frac": (batch * L * 4) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}, **tdetail, **pmc),
         }
         out["box_calibration"] = calibration
+        if mfcc_report is not None:
+            out["mfcc_path"] = mfcc_report
+        if configs is not None:
+            out["configs"] = configs
         if per_rank is not None:
             out["per_rank_ms_per_step"] = per_rank
             out["per_rank_ms_min_max"] = [min(per_rank), max(per_rank)]
@@ -517,7 +589,8 @@ def main():
             from oracle import torch_cpu_ref
             sweep = torch_cpu_ref.sweep_mel_baseline(batch, SECONDS, SR, N_FFT, HOP, N_MELS)
             best = max(sweep, key=lambda r: r["audio_sec_per_sec"])
-            out["cpu_baseline"] = {"value": best["audio_sec_per_sec"], "unit": "audio-sec/sec", "cores": best["threads"],
+            out["cpu_baseline"] = {"value": best["audio_sec_per_sec"], "unit": "audio-sec/sec", "cores": os.cpu_count(),
+                                   "threads_best": best["threads"], "cpu_model": cpu_model(),
                                    "kind": "port", "sweep": sweep,
                                    "sample": f"all {batch} clips x 10 s of one batch per call, clips dealt to `threads` host "
                                              "threads that each run the single-threaded composition on their share (the "

@@ -133,6 +133,10 @@ int         aamd_abi_version(void);
 const char* aamd_last_error(void);
 /* "gfx950" when the current device is an MI355X-class part; fills name (<=63 chars). */
 int         aamd_device_info(char* name, int32_t name_len, int32_t* cu_count, int64_t* hbm_bytes);
+/* Measurement aid (bench.py `box_calibration`; no reference counterpart): n_blocks workgroups of 256 threads each run
+ * `iters` x 64 dependent fp32 FMAs per lane and record into rec[4 b .. 4 b + 3] = {shader cycles, 100 MHz wall ticks,
+ * XCD id, start tick}: the shader clock the box sustains under vector-ALU load and the skew between its XCDs. */
+int         aamd_box_probe(int64_t* rec, int32_t n_blocks, int32_t iters, void* stream);
 
 /* ---- STFT family --------------------------------------------------------------------- */
 

@@ -25,7 +25,7 @@ def _assert_grad(fn, inputs, enable_all_grad=True, nondet_tol=0.0):
     for i in inputs:
         if torch.is_tensor(i):
             req = i.requires_grad
-            i = i.detach().to(dtype=torch.float64, device="cuda")
+            i = i.detach().to(dtype=torch.complex128 if i.is_complex() else torch.float64, device="cuda")
             i.requires_grad = True if enable_all_grad else req
         ins.append(i)
     assert gradcheck(fn, ins, nondet_tol=nondet_tol)
@@ -216,8 +216,189 @@ def test_phase_vocoder_complex128():
     pa = torch.linspace(0, math.pi * 160, 201, dtype=torch.float64)[..., None]
     with torch.no_grad():
         got = F.phase_vocoder(spec.cuda(), 1.3, pa.cuda())
-        cpu = F._phase_vocoder_f64(spec, 1.3, pa)
+        from audio_amd import _diff
+        cpu = _diff.phase_vocoder(spec, 1.3, pa)
         f32 = F.phase_vocoder(spec.to(torch.complex64).cuda(), 1.3, pa.float().cuda())
     assert got.dtype == torch.complex128 and got.shape == (2, 201, 93)
     assert float((got.cpu() - cpu).abs().max()) <= 1e-9 * float(cpu.abs().max())
     assert float((got.abs().float() - f32.abs()).abs().max()) <= 1e-5 * float(cpu.abs().max())
+
+
+# ---- SURVEY 8(f) rank 2 in training mode (VERDICT r3 missing 3): the reference's own cases --------------------------------
+def _get_spectrogram(waveform, n_fft, hop_length=None, power=None):
+    """test/torchaudio_unittest/common_utils/data_utils.py:121-159 (hop n_fft // 4, Hann window, centre / reflect)."""
+    hop_length = hop_length or n_fft // 4
+    spec = torch.stft(waveform, n_fft=n_fft, hop_length=hop_length, win_length=n_fft, window=torch.hann_window(n_fft),
+                      center=True, pad_mode="reflect", return_complex=True)
+    return spec if power is None else spec.abs() ** power
+
+
+class _Deterministic(torch.nn.Module):
+    def __init__(self, transform, seed=0):
+        super().__init__()
+        self.seed, self.transform = seed, transform
+
+    def forward(self, x):
+        torch.random.manual_seed(self.seed)
+        return self.transform(x)
+
+
+def test_inverse_spectrogram_gradcheck():
+    """transforms/autograd_test_impl.py:76-83: a realistic complex spectrogram, the waveform's length as `length`."""
+    import audio_amd.transforms as T
+    waveform = _noise(2, 400)
+    spec = _get_spectrogram(waveform, n_fft=400)
+    inv = T.InverseSpectrogram(n_fft=400).to(dtype=torch.float64, device="cuda")
+    _assert_grad(lambda s: inv(s, 400), [spec], nondet_tol=1e-10)
+
+
+@pytest.mark.parametrize("kw", [dict(n_fft=64, hop_length=16), dict(n_fft=64, hop_length=16, length=150),
+                                dict(n_fft=64, hop_length=16, length=300), dict(n_fft=48, hop_length=12, center=False),
+                                dict(n_fft=64, hop_length=16, normalized=True, onesided=False)], ids=str)
+def test_inverse_spectrogram_gradcheck_other_shapes(kw):
+    """natural length, trimmed, zero-extended, centre off, two-sided + normalised -- and the VALUES of the training path against
+    torch.istft on the CPU (the forward of the differentiable operator is a different kernel call than inference)."""
+    import audio_amd.transforms as T
+    kw = dict(kw)
+    length = kw.pop("length", None)
+    n_fft, hop = kw["n_fft"], kw["hop_length"]
+    onesided, center = kw.get("onesided", True), kw.get("center", True)
+    x = _noise(2, 200, seed=4).double()
+    wfn = torch.hann_window if center else torch.hamming_window          # (centre off: the Hann window's zero end fails NOLA)
+    w = wfn(n_fft, dtype=torch.float64)
+    spec = torch.stft(x, n_fft, hop, n_fft, w, center=center, pad_mode="reflect", normalized=kw.get("normalized", False),
+                      onesided=onesided, return_complex=True)
+    if not onesided:
+        spec = spec + 0.05 * torch.randn(spec.shape, dtype=torch.complex128, generator=torch.Generator().manual_seed(1))
+    inv = T.InverseSpectrogram(window_fn=wfn, **kw).to(dtype=torch.float64, device="cuda")
+    ref = torch.istft(spec, n_fft, hop, n_fft, w, center=center, normalized=kw.get("normalized", False), onesided=onesided,
+                      length=length)
+    s_dev = spec.cuda().requires_grad_()
+    got = inv(s_dev, length)
+    assert got.shape == ref.shape and float((got.detach().cpu() - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
+    with torch.no_grad():
+        plain = inv(spec.cuda(), length)                                  # inference kernel: same values
+    assert float((plain - got.detach()).abs().max()) <= 1e-12 * float(ref.abs().max())
+    _assert_grad(lambda s: inv(s, length), [spec], nondet_tol=1e-10)
+
+
+def test_inverse_spectrogram_float32_training_path_matches_inference():
+    import audio_amd.transforms as T
+    x = _noise(3, 8000, seed=8)
+    spec = _get_spectrogram(x, n_fft=400, hop_length=160).cuda()
+    inv = T.InverseSpectrogram(n_fft=400, hop_length=160).cuda()
+    with torch.no_grad():
+        plain = inv(spec, 8000)
+    s = spec.clone().requires_grad_()
+    got = inv(s, 8000)
+    assert float((got.detach() - plain).abs().max()) <= 2e-6 * float(plain.abs().max())
+    (g,) = torch.autograd.grad(got.square().sum(), s)
+    # d/dS sum(istft(S)^2) = 2 * adjoint(istft)(y): compare with torch's own autograd through torch.istft on the CPU
+    sc = spec.cpu().clone().requires_grad_()
+    yc = torch.istft(sc, 400, 160, 400, torch.hann_window(400), length=8000)
+    (gc,) = torch.autograd.grad(yc.square().sum(), sc)
+    assert float((g.cpu() - gc).abs().max()) <= 1e-5 * float(gc.abs().max())
+
+
+@pytest.mark.parametrize("momentum", [0, 0.99])
+@pytest.mark.parametrize("rand_init", [False, True])
+def test_griffinlim(momentum, rand_init):
+    """transforms/autograd_test_impl.py:99-109."""
+    import audio_amd.transforms as T
+    n_fft, power, n_iter = 80, 1, 2
+    spec = _get_spectrogram(_noise(2, 80), n_fft=n_fft, power=power)
+    t = _Deterministic(T.GriffinLim(n_fft=n_fft, n_iter=n_iter, momentum=momentum, rand_init=rand_init, power=power))
+    _assert_grad(t.to(dtype=torch.float64, device="cuda"), [spec], nondet_tol=1e-10)
+
+
+def test_griffinlim_training_path_matches_reference_composition_and_inference():
+    """The differentiable iteration against (a) the same algorithm on torch.stft / torch.istft in float64 on the CPU (values AND
+    gradient) and (b) the float32 inference kernels (the fused phase update) on the same spectrogram."""
+    import audio_amd.transforms as T
+    n_fft, hop = 400, 100
+    x = _noise(2, 3200, seed=6).double()
+    w = torch.hann_window(n_fft, dtype=torch.float64)
+    spec = (torch.stft(x, n_fft, hop, n_fft, w, return_complex=True).abs() ** 2)
+
+    def cpu_gl(sp):
+        mag = sp.pow(0.5)
+        ang = torch.full(mag.size(), 1, dtype=torch.complex128)
+        tprev = None
+        for _ in range(3):
+            inv = torch.istft(mag * ang, n_fft, hop, n_fft, w, length=3200)
+            reb = torch.stft(inv, n_fft, hop, n_fft, w, return_complex=True)
+            ang = reb if tprev is None else reb - tprev * (0.9 / 1.9)
+            ang = ang / (ang.abs() + 1e-16)
+            tprev = reb
+        return torch.istft(mag * ang, n_fft, hop, n_fft, w, length=3200)
+
+    sc = spec.clone().requires_grad_()
+    yc = cpu_gl(sc)
+    (gc,) = torch.autograd.grad(yc.square().sum(), sc)
+    gl = T.GriffinLim(n_fft=n_fft, hop_length=hop, n_iter=3, momentum=0.9, rand_init=False, power=2.0, length=3200)
+    gl = gl.to(dtype=torch.float64, device="cuda")
+    sd = spec.cuda().requires_grad_()
+    yd = gl(sd)
+    (gd,) = torch.autograd.grad(yd.square().sum(), sd)
+    assert float((yd.detach().cpu() - yc.detach()).abs().max()) <= 1e-9 * float(yc.abs().max())
+    assert float((gd.cpu() - gc).abs().max()) <= 1e-7 * float(gc.abs().max())
+    gl32 = T.GriffinLim(n_fft=n_fft, hop_length=hop, n_iter=3, momentum=0.9, rand_init=False, power=2.0, length=3200).cuda()
+    with torch.no_grad():
+        y32 = gl32(spec.float().cuda())
+    assert float((y32.double().cpu() - yc.detach()).abs().max()) <= 2e-4 * float(yc.abs().max())
+
+
+@pytest.mark.parametrize("rate", [0.7, 0.8, 0.9, 1.0, 1.3])
+def test_timestretch_non_zero(rate):
+    """transforms/autograd_test_impl.py:238-262: spectrogram points near zero are pushed away from the origin (atan2)."""
+    import audio_amd.transforms as T
+    n_fft = 16
+    t = T.TimeStretch(n_freq=n_fft // 2 + 1, fixed_rate=rate).to(device="cuda")
+    spec = _get_spectrogram(_noise(2, 40, scale=1.0), n_fft=n_fft)
+    eps = 2e-2
+    close = spec.abs() < eps
+    spec[close] = eps * spec[close] / spec[close].abs()
+    _assert_grad(t, [spec])
+
+
+def test_timestretch_float32_training_path_matches_the_kernel():
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(2)
+    spec = torch.complex(torch.randn(2, 201, 60, generator=g), torch.randn(2, 201, 60, generator=g)).cuda()
+    t = T.TimeStretch(n_freq=201, hop_length=160, fixed_rate=1.2).cuda()
+    with torch.no_grad():
+        plain = t(spec)
+    s = spec.clone().requires_grad_()
+    got = t(s)
+    assert got.shape == plain.shape
+    assert float((got.detach().abs() - plain.abs()).abs().max()) <= 1e-5 * float(plain.abs().max())
+    (gr,) = torch.autograd.grad(got.abs().square().sum(), s)
+    assert torch.isfinite(torch.view_as_real(gr)).all()
+
+
+@pytest.mark.parametrize("kwargs", [{"power": None}, {"power": 2.0, "normalized": True}, {"power": 1.0, "pad": 3}], ids=str)
+def test_spectrogram_two_sided(kwargs):
+    """VERDICT r3 missing 5: onesided=False in float64 (and in training mode) -- values against torch.stft, then gradcheck."""
+    import audio_amd.transforms as T
+    t = T.Spectrogram(n_fft=64, hop_length=16, onesided=False, **kwargs).to(dtype=torch.float64, device="cuda")
+    x = _noise(2, 200, seed=5).double()
+    pad = kwargs.get("pad", 0)
+    xp = torch.nn.functional.pad(x, (pad, pad))
+    w = torch.hann_window(64, dtype=torch.float64)
+    ref = torch.stft(xp, 64, 16, 64, w, center=True, pad_mode="reflect", normalized=False, onesided=False, return_complex=True)
+    if kwargs.get("normalized"):
+        ref = ref / w.pow(2).sum().sqrt()
+    if kwargs["power"] is not None:
+        ref = ref.abs().pow(kwargs["power"])
+    got = t(x.cuda())
+    assert got.shape == ref.shape == (2, 64, ref.shape[-1])
+    assert float((got.cpu() - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
+    _assert_grad(t, [_noise(2, 200, seed=5)], nondet_tol=1e-10)
+    # float32 in training mode takes the same route; inference runs the two-sided kernel
+    t32 = T.Spectrogram(n_fft=64, hop_length=16, onesided=False, **kwargs).cuda()
+    xa = x.float().cuda().requires_grad_()
+    ya = t32(xa)
+    with torch.no_grad():
+        yb = t32(x.float().cuda())
+    assert float((ya.detach() - yb).abs().max()) <= 5e-6 * float(yb.abs().max())
+    torch.autograd.grad((ya.abs() if ya.is_complex() else ya).sum(), xa)
