@@ -68,6 +68,19 @@ class Stft(torch.autograd.Function):
         rows, length = x2.shape
         T = n_frames_of(length, cfg)
         n_freq = cfg[0] // 2 + 1
+        from . import functional as F
+        ops = F._ops()
+        if ops is not None and rows * T > 0:
+            # the dispatcher-level ops (csrc/torch_shim.cpp): float32 = aamd::spectrogram with power <= 0 (complex frames)
+            if x2.dtype == torch.float64:
+                out = ops.spectrogram_f64(x2, wp, twiddles(cfg[0], x2.device, x2.dtype), cfg[0], cfg[1], cfg[2], bool(cfg[3]),
+                                          _lib.PAD_MODES[cfg[4]], T)
+            else:
+                out = ops.spectrogram(x2, wp, twiddles(cfg[0], x2.device, x2.dtype), cfg[0], cfg[1], cfg[2], bool(cfg[3]),
+                                      _lib.PAD_MODES[cfg[4]], True, T, 1.0, 0.0).view(rows, T, n_freq, 2)
+            ctx.save_for_backward(wp)
+            ctx.cfg, ctx.length = cfg, length
+            return out
         out = torch.empty((rows, T, n_freq, 2), dtype=x2.dtype, device=x2.device)
         if out.numel():
             entry = getattr(_lib.lib(), "aamd_spectrogram_" + _suffix(x2.dtype))
@@ -92,6 +105,15 @@ class StftAdjoint(torch.autograd.Function):
     def forward(ctx, G: Tensor, wp: Tensor, cfg: Cfg, length: int):
         G = G.contiguous()
         rows, T = G.shape[0], G.shape[1]
+        from . import functional as F
+        ops = F._ops()
+        if ops is not None and rows * length > 0 and T:
+            op = ops.istft_f64 if G.dtype == torch.float64 else ops.istft
+            out = op(G, wp, twiddles(cfg[0], G.device, G.dtype), None, cfg[0], cfg[1], cfg[2], bool(cfg[3]),
+                     _lib.PAD_MODES[cfg[4]], length, 1.0, True)
+            ctx.save_for_backward(wp)
+            ctx.cfg = cfg
+            return out
         out = torch.zeros((rows, length), dtype=G.dtype, device=G.device)
         if out.numel() and T:
             entry = getattr(_lib.lib(), "aamd_istft_" + _suffix(G.dtype))

@@ -39,7 +39,7 @@ class MfccFused(C.Structure):
     _fields_ = [("dct_frag", C.c_void_p), ("n_mfcc", C.c_int32), ("pass_", C.c_int32), ("multiplier", C.c_float),
                 ("amin", C.c_float), ("db_multiplier", C.c_float), ("top_db", C.c_float), ("group_max", C.c_void_p),
                 ("rows_per_group", C.c_int64), ("tile_min", C.c_void_p), ("fix_count", C.c_void_p),
-                ("tile_list", C.c_void_p)]
+                ("tile_list", C.c_void_p), ("arrive", C.c_void_p), ("arrive_base", C.c_int32)]
 
 
 class ResampleBands(C.Structure):
@@ -145,7 +145,7 @@ def lib():
                 fn = getattr(h, name)   # AttributeError if the ABI symbol is missing
                 fn.restype = res
                 fn.argtypes = args
-            if h.aamd_abi_version() != 4:
+            if h.aamd_abi_version() != 5:
                 raise RuntimeError("audio_amd: ABI version mismatch between _lib.py and libaudio_amd.so")
             _lib = h
     return _lib

@@ -4,7 +4,8 @@ Same mechanism as the reference's native extension: a LibTorch-stable-ABI librar
 boxed kernels on the CUDA dispatch key, loaded with ``torch.ops.load_library``
 (reference: src/torchaudio/_extension/utils.py:50-56, src/libtorchaudio/lfilter.cpp:118-138).
 
-  torch.ops.aamd.{spectrogram, mel_spectrogram, mel_spectrogram_db, mfcc_dct, resample, lfilter, fftconvolve}
+  torch.ops.aamd.{spectrogram, mel_spectrogram, mel_spectrogram_db, mfcc_dct, resample, lfilter, fftconvolve} and, since
+  round 4, one op for every other compute entry of include/audio_amd.h (`OPS` below)
   torch.ops.torchaudio._lfilter_core_loop      (CUDA key; the reference's own schema -- see ensure_torchaudio_op)
 
 There is no CPU-key kernel: CPU tensors raise NotImplementedError from the dispatcher.
@@ -20,7 +21,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SHIM_PATH = os.path.join(_HERE, "lib", "libaudio_amd_torch.so")
 
-OPS = ("spectrogram", "mel_spectrogram", "mel_spectrogram_db", "mfcc_dct", "resample", "lfilter", "fftconvolve")
+OPS = ("spectrogram", "mel_spectrogram", "mel_spectrogram_db", "mfcc_dct", "resample", "lfilter", "fftconvolve",
+       # round 4: the rest of the compute entries of include/audio_amd.h (one op per native entry, as the reference does)
+       "mel_spectrogram_lognorm", "mfcc_frag_build", "mfcc_fused", "istft", "istft_f64", "spectrogram_f64", "phase_vocoder",
+       "griffinlim_update", "mel_scale", "amplitude_to_db", "amplitude_to_db_clamped", "db_clamp", "spectrogram_grad",
+       "mel_spectrogram_grad", "resample_sparse", "kaldi_features", "lfilter_f64", "resample_f64", "fftconvolve_f64")
 
 _lock = threading.Lock()
 _handle = None
@@ -41,7 +46,7 @@ def load():
             torch.ops.load_library(SHIM_PATH)
             h = C.CDLL(SHIM_PATH)
             h.aamd_torch_shim_abi.restype = C.c_int
-            if h.aamd_torch_shim_abi() != 4:
+            if h.aamd_torch_shim_abi() != 5:
                 raise RuntimeError("audio_amd: ABI version mismatch between the torch shim and include/audio_amd.h")
             _register_fakes()
             _handle = h
@@ -82,6 +87,87 @@ def _register_fakes() -> None:
         return torch.empty_like(waveform)
 
     @reg("aamd::fftconvolve")
+    def _(x, y, x_row_of, y_row_of, rows, start, out_len):
+        return x.new_empty((rows, out_len))
+
+    # ---- round 4 ops ----
+    @reg("aamd::mel_spectrogram_lognorm")
+    def _(wav, window, twiddle, band_lo, band_width, band_weights, lane_order, table400, n_fft, hop, n_frames, scale, gain,
+          mean, invstddev, out_frames, table_sig):
+        rows = wav.shape[0] * (wav.shape[2] if wav.dim() == 3 else 1)
+        return window.new_empty((rows, out_frames if mean is not None else n_frames, band_lo.shape[0]))
+
+    @reg("aamd::mfcc_frag_build")
+    def _(dct_mat, n_mels, n_mfcc):
+        from . import _lib
+        return dct_mat.new_empty((int(_lib.lib().aamd_mfcc_frag_floats()),))
+
+    @reg("aamd::mfcc_fused")
+    def _(wav, window, twiddle, band_lo, band_width, band_weights, lane_order, table400, dct_frag, group_max, n_fft, hop, pad,
+          center, pad_mode, n_frames, scale, n_mfcc, multiplier, amin, db_multiplier, top_db, rows_per_group, table_sig):
+        return wav.new_empty((wav.shape[0], n_frames, n_mfcc))
+
+    def _istft_fake(spec, window, twiddle, inv_envelope, n_fft, hop, pad, center, pad_mode, length, scale, adjoint):
+        return window.new_empty((spec.shape[0], length))
+    reg("aamd::istft")(_istft_fake)
+    reg("aamd::istft_f64")(_istft_fake)
+
+    @reg("aamd::spectrogram_f64")
+    def _(wav, window, twiddle, n_fft, hop, pad, center, pad_mode, n_frames):
+        return wav.new_empty((wav.shape[0], n_frames, n_fft // 2 + 1, 2))
+
+    @reg("aamd::phase_vocoder")
+    def _(spec, phase_advance, rate, frame_major_out):
+        import math
+        rows, n_freq, n_in = spec.shape[0], spec.shape[1], spec.shape[2]
+        n_out = int(math.ceil(n_in / rate))
+        return phase_advance.new_empty((rows, n_out, n_freq, 2) if frame_major_out else (rows, n_freq, n_out, 2))
+
+    @reg("aamd::griffinlim_update")
+    def _(rebuilt, tprev, magnitude, momentum):
+        return torch.empty_like(rebuilt)
+
+    @reg("aamd::mel_scale")
+    def _(spec, band_lo, band_width, band_weights):
+        return spec.new_empty((spec.shape[0], spec.shape[1], band_lo.shape[0]))
+
+    @reg("aamd::amplitude_to_db")
+    def _(x, multiplier, amin, db_multiplier, group_max, group_size):
+        return torch.empty_like(x)
+
+    @reg("aamd::amplitude_to_db_clamped")
+    def _(x, multiplier, amin, db_multiplier, group_max, group_size, top_db):
+        return torch.empty_like(x)
+
+    @reg("aamd::db_clamp")
+    def _(x, group_max, group_size, top_db):
+        return torch.empty_like(x)
+
+    @reg("aamd::spectrogram_grad")
+    def _(spec, dpower, power):
+        return torch.empty_like(spec)
+
+    @reg("aamd::mel_spectrogram_grad")
+    def _(spec, dmel, band_lo, band_width, band_weights, power):
+        return spec
+
+    @reg("aamd::resample_sparse")
+    def _(wav, taps_compact, tap_lo, orig, new, width, out_len):
+        return wav.new_empty((wav.shape[0], out_len))
+
+    @reg("aamd::kaldi_features")
+    def _(wav, window, twiddle, band_lo, band_width, band_weights, noise, n_frames, opts, fopts):
+        return wav.new_empty((wav.shape[0], n_frames, opts[10] if band_lo is not None else opts[0] // 2 + 1))
+
+    @reg("aamd::lfilter_f64")
+    def _(waveform, a_coeffs, b_coeffs, n_stages, clamp):
+        return torch.empty_like(waveform)
+
+    @reg("aamd::resample_f64")
+    def _(wav, kernel, orig, new, width, out_len):
+        return wav.new_empty((wav.shape[0], out_len))
+
+    @reg("aamd::fftconvolve_f64")
     def _(x, y, x_row_of, y_row_of, rows, start, out_len):
         return x.new_empty((rows, out_len))
 

@@ -111,6 +111,17 @@ def _features(waveform: Tensor, window_shift: int, window_size: int, padded: int
     if dither != 0.0:
         # kaldi.py:180-183: rand_gauss = torch.randn(strided_input.shape, device, dtype); frames += rand_gauss * dither
         noise = _randn((n_utt, m, window_size) if batch else (m, window_size), device=dev, dtype=torch.float32).contiguous()
+    ops = F._ops()
+    if ops is not None and x.is_contiguous():
+        # the dispatcher-level op (csrc/torch_shim.cpp aamd::kaldi_features): options as two flat lists, (n_utt, n) rows
+        res = ops.kaldi_features(x.view(n_utt, n), win, F._twiddles(padded, dev),
+                                 None if bands is None else bands.lo, None if bands is None else bands.width,
+                                 None if bands is None else bands.weights,
+                                 None if noise is None else noise.view(n_utt, m, window_size), m,
+                                 [padded, window_shift, window_size, int(snip_edges), int(remove_dc_offset), int(raw_energy),
+                                  int(use_power), int(use_log), energy_col, first_col, n_cols],
+                                 [float(preemphasis_coefficient), float(energy_floor), float(dither)])
+        return res if batch else res.view(m, n_cols)
     out = torch.empty((n_utt, m, n_cols) if batch else (m, n_cols), dtype=torch.float32, device=dev)
     d = _lib.KaldiDesc(n, m, padded, window_shift, window_size, int(snip_edges), float(preemphasis_coefficient),
                        int(remove_dc_offset), int(raw_energy), float(energy_floor), int(use_power), int(use_log),

@@ -513,7 +513,11 @@ int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twid
   epi.group_max = f->group_max; epi.rows_per_group = f->rows_per_group;
   epi.dct_frag = f->dct_frag; epi.n_mfcc = f->n_mfcc; epi.top_db = f->top_db; epi.tile_min = f->tile_min;
   epi.fix_count = f->fix_count; epi.fixup = f->pass; epi.fix_list = f->tile_list;
-  if (f->pass == 1) {
+  if (f->arrive != nullptr) {        // pass 0 compacts the fix-up list itself (its last workgroup): no list kernel in pass 1
+    AAMD_CHECK_ARG(f->tile_list != nullptr, "the fused MFCC with `arrive` needs tile_list in pass 0 too");
+    epi.arrive = f->arrive; epi.arrive_base = f->arrive_base;
+  }
+  if (f->pass == 1 && f->arrive == nullptr) {
     // compact the tiles under their group's cut-off (known now: the caller reduced group_max over ranks between the passes)
     AAMD_CHECK_ARG(f->fix_count && f->tile_list, "pass 1 of the fused MFCC needs fix_count and tile_list");
     const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;

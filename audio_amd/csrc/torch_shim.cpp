@@ -27,10 +27,12 @@
 #include <torch/csrc/stable/tensor.h>
 #include <torch/headeronly/core/ScalarType.h>
 
+#include <cmath>
 #include <cstdint>
 #include <memory>
 #include <optional>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -282,6 +284,381 @@ Tensor fftconvolve(Tensor x, Tensor y, std::optional<Tensor> x_row_of, std::opti
   return out;
 }
 
+
+// =====================================================================================================================
+// Round 4 (VERDICT r3 missing 6): one dispatcher op per remaining compute entry of include/audio_amd.h -- the reference
+// mechanism (lfilter.cpp:118-138) is one op per native entry.  Same rules as above: validate like iir_cuda.cu:41-65,
+// allocate through torch, current stream of the tensor's device, raw pointers into the C ABI.
+// =====================================================================================================================
+void want_dev(const Tensor& t, ScalarType st, const char* what, int64_t dim = -1) {
+  STD_TORCH_CHECK(t.is_cuda(), "audio_amd: ", what, " must be on an MI355X (ROCm) device; there is no CPU kernel");
+  STD_TORCH_CHECK(t.scalar_type() == st, "audio_amd: ", what, " has the wrong dtype");
+  STD_TORCH_CHECK(t.is_contiguous(), "audio_amd: ", what, " must be contiguous");
+  if (dim >= 0) STD_TORCH_CHECK(t.dim() == dim, "audio_amd: ", what, " must have ", dim, " dimensions");
+}
+const double* dp(const Tensor& t) { return t.numel() ? static_cast<const double*>(t.data_ptr()) : nullptr; }
+double* dpm(Tensor& t) { return t.numel() ? static_cast<double*>(t.data_ptr()) : nullptr; }
+
+void stft_consts(const Tensor& ref, const Tensor& window, const Tensor& twiddle, int64_t n_fft, ScalarType st) {
+  want_dev(window, st, "window", 1);
+  want_dev(twiddle, st, "twiddle");
+  same_device(ref, window);
+  same_device(ref, twiddle);
+  STD_TORCH_CHECK(window.numel() == n_fft && twiddle.numel() == 2 * n_fft, "audio_amd: window / twiddle size");
+}
+
+// ---- aamd::mel_spectrogram_lognorm / _pcm16 (pipelines/rnnt_pipeline.py:16-47, 319-326 fused; _torchcodec.py:150-152) ----
+// wav: float32 (rows, time) | int16 (rows, time) planar PCM | int16 (clips, time, channels) interleaved PCM (channels 1 / 2).
+// mean / invstddev absent: plain mel spectrogram of the PCM (the float form of that is aamd::mel_spectrogram).
+Tensor mel_spectrogram_lognorm(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width,
+                               Tensor band_weights, std::optional<Tensor> lane_order, std::optional<Tensor> table400,
+                               int64_t n_fft, int64_t hop, int64_t n_frames, double scale, double gain,
+                               std::optional<Tensor> mean, std::optional<Tensor> invstddev, int64_t out_frames,
+                               int64_t table_sig) {
+  STD_TORCH_CHECK(wav.is_cuda() && wav.is_contiguous(), "audio_amd: waveform must be a contiguous device tensor");
+  const bool pcm = wav.scalar_type() == ScalarType::Short;
+  STD_TORCH_CHECK(pcm || wav.scalar_type() == ScalarType::Float, "audio_amd: waveform must be float32 or int16 PCM");
+  STD_TORCH_CHECK(wav.dim() == 2 || (pcm && wav.dim() == 3), "audio_amd: waveform must be (rows, time) or int16 (clips, time, channels)");
+  const int64_t channels = wav.dim() == 3 ? wav.size(2) : 0;
+  STD_TORCH_CHECK(mean.has_value() == invstddev.has_value(), "audio_amd: mean and invstddev come together");
+  STD_TORCH_CHECK(pcm || mean.has_value(), "audio_amd: float input without statistics is aamd::mel_spectrogram");
+  stft_consts(wav, window, twiddle, n_fft, ScalarType::Float);
+  aamd_stft_desc d{};
+  d.rows = channels ? wav.size(0) * channels : wav.size(0);
+  d.length = wav.size(1);
+  d.row_stride = d.length > 0 ? d.length : 1;
+  d.n_fft = (int32_t)n_fft; d.hop = (int32_t)hop; d.pad = 0; d.center = 1; d.pad_mode = AAMD_PAD_REFLECT; d.onesided = 1;
+  d.n_frames = (int32_t)n_frames; d.scale = (float)scale; d.power = 2.0f;
+  Bands bands(wav, band_lo, band_width, band_weights, lane_order, table400, table_sig);
+  const float *mp = nullptr, *ip = nullptr;
+  if (mean.has_value()) {
+    want_f32(*mean, "mean", 1); want_f32(*invstddev, "invstddev", 1);
+    same_device(wav, *mean); same_device(wav, *invstddev);
+    STD_TORCH_CHECK(mean->numel() == bands.b.n_mels && invstddev->numel() == bands.b.n_mels, "audio_amd: statistics must have n_mels entries");
+    mp = fp(*mean); ip = fp(*invstddev);
+  }
+  const int64_t frames = mean.has_value() ? out_frames : n_frames;
+  STD_TORCH_CHECK(frames >= n_frames, "audio_amd: out_frames must be >= n_frames");
+  const torch::stable::accelerator::DeviceGuard guard(wav.get_device_index());
+  Tensor out = torch::stable::new_empty(window, {d.rows, frames, (int64_t)bands.b.n_mels});
+  if (frames > n_frames && out.numel()) {               // the pipeline's right padding: zero rows (the kernel leaves them alone)
+    Tensor tail = torch::stable::narrow(out, 1, n_frames, frames - n_frames);
+    torch::stable::fill_(tail, 0.0);
+  }
+  if (out.numel() && n_frames > 0) {
+    void* st = current_stream(wav);
+    if (!pcm)
+      check(aamd_melspectrogram_lognorm_f32(fp(wav), fp(window), fp(twiddle), &bands.b, fpm(out), &d, (float)gain, mp, ip, frames, st));
+    else if (channels)
+      check(aamd_melspectrogram_pcm16_interleaved_f32(static_cast<const int16_t*>(wav.data_ptr()), (int32_t)channels, fp(window),
+                                                      fp(twiddle), &bands.b, fpm(out), &d, (float)gain, mp, ip, frames, st));
+    else
+      check(aamd_melspectrogram_pcm16_f32(static_cast<const int16_t*>(wav.data_ptr()), fp(window), fp(twiddle), &bands.b,
+                                          fpm(out), &d, (float)gain, mp, ip, frames, st));
+  }
+  return out;
+}
+
+// ---- aamd::mfcc_frag_build / aamd::mfcc_fused (transforms/_transforms.py:692-709 in one kernel + fix-up launch) ---------
+Tensor mfcc_frag_build(Tensor dct, int64_t n_mels, int64_t n_mfcc) {
+  want_f32(dct, "dct_mat", 2);
+  STD_TORCH_CHECK(dct.size(0) == n_mels && dct.size(1) == n_mfcc, "audio_amd: dct_mat must be (n_mels, n_mfcc)");
+  const torch::stable::accelerator::DeviceGuard guard(dct.get_device_index());
+  Tensor frag = torch::stable::new_empty(dct, {(int64_t)aamd_mfcc_frag_floats()});
+  check(aamd_mfcc_frag_build(fp(dct), (int32_t)n_mels, (int32_t)n_mfcc, fpm(frag), current_stream(dct)));
+  return frag;
+}
+// Single-rank form (no exchange of group_max between the passes): pass 0 compacts the fix-up list itself.
+// scratch: int32[2 * tiles + 2] (tile minima as float bits, the list, the count, the arrival word); group_max: float[n_groups]
+// pre-filled with -inf, updated in place.  Returns (rows, n_frames, n_mfcc).
+Tensor mfcc_fused(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, Tensor band_weights,
+                  std::optional<Tensor> lane_order, std::optional<Tensor> table400, Tensor dct_frag, Tensor group_max,
+                  int64_t n_fft, int64_t hop, int64_t pad, bool center, int64_t pad_mode, int64_t n_frames, double scale,
+                  int64_t n_mfcc, double multiplier, double amin, double db_multiplier, double top_db, int64_t rows_per_group,
+                  int64_t table_sig) {
+  aamd_stft_desc d = make_desc(wav, n_fft, hop, pad, center, pad_mode, true, n_frames, scale, 2.0);
+  stft_consts(wav, window, twiddle, n_fft, ScalarType::Float);
+  want_f32(dct_frag, "dct_frag", 1);
+  want_f32(group_max, "group_max", 1);
+  same_device(wav, dct_frag); same_device(wav, group_max);
+  STD_TORCH_CHECK(dct_frag.numel() == aamd_mfcc_frag_floats(), "audio_amd: dct_frag comes from aamd::mfcc_frag_build");
+  STD_TORCH_CHECK(rows_per_group > 0 && group_max.numel() * rows_per_group >= d.rows, "audio_amd: group_max too small");
+  Bands bands(wav, band_lo, band_width, band_weights, lane_order, table400, table_sig);
+  STD_TORCH_CHECK(aamd_mfcc_fused_supported(&d, &bands.b, (int32_t)n_mfcc), "audio_amd: shape not served by the fused MFCC "
+                  "(n_fft 400, hop 100 / 160 / 200, 80 mels, n_mfcc <= 48 and a multiple of 4)");
+  const torch::stable::accelerator::DeviceGuard guard(wav.get_device_index());
+  Tensor out = torch::stable::new_empty(wav, {d.rows, n_frames, n_mfcc});
+  if (!out.numel()) return out;
+  const int64_t tiles = aamd_mfcc_fused_tiles(&d);
+  Tensor scratch = torch::stable::new_zeros(wav, {2 * tiles + 2});        // zeroed: the arrival word starts at 0
+  float* sp = fpm(scratch);
+  aamd_mfcc_fused f{};
+  f.dct_frag = fp(dct_frag); f.n_mfcc = (int32_t)n_mfcc; f.pass = 0;
+  f.multiplier = (float)multiplier; f.amin = (float)amin; f.db_multiplier = (float)db_multiplier; f.top_db = (float)top_db;
+  f.group_max = fpm(group_max); f.rows_per_group = rows_per_group;
+  f.tile_min = sp; f.tile_list = reinterpret_cast<int32_t*>(sp + tiles);
+  f.fix_count = reinterpret_cast<int32_t*>(sp + 2 * tiles); f.arrive = reinterpret_cast<int32_t*>(sp + 2 * tiles + 1);
+  f.arrive_base = 0;
+  void* st = current_stream(wav);
+  check(aamd_mfcc_fused_f32(fp(wav), fp(window), fp(twiddle), &bands.b, fpm(out), &d, &f, st));
+  f.pass = 1;
+  check(aamd_mfcc_fused_f32(fp(wav), fp(window), fp(twiddle), &bands.b, fpm(out), &d, &f, st));
+  return out;
+}
+
+// ---- aamd::istft / aamd::istft_f64 (functional/functional.py:148-225; adjoint = the STFT's backward) --------------------
+template <typename T>
+Tensor istft_any(Tensor spec, Tensor window, Tensor twiddle, std::optional<Tensor> inv_envelope, int64_t n_fft, int64_t hop,
+                 int64_t pad, bool center, int64_t pad_mode, int64_t length, double scale, bool adjoint) {
+  constexpr ScalarType st = std::is_same<T, double>::value ? ScalarType::Double : ScalarType::Float;
+  want_dev(spec, st, "spec", 4);                         // (rows, n_frames, n_fft / 2 + 1, 2): view_as_real of the complex frames
+  STD_TORCH_CHECK(spec.size(2) == n_fft / 2 + 1 && spec.size(3) == 2, "audio_amd: spec must be (rows, frames, n_fft / 2 + 1, 2)");
+  stft_consts(spec, window, twiddle, n_fft, st);
+  const T* env = nullptr;
+  if (inv_envelope.has_value()) {
+    want_dev(*inv_envelope, st, "inv_envelope", 1);
+    same_device(spec, *inv_envelope);
+    STD_TORCH_CHECK(inv_envelope->numel() == length, "audio_amd: inv_envelope must have `length` entries");
+    env = static_cast<const T*>(inv_envelope->data_ptr());
+  }
+  aamd_stft_desc d{};
+  d.rows = spec.size(0); d.length = length; d.row_stride = length > 0 ? length : 1;
+  d.n_fft = (int32_t)n_fft; d.hop = (int32_t)hop; d.pad = (int32_t)pad; d.center = center; d.pad_mode = (int32_t)pad_mode;
+  d.onesided = 1; d.n_frames = (int32_t)spec.size(1); d.scale = (float)scale; d.power = 0.0f;
+  const torch::stable::accelerator::DeviceGuard guard(spec.get_device_index());
+  Tensor out = torch::stable::new_zeros(window, {d.rows, length});     // the kernel accumulates with atomic adds
+  if (out.numel() && d.n_frames) {
+    if constexpr (std::is_same<T, double>::value)
+      check(aamd_istft_f64(dp(spec), dp(window), dp(twiddle), env, dpm(out), &d, adjoint ? 1 : 0, current_stream(spec)));
+    else
+      check(aamd_istft_f32(fp(spec), fp(window), fp(twiddle), env, fpm(out), &d, adjoint ? 1 : 0, current_stream(spec)));
+  }
+  return out;
+}
+Tensor istft(Tensor spec, Tensor window, Tensor twiddle, std::optional<Tensor> inv_envelope, int64_t n_fft, int64_t hop,
+             int64_t pad, bool center, int64_t pad_mode, int64_t length, double scale, bool adjoint) {
+  return istft_any<float>(spec, window, twiddle, inv_envelope, n_fft, hop, pad, center, pad_mode, length, scale, adjoint);
+}
+Tensor istft_f64(Tensor spec, Tensor window, Tensor twiddle, std::optional<Tensor> inv_envelope, int64_t n_fft, int64_t hop,
+                 int64_t pad, bool center, int64_t pad_mode, int64_t length, double scale, bool adjoint) {
+  return istft_any<double>(spec, window, twiddle, inv_envelope, n_fft, hop, pad, center, pad_mode, length, scale, adjoint);
+}
+
+// ---- aamd::spectrogram_f64 (functional/functional.py:123-145 on double; complex frames only: the |X|^p is the caller's) ---
+Tensor spectrogram_f64(Tensor wav, Tensor window, Tensor twiddle, int64_t n_fft, int64_t hop, int64_t pad, bool center,
+                       int64_t pad_mode, int64_t n_frames) {
+  want_dev(wav, ScalarType::Double, "waveform", 2);
+  stft_consts(wav, window, twiddle, n_fft, ScalarType::Double);
+  aamd_stft_desc d{};
+  d.rows = wav.size(0); d.length = wav.size(1); d.row_stride = d.length > 0 ? d.length : 1;
+  d.n_fft = (int32_t)n_fft; d.hop = (int32_t)hop; d.pad = (int32_t)pad; d.center = center; d.pad_mode = (int32_t)pad_mode;
+  d.onesided = 1; d.n_frames = (int32_t)n_frames; d.scale = 1.0f; d.power = 0.0f;
+  const torch::stable::accelerator::DeviceGuard guard(wav.get_device_index());
+  Tensor out = torch::stable::new_empty(wav, {d.rows, n_frames, n_fft / 2 + 1, 2});
+  if (out.numel()) check(aamd_spectrogram_f64(dp(wav), dp(window), dp(twiddle), dpm(out), &d, current_stream(wav)));
+  return out;
+}
+
+// ---- aamd::phase_vocoder (functional/functional.py:732-803) ----------------------------------------------------------------
+// spec: view_as_real of a complex64 (rows, freq, frames) tensor with ANY strides (float (rows, freq, frames, 2), last stride 1);
+// frame_major_out: the result is (rows, frames_out, freq, 2) memory -- what aamd::istft eats -- else (rows, freq, frames_out, 2).
+Tensor phase_vocoder(Tensor spec, Tensor phase_advance, double rate, bool frame_major_out) {
+  STD_TORCH_CHECK(spec.is_cuda() && spec.scalar_type() == ScalarType::Float && spec.dim() == 4 && spec.size(3) == 2,
+                  "audio_amd: spec must be view_as_real of a complex64 (rows, freq, frames) device tensor");
+  STD_TORCH_CHECK(spec.numel() == 0 || (spec.stride(3) == 1 && spec.stride(0) % 2 == 0 && spec.stride(1) % 2 == 0 && spec.stride(2) % 2 == 0),
+                  "audio_amd: spec strides must address whole complex elements");
+  want_f32(phase_advance, "phase_advance", 1);
+  same_device(spec, phase_advance);
+  STD_TORCH_CHECK(rate > 0.0 && phase_advance.numel() == spec.size(1), "audio_amd: phase_advance must have n_freq entries, rate > 0");
+  const int64_t rows = spec.size(0), n_freq = spec.size(1), n_in = spec.size(2);
+  const int64_t n_out = (int64_t)std::ceil((double)n_in / rate);
+  const torch::stable::accelerator::DeviceGuard guard(spec.get_device_index());
+  Tensor out = frame_major_out ? torch::stable::new_empty(phase_advance, {rows, n_out, n_freq, 2})
+                               : torch::stable::new_empty(phase_advance, {rows, n_freq, n_out, 2});
+  if (out.numel()) {
+    aamd_vocoder_desc v{};
+    v.rows = rows; v.n_freq = (int32_t)n_freq; v.n_frames_in = (int32_t)n_in; v.n_frames_out = (int32_t)n_out;
+    v.in_stride_row = spec.stride(0) / 2; v.in_stride_freq = spec.stride(1) / 2; v.in_stride_frame = spec.stride(2) / 2;
+    v.out_stride_row = n_out * n_freq;
+    v.out_stride_freq = frame_major_out ? 1 : n_out;
+    v.out_stride_frame = frame_major_out ? n_freq : 1;
+    v.rate = rate;
+    check(aamd_phase_vocoder_f32(static_cast<const float*>(spec.data_ptr()), fp(phase_advance), fpm(out), &v, current_stream(spec)));
+  }
+  return out;
+}
+
+// ---- aamd::griffinlim_update (functional/functional.py:336-343): returns `next`, updates tprev in place ---------------------
+Tensor griffinlim_update(Tensor rebuilt, Tensor tprev, Tensor magnitude, double momentum) {
+  want_f32(rebuilt, "rebuilt"); want_f32(tprev, "tprev"); want_f32(magnitude, "magnitude");
+  same_device(rebuilt, tprev); same_device(rebuilt, magnitude);
+  STD_TORCH_CHECK(rebuilt.numel() == 2 * magnitude.numel() && tprev.numel() == rebuilt.numel(), "audio_amd: rebuilt / tprev are view_as_real of the magnitude's shape");
+  const torch::stable::accelerator::DeviceGuard guard(rebuilt.get_device_index());
+  Tensor next = torch::stable::empty_like(rebuilt);
+  if (next.numel())
+    check(aamd_griffinlim_update_f32(fp(rebuilt), fpm(tprev), fp(magnitude), fpm(next), magnitude.numel(), (float)momentum, current_stream(rebuilt)));
+  return next;
+}
+
+// ---- aamd::mel_scale (transforms/_transforms.py:403-415 on a frame-major spectrogram) ---------------------------------------
+Tensor mel_scale(Tensor spec, Tensor band_lo, Tensor band_width, Tensor band_weights) {
+  want_f32(spec, "spec", 3);                             // (rows, frames, n_freq)
+  Bands bands(spec, band_lo, band_width, band_weights, std::nullopt, std::nullopt, 0);
+  const torch::stable::accelerator::DeviceGuard guard(spec.get_device_index());
+  Tensor out = torch::stable::new_empty(spec, {spec.size(0), spec.size(1), (int64_t)bands.b.n_mels});
+  if (out.numel())
+    check(aamd_mel_scale_f32(fp(spec), &bands.b, fpm(out), spec.size(0), (int32_t)spec.size(1), (int32_t)spec.size(2), current_stream(spec)));
+  return out;
+}
+
+// ---- aamd::amplitude_to_db / _clamped / db_clamp (functional/functional.py:356-404) -----------------------------------------
+Tensor amplitude_to_db(Tensor x, double multiplier, double amin, double db_multiplier, std::optional<Tensor> group_max, int64_t group_size) {
+  want_f32(x, "x");
+  float* gm = nullptr;
+  if (group_max.has_value()) {
+    want_f32(*group_max, "group_max", 1); same_device(x, *group_max);
+    STD_TORCH_CHECK(group_size > 0 && group_max->numel() * group_size >= x.numel(), "audio_amd: group_max too small");
+    gm = fpm(*group_max);
+  }
+  const torch::stable::accelerator::DeviceGuard guard(x.get_device_index());
+  Tensor out = torch::stable::empty_like(x);
+  if (out.numel())
+    check(aamd_amplitude_to_db_f32(fp(x), fpm(out), x.numel(), (float)multiplier, (float)amin, (float)db_multiplier, gm,
+                                   group_size > 0 ? group_size : 1, current_stream(x)));
+  return out;
+}
+Tensor amplitude_to_db_clamped(Tensor x, double multiplier, double amin, double db_multiplier, Tensor group_max, int64_t group_size, double top_db) {
+  want_f32(x, "x"); want_f32(group_max, "group_max", 1); same_device(x, group_max);
+  STD_TORCH_CHECK(group_size > 0 && group_max.numel() * group_size >= x.numel(), "audio_amd: group_max too small");
+  const torch::stable::accelerator::DeviceGuard guard(x.get_device_index());
+  Tensor out = torch::stable::empty_like(x);
+  if (out.numel())
+    check(aamd_amplitude_to_db_clamped_f32(fp(x), fpm(out), x.numel(), (float)multiplier, (float)amin, (float)db_multiplier,
+                                           fp(group_max), group_size, (float)top_db, current_stream(x)));
+  return out;
+}
+Tensor db_clamp(Tensor x, Tensor group_max, int64_t group_size, double top_db) {
+  want_f32(x, "x"); want_f32(group_max, "group_max", 1); same_device(x, group_max);
+  STD_TORCH_CHECK(group_size > 0 && group_max.numel() * group_size >= x.numel(), "audio_amd: group_max too small");
+  const torch::stable::accelerator::DeviceGuard guard(x.get_device_index());
+  Tensor out = torch::stable::empty_like(x);
+  if (out.numel()) check(aamd_db_clamp_f32(fp(x), fpm(out), x.numel(), fp(group_max), group_size, (float)top_db, current_stream(x)));
+  return out;
+}
+
+// ---- aamd::spectrogram_grad / aamd::mel_spectrogram_grad (backward of |X|^p and of fb . |X|^p) ------------------------------
+Tensor spectrogram_grad(Tensor spec, Tensor dpower, double power) {
+  want_f32(spec, "spec"); want_f32(dpower, "dpower"); same_device(spec, dpower);
+  STD_TORCH_CHECK(spec.numel() == 2 * dpower.numel(), "audio_amd: spec is view_as_real of dpower's shape");
+  const torch::stable::accelerator::DeviceGuard guard(spec.get_device_index());
+  Tensor out = torch::stable::empty_like(spec);
+  if (out.numel()) check(aamd_spectrogram_grad_f32(fp(spec), fp(dpower), fpm(out), dpower.numel(), (float)power, current_stream(spec)));
+  return out;
+}
+Tensor mel_spectrogram_grad(Tensor spec, Tensor dmel, Tensor band_lo, Tensor band_width, Tensor band_weights, double power) {
+  want_f32(spec, "spec", 3);                             // (n_vec, n_freq, 2): the complex STFT, overwritten with the cotangent
+  want_f32(dmel, "dmel", 2);
+  same_device(spec, dmel);
+  Bands bt(spec, band_lo, band_width, band_weights, std::nullopt, std::nullopt, 0);     // the band table of fb^T
+  STD_TORCH_CHECK(spec.size(2) == 2 && dmel.size(0) == spec.size(0) && bt.b.n_mels == spec.size(1), "audio_amd: shapes of spec / dmel / fb^T bands");
+  const torch::stable::accelerator::DeviceGuard guard(spec.get_device_index());
+  if (spec.numel())
+    check(aamd_melspectrogram_grad_f32(fpm(spec), fp(dmel), &bt.b, spec.size(0), (int32_t)spec.size(1), (int32_t)dmel.size(1),
+                                       (float)power, current_stream(spec)));
+  return spec;
+}
+
+// ---- aamd::resample_sparse (F.pitch_shift's huge reduced rates, functional/functional.py:1790-1840) ------------------------
+Tensor resample_sparse(Tensor wav, Tensor taps_compact, Tensor tap_lo, int64_t orig, int64_t new_, int64_t width, int64_t out_len) {
+  want_f32(wav, "waveform", 2); want_f32(taps_compact, "taps_compact", 2); want_i32(tap_lo, "tap_lo");
+  same_device(wav, taps_compact); same_device(wav, tap_lo);
+  STD_TORCH_CHECK(taps_compact.size(0) == new_ && tap_lo.numel() == new_, "audio_amd: one compacted tap row per output phase");
+  const torch::stable::accelerator::DeviceGuard guard(wav.get_device_index());
+  Tensor out = torch::stable::new_empty(wav, {wav.size(0), out_len});
+  if (out.numel()) {
+    const int64_t length = wav.size(1);
+    check(aamd_resample_sparse_f32(fp(wav), fp(taps_compact), static_cast<const int32_t*>(tap_lo.data_ptr()), fpm(out), wav.size(0),
+                                   length, length > 0 ? length : 1, (int32_t)orig, (int32_t)new_, (int32_t)width,
+                                   (int32_t)taps_compact.size(1), out_len, current_stream(wav)));
+  }
+  return out;
+}
+
+// ---- aamd::kaldi_features (compliance/kaldi.py:229-315, 514-645) -----------------------------------------------------------
+// opts: [n_fft, shift, win, snip_edges, remove_dc_offset, raw_energy, use_power, use_log, energy_col, first_col, n_cols];
+// fopts: [preemphasis, energy_floor, dither].  wav: (n_utt, n_samples).  No band tensors: kaldi.spectrogram rows.
+Tensor kaldi_features(Tensor wav, Tensor window, Tensor twiddle, std::optional<Tensor> band_lo, std::optional<Tensor> band_width,
+                      std::optional<Tensor> band_weights, std::optional<Tensor> noise, int64_t n_frames, std::vector<int64_t> opts,
+                      std::vector<double> fopts) {
+  want_f32(wav, "waveform", 2);
+  STD_TORCH_CHECK(opts.size() == 11 && fopts.size() == 3, "audio_amd: kaldi_features takes 11 integer and 3 float options");
+  stft_consts(wav, window, twiddle, opts[0], ScalarType::Float);
+  aamd_kaldi_desc k{};
+  k.n_samples = wav.size(1); k.n_frames = n_frames; k.n_fft = (int32_t)opts[0]; k.shift = (int32_t)opts[1]; k.win = (int32_t)opts[2];
+  k.snip_edges = (int32_t)opts[3]; k.preemphasis = (float)fopts[0]; k.remove_dc_offset = (int32_t)opts[4]; k.raw_energy = (int32_t)opts[5];
+  k.energy_floor = (float)fopts[1]; k.use_power = (int32_t)opts[6]; k.use_log = (int32_t)opts[7]; k.energy_col = (int32_t)opts[8];
+  k.first_col = (int32_t)opts[9]; k.n_cols = (int32_t)opts[10]; k.dither = (float)fopts[2]; k.noise = nullptr;
+  k.n_utt = wav.size(0); k.utt_stride = wav.size(1);
+  if (noise.has_value()) {
+    want_f32(*noise, "noise"); same_device(wav, *noise);
+    STD_TORCH_CHECK(noise->numel() == k.n_utt * n_frames * k.win, "audio_amd: noise must be (n_utt, n_frames, win)");
+    k.noise = fp(*noise);
+  }
+  STD_TORCH_CHECK(k.dither == 0.0f || k.noise != nullptr, "audio_amd: dither needs the caller's Gaussian draws");
+  std::optional<Bands> bands;
+  const bool fbank = band_lo.has_value();
+  STD_TORCH_CHECK(fbank == band_width.has_value() && fbank == band_weights.has_value(), "audio_amd: band tensors come together");
+  if (fbank) bands.emplace(wav, *band_lo, *band_width, *band_weights, std::nullopt, std::nullopt, 0);
+  const int64_t row = fbank ? k.n_cols : k.n_fft / 2 + 1;
+  const torch::stable::accelerator::DeviceGuard guard(wav.get_device_index());
+  Tensor out = torch::stable::new_empty(wav, {k.n_utt, n_frames, row});
+  if (out.numel())
+    check(aamd_kaldi_features_f32(fp(wav), fp(window), fp(twiddle), fbank ? &bands->b : nullptr, fpm(out), &k, current_stream(wav)));
+  return out;
+}
+
+// ---- float64 entries: aamd::lfilter_f64 / resample_f64 / fftconvolve_f64 (the precision path, csrc/f64_paths.h) -------------
+Tensor lfilter_f64(Tensor x, Tensor a, Tensor b, int64_t n_stages, int64_t clamp) {
+  want_dev(x, ScalarType::Double, "waveform", 3); want_dev(a, ScalarType::Double, "a_coeffs", 3); want_dev(b, ScalarType::Double, "b_coeffs", 3);
+  same_device(x, a); same_device(x, b);
+  STD_TORCH_CHECK(a.size(0) == n_stages && b.size(0) == n_stages && a.size(1) == b.size(1) && a.size(2) == b.size(2),
+                  "audio_amd: a / b must be (n_stages, rows, n_order)");
+  STD_TORCH_CHECK(a.size(1) == 1 || a.size(1) == x.size(1), "audio_amd: coefficient rows must be 1 or channels");
+  const torch::stable::accelerator::DeviceGuard guard(x.get_device_index());
+  Tensor y = torch::stable::empty_like(x);
+  if (y.numel())
+    check(aamd_lfilter_f64(dp(x), dp(a), dp(b), dpm(y), x.size(0), (int32_t)x.size(1), x.size(2), (int32_t)a.size(2),
+                           (int32_t)a.size(1), (int32_t)n_stages, (int32_t)clamp, current_stream(x)));
+  return y;
+}
+Tensor resample_f64(Tensor wav, Tensor kernel, int64_t orig, int64_t new_, int64_t width, int64_t out_len) {
+  want_dev(wav, ScalarType::Double, "waveform", 2); want_dev(kernel, ScalarType::Double, "kernel", 2);
+  same_device(wav, kernel);
+  STD_TORCH_CHECK(kernel.size(0) == new_ && kernel.size(1) == 2 * width + orig, "audio_amd: resample kernel shape does not match (new, 2*width+orig)");
+  const torch::stable::accelerator::DeviceGuard guard(wav.get_device_index());
+  Tensor out = torch::stable::new_empty(wav, {wav.size(0), out_len});
+  if (out.numel()) {
+    const int64_t length = wav.size(1);
+    check(aamd_resample_f64(dp(wav), dp(kernel), dpm(out), wav.size(0), length, length > 0 ? length : 1, (int32_t)orig,
+                            (int32_t)new_, (int32_t)width, out_len, current_stream(wav)));
+  }
+  return out;
+}
+Tensor fftconvolve_f64(Tensor x, Tensor y, std::optional<Tensor> x_row_of, std::optional<Tensor> y_row_of, int64_t rows,
+                       int64_t start, int64_t out_len) {
+  want_dev(x, ScalarType::Double, "x", 2); want_dev(y, ScalarType::Double, "y", 2);
+  same_device(x, y);
+  const int64_t *xm = nullptr, *ym = nullptr;
+  if (x_row_of.has_value()) { want_dev(*x_row_of, ScalarType::Long, "x_row_of", 1); STD_TORCH_CHECK(x_row_of->numel() == rows); xm = static_cast<const int64_t*>(x_row_of->data_ptr()); }
+  if (y_row_of.has_value()) { want_dev(*y_row_of, ScalarType::Long, "y_row_of", 1); STD_TORCH_CHECK(y_row_of->numel() == rows); ym = static_cast<const int64_t*>(y_row_of->data_ptr()); }
+  const torch::stable::accelerator::DeviceGuard guard(x.get_device_index());
+  Tensor out = torch::stable::new_empty(x, {rows, out_len});
+  if (out.numel())
+    check(aamd_fftconvolve_f64(dp(x), dp(y), dpm(out), rows, x.size(0), y.size(0), x.size(1), y.size(1), xm, ym, start, out_len,
+                               current_stream(x)));
+  return out;
+}
+
 // ---- torchaudio::_lfilter_core_loop on the CUDA key (lfilter.cpp:118-134, iir_cuda.cu:37-79) ------------------------
 //   padded_out[n][c][i + n_order - 1] = in[n][c][i] - sum_{j < n_order-1} a_flipped[c][j] * padded_out[n][c][i + j]
 // = the pure recursion y = IIR(in; a) with a = flip(a_flipped), b = (1, 0, ...), no clamp: aamd_lfilter_f32 runs it as a
@@ -345,6 +722,36 @@ STABLE_TORCH_LIBRARY(aamd, m) {
         "int tap_span) -> Tensor");
   m.def("lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, int n_stages, int clamp) -> Tensor");
   m.def("fftconvolve(Tensor x, Tensor y, Tensor? x_row_of, Tensor? y_row_of, int rows, int start, int out_len) -> Tensor");
+  // round 4: the rest of include/audio_amd.h
+  m.def("mel_spectrogram_lognorm(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, "
+        "Tensor band_weights, Tensor? lane_order, Tensor? table400, int n_fft, int hop, int n_frames, float scale, float gain, "
+        "Tensor? mean, Tensor? invstddev, int out_frames, int table_sig) -> Tensor");
+  m.def("mfcc_frag_build(Tensor dct_mat, int n_mels, int n_mfcc) -> Tensor");
+  m.def("mfcc_fused(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, Tensor band_weights, "
+        "Tensor? lane_order, Tensor? table400, Tensor dct_frag, Tensor(a!) group_max, int n_fft, int hop, int pad, bool center, "
+        "int pad_mode, int n_frames, float scale, int n_mfcc, float multiplier, float amin, float db_multiplier, float top_db, "
+        "int rows_per_group, int table_sig) -> Tensor");
+  m.def("istft(Tensor spec, Tensor window, Tensor twiddle, Tensor? inv_envelope, int n_fft, int hop, int pad, bool center, "
+        "int pad_mode, int length, float scale, bool adjoint) -> Tensor");
+  m.def("istft_f64(Tensor spec, Tensor window, Tensor twiddle, Tensor? inv_envelope, int n_fft, int hop, int pad, bool center, "
+        "int pad_mode, int length, float scale, bool adjoint) -> Tensor");
+  m.def("spectrogram_f64(Tensor wav, Tensor window, Tensor twiddle, int n_fft, int hop, int pad, bool center, int pad_mode, "
+        "int n_frames) -> Tensor");
+  m.def("phase_vocoder(Tensor spec, Tensor phase_advance, float rate, bool frame_major_out) -> Tensor");
+  m.def("griffinlim_update(Tensor rebuilt, Tensor(a!) tprev, Tensor magnitude, float momentum) -> Tensor");
+  m.def("mel_scale(Tensor spec, Tensor band_lo, Tensor band_width, Tensor band_weights) -> Tensor");
+  m.def("amplitude_to_db(Tensor x, float multiplier, float amin, float db_multiplier, Tensor(a!)? group_max, int group_size) -> Tensor");
+  m.def("amplitude_to_db_clamped(Tensor x, float multiplier, float amin, float db_multiplier, Tensor group_max, int group_size, "
+        "float top_db) -> Tensor");
+  m.def("db_clamp(Tensor x, Tensor group_max, int group_size, float top_db) -> Tensor");
+  m.def("spectrogram_grad(Tensor spec, Tensor dpower, float power) -> Tensor");
+  m.def("mel_spectrogram_grad(Tensor(a!) spec, Tensor dmel, Tensor band_lo, Tensor band_width, Tensor band_weights, float power) -> Tensor(a!)");
+  m.def("resample_sparse(Tensor wav, Tensor taps_compact, Tensor tap_lo, int orig, int new, int width, int out_len) -> Tensor");
+  m.def("kaldi_features(Tensor wav, Tensor window, Tensor twiddle, Tensor? band_lo, Tensor? band_width, Tensor? band_weights, "
+        "Tensor? noise, int n_frames, int[] opts, float[] fopts) -> Tensor");
+  m.def("lfilter_f64(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, int n_stages, int clamp) -> Tensor");
+  m.def("resample_f64(Tensor wav, Tensor kernel, int orig, int new, int width, int out_len) -> Tensor");
+  m.def("fftconvolve_f64(Tensor x, Tensor y, Tensor? x_row_of, Tensor? y_row_of, int rows, int start, int out_len) -> Tensor");
 }
 
 STABLE_TORCH_LIBRARY_IMPL(aamd, CUDA, m) {
@@ -355,6 +762,25 @@ STABLE_TORCH_LIBRARY_IMPL(aamd, CUDA, m) {
   m.impl("resample", TORCH_BOX(&resample));
   m.impl("lfilter", TORCH_BOX(&lfilter));
   m.impl("fftconvolve", TORCH_BOX(&fftconvolve));
+  m.impl("mel_spectrogram_lognorm", TORCH_BOX(&mel_spectrogram_lognorm));
+  m.impl("mfcc_frag_build", TORCH_BOX(&mfcc_frag_build));
+  m.impl("mfcc_fused", TORCH_BOX(&mfcc_fused));
+  m.impl("istft", TORCH_BOX(&istft));
+  m.impl("istft_f64", TORCH_BOX(&istft_f64));
+  m.impl("spectrogram_f64", TORCH_BOX(&spectrogram_f64));
+  m.impl("phase_vocoder", TORCH_BOX(&phase_vocoder));
+  m.impl("griffinlim_update", TORCH_BOX(&griffinlim_update));
+  m.impl("mel_scale", TORCH_BOX(&mel_scale));
+  m.impl("amplitude_to_db", TORCH_BOX(&amplitude_to_db));
+  m.impl("amplitude_to_db_clamped", TORCH_BOX(&amplitude_to_db_clamped));
+  m.impl("db_clamp", TORCH_BOX(&db_clamp));
+  m.impl("spectrogram_grad", TORCH_BOX(&spectrogram_grad));
+  m.impl("mel_spectrogram_grad", TORCH_BOX(&mel_spectrogram_grad));
+  m.impl("resample_sparse", TORCH_BOX(&resample_sparse));
+  m.impl("kaldi_features", TORCH_BOX(&kaldi_features));
+  m.impl("lfilter_f64", TORCH_BOX(&lfilter_f64));
+  m.impl("resample_f64", TORCH_BOX(&resample_f64));
+  m.impl("fftconvolve_f64", TORCH_BOX(&fftconvolve_f64));
 }
 
 // The reference's op.  libtorchaudio (when present) has already run

@@ -351,6 +351,12 @@ def _copy_desc(desc, **changes):
 
 def _istft_launch(spec_fm: Tensor, window_padded: Tensor, desc, adjoint: bool, inv_env: Optional[Tensor]) -> Tensor:
     """spec_fm: float32 (rows, T, n_freq * 2) interleaved complex -> (rows, desc.length) via aamd_istft_f32."""
+    ops = _ops()
+    if ops is not None and spec_fm.numel():
+        n_freq = desc.n_fft // 2 + 1
+        return ops.istft(spec_fm.view(desc.rows, desc.n_frames, n_freq, 2), window_padded, _twiddles(desc.n_fft, spec_fm.device),
+                         inv_env, desc.n_fft, desc.hop, desc.pad, bool(desc.center), desc.pad_mode, desc.length, desc.scale,
+                         bool(adjoint))
     out = torch.zeros((desc.rows, desc.length), dtype=torch.float32, device=spec_fm.device)
     if out.numel() and desc.n_frames:
         L = _lib.lib()
@@ -564,6 +570,10 @@ def _phase_vocoder_launch(spec: Tensor, rate: float, phase_advance: Tensor, fram
     else:
         out = torch.empty((rows, n_freq, n_out), dtype=torch.complex64, device=dev)
         o_row, o_f, o_t = out.stride()
+    ops = _ops()
+    if ops is not None and out.numel():
+        res = torch.view_as_complex(ops.phase_vocoder(torch.view_as_real(spec), pa, float(rate), bool(frame_major_out)))
+        return res.transpose(-1, -2) if frame_major_out else res
     if out.numel():
         i_row, i_f, i_t = spec.stride()
         d = _lib.VocoderDesc(rows, n_freq, n_in, n_out, i_row, i_f, i_t, o_row, o_f, o_t, float(rate))
@@ -646,6 +656,11 @@ def griffinlim(
             raise RuntimeError("audio_amd: griffinlim needs length consistent with the number of frames")
         if not rebuilt_fm.is_contiguous():
             rebuilt_fm = rebuilt_fm.contiguous()
+        ops = _ops()
+        if ops is not None:
+            cur = torch.view_as_complex(ops.griffinlim_update(torch.view_as_real(rebuilt_fm), torch.view_as_real(tprev), mag,
+                                                              float(momentum)))
+            continue
         _lib.check(L.aamd_griffinlim_update_f32(
             torch.view_as_real(rebuilt_fm).data_ptr(), torch.view_as_real(tprev).data_ptr(), mag.data_ptr(),
             torch.view_as_real(nxt).data_ptr(), mag.numel(), float(momentum), _lib.current_stream(dev)))
@@ -992,7 +1007,11 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
             state.frag, state.frag_key, state.frag_src = frag, key, weakref.ref(dct)
         n_tiles = int(L.aamd_mfcc_fused_tiles(C.byref(desc)))
         out = torch.empty((desc.rows, desc.n_frames, n_mfcc), dtype=torch.float32, device=dev)
-        gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
+        # ONE fill initialises the group maxima AND the arrival word of pass 0 (element n_groups; its start value is the bit
+        # pattern of -inf): without an exchange between the passes (no hook) the last workgroup of pass 0 compacts the fix-up
+        # list itself and pass 1 launches no list kernel
+        gbuf = torch.full((n_groups + 1,), float("-inf"), dtype=torch.float32, device=dev)
+        gmax = gbuf[:n_groups]
         if out.numel() == 0:
             # an empty shard still takes part in the exchange of the batch-global cut-off: the other ranks are waiting in the
             # same all-reduce (returning before the hook hung the job)
@@ -1002,8 +1021,10 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
         tile_min = torch.empty((n_tiles,), dtype=torch.float32, device=dev)
         count = torch.empty((1,), dtype=torch.int32, device=dev)
         tile_list = torch.empty((n_tiles,), dtype=torch.int32, device=dev)
+        merged = group_max_hook is None
         f = _lib.MfccFused(state.frag.data_ptr(), n_mfcc, 0, float(db[0]), float(db[1]), float(db[2]), float(top_db),
-                           gmax.data_ptr(), max(packed, 1), tile_min.data_ptr(), count.data_ptr(), tile_list.data_ptr())
+                           gmax.data_ptr(), max(packed, 1), tile_min.data_ptr(), count.data_ptr(), tile_list.data_ptr(),
+                           gbuf[n_groups:].data_ptr() if merged else None, -8388608)      # 0xff800000 = -inf as int32
         args = (x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),
                 C.byref(bands.struct), out.data_ptr(), C.byref(desc))
         _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))
@@ -1024,7 +1045,15 @@ def _mfcc(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, dct_mat: Tenso
     the all-reduce(MAX) a batch-global cut-off needs when the batch is sharded)."""
     lead = tuple(waveform.shape[:-1])
     dev = waveform.device
-    dct = dct_mat.to(device=dev, dtype=torch.float32).contiguous()
+    # F.create_dct returns a TRANSPOSED view (functional.py:667 `dct.t()`), so the module's buffer is not contiguous: a
+    # `.contiguous()` here was a copy launch per call AND a new tensor object per call -- which the fragment cache of the
+    # one-kernel path is keyed by, so the fragments were rebuilt every call too (two launches, ~10 us of the cfg4 step, found
+    # in the round-4 per-config rocprof).  The kernel-ready copy is cached per buffer (invalidated by in-place updates).
+    if dct_mat.device == dev and dct_mat.dtype == torch.float32 and dct_mat.is_contiguous():
+        dct = dct_mat
+    else:
+        dct = _tensor_cached(dct_mat, ("dct_f32", str(dev)),
+                             lambda: dct_mat.detach().to(device=dev, dtype=torch.float32).contiguous())
     n_mfcc = dct.shape[1]
     L = _lib.lib()
     if log_mels:
@@ -1096,6 +1125,10 @@ def mel_scale(specgram: Tensor, fb: Tensor) -> Tensor:
     if not fm.is_contiguous():
         fm = fm.contiguous()
     bands = _mel_bands(fb, specgram.device)
+    ops = _ops()
+    if ops is not None and fm.numel():
+        out = ops.mel_scale(fm, bands.lo, bands.width, bands.weights)
+        return out.view(tuple(shape[:-2]) + (T, bands.n_mels)).transpose(-1, -2)
     out = torch.empty((fm.shape[0], T, bands.n_mels), dtype=torch.float32, device=specgram.device)
     if out.numel():
         L = _lib.lib()

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define AAMD_ABI_VERSION 4
+#define AAMD_ABI_VERSION 5
 
 enum {
   AAMD_OK = 0,
@@ -189,6 +189,11 @@ typedef struct aamd_mfcc_fused {
   int32_t* fix_count;      /* device int32: pass 0 resets it, pass 1 leaves the number of tiles it redoes here */
   int32_t* tile_list;      /* device int32[aamd_mfcc_fused_tiles(desc)]: scratch of pass 1 -- the tiles under the cut-off,
                               compacted, so that the fix-up launch deals them out evenly however they cluster by clip */
+  int32_t* arrive;         /* optional (ABI v5), NULL = off: device int32 holding `arrive_base` before pass 0.  When set, the
+                              workgroup of pass 0 that finishes last compacts tile_list / fix_count itself and pass 1 launches
+                              no list kernel: one launch less per call.  Only valid when group_max is NOT changed between the
+                              passes (no all-reduce: one rank); the word is back at arrive_base when pass 0 ends */
+  int32_t arrive_base;     /* any value (e.g. the bit pattern of -inf, so that ONE fill initialises group_max and this word) */
 } aamd_mfcc_fused;
 int32_t aamd_mfcc_frag_floats(void);
 int64_t aamd_mfcc_fused_tiles(const aamd_stft_desc* desc);

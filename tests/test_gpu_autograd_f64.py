@@ -265,12 +265,12 @@ def test_inverse_spectrogram_gradcheck_other_shapes(kw):
     onesided, center = kw.get("onesided", True), kw.get("center", True)
     x = _noise(2, 200, seed=4).double()
     wfn = torch.hann_window if center else torch.hamming_window          # (centre off: the Hann window's zero end fails NOLA)
-    w = wfn(n_fft, dtype=torch.float64)
+    inv = T.InverseSpectrogram(window_fn=wfn, **kw).to(dtype=torch.float64, device="cuda")
+    w = inv.window.detach().cpu()            # the module's buffer: float32 values widened (as the reference's .to(float64) does)
     spec = torch.stft(x, n_fft, hop, n_fft, w, center=center, pad_mode="reflect", normalized=kw.get("normalized", False),
                       onesided=onesided, return_complex=True)
     if not onesided:
         spec = spec + 0.05 * torch.randn(spec.shape, dtype=torch.complex128, generator=torch.Generator().manual_seed(1))
-    inv = T.InverseSpectrogram(window_fn=wfn, **kw).to(dtype=torch.float64, device="cuda")
     ref = torch.istft(spec, n_fft, hop, n_fft, w, center=center, normalized=kw.get("normalized", False), onesided=onesided,
                       length=length)
     s_dev = spec.cuda().requires_grad_()

@@ -684,7 +684,9 @@ def test_mfcc_path_choice_is_taken_once_per_module():
         rep = m.fused_report()
         assert rep["decided"] == "fused" and rep["decided_share"] == 0.0 and rep["path"] == "fused"
         assert torch.equal(y0, one(loud))
-        y1 = m(padded)                          # the decision stands: still one kernel, bit-equal to fused=True
+        frag = m._fused_state.frag              # the DCT operand fragments are built ONCE per module: the buffer is a
+        y1 = m(padded)                          # transposed view, and its kernel-ready copy must not be remade per call
+        assert m._fused_state.frag is frag
         assert m.fused_report()["path"] == "fused" and m.fused_report()["redone_share"] > 0.5
         assert torch.equal(y1, one(padded))
         m2 = T.MFCC(**kw0).cuda()               # a module whose first batch is zero padded decides the other way ...
