@@ -39,7 +39,7 @@ class MfccFused(C.Structure):
     _fields_ = [("dct_frag", C.c_void_p), ("n_mfcc", C.c_int32), ("pass_", C.c_int32), ("multiplier", C.c_float),
                 ("amin", C.c_float), ("db_multiplier", C.c_float), ("top_db", C.c_float), ("group_max", C.c_void_p),
                 ("rows_per_group", C.c_int64), ("tile_min", C.c_void_p), ("fix_count", C.c_void_p),
-                ("tile_list", C.c_void_p), ("arrive", C.c_void_p), ("arrive_base", C.c_int32)]
+                ("tile_list", C.c_void_p)]
 
 
 class ResampleBands(C.Structure):
@@ -152,7 +152,7 @@ def lib():
 
 
 POLICY_FORCE_GENERIC, POLICY_MEL400_WIDE, POLICY_ISTFT_ATOMIC, POLICY_RESAMPLE_FP32 = 1, 2, 4, 8
-POLICY_FFTCONV_NO_FDL, POLICY_FFTCONV_FDL = 16, 32
+POLICY_FFTCONV_NO_FDL, POLICY_FFTCONV_FDL, POLICY_FFTCONV_COMPLEX = 16, 32, 64
 
 
 class kernel_policy:

@@ -16,6 +16,7 @@
 #include "f64_paths.h"
 #include "fftconv.h"
 #include "fftconv_os.h"
+#include "fftconv_fdr.h"
 #include "istft.h"
 #include "kaldi_generic.h"
 #include "vocoder.h"
@@ -513,11 +514,7 @@ int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twid
   epi.group_max = f->group_max; epi.rows_per_group = f->rows_per_group;
   epi.dct_frag = f->dct_frag; epi.n_mfcc = f->n_mfcc; epi.top_db = f->top_db; epi.tile_min = f->tile_min;
   epi.fix_count = f->fix_count; epi.fixup = f->pass; epi.fix_list = f->tile_list;
-  if (f->arrive != nullptr) {        // pass 0 compacts the fix-up list itself (its last workgroup): no list kernel in pass 1
-    AAMD_CHECK_ARG(f->tile_list != nullptr, "the fused MFCC with `arrive` needs tile_list in pass 0 too");
-    epi.arrive = f->arrive; epi.arrive_base = f->arrive_base;
-  }
-  if (f->pass == 1 && f->arrive == nullptr) {
+  if (f->pass == 1) {
     // compact the tiles under their group's cut-off (known now: the caller reduced group_max over ranks between the passes)
     AAMD_CHECK_ARG(f->fix_count && f->tile_list, "pass 1 of the fused MFCC needs fix_count and tile_list");
     const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
@@ -1417,6 +1414,12 @@ static bool fftconv_pick_fdl(int64_t rows, int64_t taps, int64_t out_len, fco::F
   return cheaper || ((policy() & AAMD_POLICY_FFTCONV_FDL) && f.n_blocks >= 2);
 }
 
+// the real-block delay line (fftconv_fdr.h): 8193 .. 24576 taps, unless the policy asks for the complex-block kernels
+static bool fftconv_pick_fdr(int64_t rows, int64_t taps, int64_t out_len, fdr::Geom& g) {
+  if (policy() & (AAMD_POLICY_FFTCONV_NO_FDL | AAMD_POLICY_FFTCONV_FDL | AAMD_POLICY_FFTCONV_COMPLEX)) return false;
+  return fdr::plan(rows, taps, out_len, dev_props().cu_count, g);
+}
+
 int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_rows, int64_t nx, int64_t ny) {
   (void)rows;
   const bool swap = ny > nx;
@@ -1434,6 +1437,8 @@ int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_r
 int aamd_fftconvolve_plan(int64_t rows, int64_t nx, int64_t ny, int64_t out_len) {
   const int64_t taps = ny > nx ? nx : ny;
   if (!fftconv_use_fft(taps)) return 0;
+  fdr::Geom fg{};
+  if (fftconv_pick_fdr(rows, taps, out_len, fg)) return 3;
   fco::FdlGeom f{};
   return fftconv_pick_fdl(rows, taps, out_len, f) ? 2 : 1;
 }
@@ -1470,6 +1475,30 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fco::overlap_save_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(fco::twiddle_kernel, dim3(fco::kN / 256), dim3(256), 0, s, tw);
+    fdr::Geom fg{};
+    fg.rows = rows; fg.nx = nxa; fg.ny = nya; fg.start = start; fg.out_len = out_len;
+    if (fftconv_pick_fdr(rows, nya, out_len, fg)) {
+      // real blocks of 16384 samples as 8192-point complex FFTs, the delay line in registers (fftconv_fdr.h).  The tap spectra
+      // (8192 complex per partition) fit the space the workspace reserves for the complex-block plans (16384 per partition).
+      const size_t lds_r = (size_t)fdr::kLdsComplex * sizeof(fco::C32);
+      AAMD_CHECK_ARG(tap_rows * fg.n_part < (1ll << 31), "too many tap rows");
+      AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fdr::spectrum_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+      hipLaunchKernelGGL(fdr::spectrum_kernel, dim3((unsigned)(tap_rows * fg.n_part)), dim3(fdr::kThreads), lds_r, s, nya,
+                         fg.n_part, ya, tw, H);
+      int64_t blocks = dev_props().cu_count;
+      if (blocks > rows * fg.segs) blocks = rows * fg.segs;
+#define AAMD_FDR(NP)                                                                                          \
+      do {                                                                                                    \
+        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fdr::delay_line_kernel<NP>),               \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                \
+        hipLaunchKernelGGL(fdr::delay_line_kernel<NP>, dim3((unsigned)blocks), dim3(fdr::kThreads), lds_r, s, \
+                           fg, xa, tw, H, xmap, ymap, out);                                                   \
+      } while (0)
+      if (fg.n_part == 2) AAMD_FDR(2); else AAMD_FDR(3);
+#undef AAMD_FDR
+      return launch_check();
+    }
     fco::FdlGeom f{};
     f.rows = rows; f.nx = nxa; f.ny = nya; f.start = start; f.out_len = out_len;
     if (fftconv_pick_fdl(rows, nya, out_len, f)) {

@@ -1,0 +1,502 @@
+// F.fftconvolve for 8193 .. 24576 taps (0.17 .. 0.5 s impulse responses at 48 kHz; BASELINE config 5b): the frequency-domain
+// delay line on REAL blocks, the whole state of a row on one CU (functional/functional.py:2252-2258 computes
+// irfft(rfft(x) * rfft(y)); the contract is the linear convolution, so block-wise FFTs of another length are free).
+//
+// What it replaces (fco::overlap_save_fdl_kernel, fftconv_os.h): a 16384-point COMPLEX FFT in LDS (two real blocks per
+// transform, 150 of 160 KB), 512 threads at 256 registers = 2 waves per SIMD -- a wave64 VALU instruction issues every ~4
+// cycles there (profiles/r03_zz_valu_issue.txt) -- and a spectrum ring in global memory (256 KB of ring + 384 KB of tap
+// spectra through L2 per step and CU for 128 KB of algorithmic I/O).  VERDICT r3: 0.138 of the HBM roofline.
+//
+// Formulation (MI355X: 160 KB LDS, 512 KB of registers per CU, 4 waves per SIMD at <= 128 registers):
+//   * one step = ONE real block of N = 16384 input samples (hop B = 8192) as an M = 8192-point complex FFT of
+//     z[n] = s[2n] + i s[2n+1]; the spectrum of the real block follows from the split  Z[k] = E + T, Z[M-k] = conj(E - T),
+//     E = (C[k] + conj C[M-k]) / 2, T = -i W_N^k (C[k] - conj C[M-k]) / 2 (and back by the merge) -- 68 KB of LDS;
+//   * 1024 threads; thread t owns 8 spectrum bins for the whole launch, so the delay line Z_(j-1), Z_(j-2) is 2 x 16 REGISTERS
+//     per thread: no ring in memory, no ring in LDS;  Y_j = H_0 Z_j + H_1 Z_(j-1) + H_2 Z_(j-2), tap spectra H_p (8192-tap
+//     partitions) read from L2 in the thread-owned layout (coalesced, half the bytes per output of the complex kernel);
+//   * radices (8, 8, 8, 8, 2), decimation in frequency forward / mirrored decimation in time inverse, no reordering pass:
+//     the first pass takes its 8 inputs per thread straight from global memory (n = t + 1024 r: coalesced 8-byte loads), the
+//     passes of length 128 and 16 stay inside a wave's own 512 elements (no workgroup barrier), the final radix-2 is a DPP
+//     exchange between neighbouring lanes; the spectrum sits digit-reversed in LDS: frequency k = r1 + 8 r2 + 64 r3 + 512 r4
+//     + 4096 r5 at position 1024 r1 + 128 r2 + 16 r3 + 2 r4 + r5;
+//   * in that order bins k and k + 4096 are neighbours and so are their mirror bins 4096 - k and 8192 - k: a thread reads the
+//     two pairs of its "quad" with two 16-byte LDS reads, splits, multiplies, merges and writes them back in place.
+// Everything is AAMD_HD and replayed on the CPU by tests/cpu_sim (sim_fftconv_fdr).
+#pragma once
+#include "hd.h"
+#include "fftconv_os.h"      // fco::C32, cmulc, dft4, opaque, wave_sync, block geometry helpers
+
+namespace aamd {
+namespace fdr {
+
+using fco::C32;
+constexpr int kM = 8192;                   // complex FFT length
+constexpr int kN = 16384;                  // real samples per block
+constexpr int kHop = 8192;                 // outputs per block = taps per partition
+constexpr int kThreads = 1024;
+constexpr int kMaxParts = 3;               // Z_j in flight + two delayed spectra in registers
+AAMD_HD int pad(int i) { return i + ((i >> 5) << 1); }            // 2 complex per 32: see the bank notes at each pass
+constexpr int kLdsData = kM + (kM >> 5) * 2;                      // 8704 complex = 69 632 B
+// twiddle tables behind the data (W = W_M = e^(-2 pi i / 8192)):
+//   tl[a], a < 128: W^(64 a);  tl[128 + b], b < 64: W^b;  kTw3 + 16 (k - 1) + j: W_128^(j k), j < 16;  kTw4 + 2 (k - 1) + j: W_16^(j k)
+constexpr int kTw3 = 192, kTw4 = kTw3 + 7 * 16, kTwEnd = kTw4 + 7 * 2;
+constexpr int kLdsComplex = kLdsData + kTwEnd;                    // 8 924 complex = 71 392 B
+
+// tw16k: the W_16384^m table of fco::twiddle_kernel (m < 16384); W_M^e = tw16k[2 e]
+AAMD_HD void twiddle_tables(int tid, const C32* tw16k, C32* tl) {
+  if (tid < 128) tl[tid] = tw16k[2 * 64 * tid];
+  else if (tid < 192) tl[tid] = tw16k[2 * (tid - 128)];
+  else if (tid < 192 + 112) { const int u = tid - 192, k = u / 16 + 1, j = u % 16; tl[kTw3 + u] = tw16k[2 * 64 * j * k]; }
+  else if (tid < 192 + 112 + 14) { const int u = tid - 192 - 112, k = u / 2 + 1, j = u % 2; tl[kTw4 + u] = tw16k[2 * 512 * j * k]; }
+}
+AAMD_HD C32 tw_at(const C32* tl, int e) { return cmul(tl[e >> 6], tl[128 + (e & 63)]); }
+
+// 8-point DFT in registers, natural order in and out; forward (e^-) or inverse (e^+, unnormalised)
+template <bool inv>
+AAMD_HD void dft8(C32 (&v)[8]) {
+  constexpr float r2 = 0.70710678118654752f;
+  fco::dft4<inv>(v[0], v[2], v[4], v[6]);      // E[k] -> v[0], v[2], v[4], v[6]
+  fco::dft4<inv>(v[1], v[3], v[5], v[7]);      // O[k] -> v[1], v[3], v[5], v[7]
+  // O[k] *= W8^k (forward: 1, (1 - i) / sqrt2, -i, (-1 - i) / sqrt2; inverse: conjugates)
+  const C32 o1 = v[3], o2 = v[5], o3 = v[7];
+  if (!inv) {
+    v[3] = C32{(o1.x + o1.y) * r2, (o1.y - o1.x) * r2};
+    v[5] = C32{o2.y, -o2.x};
+    v[7] = C32{(o3.y - o3.x) * r2, -(o3.x + o3.y) * r2};
+  } else {
+    v[3] = C32{(o1.x - o1.y) * r2, (o1.y + o1.x) * r2};
+    v[5] = C32{-o2.y, o2.x};
+    v[7] = C32{-(o3.x + o3.y) * r2, (o3.x - o3.y) * r2};
+  }
+  // X[k] = E[k] + O'[k], X[k + 4] = E[k] - O'[k]
+  const C32 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], p0 = v[1], p1 = v[3], p2 = v[5], p3 = v[7];
+  v[0] = cadd(e0, p0); v[4] = csub(e0, p0);
+  v[1] = cadd(e1, p1); v[5] = csub(e1, p1);
+  v[2] = cadd(e2, p2); v[6] = csub(e2, p2);
+  v[3] = cadd(e3, p3); v[7] = csub(e3, p3);
+}
+
+// v[k] *= w^k (or conj) for k = 1 .. 7, w = W_M^e with 4 e < M: three look-ups, products of depth <= 2
+template <bool conj_w>
+AAMD_HD void mul_twiddles8(C32 (&v)[8], const C32* tl, int e) {
+  const C32 w1 = tw_at(tl, e), w2 = tw_at(tl, 2 * e), w4 = tw_at(tl, 4 * e);
+  const C32 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+  v[1] = fco::cmulc<conj_w>(v[1], w1); v[2] = fco::cmulc<conj_w>(v[2], w2); v[3] = fco::cmulc<conj_w>(v[3], w3);
+  v[4] = fco::cmulc<conj_w>(v[4], w4); v[5] = fco::cmulc<conj_w>(v[5], w5); v[6] = fco::cmulc<conj_w>(v[6], w6);
+  v[7] = fco::cmulc<conj_w>(v[7], w7);
+}
+
+// ---- pass 1 (length 8192, m = 1024): thread tid owns elements tid + 1024 r -- what a coalesced load of the block gives it ----
+AAMD_HD void first_pass_from_regs(int tid, C32 (&v)[8], C32* lds, const C32* tl) {
+  dft8<false>(v);
+  tid = fco::opaque(tid);
+  mul_twiddles8<false>(v, tl, tid);
+  C32* cell = lds + pad(tid);                  // pad(tid + 1024 r) = pad(tid) + 1088 r; consecutive lanes, consecutive cells
+#pragma unroll
+  for (int r = 0; r < 8; ++r) cell[1088 * r] = v[r];
+}
+AAMD_HD void last_pass_to_regs(int tid, const C32* lds, const C32* tl, C32 (&v)[8]) {
+  tid = fco::opaque(tid);
+  const C32* cell = lds + pad(tid);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = cell[1088 * r];
+  mul_twiddles8<true>(v, tl, tid);
+  dft8<true>(v);
+}
+
+// ---- pass 2 (length 1024, m = 128): butterfly j of block blk owns 1024 blk + j + 128 r; crosses waves (two per block half) ----
+template <bool inv>
+AAMD_HD void pass_m128(int tid, C32* lds, const C32* tl) {
+  tid = fco::opaque(tid);
+  const int blk = tid >> 7, j = tid & 127;
+  C32* cell = lds + pad(1024 * blk + j);       // pad(base + 128 r) = pad(base) + 136 r; lanes read consecutive cells
+  C32 v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = cell[136 * r];
+  if (inv) mul_twiddles8<true>(v, tl, 8 * j);  // W_1024^(j k) = W_M^(8 j k)
+  dft8<inv>(v);
+  if (!inv) mul_twiddles8<false>(v, tl, 8 * j);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) cell[136 * r] = v[r];
+}
+
+// ---- pass 3 (length 128, m = 16): 128 blk + j + 16 r, inside the wave's own 512 elements ----
+template <bool inv>
+AAMD_HD void pass_m16(int tid, C32* lds, const C32* tl) {
+  tid = fco::opaque(tid);
+  const int blk = tid >> 4, j = tid & 15;
+  C32* cell = lds + pad(128 * blk + j);        // offsets of r: 16 r + 2 (r >> 1)  (j < 16: the run of 32 changes every second r)
+  const C32* tab = tl + kTw3 + j;
+  C32 v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = cell[16 * r + 2 * (r >> 1)];
+  if (inv) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = fco::cmulc<true>(v[k], tab[16 * (k - 1)]);
+  }
+  dft8<inv>(v);
+  if (!inv) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = fco::cmulc<false>(v[k], tab[16 * (k - 1)]);
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) cell[16 * r + 2 * (r >> 1)] = v[r];
+}
+
+// ---- pass 4 (length 16, m = 2) + the final radix-2 (length 2): thread (blk, j) owns 16 blk + j + 2 r.  The radix-2 pairs
+// positions (2 q, 2 q + 1) = output r of lane j = 0 with output r of lane j = 1: a neighbour exchange (DPP on the device; the
+// CPU replay hands over the neighbour's array).  Forward: o = twiddled DFT-8 outputs; lane 0 keeps o0 + o1, lane 1 o0 - o1. ----
+AAMD_HD void pass_m2_fwd_a(int tid, const C32* lds, const C32* tl, C32 (&o)[8]) {
+  tid = fco::opaque(tid);
+  const int blk = tid >> 1, j = tid & 1;
+  const C32* cell = lds + pad(16 * blk + j);   // 16 blk + j + 2 r stays inside one run of 32: offsets 2 r
+#pragma unroll
+  for (int r = 0; r < 8; ++r) o[r] = cell[2 * r];
+  dft8<false>(o);
+  const C32* tab = tl + kTw4 + j;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) o[k] = fco::cmulc<false>(o[k], tab[2 * (k - 1)]);
+}
+AAMD_HD void pass_m2_fwd_b(int tid, const C32 (&o)[8], const C32 (&nb)[8], C32* lds) {
+  tid = fco::opaque(tid);
+  const int blk = tid >> 1, j = tid & 1;
+  C32* cell = lds + pad(16 * blk + j);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) cell[2 * r] = j ? csub(nb[r], o[r]) : cadd(o[r], nb[r]);
+}
+// inverse: x = the values at 16 blk + j + 2 r; lane 0 forms x0 + x1, lane 1 x0 - x1, then the inverse radix-8 pass
+AAMD_HD void pass_m2_inv_a(int tid, const C32* lds, C32 (&x)[8]) {
+  tid = fco::opaque(tid);
+  const C32* cell = lds + pad(16 * (tid >> 1) + (tid & 1));
+#pragma unroll
+  for (int r = 0; r < 8; ++r) x[r] = cell[2 * r];
+}
+AAMD_HD void pass_m2_inv_b(int tid, const C32 (&x)[8], const C32 (&nb)[8], C32* lds, const C32* tl) {
+  tid = fco::opaque(tid);
+  const int blk = tid >> 1, j = tid & 1;
+  C32 v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = j ? csub(nb[r], x[r]) : cadd(x[r], nb[r]);
+  const C32* tab = tl + kTw4 + j;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) v[k] = fco::cmulc<true>(v[k], tab[2 * (k - 1)]);
+  dft8<true>(v);
+  C32* cell = lds + pad(16 * blk + j);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) cell[2 * r] = v[r];
+}
+
+// ---- the middle step: split, delay line, merge ------------------------------------------------------------------------
+// Position of frequency k (< 8192) in the digit-reversed spectrum.
+AAMD_HD int rev_pos(int k) {
+  return ((k & 7) << 10) + (((k >> 3) & 7) << 7) + (((k >> 6) & 7) << 4) + (((k >> 9) & 7) << 1) + (k >> 12);
+}
+// Thread t owns two QUADS s = 0, 1: q = 8 (t >> 1) + 2 (t & 1) + s, i.e. the bins k, k + 4096 (positions 2 q, 2 q + 1) with
+// k = k_of_q(q) < 2048, and their mirror bins 4096 - k, 8192 - k (positions 2 q', 2 q' + 1).  Thread 0's quad 0 is the one
+// exception: k = 0 -- bins 0 and 4096 mirror themselves (DC / Nyquist of the real block, and the bin M / 2) -- and it also
+// takes the pair (2048, 6144) that no k < 2048 mirrors (positions 8, 9).
+AAMD_HD int k_of_q(int q) { return (q >> 9) + 8 * ((q >> 6) & 7) + 64 * ((q >> 3) & 7) + 512 * (q & 7); }
+struct MidConst {
+  int a0, a1[2];         // padded LDS index of position 2 q of quad 0 (quad 1: + 2, same run of 32) and of position 2 q' of both
+  C32 w0;                // W_N^k of quad 0 (the pair (k + 4096, 4096 - k) uses -i w); quad 1 has k + 512: w0 W_N^512, formed
+                         // per step (4 instructions) instead of held (2 registers: the 128 of four waves per SIMD are all in use)
+  AAMD_HD int a0s(int s) const { return a0 + 2 * s; }
+  AAMD_HD C32 w(int s, int tid) const {
+    const C32 c = C32{0.98078528040323043f, -0.19509032201612825f};       // W_16384^512 = e^(-i pi / 16)
+    if (s == 0) return w0;
+    return tid == 0 ? c : cmul(w0, c);                                    // (thread 0 holds W^2048 of its extra pair in w0)
+  }
+};
+AAMD_HD void mid_init(int tid, const C32* tw16k, MidConst& mc) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int q = 8 * (tid >> 1) + 2 * (tid & 1) + s;
+    const int k = k_of_q(q);
+    if (s == 0) mc.a0 = pad(2 * q);
+    const bool special = (tid == 0 && s == 0);
+    mc.a1[s] = pad(special ? 8 : rev_pos(4096 - k));
+    if (s == 0) mc.w0 = tw16k[special ? 2048 : k];
+  }
+}
+// un-halved split of the pair (C[k], C[M - k]) with w = W_N^k:  zk = 2 Z[k], zm = 2 Z[M - k]
+AAMD_HD void split_pair(C32 ck, C32 cm, C32 w, C32& zk, C32& zm) {
+  const C32 e = C32{ck.x + cm.x, ck.y - cm.y};          // C[k] + conj C[M-k]
+  const C32 d = C32{ck.x - cm.x, ck.y + cm.y};          // C[k] - conj C[M-k]
+  const C32 wd = cmul(w, d);
+  const C32 t = C32{wd.y, -wd.x};                       // -i w d
+  zk = cadd(e, t);
+  zm = C32{e.x - t.x, -(e.y - t.y)};                    // conj(e - t)
+}
+// un-halved merge: (Y[k], Y[M - k]) -> 2 C'[k], 2 C'[M - k]
+AAMD_HD void merge_pair(C32 yk, C32 ym, C32 w, C32& ck, C32& cm) {
+  const C32 e = C32{yk.x + ym.x, yk.y - ym.y};
+  const C32 t = C32{yk.x - ym.x, yk.y + ym.y};
+  const C32 wt = fco::cmulc<true>(t, w);                // t conj(w)
+  const C32 d = C32{-wt.y, wt.x};                       // i conj(w) t
+  ck = cadd(e, d);
+  cm = C32{e.x - d.x, -(e.y - d.y)};
+}
+// the thread's 8 spectrum bins of the block in LDS -> z[0 .. 7] (twice the real block's spectrum):
+//   z[4 s + 0] = Z[k], + 1: Z[k + 4096], + 2: Z[4096 - k], + 3: Z[8192 - k]
+//   thread 0, s = 0: z[0] = (Z[0], Z[8192]) (both real), z[1] = Z[4096], z[2] = Z[2048], z[3] = Z[6144]
+AAMD_HD void mid_split(int tid, const C32* lds, const MidConst& mc, C32 (&z)[8]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const C32 c0 = lds[mc.a0s(s)], c1 = lds[mc.a0s(s) + 1], c2 = lds[mc.a1[s]], c3 = lds[mc.a1[s] + 1];
+    if (tid == 0 && s == 0) {
+      z[0] = C32{2.0f * (c0.x + c0.y), 2.0f * (c0.x - c0.y)};
+      z[1] = C32{2.0f * c1.x, -2.0f * c1.y};
+      split_pair(c2, c3, mc.w0, z[2], z[3]);
+    } else {
+      const C32 w = mc.w(s, tid);
+      split_pair(c0, c3, w, z[4 * s], z[4 * s + 3]);
+      split_pair(c1, c2, C32{w.y, -w.x}, z[4 * s + 1], z[4 * s + 2]);     // -i w = W_N^(k + 4096)
+    }
+  }
+}
+AAMD_HD void mid_merge(int tid, const C32 (&y)[8], const MidConst& mc, C32* lds) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    C32 c0, c1, c2, c3;
+    if (tid == 0 && s == 0) {
+      c0 = C32{y[0].x + y[0].y, y[0].x - y[0].y};
+      c1 = C32{2.0f * y[1].x, -2.0f * y[1].y};
+      merge_pair(y[2], y[3], mc.w0, c2, c3);
+    } else {
+      const C32 w = mc.w(s, tid);
+      merge_pair(y[4 * s], y[4 * s + 3], w, c0, c3);
+      merge_pair(y[4 * s + 1], y[4 * s + 2], C32{w.y, -w.x}, c1, c2);
+    }
+    lds[mc.a0s(s)] = c0; lds[mc.a0s(s) + 1] = c1; lds[mc.a1[s]] = c2; lds[mc.a1[s] + 1] = c3;
+  }
+}
+// acc += h * z bin by bin (complex), except thread 0's slot 0 = two REAL bins packed into one complex number
+AAMD_HD void mid_mac(int tid, const C32 (&h)[8], const C32 (&z)[8], C32 (&acc)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i == 0 && tid == 0) {
+      acc[0].x += h[0].x * z[0].x;
+      acc[0].y += h[0].y * z[0].y;
+    } else {
+      acc[i].x += z[i].x * h[i].x - z[i].y * h[i].y;
+      acc[i].y += z[i].x * h[i].y + z[i].y * h[i].x;
+    }
+  }
+}
+// tap spectra in the thread-owned layout: complex index ((p * 8 + i) * 1024 + tid) of a y row's table
+AAMD_HD int64_t h_index(int p, int i, int tid) { return ((int64_t)p * 8 + i) * kThreads + tid; }
+constexpr int64_t kHPerPart = 8 * kThreads;            // complex numbers per partition (= 8192)
+
+// ---- geometry --------------------------------------------------------------------------------------------------------
+struct Geom {
+  int64_t rows, nx, ny, start, out_len;
+  int n_part;              // ceil(ny / kHop): 2 or 3
+  int segs;                // segments per row (one work item each)
+  int64_t n_blocks;        // ceil(out_len / kHop)
+  int64_t seg_blocks;      // blocks per segment (the last may be shorter)
+};
+// cost = steps on the busiest workgroup (a forward-only warm-up step counts half); returns false when the shape is not served
+AAMD_HD bool plan(int64_t rows, int64_t ny, int64_t out_len, int cu_count, Geom& g) {
+  g.n_part = (int)((ny + kHop - 1) / kHop);
+  g.n_blocks = (out_len + kHop - 1) / kHop;
+  g.segs = 1;
+  g.seg_blocks = g.n_blocks;
+  if (g.n_part < 2 || g.n_part > kMaxParts || rows < 1 || g.n_blocks < 1 || cu_count < 1) return false;
+  int64_t best = -1;
+  for (int segs = 1; segs <= 1024 && segs <= g.n_blocks; ++segs) {
+    const int64_t sb = (g.n_blocks + segs - 1) / segs;
+    const int64_t used = (g.n_blocks + sb - 1) / sb;
+    const int64_t cost = ((rows * used + cu_count - 1) / cu_count) * (2 * sb + (g.n_part - 1));
+    if (best < 0 || cost < best) { best = cost; g.segs = (int)used; g.seg_blocks = sb; }
+  }
+  return true;
+}
+// block j covers outputs [(j) kHop, (j + 1) kHop) of the slice... as in fco: its input segment starts at
+AAMD_HD int64_t seg_start(const Geom& g, int64_t j) { return g.start + (j - 1) * (int64_t)kHop; }
+
+// inputs of block j: z[n] = (x[s0 + 2 n], x[s0 + 2 n + 1]) for n = tid + 1024 r; zeros outside [0, nx)
+AAMD_HD void load_block(int tid, const Geom& g, const float* xr, int64_t j, bool vec_ok, C32 (&v)[8]) {
+  const int64_t s0 = seg_start(g, j);
+  const unsigned lane = (unsigned)fco::opaque(tid);
+  if (vec_ok && s0 >= 0 && s0 + kN <= g.nx) {            // interior block on an 8-byte aligned row offset (uniform branch)
+    const C32* p = reinterpret_cast<const C32*>(xr + s0);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = (p + 1024 * r)[lane];
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int64_t i = s0 + 2 * ((int64_t)lane + 1024 * r);
+    v[r].x = (i >= 0 && i < g.nx) ? xr[i] : 0.0f;
+    v[r].y = (i + 1 >= 0 && i + 1 < g.nx) ? xr[i + 1] : 0.0f;
+  }
+}
+// outputs of block j: sample 2 n (+ 1) of the block, n >= 4096, is output (j - 1) kHop + 2 n (+ 1) of the slice
+AAMD_HD void store_block(int tid, const Geom& g, const C32 (&v)[8], int64_t j, int64_t j_hi, bool vec_ok, float* out_row) {
+  if (j >= j_hi) return;
+  const unsigned lane = (unsigned)fco::opaque(tid);
+  const int64_t o0 = (j - 1) * (int64_t)kHop;
+  if (vec_ok && o0 + kN <= g.out_len) {
+    C32* p = reinterpret_cast<C32*>(out_row + o0);
+#pragma unroll
+    for (int r = 4; r < 8; ++r) (p + 1024 * r)[lane] = v[r];
+    return;
+  }
+#pragma unroll
+  for (int r = 4; r < 8; ++r) {
+    const int64_t o = o0 + 2 * ((int64_t)lane + 1024 * r);
+    if (o < g.out_len) out_row[o] = v[r].x;
+    if (o + 1 < g.out_len) out_row[o + 1] = v[r].y;
+  }
+}
+// taps of partition p of one y row as the packed real block (imaginary lane = odd samples)
+AAMD_HD void load_taps(int tid, int64_t ny, const float* yr, int p, C32 (&v)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int n = tid + 1024 * r;                        // block-local sample 2 n, 2 n + 1; taps occupy samples [0, kHop)
+    const int64_t k = (int64_t)p * kHop + 2 * n;
+    v[r].x = (2 * n < kHop && k < ny) ? yr[k] : 0.0f;
+    v[r].y = (2 * n + 1 < kHop && k + 1 < ny) ? yr[k + 1] : 0.0f;
+  }
+}
+constexpr float kSpectrumScale = 1.0f / (8.0f * (float)kM);      // un-halved split (2) x un-halved merge (2) x split of H (2) x M
+
+#if defined(__HIPCC__)
+// neighbour exchange (lane ^ 1) of 8 complex registers: DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ void swap_neighbour(const C32 (&o)[8], C32 (&nb)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    nb[r].x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o[r].x), 0xB1, 0xf, 0xf, false));
+    nb[r].y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o[r].y), 0xB1, 0xf, 0xf, false));
+  }
+}
+// forward transform of the block in v (registers) to the digit-reversed spectrum in LDS; ends with a workgroup barrier
+__device__ __forceinline__ void forward_block(int tid, C32 (&v)[8], C32* lds, const C32* tl) {
+  first_pass_from_regs(tid, v, lds, tl);
+  __syncthreads();
+  pass_m128<false>(tid, lds, tl);
+  __syncthreads();
+  pass_m16<false>(tid, lds, tl);
+  fco::wave_sync();
+  C32 o[8], nb[8];
+  pass_m2_fwd_a(tid, lds, tl, o);
+  swap_neighbour(o, nb);
+  pass_m2_fwd_b(tid, o, nb, lds);
+  __syncthreads();
+}
+// ... and back: LDS spectrum (digit-reversed) -> the block's samples in v
+__device__ __forceinline__ void inverse_block(int tid, C32* lds, const C32* tl, C32 (&v)[8]) {
+  C32 x[8], nb[8];
+  pass_m2_inv_a(tid, lds, x);
+  swap_neighbour(x, nb);
+  pass_m2_inv_b(tid, x, nb, lds, tl);
+  fco::wave_sync();
+  pass_m16<true>(tid, lds, tl);
+  __syncthreads();
+  pass_m128<true>(tid, lds, tl);
+  __syncthreads();
+  last_pass_to_regs(tid, lds, tl, v);
+}
+
+// H[(yrow * n_part + p) * 8192 + h_index] = scale * (twice the spectrum of the taps of partition p), thread-owned layout
+__global__ void __launch_bounds__(kThreads)
+spectrum_kernel(int64_t ny, int n_part, const float* __restrict__ y, const C32* __restrict__ tw16k, C32* __restrict__ H) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_fdr[];
+  C32* lds = reinterpret_cast<C32*>(smem_fdr);
+  C32* tl = lds + kLdsData;
+  const int tid = threadIdx.x;
+  const int64_t yrow = blockIdx.x / n_part;
+  const int p = blockIdx.x - (int)yrow * n_part;
+  twiddle_tables(tid, tw16k, tl);
+  MidConst mc;
+  mid_init(tid, tw16k, mc);
+  C32 v[8];
+  load_taps(tid, ny, y + yrow * ny, p, v);
+  __syncthreads();
+  forward_block(tid, v, lds, tl);
+  C32 z[8];
+  mid_split(tid, lds, mc, z);
+  C32* Hp = H + (int64_t)blockIdx.x * kHPerPart;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) Hp[h_index(0, i, tid)] = C32{z[i].x * kSpectrumScale, z[i].y * kSpectrumScale};
+}
+
+// One work item = one row segment, walked block by block; NP - 1 forward-only steps fill the delay line first.
+template <int NP>
+__global__ void __launch_bounds__(kThreads, 4)
+delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ tw16k, const C32* __restrict__ H,
+                  const int64_t* __restrict__ x_row_of, const int64_t* __restrict__ y_row_of, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_fdr[];
+  C32* lds = reinterpret_cast<C32*>(smem_fdr);
+  C32* tl = lds + kLdsData;
+  const int tid = threadIdx.x;
+  twiddle_tables(tid, tw16k, tl);
+  MidConst mc;
+  mid_init(tid, tw16k, mc);
+  __syncthreads();
+  const unsigned n_items = (unsigned)(g.rows * g.segs);          // < 2^31 (checked by the launcher): 32-bit item arithmetic
+#pragma unroll 1
+  for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int64_t row = (int64_t)(item / (unsigned)g.segs);
+    const int64_t j_lo = (int64_t)(item - (unsigned)row * (unsigned)g.segs) * g.seg_blocks;
+    const int64_t j_hi = j_lo + g.seg_blocks < g.n_blocks ? j_lo + g.seg_blocks : g.n_blocks;
+    const int64_t rx = x_row_of ? x_row_of[row] : row;
+    const float* xr = x + rx * g.nx;
+    const C32* Hr = H + (y_row_of ? y_row_of[row] : row) * NP * kHPerPart;
+    float* out_row = out + row * g.out_len;
+    // 8-byte paths: the row's first sample / first output on an even float offset (block starts are multiples of 8192)
+    const bool vin = (reinterpret_cast<uintptr_t>(xr + g.start) & 7) == 0;
+    const bool vout = (reinterpret_cast<uintptr_t>(out_row) & 7) == 0;
+    C32 z1[8], z2[8];                      // Z_(j-1), Z_(j-2): this thread's 8 bins
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z1[i] = z2[i] = C32{0.0f, 0.0f};
+    C32 v[8];
+    load_block(tid, g, xr, j_lo - (NP - 1), vin, v);
+#pragma unroll 1
+    for (int64_t j = j_lo - (NP - 1); j < j_hi; ++j) {
+      const bool produce = j >= j_lo;
+      forward_block(tid, v, lds, tl);
+      C32 z0[8];
+      mid_split(tid, lds, mc, z0);
+      if (produce) {
+        C32 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = C32{0.0f, 0.0f};
+        // one partition at a time: a uniform base (SGPRs) + ONE lane offset that the optimiser may not hoist (opaque) -- 24
+        // hoisted 64-bit element addresses were the spills of the first build
+        auto part = [&](const C32* Hp, const C32 (&z)[8]) {
+          const unsigned lane = (unsigned)fco::opaque(tid);
+          C32 h[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) h[i] = (Hp + 1024 * i)[lane];
+          mid_mac(tid, h, z, acc);
+        };
+        part(Hr, z0);
+        __builtin_amdgcn_sched_barrier(0);     // (the next partition's 8 loads hoisted above this one's products: 5 spill slots)
+        part(Hr + kHPerPart, z1);
+        if (NP > 2) {
+          __builtin_amdgcn_sched_barrier(0);
+          part(Hr + 2 * kHPerPart, z2);
+        }
+        mid_merge(tid, acc, mc, lds);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { z2[i] = z1[i]; z1[i] = z0[i]; }
+      __syncthreads();
+      // the next block's samples: in flight during the inverse passes and the stores (requested only now: during the middle
+      // step the thread holds three spectra, the accumulators and a partition of tap spectra -- with these 16 registers on top
+      // the 128-register budget of four waves per SIMD spilled)
+      if (j + 1 < j_hi) load_block(tid, g, xr, j + 1, vin, v);
+      if (produce) {
+        C32 w[8];
+        inverse_block(tid, lds, tl, w);
+        store_block(tid, g, w, j, j_hi, vout, out_row);
+        __syncthreads();                   // the next first pass overwrites what the last pass has just read
+      }
+    }
+  }
+}
+#endif  // __HIPCC__
+
+}  // namespace fdr
+}  // namespace aamd

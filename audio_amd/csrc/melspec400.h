@@ -164,12 +164,8 @@ struct Epi400 {
   int n_mfcc;                       // MFCC: coefficients (<= 48, multiple of 4)
   float top_db;                     // MFCC fix-up: cut-off = group_max[g] - top_db
   float* tile_min;                  // MFCC: [n_tiles] minimum dB value of each tile (written by pass 0, read by the fix-up)
-  int* fix_count;                   // MFCC fix-up: number of tiles to redo = entries of fix_list (written by mfcc_fix_list_kernel,
-                                    //   or by pass 0's last workgroup when `arrive` is set)
+  int* fix_count;                   // MFCC fix-up: number of tiles to redo = entries of fix_list (written by mfcc_fix_list_kernel)
   const int* fix_list;              // MFCC fix-up: the tiles under the cut-off, compacted (any order)
-  int* arrive;                      // MFCC pass 0, optional: arrival counter (any start value `arrive_base`): the LAST workgroup to
-  int arrive_base;                  //   finish compacts the fix-up list itself (no mfcc_fix_list_kernel launch in between) -- only
-                                    //   without a group_max exchange between the passes (one rank)
   int frag_in_lds;                  // MFCC: the workgroup's LDS has room for the fragment table (hop 100 / 160; not hop 200)
   int fixup;                        // MFCC: 0 = first pass, 1 = fix-up pass
   int lab;                          // MFCC (tools only): 1 no fragment loads, 2 no MFMA, 4 no tile minimum, 8 no stores
@@ -1021,10 +1017,8 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // pass 0 of the fused MFCC resets the counter of the compacted fix-up list that pass 1 fills (one launch less per call than a
   // memset; nothing reads it before mfcc_fix_list_kernel, which is ordered behind this kernel on the stream)
   // (every instantiation does it, the tools-only ones included: the caller hands over an uninitialised counter -- ADVICE r3)
-  // (not when the last workgroup of this pass writes the count itself: two plain stores to one word from different XCDs have
-  // no defined order in memory)
-  if (EPI == EPI400_MFCC && epi.fixup == 0 && epi.fix_count != nullptr && epi.arrive == nullptr && !(LAB & (1048576 | 8388608)) &&
-      blockIdx.x == 0 && threadIdx.x == 0)
+  if (EPI == EPI400_MFCC && epi.fixup == 0 && epi.fix_count != nullptr && !(LAB & (1048576 | 8388608)) && blockIdx.x == 0 &&
+      threadIdx.x == 0)
     *epi.fix_count = 0;
   // the tools-only switches of the MFCC epilogue (AAMD_MFCC_LAB) are honoured by an instantiation of their own: as run-time
   // branches in the product kernel they cut its MFMA section into basic blocks (the lesson of the resampler's census)
@@ -1532,46 +1526,6 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
         }
       }
       if (g_run >= 0) atomic_max_f32(epi.group_max + g_run, m_run);
-    }
-  }
-  if (EPI == EPI400_MFCC && !fix && epi.arrive != nullptr && !(LAB & (1048576 | 8388608))) {
-    // One launch less per call: the workgroup that finishes LAST -- every group maximum and every tile
-    // minimum of the pass is final then -- compacts the list of tiles under their cut-off that the fix-up launch deals out.
-    // Cross-workgroup hand-off as MI355X_MICROARCH.md prescribes: plain stores (tile_min) -> __syncthreads -> one lane's
-    // agent-scope release + drained vmcnt -> relaxed agent atomic; the last arriver: one agent acquire -> __syncthreads ->
-    // plain loads.  The group maxima were combined with device-scope atomics and are read with agent-scope atomic loads.
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int a = __hip_atomic_fetch_add(epi.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool last = (a - epi.arrive_base) == (int)gridDim.x - 1;
-      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      queue[0] = last ? 1 : 0;
-      queue[1] = 0;                                     // entries of the list so far (LDS counter of the last workgroup)
-    }
-    __syncthreads();
-    if (queue[0] != 0) {
-      int* list = const_cast<int*>(epi.fix_list);
-      for (int64_t base = 0; base < n_tiles; base += blockDim.x) {
-        const int64_t i = base + threadIdx.x;
-        bool hit = false;
-        if (i < n_tiles) {
-          const int64_t row = i / tiles_per_row;
-          const float gm = __hip_atomic_load(epi.group_max + row / epi.rows_per_group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          hit = epi.tile_min[i] < gm - epi.top_db;
-        }
-        const unsigned long long m = __ballot(hit);
-        int start = 0;
-        if (lane == 0 && m) start = __hip_atomic_fetch_add(queue + 1, __popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        start = __builtin_amdgcn_readfirstlane(start);
-        if (hit) list[start + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        *epi.fix_count = queue[1];
-        __hip_atomic_store(epi.arrive, epi.arrive_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // at rest again
-      }
     }
   }
   if ((LAB & 1048576) && lane == 0) {  // lab (tools/mel400_lab.py): cycle counter and 100 MHz wall clock at the wave's exit

@@ -368,9 +368,9 @@ Tensor mfcc_frag_build(Tensor dct, int64_t n_mels, int64_t n_mfcc) {
   check(aamd_mfcc_frag_build(fp(dct), (int32_t)n_mels, (int32_t)n_mfcc, fpm(frag), current_stream(dct)));
   return frag;
 }
-// Single-rank form (no exchange of group_max between the passes): pass 0 compacts the fix-up list itself.
-// scratch: int32[2 * tiles + 2] (tile minima as float bits, the list, the count, the arrival word); group_max: float[n_groups]
-// pre-filled with -inf, updated in place.  Returns (rows, n_frames, n_mfcc).
+// Single-rank form (no exchange of group_max between the passes): both passes in one op.
+// scratch: int32[2 * tiles + 1] (tile minima as float bits, the list, the count); group_max: float[n_groups] pre-filled with
+// -inf, updated in place.  Returns (rows, n_frames, n_mfcc).
 Tensor mfcc_fused(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, Tensor band_weights,
                   std::optional<Tensor> lane_order, std::optional<Tensor> table400, Tensor dct_frag, Tensor group_max,
                   int64_t n_fft, int64_t hop, int64_t pad, bool center, int64_t pad_mode, int64_t n_frames, double scale,
@@ -390,15 +390,14 @@ Tensor mfcc_fused(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Ten
   Tensor out = torch::stable::new_empty(wav, {d.rows, n_frames, n_mfcc});
   if (!out.numel()) return out;
   const int64_t tiles = aamd_mfcc_fused_tiles(&d);
-  Tensor scratch = torch::stable::new_zeros(wav, {2 * tiles + 2});        // zeroed: the arrival word starts at 0
+  Tensor scratch = torch::stable::new_empty(wav, {2 * tiles + 1});
   float* sp = fpm(scratch);
   aamd_mfcc_fused f{};
   f.dct_frag = fp(dct_frag); f.n_mfcc = (int32_t)n_mfcc; f.pass = 0;
   f.multiplier = (float)multiplier; f.amin = (float)amin; f.db_multiplier = (float)db_multiplier; f.top_db = (float)top_db;
   f.group_max = fpm(group_max); f.rows_per_group = rows_per_group;
   f.tile_min = sp; f.tile_list = reinterpret_cast<int32_t*>(sp + tiles);
-  f.fix_count = reinterpret_cast<int32_t*>(sp + 2 * tiles); f.arrive = reinterpret_cast<int32_t*>(sp + 2 * tiles + 1);
-  f.arrive_base = 0;
+  f.fix_count = reinterpret_cast<int32_t*>(sp + 2 * tiles);
   void* st = current_stream(wav);
   check(aamd_mfcc_fused_f32(fp(wav), fp(window), fp(twiddle), &bands.b, fpm(out), &d, &f, st));
   f.pass = 1;

@@ -1007,11 +1007,7 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
             state.frag, state.frag_key, state.frag_src = frag, key, weakref.ref(dct)
         n_tiles = int(L.aamd_mfcc_fused_tiles(C.byref(desc)))
         out = torch.empty((desc.rows, desc.n_frames, n_mfcc), dtype=torch.float32, device=dev)
-        # ONE fill initialises the group maxima AND the arrival word of pass 0 (element n_groups; its start value is the bit
-        # pattern of -inf): without an exchange between the passes (no hook) the last workgroup of pass 0 compacts the fix-up
-        # list itself and pass 1 launches no list kernel
-        gbuf = torch.full((n_groups + 1,), float("-inf"), dtype=torch.float32, device=dev)
-        gmax = gbuf[:n_groups]
+        gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
         if out.numel() == 0:
             # an empty shard still takes part in the exchange of the batch-global cut-off: the other ranks are waiting in the
             # same all-reduce (returning before the hook hung the job)
@@ -1021,10 +1017,11 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
         tile_min = torch.empty((n_tiles,), dtype=torch.float32, device=dev)
         count = torch.empty((1,), dtype=torch.int32, device=dev)
         tile_list = torch.empty((n_tiles,), dtype=torch.int32, device=dev)
-        merged = group_max_hook is None
+        # (round 4 tried to fold the compaction of the fix-up list into pass 0 -- its last workgroup to finish scanned the tile
+        # minima itself: one workgroup walking 85 k minima is latency-bound, +50 us on the cfg4 batch against the 4.8 us of the
+        # chip-wide list kernel it saved; profiles/r04_b_configs.jsonl.  Two launches stay.)
         f = _lib.MfccFused(state.frag.data_ptr(), n_mfcc, 0, float(db[0]), float(db[1]), float(db[2]), float(top_db),
-                           gmax.data_ptr(), max(packed, 1), tile_min.data_ptr(), count.data_ptr(), tile_list.data_ptr(),
-                           gbuf[n_groups:].data_ptr() if merged else None, -8388608)      # 0xff800000 = -inf as int32
+                           gmax.data_ptr(), max(packed, 1), tile_min.data_ptr(), count.data_ptr(), tile_list.data_ptr())
         args = (x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),
                 C.byref(bands.struct), out.data_ptr(), C.byref(desc))
         _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))

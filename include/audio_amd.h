@@ -125,7 +125,9 @@ enum {
   AAMD_POLICY_ISTFT_ATOMIC  = 4,  /* inverse STFT: one atomic per contribution instead of run-based overlap-add */
   AAMD_POLICY_RESAMPLE_FP32 = 8,  /* banded resampling on v_mfma_f32_16x16x4_f32 instead of the f16 hi/lo-split MFMAs (16 x slower pipe) */
   AAMD_POLICY_FFTCONV_NO_FDL = 16, /* overlap-save: never the frequency-domain delay-line plan */
-  AAMD_POLICY_FFTCONV_FDL   = 32  /* overlap-save: the delay-line plan whenever the tap count allows it (cost model ignored) */
+  AAMD_POLICY_FFTCONV_FDL   = 32, /* overlap-save: the COMPLEX-block delay-line plan (2) whenever the tap count allows it (cost model ignored) */
+  AAMD_POLICY_FFTCONV_COMPLEX = 64 /* overlap-save: only the complex-block kernels of rounds 1-3 (plans 1 / 2), never the
+                                      real-block delay line of round 4 (plan 3) */
 };
 int         aamd_set_kernel_policy(int flags);
 
@@ -189,11 +191,6 @@ typedef struct aamd_mfcc_fused {
   int32_t* fix_count;      /* device int32: pass 0 resets it, pass 1 leaves the number of tiles it redoes here */
   int32_t* tile_list;      /* device int32[aamd_mfcc_fused_tiles(desc)]: scratch of pass 1 -- the tiles under the cut-off,
                               compacted, so that the fix-up launch deals them out evenly however they cluster by clip */
-  int32_t* arrive;         /* optional (ABI v5), NULL = off: device int32 holding `arrive_base` before pass 0.  When set, the
-                              workgroup of pass 0 that finishes last compacts tile_list / fix_count itself and pass 1 launches
-                              no list kernel: one launch less per call.  Only valid when group_max is NOT changed between the
-                              passes (no all-reduce: one rank); the word is back at arrive_base when pass 0 ends */
-  int32_t arrive_base;     /* any value (e.g. the bit pattern of -inf, so that ONE fill initialises group_max and this word) */
 } aamd_mfcc_fused;
 int32_t aamd_mfcc_frag_floats(void);
 int64_t aamd_mfcc_fused_tiles(const aamd_stft_desc* desc);
@@ -404,7 +401,9 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
  * aamd_fftconvolve_workspace() bytes, 8-byte aligned; it may be NULL when that is 0).
  * aamd_fftconvolve_plan reports what a call of that shape runs on the current device: 0 time domain, 1 overlap-save
  * with the input spectrum recomputed per tap partition, 2 overlap-save with a frequency-domain delay line (uniform
- * 8192-tap partitions, one forward + one inverse FFT per block; chosen by a cost model over rows, blocks and CUs). */
+ * 8192-tap partitions, one forward + one inverse FFT per block; chosen by a cost model over rows, blocks and CUs),
+ * 3 (8193 .. 24576 taps) the delay line on REAL blocks: 8192-point complex FFTs, the delayed spectra in registers,
+ * one row per workgroup of 1024 threads (csrc/fftconv_fdr.h). */
 int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_rows, int64_t nx, int64_t ny);
 int aamd_fftconvolve_plan(int64_t rows, int64_t nx, int64_t ny, int64_t out_len);
 int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows,

@@ -13,6 +13,7 @@
 #include "../../audio_amd/csrc/db_mfcc.h"
 #include "../../audio_amd/csrc/fftconv.h"
 #include "../../audio_amd/csrc/fftconv_os.h"
+#include "../../audio_amd/csrc/fftconv_fdr.h"
 #include "../../audio_amd/csrc/istft.h"
 #include "../../audio_amd/csrc/vocoder.h"
 #include "../../audio_amd/csrc/stft_pow2.h"
@@ -1196,6 +1197,100 @@ int sim_fftconv_os(const float* x, const float* y, float* out, int64_t rows, int
     }
   }
   return 0;
+}
+
+// Replay of the real-block delay line (fdr::spectrum_kernel + fdr::delay_line_kernel<NP>): the launcher's logic of
+// aamd_fftconvolve_f32 (plan 3), 1024 "threads" per phase, phases separated where the kernel has barriers or wave hand-offs; the
+// neighbour exchange of the radix-2 stage is the DPP swap of the device.  Returns 1 when the plan serves the shape, else 0.
+int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows, int64_t n_y_rows,
+                    int64_t nx, int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of, int64_t start,
+                    int64_t out_len, int cu_count) {
+  using namespace fdr;
+  const bool swap = ny > nx;
+  const float* xa = swap ? y : x; const float* ya = swap ? x : y;
+  const int64_t nxa = swap ? ny : nx, nya = swap ? nx : ny;
+  const int64_t tap_rows = swap ? n_x_rows : n_y_rows;
+  const int64_t* xmap = swap ? y_row_of : x_row_of; const int64_t* ymap = swap ? x_row_of : y_row_of;
+  Geom g{};
+  g.rows = rows; g.nx = nxa; g.ny = nya; g.start = start; g.out_len = out_len;
+  if (!plan(rows, nya, out_len, cu_count, g)) return 0;
+  const int NP = g.n_part;
+  std::vector<C32> tw(fco::kN), lds(kLdsComplex), H((size_t)tap_rows * NP * kHPerPart);
+  for (int m = 0; m < fco::kN; ++m) {
+    const double a = -2.0 * M_PI * (double)m / (double)fco::kN;
+    tw[m] = C32{(float)std::cos(a), (float)std::sin(a)};
+  }
+  C32* tl = lds.data() + kLdsData;
+  for (int t = 0; t < kThreads; ++t) twiddle_tables(t, tw.data(), tl);
+  std::vector<MidConst> mc(kThreads);
+  for (int t = 0; t < kThreads; ++t) mid_init(t, tw.data(), mc[t]);
+  using A8 = std::array<C32, 8>;
+  auto arr = [](A8& a) -> C32 (&)[8] { return *reinterpret_cast<C32 (*)[8]>(a.data()); };
+  std::vector<A8> v(kThreads), o(kThreads), z0(kThreads), z1(kThreads), z2(kThreads), acc(kThreads);
+  auto forward = [&]() {
+    for (int t = 0; t < kThreads; ++t) first_pass_from_regs(t, arr(v[t]), lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) pass_m128<false>(t, lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) pass_m16<false>(t, lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) pass_m2_fwd_a(t, lds.data(), tl, arr(o[t]));
+    for (int t = 0; t < kThreads; ++t) pass_m2_fwd_b(t, arr(o[t]), arr(o[t ^ 1]), lds.data());
+  };
+  auto inverse = [&]() {
+    for (int t = 0; t < kThreads; ++t) pass_m2_inv_a(t, lds.data(), arr(o[t]));
+    for (int t = 0; t < kThreads; ++t) pass_m2_inv_b(t, arr(o[t]), arr(o[t ^ 1]), lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) pass_m16<true>(t, lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) pass_m128<true>(t, lds.data(), tl);
+    for (int t = 0; t < kThreads; ++t) last_pass_to_regs(t, lds.data(), tl, arr(v[t]));
+  };
+  for (int64_t b = 0; b < tap_rows * NP; ++b) {
+    const int64_t yrow = b / NP; const int p = (int)(b - yrow * NP);
+    for (int t = 0; t < kThreads; ++t) load_taps(t, nya, ya + yrow * nya, p, arr(v[t]));
+    forward();
+    for (int t = 0; t < kThreads; ++t) {
+      mid_split(t, lds.data(), mc[t], arr(z0[t]));
+      for (int i = 0; i < 8; ++i)
+        H[(size_t)b * kHPerPart + h_index(0, i, t)] = C32{z0[t][i].x * kSpectrumScale, z0[t][i].y * kSpectrumScale};
+    }
+  }
+  for (int64_t item = 0; item < rows * g.segs; ++item) {
+    const int64_t row = item / g.segs, j_lo = (item - row * g.segs) * g.seg_blocks;
+    const int64_t j_hi = j_lo + g.seg_blocks < g.n_blocks ? j_lo + g.seg_blocks : g.n_blocks;
+    const int64_t rx = xmap ? xmap[row] : row, ry = ymap ? ymap[row] : row;
+    const float* xr = xa + rx * g.nx;
+    const C32* Hr = H.data() + ry * NP * kHPerPart;
+    const bool vin = ((rx * g.nx + g.start) & 1) == 0, vout = ((row * out_len) & 1) == 0;   // what 8-byte alignment means here
+    for (int t = 0; t < kThreads; ++t)
+      for (int i = 0; i < 8; ++i) z1[t][i] = z2[t][i] = C32{0.0f, 0.0f};
+    for (int64_t j = j_lo - (NP - 1); j < j_hi; ++j) {
+      const bool produce = j >= j_lo;
+      for (int t = 0; t < kThreads; ++t) load_block(t, g, xr, j, vin, arr(v[t]));
+      forward();
+      for (int t = 0; t < kThreads; ++t) {
+        mid_split(t, lds.data(), mc[t], arr(z0[t]));
+        if (produce) {
+          C32 h[8];
+          for (int i = 0; i < 8; ++i) acc[t][i] = C32{0.0f, 0.0f};
+          for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(0, i, t)];
+          mid_mac(t, h, arr(z0[t]), arr(acc[t]));
+          for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(1, i, t)];
+          mid_mac(t, h, arr(z1[t]), arr(acc[t]));
+          if (NP > 2) {
+            for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(2, i, t)];
+            mid_mac(t, h, arr(z2[t]), arr(acc[t]));
+          }
+        }
+      }
+      // (every thread has read its quads before any thread writes: on the device a thread rewrites only the cells it read)
+      for (int t = 0; t < kThreads; ++t) {
+        if (produce) mid_merge(t, arr(acc[t]), mc[t], lds.data());
+        z2[t] = z1[t]; z1[t] = z0[t];
+      }
+      if (produce) {
+        inverse();
+        for (int t = 0; t < kThreads; ++t) store_block(t, g, arr(v[t]), j, j_hi, vout, out + row * out_len);
+      }
+    }
+  }
+  return 1;
 }
 
 int sim_fftconv(const float* x, const float* y, float* out, int64_t rows, int64_t nx, int64_t ny,

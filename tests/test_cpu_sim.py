@@ -367,6 +367,29 @@ def test_sim_fftconvolve_overlap_save(nx, ny, mode):
     assert peak_rel_err(got, exp) <= 2e-6
 
 
+@pytest.mark.parametrize("nx,ny,mode,cus", [(40000, 9000, "full", 256), (70001, 24000, "same", 256), (70000, 24576, "full", 4),
+                                            (30001, 20000, "valid", 2), (16385, 8193, "full", 256)])
+def test_sim_fftconvolve_real_block_delay_line(nx, ny, mode, cus):
+    """Plan 3 of aamd_fftconvolve_f32 (csrc/fftconv_fdr.h: real blocks as 8192-point complex FFTs, radices 8.8.8.8.2 with
+    the digit-reversed spectrum in place, the real-FFT split / merge on mirror-bin quads, the delay line in "registers"),
+    replayed thread by thread: 2 and 3 partitions, row segments (few CUs), odd lengths, slices that start inside the
+    convolution -- against the float64 oracle."""
+    rng = np.random.default_rng(nx + ny)
+    x = rng.standard_normal((2, nx)).astype(np.float32)
+    y = (rng.standard_normal((1, ny)) * np.exp(-np.arange(ny) / (0.3 * ny))).astype(np.float32)
+    exp = O.fftconvolve(x.astype(np.float64), np.broadcast_to(y, (2, ny)).astype(np.float64), mode)
+    full = nx + ny - 1
+    out_len = exp.shape[-1]
+    start = 0 if mode == "full" else (full - out_len) // 2
+    got = S.sim_fftconv_fdr(x, y, start, out_len, ymap=np.zeros(2, dtype=np.int64), rows=2, cu_count=cus)
+    assert got is not None and not np.isnan(got).any()
+    assert peak_rel_err(got, exp) <= 2e-6
+    assert S.sim_fftconv_fdr(x, y[:, :8000], 0, nx + 7999, ymap=np.zeros(2, dtype=np.int64), rows=2) is None     # <= 8192 taps
+    if nx >= 30000:
+        assert S.sim_fftconv_fdr(x[:, :30000], rng.standard_normal((1, 24577)).astype(np.float32), 0, 30000 + 24576,
+                                 ymap=np.zeros(2, dtype=np.int64), rows=2) is None                                # > 24576 taps
+
+
 @pytest.mark.parametrize("nx,ny,mode,cus,fdl", [
     (70000, 16000, "full", 2, True), (60000, 24000, "full", 2, True), (50000, 17000, "same", 1, True),
     (90000, 30000, "valid", 4, True), (150000, 24000, "full", 16, True), (70000, 24000, "full", 4, True),

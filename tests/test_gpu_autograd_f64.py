@@ -267,12 +267,12 @@ def test_inverse_spectrogram_gradcheck_other_shapes(kw):
     wfn = torch.hann_window if center else torch.hamming_window          # (centre off: the Hann window's zero end fails NOLA)
     inv = T.InverseSpectrogram(window_fn=wfn, **kw).to(dtype=torch.float64, device="cuda")
     w = inv.window.detach().cpu()            # the module's buffer: float32 values widened (as the reference's .to(float64) does)
-    spec = torch.stft(x, n_fft, hop, n_fft, w, center=center, pad_mode="reflect", normalized=kw.get("normalized", False),
-                      onesided=onesided, return_complex=True)
+    spec = torch.stft(x, n_fft, hop, n_fft, w, center=center, pad_mode="reflect", onesided=onesided, return_complex=True)
     if not onesided:
         spec = spec + 0.05 * torch.randn(spec.shape, dtype=torch.complex128, generator=torch.Generator().manual_seed(1))
-    ref = torch.istft(spec, n_fft, hop, n_fft, w, center=center, normalized=kw.get("normalized", False), onesided=onesided,
-                      length=length)
+    ref = torch.istft(spec, n_fft, hop, n_fft, w, center=center, onesided=onesided, length=length)
+    if kw.get("normalized"):          # torchaudio's normalized=True is the WINDOW norm (functional.py:205-207), not aten's 1/sqrt(n_fft)
+        ref = ref * w.pow(2).sum().sqrt()
     s_dev = spec.cuda().requires_grad_()
     got = inv(s_dev, length)
     assert got.shape == ref.shape and float((got.detach().cpu() - ref).abs().max()) <= 1e-11 * float(ref.abs().max())

@@ -391,13 +391,45 @@ def test_fftconvolve_delay_line_plan_against_oracle(case):
     with _lib.kernel_policy(_lib.POLICY_FFTCONV_NO_FDL):
         assert _lib.lib().aamd_fftconvolve_plan(rows, xs[-1], ys[-1], exp.shape[-1]) == 1
         rec = F.fftconvolve(xd, yd, mode)
+    with _lib.kernel_policy(_lib.POLICY_FFTCONV_COMPLEX):       # the cost model among the complex-block plans (rounds 1-3)
+        cplan = _lib.lib().aamd_fftconvolve_plan(rows, xs[-1], ys[-1], exp.shape[-1])
+        cown = F.fftconvolve(xd, yd, mode)
+    assert cplan in (1, 2) and torch.equal(cown, fdl if cplan == 2 else rec)
     own = F.fftconvolve(xd, yd, mode)
     plan = _lib.lib().aamd_fftconvolve_plan(rows, xs[-1], ys[-1], exp.shape[-1])
-    assert plan in (1, 2)
-    assert fdl.shape == exp.shape
+    # default: the real-block delay line of round 4 (plan 3) serves 8193 .. 24576 taps, the complex plans the rest
+    assert plan == (3 if 8192 < ys[-1] <= 24576 else cplan)
+    assert fdl.shape == exp.shape == own.shape
     assert peak_rel_err(fdl.cpu().numpy(), exp) <= 1e-5
     assert peak_rel_err(rec.cpu().numpy(), exp) <= 1e-5
-    assert torch.equal(own, fdl if plan == 2 else rec)
+    assert peak_rel_err(own.cpu().numpy(), exp) <= 1e-5
+    if plan != 3:
+        assert torch.equal(own, cown)
+
+
+@pytest.mark.parametrize("case", [((3, 50001), (1, 8193), "full"), ((2, 3, 33333), (2, 3, 12345), "same"),
+                                  ((5, 70001), (5, 24576), "valid"), ((1, 200000), (1, 17000), "full"),
+                                  ((7, 16385), (1, 16384), "full"), ((2, 9000), (2, 8500), "full")])
+def test_fftconvolve_real_block_delay_line_edges(case):
+    """Plan 3 (csrc/fftconv_fdr.h) at its edges: the smallest / largest tap counts it serves, odd row lengths (rows on odd
+    float offsets take the scalar load / store paths), outputs that end inside a block, a single row cut into segments, taps
+    as long as the signal, per-row taps, all three modes -- against the float64 oracle, and bit-equal on a second call."""
+    import audio_amd.functional as F
+    from audio_amd import _lib
+    from oracle import dsp_oracle as O
+    xs, ys, mode = case
+    g = torch.Generator().manual_seed(xs[-1] * 3 + ys[-1])
+    x = torch.randn(*xs, generator=g)
+    y = torch.randn(*ys, generator=g) * torch.exp(-torch.arange(ys[-1]) / (0.3 * ys[-1]))
+    lead = np.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    exp = O.fftconvolve(np.broadcast_to(x.numpy().astype(np.float64), lead + x.shape[-1:]),
+                        np.broadcast_to(y.numpy().astype(np.float64), lead + y.shape[-1:]), mode)
+    rows = int(np.prod(lead))
+    assert _lib.lib().aamd_fftconvolve_plan(rows, xs[-1], ys[-1], exp.shape[-1]) == 3
+    got = F.fftconvolve(x.cuda(), y.cuda(), mode)
+    assert got.shape == exp.shape
+    assert peak_rel_err(got.cpu().numpy(), exp) <= 1e-5
+    assert torch.equal(got, F.fftconvolve(x.cuda(), y.cuda(), mode))
 
 
 def test_fftconvolve_headline_shape_properties():
@@ -409,7 +441,7 @@ def test_fftconvolve_headline_shape_properties():
     t = torch.arange(24000, device="cuda") / 48000.0
     rir = (torch.randn(1, 1, 24000, device="cuda", generator=g) * torch.exp(-t / 0.1) * 0.05)
     from audio_amd import _lib
-    assert _lib.lib().aamd_fftconvolve_plan(256, 480000, 24000, 503999) == 2      # the delay-line plan serves this shape
+    assert _lib.lib().aamd_fftconvolve_plan(256, 480000, 24000, 503999) == 3      # the real-block delay line serves this shape
     y = F.fftconvolve(x, rir)
     assert y.shape == (32, 8, 503999) and torch.isfinite(y).all()
     y2 = F.fftconvolve(0.5 * x[:2], rir)

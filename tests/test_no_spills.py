@@ -21,6 +21,10 @@ ALLOW = [(r"aamd14lfilter_kernelILi(8|12|16)E", 4200), (r"aamd2p217kaldi_pow2_ke
          # lab instantiations of the one-tile biquad kernel (tools only: AAMD_LFW_LAB copy-order / non-temporal variants)
          (r"aamd3lfw19lfilter_wave_kernelILi(128|896)ELi16E", 128),
          (r"aamd3lfw25lfilter_wave_mover_kernel", 32), (r"aamd4m40015istft400_kernel", 16),
+         # the 3-partition real-block delay line runs at exactly the 128 registers of four waves per SIMD: the allocator parks
+         # three launch constants of the ITEM loop in scratch (stored in the kernel prologue, reloaded once per work item = per
+         # row; nothing inside the block-step loop -- the ISA is checked by test_real_block_delay_line_steps_do_not_touch_scratch)
+         (r"aamd3fdr17delay_line_kernelILi3E", 16),
          # lab instantiations of the f16 resampler (tools only: AAMD_RSM_LAB), never the product one (<KS, 0>)
          (r"aamd3rsm19resample_f16_kernelILi\d+ELi[12]E", 64)]
 
@@ -76,3 +80,29 @@ def test_headline_kernels_have_no_scratch_at_all(pattern):
     assert ks, pattern
     for n, k in ks.items():
         assert k.get("private_segment_fixed_size", 0) == 0 and k.get("vgpr_spill_count", 0) == 0, (n, k)
+
+
+def test_real_block_delay_line_steps_do_not_touch_scratch():
+    """cfg5b's kernel (fdr::delay_line_kernel<3>) may park item-loop constants in scratch (ALLOW above) but its block-step
+    loop -- everything between the first and the last workgroup barrier of the disassembly -- must not contain a single
+    scratch instruction: a reload there would wait for the prefetched inputs (s_waitcnt vmcnt(0))."""
+    from audio_amd import _build
+    so = _build.OUT
+    if not os.path.exists(so) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("library or llvm-objdump missing")
+    with tempfile.TemporaryDirectory() as d:
+        local = os.path.join(d, "lib.so")
+        shutil.copy(so, local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, capture_output=True, cwd=d)
+        obj = [f for f in os.listdir(d) if "gfx950" in f][0]
+        dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", os.path.join(d, obj)], check=True,
+                             capture_output=True, text=True).stdout
+    for np_ in (2, 3):
+        m = re.search(r"<_ZN4aamd3fdr17delay_line_kernelILi%dE[^>]*>:\n(.*?)s_endpgm" % np_, dis, re.S)
+        assert m, np_
+        body = m.group(1).splitlines()
+        bars = [i for i, l in enumerate(body) if "s_barrier" in l]
+        assert len(bars) >= 6, len(bars)
+        # the first barrier follows the table set-up; the step loop spans from the second barrier to the last one
+        inside = [l for l in body[bars[1]:bars[-1]] if "scratch_" in l]
+        assert not inside, (np_, inside[:3])

@@ -23,7 +23,7 @@ def timed(fn, warmup=3, steps=10):
     return e0.elapsed_time(e1) / steps
 
 
-cases = [((256, 480000), 12000), ((256, 480000), 16000), ((256, 480000), 24000), ((256, 480000), 30000),
+cases = [((256, 480000), 9000), ((256, 480000), 12000), ((256, 480000), 16000), ((256, 480000), 24000), ((256, 480000), 30000),
          ((32, 480000), 24000), ((8, 1920000), 24000), ((1024, 120000), 24000), ((256, 100000), 24000)]
 with torch.no_grad():
     for (rows, nx), taps in cases:
@@ -34,5 +34,10 @@ with torch.no_grad():
             rec["delay_line_ms"] = round(timed(lambda: F.fftconvolve(x, h)), 4)
         with _lib.kernel_policy(_lib.POLICY_FFTCONV_NO_FDL):
             rec["recompute_ms"] = round(timed(lambda: F.fftconvolve(x, h)), 4)
-        rec["cost_model_picks"] = {1: "recompute", 2: "delay line"}[_lib.lib().aamd_fftconvolve_plan(rows, nx, taps, nx + taps - 1)]
+        rec["default_ms"] = round(timed(lambda: F.fftconvolve(x, h)), 4)
+        rec["default_plan"] = {1: "recompute", 2: "complex-block delay line", 3: "real-block delay line (round 4)"}[
+            _lib.lib().aamd_fftconvolve_plan(rows, nx, taps, nx + taps - 1)]
+        with _lib.kernel_policy(_lib.POLICY_FFTCONV_COMPLEX):
+            rec["cost_model_among_complex_plans"] = {1: "recompute", 2: "delay line"}[
+                _lib.lib().aamd_fftconvolve_plan(rows, nx, taps, nx + taps - 1)]
         print(json.dumps(rec), flush=True)
