@@ -354,7 +354,8 @@ int aamd_abi_version(void) { return AAMD_ABI_VERSION; }
 int aamd_set_kernel_policy(int flags) {
   const int prev = policy();
   if (flags >= 0) g_policy.store(flags & (AAMD_POLICY_FORCE_GENERIC | AAMD_POLICY_MEL400_WIDE | AAMD_POLICY_ISTFT_ATOMIC |
-                                          AAMD_POLICY_RESAMPLE_FP32 | AAMD_POLICY_FFTCONV_NO_FDL | AAMD_POLICY_FFTCONV_FDL));
+                                          AAMD_POLICY_RESAMPLE_FP32 | AAMD_POLICY_FFTCONV_NO_FDL | AAMD_POLICY_FFTCONV_FDL |
+                                          AAMD_POLICY_FFTCONV_COMPLEX));
   return prev;
 }
 

@@ -37,19 +37,31 @@ constexpr int kThreads = 1024;
 constexpr int kMaxParts = 3;               // Z_j in flight + two delayed spectra in registers
 AAMD_HD int pad(int i) { return i + ((i >> 5) << 1); }            // 2 complex per 32: see the bank notes at each pass
 constexpr int kLdsData = kM + (kM >> 5) * 2;                      // 8704 complex = 69 632 B
-// twiddle tables behind the data (W = W_M = e^(-2 pi i / 8192)):
-//   tl[a], a < 128: W^(64 a);  tl[128 + b], b < 64: W^b;  kTw3 + 16 (k - 1) + j: W_128^(j k), j < 16;  kTw4 + 2 (k - 1) + j: W_16^(j k)
-constexpr int kTw3 = 192, kTw4 = kTw3 + 7 * 16, kTwEnd = kTw4 + 7 * 2;
-constexpr int kLdsComplex = kLdsData + kTwEnd;                    // 8 924 complex = 71 392 B
+// complete twiddle tables behind the data (W_M = e^(-2 pi i / 8192)), [k - 1][j] so that the lanes of a wave read consecutive
+// entries: 65 KB of the 90 KB this kernel leaves free -- forming w^2 .. w^7 from three look-ups cost a pass 28 of its ~130 vector
+// instructions (first build: two-level table + products), a table entry costs one conflict-free ds_read_b64
+//   kTw1 + 1024 (k - 1) + t: W_8192^(t k), t < 1024;   kTw2 + 128 (k - 1) + j: W_1024^(j k), j < 128;
+//   kTw3 + 16 (k - 1) + j: W_128^(j k), j < 16;        kTw4 + 2 (k - 1) + j: W_16^(j k), j < 2
+constexpr int kTw1 = 0, kTw2 = kTw1 + 7 * 1024, kTw3 = kTw2 + 7 * 128, kTw4 = kTw3 + 7 * 16, kTwEnd = kTw4 + 7 * 2;
+constexpr int kLdsComplex = kLdsData + kTwEnd;                    // 16 894 complex = 135 152 B
 
 // tw16k: the W_16384^m table of fco::twiddle_kernel (m < 16384); W_M^e = tw16k[2 e]
 AAMD_HD void twiddle_tables(int tid, const C32* tw16k, C32* tl) {
-  if (tid < 128) tl[tid] = tw16k[2 * 64 * tid];
-  else if (tid < 192) tl[tid] = tw16k[2 * (tid - 128)];
-  else if (tid < 192 + 112) { const int u = tid - 192, k = u / 16 + 1, j = u % 16; tl[kTw3 + u] = tw16k[2 * 64 * j * k]; }
-  else if (tid < 192 + 112 + 14) { const int u = tid - 192 - 112, k = u / 2 + 1, j = u % 2; tl[kTw4 + u] = tw16k[2 * 512 * j * k]; }
+  for (int u = tid; u < kTwEnd; u += kThreads) {
+    int e;                                                        // exponent of W_M
+    if (u < kTw2) { const int k = u / 1024 + 1, t = u % 1024; e = t * k; }
+    else if (u < kTw3) { const int v = u - kTw2, k = v / 128 + 1, j = v % 128; e = 8 * j * k; }
+    else if (u < kTw4) { const int v = u - kTw3, k = v / 16 + 1, j = v % 16; e = 64 * j * k; }
+    else { const int v = u - kTw4, k = v / 2 + 1, j = v % 2; e = 512 * j * k; }
+    tl[u] = tw16k[2 * e];                                         // 2 e < 16384 for every entry
+  }
 }
-AAMD_HD C32 tw_at(const C32* tl, int e) { return cmul(tl[e >> 6], tl[128 + (e & 63)]); }
+// v[k] *= tab[stride (k - 1)] (or its conjugate), k = 1 .. 7
+template <bool conj_w>
+AAMD_HD void mul_table8(C32 (&v)[8], const C32* tab, int stride) {
+#pragma unroll
+  for (int k = 1; k < 8; ++k) v[k] = fco::cmulc<conj_w>(v[k], tab[stride * (k - 1)]);
+}
 
 // 8-point DFT in registers, natural order in and out; forward (e^-) or inverse (e^+, unnormalised)
 template <bool inv>
@@ -76,21 +88,11 @@ AAMD_HD void dft8(C32 (&v)[8]) {
   v[3] = cadd(e3, p3); v[7] = csub(e3, p3);
 }
 
-// v[k] *= w^k (or conj) for k = 1 .. 7, w = W_M^e with 4 e < M: three look-ups, products of depth <= 2
-template <bool conj_w>
-AAMD_HD void mul_twiddles8(C32 (&v)[8], const C32* tl, int e) {
-  const C32 w1 = tw_at(tl, e), w2 = tw_at(tl, 2 * e), w4 = tw_at(tl, 4 * e);
-  const C32 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
-  v[1] = fco::cmulc<conj_w>(v[1], w1); v[2] = fco::cmulc<conj_w>(v[2], w2); v[3] = fco::cmulc<conj_w>(v[3], w3);
-  v[4] = fco::cmulc<conj_w>(v[4], w4); v[5] = fco::cmulc<conj_w>(v[5], w5); v[6] = fco::cmulc<conj_w>(v[6], w6);
-  v[7] = fco::cmulc<conj_w>(v[7], w7);
-}
-
 // ---- pass 1 (length 8192, m = 1024): thread tid owns elements tid + 1024 r -- what a coalesced load of the block gives it ----
 AAMD_HD void first_pass_from_regs(int tid, C32 (&v)[8], C32* lds, const C32* tl) {
   dft8<false>(v);
   tid = fco::opaque(tid);
-  mul_twiddles8<false>(v, tl, tid);
+  mul_table8<false>(v, tl + kTw1 + tid, 1024);
   C32* cell = lds + pad(tid);                  // pad(tid + 1024 r) = pad(tid) + 1088 r; consecutive lanes, consecutive cells
 #pragma unroll
   for (int r = 0; r < 8; ++r) cell[1088 * r] = v[r];
@@ -100,7 +102,7 @@ AAMD_HD void last_pass_to_regs(int tid, const C32* lds, const C32* tl, C32 (&v)[
   const C32* cell = lds + pad(tid);
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = cell[1088 * r];
-  mul_twiddles8<true>(v, tl, tid);
+  mul_table8<true>(v, tl + kTw1 + tid, 1024);
   dft8<true>(v);
 }
 
@@ -113,9 +115,9 @@ AAMD_HD void pass_m128(int tid, C32* lds, const C32* tl) {
   C32 v[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = cell[136 * r];
-  if (inv) mul_twiddles8<true>(v, tl, 8 * j);  // W_1024^(j k) = W_M^(8 j k)
+  if (inv) mul_table8<true>(v, tl + kTw2 + j, 128);
   dft8<inv>(v);
-  if (!inv) mul_twiddles8<false>(v, tl, 8 * j);
+  if (!inv) mul_table8<false>(v, tl + kTw2 + j, 128);
 #pragma unroll
   for (int r = 0; r < 8; ++r) cell[136 * r] = v[r];
 }
@@ -124,7 +126,9 @@ AAMD_HD void pass_m128(int tid, C32* lds, const C32* tl) {
 template <bool inv>
 AAMD_HD void pass_m16(int tid, C32* lds, const C32* tl) {
   tid = fco::opaque(tid);
-  const int blk = tid >> 4, j = tid & 15;
+  // the wave's 64 butterflies are its four blocks x 16 j; lane l takes (block l & 3, j = l >> 2): the 32 lanes of a b64 access
+  // then hit banks 8 (l & 3) + (l >> 2) -- all distinct (136 = 8 mod 32) -- where (block l >> 4, j = l & 15) collided two-way
+  const int blk = ((tid >> 6) << 2) + (tid & 3), j = (tid & 63) >> 2;
   C32* cell = lds + pad(128 * blk + j);        // offsets of r: 16 r + 2 (r >> 1)  (j < 16: the run of 32 changes every second r)
   const C32* tab = tl + kTw3 + j;
   C32 v[8];
@@ -455,13 +459,26 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
 #pragma unroll 1
     for (int64_t j = j_lo - (NP - 1); j < j_hi; ++j) {
       const bool produce = j >= j_lo;
+      // the delayed partitions do not wait for this block's spectrum: H_1 Z_(j-1) + H_2 Z_(j-2) is formed BEFORE the forward
+      // transform (its 16 tap-spectrum loads fly during the first pass) and only H_0 Z_j is left for the middle step
+      C32 acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = C32{0.0f, 0.0f};
+      if (produce) {
+        auto part_early = [&](const C32* Hp, const C32 (&z)[8]) {
+          const unsigned lane = (unsigned)fco::opaque(tid);
+          C32 h[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) h[i] = (Hp + 1024 * i)[lane];
+          mid_mac(tid, h, z, acc);
+        };
+        part_early(Hr + kHPerPart, z1);
+        if (NP > 2) part_early(Hr + 2 * kHPerPart, z2);
+      }
       forward_block(tid, v, lds, tl);
       C32 z0[8];
       mid_split(tid, lds, mc, z0);
       if (produce) {
-        C32 acc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = C32{0.0f, 0.0f};
         // one partition at a time: a uniform base (SGPRs) + ONE lane offset that the optimiser may not hoist (opaque) -- 24
         // hoisted 64-bit element addresses were the spills of the first build
         auto part = [&](const C32* Hp, const C32 (&z)[8]) {
@@ -472,12 +489,6 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
           mid_mac(tid, h, z, acc);
         };
         part(Hr, z0);
-        __builtin_amdgcn_sched_barrier(0);     // (the next partition's 8 loads hoisted above this one's products: 5 spill slots)
-        part(Hr + kHPerPart, z1);
-        if (NP > 2) {
-          __builtin_amdgcn_sched_barrier(0);
-          part(Hr + 2 * kHPerPart, z2);
-        }
         mid_merge(tid, acc, mc, lds);
       }
 #pragma unroll

@@ -1262,21 +1262,26 @@ int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, in
       for (int i = 0; i < 8; ++i) z1[t][i] = z2[t][i] = C32{0.0f, 0.0f};
     for (int64_t j = j_lo - (NP - 1); j < j_hi; ++j) {
       const bool produce = j >= j_lo;
-      for (int t = 0; t < kThreads; ++t) load_block(t, g, xr, j, vin, arr(v[t]));
-      forward();
-      for (int t = 0; t < kThreads; ++t) {
-        mid_split(t, lds.data(), mc[t], arr(z0[t]));
+      for (int t = 0; t < kThreads; ++t) {       // the delayed partitions first, as the kernel does (same summation order)
+        C32 h[8];
+        for (int i = 0; i < 8; ++i) acc[t][i] = C32{0.0f, 0.0f};
         if (produce) {
-          C32 h[8];
-          for (int i = 0; i < 8; ++i) acc[t][i] = C32{0.0f, 0.0f};
-          for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(0, i, t)];
-          mid_mac(t, h, arr(z0[t]), arr(acc[t]));
           for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(1, i, t)];
           mid_mac(t, h, arr(z1[t]), arr(acc[t]));
           if (NP > 2) {
             for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(2, i, t)];
             mid_mac(t, h, arr(z2[t]), arr(acc[t]));
           }
+        }
+      }
+      for (int t = 0; t < kThreads; ++t) load_block(t, g, xr, j, vin, arr(v[t]));
+      forward();
+      for (int t = 0; t < kThreads; ++t) {
+        mid_split(t, lds.data(), mc[t], arr(z0[t]));
+        if (produce) {
+          C32 h[8];
+          for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(0, i, t)];
+          mid_mac(t, h, arr(z0[t]), arr(acc[t]));
         }
       }
       // (every thread has read its quads before any thread writes: on the device a thread rewrites only the cells it read)

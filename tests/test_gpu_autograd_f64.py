@@ -317,7 +317,9 @@ def test_griffinlim_training_path_matches_reference_composition_and_inference():
     import audio_amd.transforms as T
     n_fft, hop = 400, 100
     x = _noise(2, 3200, seed=6).double()
-    w = torch.hann_window(n_fft, dtype=torch.float64)
+    gl = T.GriffinLim(n_fft=n_fft, hop_length=hop, n_iter=3, momentum=0.9, rand_init=False, power=2.0, length=3200)
+    gl = gl.to(dtype=torch.float64, device="cuda")
+    w = gl.window.detach().cpu()             # the module's buffer (float32 values widened), as in the reference's own float64 tests
     spec = (torch.stft(x, n_fft, hop, n_fft, w, return_complex=True).abs() ** 2)
 
     def cpu_gl(sp):
@@ -335,8 +337,6 @@ def test_griffinlim_training_path_matches_reference_composition_and_inference():
     sc = spec.clone().requires_grad_()
     yc = cpu_gl(sc)
     (gc,) = torch.autograd.grad(yc.square().sum(), sc)
-    gl = T.GriffinLim(n_fft=n_fft, hop_length=hop, n_iter=3, momentum=0.9, rand_init=False, power=2.0, length=3200)
-    gl = gl.to(dtype=torch.float64, device="cuda")
     sd = spec.cuda().requires_grad_()
     yd = gl(sd)
     (gd,) = torch.autograd.grad(yd.square().sum(), sd)
