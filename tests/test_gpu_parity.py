@@ -888,14 +888,14 @@ def test_lfilter_autograd_vs_reference_gradients(name):
         exp = G[f"{name}/{key}"]
         assert got.shape == exp.shape
         assert peak_rel_err(got.cpu().numpy(), exp) <= 2e-4, key
-    # the thin dB caller is differentiable since round 2 (reference formula under autograd); the inverse STFT still
-    # refuses tensors that require grad
+    # the thin dB caller is differentiable since round 2 (reference formula under autograd), the inverse STFT since round 4
+    # (the adjoint-operator pair of _diff.py; gradcheck in tests/test_gpu_autograd_f64.py)
     import audio_amd.transforms as T
     db = T.AmplitudeToDB()(x.reshape(-1, x.shape[-1]).abs() + 1e-3)
     assert db.requires_grad
-    z = torch.zeros(1, 201, 5, dtype=torch.complex64, device="cuda", requires_grad=True)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        T.InverseSpectrogram(n_fft=400)(z)
+    z = torch.randn(1, 201, 5, dtype=torch.complex64, device="cuda", requires_grad=True)
+    w = T.InverseSpectrogram(n_fft=400)(z)
+    assert w.requires_grad and torch.autograd.grad(w.square().sum(), z)[0].shape == z.shape
 
 
 @pytest.mark.parametrize("shapes,mode", [(((3, 700), (3, 90)), "full"), (((2, 2, 5000), (1, 1, 400)), "same"),
