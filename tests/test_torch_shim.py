@@ -256,11 +256,12 @@ def test_round4_ops_reach_every_remaining_entry_point():
         p = mel(x)
         want = F.amplitude_to_DB(p, 10.0, 1e-10, 0.0, 80.0)
         pc = p.transpose(-1, -2).contiguous()
-        gm = torch.full((4,), float("-inf"), device=dev)
-        db = ops.amplitude_to_db(pc, 10.0, 1e-10, 0.0, gm, pc[0].numel())
-        got = ops.db_clamp(db, gm, pc[0].numel(), 80.0)
+        # a 3-D input is ONE item of (channel, freq, time) for the reference's cut-off (functional.py:393-402): one group
+        gm = torch.full((1,), float("-inf"), device=dev)
+        db = ops.amplitude_to_db(pc, 10.0, 1e-10, 0.0, gm, pc.numel())
+        got = ops.db_clamp(db, gm, pc.numel(), 80.0)
         assert torch.equal(got.transpose(-1, -2), want)
-        got2 = ops.amplitude_to_db_clamped(pc, 10.0, 1e-10, 0.0, gm, pc[0].numel(), 80.0)
+        got2 = ops.amplitude_to_db_clamped(pc, 10.0, 1e-10, 0.0, gm, pc.numel(), 80.0)
         assert torch.equal(got2, got)
         # --- float64 precision entries
         x64 = x[:2, :3000].double()
