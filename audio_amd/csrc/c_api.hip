@@ -17,9 +17,6 @@
 #include "fftconv.h"
 #include "fftconv_os.h"
 #include "fftconv_fdr.h"
-#ifndef AAMD_FDR_PIPE_DEFAULT
-#define AAMD_FDR_PIPE_DEFAULT 0
-#endif
 #include "istft.h"
 #include "kaldi_generic.h"
 #include "vocoder.h"
@@ -1492,21 +1489,14 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
                          fg.n_part, ya, tw, H);
       int64_t blocks = dev_props().cu_count;
       if (blocks > rows * fg.segs) blocks = rows * fg.segs;
-      // two walks of the same arithmetic: one spectrum buffer and 7 barriers per block, or two buffers with the inverse of block
-      // j between the same barriers as the forward of block j + 1 (4 barriers per block).  AAMD_FDR_PIPE=0 / 1 picks (A/B tool)
-      static const int fdr_pipe = [] { const char* e = std::getenv("AAMD_FDR_PIPE"); return e ? std::atoi(e) : AAMD_FDR_PIPE_DEFAULT; }();
-      const size_t lds_p = (size_t)fdr::kPipeLdsComplex * sizeof(fco::C32);
-#define AAMD_FDR(KERN, LDS)                                                                                   \
+#define AAMD_FDR(NP)                                                                                          \
       do {                                                                                                    \
-        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERN),                                     \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)));                \
-        hipLaunchKernelGGL(KERN, dim3((unsigned)blocks), dim3(fdr::kThreads), (LDS), s, fg, xa, tw, H, xmap, ymap, out);   \
+        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fdr::delay_line_kernel<NP>),               \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));                \
+        hipLaunchKernelGGL(fdr::delay_line_kernel<NP>, dim3((unsigned)blocks), dim3(fdr::kThreads), lds_r, s, \
+                           fg, xa, tw, H, xmap, ymap, out);                                                   \
       } while (0)
-      if (fdr_pipe) {
-        if (fg.n_part == 2) AAMD_FDR(fdr::delay_line_pipe_kernel<2>, lds_p); else AAMD_FDR(fdr::delay_line_pipe_kernel<3>, lds_p);
-      } else {
-        if (fg.n_part == 2) AAMD_FDR(fdr::delay_line_kernel<2>, lds_r); else AAMD_FDR(fdr::delay_line_kernel<3>, lds_r);
-      }
+      if (fg.n_part == 2) AAMD_FDR(2); else AAMD_FDR(3);
 #undef AAMD_FDR
       return launch_check();
     }

@@ -125,41 +125,19 @@ AAMD_HD void dft8(C32 (&v)[8]) {
   v[3] = cadd(e3, p3); v[7] = csub(e3, p3);
 }
 
-// two-level form of the pass-1 twiddles (the pipelined kernel has no room for the 57 KB table): t2l[a] = W^(64 a), a < 128,
-// t2l[128 + b] = W^b, b < 64; w, w^2, w^4 by look-up, the other powers by <= 2 chained products
-constexpr int kTwoLevel = 192;
-AAMD_HD void two_level_table(int tid, const C32* tw16k, C32* t2l) {
-  if (tid < 128) t2l[tid] = tw16k[2 * 64 * tid];
-  else if (tid < 192) t2l[tid] = tw16k[2 * (tid - 128)];
-}
-template <bool conj_w>
-AAMD_HD void mul_two_level8(C32 (&v)[8], const C32* t2l, int e) {      // v[k] *= W_M^(e k), 4 e < M
-  const C32 w1 = cmul(t2l[e >> 6], t2l[128 + (e & 63)]);
-  const C32 w2 = cmul(t2l[(2 * e) >> 6], t2l[128 + ((2 * e) & 63)]);
-  const C32 w4 = cmul(t2l[(4 * e) >> 6], t2l[128 + ((4 * e) & 63)]);
-  const C32 w3 = cmul(w1, w2), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
-  v[1] = fco::cmulc<conj_w>(v[1], w1); v[2] = fco::cmulc<conj_w>(v[2], w2); v[3] = fco::cmulc<conj_w>(v[3], w3);
-  v[4] = fco::cmulc<conj_w>(v[4], w4); v[5] = fco::cmulc<conj_w>(v[5], w5); v[6] = fco::cmulc<conj_w>(v[6], w6);
-  v[7] = fco::cmulc<conj_w>(v[7], w7);
-}
-
 // ---- pass 1 (length 8192, m = 1024): thread tid owns elements tid + 1024 r -- what a coalesced load of the block gives it ----
-template <bool TWO_LEVEL = false>
-AAMD_HD void first_pass_from_regs(int tid, C32 (&v)[8], C32* lds, const C32* tl) {   // TWO_LEVEL: tl = the two-level table
+AAMD_HD void first_pass_from_regs(int tid, C32 (&v)[8], C32* lds, const C32* tl) {
   dft8<false>(v);
   tid = fco::opaque(tid);
-  if (TWO_LEVEL) mul_two_level8<false>(v, tl, tid);
-  else mul_table8<false, 1024>(v, tl + kTw1 + tid);
+  mul_table8<false, 1024>(v, tl + kTw1 + tid);
   C32* cell = lds + pad(tid);                  // pad(tid + 1024 r) = pad(tid) + 1088 r; consecutive lanes, consecutive cells
   lds_write8<AAMD_FDR_STRIDE(1088)>(cell, v);
 }
-template <bool TWO_LEVEL = false>
 AAMD_HD void last_pass_to_regs(int tid, const C32* lds, const C32* tl, C32 (&v)[8]) {
   tid = fco::opaque(tid);
   const C32* cell = lds + pad(tid);
   lds_read8<AAMD_FDR_STRIDE(1088)>(cell, v);
-  if (TWO_LEVEL) mul_two_level8<true>(v, tl, tid);
-  else mul_table8<true, 1024>(v, tl + kTw1 + tid);
+  mul_table8<true, 1024>(v, tl + kTw1 + tid);
   dft8<true>(v);
 }
 
@@ -574,126 +552,11 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
     }
   }
 }
-// ---- the pipelined walk: TWO spectrum buffers, the inverse of block j between the same barriers as the forward of block j + 1 ----
-// The kernel above moves all 16 waves through read -> compute -> write between 7 barriers per block, so the LDS pipe (~5 us
-// per step) and the vector ALU (~5 us) take turns instead of overlapping (profiles/r04_f_*).  Here every barrier interval holds
-// two independent passes -- one on each buffer -- and a block costs 4 barriers:
-//   interval 1: forward pass 1 of block j (registers -> B)     | inverse length-16 and length-128... passes of block j - 1 (A, wave-local)
-//   interval 2: forward length-1024 pass (B)                    | inverse length-1024 pass (A)
-//   interval 3: forward length-128 / 16 / 2 passes (B, wave-local) | inverse pass 1 (A -> registers -> global memory)
-//   interval 4: middle step of block j on B (split, delay line, merge); then A and B swap roles
-// LDS: 2 x 69 632 B of data + the small tables (pass 1 forms its twiddles from the two-level table) = 148 976 B.
-constexpr int kPipeTabs = kTwoLevel + 7 * 128 + 7 * 16 + 7 * 2;     // two-level | pass 2 | pass 3 | pass 4
-constexpr int kPipeLdsComplex = 2 * kLdsData + kPipeTabs;
-template <int NP>
-__global__ void __launch_bounds__(kThreads, 4)
-delay_line_pipe_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ tw16k, const C32* __restrict__ H,
-                       const int64_t* __restrict__ x_row_of, const int64_t* __restrict__ y_row_of, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_fdr[];
-  C32* bufA = reinterpret_cast<C32*>(smem_fdr);
-  C32* bufB = bufA + kLdsData;
-  C32* t2l = bufA + 2 * kLdsData;
-  // passes 2 .. 4 address their tables as tl + kTw2 / kTw3 / kTw4: tl is placed so that those land behind the two-level table
-  C32* tabs = t2l + kTwoLevel;
-  const C32* tl = tabs - kTw2;
-  const int tid = threadIdx.x;
-  two_level_table(tid, tw16k, t2l);
-  for (int u = tid; u < kTwEnd - kTw2; u += kThreads) {
-    const int uu = u + kTw2;
-    int e;
-    if (uu < kTw3) { const int v = uu - kTw2, k = v / 128 + 1, j = v % 128; e = 8 * j * k; }
-    else if (uu < kTw4) { const int v = uu - kTw3, k = v / 16 + 1, j = v % 16; e = 64 * j * k; }
-    else { const int v = uu - kTw4, k = v / 2 + 1, j = v % 2; e = 512 * j * k; }
-    tabs[u] = tw16k[2 * e];
-  }
-  MidConst mc;
-  mid_init(tid, tw16k, mc);
-  __syncthreads();
-  const unsigned n_items = (unsigned)(g.rows * g.segs);
-#pragma unroll 1
-  for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int64_t row = (int64_t)(item / (unsigned)g.segs);
-    const int64_t j_lo = (int64_t)(item - (unsigned)row * (unsigned)g.segs) * g.seg_blocks;
-    const int64_t j_hi = j_lo + g.seg_blocks < g.n_blocks ? j_lo + g.seg_blocks : g.n_blocks;
-    const int64_t rx = x_row_of ? x_row_of[row] : row;
-    const float* xr = x + rx * g.nx;
-    const C32* Hr = H + (y_row_of ? y_row_of[row] : row) * NP * kHPerPart;
-    float* out_row = out + row * g.out_len;
-    const bool vin = (reinterpret_cast<uintptr_t>(xr + g.start) & 7) == 0;
-    const bool vout = (reinterpret_cast<uintptr_t>(out_row) & 7) == 0;
-    C32 z1[8], z2[8], acc[8], v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) z1[i] = z2[i] = acc[i] = C32{0.0f, 0.0f};
-    load_block(tid, g, xr, j_lo - (NP - 1), vin, v);
-    bool have_inv = false;                 // buffer A holds the merged spectrum of block j - 1
-    C32* A = bufA;
-    C32* B = bufB;
-#pragma unroll 1
-    for (int64_t j = j_lo - (NP - 1); j <= j_hi; ++j) {          // one extra turn drains the last inverse
-      const bool fwd = j < j_hi, produce = fwd && j >= j_lo;
-      // interval 1
-      if (fwd) first_pass_from_regs<true>(tid, v, B, t2l);
-      if (have_inv) {
-        C32 xx[8], nb[8];
-        pass_m2_inv_a(tid, A, xx);
-        swap_neighbour(xx, nb);
-        pass_m2_inv_b(tid, xx, nb, A, tl);
-        fco::wave_sync();
-        pass_m16<true>(tid, A, tl);
-      }
-      __syncthreads();
-      if (j + 1 < j_hi) load_block(tid, g, xr, j + 1, vin, v);    // in flight during intervals 2 .. 4
-      // interval 2
-      if (fwd) pass_m128<false>(tid, B, tl);
-      if (have_inv) pass_m128<true>(tid, A, tl);
-      __syncthreads();
-      // interval 3
-      if (fwd) {
-        pass_m16<false>(tid, B, tl);
-        fco::wave_sync();
-        C32 o[8], nb[8];
-        pass_m2_fwd_a(tid, B, tl, o);
-        swap_neighbour(o, nb);
-        pass_m2_fwd_b(tid, o, nb, B);
-      }
-      if (have_inv) {
-        C32 w[8];
-        last_pass_to_regs<true>(tid, A, t2l, w);
-        store_block(tid, g, w, j - 1, j_hi, vout, out_row);
-      }
-      __syncthreads();
-      // interval 4: the middle step of block j
-      if (fwd) {
-        C32 z0[8];
-        mid_split(tid, B, mc, z0);
-        if (produce) {
-          const unsigned lane = (unsigned)fco::opaque(tid);
-          C32 h[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) h[i] = (Hr + 1024 * i)[lane];
-          mid_mac(tid, h, z0, acc);
-          mid_merge(tid, acc, mc, B);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { z2[i] = z1[i]; z1[i] = z0[i]; acc[i] = C32{0.0f, 0.0f}; }
-        if (j + 1 < j_hi && j + 1 >= j_lo) {                      // the delayed partitions of the NEXT block (see the kernel above)
-          auto part_early = [&](const C32* Hp, const C32 (&z)[8]) {
-            const unsigned lane = (unsigned)fco::opaque(tid);
-            C32 h[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) h[i] = (Hp + 1024 * i)[lane];
-            mid_mac(tid, h, z, acc);
-          };
-          part_early(Hr + kHPerPart, z1);
-          if (NP > 2) part_early(Hr + 2 * kHPerPart, z2);
-        }
-      }
-      __syncthreads();
-      have_inv = produce;
-      C32* t = A; A = B; B = t;
-    }
-  }
-}
+// (Round 4 also built the PIPELINED walk -- two spectrum buffers, the inverse of block j between the same barriers as the forward
+// of block j + 1, 4 barriers per block instead of 7, pass-1 twiddles formed from a two-level table because the 57 KB table no
+// longer fits -- correct (3e-7 of the peak) and 10 % SLOWER on the cfg5b shard, 0.84-0.86 against 0.76-0.78 ms on the same box:
+// profiles/r04_g_fdr_pipelined_walk_ab.txt, code at commit b5384a0.  Two passes per barrier interval do not overlap better
+// than one, and the formed twiddles cost what the saved barriers gave.  Removed.)
 #endif  // __HIPCC__
 
 }  // namespace fdr

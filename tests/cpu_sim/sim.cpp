@@ -1204,7 +1204,7 @@ int sim_fftconv_os(const float* x, const float* y, float* out, int64_t rows, int
 // neighbour exchange of the radix-2 stage is the DPP swap of the device.  Returns 1 when the plan serves the shape, else 0.
 int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows, int64_t n_y_rows,
                     int64_t nx, int64_t ny, const int64_t* x_row_of, const int64_t* y_row_of, int64_t start,
-                    int64_t out_len, int cu_count, int two_level) {   // two_level: pass-1 twiddles as the pipelined kernel forms them
+                    int64_t out_len, int cu_count) {
   using namespace fdr;
   const bool swap = ny > nx;
   const float* xa = swap ? y : x; const float* ya = swap ? x : y;
@@ -1224,16 +1224,11 @@ int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, in
   for (int t = 0; t < kThreads; ++t) twiddle_tables(t, tw.data(), tl);
   std::vector<MidConst> mc(kThreads);
   for (int t = 0; t < kThreads; ++t) mid_init(t, tw.data(), mc[t]);
-  std::vector<C32> t2l(kTwoLevel);
-  for (int t = 0; t < kThreads; ++t) two_level_table(t, tw.data(), t2l.data());
   using A8 = std::array<C32, 8>;
   auto arr = [](A8& a) -> C32 (&)[8] { return *reinterpret_cast<C32 (*)[8]>(a.data()); };
   std::vector<A8> v(kThreads), o(kThreads), z0(kThreads), z1(kThreads), z2(kThreads), acc(kThreads);
   auto forward = [&]() {
-    for (int t = 0; t < kThreads; ++t) {
-      if (two_level) first_pass_from_regs<true>(t, arr(v[t]), lds.data(), t2l.data());
-      else first_pass_from_regs<false>(t, arr(v[t]), lds.data(), tl);
-    }
+    for (int t = 0; t < kThreads; ++t) first_pass_from_regs(t, arr(v[t]), lds.data(), tl);
     for (int t = 0; t < kThreads; ++t) pass_m128<false>(t, lds.data(), tl);
     for (int t = 0; t < kThreads; ++t) pass_m16<false>(t, lds.data(), tl);
     for (int t = 0; t < kThreads; ++t) pass_m2_fwd_a(t, lds.data(), tl, arr(o[t]));
@@ -1244,10 +1239,7 @@ int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, in
     for (int t = 0; t < kThreads; ++t) pass_m2_inv_b(t, arr(o[t]), arr(o[t ^ 1]), lds.data(), tl);
     for (int t = 0; t < kThreads; ++t) pass_m16<true>(t, lds.data(), tl);
     for (int t = 0; t < kThreads; ++t) pass_m128<true>(t, lds.data(), tl);
-    for (int t = 0; t < kThreads; ++t) {
-      if (two_level) last_pass_to_regs<true>(t, lds.data(), t2l.data(), arr(v[t]));
-      else last_pass_to_regs<false>(t, lds.data(), tl, arr(v[t]));
-    }
+    for (int t = 0; t < kThreads; ++t) last_pass_to_regs(t, lds.data(), tl, arr(v[t]));
   };
   for (int64_t b = 0; b < tap_rows * NP; ++b) {
     const int64_t yrow = b / NP; const int p = (int)(b - yrow * NP);

@@ -290,7 +290,7 @@ def sim_fftconv_os(x, y, start, out_len, xmap=None, ymap=None, rows=None, cu_cou
     return out
 
 
-def sim_fftconv_fdr(x, y, start, out_len, xmap=None, ymap=None, rows=None, cu_count=256, two_level=False):
+def sim_fftconv_fdr(x, y, start, out_len, xmap=None, ymap=None, rows=None, cu_count=256):
     """The real-block delay line (csrc/fftconv_fdr.h, plan 3 of aamd_fftconvolve_f32), replayed; None when the plan does
     not serve the shape."""
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -299,10 +299,10 @@ def sim_fftconv_fdr(x, y, start, out_len, xmap=None, ymap=None, rows=None, cu_co
     rows = rows if rows is not None else x.shape[0]
     out = np.full((rows, out_len), np.nan, dtype=np.float32)
     f = sim().sim_fftconv_fdr
-    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 5 + [C.c_void_p] * 2 + [C.c_int64] * 2 + [C.c_int, C.c_int]
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 5 + [C.c_void_p] * 2 + [C.c_int64] * 2 + [C.c_int]
     xm = None if xmap is None else fptr(np.ascontiguousarray(xmap, dtype=np.int64))
     ym = None if ymap is None else fptr(np.ascontiguousarray(ymap, dtype=np.int64))
-    rc = f(fptr(x), fptr(y), fptr(out), rows, x.shape[0], y.shape[0], nx, ny, xm, ym, start, out_len, cu_count, int(two_level))
+    rc = f(fptr(x), fptr(y), fptr(out), rows, x.shape[0], y.shape[0], nx, ny, xm, ym, start, out_len, cu_count)
     return out if rc == 1 else None
 
 
