@@ -520,19 +520,16 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
         if (NP > 2) part_early(Hr + 2 * kHPerPart, z2);
       }
       forward_block(tid, v, lds, tl);
+      C32 h0[8];                           // H_0 of this thread's bins: requested before the split reads LDS (an L2 round trip)
+      if (produce) {
+        const unsigned lane = (unsigned)fco::opaque(tid);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h0[i] = (Hr + 1024 * i)[lane];
+      }
       C32 z0[8];
       mid_split(tid, lds, mc, z0);
       if (produce) {
-        // one partition at a time: a uniform base (SGPRs) + ONE lane offset that the optimiser may not hoist (opaque) -- 24
-        // hoisted 64-bit element addresses were the spills of the first build
-        auto part = [&](const C32* Hp, const C32 (&z)[8]) {
-          const unsigned lane = (unsigned)fco::opaque(tid);
-          C32 h[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) h[i] = (Hp + 1024 * i)[lane];
-          mid_mac(tid, h, z, acc);
-        };
-        part(Hr, z0);
+        mid_mac(tid, h0, z0, acc);
         mid_merge(tid, acc, mc, lds);
       }
 #pragma unroll
