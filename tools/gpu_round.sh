@@ -3,6 +3,7 @@
 #     bash tools/gpu_round.sh <tag> <step> [<step> ...]
 # writes everything under gpurun_out/<tag>/ (copy what should be judged into profiles/).  Steps:
 #   tests            the whole `pytest -m gpu` suite                      -> pytest.log
+#   tests_reverse / tests_serialize   the suite in reverse order / under AMD_SERIALIZE_KERNEL=3 -> pytest_reverse.log / pytest_serialize.log
 #   tests:<expr>     `pytest -m gpu -k <expr>`                            -> pytest_k.log
 #   smoke            __graft_entry__.smoke()                              -> smoke.log
 #   bench            bench.py with its defaults (all configs, PMC passes, CPU baseline)   -> bench.json
@@ -23,6 +24,8 @@ export TMPDIR=/tmp
 for step in "$@"; do
   case "$step" in
     tests) timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -4 $O/pytest.log ;;
+    tests_reverse) timeout 1500 python -m pytest tests -m gpu -x -q --reverse-order > $O/pytest_reverse.log 2>&1; echo "pytest rc=$?" >> $O/pytest_reverse.log; tail -3 $O/pytest_reverse.log ;;
+    tests_serialize) AMD_SERIALIZE_KERNEL=3 timeout 1800 python -m pytest tests -m gpu -x -q > $O/pytest_serialize.log 2>&1; echo "pytest rc=$?" >> $O/pytest_serialize.log; tail -3 $O/pytest_serialize.log ;;
     tests:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${step#tests:}" > $O/pytest_k.log 2>&1; echo "pytest rc=$?" >> $O/pytest_k.log; tail -15 $O/pytest_k.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log; tail -2 $O/smoke.log ;;
     bench) timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "rc=$?" >> $O/bench.err; cat $O/bench.json; tail -3 $O/bench.err ;;
