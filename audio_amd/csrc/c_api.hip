@@ -1482,7 +1482,7 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
       // real blocks of 16384 samples as 8192-point complex FFTs, the delay line in registers (fftconv_fdr.h).  The tap spectra
       // (8192 complex per partition) fit the space the workspace reserves for the complex-block plans (16384 per partition).
       const size_t lds_r = (size_t)fdr::kLdsComplex * sizeof(fco::C32);
-      AAMD_CHECK_ARG(tap_rows * fg.n_part < (1ll << 31), "too many tap rows");
+      AAMD_CHECK_ARG(tap_rows * fg.n_part < (1ll << 31) && rows * fg.segs < (1ll << 31), "too many tap rows / work items");
       AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fdr::spectrum_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
       hipLaunchKernelGGL(fdr::spectrum_kernel, dim3((unsigned)(tap_rows * fg.n_part)), dim3(fdr::kThreads), lds_r, s, nya,
@@ -1496,7 +1496,7 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
         hipLaunchKernelGGL(fdr::delay_line_kernel<NP>, dim3((unsigned)blocks), dim3(fdr::kThreads), lds_r, s, \
                            fg, xa, tw, H, xmap, ymap, out);                                                   \
       } while (0)
-      if (fg.n_part == 2) AAMD_FDR(2); else AAMD_FDR(3);
+      if (fg.n_part == 1) AAMD_FDR(1); else if (fg.n_part == 2) AAMD_FDR(2); else AAMD_FDR(3);
 #undef AAMD_FDR
       return launch_check();
     }

@@ -1,5 +1,5 @@
-// F.fftconvolve for 8193 .. 24576 taps (0.17 .. 0.5 s impulse responses at 48 kHz; BASELINE config 5b): the frequency-domain
-// delay line on REAL blocks, the whole state of a row on one CU (functional/functional.py:2252-2258 computes
+// F.fftconvolve for 193 .. 24576 taps (4 ms .. 0.5 s impulse responses at 48 kHz; BASELINE config 5b): overlap-save and, beyond
+// 8192 taps, the frequency-domain delay line on REAL blocks, the whole state of a row on one CU (functional/functional.py:2252-2258 computes
 // irfft(rfft(x) * rfft(y)); the contract is the linear convolution, so block-wise FFTs of another length are free).
 //
 // What it replaces (fco::overlap_save_fdl_kernel, fftconv_os.h): a 16384-point COMPLEX FFT in LDS (two real blocks per
@@ -32,7 +32,7 @@ namespace fdr {
 using fco::C32;
 constexpr int kM = 8192;                   // complex FFT length
 constexpr int kN = 16384;                  // real samples per block
-constexpr int kHop = 8192;                 // outputs per block = taps per partition
+constexpr int kHop = 8192;                 // taps per partition; outputs per block of the 2 / 3-partition delay line
 constexpr int kThreads = 1024;
 constexpr int kMaxParts = 3;               // Z_j in flight + two delayed spectra in registers
 AAMD_HD int pad(int i) { return i + ((i >> 5) << 1); }            // 2 complex per 32: see the bank notes at each pass
@@ -333,20 +333,28 @@ AAMD_HD int64_t h_index(int p, int i, int tid) { return ((int64_t)p * 8 + i) * k
 constexpr int64_t kHPerPart = 8 * kThreads;            // complex numbers per partition (= 8192)
 
 // ---- geometry --------------------------------------------------------------------------------------------------------
+// Block j covers outputs [j hop, (j + 1) hop) of the slice; its 16384 input samples start at  start + j hop - skip, and sample
+// i >= skip of the transformed block is output j hop + (i - skip):
+//   2 / 3 partitions of 8192 taps: hop = skip = 8192 (the delay line needs hop = partition length);
+//   1 partition (<= 8192 taps):    skip = taps - 1, hop = 16384 - skip -- every sample the circular convolution leaves valid
 struct Geom {
   int64_t rows, nx, ny, start, out_len;
-  int n_part;              // ceil(ny / kHop): 2 or 3
+  int n_part;              // 1 .. 3
+  int hop, skip;
   int segs;                // segments per row (one work item each)
-  int64_t n_blocks;        // ceil(out_len / kHop)
+  int64_t n_blocks;        // ceil(out_len / hop)
   int64_t seg_blocks;      // blocks per segment (the last may be shorter)
 };
 // cost = steps on the busiest workgroup (a forward-only warm-up step counts half); returns false when the shape is not served
 AAMD_HD bool plan(int64_t rows, int64_t ny, int64_t out_len, int cu_count, Geom& g) {
   g.n_part = (int)((ny + kHop - 1) / kHop);
-  g.n_blocks = (out_len + kHop - 1) / kHop;
+  if (g.n_part < 1 || g.n_part > kMaxParts || ny < 2) return false;
+  g.skip = g.n_part == 1 ? (int)ny - 1 : kHop;
+  g.hop = kN - g.skip;
+  g.n_blocks = (out_len + g.hop - 1) / g.hop;
   g.segs = 1;
   g.seg_blocks = g.n_blocks;
-  if (g.n_part < 2 || g.n_part > kMaxParts || rows < 1 || g.n_blocks < 1 || cu_count < 1) return false;
+  if (rows < 1 || g.n_blocks < 1 || cu_count < 1) return false;
   int64_t best = -1;
   for (int segs = 1; segs <= 1024 && segs <= g.n_blocks; ++segs) {
     const int64_t sb = (g.n_blocks + segs - 1) / segs;
@@ -356,14 +364,13 @@ AAMD_HD bool plan(int64_t rows, int64_t ny, int64_t out_len, int cu_count, Geom&
   }
   return true;
 }
-// block j covers outputs [(j) kHop, (j + 1) kHop) of the slice... as in fco: its input segment starts at
-AAMD_HD int64_t seg_start(const Geom& g, int64_t j) { return g.start + (j - 1) * (int64_t)kHop; }
+AAMD_HD int64_t seg_start(const Geom& g, int64_t j) { return g.start + j * (int64_t)g.hop - g.skip; }
 
 // inputs of block j: z[n] = (x[s0 + 2 n], x[s0 + 2 n + 1]) for n = tid + 1024 r; zeros outside [0, nx)
 AAMD_HD void load_block(int tid, const Geom& g, const float* xr, int64_t j, bool vec_ok, C32 (&v)[8]) {
   const int64_t s0 = seg_start(g, j);
   const unsigned lane = (unsigned)fco::opaque(tid);
-  if (vec_ok && s0 >= 0 && s0 + kN <= g.nx) {            // interior block on an 8-byte aligned row offset (uniform branch)
+  if (vec_ok && !(s0 & 1) && s0 >= 0 && s0 + kN <= g.nx) {     // interior block on an 8-byte aligned offset (uniform branch)
     const C32* p = reinterpret_cast<const C32*>(xr + s0);
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = (p + 1024 * r)[lane];
@@ -376,22 +383,29 @@ AAMD_HD void load_block(int tid, const Geom& g, const float* xr, int64_t j, bool
     v[r].y = (i + 1 >= 0 && i + 1 < g.nx) ? xr[i + 1] : 0.0f;
   }
 }
-// outputs of block j: sample 2 n (+ 1) of the block, n >= 4096, is output (j - 1) kHop + 2 n (+ 1) of the slice
+// outputs of block j: sample i = 2 n (+ 1) >= skip of the block is output j hop + i - skip of the slice.  vec_ok: the ROW starts
+// on an even float offset; a pair (2 n, 2 n + 1) is then one 8-byte store when skip and j hop are even
 AAMD_HD void store_block(int tid, const Geom& g, const C32 (&v)[8], int64_t j, int64_t j_hi, bool vec_ok, float* out_row) {
   if (j >= j_hi) return;
   const unsigned lane = (unsigned)fco::opaque(tid);
-  const int64_t o0 = (j - 1) * (int64_t)kHop;
-  if (vec_ok && o0 + kN <= g.out_len) {
+  const int64_t o0 = j * (int64_t)g.hop - g.skip;              // output index of block sample 0 (may be negative)
+  if (g.skip == kHop && vec_ok && o0 + kN <= g.out_len) {       // delay-line blocks: the upper half, aligned, inside the row
     C32* p = reinterpret_cast<C32*>(out_row + o0);
 #pragma unroll
     for (int r = 4; r < 8; ++r) (p + 1024 * r)[lane] = v[r];
     return;
   }
+  const bool pair_ok = vec_ok && !(o0 & 1);
 #pragma unroll
-  for (int r = 4; r < 8; ++r) {
-    const int64_t o = o0 + 2 * ((int64_t)lane + 1024 * r);
-    if (o < g.out_len) out_row[o] = v[r].x;
-    if (o + 1 < g.out_len) out_row[o + 1] = v[r].y;
+  for (int r = 0; r < 8; ++r) {
+    const int i = 2 * ((int)lane + 1024 * r);
+    const int64_t o = o0 + i;
+    if (pair_ok && i >= g.skip && o + 1 < g.out_len) {
+      *reinterpret_cast<C32*>(out_row + o) = v[r];
+    } else {
+      if (i >= g.skip && o < g.out_len) out_row[o] = v[r].x;
+      if (i + 1 >= g.skip && o + 1 < g.out_len) out_row[o + 1] = v[r].y;
+    }
   }
 }
 // taps of partition p of one y row as the packed real block (imaginary lane = odd samples)
@@ -493,7 +507,7 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
     const C32* Hr = H + (y_row_of ? y_row_of[row] : row) * NP * kHPerPart;
     float* out_row = out + row * g.out_len;
     // 8-byte paths: the row's first sample / first output on an even float offset (block starts are multiples of 8192)
-    const bool vin = (reinterpret_cast<uintptr_t>(xr + g.start) & 7) == 0;
+    const bool vin = (reinterpret_cast<uintptr_t>(xr) & 7) == 0;        // (load_block adds the parity of the block's own offset)
     const bool vout = (reinterpret_cast<uintptr_t>(out_row) & 7) == 0;
     C32 z1[8], z2[8];                      // Z_(j-1), Z_(j-2): this thread's 8 bins
 #pragma unroll
@@ -516,7 +530,7 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
           for (int i = 0; i < 8; ++i) h[i] = (Hp + 1024 * i)[lane];
           mid_mac(tid, h, z, acc);
         };
-        part_early(Hr + kHPerPart, z1);
+        if (NP > 1) part_early(Hr + kHPerPart, z1);
         if (NP > 2) part_early(Hr + 2 * kHPerPart, z2);
       }
       forward_block(tid, v, lds, tl);

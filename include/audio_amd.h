@@ -402,8 +402,9 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
  * aamd_fftconvolve_plan reports what a call of that shape runs on the current device: 0 time domain, 1 overlap-save
  * with the input spectrum recomputed per tap partition, 2 overlap-save with a frequency-domain delay line (uniform
  * 8192-tap partitions, one forward + one inverse FFT per block; chosen by a cost model over rows, blocks and CUs),
- * 3 (8193 .. 24576 taps) the delay line on REAL blocks: 8192-point complex FFTs, the delayed spectra in registers,
- * one row per workgroup of 1024 threads (csrc/fftconv_fdr.h). */
+ * 3 (193 .. 24576 taps, the default) REAL blocks as 8192-point complex FFTs, one row per workgroup of 1024 threads
+ * (csrc/fftconv_fdr.h): plain overlap-save up to 8192 taps (hop = 16385 - taps), beyond that the delay line over 8192-tap
+ * partitions with the delayed spectra in registers. */
 int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_rows, int64_t nx, int64_t ny);
 int aamd_fftconvolve_plan(int64_t rows, int64_t nx, int64_t ny, int64_t out_len);
 int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows,

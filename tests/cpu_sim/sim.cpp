@@ -1257,7 +1257,7 @@ int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, in
     const int64_t rx = xmap ? xmap[row] : row, ry = ymap ? ymap[row] : row;
     const float* xr = xa + rx * g.nx;
     const C32* Hr = H.data() + ry * NP * kHPerPart;
-    const bool vin = ((rx * g.nx + g.start) & 1) == 0, vout = ((row * out_len) & 1) == 0;   // what 8-byte alignment means here
+    const bool vin = ((rx * g.nx) & 1) == 0, vout = ((row * out_len) & 1) == 0;   // what 8-byte alignment of a row means here
     for (int t = 0; t < kThreads; ++t)
       for (int i = 0; i < 8; ++i) z1[t][i] = z2[t][i] = C32{0.0f, 0.0f};
     for (int64_t j = j_lo - (NP - 1); j < j_hi; ++j) {
@@ -1266,8 +1266,10 @@ int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, in
         C32 h[8];
         for (int i = 0; i < 8; ++i) acc[t][i] = C32{0.0f, 0.0f};
         if (produce) {
-          for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(1, i, t)];
-          mid_mac(t, h, arr(z1[t]), arr(acc[t]));
+          if (NP > 1) {
+            for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(1, i, t)];
+            mid_mac(t, h, arr(z1[t]), arr(acc[t]));
+          }
           if (NP > 2) {
             for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(2, i, t)];
             mid_mac(t, h, arr(z2[t]), arr(acc[t]));

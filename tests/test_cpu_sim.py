@@ -384,7 +384,11 @@ def test_sim_fftconvolve_real_block_delay_line(nx, ny, mode, cus):
     got = S.sim_fftconv_fdr(x, y, start, out_len, ymap=np.zeros(2, dtype=np.int64), rows=2, cu_count=cus)
     assert got is not None and not np.isnan(got).any()
     assert peak_rel_err(got, exp) <= 2e-6
-    assert S.sim_fftconv_fdr(x, y[:, :8000], 0, nx + 7999, ymap=np.zeros(2, dtype=np.int64), rows=2) is None     # <= 8192 taps
+    # one partition (<= 8192 taps): plain overlap-save on the same kernel, hop = 16384 - (taps - 1); odd and even tap counts
+    for taps in (8000, 701):
+        e1 = O.fftconvolve(x.astype(np.float64), np.broadcast_to(y[:, :taps], (2, taps)).astype(np.float64), "full")
+        g1 = S.sim_fftconv_fdr(x, y[:, :taps], 0, nx + taps - 1, ymap=np.zeros(2, dtype=np.int64), rows=2, cu_count=cus)
+        assert g1 is not None and peak_rel_err(g1, e1) <= 2e-6, taps
     if nx >= 30000:
         assert S.sim_fftconv_fdr(x[:, :30000], rng.standard_normal((1, 24577)).astype(np.float32), 0, 30000 + 24576,
                                  ymap=np.zeros(2, dtype=np.int64), rows=2) is None                                # > 24576 taps

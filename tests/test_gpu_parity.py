@@ -398,7 +398,7 @@ def test_fftconvolve_delay_line_plan_against_oracle(case):
     own = F.fftconvolve(xd, yd, mode)
     plan = _lib.lib().aamd_fftconvolve_plan(rows, xs[-1], ys[-1], exp.shape[-1])
     # default: the real-block delay line of round 4 (plan 3) serves 8193 .. 24576 taps, the complex plans the rest
-    assert plan == (3 if 8192 < ys[-1] <= 24576 else cplan)
+    assert plan == (3 if 192 < ys[-1] <= 24576 else cplan)
     assert fdl.shape == exp.shape == own.shape
     assert peak_rel_err(fdl.cpu().numpy(), exp) <= 1e-5
     assert peak_rel_err(rec.cpu().numpy(), exp) <= 1e-5
@@ -407,7 +407,9 @@ def test_fftconvolve_delay_line_plan_against_oracle(case):
         assert torch.equal(own, cown)
 
 
-@pytest.mark.parametrize("case", [((3, 50001), (1, 8193), "full"), ((2, 3, 33333), (2, 3, 12345), "same"),
+@pytest.mark.parametrize("case", [((4, 60001), (1, 193), "full"), ((2, 2, 50000), (2, 2, 2400), "same"), ((3, 40000), (3, 8192), "valid"),
+                                  ((6, 20001), (1, 4001), "full"),
+                                  ((3, 50001), (1, 8193), "full"), ((2, 3, 33333), (2, 3, 12345), "same"),
                                   ((5, 70001), (5, 24576), "valid"), ((1, 200000), (1, 17000), "full"),
                                   ((7, 16385), (1, 16384), "full"), ((2, 9000), (2, 8500), "full")])
 def test_fftconvolve_real_block_delay_line_edges(case):

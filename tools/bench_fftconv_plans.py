@@ -23,15 +23,16 @@ def timed(fn, warmup=3, steps=10):
     return e0.elapsed_time(e1) / steps
 
 
-cases = [((256, 480000), 9000), ((256, 480000), 12000), ((256, 480000), 16000), ((256, 480000), 24000), ((256, 480000), 30000),
+cases = [((256, 480000), 700), ((256, 480000), 2400), ((256, 480000), 8192), ((256, 480000), 9000), ((256, 480000), 12000), ((256, 480000), 16000), ((256, 480000), 24000), ((256, 480000), 30000),
          ((32, 480000), 24000), ((8, 1920000), 24000), ((1024, 120000), 24000), ((256, 100000), 24000)]
 with torch.no_grad():
     for (rows, nx), taps in cases:
         x = torch.rand(rows, nx, device=dev) - 0.5
         h = torch.randn(1, taps, device=dev) * 0.01
         rec = {"rows": rows, "nx": nx, "taps": taps}
-        with _lib.kernel_policy(_lib.POLICY_FFTCONV_FDL):
-            rec["delay_line_ms"] = round(timed(lambda: F.fftconvolve(x, h)), 4)
+        if taps > 8192:
+            with _lib.kernel_policy(_lib.POLICY_FFTCONV_FDL):
+                rec["delay_line_ms"] = round(timed(lambda: F.fftconvolve(x, h)), 4)
         with _lib.kernel_policy(_lib.POLICY_FFTCONV_NO_FDL):
             rec["recompute_ms"] = round(timed(lambda: F.fftconvolve(x, h)), 4)
         rec["default_ms"] = round(timed(lambda: F.fftconvolve(x, h)), 4)
