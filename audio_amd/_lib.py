@@ -103,7 +103,6 @@ _SIGS = {
     "aamd_mfcc_fused_tiles": (C.c_int64, [C.POINTER(StftDesc)]),
     "aamd_mfcc_fused_supported": (C.c_int, [C.POINTER(StftDesc), C.POINTER(MelBands), C.c_int32]),
     "aamd_mfcc_frag_build": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
-    "aamd_mfcc_fused_sync_floats": (C.c_int32, []),
     "aamd_mfcc_fused_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), C.POINTER(MfccFused), _P]),
     "aamd_resample_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int64, _P]),
@@ -146,7 +145,7 @@ def lib():
                 fn = getattr(h, name)   # AttributeError if the ABI symbol is missing
                 fn.restype = res
                 fn.argtypes = args
-            if h.aamd_abi_version() != 6:
+            if h.aamd_abi_version() != 5:
                 raise RuntimeError("audio_amd: ABI version mismatch between _lib.py and libaudio_amd.so")
             _lib = h
     return _lib
@@ -154,7 +153,6 @@ def lib():
 
 POLICY_FORCE_GENERIC, POLICY_MEL400_WIDE, POLICY_ISTFT_ATOMIC, POLICY_RESAMPLE_FP32 = 1, 2, 4, 8
 POLICY_FFTCONV_NO_FDL, POLICY_FFTCONV_FDL, POLICY_FFTCONV_COMPLEX = 16, 32, 64
-POLICY_MFCC_THREE_LAUNCHES = 128
 
 
 class kernel_policy:

@@ -46,7 +46,7 @@ def load():
             torch.ops.load_library(SHIM_PATH)
             h = C.CDLL(SHIM_PATH)
             h.aamd_torch_shim_abi.restype = C.c_int
-            if h.aamd_torch_shim_abi() != 6:
+            if h.aamd_torch_shim_abi() != 5:
                 raise RuntimeError("audio_amd: ABI version mismatch between the torch shim and include/audio_amd.h")
             _register_fakes()
             _handle = h

@@ -72,7 +72,6 @@ int policy() {
     if (std::getenv("AAMD_RESAMPLE_FP32") != nullptr) p |= AAMD_POLICY_RESAMPLE_FP32;
     if (std::getenv("AAMD_FFTCONV_NO_FDL") != nullptr) p |= AAMD_POLICY_FFTCONV_NO_FDL;
     if (std::getenv("AAMD_FFTCONV_FDL") != nullptr) p |= AAMD_POLICY_FFTCONV_FDL;
-    if (std::getenv("AAMD_MFCC_THREE_LAUNCHES") != nullptr) p |= AAMD_POLICY_MFCC_THREE_LAUNCHES;
     int expected = -1;
     g_policy.compare_exchange_strong(expected, p);
     p = g_policy.load(std::memory_order_relaxed);
@@ -356,7 +355,7 @@ int aamd_set_kernel_policy(int flags) {
   const int prev = policy();
   if (flags >= 0) g_policy.store(flags & (AAMD_POLICY_FORCE_GENERIC | AAMD_POLICY_MEL400_WIDE | AAMD_POLICY_ISTFT_ATOMIC |
                                           AAMD_POLICY_RESAMPLE_FP32 | AAMD_POLICY_FFTCONV_NO_FDL | AAMD_POLICY_FFTCONV_FDL |
-                                          AAMD_POLICY_FFTCONV_COMPLEX | AAMD_POLICY_MFCC_THREE_LAUNCHES));
+                                          AAMD_POLICY_FFTCONV_COMPLEX));
   return prev;
 }
 
@@ -471,10 +470,6 @@ bool mfcc_fused_ok(const StftGeom& g, const MelBandsDev& mb, int n_mfcc) {
 
 int32_t aamd_mfcc_frag_floats(void) { return m400::kMfccFragFloats; }
 
-// pass 2: floats behind the group maxima (the barrier's arrival counter, one 128-byte flag line and one census line per
-// workgroup of the grid)
-int32_t aamd_mfcc_fused_sync_floats(void) { return m400::kMfccFlagStride * (1 + 2 * dev_props().cu_count); }
-
 int64_t aamd_mfcc_fused_tiles(const aamd_stft_desc* desc) {
   StftGeom g;
   if (validate_desc(desc, g) != AAMD_OK) return -1;
@@ -497,59 +492,15 @@ int aamd_mfcc_frag_build(const float* dct, int32_t n_mels, int32_t n_mfcc, float
   return launch_check();
 }
 
-}  // extern "C"
-
-namespace {
-// The one-launch form of the fused MFCC holds every CU until all of its workgroups have arrived at an in-kernel barrier.  Two
-// such launches dispatched side by side from different streams could each hold half of the chip and wait for the other half
-// for ever, so the library lets a stream take the one-launch form only when the stream that last took it on this device has
-// drained (or is the same stream: launches of one stream run in order); otherwise that call runs as three launches.  A stream
-// under capture always runs three launches (a graph replays on any stream at any time).
-bool mfcc_one_launch_allowed(hipStream_t s) {
-  if (policy() & AAMD_POLICY_MFCC_THREE_LAUNCHES) return false;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return false;
-  }
-  static std::mutex mu;
-  static hipStream_t last[64];
-  static bool have[64];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64) return false;
-  std::lock_guard<std::mutex> lock(mu);
-  if (have[dev] && last[dev] != s) {
-    const hipError_t q = hipStreamQuery(last[dev]);
-    if (q == hipErrorNotReady) return false;             // the other stream may still be inside its barrier
-    if (q != hipSuccess) (void)hipGetLastError();        // (a destroyed stream: nothing of it is running any more)
-  }
-  have[dev] = true;
-  last[dev] = s;
-  return true;
-}
-}  // namespace
-
-extern "C" {
-
 int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twiddle, const aamd_mel_bands* bands,
                         float* out, const aamd_stft_desc* desc, const aamd_mfcc_fused* f, void* stream) {
   DeviceScope dev_scope_(wav);
-  if (f != nullptr && f->pass == 2 && !mfcc_one_launch_allowed((hipStream_t)stream)) {
-    // pass 2 = "both passes, nothing in between": the same three launches the caller would issue itself
-    aamd_mfcc_fused g = *f;
-    g.pass = 0;
-    const int rc0 = aamd_mfcc_fused_f32(wav, window, twiddle, bands, out, desc, &g, stream);
-    if (rc0 != AAMD_OK) return rc0;
-    g.pass = 1;
-    return aamd_mfcc_fused_f32(wav, window, twiddle, bands, out, desc, &g, stream);
-  }
   StftGeom g;
   int rc = validate_desc(desc, g);
   if (rc != AAMD_OK) return rc;
   AAMD_CHECK_ARG(wav && window && twiddle && out && f, "null buffer");
   AAMD_CHECK_ARG(f->dct_frag && f->group_max && f->tile_min, "the fused MFCC needs dct_frag, group_max and tile_min");
-  AAMD_CHECK_ARG(f->rows_per_group >= 1 && f->pass >= 0 && f->pass <= 2, "bad rows_per_group / pass");
+  AAMD_CHECK_ARG(f->rows_per_group >= 1 && (f->pass == 0 || f->pass == 1), "bad rows_per_group / pass");
   AAMD_CHECK_ARG(f->fix_count != nullptr, "the fused MFCC needs fix_count in both passes (pass 0 resets it)");
   AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(out) % 16 == 0 && reinterpret_cast<uintptr_t>(f->dct_frag) % 16 == 0,
                  "out and dct_frag must be 16-byte aligned");
@@ -564,15 +515,6 @@ int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twid
   epi.group_max = f->group_max; epi.rows_per_group = f->rows_per_group;
   epi.dct_frag = f->dct_frag; epi.n_mfcc = f->n_mfcc; epi.top_db = f->top_db; epi.tile_min = f->tile_min;
   epi.fix_count = f->fix_count; epi.fixup = f->pass; epi.fix_list = f->tile_list;
-  if (f->pass == 2) {
-    // one launch: the word behind the group maxima is the arrival counter of the in-kernel grid barrier, one flag line per
-    // workgroup follows (aamd_mfcc_fused_sync_floats); the caller's fill of group_max (-inf) covers them, so their rest
-    // value is that bit pattern
-    AAMD_CHECK_ARG(f->tile_list != nullptr, "pass 2 of the fused MFCC needs tile_list");
-    const int64_t n_groups = (g.rows + f->rows_per_group - 1) / f->rows_per_group;
-    epi.arrive = reinterpret_cast<int*>(f->group_max + n_groups);
-    epi.arrive_base = (int)0xff800000u;
-  }
   if (f->pass == 1) {
     // compact the tiles under their group's cut-off (known now: the caller reduced group_max over ranks between the passes)
     AAMD_CHECK_ARG(f->fix_count && f->tile_list, "pass 1 of the fused MFCC needs fix_count and tile_list");

@@ -164,15 +164,11 @@ struct Epi400 {
   int n_mfcc;                       // MFCC: coefficients (<= 48, multiple of 4)
   float top_db;                     // MFCC fix-up: cut-off = group_max[g] - top_db
   float* tile_min;                  // MFCC: [n_tiles] minimum dB value of each tile (written by pass 0, read by the fix-up)
-  int* fix_count;                   // MFCC fix-up: number of tiles to redo = entries of fix_list (written by mfcc_fix_list_kernel;
-                                    //   fixup 2: summed by the workgroups themselves)
-  int* fix_list;                    // MFCC fix-up: the tiles under the cut-off, compacted (any order); fixup 2: [n_tiles] scratch,
-                                    //   every workgroup keeps the list of ITS flagged tiles in a private run of it
-  int* arrive;                      // MFCC fixup 2: arrival counter of the in-kernel grid barrier; holds `arrive_base` at launch
-  int arrive_base;                  //   (any value: the caller's ONE fill of group_max covers the word -- the bit pattern of -inf)
+  int* fix_count;                   // MFCC fix-up: number of tiles to redo = entries of fix_list (written by mfcc_fix_list_kernel)
+  const int* fix_list;              // MFCC fix-up: the tiles under the cut-off, compacted (any order)
   int frag_in_lds;                  // MFCC: the workgroup's LDS has room for the fragment table (hop 100 / 160; not hop 200)
-  int fixup;                        // MFCC: 0 = first pass, 1 = fix-up pass, 2 = both in ONE launch (grid barrier in between)
-  int lab;                          // MFCC (tools only): 1 no fragment loads, 2 no MFMA, 4 no tile minimum, 8 no stores, 16 one-launch form with plain first-pass stores (timing only: wrong when another XCD redoes a tile), 32 nothing
+  int fixup;                        // MFCC: 0 = first pass, 1 = fix-up pass
+  int lab;                          // MFCC (tools only): 1 no fragment loads, 2 no MFMA, 4 no tile minimum, 8 no stores
 };
 constexpr int kSpecBins = 201;
 static_assert(kFramesPerWave * kSpecBins + 3 <= kSOff && 3 * 2 * kSpecBins + 3 <= kSOff, "SPEC rows must fit below the staging area");
@@ -200,7 +196,6 @@ AAMD_HD constexpr int pos_of_col(int c) {
 //   n_mels = 80 exactly (every K slot is a real mel), n_mfcc <= 48.
 constexpr int kMfccMT = 3, kMfccMels = 80, kMfccSteps = 3;
 constexpr float kMfccYScale = 1.0f / 256.0f, kMfccDScale = 0.5f, kMfccOutScale = 512.0f;
-constexpr int kMfccFlagStride = 32;     // one-launch form: dwords between the barrier's per-workgroup flag words (one 128-B line each)
 // fragment table: [t][s][hi / lo][lane][8 halves] as 16-byte pieces -> floats
 constexpr int kMfccFragFloats = kMfccMT * kMfccSteps * 2 * 64 * 4;      // 4608 floats = 18 432 B
 AAMD_HD int mfcc_frag_piece(int t, int s, int hl, int lane) { return ((t * kMfccSteps + s) * 2 + hl) * 64 + lane; }   // 16-B pieces
@@ -954,15 +949,6 @@ struct TileInfo {
 //   bit 17 (131072): tiles handed out chip-wide in chunks of kLabChunk from ONE global counter (epi.group_max, zeroed by
 //                   the lab before each launch) instead of static per-workgroup ranges
 // float max through integer atomics (target initialised to -inf or any float)
-// 16-byte WRITE-THROUGH store (sc1: agent scope -- the bytes reach memory, no dirty line stays in this XCD's L2).  The
-// one-launch fused MFCC stores its first-pass output this way: another XCD's workgroup may rewrite a tile behind the grid
-// barrier, and two L2s holding the same bytes dirty would write them back in no defined order.  (hipcc does not count an asm
-// store: the barrier drains vmcnt itself; `s_nop 1` keeps the data registers intact until the store has read them.)
-__device__ __forceinline__ void store_f4_wt(float* p, float a, float b, float c, float d) {
-  using f32x4_t = __attribute__((ext_vector_type(4))) float;
-  const f32x4_t v = {a, b, c, d};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
   if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
   else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
@@ -1024,18 +1010,16 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
                   int out_wide, Epi400 epi) {
   extern __shared__ __attribute__((aligned(16))) float smem400[];
   int fix_n = 0;      // fix-up pass of the fused MFCC: entries of the compacted tile list (kernel-uniform)
-  if (EPI == EPI400_MFCC && epi.fixup == 1) {
+  if (EPI == EPI400_MFCC && epi.fixup != 0) {
     fix_n = *epi.fix_count;
     if (fix_n <= (int)blockIdx.x) return;                 // nothing for this workgroup (nothing at all: the common case)
   }
   // pass 0 of the fused MFCC resets the counter of the compacted fix-up list that pass 1 fills (one launch less per call than a
   // memset; nothing reads it before mfcc_fix_list_kernel, which is ordered behind this kernel on the stream)
   // (every instantiation does it, the tools-only ones included: the caller hands over an uninitialised counter -- ADVICE r3)
-  // (an agent-scope store: in the one-launch form the other workgroups ADD to the word behind the grid barrier, and a plain
-  // store would sit dirty in this XCD's L2 until then)
-  if (EPI == EPI400_MFCC && epi.fixup != 1 && epi.fix_count != nullptr && !(LAB & (1048576 | 8388608)) && blockIdx.x == 0 &&
+  if (EPI == EPI400_MFCC && epi.fixup == 0 && epi.fix_count != nullptr && !(LAB & (1048576 | 8388608)) && blockIdx.x == 0 &&
       threadIdx.x == 0)
-    __hip_atomic_store(epi.fix_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *epi.fix_count = 0;
   // the tools-only switches of the MFCC epilogue (AAMD_MFCC_LAB) are honoured by an instantiation of their own: as run-time
   // branches in the product kernel they cut its MFMA section into basic blocks (the lesson of the resampler's census)
   const int elab = (LAB & 524288) ? epi.lab : 0;
@@ -1043,8 +1027,6 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   long long lab_t0 = 0;
   if (LAB & 1024) lab_t0 = wall_clock64();
-  long long t_entry = 0;
-  if (EPI == EPI400_MFCC && epi.fixup == 2 && threadIdx.x == 0) t_entry = wall_clock64();
   if ((LAB & 1048576) && lane == 0) {  // lab: ... and at its entry (shader clock of the launch = cycles / wall time)
     long long* rec = reinterpret_cast<long long*>(epi.fix_count);
     const int w = blockIdx.x * kWavesPerBlock + wave;
@@ -1163,11 +1145,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     blk_count = (unsigned)n_tiles - blk_first;
     if (blk_count > (unsigned)tiles_per_block) blk_count = (unsigned)tiles_per_block;
   }
-  // which list entries are this workgroup's in a fix-up pass: entry idx of the workgroup is fix_list[fix_base + idx * fix_step]
-  unsigned fix_base = blockIdx.x, fix_step = (unsigned)nb;  // separate launch: blockIdx, blockIdx + nb, ... of the chip-wide list
-  bool fix = (EPI == EPI400_MFCC) && epi.fixup == 1;        // workgroup-uniform: the tile loop is in its fix-up pass
-  const bool one_launch = (EPI == EPI400_MFCC) && epi.fixup == 2;   // kernel-uniform: first pass, grid barrier, fix-up pass
-  if (fix) {
+  if (EPI == EPI400_MFCC && epi.fixup != 0) {             // list entries blockIdx, blockIdx + nb, ... belong to this workgroup
     blk_first = 0;
     blk_count = ((unsigned)fix_n - blockIdx.x + (unsigned)nb - 1u) / (unsigned)nb;
   }
@@ -1202,8 +1180,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   auto tile_info = [&](unsigned idx) {
     TileInfo ti;
     unsigned t = ((LAB & 131072) ? 0u : blk_first) + idx;
-    if (EPI == EPI400_MFCC && fix)    // (an L1-bypassing load: in the one-launch form other waves of this workgroup wrote the entry)
-      t = idx < blk_count ? (unsigned)__hip_atomic_load(epi.fix_list + fix_base + idx * fix_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (EPI == EPI400_MFCC && epi.fixup != 0) t = idx < blk_count ? (unsigned)epi.fix_list[blockIdx.x + idx * (unsigned)nb] : 0u;
     const unsigned row = t / (unsigned)tiles_per_row;
     ti.row = row;
     ti.t0 = (int64_t)(t - row * (unsigned)tiles_per_row) * kFramesPerWave;
@@ -1224,6 +1201,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   float wmax = -INFINITY;
   int64_t wgroup = -1, wrow = -1;
   constexpr bool kDb = (EPI == EPI400_MEL_DB) || (EPI == EPI400_MFCC);
+  const bool fix = (EPI == EPI400_MFCC) && epi.fixup != 0;      // kernel-uniform: the fix-up pass of the fused MFCC
   auto flush_max = [&]() {
     if (kDb && !fix && epi.group_max != nullptr && wgroup >= 0) {
       float m = wmax;
@@ -1234,9 +1212,6 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     wmax = -INFINITY;
   };
 
-  // The tile loop runs once -- or twice in the one-launch form of the fused MFCC (epi.fixup == 2): first pass, grid barrier,
-  // then, as the fix-up pass, over the flagged tiles this workgroup found among ITS candidates.
-  for (int phase = 0; phase < 2; ++phase) {
   unsigned cur_idx = (LAB & 131072) ? g_base : (unsigned)wave;
   TileInfo cur = tile_info(cur_idx);
   if (LAB & 128) {   // lab: stagger the waves of a SIMD by thirds of a tile time.  Interleaved A/B runs
@@ -1287,8 +1262,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     if (fix) {
       // fix-up pass: the tiles of the compacted list (smallest dB value under the cut-off) are redone, clamped; their samples
       // are staged now, without prefetch: flagged tiles are the exception
-      // (agent-scope load: in the one-launch form the maxima were combined by this very launch)
-      fix_cut = __hip_atomic_load(epi.group_max + cur.row / epi.rows_per_group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epi.top_db;
+      fix_cut = epi.group_max[cur.row / epi.rows_per_group] - epi.top_db;
       if (cur.staged) stage_issue(cur);
     }
 
@@ -1392,10 +1366,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
         AAMD_MIN_STEP(0x111, 0xf) AAMD_MIN_STEP(0x112, 0xf) AAMD_MIN_STEP(0x114, 0xf) AAMD_MIN_STEP(0x118, 0xf)
         AAMD_MIN_STEP(0x142, 0xa) AAMD_MIN_STEP(0x143, 0xc)
 #undef AAMD_MIN_STEP
-        if (lane == 63) {
-          if (one_launch) __hip_atomic_store(epi.tile_min + blk_first + cur_idx, tmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else epi.tile_min[blk_first + cur_idx] = tmin;
-        }
+        if (lane == 63) epi.tile_min[blk_first + cur_idx] = tmin;
       }
     }
     if (EPI == EPI400_MFCC) {
@@ -1488,14 +1459,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 #pragma unroll
         for (int t = 0; t < kMfccMT; ++t) {
           const int k0 = 16 * t + 4 * (lane >> 4);
-          if (k0 < epi.n_mfcc) {
-            if (one_launch && !fix && !(elab & 16))   // first pass of the one-launch form: write-through (see store_f4_wt; lab bit 4: plain, for timing only)
-              store_f4_wt(orow + k0, cf[t][0] * kMfccOutScale, cf[t][1] * kMfccOutScale, cf[t][2] * kMfccOutScale,
-                          cf[t][3] * kMfccOutScale);
-            else
-              *reinterpret_cast<F4*>(orow + k0) = F4{cf[t][0] * kMfccOutScale, cf[t][1] * kMfccOutScale,
-                                                     cf[t][2] * kMfccOutScale, cf[t][3] * kMfccOutScale};
-          }
+          if (k0 < epi.n_mfcc)
+            *reinterpret_cast<F4*>(orow + k0) = F4{cf[t][0] * kMfccOutScale, cf[t][1] * kMfccOutScale,
+                                                   cf[t][2] * kMfccOutScale, cf[t][3] * kMfccOutScale};
         }
       }
       wave_lds_fence();
@@ -1562,90 +1528,6 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       if (g_run >= 0) atomic_max_f32(epi.group_max + g_run, m_run);
     }
   }
-  if (!(EPI == EPI400_MFCC && one_launch) || phase != 0) break;
-  if (EPI == EPI400_MFCC) {
-    // ---- one launch instead of three ----------------------------------------------------------------
-    // Grid barrier: the launcher starts at most one workgroup per CU and no more than the chip has CUs, so all of them are
-    // resident.  Hand-off in the write-through form of MI355X_MICROARCH.md (R1): everything another workgroup reads or
-    // rewrites behind the barrier -- tile minima, group maxima (atomics), the first-pass output -- left this CU by sc1 stores,
-    // every wave drained its vmcnt below, thread 0's atomics follow in program order and are drained here; then ONE lane
-    // draws an arrival ticket.  The readers use sc1 loads (L1 bypassed), so neither an L2 write-back nor an L1 invalidation is
-    // needed.  Nobody polls the arrival counter: a workgroup waits on a flag word of ITS OWN (one 128-byte line each, behind
-    // the counter), and the workgroup that draws the last ticket sets them all.  (Measured on the way here,
-    // profiles/r04_m_mfcc_launch_ab_wbl2.txt / r04_n_mfcc_launch_ab_hotspot.txt: a release with buffer_wbl2 in all 256
-    // workgroups, and then 255 lanes polling the ONE counter word while the stragglers still compute -- their loads queue
-    // behind the polls at that word's memory channel -- each made the launch 25 us longer than the first pass alone, where
-    // the two launches it replaces cost 17.)  The spin is bounded: a workgroup that is not resident after 30 s (a CU mask
-    // the device properties do not show) traps instead of hanging the stream.
-    // (census: thread 0 leaves four 100 MHz stamps in a line of its own behind the flag lines -- entry, first pass done,
-    // barrier passed, candidates checked -- tools/mfcc_launch_ab.py reads them; four 8-byte stores per workgroup and launch.
-    // Not in the flag line: a plain store would leave that line partly dirty in this XCD's L2 while its flag word is polled.)
-    long long* const census = reinterpret_cast<long long*>(epi.arrive + kMfccFlagStride * (1 + nb + (int)blockIdx.x));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the asm stores are invisible to the compiler's own counting)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      census[0] = t_entry;
-      census[1] = wall_clock64();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int ticket = __hip_atomic_fetch_add(epi.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epi.arrive_base;
-      queue[0] = kWavesPerBlock;                          // the tile queue of the fix-up pass
-      queue[1] = 0;                                       // entries of this workgroup's list
-      queue[2] = (ticket == nb - 1) ? 1 : 0;              // this workgroup arrived last
-    }
-    __syncthreads();
-    int* const flags = epi.arrive + kMfccFlagStride;      // flag of workgroup b: flags[b * kMfccFlagStride]
-    if (__builtin_amdgcn_readfirstlane(queue[2]) != 0) {
-      for (int i = threadIdx.x; i < nb; i += blockDim.x)
-        __hip_atomic_store(flags + i * kMfccFlagStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (threadIdx.x == 0) {
-      const long long t_arrive = wall_clock64();
-      while (__hip_atomic_load(flags + blockIdx.x * kMfccFlagStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epi.arrive_base) {
-        __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t_arrive > 3000000000ll) __builtin_trap();
-      }
-    }
-    // ONE cut-off for the whole batch ((B, L) input): one load of it per workgroup, not one per candidate tile -- 85 k loads
-    // of one word at the same moment are the same hot spot again
-    const bool one_group = rows <= epi.rows_per_group;
-    if (threadIdx.x == 0) census[2] = wall_clock64();
-    if (one_group && threadIdx.x == 0)
-      lds[2] = __hip_atomic_load(epi.group_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (wave 0's region; nothing lives there now)
-    __syncthreads();
-    const float gm_all = one_group ? smem400[2] : 0.0f;
-    // Candidates of workgroup b are the tiles b, b + nb, b + 2 nb, ...: clamped tiles cluster by clip (silence), a strided
-    // share spreads any run of them over the whole chip.  Its flagged ones go to a private run of the scratch list
-    // (b-th share of n_tiles entries), in any order.
-    const unsigned nt = (unsigned)n_tiles, b = blockIdx.x;
-    const unsigned n_cand = b < nt ? (nt - b + (unsigned)nb - 1u) / (unsigned)nb : 0u;
-    fix_base = b * (nt / (unsigned)nb) + (b < nt % (unsigned)nb ? b : nt % (unsigned)nb);
-    fix_step = 1u;
-    for (unsigned k0 = 0; k0 < n_cand; k0 += blockDim.x) {
-      const unsigned k = k0 + threadIdx.x;
-      bool hit = false;
-      unsigned t = 0;
-      if (k < n_cand) {
-        t = b + k * (unsigned)nb;
-        const unsigned row = t / (unsigned)tiles_per_row;
-        const float gm = one_group ? gm_all
-                                   : __hip_atomic_load(epi.group_max + row / epi.rows_per_group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float tm = __hip_atomic_load(epi.tile_min + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hit = tm < gm - epi.top_db;
-      }
-      const unsigned long long m = __ballot(hit);
-      int slot = 0;
-      if (lane == 0 && m) slot = __hip_atomic_fetch_add(queue + 1, __popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      slot = __builtin_amdgcn_readfirstlane(slot);
-      if (hit) epi.fix_list[fix_base + slot + __popcll(m & ((1ull << lane) - 1ull))] = (int)t;
-    }
-    __syncthreads();                                      // (drains the list stores of every wave)
-    if (threadIdx.x == 0) census[3] = wall_clock64();
-    blk_first = 0;
-    blk_count = (unsigned)__builtin_amdgcn_readfirstlane(queue[1]);
-    if (blk_count == 0) break;                            // nothing under the cut-off among this workgroup's tiles: the common case
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(epi.fix_count, (int)blk_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    fix = true;
-  }
-  }   // phase
   if ((LAB & 1048576) && lane == 0) {  // lab (tools/mel400_lab.py): cycle counter and 100 MHz wall clock at the wave's exit
     long long* rec = reinterpret_cast<long long*>(epi.fix_count);
     const int w = blockIdx.x * kWavesPerBlock + wave;

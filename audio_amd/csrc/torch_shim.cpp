@@ -370,8 +370,7 @@ Tensor mfcc_frag_build(Tensor dct, int64_t n_mels, int64_t n_mfcc) {
 }
 // Single-rank form (no exchange of group_max between the passes): both passes in one op.
 // scratch: int32[2 * tiles + 1] (tile minima as float bits, the list, the count); group_max: float[n_groups] pre-filled with
-// -inf, updated in place -- or float[n_groups + aamd_mfcc_fused_sync_floats()], all -inf: the op then asks for pass 2 (ONE
-// launch with an in-kernel grid barrier; the extra words are its arrival counter and flags).  Returns (rows, n_frames, n_mfcc).
+// -inf, updated in place.  Returns (rows, n_frames, n_mfcc).
 Tensor mfcc_fused(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Tensor band_width, Tensor band_weights,
                   std::optional<Tensor> lane_order, std::optional<Tensor> table400, Tensor dct_frag, Tensor group_max,
                   int64_t n_fft, int64_t hop, int64_t pad, bool center, int64_t pad_mode, int64_t n_frames, double scale,
@@ -400,12 +399,6 @@ Tensor mfcc_fused(Tensor wav, Tensor window, Tensor twiddle, Tensor band_lo, Ten
   f.tile_min = sp; f.tile_list = reinterpret_cast<int32_t*>(sp + tiles);
   f.fix_count = reinterpret_cast<int32_t*>(sp + 2 * tiles);
   void* st = current_stream(wav);
-  const int64_t n_groups = (d.rows + rows_per_group - 1) / rows_per_group;
-  if (group_max.numel() >= n_groups + aamd_mfcc_fused_sync_floats()) {
-    f.pass = 2;
-    check(aamd_mfcc_fused_f32(fp(wav), fp(window), fp(twiddle), &bands.b, fpm(out), &d, &f, st));
-    return out;
-  }
   check(aamd_mfcc_fused_f32(fp(wav), fp(window), fp(twiddle), &bands.b, fpm(out), &d, &f, st));
   f.pass = 1;
   check(aamd_mfcc_fused_f32(fp(wav), fp(window), fp(twiddle), &bands.b, fpm(out), &d, &f, st));

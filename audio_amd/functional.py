@@ -973,7 +973,6 @@ class MfccFusedState:
         self.decided_share = None     # share of redone tiles the decision was taken on
         self.last_count = None        # device int32[1]: tiles redone by the last one-kernel call (never read unless asked)
         self.last_tiles = 0
-        self.last_sync = None         # device float[...]: barrier words of the last one-launch call (census stamps for the tools)
         self.force = False            # MFCC.fused = True: always the one-kernel path
         self.path = None
         self.calls_fused = 0
@@ -1008,10 +1007,7 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
             state.frag, state.frag_key, state.frag_src = frag, key, weakref.ref(dct)
         n_tiles = int(L.aamd_mfcc_fused_tiles(C.byref(desc)))
         out = torch.empty((desc.rows, desc.n_frames, n_mfcc), dtype=torch.float32, device=dev)
-        # (behind the groups: the arrival counter and per-workgroup flags of the one-launch form's grid barrier, same fill)
-        n_sync = int(L.aamd_mfcc_fused_sync_floats()) if group_max_hook is None else 0
-        gmax_all = torch.full((n_groups + n_sync,), float("-inf"), dtype=torch.float32, device=dev)
-        gmax = gmax_all[:n_groups]
+        gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
         if out.numel() == 0:
             # an empty shard still takes part in the exchange of the batch-global cut-off: the other ranks are waiting in the
             # same all-reduce (returning before the hook hung the job)
@@ -1021,24 +1017,22 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
         tile_min = torch.empty((n_tiles,), dtype=torch.float32, device=dev)
         count = torch.empty((1,), dtype=torch.int32, device=dev)
         tile_list = torch.empty((n_tiles,), dtype=torch.int32, device=dev)
+        # (round 4 tried to fold the compaction of the fix-up list into pass 0 -- its last workgroup to finish scanned the tile
+        # minima itself: one workgroup walking 85 k minima is latency-bound, +50 us on the cfg4 batch against the 4.8 us of the
+        # chip-wide list kernel it saved; profiles/r04_b_configs.jsonl.  The in-kernel grid barrier form (all workgroups meet, each
+        # redoes the flagged tiles of a strided share) was built and measured too: + 2.3 us -- un-profiled, the two small launches
+        # cost ~5.5 us together, the barrier 3 us and the write-through stores a cross-XCD rewrite needs 4-6 us;
+        # profiles/r04_p_mfcc_one_launch.txt.  Two launches stay.)
         f = _lib.MfccFused(state.frag.data_ptr(), n_mfcc, 0, float(db[0]), float(db[1]), float(db[2]), float(top_db),
                            gmax.data_ptr(), max(packed, 1), tile_min.data_ptr(), count.data_ptr(), tile_list.data_ptr())
         args = (x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),
                 C.byref(bands.struct), out.data_ptr(), C.byref(desc))
-        if group_max_hook is None:
-            # Nothing happens between the passes on one rank: pass 2 = both in ONE launch (in-kernel grid barrier; the library
-            # falls back to the three launches below by itself when another stream holds that form or a capture is in progress).
-            # (An earlier round-4 form -- the LAST workgroup of pass 0 compacting the list alone -- cost +50 us: one workgroup
-            # walking 85 k minima is latency-bound; here every workgroup checks its strided 1/256 of them.)
-            f.pass_ = 2
-            _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))
-        else:
-            _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))
+        _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))
+        if group_max_hook is not None:
             group_max_hook(gmax)
-            f.pass_ = 1
-            _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))
+        f.pass_ = 1
+        _lib.check(L.aamd_mfcc_fused_f32(*args, C.byref(f), stream))
         state.last_count, state.last_tiles = count, n_tiles     # stays on the device; read only by a decision / a report
-        state.last_sync = gmax_all[n_groups:] if n_sync else None   # barrier words + census stamps of the one-launch form (tools)
     return out
 
 

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define AAMD_ABI_VERSION 6
+#define AAMD_ABI_VERSION 5
 
 enum {
   AAMD_OK = 0,
@@ -126,10 +126,8 @@ enum {
   AAMD_POLICY_RESAMPLE_FP32 = 8,  /* banded resampling on v_mfma_f32_16x16x4_f32 instead of the f16 hi/lo-split MFMAs (16 x slower pipe) */
   AAMD_POLICY_FFTCONV_NO_FDL = 16, /* overlap-save: never the frequency-domain delay-line plan */
   AAMD_POLICY_FFTCONV_FDL   = 32, /* overlap-save: the COMPLEX-block delay-line plan (2) whenever the tap count allows it (cost model ignored) */
-  AAMD_POLICY_FFTCONV_COMPLEX = 64, /* overlap-save: only the complex-block kernels of rounds 1-3 (plans 1 / 2), never the
+  AAMD_POLICY_FFTCONV_COMPLEX = 64 /* overlap-save: only the complex-block kernels of rounds 1-3 (plans 1 / 2), never the
                                       real-block delay line of round 4 (plan 3) */
-  AAMD_POLICY_MFCC_THREE_LAUNCHES = 128 /* fused MFCC, pass 2: always first pass + list + fix-up launch, never the one-launch
-                                      form with its in-kernel grid barrier (env AAMD_MFCC_THREE_LAUNCHES) */
 };
 int         aamd_set_kernel_policy(int flags);
 
@@ -181,31 +179,20 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
  *   pass 1  redoes, clamped at group_max[g] - top_db, exactly the tiles whose minimum lies under that cut-off and counts
  *           them in fix_count (required in both passes: pass 0 resets it).  Batches in which nothing reaches the cut-off pay ~2 us for it; batches in which
  *           most tiles do should take aamd_melspectrogram_db_f32 + aamd_mfcc_dct_f32 (the caller's choice).
- *   pass 2  (ABI v6) = pass 0 followed by pass 1 with nothing in between (one rank: no exchange of group_max), in ONE launch:
- *           the persistent workgroups (one per CU, all resident) meet at an in-kernel grid barrier once every group maximum
- *           and tile minimum is final, each then checks a strided share of the tile minima and redoes its flagged tiles --
- *           no list kernel, no second launch (~17 us of kernel boundaries on the 512-clip batch).  group_max must then hold
- *           aamd_mfcc_fused_sync_floats() MORE floats than it has groups, pre-filled with -inf like the rest: the arrival
- *           counter of the barrier and one flag line per workgroup.
- *           Same bits as passes 0 + 1.  Because such a launch holds every CU until all its workgroups have arrived, the
- *           library grants the form to one stream per device at a time (a call from another stream while the previous
- *           holder is still busy, a stream under capture, or AAMD_POLICY_MFCC_THREE_LAUNCHES run the three launches
- *           instead -- same results); a workgroup that waits 30 s at the barrier traps rather than hang the stream.
  * Results equal the two-kernel path's up to the rounding of the fp32 contraction order. */
 typedef struct aamd_mfcc_fused {
   const float* dct_frag;   /* device float[aamd_mfcc_frag_floats()], from aamd_mfcc_frag_build */
   int32_t n_mfcc;
-  int32_t pass;            /* 0, 1 or 2 (both in one call) */
+  int32_t pass;            /* 0 or 1 */
   float multiplier, amin, db_multiplier, top_db;   /* F.amplitude_to_DB's (functional.py:356-404) */
-  float* group_max;        /* device float[ceil(rows / rows_per_group)] (+ aamd_mfcc_fused_sync_floats() for pass 2) */
+  float* group_max;        /* device float[ceil(rows / rows_per_group)] */
   int64_t rows_per_group;
   float* tile_min;         /* device float[aamd_mfcc_fused_tiles(desc)] */
   int32_t* fix_count;      /* device int32: pass 0 resets it, pass 1 leaves the number of tiles it redoes here */
-  int32_t* tile_list;      /* device int32[aamd_mfcc_fused_tiles(desc)]: scratch of pass 1 / 2 -- the tiles under the cut-off,
-                              compacted, so that the fix-up deals them out evenly however they cluster by clip */
+  int32_t* tile_list;      /* device int32[aamd_mfcc_fused_tiles(desc)]: scratch of pass 1 -- the tiles under the cut-off,
+                              compacted, so that the fix-up launch deals them out evenly however they cluster by clip */
 } aamd_mfcc_fused;
 int32_t aamd_mfcc_frag_floats(void);
-int32_t aamd_mfcc_fused_sync_floats(void);   /* pass 2: extra floats behind group_max (current device) */
 int64_t aamd_mfcc_fused_tiles(const aamd_stft_desc* desc);
 int aamd_mfcc_fused_supported(const aamd_stft_desc* desc, const aamd_mel_bands* bands, int32_t n_mfcc);   /* 1 / 0 */
 /* dct: device float[n_mels][n_mfcc] (F.create_dct, functional.py:636-667) -> the MFMA operand layout of the fused kernel */

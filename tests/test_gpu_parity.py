@@ -696,76 +696,6 @@ def test_mfcc_one_kernel_path_equals_two_kernel_path_and_oracle(hop, n_mfcc, sha
         assert float(np.abs(a.cpu().numpy() - exp).max()) <= 2e-6 * float(np.abs(exp).max()) + 5e-4      # MFCC absolute (dB scale)
 
 
-@pytest.mark.parametrize("shape,kind", [((6, 48000), "clustered"), ((2, 3, 30011), "clustered"), ((300, 16000), "clustered"),
-                                        ((300, 16000), "spread"), ((64, 4, 8000), "spread"), ((40, 32000), "none"),
-                                        ((512, 160000), "clustered")])
-def test_mfcc_one_launch_equals_three_launches(shape, kind):
-    """pass 2 of aamd_mfcc_fused_f32 -- ONE launch: first pass, in-kernel grid barrier, every workgroup redoes the flagged
-    tiles among its strided share -- returns the bits of pass 0 + list kernel + pass 1 and counts the same tiles: small grids
-    and the full persistent grid (all 256 workgroups at the barrier), ONE batch-global cut-off and per-item ones, clamped
-    tiles clustered in a few clips (uneven fix-up load), spread over all of them, or absent."""
-    import audio_amd.transforms as T
-    from audio_amd import _lib
-    g = torch.Generator().manual_seed(len(shape) * 1000 + shape[0])
-    x = (0.4 * torch.randn(*shape, generator=g)).clamp_(-1, 1)
-    rows = x.view(-1, shape[-1])
-    if kind == "clustered":
-        rows[1] *= 1e-4
-        rows[0, shape[-1] // 2:] = 0.0
-        rows[rows.shape[0] // 2: rows.shape[0] // 2 + max(rows.shape[0] // 10, 1)] = 0.0
-    elif kind == "spread":
-        rows[:, shape[-1] // 3: shape[-1] // 3 + 2000] = 0.0
-    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
-    m.fused = True
-    xd = x.cuda()
-    with torch.no_grad():
-        one = m(xd).clone()
-        share_one = m.fused_report()["redone_share"]
-        with _lib.kernel_policy(_lib.POLICY_MFCC_THREE_LAUNCHES):
-            three = m(xd).clone()
-            share_three = m.fused_report()["redone_share"]
-        again = m(xd)
-    assert torch.equal(one, three) and torch.equal(one, again)
-    assert share_one == share_three and ((share_one > 0) if kind != "none" else (share_one == 0.0)), (share_one, share_three)
-    assert bool(torch.isfinite(one).all())
-
-
-def test_mfcc_one_launch_from_two_streams_and_threads():
-    """The one-launch form holds every CU at its barrier, so the library grants it to one stream per device at a time: calls
-    issued back to back from two streams (and from two host threads) finish, with the right results -- whichever of them ran
-    as one launch and whichever as three."""
-    import threading
-    import audio_amd.transforms as T
-    g = torch.Generator().manual_seed(77)
-    x = (0.4 * torch.randn(384, 48000, generator=g)).clamp_(-1, 1)
-    x[5:40] = 0.0
-    xd = x.cuda()
-    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()
-    m.fused = True
-    with torch.no_grad():
-        want = m(xd).clone()
-    torch.cuda.synchronize()
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    outs = [[], []]
-
-    def work(i):
-        with torch.no_grad(), torch.cuda.stream(streams[i]):
-            for _ in range(12):
-                outs[i].append(m(xd))
-
-    for s in streams:
-        s.wait_stream(torch.cuda.current_stream())
-    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    torch.cuda.synchronize()
-    for i in range(2):
-        for y in outs[i]:
-            assert torch.equal(y, want)
-
-
 def test_mfcc_path_choice_is_taken_once_per_module():
     """`fused="auto"`: the module decides at its FIRST eligible call (synchronised) from the share of tiles that call had to
     redo, and keeps that arithmetic; a zero-padded first batch puts it on the two-kernel path -- including for that first

@@ -86,4 +86,4 @@ def test_abi_header_symbols_exported():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name)
-    assert L.aamd_abi_version() == 6
+    assert L.aamd_abi_version() == 5

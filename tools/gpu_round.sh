@@ -13,7 +13,6 @@
 #   prof_configs     rocprofv3 --kernel-trace --stats of tools/bench_configs.py (every BASELINE config) -> prof_configs_summary.txt
 #   configs          tools/bench_configs.py                               -> configs.jsonl
 #   pmc:<op>:<kernel> rocprofv3 PMC passes (tools/pmc_groups_short.txt) of tools/run_op_once.py <op> -> pmc_<op>.txt
-#   mfcc_trace       rocprofv3 --kernel-trace of tools/mfcc_launch_ab.py, dispatches split by role (tools/mfcc_trace_split.py) -> mfcc_trace_split.txt
 #   py:<file.py>     any tools/ script, stdout+stderr                     -> <file>.log
 # Every step runs under its own `timeout`; a hung kernel cannot take the box with it.
 set -x
@@ -42,10 +41,6 @@ for step in "$@"; do
       rm -rf $O/prof_configs/*/ 2>/dev/null; find $O/prof_configs -name "*.csv" -size +2M -delete 2>/dev/null ;;
     configs) timeout 600 python tools/bench_configs.py > $O/configs.jsonl 2> $O/configs.err; cut -c1-300 $O/configs.jsonl ;;
     pmc:*) a=${step#pmc:}; op=${a%%:*}; key=${a#*:}; timeout 900 bash tools/pmc_run.sh $O/pmc_$op tools/pmc_groups_short.txt "$key" python tools/run_op_once.py $op 4 > $O/pmc_$op.txt 2>&1; tail -40 $O/pmc_$op.txt; rm -rf $O/pmc_$op/p*/ 2>/dev/null ;;
-    mfcc_trace)
-      (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/$O/mfcc_trace -o ab -- python $R/tools/mfcc_launch_ab.py --steps 60 --warmup 20 --rounds 1 > $R/$O/mfcc_trace_ab.log 2>&1)
-      python tools/mfcc_trace_split.py $O/mfcc_trace > $O/mfcc_trace_split.txt 2>&1; cat $O/mfcc_trace_split.txt
-      rm -rf $O/mfcc_trace 2>/dev/null ;;
     py:*) f=${step#py:}; b=$(basename ${f%% *} .py); timeout 900 python tools/$f > $O/$b.log 2>&1; echo "rc=$?" >> $O/$b.log; tail -40 $O/$b.log ;;
     *) echo "unknown step $step" ;;
   esac
