@@ -515,18 +515,9 @@ int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twid
   epi.group_max = f->group_max; epi.rows_per_group = f->rows_per_group;
   epi.dct_frag = f->dct_frag; epi.n_mfcc = f->n_mfcc; epi.top_db = f->top_db; epi.tile_min = f->tile_min;
   epi.fix_count = f->fix_count; epi.fixup = f->pass; epi.fix_list = f->tile_list;
-  if (f->pass == 1) {
-    // compact the tiles under their group's cut-off (known now: the caller reduced group_max over ranks between the passes)
-    AAMD_CHECK_ARG(f->fix_count && f->tile_list, "pass 1 of the fused MFCC needs fix_count and tile_list");
-    const int tiles_per_row = (g.n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
-    const int64_t n_tiles = g.rows * tiles_per_row;
-    // (fix_count was reset by pass 0 of this call -- the kernel's first workgroup does it)
-    hipLaunchKernelGGL(m400::mfcc_fix_list_kernel, dim3(grid_for(n_tiles, 256, dev_props().cu_count * 4)), dim3(256), 0,
-                       (hipStream_t)stream, f->tile_min, f->group_max, f->rows_per_group, tiles_per_row, n_tiles, f->top_db,
-                       f->tile_list, f->fix_count);
-    rc = launch_check();
-    if (rc != AAMD_OK) return rc;
-  }
+  // (pass 1: every workgroup of the fix-up launch finds the flagged tiles among its own strided share of the tile minima --
+  // no list kernel between the passes; fix_count was reset by pass 0 of this call and collects what the workgroups redo)
+  if (f->pass == 1) AAMD_CHECK_ARG(f->fix_count && f->tile_list, "pass 1 of the fused MFCC needs fix_count and tile_list");
   static const int mfcc_lab = [] { const char* e = std::getenv("AAMD_MFCC_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
   epi.lab = mfcc_lab;
   hipStream_t s = (hipStream_t)stream;

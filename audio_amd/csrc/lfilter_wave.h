@@ -713,6 +713,18 @@ lfilter_wave_mover_kernel(const float* __restrict__ x, const float* __restrict__
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int W = (blockDim.x >> 6) - kMovers;                 // filter waves
+#ifndef AAMD_LFW_STAGGER
+#define AAMD_LFW_STAGGER 0
+#endif
+  if (AAMD_LFW_STAGGER != 0) {
+    // lab (tools/lfw_ab.py): every workgroup walks an equally long sequence block by block, so the whole chip issues its copies
+    // and its stores in the same phase of the ~10 us block period.  Start the workgroups in 8 phases, `units` x 64 cycles apart:
+    // mode 0 by XCD (block & 7), 1 within an XCD ((block >> 3) & 7), 2 both.
+    constexpr int mode = AAMD_LFW_STAGGER >> 8;
+    const int b_ = (int)blockIdx.x;
+    const int k_ = mode == 0 ? (b_ & 7) : mode == 1 ? ((b_ >> 3) & 7) : ((b_ * 5 + (b_ >> 3)) & 7);
+    for (int i = 0; i < k_; ++i) __builtin_amdgcn_s_sleep(AAMD_LFW_STAGGER & 127);
+  }
   float* tabs = smem_lfw + W * kPipeTile;
   float* xch = tabs + n_stages * kTabFloats;
   const int64_t block_len = (int64_t)W * kWaveBlock;

@@ -164,8 +164,9 @@ struct Epi400 {
   int n_mfcc;                       // MFCC: coefficients (<= 48, multiple of 4)
   float top_db;                     // MFCC fix-up: cut-off = group_max[g] - top_db
   float* tile_min;                  // MFCC: [n_tiles] minimum dB value of each tile (written by pass 0, read by the fix-up)
-  int* fix_count;                   // MFCC fix-up: number of tiles to redo = entries of fix_list (written by mfcc_fix_list_kernel)
-  const int* fix_list;              // MFCC fix-up: the tiles under the cut-off, compacted (any order)
+  int* fix_count;                   // MFCC: number of tiles the fix-up pass redoes (pass 0 zeroes it, the fix-up workgroups add theirs)
+  int* fix_list;                    // MFCC fix-up: [n_tiles] scratch -- every workgroup keeps the list of ITS flagged tiles in a
+                                    //   private run of it (any order)
   int frag_in_lds;                  // MFCC: the workgroup's LDS has room for the fragment table (hop 100 / 160; not hop 200)
   int fixup;                        // MFCC: 0 = first pass, 1 = fix-up pass
   int lab;                          // MFCC (tools only): 1 no fragment loads, 2 no MFMA, 4 no tile minimum, 8 no stores
@@ -969,28 +970,6 @@ __global__ void __launch_bounds__(256) mfcc_frag_build_kernel(const float* __res
   }
 }
 
-// Between the two passes of the fused MFCC: the tiles whose smallest dB value lies under their group's cut-off, compacted
-// into `list` (one atomic per wave; `count` was zeroed by pass 0 of the same call, whose first workgroup resets it).  The fix-up launch deals list entries out block by
-// block, so 5 % flagged tiles that all sit in a few clips cost 5 % of a pass, not the +100 us of static tile ranges.
-__global__ void __launch_bounds__(256) mfcc_fix_list_kernel(const float* __restrict__ tile_min, const float* __restrict__ group_max,
-                                                            int64_t rows_per_group, int tiles_per_row, int64_t n_tiles,
-                                                            float top_db, int* __restrict__ list, int* __restrict__ count) {
-  for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n_tiles; base += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = base + threadIdx.x;
-    bool hit = false;
-    if (i < n_tiles) {
-      const int64_t row = i / tiles_per_row;
-      hit = tile_min[i] < group_max[row / rows_per_group] - top_db;
-    }
-    const unsigned long long m = __ballot(hit);
-    const int lane = threadIdx.x & 63;
-    int start = 0;
-    if (lane == 0 && m) start = atomicAdd(count, __popcll(m));
-    start = __shfl(start, 0, 64);
-    if (hit) list[start + __popcll(m & ((1ull << lane) - 1ull))] = (int)i;
-  }
-}
-
 // One workgroup lays out the band table image in global memory (once per filterbank; aamd_mel400_table_build).
 __global__ void __launch_bounds__(256) mel_tab_build_kernel(MelBandsDev mb, float* __restrict__ out) {
   MelTab mt{};
@@ -1009,13 +988,44 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
                   int tiles_per_row, int64_t n_tiles, int tiles_per_block, int in_aligned,
                   int out_wide, Epi400 epi) {
   extern __shared__ __attribute__((aligned(16))) float smem400[];
-  int fix_n = 0;      // fix-up pass of the fused MFCC: entries of the compacted tile list (kernel-uniform)
+  // Fix-up pass of the fused MFCC.  The workgroup's candidates are the tiles b, b + nb, b + 2 nb, ... (clamped tiles cluster by
+  // clip -- silence --, a strided share spreads any run of them over the whole chip): it checks their minima against the
+  // cut-offs -- final now: the caller reduced group_max over the ranks between the passes --, keeps the flagged ones in its
+  // private run of the scratch list and leaves when there are none (the common case), before any table is built.  (Rounds
+  // 3-4 compacted ONE chip-wide list in a kernel of its own between the passes; un-profiled that launch cost 3-5 us per call,
+  // profiles/r04_p_mfcc_one_launch.txt.)
+  unsigned fix_base = 0, fix_cnt = 0;
   if (EPI == EPI400_MFCC && epi.fixup != 0) {
-    fix_n = *epi.fix_count;
-    if (fix_n <= (int)blockIdx.x) return;                 // nothing for this workgroup (nothing at all: the common case)
+    int* const cnt = reinterpret_cast<int*>(smem400);     // (wave 0's region: nothing lives there yet)
+    if (threadIdx.x == 0) *cnt = 0;
+    __syncthreads();
+    const unsigned nt = (unsigned)n_tiles, nbk = gridDim.x, b = blockIdx.x;
+    const unsigned n_cand = b < nt ? (nt - b + nbk - 1u) / nbk : 0u;
+    fix_base = b * (nt / nbk) + (b < nt % nbk ? b : nt % nbk);
+    for (unsigned k0 = 0; k0 < n_cand; k0 += blockDim.x) {
+      const unsigned k = k0 + threadIdx.x;
+      bool hit = false;
+      unsigned t = 0;
+      if (k < n_cand) {
+        t = b + k * nbk;
+        const unsigned row = t / (unsigned)tiles_per_row;
+        hit = epi.tile_min[t] < epi.group_max[row / epi.rows_per_group] - epi.top_db;
+      }
+      const unsigned long long m = __ballot(hit);
+      int slot = 0;
+      if ((threadIdx.x & 63) == 0 && m)
+        slot = __hip_atomic_fetch_add(cnt, __popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      slot = __builtin_amdgcn_readfirstlane(slot);
+      if (hit) epi.fix_list[fix_base + slot + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (int)t;
+    }
+    __syncthreads();                                      // (also drains the list stores of every wave)
+    fix_cnt = (unsigned)__builtin_amdgcn_readfirstlane(*cnt);
+    if (fix_cnt == 0) return;
+    if (threadIdx.x == 0) atomicAdd(epi.fix_count, (int)fix_cnt);
+    __syncthreads();                                      // *cnt is read: the tile loop may reuse the word
   }
-  // pass 0 of the fused MFCC resets the counter of the compacted fix-up list that pass 1 fills (one launch less per call than a
-  // memset; nothing reads it before mfcc_fix_list_kernel, which is ordered behind this kernel on the stream)
+  // pass 0 of the fused MFCC resets the counter of redone tiles that the fix-up workgroups add to (one launch less per call
+  // than a memset; nothing touches it before the fix-up launch, which is ordered behind this kernel on the stream)
   // (every instantiation does it, the tools-only ones included: the caller hands over an uninitialised counter -- ADVICE r3)
   if (EPI == EPI400_MFCC && epi.fixup == 0 && epi.fix_count != nullptr && !(LAB & (1048576 | 8388608)) && blockIdx.x == 0 &&
       threadIdx.x == 0)
@@ -1145,9 +1155,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     blk_count = (unsigned)n_tiles - blk_first;
     if (blk_count > (unsigned)tiles_per_block) blk_count = (unsigned)tiles_per_block;
   }
-  if (EPI == EPI400_MFCC && epi.fixup != 0) {             // list entries blockIdx, blockIdx + nb, ... belong to this workgroup
+  if (EPI == EPI400_MFCC && epi.fixup != 0) {             // the entries of this workgroup's own list
     blk_first = 0;
-    blk_count = ((unsigned)fix_n - blockIdx.x + (unsigned)nb - 1u) / (unsigned)nb;
+    blk_count = fix_cnt;
   }
   auto claim = [&]() {   // wave-uniform
     int v = 0;
@@ -1180,7 +1190,8 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   auto tile_info = [&](unsigned idx) {
     TileInfo ti;
     unsigned t = ((LAB & 131072) ? 0u : blk_first) + idx;
-    if (EPI == EPI400_MFCC && epi.fixup != 0) t = idx < blk_count ? (unsigned)epi.fix_list[blockIdx.x + idx * (unsigned)nb] : 0u;
+    if (EPI == EPI400_MFCC && epi.fixup != 0)   // (an L1-bypassing load: other waves of this workgroup wrote the entry)
+      t = idx < blk_count ? (unsigned)__hip_atomic_load(epi.fix_list + fix_base + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     const unsigned row = t / (unsigned)tiles_per_row;
     ti.row = row;
     ti.t0 = (int64_t)(t - row * (unsigned)tiles_per_row) * kFramesPerWave;

@@ -1022,7 +1022,9 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
         # chip-wide list kernel it saved; profiles/r04_b_configs.jsonl.  The in-kernel grid barrier form (all workgroups meet, each
         # redoes the flagged tiles of a strided share) was built and measured too: + 2.3 us -- un-profiled, the two small launches
         # cost ~5.5 us together, the barrier 3 us and the write-through stores a cross-XCD rewrite needs 4-6 us;
-        # profiles/r04_p_mfcc_one_launch.txt.  Two launches stay.)
+        # profiles/r04_p_mfcc_one_launch.txt.  What that measurement did pay for: the chip-wide list kernel between the passes is
+        # gone -- the fix-up launch's workgroups check a strided share of the tile minima themselves and leave when none is
+        # flagged.  Two launches per call.)
         f = _lib.MfccFused(state.frag.data_ptr(), n_mfcc, 0, float(db[0]), float(db[1]), float(db[2]), float(top_db),
                            gmax.data_ptr(), max(packed, 1), tile_min.data_ptr(), count.data_ptr(), tile_list.data_ptr())
         args = (x2.data_ptr(), _padded_window(window, n_fft).data_ptr(), _twiddles(n_fft, dev).data_ptr(),

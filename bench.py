@@ -524,7 +524,7 @@ def main():
             mfcc_report = mod.fused_report()
             if mfcc_report["calls_two_kernel"] == 0:
                 kernels = ["melspec400_kernel<EPI400_MFCC> pass 0 (mel + dB + DCT on the f16 matrix pipe + group max)",
-                           "mfcc_fix_list_kernel", "melspec400_kernel<EPI400_MFCC> fix-up pass"]
+                           "melspec400_kernel<EPI400_MFCC> fix-up launch (each workgroup checks its share of the tile minima)"]
         xs = ys = None
         torch.cuda.empty_cache()
         configs = None

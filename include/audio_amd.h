@@ -177,7 +177,9 @@ int aamd_melspectrogram_db_f32(const float* wav, const float* window, const floa
  *           into group_max (caller pre-fills with -inf) and records the smallest dB value of every 6-frame tile in tile_min;
  *   (multi-GPU: all-reduce group_max with MAX here)
  *   pass 1  redoes, clamped at group_max[g] - top_db, exactly the tiles whose minimum lies under that cut-off and counts
- *           them in fix_count (required in both passes: pass 0 resets it).  Batches in which nothing reaches the cut-off pay ~2 us for it; batches in which
+ *           them in fix_count (required in both passes: pass 0 resets it); every workgroup of this launch checks a strided
+ *           share of the tile minima itself (its flagged tiles go to a private run of tile_list) and leaves when none is
+ *           flagged -- no separate compaction kernel between the passes.  Batches in which nothing reaches the cut-off pay ~2 us for it; batches in which
  *           most tiles do should take aamd_melspectrogram_db_f32 + aamd_mfcc_dct_f32 (the caller's choice).
  * Results equal the two-kernel path's up to the rounding of the fp32 contraction order. */
 typedef struct aamd_mfcc_fused {
@@ -189,8 +191,8 @@ typedef struct aamd_mfcc_fused {
   int64_t rows_per_group;
   float* tile_min;         /* device float[aamd_mfcc_fused_tiles(desc)] */
   int32_t* fix_count;      /* device int32: pass 0 resets it, pass 1 leaves the number of tiles it redoes here */
-  int32_t* tile_list;      /* device int32[aamd_mfcc_fused_tiles(desc)]: scratch of pass 1 -- the tiles under the cut-off,
-                              compacted, so that the fix-up launch deals them out evenly however they cluster by clip */
+  int32_t* tile_list;      /* device int32[aamd_mfcc_fused_tiles(desc)]: scratch of pass 1 -- each workgroup's flagged tiles (its
+                              candidates are every n-th tile, so clamped tiles spread evenly however they cluster by clip) */
 } aamd_mfcc_fused;
 int32_t aamd_mfcc_frag_floats(void);
 int64_t aamd_mfcc_fused_tiles(const aamd_stft_desc* desc);

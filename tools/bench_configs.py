@@ -18,10 +18,27 @@ import audio_amd.transforms as T
 HBM, FP32, F16 = 8000.0, 157.3, 2500.0   # GB/s, TFLOP/s fp32 vector / MFMA, TFLOP/s dense f16 MFMA (MI355X_MICROARCH.md)
 
 
-def timed(fn, warmup, steps):
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
+RAMP_MS = 60.0   # GPU time of set-up launches per workload before its warm-up counts as done (see timed())
+
+
+def timed(fn, warmup, steps, ramp_ms=None):
+    """ms per call, steady state.  Set-up as in bench.py (--clock-ramp): a workload that starts on a chip that was idle -- or
+    was running something else -- runs 8-12 % slow for its first 25-30 ms while power management settles, whatever the
+    kernel (cfg5a: 271 us per call over launches 10..60 of a fresh process against 240 us from launch ~110 on; cfg3 611
+    against 558 us; profiles/r04_t_clock_ramp_configs.txt).  Ten warm-up launches of a 0.25 ms kernel end inside that ramp,
+    so the warm-up repeats until RAMP_MS of GPU time have gone by."""
+    ramp_ms = RAMP_MS if ramp_ms is None else ramp_ms
+    spent = 0.0
+    while True:
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record()
+        for _ in range(max(warmup, 1)):
+            fn()
+        r1.record()
+        torch.cuda.synchronize()
+        spent += r0.elapsed_time(r1)
+        if spent >= ramp_ms:
+            break
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(steps):
@@ -57,7 +74,7 @@ def measure_configs(dev, steps=200, warmup=100, which=None, gen_seed=1234):
         return step
 
     def emit(key, name, ms, clip_seconds, algo_bytes, flops=None, note="", f16_terms=0, channels=1, extra=None):
-        rec = {"id": key, "workload": name, "ms": ms, "clip_seconds_per_launch": clip_seconds,
+        rec = {"id": key, "workload": name, "ms": ms, "clock_ramp_ms": RAMP_MS, "clip_seconds_per_launch": clip_seconds,
                "value": clip_seconds / (ms * 1e-3), "unit": "audio-sec/sec (per GPU)", "algorithmic_bytes": algo_bytes,
                "roofline": {"bound": "hbm", "achieved": algo_bytes / ms / 1e6, "peak": HBM, "unit": "GB/s",
                             "frac": algo_bytes / ms / 1e6 / HBM}}
@@ -105,7 +122,7 @@ def measure_configs(dev, steps=200, warmup=100, which=None, gen_seed=1234):
                      note="3 input batches rotate",
                      extra={"mfcc_path": rep["path"], "mfcc_fused_setting": repr(mf.fused), "mfcc_decided": rep["decided"],
                             "mfcc_redone_share": rep["redone_share"],
-                            "kernels": ("melspec400_kernel<EPI400_MFCC> pass 0 + mfcc_fix_list_kernel + fix-up pass"
+                            "kernels": ("melspec400_kernel<EPI400_MFCC> pass 0 + fix-up launch of the same kernel"
                                         if rep["path"] == "fused" else
                                         "melspec400_kernel<EPI400_MEL_DB> + mfcc_dct_mfma_kernel")})
             if on("cfg4_per_item"):
