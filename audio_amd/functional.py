@@ -964,7 +964,7 @@ class MfccFusedState:
     ``group_max_hook`` is installed (every rank of a sharded batch must run the same arithmetic; a rank cannot know what the
     others saw).  ``MFCC.fused_report()`` says what ran and why; ``MFCC.reset_fused_decision()`` forgets the decision."""
 
-    def __init__(self, max_share: float = 0.12):
+    def __init__(self, max_share: float = 0.15):
         self.frag = None
         self.frag_key = None
         self.frag_src = None          # weak reference to the DCT tensor the fragments were built from

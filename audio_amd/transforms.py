@@ -444,7 +444,7 @@ class MFCC(torch.nn.Module):
         #: EXTENSION: which MFCC path runs.  True = the one-kernel MFCC (DCT on the f16 matrix pipe in the mel kernel's epilogue,
         #: operands split into two binary16 numbers, + a fix-up launch over the compacted list of tiles the top_db cut-off
         #: reaches); False = the exact two-kernel path; both are bit-reproducible call to call.  "auto" (default) decides ONCE
-        #: per module, at its first eligible call, from the share of tiles that call had to redo (> 12 %: two kernels are
+        #: per module, at its first eligible call, from the share of tiles that call had to redo (> 15 %: two kernels are
         #: cheaper) and keeps that arithmetic for every later call (F.MfccFusedState; round 3 re-decided from a polled event,
         #: so equal inputs could return different bits).  A group_max_hook (sharded batches) or a HIP-graph capture in
         #: progress run the one-kernel path without deciding.  Same results within 3e-5 dB.  Measured on the cfg4 batch
