@@ -1054,7 +1054,17 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   const int tab_dwords = (EPI != EPI400_SPEC) ? mel_tab_dwords(mb.n_mels, mb.max_width) : 0;
   // tile queue of this workgroup: the next unclaimed tile (waves start on tiles 0 .. W-1)
   int* queue = reinterpret_cast<int*>(const_tab + kConstDwords + tab_dwords);
-  if (threadIdx.x == 0) *queue = kWavesPerBlock;
+  // lab bit 24 (16777216, tools/mel400_lab.py): UPPER BOUND of a wave-specialised variant, emulated without
+  // any hand-off: the last wave of the workgroup is an I/O wave that issues every LDS-DMA of the workgroup's tiles (into the
+  // staging areas, 8 tiles in flight) and every output store (16-byte stores from LDS), the other 11 waves claim all the
+  // tiles and run the arithmetic with no vector-memory instruction at all (build with bits 1 | 2 | 8 and launch with the wide
+  // store path, so phase C still ends in the LDS staging writes a real hand-off needs).  Outputs are garbage -- nothing
+  // orders the two kinds of waves -- the TIME is what a perfect, free hand-off would approach.  Bit 25: the I/O wave idles.
+  // Bit 26: TWO I/O waves (tiles dealt alternately, 10 compute waves).  Bit 27: the I/O waves only fetch; the compute waves
+  // keep their own (narrow) stores -- build without bit 2 and launch the narrow path.
+  constexpr bool kIoWave = (LAB & 16777216) != 0;
+  constexpr int kNio = kIoWave ? ((LAB & 67108864) ? 2 : 1) : 0;
+  if (threadIdx.x == 0) *queue = kWavesPerBlock - kNio;
   // MFCC: the DCT fragments (18 KB) live in LDS behind the queue -- fetched from memory per tile they cost 18 global
   // loads per lane whose registers (prefetch) pushed the kernel into scratch, and a scratch reload waits for the LDS-DMA in
   // flight (one in-order vmcnt)
@@ -1223,6 +1233,37 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     wmax = -INFINITY;
   };
 
+  if (kIoWave && wave >= kWavesPerBlock - kNio) {
+    constexpr unsigned D = 8;                              // tiles in flight per I/O wave
+    constexpr bool kFetchOnly = (LAB & 134217728) != 0;
+    if (!(LAB & 33554432)) {
+      const unsigned n_mine = (blk_count + (unsigned)kNio - 1u - (unsigned)(wave - (kWavesPerBlock - kNio))) / (unsigned)kNio;
+      for (unsigned i = 0; i < n_mine + D; ++i) {
+        const unsigned t = i * (unsigned)kNio + (unsigned)(wave - (kWavesPerBlock - kNio));
+        if (i < n_mine) {
+          const TileInfo ti = tile_info(t);
+          const unsigned dst = (unsigned)(uintptr_t)(smem400 + (t % (unsigned)kWavesPerBlock) * HC::lds_dwords + kSOff);
+          if (ti.staged) {
+            const TIn* src = wav + (ti.row / InTraits<TIn>::chans) * row_stride + (ti.t0 * kHop - kPad);
+#pragma unroll
+            for (int k = 0; k < SG::ndma; ++k) glds16(src + spiece[k], dst + 1024 * k);
+          }
+        }
+        if (i >= D) {
+          if (kFetchOnly) {
+            asm volatile("s_waitcnt vmcnt(40)" ::: "memory");   // 5 D younger operations
+          } else {
+            asm volatile("s_waitcnt vmcnt(56)" ::: "memory");   // 7 D younger operations: the pieces of the tile D back have landed
+            const unsigned told = t - D * (unsigned)kNio;
+            const TileInfo to = tile_info(told);
+            const float* stg = smem400 + (told % (unsigned)kWavesPerBlock) * HC::lds_dwords;
+            store_wide(lane, mt, stg, out + to.row * (int64_t)n_frames * (int64_t)mb.n_mels, to.t0, n_frames);
+          }
+        }
+      }
+    }
+    blk_count = 0;                                         // (this wave's copy: it runs no tile)
+  }
   unsigned cur_idx = (LAB & 131072) ? g_base : (unsigned)wave;
   TileInfo cur = tile_info(cur_idx);
   if (LAB & 128) {   // lab: stagger the waves of a SIMD by thirds of a tile time.  Interleaved A/B runs

@@ -84,10 +84,12 @@ def run(names, launches, rounds, rows=256, seconds=10.0, wide=0, blocks=0):
         L.lab_set_debug.argtypes = [C.c_void_p]
         L.lab_set_debug(dbg.data_ptr())
 
+    wide_of = {id(L): (1 if n.endswith("_w") else wide) for n, L in libs.items()}   # variants named *_w: the wide store path
+
     def launch(L, i):
         x, o = xs[i % 4], outs[i % 5]
         rc = L.lab_mel400(x.data_ptr(), window.data_ptr(), tw.data_ptr(), C.byref(bands.struct), o.data_ptr(), rows, length,
-                          length, n_frames, 1.0, wide, blocks, stream)
+                          length, n_frames, 1.0, wide_of[id(L)], blocks, stream)
         assert rc == 0, rc
         return o
 
