@@ -945,6 +945,49 @@ def _mfcc_dct_launch(mel2: Tensor, dct: Tensor, log_mode: int, gmax: Optional[Te
     return out
 
 
+class _NegInfPool:
+    """-inf-filled float32 scratch for the group maxima of the top_db cut-off, handed out in slices.
+
+    Every MFCC / amplitude_to_DB call needs a handful of floats pre-filled with -inf (the kernels max-reduce into them with
+    atomics).  A ``torch.full`` per call is a kernel of its own in front of the transform -- 3-5 us of every ~190 us MFCC call on
+    the cfg4 batch (profiles/r04_p_mfcc_one_launch.txt: the launches around the main kernel are what is left to remove).  One
+    fill covers ~32 calls instead: the pool is filled once ON the stream that uses it and each call takes the next slice, used
+    exactly once.  Pools are per (device, stream) -- a slice is only ever touched by launches ordered behind its fill -- and are
+    bypassed while a HIP graph is being captured (a captured call must own its fill) and for large requests."""
+
+    def __init__(self, calls_per_fill: int = 32, max_request: int = 4096):
+        self.lock = threading.Lock()
+        self.pools = {}
+        self.calls_per_fill = calls_per_fill
+        self.max_request = max_request
+
+    def take(self, n: int, dev: torch.device) -> Tensor:
+        if torch.device(dev).type != "cuda":         # (host-logic tests drive the callers with stubbed launches)
+            return torch.full((max(n, 0),), float("-inf"), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):                 # (the capture status and the current stream are per device)
+            if n > self.max_request or n <= 0 or torch.cuda.is_current_stream_capturing():
+                return torch.full((max(n, 0),), float("-inf"), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream()
+            key = (stream.device_index, stream.cuda_stream)
+            return self._slice(key, n, dev)
+
+    def _slice(self, key, n: int, dev: torch.device) -> Tensor:
+        with self.lock:
+            ent = self.pools.get(key)
+            if ent is None or ent[1] + n > ent[0].numel():
+                if len(self.pools) >= 32:            # streams come and go: forget the lot rather than grow without bound
+                    self.pools.clear()
+                buf = torch.full((max(self.calls_per_fill * n, 1024),), float("-inf"), dtype=torch.float32, device=dev)
+                ent = [buf, 0]
+                self.pools[key] = ent
+            out = ent[0][ent[1]:ent[1] + n]
+            ent[1] += n
+        return out
+
+
+_neg_inf = _NegInfPool()
+
+
 class MfccFusedState:
     """What the module keeps between calls of the one-kernel MFCC: the DCT matrix in the kernel's operand layout, and the
     module's path DECISION.
@@ -1007,7 +1050,7 @@ def _mfcc_fused(waveform: Tensor, window: Tensor, fb: Tensor, dct: Tensor, n_fft
             state.frag, state.frag_key, state.frag_src = frag, key, weakref.ref(dct)
         n_tiles = int(L.aamd_mfcc_fused_tiles(C.byref(desc)))
         out = torch.empty((desc.rows, desc.n_frames, n_mfcc), dtype=torch.float32, device=dev)
-        gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
+        gmax = _neg_inf.take(n_groups, dev)
         if out.numel() == 0:
             # an empty shard still takes part in the exchange of the batch-global cut-off: the other ranks are waiting in the
             # same all-reduce (returning before the hook hung the job)
@@ -1094,7 +1137,7 @@ def _mfcc(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, dct_mat: Tenso
         if fused_state is not None:
             fused_state.path = "two-kernel"
             fused_state.calls_two_kernel += 1
-        gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=dev)
+        gmax = _neg_inf.take(n_groups, dev)
         mel = _melspectrogram(waveform, pad, window, fb, n_fft, hop_length, win_length, power, normalized, center,
                               pad_mode, db=(db[0], db[1], db[2], gmax, max(packed, 1)))
         rows, T, n_mels = mel.shape
@@ -1182,7 +1225,7 @@ def amplitude_to_DB(x: Tensor, multiplier: float, amin: float, db_multiplier: fl
     packed = shape[-3] if x.dim() > 2 else 1
     group = packed * shape[-2] * shape[-1]
     n_groups = n // group
-    gmax = torch.full((n_groups,), float("-inf"), dtype=torch.float32, device=x.device)
+    gmax = _neg_inf.take(n_groups, x.device)
     # pass 1: group maxima only (reads x, writes nothing); pass 2: dB + clamp + store
     _lib.check(L.aamd_amplitude_to_db_f32(xc.data_ptr(), None, n, multiplier, amin, db_multiplier, gmax.data_ptr(), group,
                                           stream))

@@ -696,6 +696,41 @@ def test_mfcc_one_kernel_path_equals_two_kernel_path_and_oracle(hop, n_mfcc, sha
         assert float(np.abs(a.cpu().numpy() - exp).max()) <= 2e-6 * float(np.abs(exp).max()) + 5e-4      # MFCC absolute (dB scale)
 
 
+def test_group_max_scratch_pool_hands_out_fresh_slices():
+    """The -inf scratch of the top_db group maxima comes from a per-(device, stream) pool filled once per ~32 calls (one
+    launch less per MFCC / amplitude_to_DB call): every slice is -inf when handed out, no two calls share one, a second stream
+    gets its own pool, a capture in progress bypasses the pool, and results do not change across a refill."""
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    dev = torch.device("cuda", 0)
+    pool = F._NegInfPool(calls_per_fill=4)
+    seen, live = [], []
+    for i in range(11):
+        t = pool.take(300, dev)
+        assert t.shape == (300,) and bool(torch.isinf(t).all()) and bool((t < 0).all())
+        seen.append((t.untyped_storage().data_ptr(), t.storage_offset()))
+        live.append(t)                               # (a dropped pool's memory may come back from the allocator: compare LIVE slices)
+        t.fill_(float(i))                            # a call max-reduces into its slice: the next one must not see that
+    assert len(set(seen)) == len(seen)
+    assert len({p for p, _ in seen}) >= 2            # refilled at least once
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        u = pool.take(300, dev)
+    assert u.untyped_storage().data_ptr() not in {p for p, _ in seen} and bool(torch.isinf(u).all())
+    big = pool.take(100000, dev)
+    assert big.storage_offset() == 0 and big.numel() == 100000
+    g = torch.Generator().manual_seed(3)
+    x = (0.4 * torch.randn(6, 20000, generator=g)).clamp_(-1, 1).cuda()
+    x[2, 9000:] = 0.0
+    db = T.AmplitudeToDB(top_db=60.0).cuda()
+    mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).cuda()
+    with torch.no_grad():
+        p = mel(x)
+        first = db(p).clone()
+        for i in range(70):                          # across two refills of the module-level pool
+            assert torch.equal(db(p), first), i
+
+
 def test_mfcc_path_choice_is_taken_once_per_module():
     """`fused="auto"`: the module decides at its FIRST eligible call (synchronised) from the share of tiles that call had to
     redo, and keeps that arithmetic; a zero-padded first batch puts it on the two-kernel path -- including for that first
