@@ -87,3 +87,27 @@ def test_abi_header_symbols_exported():
     for name in declared:
         assert hasattr(L, name)
     assert L.aamd_abi_version() == 5
+
+
+def test_mfcc_fixup_shares_partition_the_tiles():
+    """The fix-up launch of the fused MFCC (csrc/melspec400.h, top of melspec400_kernel): workgroup b of nb checks the tiles
+    b, b + nb, ... and keeps its flagged ones in a private run of the n_tiles-entry scratch list starting at
+    b * (nt / nb) + min(b, nt % nb).  Restated here (the kernel body is device code): every tile is some workgroup's candidate
+    exactly once, and the private runs are disjoint, in order, and exactly fill [0, nt)."""
+    import random
+    rnd = random.Random(7)
+    cases = [(1, 1), (5, 8), (8, 8), (9, 8), (85504, 256), (42752, 256), (167, 24), (1000003, 248)]
+    cases += [(rnd.randint(1, 5000), rnd.choice([1, 8, 16, 104, 248, 256])) for _ in range(40)]
+    for nt, nb in cases:
+        seen = [0] * nt
+        end_prev = 0
+        for b in range(nb):
+            n_cand = (nt - b + nb - 1) // nb if b < nt else 0
+            base = b * (nt // nb) + min(b, nt % nb)
+            assert base == end_prev, (nt, nb, b)
+            end_prev = base + n_cand
+            for k in range(n_cand):
+                t = b + k * nb
+                assert 0 <= t < nt
+                seen[t] += 1
+        assert end_prev == nt and all(c == 1 for c in seen), (nt, nb)
