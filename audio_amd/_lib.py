@@ -124,6 +124,8 @@ _SIGS = {
     "aamd_fftconvolve_plan": (C.c_int, [C.c_int64] * 4),
     "aamd_fftconvolve_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
                                        C.c_int64, C.c_int64, _P, _P]),
+    "aamd_fftconvolve_staged_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
+                                              C.c_int64, C.c_int64, _P, C.c_int32, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
@@ -145,7 +147,7 @@ def lib():
                 fn = getattr(h, name)   # AttributeError if the ABI symbol is missing
                 fn.restype = res
                 fn.argtypes = args
-            if h.aamd_abi_version() != 5:
+            if h.aamd_abi_version() != 6:
                 raise RuntimeError("audio_amd: ABI version mismatch between _lib.py and libaudio_amd.so")
             _lib = h
     return _lib

@@ -25,7 +25,9 @@ OPS = ("spectrogram", "mel_spectrogram", "mel_spectrogram_db", "mfcc_dct", "resa
        # round 4: the rest of the compute entries of include/audio_amd.h (one op per native entry, as the reference does)
        "mel_spectrogram_lognorm", "mfcc_frag_build", "mfcc_fused", "istft", "istft_f64", "spectrogram_f64", "phase_vocoder",
        "griffinlim_update", "mel_scale", "amplitude_to_db", "amplitude_to_db_clamped", "db_clamp", "spectrogram_grad",
-       "mel_spectrogram_grad", "resample_sparse", "kaldi_features", "lfilter_f64", "resample_f64", "fftconvolve_f64")
+       "mel_spectrogram_grad", "resample_sparse", "kaldi_features", "lfilter_f64", "resample_f64", "fftconvolve_f64",
+       # round 5: the staged form of fftconvolve (prepared tap spectra for a repeated impulse response)
+       "fftconvolve_staged")
 
 _lock = threading.Lock()
 _handle = None
@@ -46,7 +48,7 @@ def load():
             torch.ops.load_library(SHIM_PATH)
             h = C.CDLL(SHIM_PATH)
             h.aamd_torch_shim_abi.restype = C.c_int
-            if h.aamd_torch_shim_abi() != 5:
+            if h.aamd_torch_shim_abi() != 6:
                 raise RuntimeError("audio_amd: ABI version mismatch between the torch shim and include/audio_amd.h")
             _register_fakes()
             _handle = h
@@ -89,6 +91,10 @@ def _register_fakes() -> None:
     @reg("aamd::fftconvolve")
     def _(x, y, x_row_of, y_row_of, rows, start, out_len):
         return x.new_empty((rows, out_len))
+
+    @reg("aamd::fftconvolve_staged")
+    def _(x, y, x_row_of, y_row_of, rows, start, out_len, workspace, stages):
+        return x.new_empty((rows if stages & 2 else 0, out_len))
 
     # ---- round 4 ops ----
     @reg("aamd::mel_spectrogram_lognorm")

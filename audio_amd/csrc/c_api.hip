@@ -1406,7 +1406,10 @@ static bool fftconv_pick_fdl(int64_t rows, int64_t taps, int64_t out_len, fco::F
   return cheaper || ((policy() & AAMD_POLICY_FFTCONV_FDL) && f.n_blocks >= 2);
 }
 
-// the real-block delay line (fftconv_fdr.h): 8193 .. 24576 taps, unless the policy asks for the complex-block kernels
+// the real-block kernel (fftconv_fdr.h, plan 3): EVERY FFT-eligible tap count up to 24576 -- plain overlap-save on real blocks up
+// to 8192 taps (one partition, no delay line), the register delay line for 8193 .. 24576 -- unless ANY of the three FFTCONV
+// policy bits is set: NO_FDL / FDL / COMPLEX all select the complex-block kernels (plans 1 / 2) for all tap counts, also for
+// <= 8192 taps where plan 3 is not a delay line at all (the bits exist for A/B runs against the round-1..3 kernels)
 static bool fftconv_pick_fdr(int64_t rows, int64_t taps, int64_t out_len, fdr::Geom& g) {
   if (policy() & (AAMD_POLICY_FFTCONV_NO_FDL | AAMD_POLICY_FFTCONV_FDL | AAMD_POLICY_FFTCONV_COMPLEX)) return false;
   return fdr::plan(rows, taps, out_len, dev_props().cu_count, g);
@@ -1439,8 +1442,22 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
                          int64_t n_y_rows, int64_t nx, int64_t ny, const int64_t* x_row_of,
                          const int64_t* y_row_of, int64_t start, int64_t out_len, void* workspace,
                          void* stream) {
-  DeviceScope dev_scope_(x);
-  AAMD_CHECK_ARG(x && y && out, "null buffer");
+  return aamd_fftconvolve_staged_f32(x, y, out, rows, n_x_rows, n_y_rows, nx, ny, x_row_of, y_row_of, start, out_len,
+                                     workspace, AAMD_FFTCONV_PREPARE | AAMD_FFTCONV_RUN, stream);
+}
+
+// stages: PREPARE lays the twiddles and the tap spectra of the plan down in the workspace (two small launches), RUN walks the
+// rows.  A caller that convolves many batches with ONE impulse response prepares once and runs with the same workspace
+// afterwards (the plan must be the same: aamd_fftconvolve_plan, same policy, same tap rows).
+int aamd_fftconvolve_staged_f32(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows,
+                                int64_t n_y_rows, int64_t nx, int64_t ny, const int64_t* x_row_of,
+                                const int64_t* y_row_of, int64_t start, int64_t out_len, void* workspace,
+                                int32_t stages, void* stream) {
+  const bool prep = (stages & AAMD_FFTCONV_PREPARE) != 0, run = (stages & AAMD_FFTCONV_RUN) != 0;
+  AAMD_CHECK_ARG((prep || run) && !(stages & ~(AAMD_FFTCONV_PREPARE | AAMD_FFTCONV_RUN)), "stages: PREPARE, RUN or both");
+  DeviceScope dev_scope_(run ? (const void*)x : (const void*)workspace);
+  AAMD_CHECK_ARG(!run || (x && y && out), "null buffer");
+  AAMD_CHECK_ARG(!prep || y, "null tap buffer");
   AAMD_CHECK_ARG(rows >= 0 && nx >= 1 && ny >= 1 && n_x_rows >= 1 && n_y_rows >= 1, "bad sizes");
   AAMD_CHECK_ARG(start >= 0 && out_len >= 0 && start + out_len <= nx + ny - 1, "slice outside the full convolution");
   if (rows == 0 || out_len == 0) return AAMD_OK;
@@ -1453,6 +1470,7 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
   const int64_t* xmap = swap ? y_row_of : x_row_of;
   const int64_t* ymap = swap ? x_row_of : y_row_of;
   hipStream_t s = (hipStream_t)stream;
+  AAMD_CHECK_ARG(!prep || ya, "null tap buffer");
   if (fftconv_use_fft(nya)) {
     AAMD_CHECK_ARG(workspace != nullptr, "fftconvolve needs the workspace of aamd_fftconvolve_workspace()");
     AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(workspace) % 8 == 0, "workspace must be 8-byte aligned");
@@ -1466,7 +1484,7 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fco::overlap_save_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fco::twiddle_kernel, dim3(fco::kN / 256), dim3(256), 0, s, tw);
+    if (prep) hipLaunchKernelGGL(fco::twiddle_kernel, dim3(fco::kN / 256), dim3(256), 0, s, tw);
     fdr::Geom fg{};
     fg.rows = rows; fg.nx = nxa; fg.ny = nya; fg.start = start; fg.out_len = out_len;
     if (fftconv_pick_fdr(rows, nya, out_len, fg)) {
@@ -1474,10 +1492,13 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
       // (8192 complex per partition) fit the space the workspace reserves for the complex-block plans (16384 per partition).
       const size_t lds_r = (size_t)fdr::kLdsComplex * sizeof(fco::C32);
       AAMD_CHECK_ARG(tap_rows * fg.n_part < (1ll << 31) && rows * fg.segs < (1ll << 31), "too many tap rows / work items");
-      AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fdr::spectrum_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-      hipLaunchKernelGGL(fdr::spectrum_kernel, dim3((unsigned)(tap_rows * fg.n_part)), dim3(fdr::kThreads), lds_r, s, nya,
-                         fg.n_part, ya, tw, H);
+      if (prep) {
+        AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fdr::spectrum_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+        hipLaunchKernelGGL(fdr::spectrum_kernel, dim3((unsigned)(tap_rows * fg.n_part)), dim3(fdr::kThreads), lds_r, s, nya,
+                           fg.n_part, ya, tw, H);
+      }
+      if (!run) return launch_check();
       int64_t blocks = dev_props().cu_count;
       if (blocks > rows * fg.segs) blocks = rows * fg.segs;
 #define AAMD_FDR(NP)                                                                                          \
@@ -1498,8 +1519,10 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
       fco::Geom gs = g;
       gs.n_part = f.n_part; gs.part_taps = fco::kHop;
       AAMD_CHECK_ARG(tap_rows * f.n_part < (1ll << 31), "too many tap rows");
-      hipLaunchKernelGGL(fco::spectrum_kernel, dim3((unsigned)(tap_rows * f.n_part)), dim3(fco::kThreads), lds, s, gs,
-                         ya, tw, H);
+      if (prep)
+        hipLaunchKernelGGL(fco::spectrum_kernel, dim3((unsigned)(tap_rows * f.n_part)), dim3(fco::kThreads), lds, s, gs,
+                           ya, tw, H);
+      if (!run) return launch_check();
       const int64_t n_spec = tap_rows * (f.n_part > g.n_part ? f.n_part : g.n_part);
       fco::C32* ring = H + n_spec * fco::kN;
       int64_t blocks = dev_props().cu_count;
@@ -1520,8 +1543,10 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
       return launch_check();
     }
     AAMD_CHECK_ARG(tap_rows * g.n_part < (1ll << 31), "too many tap rows");
-    hipLaunchKernelGGL(fco::spectrum_kernel, dim3((unsigned)(tap_rows * g.n_part)), dim3(fco::kThreads), lds, s, g,
-                       ya, tw, H);
+    if (prep)
+      hipLaunchKernelGGL(fco::spectrum_kernel, dim3((unsigned)(tap_rows * g.n_part)), dim3(fco::kThreads), lds, s, g,
+                         ya, tw, H);
+    if (!run) return launch_check();
     const int64_t items = rows * g.n_pairs;
     int64_t blocks = dev_props().cu_count;
     if (blocks > items) blocks = items;
@@ -1529,6 +1554,7 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
                        xmap, ymap, out);
     return launch_check();
   }
+  if (!run) return AAMD_OK;             // the time-domain kernel reads the taps as they are: nothing to prepare
   FcGeom g;
   g.rows = rows; g.start = start; g.out_len = out_len;
   g.nx = nxa;

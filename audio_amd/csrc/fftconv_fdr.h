@@ -175,6 +175,39 @@ AAMD_HD void pass_m16(int tid, C32* lds, const C32* tl) {
   lds_write8<AAMD_FDR_M16>(cell, v);
 }
 
+// The same pass with the first NR of its 7 twiddles W_128^(j k) held in registers: they depend on the lane only (j = tid & 15),
+// so 2 NR registers replace NR ds_read_b64 in each direction of every step (round 5; the values are the table's own entries:
+// bit-identical results).  w[k - 1] = tl[kTw3 + 16 (k - 1) + j]; twiddles NR + 1 .. 7 still come from the table.
+template <int NR>
+AAMD_HD void load_tw3(int tid, const C32* tl, C32 (&w)[7]) {
+#pragma unroll
+  for (int k = 0; k < 7; ++k) w[k] = k < NR ? tl[kTw3 + 16 * k + (tid & 15)] : C32{0.0f, 0.0f};
+}
+template <bool inv, int NR>
+AAMD_HD void pass_m16_regtw(int tid, C32* lds, const C32* tl, const C32 (&wr)[7]) {
+  tid = fco::opaque(tid);
+  const int sub = (tid >> 4) & 3;
+  const int blk = ((tid >> 6) << 2) + (((sub & 1) << 1) | (sub >> 1)), j = tid & 15;
+  C32* cell = lds + pad(128 * blk + j);
+  C32 v[8], w[7];
+  lds_read8<AAMD_FDR_M16>(cell, v);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    if (k < NR) w[k] = wr[k];
+    else { w[k] = tl[kTw3 + 16 * k + j]; AAMD_FDR_FENCE }
+  }
+  if (inv) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = fco::cmulc<true>(v[k], w[k - 1]);
+  }
+  dft8<inv>(v);
+  if (!inv) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v[k] = fco::cmulc<false>(v[k], w[k - 1]);
+  }
+  lds_write8<AAMD_FDR_M16>(cell, v);
+}
+
 // ---- pass 4 (length 16, m = 2) + the final radix-2 (length 2): thread (blk, j) owns 16 blk + j + 2 r.  The radix-2 pairs
 // positions (2 q, 2 q + 1) = output r of lane j = 0 with output r of lane j = 1: a neighbour exchange (DPP on the device; the
 // CPU replay hands over the neighbour's array).  Forward: o = twiddled DFT-8 outputs; lane 0 keeps o0 + o1, lane 1 o0 - o1. ----
@@ -421,6 +454,13 @@ AAMD_HD void load_taps(int tid, int64_t ny, const float* yr, int p, C32 (&v)[8])
 constexpr float kSpectrumScale = 1.0f / (8.0f * (float)kM);      // un-halved split (2) x un-halved merge (2) x split of H (2) x M
 
 #if defined(__HIPCC__)
+// lab switches (tools/fdr_lab.py; timing only, the results are wrong): AAMD_FDR_LAB_NOBAR bit 0 turns the barriers around the
+// length-1024 pass into wave-local fences, bit 1 those around the middle step, bit 2 the ones of the first / last pass --
+// an upper bound on what any restructuring of the barriers could win; AAMD_FDR_LAB_NOH reads no tap spectra
+#ifndef AAMD_FDR_LAB_NOBAR
+#define AAMD_FDR_LAB_NOBAR 0
+#endif
+#define AAMD_FDR_BARRIER(BIT) do { if (AAMD_FDR_LAB_NOBAR & (BIT)) fco::wave_sync(); else __syncthreads(); } while (0)
 // neighbour exchange (lane ^ 1) of 8 complex registers: DPP quad_perm [1, 0, 3, 2]
 __device__ __forceinline__ void swap_neighbour(const C32 (&o)[8], C32 (&nb)[8]) {
 #pragma unroll
@@ -430,33 +470,44 @@ __device__ __forceinline__ void swap_neighbour(const C32 (&o)[8], C32 (&nb)[8]) 
   }
 }
 // forward transform of the block in v (registers) to the digit-reversed spectrum in LDS; ends with a workgroup barrier
-__device__ __forceinline__ void forward_block(int tid, C32 (&v)[8], C32* lds, const C32* tl) {
+// how many of the 7 twiddles of the length-128 pass live in registers, by partition count (the 3-partition kernel holds two
+// delayed spectra and has fewer registers to spare: tools/fdr_lab.py reports registers and scratch per setting)
+#ifndef AAMD_FDR_TW3_N12
+#define AAMD_FDR_TW3_N12 7
+#endif
+#ifndef AAMD_FDR_TW3_N3
+#define AAMD_FDR_TW3_N3 5
+#endif
+template <int NP> struct Tw3Regs { static constexpr int n = NP >= 3 ? AAMD_FDR_TW3_N3 : AAMD_FDR_TW3_N12; };
+template <int NR>
+__device__ __forceinline__ void forward_block(int tid, C32 (&v)[8], C32* lds, const C32* tl, const C32 (&tw3)[7]) {
   first_pass_from_regs(tid, v, lds, tl);
-  __syncthreads();
+  AAMD_FDR_BARRIER(4);
   pass_m128<false>(tid, lds, tl);
-  __syncthreads();
-  pass_m16<false>(tid, lds, tl);
+  AAMD_FDR_BARRIER(1);
+  if (NR > 0) pass_m16_regtw<false, NR>(tid, lds, tl, tw3); else pass_m16<false>(tid, lds, tl);
   fco::wave_sync();
   C32 o[8], nb[8];
   pass_m2_fwd_a(tid, lds, tl, o);
   swap_neighbour(o, nb);
   pass_m2_fwd_b(tid, o, nb, lds);
-  __syncthreads();
+  AAMD_FDR_BARRIER(2);
 }
 // ... and back: LDS spectrum (digit-reversed) -> the block's samples in v, in two halves (the kernel requests the next block's
 // samples between them: during the first half a thread holds the exchanged radix-2 operands on top of its delay line)
-__device__ __forceinline__ void inverse_block_a(int tid, C32* lds, const C32* tl) {
+template <int NR>
+__device__ __forceinline__ void inverse_block_a(int tid, C32* lds, const C32* tl, const C32 (&tw3)[7]) {
   C32 x[8], nb[8];
   pass_m2_inv_a(tid, lds, x);
   swap_neighbour(x, nb);
   pass_m2_inv_b(tid, x, nb, lds, tl);
   fco::wave_sync();
-  pass_m16<true>(tid, lds, tl);
-  __syncthreads();
+  if (NR > 0) pass_m16_regtw<true, NR>(tid, lds, tl, tw3); else pass_m16<true>(tid, lds, tl);
+  AAMD_FDR_BARRIER(1);
 }
 __device__ __forceinline__ void inverse_block_b(int tid, C32* lds, const C32* tl, C32 (&v)[8]) {
   pass_m128<true>(tid, lds, tl);
-  __syncthreads();
+  AAMD_FDR_BARRIER(4);
   last_pass_to_regs(tid, lds, tl, v);
 }
 
@@ -475,7 +526,9 @@ spectrum_kernel(int64_t ny, int n_part, const float* __restrict__ y, const C32* 
   C32 v[8];
   load_taps(tid, ny, y + yrow * ny, p, v);
   __syncthreads();
-  forward_block(tid, v, lds, tl);
+  C32 tw3[7];
+  load_tw3<7>(tid, tl, tw3);
+  forward_block<7>(tid, v, lds, tl, tw3);
   C32 z[8];
   mid_split(tid, lds, mc, z);
   C32* Hp = H + (int64_t)blockIdx.x * kHPerPart;
@@ -496,6 +549,25 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
   MidConst mc;
   mid_init(tid, tw16k, mc);
   __syncthreads();
+  constexpr int kTw3 = Tw3Regs<NP>::n;
+  C32 tw3[7];
+  load_tw3<kTw3>(tid, tl, tw3);
+#ifdef AAMD_FDR_PRIO
+  // lab (tools/fdr_lab.py): static issue priority per wave -- the four waves of a SIMD (w, w + 4, w + 8, w + 12) get distinct
+  // priorities so that they leave a pass one after the other instead of together
+  {
+#if AAMD_FDR_PRIO == 1
+    const int pr = __builtin_amdgcn_readfirstlane((threadIdx.x >> 8) & 3);
+#elif AAMD_FDR_PRIO == 2
+    const int pr = __builtin_amdgcn_readfirstlane(3 - ((threadIdx.x >> 8) & 3));
+#else
+    const int pr = __builtin_amdgcn_readfirstlane((threadIdx.x >> 9) & 1);
+#endif
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
+#endif
   const unsigned n_items = (unsigned)(g.rows * g.segs);          // < 2^31 (checked by the launcher): 32-bit item arithmetic
 #pragma unroll 1
   for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -528,17 +600,25 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
           C32 h[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) h[i] = (Hp + 1024 * i)[lane];
+#ifdef AAMD_FDR_LAB_NOH
+#pragma unroll
+          for (int i = 0; i < 8; ++i) h[i] = C32{1.0f + (float)i, 0.5f};
+#endif
           mid_mac(tid, h, z, acc);
         };
         if (NP > 1) part_early(Hr + kHPerPart, z1);
         if (NP > 2) part_early(Hr + 2 * kHPerPart, z2);
       }
-      forward_block(tid, v, lds, tl);
+      forward_block<kTw3>(tid, v, lds, tl, tw3);
       C32 h0[8];                           // H_0 of this thread's bins: requested before the split reads LDS (an L2 round trip)
       if (produce) {
         const unsigned lane = (unsigned)fco::opaque(tid);
 #pragma unroll
         for (int i = 0; i < 8; ++i) h0[i] = (Hr + 1024 * i)[lane];
+#ifdef AAMD_FDR_LAB_NOH
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h0[i] = C32{1.0f + (float)i, 0.25f};
+#endif
       }
       C32 z0[8];
       mid_split(tid, lds, mc, z0);
@@ -548,17 +628,17 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) { z2[i] = z1[i]; z1[i] = z0[i]; }
-      __syncthreads();
+      AAMD_FDR_BARRIER(2);
       // the next block's samples: in flight during the inverse passes and the stores (requested only now: during the middle
       // step the thread holds three spectra, the accumulators and a partition of tap spectra -- with these 16 registers on top
       // the 128-register budget of four waves per SIMD spilled)
-      if (produce) inverse_block_a(tid, lds, tl);
+      if (produce) inverse_block_a<kTw3>(tid, lds, tl, tw3);
       if (j + 1 < j_hi) load_block(tid, g, xr, j + 1, vin, v);
       if (produce) {
         C32 w[8];
         inverse_block_b(tid, lds, tl, w);
         store_block(tid, g, w, j, j_hi, vout, out_row);
-        __syncthreads();                   // the next first pass overwrites what the last pass has just read
+        AAMD_FDR_BARRIER(4);               // the next first pass overwrites what the last pass has just read
       }
     }
   }

@@ -1035,6 +1035,14 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   const int elab = (LAB & 524288) ? epi.lab : 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef AAMD_M400_PRIO
+  // lab (tools/mel400_lab.py): a static issue priority per wave; the waves w, w + 4, w + 8 of a SIMD get distinct ones
+  {
+    const int pr = AAMD_M400_PRIO == 1 ? (wave >> 2) : AAMD_M400_PRIO == 2 ? 2 - (wave >> 2) : (wave >> 2) == 0 ? 1 : 0;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+  }
+#endif
   long long lab_t0 = 0;
   if (LAB & 1024) lab_t0 = wall_clock64();
   if ((LAB & 1048576) && lane == 0) {  // lab: ... and at its entry (shader clock of the launch = cycles / wall time)

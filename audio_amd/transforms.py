@@ -486,9 +486,17 @@ class MFCC(torch.nn.Module):
             # differentiable mel spectrogram): the dB / top_db / DCT tail is cheap and torch's autograd
             # reproduces the reference's sub-gradients (clamp, amax) exactly
             if waveform.numel() == 0 and self.group_max_hook is not None and not self.log_mels:
-                # an empty shard still joins the exchange of the batch-global cut-off (the other ranks wait in it)
-                self.group_max_hook(torch.full((1,), float("-inf"), dtype=waveform.dtype, device=waveform.device))
-                T_ = 1 + waveform.shape[-1] // self.MelSpectrogram.hop_length
+                # an empty shard still joins the exchange of the batch-global cut-off (the other ranks wait in it): one -inf per
+                # cut-off group, counted as F._mfcc counts them, and the frame count every other path takes from the descriptor
+                # (`1 + L // hop` only held for center=True, pad=0)
+                sp_ = self.MelSpectrogram.spectrogram
+                packed = waveform.shape[-2] if waveform.dim() > 1 else 1
+                n_rows = 1
+                for d in waveform.shape[:-1]:
+                    n_rows *= d
+                n_groups = max(n_rows // max(packed, 1), 1)
+                self.group_max_hook(torch.full((n_groups,), float("-inf"), dtype=waveform.dtype, device=waveform.device))
+                T_ = max(_host.frame_count(waveform.shape[-1], sp_.n_fft, sp_.hop_length, sp_.center, sp_.pad), 0)
                 return waveform.new_zeros(tuple(waveform.shape[:-1]) + (self.n_mfcc, T_))
             mel = self.MelSpectrogram(waveform)
             if self.log_mels:

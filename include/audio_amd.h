@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define AAMD_ABI_VERSION 5
+#define AAMD_ABI_VERSION 6
 
 enum {
   AAMD_OK = 0,
@@ -127,7 +127,9 @@ enum {
   AAMD_POLICY_FFTCONV_NO_FDL = 16, /* overlap-save: never the frequency-domain delay-line plan */
   AAMD_POLICY_FFTCONV_FDL   = 32, /* overlap-save: the COMPLEX-block delay-line plan (2) whenever the tap count allows it (cost model ignored) */
   AAMD_POLICY_FFTCONV_COMPLEX = 64 /* overlap-save: only the complex-block kernels of rounds 1-3 (plans 1 / 2), never the
-                                      real-block delay line of round 4 (plan 3) */
+                                      real-block kernel of round 4 (plan 3).  NOTE: ANY of the three FFTCONV bits selects the
+                                      complex-block kernels for ALL tap counts -- also for <= 8192 taps, where plan 3 is plain
+                                      overlap-save on real blocks and no delay line is involved */
 };
 int         aamd_set_kernel_policy(int flags);
 
@@ -413,6 +415,19 @@ int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t row
                          int64_t n_y_rows, int64_t nx, int64_t ny, const int64_t* x_row_of,
                          const int64_t* y_row_of, int64_t start, int64_t out_len, void* workspace,
                          void* stream);
+/* The same call in two stages (ABI 6), for the case the reference's users have in practice -- many batches convolved with
+ * ONE room impulse response (`T.FFTConvolve` inside an augmentation loop, functional.py:2222-2258 recomputes rfft(y) every
+ * call): AAMD_FFTCONV_PREPARE writes the twiddle table and the tap spectra of the call's plan into `workspace` (two small
+ * launches, ~16 us on the BASELINE config-5 shard), AAMD_FFTCONV_RUN walks the rows using a workspace prepared before.
+ * Both bits = aamd_fftconvolve_f32.  A RUN-only call must see the workspace of a PREPARE call with the same taps, tap rows,
+ * kernel policy and plan (aamd_fftconvolve_plan; plan 3 and plan 1 keep the workspace read-only while they run, plan 2
+ * holds its delay-line ring there: one call at a time), stream-ordered after it.  PREPARE alone accepts x = out = NULL;
+ * with <= 192 taps (time-domain kernel) it does nothing. */
+enum { AAMD_FFTCONV_PREPARE = 1, AAMD_FFTCONV_RUN = 2 };
+int aamd_fftconvolve_staged_f32(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows,
+                                int64_t n_y_rows, int64_t nx, int64_t ny, const int64_t* x_row_of,
+                                const int64_t* y_row_of, int64_t start, int64_t out_len, void* workspace,
+                                int32_t stages, void* stream);
 
 /* ---- float64 ------------------------------------------------------------------------------ */
 

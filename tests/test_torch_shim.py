@@ -290,3 +290,86 @@ def test_round4_ops_reach_every_remaining_entry_point():
         G = ops.spectrogram_grad(Xc, dP, 2.0)
         want = 2.0 * dP.unsqueeze(-1) * Xc
         assert float((G - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+# ------------------------------------------------------------------ round 5: prepared tap spectra (aamd_fftconvolve_staged_f32)
+
+
+def test_staged_fftconvolve_schema():
+    from audio_amd import _shim
+    _shim.load()
+    assert str(torch._C._get_schema("aamd::fftconvolve_staged", "")) == (
+        "aamd::fftconvolve_staged(Tensor x, Tensor y, Tensor? x_row_of, Tensor? y_row_of, int rows, int start, int out_len, "
+        "Tensor(a!) workspace, int stages) -> Tensor")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["shim", "ctypes"])
+@pytest.mark.parametrize("taps", [700, 9000, 24000, 30000])
+def test_repeated_impulse_response_skips_the_preparation_and_stays_bit_identical(route, taps):
+    """The second call with the SAME tap tensor runs on the workspace the first call prepared (no twiddle / tap-spectrum
+    launches); its result is bit-identical to a call that prepares afresh (a clone of the taps), an in-place update of the
+    taps invalidates the held workspace, and plan 2 (complex-block delay line, 24577 .. 32768 taps: the ring lives in the
+    workspace) is never held."""
+    import audio_amd.functional as F
+    from audio_amd import _lib
+    g = torch.Generator().manual_seed(taps)
+    x1 = (torch.rand(6, 70000, generator=g) - 0.5).cuda()
+    x2 = (torch.rand(6, 70000, generator=g) - 0.5).cuda()
+    h = (torch.randn(1, taps, generator=g) * 0.02).cuda()
+    try:
+        F._force_route(route)
+        plan = _lib.lib().aamd_fftconvolve_plan(6, 70000, taps, 70000 + taps - 1)
+        y1 = F.fftconvolve(x1, h)
+        held = F.fftconvolve_held_taps(h)
+        assert held == (1 if plan in (1, 3) else 0)
+        y2 = F.fftconvolve(x2, h)                       # run-only on the held workspace
+        y2_fresh = F.fftconvolve(x2, h.clone())         # prepares again
+        assert torch.equal(y2, y2_fresh)
+        y1_again = F.fftconvolve(x1, h)
+        assert torch.equal(y1, y1_again)
+        # against the float64 direct evaluation at a few output samples
+        idx = torch.tensor([0, 1234, taps - 1, taps + 5000, 70000 + taps - 2])
+        xd, hd = x2.double().cpu(), h.double().cpu()[0]
+        for i in idx.tolist():
+            lo, hi = max(0, i - taps + 1), min(i, 69999)
+            want = (xd[:, lo:hi + 1] * hd[i - hi:i - lo + 1].flip(0)).sum(-1)
+            assert float((y2[:, i].double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max() + 1.0)
+        h.mul_(2.0)                                     # in-place update: the version counter moves, the workspace is stale
+        assert F.fftconvolve_held_taps(h) == 0
+        y3 = F.fftconvolve(x2, h)
+        assert torch.allclose(y3, 2.0 * y2, rtol=1e-5, atol=1e-6)
+    finally:
+        F._force_route(None)
+
+
+@pytest.mark.gpu
+def test_held_taps_are_per_stream_and_not_used_under_capture():
+    import audio_amd.functional as F
+    g = torch.Generator().manual_seed(77)
+    x = (torch.rand(4, 50000, generator=g) - 0.5).cuda()
+    h = (torch.randn(1, 12000, generator=g) * 0.02).cuda()
+    y0 = F.fftconvolve(x, h)
+    assert F.fftconvolve_held_taps(h) == 1
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        y1 = F.fftconvolve(x, h)                        # another stream: its own prepared workspace
+    s.synchronize()
+    assert F.fftconvolve_held_taps(h) == 2
+    assert torch.equal(y0, y1)
+    # a captured call prepares inside the graph (a replay must not depend on a host-side version check)
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cap):
+        F.fftconvolve(x, h)                             # warm-up on the capture stream
+        cap.synchronize()
+        held_before = F.fftconvolve_held_taps(h)
+        with torch.cuda.graph(graph, stream=cap):
+            yg = F.fftconvolve(x, h)
+    assert F.fftconvolve_held_taps(h) == held_before
+    h.mul_(0.5)                                         # the replay sees the new taps: the preparation is part of the graph
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(yg, 0.5 * y0, rtol=1e-5, atol=1e-6)
