@@ -43,7 +43,8 @@ constexpr int kLdsData = kM + (kM >> 5) * 2;                      // 8704 comple
 //   kTw1 + 1024 (k - 1) + t: W_8192^(t k), t < 1024;   kTw2 + 128 (k - 1) + j: W_1024^(j k), j < 128;
 //   kTw3 + 16 (k - 1) + j: W_128^(j k), j < 16;        kTw4 + 2 (k - 1) + j: W_16^(j k), j < 2
 constexpr int kTw1 = 0, kTw2 = kTw1 + 7 * 1024, kTw3 = kTw2 + 7 * 128, kTw4 = kTw3 + 7 * 16, kTwEnd = kTw4 + 7 * 2;
-constexpr int kLdsComplex = kLdsData + kTwEnd;                    // 16 894 complex = 135 152 B
+constexpr int kFlags = kLdsData + kTwEnd;                         // 16 arrival counters (one dword per wave) of pair_sync
+constexpr int kLdsComplex = kFlags + 8;                           // 16 902 complex = 135 216 B
 
 // tw16k: the W_16384^m table of fco::twiddle_kernel (m < 16384); W_M^e = tw16k[2 e]
 AAMD_HD void twiddle_tables(int tid, const C32* tw16k, C32* tl) {
@@ -460,6 +461,36 @@ constexpr float kSpectrumScale = 1.0f / (8.0f * (float)kM);      // un-halved sp
 #ifndef AAMD_FDR_LAB_NOBAR
 #define AAMD_FDR_LAB_NOBAR 0
 #endif
+// The length-1024 pass runs on the 1024 elements of TWO neighbouring waves (w, w ^ 1) and the passes on either side of it are
+// wave-local: the two workgroup barriers around it are replaced by a rendezvous of the pair (AAMD_FDR_PAIRSYNC, default on) --
+// a wave waits for its neighbour only, not for the slowest of sixteen (the lab build without those two barriers: - 6.5 %).
+// gfx950 has no named barriers: each wave publishes an arrival counter in LDS and polls its neighbour's.  LDS executes a
+// wave's instructions in order, and the s_waitcnt in front of the flag write has every data write of the pass performed
+// before the counter moves; the reads behind the poll are issued after the neighbour's counter has been seen.
+#ifndef AAMD_FDR_PAIRSYNC
+#define AAMD_FDR_PAIRSYNC 1
+#endif
+#ifndef AAMD_FDR_WAR_BARRIER
+#define AAMD_FDR_WAR_BARRIER 0
+#endif
+__device__ __forceinline__ void pair_sync(unsigned* flags, unsigned gen) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  volatile unsigned* vf = flags;
+  if ((threadIdx.x & 63) == 0) vf[wave] = gen;
+  for (;;) {
+    const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)vf[wave ^ 1]);
+    if ((int)(f - gen) >= 0) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+#define AAMD_FDR_PAIR(BIT)                                                                \
+  do {                                                                                    \
+    if (AAMD_FDR_LAB_NOBAR & (BIT)) fco::wave_sync();                                      \
+    else if (AAMD_FDR_PAIRSYNC) pair_sync(pair_flags, ++pair_gen);                         \
+    else __syncthreads();                                                                 \
+  } while (0)
 #define AAMD_FDR_BARRIER(BIT) do { if (AAMD_FDR_LAB_NOBAR & (BIT)) fco::wave_sync(); else __syncthreads(); } while (0)
 // neighbour exchange (lane ^ 1) of 8 complex registers: DPP quad_perm [1, 0, 3, 2]
 __device__ __forceinline__ void swap_neighbour(const C32 (&o)[8], C32 (&nb)[8]) {
@@ -493,24 +524,20 @@ __device__ __forceinline__ void forward_block(int tid, C32 (&v)[8], C32* lds, co
   pass_m2_fwd_b(tid, o, nb, lds);
   AAMD_FDR_BARRIER(2);
 }
-// ... and back: LDS spectrum (digit-reversed) -> the block's samples in v, in two halves (the kernel requests the next block's
-// samples between them: during the first half a thread holds the exchanged radix-2 operands on top of its delay line)
-template <int NR>
-__device__ __forceinline__ void inverse_block_a(int tid, C32* lds, const C32* tl, const C32 (&tw3)[7]) {
-  C32 x[8], nb[8];
-  pass_m2_inv_a(tid, lds, x);
-  swap_neighbour(x, nb);
-  pass_m2_inv_b(tid, x, nb, lds, tl);
-  fco::wave_sync();
-  if (NR > 0) pass_m16_regtw<true, NR>(tid, lds, tl, tw3); else pass_m16<true>(tid, lds, tl);
-  AAMD_FDR_BARRIER(1);
-}
+// ... and back: LDS spectrum (digit-reversed) -> the block's samples in v.  The first half (inverse radix-2 + length-16 and
+// length-128 passes, wave-local) is written out in the kernel; this is the second (the kernel requests the next block's samples
+// between the two: during the first half a thread holds the exchanged radix-2 operands on top of its delay line)
 __device__ __forceinline__ void inverse_block_b(int tid, C32* lds, const C32* tl, C32 (&v)[8]) {
   pass_m128<true>(tid, lds, tl);
   AAMD_FDR_BARRIER(4);
   last_pass_to_regs(tid, lds, tl, v);
 }
 
+__device__ __forceinline__ int64_t uniform64(int64_t v) {      // a wave-uniform 64-bit value through two scalar registers
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
 // H[(yrow * n_part + p) * 8192 + h_index] = scale * (twice the spectrum of the taps of partition p), thread-owned layout
 __global__ void __launch_bounds__(kThreads)
 spectrum_kernel(int64_t ny, int n_part, const float* __restrict__ y, const C32* __restrict__ tw16k, C32* __restrict__ H) {
@@ -546,6 +573,9 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
   C32* tl = lds + kLdsData;
   const int tid = threadIdx.x;
   twiddle_tables(tid, tw16k, tl);
+  unsigned* pair_flags = reinterpret_cast<unsigned*>(lds + kFlags);
+  unsigned pair_gen = 0;                  // wave-uniform: rendezvous executed so far (the arrival counters start at 0)
+  if (tid < 16) pair_flags[tid] = 0u;
   MidConst mc;
   mid_init(tid, tw16k, mc);
   __syncthreads();
@@ -574,9 +604,12 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
     const int64_t row = (int64_t)(item / (unsigned)g.segs);
     const int64_t j_lo = (int64_t)(item - (unsigned)row * (unsigned)g.segs) * g.seg_blocks;
     const int64_t j_hi = j_lo + g.seg_blocks < g.n_blocks ? j_lo + g.seg_blocks : g.n_blocks;
-    const int64_t rx = x_row_of ? x_row_of[row] : row;
+    // row numbers are uniform over the workgroup: taken through scalar registers, so that every row pointer below is a scalar
+    // base (global_load v, v_offset, s[base]) instead of eight 64-bit vector addresses per tap-spectrum partition
+    const int64_t rx = uniform64(x_row_of ? x_row_of[row] : row);
+    const int64_t ry = uniform64(y_row_of ? y_row_of[row] : row);
     const float* xr = x + rx * g.nx;
-    const C32* Hr = H + (y_row_of ? y_row_of[row] : row) * NP * kHPerPart;
+    const C32* Hr = H + ry * NP * kHPerPart;
     float* out_row = out + row * g.out_len;
     // 8-byte paths: the row's first sample / first output on an even float offset (block starts are multiples of 8192)
     const bool vin = (reinterpret_cast<uintptr_t>(xr) & 7) == 0;        // (load_block adds the parity of the block's own offset)
@@ -589,37 +622,50 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
 #pragma unroll 1
     for (int64_t j = j_lo - (NP - 1); j < j_hi; ++j) {
       const bool produce = j >= j_lo;
-      // the delayed partitions do not wait for this block's spectrum: H_1 Z_(j-1) + H_2 Z_(j-2) is formed BEFORE the forward
-      // transform (its 16 tap-spectrum loads fly during the first pass) and only H_0 Z_j is left for the middle step
       C32 acc[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = C32{0.0f, 0.0f};
-      if (produce) {
-        auto part_early = [&](const C32* Hp, const C32 (&z)[8]) {
-          const unsigned lane = (unsigned)fco::opaque(tid);
-          C32 h[8];
+      C32 h0[8];                           // tap spectra of this thread's bins, one partition at a time
+      auto h_load = [&](int p) {           // partition p: 8 coalesced 8-byte loads from L2 (the thread-owned layout)
+        // ONE scalar base (the row's table) + a 32-bit vector byte offset per load: global_load_dwordx2 v, v_off, s[base].
+        // Left to itself the compiler forms eight 64-bit vector addresses per partition (16 registers and 16 carry chains)
+        // or, with per-load scalar bases, hoists 24 base pairs out of the step loop and spills scalar registers.
+        const unsigned off = (unsigned)fco::opaque(tid) * (unsigned)sizeof(C32);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) h[i] = (Hp + 1024 * i)[lane];
+        for (int i = 0; i < 8; ++i) {
+          unsigned o = off + (unsigned)((p * 8 + i) * kThreads * (int)sizeof(C32));
+          asm volatile("" : "+v"(o));
+          h0[i] = *reinterpret_cast<const C32*>(reinterpret_cast<const char*>(Hr) + o);
+        }
 #ifdef AAMD_FDR_LAB_NOH
 #pragma unroll
-          for (int i = 0; i < 8; ++i) h[i] = C32{1.0f + (float)i, 0.5f};
+        for (int i = 0; i < 8; ++i) h0[i] = C32{1.0f + (float)i, 0.5f};
 #endif
-          mid_mac(tid, h, z, acc);
-        };
-        if (NP > 1) part_early(Hr + kHPerPart, z1);
-        if (NP > 2) part_early(Hr + 2 * kHPerPart, z2);
-      }
-      forward_block<kTw3>(tid, v, lds, tl, tw3);
-      C32 h0[8];                           // H_0 of this thread's bins: requested before the split reads LDS (an L2 round trip)
+      };
+      // the delayed partitions do not wait for this block's spectrum: H_1 Z_(j-1) + H_2 Z_(j-2) is formed BEFORE the forward
+      // transform and only H_0 Z_j is left for the middle step
       if (produce) {
-        const unsigned lane = (unsigned)fco::opaque(tid);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) h0[i] = (Hr + 1024 * i)[lane];
-#ifdef AAMD_FDR_LAB_NOH
-#pragma unroll
-        for (int i = 0; i < 8; ++i) h0[i] = C32{1.0f + (float)i, 0.25f};
-#endif
+        if (NP > 1) { h_load(1); mid_mac(tid, h0, z1, acc); }
+        if (NP > 2) { h_load(2); mid_mac(tid, h0, z2, acc); }
       }
+      // (Round 5 tried to hide the tap-spectrum loads behind the passes -- H_1 in flight during the first pass, H_2 during the
+      // length-1024 pass, H_0 during the wave-local ones, unconditional so that the compiler's vmcnt stays exact: 0.710-0.724 ms
+      // against 0.700 for this order on the cfg5b shard, although the kernel WITHOUT any tap-spectrum read runs 0.61: the
+      // 192 KB per step are a throughput cost of the vector-memory path, not an exposed latency.  profiles/r05_c_fdr_lab_barriers_hloads.txt)
+      first_pass_from_regs(tid, v, lds, tl);
+      AAMD_FDR_BARRIER(4);
+      pass_m128<false>(tid, lds, tl);
+      AAMD_FDR_PAIR(1);
+      if (kTw3 > 0) pass_m16_regtw<false, kTw3>(tid, lds, tl, tw3); else pass_m16<false>(tid, lds, tl);
+      fco::wave_sync();
+      {
+        C32 o[8], nb[8];
+        pass_m2_fwd_a(tid, lds, tl, o);
+        swap_neighbour(o, nb);
+        pass_m2_fwd_b(tid, o, nb, lds);
+      }
+      AAMD_FDR_BARRIER(2);
+      if (produce) h_load(0);              // H_0: requested before the split reads LDS (an L2 round trip)
       C32 z0[8];
       mid_split(tid, lds, mc, z0);
       if (produce) {
@@ -632,13 +678,27 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
       // the next block's samples: in flight during the inverse passes and the stores (requested only now: during the middle
       // step the thread holds three spectra, the accumulators and a partition of tap spectra -- with these 16 registers on top
       // the 128-register budget of four waves per SIMD spilled)
-      if (produce) inverse_block_a<kTw3>(tid, lds, tl, tw3);
+      if (produce) {                       // inverse_block_a with the pair rendezvous in place of its closing barrier
+        C32 xq[8], nb[8];
+        pass_m2_inv_a(tid, lds, xq);
+        swap_neighbour(xq, nb);
+        pass_m2_inv_b(tid, xq, nb, lds, tl);
+        fco::wave_sync();
+        if (kTw3 > 0) pass_m16_regtw<true, kTw3>(tid, lds, tl, tw3); else pass_m16<true>(tid, lds, tl);
+        AAMD_FDR_PAIR(1);
+      }
       if (j + 1 < j_hi) load_block(tid, g, xr, j + 1, vin, v);
       if (produce) {
         C32 w[8];
         inverse_block_b(tid, lds, tl, w);
         store_block(tid, g, w, j, j_hi, vout, out_row);
-        AAMD_FDR_BARRIER(4);               // the next first pass overwrites what the last pass has just read
+        // No barrier here (round 5; rounds 3-4 had one: "the next first pass overwrites what the last pass has just read"):
+        // the last pass READS the cells pad(tid) + 1088 r and the next first pass WRITES exactly those cells from the same
+        // thread -- program order of one thread is all the hazard needs, and every other access to them lies behind the
+        // barrier that follows the first pass.  AAMD_FDR_WAR_BARRIER=1 restores it for A/B runs.
+#if AAMD_FDR_WAR_BARRIER
+        AAMD_FDR_BARRIER(4);
+#endif
       }
     }
   }

@@ -357,6 +357,10 @@ Tensor mel_spectrogram_lognorm(Tensor wav, Tensor window, Tensor twiddle, Tensor
   STD_TORCH_CHECK(pcm || wav.scalar_type() == ScalarType::Float, "audio_amd: waveform must be float32 or int16 PCM");
   STD_TORCH_CHECK(wav.dim() == 2 || (pcm && wav.dim() == 3), "audio_amd: waveform must be (rows, time) or int16 (clips, time, channels)");
   const int64_t channels = wav.dim() == 3 ? wav.size(2) : 0;
+  // interleaved stereo: the kernel reads one 32-bit (L, R) word per sample time (a view that starts on an odd
+  // int16 offset is contiguous and still misaligned -- refuse it here instead of faulting in the kernel)
+  STD_TORCH_CHECK(channels != 2 || wav.numel() == 0 || reinterpret_cast<uintptr_t>(wav.data_ptr()) % 4 == 0,
+                  "audio_amd: interleaved stereo PCM must start on a 4-byte boundary (clone() the view)");
   STD_TORCH_CHECK(mean.has_value() == invstddev.has_value(), "audio_amd: mean and invstddev come together");
   STD_TORCH_CHECK(pcm || mean.has_value(), "audio_amd: float input without statistics is aamd::mel_spectrogram");
   stft_consts(wav, window, twiddle, n_fft, ScalarType::Float);

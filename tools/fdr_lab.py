@@ -112,6 +112,17 @@ def run(names, launches, rounds, taps, rows=256, nx=480000):
             e1.record()
             torch.cuda.synchronize()
             res[n].append(e0.elapsed_time(e1) / launches)
+    # a race shows up as run-to-run differences: every variant again on the first input, 6 times, against its own first answer
+    for n in names:
+        first = launch(n, 0).clone()
+        same = True
+        for _ in range(6):
+            for i in (1, 2, 0):
+                o = launch(n, i)
+            same = same and bool(torch.equal(o, first))
+        torch.cuda.synchronize()
+        print(json.dumps({"repeat_check": n, "bit_stable": same,
+                          "vs_first_variant_peak_rel": float((first - base).abs().max()) / peak}))
     alg = 4.0 * rows * (nx + n_out)
     for n in names:
         v = res[n]
