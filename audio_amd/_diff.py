@@ -150,6 +150,44 @@ def onesided_part(spec: Tensor, n_fft: int) -> Tensor:
     return spec[..., : n_fft // 2 + 1, :]
 
 
+def stft_complex_learnable_window(x2: Tensor, w_padded: Tensor, cfg: Cfg) -> Tensor:
+    """(rows, L) -> complex (rows, T, F) with gradients into the WINDOW as well (round 5; the reference propagates into a
+    learnable window through aten::stft, transforms/_transforms.py:101-123).  The STFT is bilinear in (signal, window): the
+    frames are cut by tensor arithmetic the way the kernel cuts them (explicit zero padding, then the centre padding of
+    `pad_mode`), multiplied by the window -- both differentiable by autograd -- and transformed by the SAME onesided kernel,
+    called on the windowed frames as rows with a unit window, hop = n_fft and no padding (`Stft`, whose backward is its adjoint
+    kernel).  Differentiable to any order in x and in the window; a training path, not the throughput path (it materialises
+    the (rows, T, n_fft) frame tensor)."""
+    n_fft, hop, pad, center, pad_mode = cfg
+    rows = x2.shape[0]
+    xp = x2
+    if pad > 0:
+        xp = torch.nn.functional.pad(xp, (pad, pad))
+    if center:
+        mode = {"constant": "constant", "reflect": "reflect", "replicate": "replicate", "circular": "circular"}[pad_mode]
+        xp = torch.nn.functional.pad(xp.unsqueeze(0), (n_fft // 2, n_fft // 2), mode=mode).squeeze(0)
+    fr = xp.unfold(-1, n_fft, hop)                                      # (rows, T, n_fft) view
+    T = fr.shape[1]
+    fr = (fr * w_padded).reshape(rows * T, n_fft)
+    ones = torch.ones(n_fft, dtype=x2.dtype, device=x2.device)
+    X = Stft.apply(fr, ones, (n_fft, n_fft, 0, False, "constant"))     # (rows * T, 1, F, 2)
+    return torch.view_as_complex(X.reshape(rows, T, n_fft // 2 + 1, 2))
+
+
+def resample_learnable_kernel(x2: Tensor, kern: Tensor, orig: int, new: int, width: int) -> Tensor:
+    """(rows, L) x (new, 2 width + orig) tap table -> (rows, ceil(new L / orig)) with gradients into the TAP TABLE (and the
+    signal): the reference's own formulation -- a strided correlation, functional/functional.py:1419-1431 -- as an unfold and
+    a matrix product, which autograd differentiates in both operands to any order.  A training path for a learnable resampling
+    filter; the throughput path is the banded MFMA kernel (csrc/resample_mfma.h)."""
+    rows, length = x2.shape
+    xp = torch.nn.functional.pad(x2, (width, width + orig))
+    fr = xp.unfold(-1, 2 * width + orig, orig)                          # (rows, Q, taps)
+    y = torch.matmul(fr, kern.t())                                      # (rows, Q, new)
+    y = y.reshape(rows, -1)
+    target = -(-new * length // orig)
+    return y[:, :target]
+
+
 def spectrogram(waveform: Tensor, pad: int, window: Tensor, n_fft: int, hop_length: int, win_length: int, power,
                 normalized, center: bool, pad_mode: str, onesided: bool = True) -> Tensor:
     """The reference composition (functional/functional.py:112-145) with torch.stft replaced by `Stft`:
@@ -160,10 +198,14 @@ def spectrogram(waveform: Tensor, pad: int, window: Tensor, n_fft: int, hop_leng
     shape = waveform.size()
     x2 = waveform.reshape(-1, shape[-1])
     w = window.to(device=waveform.device, dtype=waveform.dtype)
-    wp = _host.center_pad_window(w.detach(), n_fft).contiguous()
     if pad_mode not in _lib.PAD_MODES:
         raise NotImplementedError(f"audio_amd: pad_mode {pad_mode!r} is not supported")
-    spec_f = stft_complex(x2, wp, (n_fft, hop_length, pad, bool(center), pad_mode))       # (rows, T, F)
+    if torch.is_grad_enabled() and w.requires_grad:
+        # a learnable window: the bilinear form (gradients into the window and the signal)
+        spec_f = stft_complex_learnable_window(x2, _host.center_pad_window(w, n_fft), (n_fft, hop_length, pad, bool(center), pad_mode))
+    else:
+        wp = _host.center_pad_window(w.detach(), n_fft).contiguous()
+        spec_f = stft_complex(x2, wp, (n_fft, hop_length, pad, bool(center), pad_mode))       # (rows, T, F)
     if frame_length_norm:
         spec_f = spec_f * (float(n_fft) ** -0.5)
     if window_norm:

@@ -86,6 +86,7 @@ _SIGS = {
                                                 _P, _P, C.c_int64, _P]),
     "aamd_melspectrogram_pcm16_interleaved_f32": (C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(MelBands), _P,
                                                             C.POINTER(StftDesc), C.c_float, _P, _P, C.c_int64, _P]),
+    "aamd_melspectrogram_lowp_f32": (C.c_int, [_P, C.c_int32, _P, _P, C.POINTER(MelBands), _P, C.POINTER(StftDesc), _P]),
     "aamd_spectrogram_grad_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, _P]),
     "aamd_melspectrogram_grad_f32": (C.c_int, [_P, _P, C.POINTER(MelBands), C.c_int64, C.c_int32, C.c_int32, C.c_float, _P]),
     "aamd_kaldi_features_f32": (C.c_int, [_P, _P, _P, C.POINTER(MelBands), _P, C.POINTER(KaldiDesc), _P]),
@@ -170,6 +171,9 @@ class kernel_policy:
     def __exit__(self, *exc):
         lib().aamd_set_kernel_policy(self.prev)
         return False
+
+
+EUNSUPPORTED = -2          # AAMD_EUNSUPPORTED: valid request this build cannot serve
 
 
 def check(rc: int) -> None:

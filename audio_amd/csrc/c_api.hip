@@ -614,6 +614,37 @@ int aamd_melspectrogram_pcm16_f32(const int16_t* wav, const float* window, const
                       : launch_fft400_h<m400::EPI400_MEL, 10, int16_t>(g, mb, wav, window, twiddle, out, m400::Epi400{}, s);
 }
 
+// Reduced-precision waveforms (the reference takes any floating dtype, functional/functional.py:1413-1414 and every
+// transform's forward; a half / bfloat16 pipeline hands such tensors over): read as they are, converted to float in the gather
+// of the radix-20x20 kernel -- half the input bytes, no separate cast pass.  Arithmetic and output stay float32 (the host
+// casts the result to the input dtype, which is what the reference returns).  n_fft = 400, hop 160 / 200 only; every other
+// shape takes the host's cast + the float kernels.
+int aamd_melspectrogram_lowp_f32(const void* wav, int32_t wav_dtype, const float* window, const float* twiddle,
+                                 const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, void* stream) {
+  DeviceScope dev_scope_(wav);
+  StftGeom g;
+  int rc = validate_desc(desc, g);
+  if (rc != AAMD_OK) return rc;
+  AAMD_CHECK_ARG(wav && window && twiddle && out, "null buffer");
+  AAMD_CHECK_ARG(wav_dtype == AAMD_DTYPE_F16 || wav_dtype == AAMD_DTYPE_BF16, "wav_dtype: AAMD_DTYPE_F16 or AAMD_DTYPE_BF16");
+  AAMD_CHECK_ARG(desc->power > 0.0f && desc->onesided, "mel spectrogram needs power > 0 and a onesided spectrum");
+  MelBandsDev mb;
+  rc = validate_bands(bands, g.n_freq, mb);
+  if (rc != AAMD_OK) return rc;
+  if (!mel400_eligible(g, mb) || (g.hop != 160 && g.hop != 200))
+    return fail(AAMD_EUNSUPPORTED, "audio_amd: half / bfloat16 input is read directly by the n_fft = 400, hop 160 / 200 kernel only");
+  hipStream_t s = (hipStream_t)stream;
+  const m400::Epi400 epi{};
+  if (wav_dtype == AAMD_DTYPE_F16) {
+    const _Float16* w = static_cast<const _Float16*>(wav);
+    return g.hop == 160 ? launch_fft400_h<m400::EPI400_MEL, 8, _Float16>(g, mb, w, window, twiddle, out, epi, s)
+                        : launch_fft400_h<m400::EPI400_MEL, 10, _Float16>(g, mb, w, window, twiddle, out, epi, s);
+  }
+  const __bf16* w = static_cast<const __bf16*>(wav);
+  return g.hop == 160 ? launch_fft400_h<m400::EPI400_MEL, 8, __bf16>(g, mb, w, window, twiddle, out, epi, s)
+                      : launch_fft400_h<m400::EPI400_MEL, 10, __bf16>(g, mb, w, window, twiddle, out, epi, s);
+}
+
 int aamd_melspectrogram_pcm16_interleaved_f32(const int16_t* pcm, int32_t channels, const float* window, const float* twiddle,
                                               const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc,
                                               float gain, const float* mean, const float* invstddev, int64_t out_frames,
@@ -1406,8 +1437,9 @@ static bool fftconv_pick_fdl(int64_t rows, int64_t taps, int64_t out_len, fco::F
   return cheaper || ((policy() & AAMD_POLICY_FFTCONV_FDL) && f.n_blocks >= 2);
 }
 
-// the real-block kernel (fftconv_fdr.h, plan 3): EVERY FFT-eligible tap count up to 24576 -- plain overlap-save on real blocks up
-// to 8192 taps (one partition, no delay line), the register delay line for 8193 .. 24576 -- unless ANY of the three FFTCONV
+// the real-block kernel (fftconv_fdr.h, plan 3): EVERY FFT-eligible tap count up to 32768 (round 5; 24576 in round 4) -- plain
+// overlap-save on real blocks up to 8192 taps (one partition, no delay line), the register delay line of up to three delayed
+// spectra for 8193 .. 32768 -- unless ANY of the three FFTCONV
 // policy bits is set: NO_FDL / FDL / COMPLEX all select the complex-block kernels (plans 1 / 2) for all tap counts, also for
 // <= 8192 taps where plan 3 is not a delay line at all (the bits exist for A/B runs against the round-1..3 kernels)
 static bool fftconv_pick_fdr(int64_t rows, int64_t taps, int64_t out_len, fdr::Geom& g) {
@@ -1508,7 +1540,7 @@ int aamd_fftconvolve_staged_f32(const float* x, const float* y, float* out, int6
         hipLaunchKernelGGL(fdr::delay_line_kernel<NP>, dim3((unsigned)blocks), dim3(fdr::kThreads), lds_r, s, \
                            fg, xa, tw, H, xmap, ymap, out);                                                   \
       } while (0)
-      if (fg.n_part == 1) AAMD_FDR(1); else if (fg.n_part == 2) AAMD_FDR(2); else AAMD_FDR(3);
+      if (fg.n_part == 1) AAMD_FDR(1); else if (fg.n_part == 2) AAMD_FDR(2); else if (fg.n_part == 3) AAMD_FDR(3); else AAMD_FDR(4);
 #undef AAMD_FDR
       return launch_check();
     }

@@ -1,4 +1,4 @@
-// F.fftconvolve for 193 .. 24576 taps (4 ms .. 0.5 s impulse responses at 48 kHz; BASELINE config 5b): overlap-save and, beyond
+// F.fftconvolve for 193 .. 32768 taps (4 ms .. 0.68 s impulse responses at 48 kHz; BASELINE config 5b): overlap-save and, beyond
 // 8192 taps, the frequency-domain delay line on REAL blocks, the whole state of a row on one CU (functional/functional.py:2252-2258 computes
 // irfft(rfft(x) * rfft(y)); the contract is the linear convolution, so block-wise FFTs of another length are free).
 //
@@ -34,7 +34,7 @@ constexpr int kM = 8192;                   // complex FFT length
 constexpr int kN = 16384;                  // real samples per block
 constexpr int kHop = 8192;                 // taps per partition; outputs per block of the 2 / 3-partition delay line
 constexpr int kThreads = 1024;
-constexpr int kMaxParts = 3;               // Z_j in flight + two delayed spectra in registers
+constexpr int kMaxParts = 4;               // Z_j in flight + up to three delayed spectra in registers (round 5: 24 577 .. 32 768 taps too)
 AAMD_HD int pad(int i) { return i + ((i >> 5) << 1); }            // 2 complex per 32: see the bank notes at each pass
 constexpr int kLdsData = kM + (kM >> 5) * 2;                      // 8704 complex = 69 632 B
 // complete twiddle tables behind the data (W_M = e^(-2 pi i / 8192)), [k - 1][j] so that the lanes of a wave read consecutive
@@ -509,7 +509,10 @@ __device__ __forceinline__ void swap_neighbour(const C32 (&o)[8], C32 (&nb)[8]) 
 #ifndef AAMD_FDR_TW3_N3
 #define AAMD_FDR_TW3_N3 5
 #endif
-template <int NP> struct Tw3Regs { static constexpr int n = NP >= 3 ? AAMD_FDR_TW3_N3 : AAMD_FDR_TW3_N12; };
+#ifndef AAMD_FDR_TW3_N4
+#define AAMD_FDR_TW3_N4 0
+#endif
+template <int NP> struct Tw3Regs { static constexpr int n = NP >= 4 ? AAMD_FDR_TW3_N4 : NP == 3 ? AAMD_FDR_TW3_N3 : AAMD_FDR_TW3_N12; };
 template <int NR>
 __device__ __forceinline__ void forward_block(int tid, C32 (&v)[8], C32* lds, const C32* tl, const C32 (&tw3)[7]) {
   first_pass_from_regs(tid, v, lds, tl);
@@ -602,8 +605,9 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
 #pragma unroll 1
   for (unsigned item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int64_t row = (int64_t)(item / (unsigned)g.segs);
-    const int64_t j_lo = (int64_t)(item - (unsigned)row * (unsigned)g.segs) * g.seg_blocks;
-    const int64_t j_hi = j_lo + g.seg_blocks < g.n_blocks ? j_lo + g.seg_blocks : g.n_blocks;
+    // block numbers fit 32 bits (n_blocks <= out_len / hop; the launcher checks rows * segs < 2^31): scalar compares in the loop
+    const int j_lo = (int)((int64_t)(item - (unsigned)row * (unsigned)g.segs) * g.seg_blocks);
+    const int j_hi = (int)(j_lo + g.seg_blocks < g.n_blocks ? j_lo + g.seg_blocks : g.n_blocks);
     // row numbers are uniform over the workgroup: taken through scalar registers, so that every row pointer below is a scalar
     // base (global_load v, v_offset, s[base]) instead of eight 64-bit vector addresses per tap-spectrum partition
     const int64_t rx = uniform64(x_row_of ? x_row_of[row] : row);
@@ -614,13 +618,13 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
     // 8-byte paths: the row's first sample / first output on an even float offset (block starts are multiples of 8192)
     const bool vin = (reinterpret_cast<uintptr_t>(xr) & 7) == 0;        // (load_block adds the parity of the block's own offset)
     const bool vout = (reinterpret_cast<uintptr_t>(out_row) & 7) == 0;
-    C32 z1[8], z2[8];                      // Z_(j-1), Z_(j-2): this thread's 8 bins
+    C32 z1[8], z2[8], z3[8];               // Z_(j-1), Z_(j-2), Z_(j-3): this thread's 8 bins (as many as NP - 1 are live)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) z1[i] = z2[i] = C32{0.0f, 0.0f};
+    for (int i = 0; i < 8; ++i) z1[i] = z2[i] = z3[i] = C32{0.0f, 0.0f};
     C32 v[8];
     load_block(tid, g, xr, j_lo - (NP - 1), vin, v);
 #pragma unroll 1
-    for (int64_t j = j_lo - (NP - 1); j < j_hi; ++j) {
+    for (int j = j_lo - (NP - 1); j < j_hi; ++j) {
       const bool produce = j >= j_lo;
       C32 acc[8];
 #pragma unroll
@@ -647,6 +651,7 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
       if (produce) {
         if (NP > 1) { h_load(1); mid_mac(tid, h0, z1, acc); }
         if (NP > 2) { h_load(2); mid_mac(tid, h0, z2, acc); }
+        if (NP > 3) { h_load(3); mid_mac(tid, h0, z3, acc); }
       }
       // (Round 5 tried to hide the tap-spectrum loads behind the passes -- H_1 in flight during the first pass, H_2 during the
       // length-1024 pass, H_0 during the wave-local ones, unconditional so that the compiler's vmcnt stays exact: 0.710-0.724 ms
@@ -673,7 +678,10 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
         mid_merge(tid, acc, mc, lds);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { z2[i] = z1[i]; z1[i] = z0[i]; }
+      for (int i = 0; i < 8; ++i) {
+        if (NP > 3) z3[i] = z2[i];
+        z2[i] = z1[i]; z1[i] = z0[i];
+      }
       AAMD_FDR_BARRIER(2);
       // the next block's samples: in flight during the inverse passes and the stores (requested only now: during the middle
       // step the thread holds three spectra, the accumulators and a partition of tap spectra -- with these 16 registers on top

@@ -69,18 +69,22 @@ def scatter_batch(batch: Optional[Tensor], shape: Tuple[int, ...], device, root:
     if world == 1:
         return batch.to(device)
     local = torch.empty((hi - lo,) + tuple(shape[1:]), dtype=dtype, device=device)
+    # ONE batch of point-to-point operations per rank (dist.batch_isend_irecv = one ncclGroupStart / End on RCCL): the root's
+    # sends to its world - 1 peers leave over their own xGMI links concurrently instead of one isend after the other on the
+    # root's stream; row slices of a contiguous batch are contiguous, so nothing is copied first
+    ops = []
     if rank == root:
-        reqs = []
         for r in range(world):
             a, b = shard_range(shape[0], world, r)
             if r == root:
                 local.copy_(batch[a:b])
             elif b > a:
-                reqs.append(dist.isend(batch[a:b].contiguous(), dst=r, group=group))
-        for q in reqs:
-            q.wait()
+                ops.append(dist.P2POp(dist.isend, batch[a:b].contiguous(), r, group))
     elif hi > lo:
-        dist.recv(local, src=root, group=group)
+        ops.append(dist.P2POp(dist.irecv, local, root, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     return local
 
 
@@ -92,19 +96,21 @@ def gather_batch(local: Tensor, n_rows: int, root: int = 0, group=None) -> Optio
     local = local.contiguous()
     if rank == root:
         out = torch.empty((n_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        reqs = []
+        ops = []
         for r in range(world):
             a, b = shard_range(n_rows, world, r)
             if r == root:
                 out[a:b].copy_(local)
             elif b > a:
-                reqs.append(dist.irecv(out[a:b], src=r, group=group))
-        for q in reqs:
-            q.wait()
+                ops.append(dist.P2POp(dist.irecv, out[a:b], r, group))
+        if ops:                                   # one batch: the world - 1 receives are posted together (see scatter_batch)
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
         return out
     lo, hi = shard_range(n_rows, world, rank)
     if hi > lo:
-        dist.send(local, dst=root, group=group)
+        for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, root, group)]):
+            q.wait()
     return None
 
 

@@ -53,18 +53,52 @@ def _require_device(t: Tensor, what: str, allow_grad: bool = False, allow_f64: b
                            "wrap the call in torch.no_grad().")
 
 
-def _reject_param_grad(**params) -> None:
-    """The window / mel filterbank / DCT matrix are constants of this implementation's autograd (as in the reference's
-    own gradient tests).  The reference would propagate into them through stft / matmul; silently returning no
-    gradient would be wrong, so a learnable one is refused loudly."""
-    if not torch.is_grad_enabled():
-        return
-    for name, t in params.items():
-        if t is not None and t.requires_grad:
-            raise RuntimeError(
-                f"audio_amd: `{name}` requires grad, but gradients with respect to {name} are not implemented on the "
-                "HIP path (only the waveform is differentiated). Detach it (e.g. register it as a buffer), or use the "
-                "ATen composition for a learnable " + name + ".")
+LOW_PRECISION = (torch.float16, torch.bfloat16)
+
+
+def _cast_result(out, dtype):
+    if isinstance(out, Tensor):
+        if out.is_complex():                       # half -> ComplexHalf as aten::stft does; bfloat16 has no complex type
+            return out.to(torch.complex32) if dtype == torch.float16 else out
+        return out.to(dtype) if out.is_floating_point() else out
+    if isinstance(out, (tuple, list)):
+        return type(out)(_cast_result(o, dtype) for o in out)
+    return out
+
+
+def _reduced_precision_io(fn):
+    """float16 / bfloat16 in, the same dtype out (round 5; the reference accepts every floating dtype and returns it --
+    functional/functional.py:1413-1414, filtering.py:1032-1099 -- where its backend implements the dtype: resample, lfilter,
+    amplitude_to_DB and the matmul of MelScale do on CPU, aten::stft and fft do not).  The kernels compute in float32 -- strictly
+    more accurate than the reference's half arithmetic -- so a reduced-precision tensor argument is widened on entry and the
+    result narrowed on exit (two element-wise passes; the n_fft = 400 MelSpectrogram reads half directly instead,
+    `_melspectrogram_lowp`).  The casts are ordinary autograd nodes.  The FIRST tensor argument decides."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        first = next((a for a in args if isinstance(a, Tensor)), None)
+        if first is None:
+            first = next((v for v in kwargs.values() if isinstance(v, Tensor)), None)
+        if first is None or first.dtype not in LOW_PRECISION:
+            return fn(*args, **kwargs)
+        dt = first.dtype
+
+        def widen(a):
+            if isinstance(a, Tensor) and (a.dtype in LOW_PRECISION):
+                return a.float()
+            if isinstance(a, Tensor) and a.dtype == torch.complex32:
+                return a.to(torch.complex64)
+            return a
+        out = fn(*[widen(a) for a in args], **{k: widen(v) for k, v in kwargs.items()})
+        return _cast_result(out, dt)
+    return wrapper
+
+
+def _learnable(*tensors) -> bool:
+    """True when autograd is on and one of the module constants asks for a gradient: the call takes the differentiable
+    composition (reference behaviour: _transforms.py:413, 708 -- gradients flow into `fb` / `dct_mat` / `window`)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 def _rows2d(t: Tensor) -> Tensor:
@@ -213,7 +247,10 @@ class MelBandsOnDevice:
 
 
 def _mel_bands(fb: Tensor, device) -> MelBandsOnDevice:
-    return _tensor_cached(fb, ("bands", str(device)), lambda: MelBandsOnDevice(fb, device))
+    # (a module cast with .half() / .bfloat16() carries a reduced-precision filterbank: the band table is built from its values
+    # widened to float32, once per buffer)
+    return _tensor_cached(fb, ("bands", str(device)),
+                          lambda: MelBandsOnDevice(fb if fb.dtype == torch.float32 else fb.detach().float(), device))
 
 
 def _get_spec_norms(normalized: Union[str, bool]):
@@ -269,6 +306,7 @@ def _stft_desc(x2: Tensor, pad: int, window: Tensor, n_fft: int, hop_length: int
 # --------------------------------------------------------------------------- #
 
 
+@_reduced_precision_io
 def spectrogram(
     waveform: Tensor,
     pad: int,
@@ -293,7 +331,6 @@ def spectrogram(
             "`torchaudio.functional.spectrogram(power=None)` always returns a tensor with "
             "complex dtype. Please remove the argument in the function call."
         )
-    _reject_param_grad(window=window)
     _require_device(waveform, "waveform", allow_grad=True, allow_f64=True)
     if window.shape[0] != win_length:
         raise RuntimeError(
@@ -301,8 +338,11 @@ def spectrogram(
             f"but got window with size {list(window.shape)}")
     if not 0 < win_length <= n_fft:
         raise RuntimeError(f"stft: expected 0 < win_length <= n_fft, but got win_length={win_length}")
-    if waveform.dtype == torch.float64 or (not onesided and torch.is_grad_enabled() and waveform.requires_grad):
-        # precision / two-sided training path: the differentiable blocks (onesided kernel + Hermitian extension)
+    learn_window = torch.is_grad_enabled() and window.requires_grad
+    if waveform.dtype == torch.float64 or learn_window or (not onesided and torch.is_grad_enabled() and waveform.requires_grad):
+        # precision / two-sided training / learnable-window path: the differentiable blocks (onesided kernel + Hermitian
+        # extension; a window that requires grad takes the bilinear form of _diff.stft_complex_learnable_window -- the reference
+        # propagates into it through aten::stft)
         _stft_desc(_rows2d(waveform), pad, window.to(waveform.device), n_fft, hop_length, power, normalized, center, pad_mode,
                    True)                       # the reference's argument checks and error messages
         return _diff.spectrogram(waveform, pad, window, n_fft, hop_length, win_length, power, normalized, center, pad_mode,
@@ -460,6 +500,7 @@ class _SpectrogramFunction(torch.autograd.Function):
         return dx, None, None, None
 
 
+@_reduced_precision_io
 def inverse_spectrogram(
     spectrogram: Tensor,
     length: Optional[int],
@@ -584,6 +625,7 @@ def _phase_vocoder_launch(spec: Tensor, rate: float, phase_advance: Tensor, fram
     return out.transpose(-1, -2) if frame_major_out else out
 
 
+@_reduced_precision_io
 def phase_vocoder(complex_specgrams: Tensor, rate: float, phase_advance: Tensor) -> Tensor:
     r"""Stretch a complex spectrogram in time by ``rate`` without changing pitch
     (reference: functional/functional.py:732-803) -- one HIP kernel, a thread per (row, frequency) chain."""
@@ -606,6 +648,7 @@ def phase_vocoder(complex_specgrams: Tensor, rate: float, phase_advance: Tensor)
     return out.reshape(tuple(shape[:-2]) + out.shape[1:])
 
 
+@_reduced_precision_io
 def griffinlim(
     specgram: Tensor,
     window: Tensor,
@@ -734,6 +777,7 @@ def _fix_waveform_shape(waveform_shift: Tensor, shape) -> Tensor:
     return waveform_shift.reshape(tuple(shape[:-1]) + waveform_shift.shape[-1:])
 
 
+@_reduced_precision_io
 def pitch_shift(waveform: Tensor, sample_rate: int, n_steps: int, bins_per_octave: int = 12, n_fft: int = 512,
                 win_length: Optional[int] = None, hop_length: Optional[int] = None,
                 window: Optional[Tensor] = None) -> Tensor:
@@ -746,6 +790,7 @@ def pitch_shift(waveform: Tensor, sample_rate: int, n_steps: int, bins_per_octav
     return _fix_waveform_shape(waveform_shift, waveform.size())
 
 
+@_reduced_precision_io
 def speed(waveform: Tensor, orig_freq: int, factor: float, lengths: Optional[Tensor] = None):
     r"""Adjust waveform speed (reference: functional/functional.py:2385-2423): resample by 1 / factor."""
     source_sample_rate = int(factor * orig_freq)
@@ -803,6 +848,34 @@ def _melspectrogram(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_ff
             _lib.check(L.aamd_melspectrogram_db_f32(
                 *args, multiplier, amin, db_multiplier, None if group_max is None else group_max.data_ptr(),
                 rows_per_group, _lib.current_stream(waveform.device)))
+    return out
+
+
+def _melspectrogram_lowp(waveform: Tensor, pad: int, window: Tensor, fb: Tensor, n_fft: int, hop_length: int,
+                         win_length: int, power: float, normalized, center: bool, pad_mode: str) -> Optional[Tensor]:
+    """MelSpectrogram of a float16 / bfloat16 waveform read AS IT IS (aamd_melspectrogram_lowp_f32: the conversion happens in
+    the kernel's load -- half the input bytes, no cast pass).  Frame-major float32 (rows, T, n_mels), or None when the shape is
+    not the n_fft = 400 / hop 160, 200 / power 2 kernel's (the caller then casts and takes the float path)."""
+    if n_fft != 400 or hop_length not in (160, 200) or power != 2.0 or not waveform.is_cuda:
+        return None
+    dev = waveform.device
+    window = window.to(device=dev, dtype=torch.float32)
+    x2 = _rows2d(waveform)
+    desc = _stft_desc(x2, pad, window, n_fft, hop_length, power, normalized, center, pad_mode, True)
+    bands = _mel_bands(fb, dev)
+    if bands.n_freq != n_fft // 2 + 1:
+        return None
+    L = _lib.lib()
+    out = torch.empty((desc.rows, desc.n_frames, bands.n_mels), dtype=torch.float32, device=dev)
+    if out.numel():
+        code = 1 if waveform.dtype == torch.float16 else 2
+        with torch.cuda.device(dev):
+            rc = L.aamd_melspectrogram_lowp_f32(x2.data_ptr(), code, _padded_window(window, n_fft).data_ptr(),
+                                                _twiddles(n_fft, dev).data_ptr(), C.byref(bands.struct), out.data_ptr(),
+                                                C.byref(desc), _lib.current_stream(dev))
+        if rc == _lib.EUNSUPPORTED:
+            return None
+        _lib.check(rc)
     return out
 
 
@@ -1163,12 +1236,14 @@ def _dct_rows(x: Tensor, dct: Tensor) -> Tensor:
     return _mfcc_dct_launch(x, dct, 2, None, 1, -1.0)
 
 
+@_reduced_precision_io
 def mel_scale(specgram: Tensor, fb: Tensor) -> Tensor:
     """MelScale.forward (transforms/_transforms.py:403-415): (..., freq, time) -> (..., n_mels, time)."""
-    if specgram.is_cuda and (specgram.dtype == torch.float64 or (torch.is_grad_enabled() and specgram.requires_grad)):
-        # precision / training path of this thin caller: the reference's own product, differentiable to any order
+    if specgram.is_cuda and (specgram.dtype == torch.float64 or
+                             (torch.is_grad_enabled() and (specgram.requires_grad or fb.requires_grad))):
+        # precision / training path of this thin caller: the reference's own product, differentiable to any order in the
+        # spectrogram AND in a learnable filterbank (_transforms.py:413: the reference propagates into `fb` through matmul)
         # (the fused MelSpectrogram kernel is the throughput path; test: transforms/autograd_test_impl.py test_melscale)
-        _reject_param_grad(fb=fb)
         return torch.matmul(specgram.transpose(-1, -2), fb.to(device=specgram.device, dtype=specgram.dtype)).transpose(-1, -2)
     _require_device(specgram, "specgram")
     shape = specgram.shape
@@ -1197,6 +1272,7 @@ def mel_scale(specgram: Tensor, fb: Tensor) -> Tensor:
 # --------------------------------------------------------------------------- #
 
 
+@_reduced_precision_io
 def amplitude_to_DB(x: Tensor, multiplier: float, amin: float, db_multiplier: float,
                     top_db: Optional[float] = None) -> Tensor:
     r"""Power/amplitude -> decibel (functional/functional.py:356-404).  With ``top_db`` the cut-off
@@ -1334,6 +1410,7 @@ class _ResampleFunction(torch.autograd.Function):
         return dx[:, :ctx.length], None, None, None, None, None
 
 
+@_reduced_precision_io
 def _apply_sinc_resample_kernel(waveform: Tensor, orig_freq: int, new_freq: int, gcd: int, kernel: Tensor,
                                 width: int) -> Tensor:
     """functional/functional.py:1405-1432 as one polyphase HIP kernel (differentiable in the waveform)."""
@@ -1347,13 +1424,18 @@ def _apply_sinc_resample_kernel(waveform: Tensor, orig_freq: int, new_freq: int,
     kern = kernel.to(device=waveform.device, dtype=waveform.dtype).reshape(new, -1).contiguous()
     if kern.shape[1] != 2 * width + orig:
         raise RuntimeError("audio_amd: resample kernel shape does not match (new, 2*width+orig)")
-    if torch.is_grad_enabled() and waveform.requires_grad:
+    if torch.is_grad_enabled() and kernel.requires_grad:
+        # a learnable tap table (the reference propagates into it through conv1d, functional.py:1419-1431)
+        out = _diff.resample_learnable_kernel(x2, kernel.to(device=waveform.device, dtype=waveform.dtype).reshape(new, -1),
+                                              orig, new, width)
+    elif torch.is_grad_enabled() and waveform.requires_grad:
         out = _ResampleFunction.apply(x2, kern, kernel, orig, new, width)
     else:
         out = _polyphase(x2, kern, kernel, "fwd", orig, new, width)
     return out.view(tuple(shape[:-1]) + (out.shape[-1],))
 
 
+@_reduced_precision_io
 def resample(
     waveform: Tensor,
     orig_freq: int,
@@ -1520,6 +1602,7 @@ def _lfilter_sections(a_key: Tensor, b_key: Tensor, a: Tensor, b: Tensor):
     return None if got[0] is None else got[:2]
 
 
+@_reduced_precision_io
 def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = True, batching: bool = True) -> Tensor:
     r"""IIR filter by the difference equation (functional/filtering.py:1032-1099): FIR + recursion
     + clamp in one HIP kernel (chunked linear-recurrence scan, see csrc/lfilter.h)."""
@@ -1569,6 +1652,7 @@ def lfilter(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = 
     return y.reshape(shape[:-1] + y.shape[-1:])
 
 
+@_reduced_precision_io
 def biquad_cascade(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = True) -> Tensor:
     """``n_stages`` sequential ``lfilter`` calls (each clamped like the reference's default) fused in
     ONE pass over the audio.  a_coeffs, b_coeffs: (n_stages, n_order) shared across channels or
@@ -1607,6 +1691,7 @@ def biquad(waveform: Tensor, b0: float, b1: float, b2: float, a0: float, a1: flo
     return lfilter(waveform, coef[:3], coef[3:])
 
 
+@_reduced_precision_io
 def filtfilt(waveform: Tensor, a_coeffs: Tensor, b_coeffs: Tensor, clamp: bool = True) -> Tensor:
     r"""Forward-backward IIR filtering (functional/filtering.py:672-711)."""
     fwd = lfilter(waveform, a_coeffs, b_coeffs, clamp=False, batching=True)
@@ -1903,6 +1988,7 @@ class _FFTConvolveFunction(torch.autograd.Function):
         return dx, dy, None, None
 
 
+@_reduced_precision_io
 def fftconvolve(x: Tensor, y: Tensor, mode: str = "full") -> Tensor:
     r"""Linear convolution along the last dim with broadcast leading dims and the reference's
     full / valid / same crops (functional/functional.py:2222-2258).  Differentiable in both operands."""

@@ -203,6 +203,8 @@ class PitchShift(torch.nn.Module):
         self.kernel = None          # built on the first call (the reference uses a lazy UninitializedParameter)
 
     def forward(self, waveform: Tensor) -> Tensor:
+        if waveform.dtype in F.LOW_PRECISION:         # float16 / bfloat16: float32 arithmetic, the input dtype back (F._reduced_precision_io)
+            return self.forward(waveform.float()).to(waveform.dtype)
         F._require_device(waveform, "waveform")
         shape = waveform.size()
         stretch = F._stretch_waveform(waveform, self.n_steps, self.bins_per_octave, self.n_fft, self.win_length,
@@ -372,8 +374,18 @@ class MelSpectrogram(torch.nn.Module):
             return torch.ops.audio_amd.mel_spectrogram(waveform, sp.window, self.mel_scale.fb, sp.pad, sp.n_fft,
                                                        sp.hop_length, sp.win_length, float(sp.power),
                                                        _norm_mode(sp.normalized), sp.center, sp.pad_mode)
-        F._reject_param_grad(window=self.spectrogram.window, fb=self.mel_scale.fb)
-        if waveform.dtype == torch.float64 and waveform.is_cuda:
+        if waveform.dtype in F.LOW_PRECISION:
+            # float16 / bfloat16 waveforms (the reference takes any floating dtype and returns it): the n_fft = 400 kernel reads
+            # them as they are (conversion in its load); every other shape, and training, widens first.  float32 arithmetic.
+            if not (torch.is_grad_enabled() and waveform.requires_grad) and not F._learnable(self.spectrogram.window, self.mel_scale.fb):
+                sp = self.spectrogram
+                out = F._melspectrogram_lowp(waveform, sp.pad, sp.window, self.mel_scale.fb, sp.n_fft, sp.hop_length,
+                                             sp.win_length, sp.power, sp.normalized, sp.center, sp.pad_mode)
+                if out is not None:
+                    return out.view(tuple(waveform.shape[:-1]) + out.shape[-2:]).transpose(-1, -2).to(waveform.dtype)
+            return self.forward(waveform.float()).to(waveform.dtype)
+        if (waveform.dtype == torch.float64 and waveform.is_cuda) or F._learnable(self.spectrogram.window, self.mel_scale.fb):
+            # (a learnable window / filterbank: the same composition; gradients flow into both, as in the reference)
             # precision path: the reference composition (_transforms.py:612-622) over the float64 STFT kernels
             return self.mel_scale(self.spectrogram(waveform))
         if torch.is_grad_enabled() and waveform.requires_grad:
@@ -478,10 +490,10 @@ class MFCC(torch.nn.Module):
             return torch.ops.audio_amd.mfcc(waveform, sp.window, self.MelSpectrogram.mel_scale.fb, self.dct_mat, sp.pad,
                                             sp.n_fft, sp.hop_length, sp.win_length, float(sp.power),
                                             _norm_mode(sp.normalized), sp.center, sp.pad_mode, self.log_mels, self.top_db)
-        F._reject_param_grad(window=self.MelSpectrogram.spectrogram.window, fb=self.MelSpectrogram.mel_scale.fb)
-        if not waveform.requires_grad:
-            F._reject_param_grad(dct_mat=self.dct_mat)     # (the differentiable path below does propagate into it)
-        if (torch.is_grad_enabled() and waveform.requires_grad) or (waveform.dtype == torch.float64 and waveform.is_cuda):
+        if waveform.dtype in F.LOW_PRECISION:         # float16 / bfloat16: float32 arithmetic, the input dtype back
+            return self.forward(waveform.float()).to(waveform.dtype)
+        if (torch.is_grad_enabled() and waveform.requires_grad) or (waveform.dtype == torch.float64 and waveform.is_cuda) or \
+                F._learnable(self.MelSpectrogram.spectrogram.window, self.MelSpectrogram.mel_scale.fb, self.dct_mat):
             # differentiable / float64 path (reference composition, _transforms.py:692-709, on top of the
             # differentiable mel spectrogram): the dB / top_db / DCT tail is cheap and torch's autograd
             # reproduces the reference's sub-gradients (clamp, amax) exactly

@@ -24,6 +24,10 @@
     ranks (scatter_batch) and the features back (gather_batch): SURVEY 8(d) "scatter/gather timed separately".
   * N > 1: the line carries every rank's own wall time (`per_rank_ms_per_step`, min / max) next to the MAX that `value`
     is computed from.
+  * --curve: the whole weak-scaling curve (1, 2, 4, ... N ranks, one launch each) in ONE invocation, one JSON line with
+    `curve: [{n, value, per_rank_ms_min_max, rccl_ranks, efficiency_vs_1}]`.
+  * K < 500 (the driver's --steps 20): `roofline.frac` / `achieved` are priced on 1000 further steps of the same loop, run
+    right behind the timed K (`priced_on`); the K-step sample is `frac_timed_region`.  `value` is always the K timed steps.
 
 Prints ONE JSON line on rank 0 with the driver's fields plus `roofline` (dominant kernel vs the HBM roofline, timed
 live with HIP events on the launch stream; `traffic` measured in-run with rocprofv3 PMC passes when rocprofv3 is on
@@ -278,11 +282,13 @@ def selftest_cpu(args, world, rank, launched):
             assert torch.equal(back, root * 2.0)
         sg = {"scatter_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3, "root_batch_rows": rows}
     if rank == 0:
-        line = {"metric": "selftest (CPU plumbing only, not a measurement)", "value": 0.0, "unit": "none",
+        line = {"metric": "selftest (CPU plumbing only, not a measurement)",
+                "value": world * args.steps / max(float(t.item()), 1e-9), "unit": "selftest steps/s (all ranks)",
                 "n_gpus": world, "rccl_ranks": ranks, "steps": args.steps, "warmup": args.warmup, "op": args.op,
                 "ms_per_step": float(t.item()) / max(args.steps, 1) * 1e3, "data": "selftest"}
         if per_rank is not None:
             line["per_rank_ms_per_step"] = per_rank
+            line["per_rank_ms_min_max"] = [min(per_rank), max(per_rank)]
         if sg is not None:
             line["scatter_gather"] = sg
         print(json.dumps(line), flush=True)
@@ -296,6 +302,65 @@ def free_port():
     p = s.getsockname()[1]
     s.close()
     return p
+
+
+def curve(args):
+    """`--curve`: one child launch per point (1, 2, 4, ..., N ranks; N itself if it is not a power of two), each the exact
+    command the driver would run for that N, so a point of the curve and a stand-alone run are the same measurement.  Side
+    measurements (configs, PMC passes, CPU baseline) run once, at N = 1.  The efficiency printed here is value(n) / (n x
+    value(1)) -- a convenience; the driver computes its own from its own runs."""
+    ns, n = [], 1
+    while n < args.gpus:
+        ns.append(n)
+        n *= 2
+    ns.append(args.gpus)
+    passthrough = []
+    skip = False
+    for a in sys.argv[1:]:
+        if skip:
+            skip = False
+            continue
+        if a == "--curve":
+            continue
+        if a == "--gpus":
+            skip = True
+            continue
+        if a.startswith("--gpus="):
+            continue
+        passthrough.append(a)
+    points, lines = [], {}
+    for n in ns:
+        extra = [] if n == 1 else ["--no-configs", "--no-traffic", "--no-cpu-baseline"]
+        extra = [e for e in extra if e not in passthrough]
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n)] + passthrough + extra
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        sys.stderr.write(r.stderr[-4000:])
+        line = None
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                line = json.loads(ln)
+                break
+        if r.returncode != 0 or line is None:
+            points.append({"n": n, "error": f"rc {r.returncode}: " + (r.stderr or r.stdout)[-300:]})
+            continue
+        lines[n] = line
+        points.append({"n": n, "value": line["value"], "ms_per_step": line["ms_per_step"],
+                       "per_rank_ms_min_max": line.get("per_rank_ms_min_max"), "rccl_ranks": line.get("rccl_ranks")})
+    base = next((p["value"] for p in points if p["n"] == 1 and "value" in p), None)
+    for p in points:
+        p["efficiency_vs_1"] = (p["value"] / (p["n"] * base)) if base and "value" in p else None
+    top = dict(lines[max(lines)]) if lines else {"metric": OPS[args.op][1], "value": None, "n_gpus": args.gpus}
+    if 1 in lines and max(lines) != 1:
+        for k in ("roofline", "cpu_baseline", "configs", "box_calibration", "steady_state_1000_steps"):
+            if k in lines[1]:
+                top[k + "_at_n1"] = lines[1][k]
+    top["curve"] = points
+    top["curve_note"] = ("one torch.distributed.run launch per point, same K / W / shapes (weak scaling: per-GPU batch fixed); "
+                         "top-level fields = the largest N that ran; *_at_n1 = the side measurements of the 1-GPU point")
+    print(json.dumps(top), flush=True)
+    return 0 if len(lines) == len(ns) else 1
 
 
 def main():
@@ -319,11 +384,20 @@ def main():
                     help="plumbing self-test WITHOUT GPUs (tests/test_bench_cli.py): same launch / rendezvous / barrier / "
                          "MAX-reduce / JSON path over gloo, the step replaced by a tiny CPU STFT; the line says "
                          "data=selftest and is never a measurement")
+    ap.add_argument("--curve", action="store_true",
+                    help="the weak-scaling curve in ONE invocation: runs 1, 2, 4, ... up to --gpus ranks back to back (each as "
+                         "its own torch.distributed.run launch with the same K / W) and prints ONE line whose `curve` holds "
+                         "{n, value, ms_per_step, per_rank_ms_min_max, rccl_ranks, efficiency_vs_1} per point; the top-level "
+                         "fields are those of the largest N.  Only from a plain `python bench.py` (not under torchrun).")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child()
 
     launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.curve:
+        if launched:
+            sys.exit("bench.py: --curve starts its own torch.distributed.run launches; run it as `python bench.py --gpus N --curve`")
+        return curve(args)
     if args.gpus > 1 and not launched:
         # self-spawn: one process per GPU under torch.distributed.run, RCCL over xGMI
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -516,6 +590,17 @@ def main():
         audio_s = world * batch * SECONDS * args.steps
         algo_bytes = algo_fn(batch, L, n_frames)             # mel: 245 821 440 B, mfcc: 409 661 440 B
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        # with a short timed region (the driver's --steps 20 = 1.4 ms of GPU time) the event-timed sample ran
+        # 4.5 % ahead of the same process's own 1000-step steady state.  `roofline.achieved` / `frac` are therefore priced on the
+        # steady-state figure whenever K < 500; the K-step sample stays in the line as `*_timed_region` (and `value` /
+        # `ms_per_step` stay what the contract says: the K timed steps on the wall clock).
+        priced_ms, priced_on = kernel_ms, f"HIP events around the K = {args.steps} timed steps"
+        if steady is not None:
+            priced_ms = steady["ms_per_step"]
+            priced_on = ("HIP events around 1000 further steps of the same loop, run right after the timed K steps (K < 500 is too "
+                         "small a sample); the K-step sample is `frac_timed_region`")
+        achieved_timed = achieved
+        achieved = algo_bytes / (priced_ms * 1e-3) / 1e9
         traffic, tdetail = (None, {"traffic_source": "committed", "why": "--no-traffic, --op mfcc or N > 1"})
         pmc = {}
         mfcc_report = None
@@ -540,7 +625,7 @@ def main():
                 configs = [{"error": f"{type(e).__name__}: {e}"[:400]}]
         if world == 1 and not args.no_traffic and args.op == "mel":
             traffic, tdetail = measure_traffic()
-            pmc = measure_issue(kernel_ms)
+            pmc = measure_issue(priced_ms)
         if traffic is None and args.op == "mel":
             traffic = committed_traffic()
         out = {
@@ -566,11 +651,14 @@ def main():
                                       f"({ring * algo_bytes / 1e6:.0f} MB per cycle > 256 MiB Infinity Cache)"},
             "roofline": dict({"bound": "hbm", "kernel": " + ".join(kernels), "achieved": achieved, "peak": HBM_PEAK_GBS,
                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "priced_on": priced_on, "priced_ms": priced_ms,
+                              "achieved_timed_region": achieved_timed, "frac_timed_region": achieved_timed / HBM_PEAK_GBS,
                               "frac_on_wall_clock": algo_bytes / (wall / args.steps) / 1e9 / HBM_PEAK_GBS,
-                              "timing": "`achieved` / `frac` from HIP events around the K steps on the launch stream "
-                                        "(`kernel_ms`); `frac_on_wall_clock` from `ms_per_step` (host clock, barrier to barrier)",
+                              "timing": "`achieved` / `frac`: see `priced_on`; `*_timed_region` from HIP events around the K "
+                                        "steps on the launch stream (`kernel_ms`); `frac_on_wall_clock` from `ms_per_step` "
+                                        "(host clock, barrier to barrier)",
                               "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
-                              "read_only_frac": (batch * L * 4) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}, **tdetail, **pmc),
+                              "read_only_frac": (batch * L * 4) / (priced_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}, **tdetail, **pmc),
         }
         out["box_calibration"] = calibration
         if mfcc_report is not None:
@@ -589,9 +677,15 @@ def main():
             from oracle import torch_cpu_ref
             sweep = torch_cpu_ref.sweep_mel_baseline(batch, SECONDS, SR, N_FFT, HOP, N_MELS)
             best = max(sweep, key=lambda r: r["audio_sec_per_sec"])
+            proto = torch_cpu_ref.protocol_set_num_threads(batch, SECONDS, SR, N_FFT, HOP, N_MELS)
             out["cpu_baseline"] = {"value": best["audio_sec_per_sec"], "unit": "audio-sec/sec", "cores": os.cpu_count(),
                                    "threads_best": best["threads"], "cpu_model": cpu_model(),
                                    "kind": "port", "sweep": sweep,
+                                   "protocol_set_num_threads": proto,
+                                   "protocol_note": "BASELINE.md section 4 as written -- ONE call over the whole batch under "
+                                                    "torch.set_num_threads(n), n in {1, all host cores}, best of >= 3 -- is "
+                                                    "`protocol_set_num_threads`; `value` is the dealt-threads sweep, which is "
+                                                    "MORE favourable to the CPU (the intra-op pool of one call does not scale)",
                                    "sample": f"all {batch} clips x 10 s of one batch per call, clips dealt to `threads` host "
                                              "threads that each run the single-threaded composition on their share (the "
                                              "intra-op pool of one big call does not scale past a few cores); thread counts "

@@ -237,6 +237,15 @@ int aamd_melspectrogram_pcm16_interleaved_f32(const int16_t* pcm, int32_t channe
                                               float gain, const float* mean, const float* invstddev, int64_t out_frames,
                                               void* stream);
 
+/* Half / bfloat16 WAVEFORMS (ABI 6; the reference accepts any floating dtype -- functional/functional.py:1413-1414, the
+ * `forward` of every transform -- and returns it): wav is read as binary16 / bfloat16 and converted in the load of the
+ * radix-20x20 kernel (n_fft = 400, hop 160 / 200, power 2: AAMD_EUNSUPPORTED otherwise -- the host then casts and calls the
+ * float entry).  Arithmetic and `out` are float32; the caller casts the result to the input dtype.  row_stride and length in
+ * SAMPLES. */
+enum { AAMD_DTYPE_F16 = 1, AAMD_DTYPE_BF16 = 2 };
+int aamd_melspectrogram_lowp_f32(const void* wav, int32_t wav_dtype, const float* window, const float* twiddle,
+                                 const aamd_mel_bands* bands, float* out, const aamd_stft_desc* desc, void* stream);
+
 /* Backward of the |X|^p stage of F.spectrogram (functional.py:141-145), element-wise over n bins:
  *   out = dpower * p * |X|^(p-2) * X   (interleaved complex; 0 where X = 0 and p < 2)
  * -- the spectrum-domain cotangent aamd_istft_f32(adjoint = 1) turns into d loss / d waveform.  The filterbank's backward
@@ -406,9 +415,9 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
  * aamd_fftconvolve_plan reports what a call of that shape runs on the current device: 0 time domain, 1 overlap-save
  * with the input spectrum recomputed per tap partition, 2 overlap-save with a frequency-domain delay line (uniform
  * 8192-tap partitions, one forward + one inverse FFT per block; chosen by a cost model over rows, blocks and CUs),
- * 3 (193 .. 24576 taps, the default) REAL blocks as 8192-point complex FFTs, one row per workgroup of 1024 threads
- * (csrc/fftconv_fdr.h): plain overlap-save up to 8192 taps (hop = 16385 - taps), beyond that the delay line over 8192-tap
- * partitions with the delayed spectra in registers. */
+ * 3 (193 .. 32768 taps, the default; 24576 until ABI 5) REAL blocks as 8192-point complex FFTs, one row per workgroup of
+ * 1024 threads (csrc/fftconv_fdr.h): plain overlap-save up to 8192 taps (hop = 16385 - taps), beyond that the delay line over
+ * 8192-tap partitions with up to three delayed spectra in registers. */
 int64_t aamd_fftconvolve_workspace(int64_t rows, int64_t n_x_rows, int64_t n_y_rows, int64_t nx, int64_t ny);
 int aamd_fftconvolve_plan(int64_t rows, int64_t nx, int64_t ny, int64_t out_len);
 int aamd_fftconvolve_f32(const float* x, const float* y, float* out, int64_t rows, int64_t n_x_rows,

@@ -1226,7 +1226,7 @@ int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, in
   for (int t = 0; t < kThreads; ++t) mid_init(t, tw.data(), mc[t]);
   using A8 = std::array<C32, 8>;
   auto arr = [](A8& a) -> C32 (&)[8] { return *reinterpret_cast<C32 (*)[8]>(a.data()); };
-  std::vector<A8> v(kThreads), o(kThreads), z0(kThreads), z1(kThreads), z2(kThreads), acc(kThreads);
+  std::vector<A8> v(kThreads), o(kThreads), z0(kThreads), z1(kThreads), z2(kThreads), z3(kThreads), acc(kThreads);
   auto forward = [&]() {
     for (int t = 0; t < kThreads; ++t) first_pass_from_regs(t, arr(v[t]), lds.data(), tl);
     for (int t = 0; t < kThreads; ++t) pass_m128<false>(t, lds.data(), tl);
@@ -1259,7 +1259,7 @@ int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, in
     const C32* Hr = H.data() + ry * NP * kHPerPart;
     const bool vin = ((rx * g.nx) & 1) == 0, vout = ((row * out_len) & 1) == 0;   // what 8-byte alignment of a row means here
     for (int t = 0; t < kThreads; ++t)
-      for (int i = 0; i < 8; ++i) z1[t][i] = z2[t][i] = C32{0.0f, 0.0f};
+      for (int i = 0; i < 8; ++i) z1[t][i] = z2[t][i] = z3[t][i] = C32{0.0f, 0.0f};
     for (int64_t j = j_lo - (NP - 1); j < j_hi; ++j) {
       const bool produce = j >= j_lo;
       for (int t = 0; t < kThreads; ++t) {       // the delayed partitions first, as the kernel does (same summation order)
@@ -1273,6 +1273,10 @@ int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, in
           if (NP > 2) {
             for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(2, i, t)];
             mid_mac(t, h, arr(z2[t]), arr(acc[t]));
+          }
+          if (NP > 3) {
+            for (int i = 0; i < 8; ++i) h[i] = Hr[h_index(3, i, t)];
+            mid_mac(t, h, arr(z3[t]), arr(acc[t]));
           }
         }
       }
@@ -1289,7 +1293,7 @@ int sim_fftconv_fdr(const float* x, const float* y, float* out, int64_t rows, in
       // (every thread has read its quads before any thread writes: on the device a thread rewrites only the cells it read)
       for (int t = 0; t < kThreads; ++t) {
         if (produce) mid_merge(t, arr(acc[t]), mc[t], lds.data());
-        z2[t] = z1[t]; z1[t] = z0[t];
+        z3[t] = z2[t]; z2[t] = z1[t]; z1[t] = z0[t];
       }
       if (produce) {
         inverse();

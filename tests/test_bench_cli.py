@@ -70,3 +70,28 @@ def test_mfcc_op_and_scatter_gather_modes_over_two_ranks():
 def test_bench_source_names_both_baseline_configs():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "BASELINE configs[1]" in src and "BASELINE configs[3]" in src and "ShardedTransform" in src
+
+
+def test_curve_runs_every_point_in_one_invocation_and_prints_one_line():
+    """`bench.py --gpus N --curve` = the 1, 2, ..., N-rank points back to back, ONE JSON line with
+    `curve: [{n, value, per_rank_ms_min_max, rccl_ranks, efficiency_vs_1}]`; the top-level fields are the largest N's."""
+    r = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-cpu", "--curve"], timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    pts = line["curve"]
+    assert [p["n"] for p in pts] == [1, 2]
+    assert all(p["value"] > 0 and p["ms_per_step"] > 0 for p in pts)
+    assert pts[0]["efficiency_vs_1"] == 1.0 and pts[1]["efficiency_vs_1"] > 0
+    assert pts[0]["rccl_ranks"] == 1 and pts[1]["rccl_ranks"] == 2
+    assert len(pts[1]["per_rank_ms_min_max"]) == 2 and pts[0]["per_rank_ms_min_max"] is None
+
+
+def test_curve_with_three_ranks_adds_the_odd_endpoint_and_refuses_a_torchrun_launch():
+    r = _run(["--gpus", "3", "--steps", "2", "--warmup", "1", "--selftest-cpu", "--curve"], timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [p["n"] for p in _json_lines(r.stdout)[0]["curve"]] == [1, 2, 3]
+    r = _run(["--gpus", "2", "--selftest-cpu", "--curve"], env={"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "--curve" in (r.stderr + r.stdout)

@@ -368,11 +368,12 @@ def test_sim_fftconvolve_overlap_save(nx, ny, mode):
 
 
 @pytest.mark.parametrize("nx,ny,mode,cus", [(40000, 9000, "full", 256), (70001, 24000, "same", 256), (70000, 24576, "full", 4),
-                                            (30001, 20000, "valid", 2), (16385, 8193, "full", 256)])
+                                            (30001, 20000, "valid", 2), (16385, 8193, "full", 256),
+                                            (60000, 24577, "full", 256), (70001, 32768, "same", 3), (40000, 30000, "valid", 2)])
 def test_sim_fftconvolve_real_block_delay_line(nx, ny, mode, cus):
     """Plan 3 of aamd_fftconvolve_f32 (csrc/fftconv_fdr.h: real blocks as 8192-point complex FFTs, radices 8.8.8.8.2 with
     the digit-reversed spectrum in place, the real-FFT split / merge on mirror-bin quads, the delay line in "registers"),
-    replayed thread by thread: 2 and 3 partitions, row segments (few CUs), odd lengths, slices that start inside the
+    replayed thread by thread: 2, 3 and (round 5) 4 partitions, row segments (few CUs), odd lengths, slices that start inside the
     convolution -- against the float64 oracle."""
     rng = np.random.default_rng(nx + ny)
     x = rng.standard_normal((2, nx)).astype(np.float32)
@@ -389,9 +390,9 @@ def test_sim_fftconvolve_real_block_delay_line(nx, ny, mode, cus):
         e1 = O.fftconvolve(x.astype(np.float64), np.broadcast_to(y[:, :taps], (2, taps)).astype(np.float64), "full")
         g1 = S.sim_fftconv_fdr(x, y[:, :taps], 0, nx + taps - 1, ymap=np.zeros(2, dtype=np.int64), rows=2, cu_count=cus)
         assert g1 is not None and peak_rel_err(g1, e1) <= 2e-6, taps
-    if nx >= 30000:
-        assert S.sim_fftconv_fdr(x[:, :30000], rng.standard_normal((1, 24577)).astype(np.float32), 0, 30000 + 24576,
-                                 ymap=np.zeros(2, dtype=np.int64), rows=2) is None                                # > 24576 taps
+    if nx >= 40000:
+        assert S.sim_fftconv_fdr(x[:, :40000], rng.standard_normal((1, 32769)).astype(np.float32), 0, 40000 + 32768,
+                                 ymap=np.zeros(2, dtype=np.int64), rows=2) is None                                # > 32768 taps
 
 
 @pytest.mark.parametrize("nx,ny,mode,cus,fdl", [

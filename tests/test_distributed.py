@@ -321,3 +321,80 @@ print("RCCL_OK", torch.cuda.get_device_name(0))
         cmd = cmd[:-2] + [path]
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert res.returncode == 0 and "RCCL_OK" in res.stdout, (res.stdout[-2000:], res.stderr[-4000:])
+
+
+_TWO_RANK_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from audio_amd import distributed as D
+import audio_amd.transforms as T
+rank, world, dev = D.init_from_env()
+assert world >= 2 and dev.type == "cuda" and dev.index == int(os.environ["LOCAL_RANK"])
+if not dist.is_initialized():
+    dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl"
+one = torch.ones(1, device=dev)
+dist.all_reduce(one)
+assert int(one.item()) == world                     # RCCL really joined `world` ranks (not `world` one-rank groups)
+# one root-born batch; rank 0 holds it.  Rows are loud except the last, whose tail is silent: the batch-global top_db cut-off
+# (functional.py:393-402 on 2-D input) then clamps rows that live on OTHER ranks than the one holding the maximum
+N, L = 2 * world + 1, 24000                         # ragged: shard sizes differ by one
+g = torch.Generator().manual_seed(11)
+full_x = (0.4 * torch.randn(N, L, generator=g)).clamp_(-1, 1)
+full_x[-1, 6000:] = 0.0
+full_x[0] *= 2.0
+m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs={"n_fft": 400, "hop_length": 160, "n_mels": 80}).to(dev)
+for fused in (False, True):
+    m.fused = fused
+    want = m(full_x.to(dev))                        # the unsharded call, on every rank
+    a, b = D.shard_range(N, world, rank)
+    y = D.ShardedTransform(m)(full_x[a:b].to(dev))  # this rank's shard through the REAL all_reduce(MAX)
+    assert torch.equal(y, want[a:b]), ("sharded != unsharded", fused, rank)
+    # scatter from the root, transform, gather back on the root
+    loc = D.scatter_batch(full_x.to(dev) if rank == 0 else None, (N, L), dev, root=0)
+    assert torch.equal(loc.cpu(), full_x[a:b])
+    back = D.gather_batch(D.ShardedTransform(m)(loc), N, root=0)
+    if rank == 0:
+        assert torch.equal(back, want), ("gathered != unsharded", fused)
+    # an EMPTY shard on the last rank: it must join the exchange and return an empty result
+    n_small = world - 1
+    a2, b2 = D.shard_range(n_small, world, rank)
+    want2 = m(full_x[:n_small].to(dev))
+    y2 = D.ShardedTransform(m)(full_x[a2:b2].to(dev))
+    assert y2.shape[0] == b2 - a2 and torch.equal(y2, want2[a2:b2]), ("empty / tiny shards", fused, rank)
+torch.cuda.synchronize()
+dist.barrier(device_ids=[dev.index])
+dist.destroy_process_group()
+if rank == 0:
+    print("RCCL2_OK", world, torch.cuda.get_device_name(0))
+"""
+
+
+@pytest.mark.gpu
+def test_two_rank_rccl_sharded_mfcc_bit_equal_to_unsharded_when_two_gpus_are_visible():
+    """the moment a box shows >= 2 GPUs, the product's sharded MFCC runs over REAL RCCL with two ranks
+    (torch.distributed.run, one process per GPU, 127.0.0.1): the batch-global top_db cut-off through all_reduce(MAX) on the
+    product's stream, ragged and empty shards, scatter_batch / gather_batch -- bit-equal to the unsharded call, on both MFCC
+    paths.  Self-skips on a 1-GPU box (every box of this pool so far; the gloo tests above cover the logic on CPU)."""
+    import subprocess
+    import tempfile
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs >= 2 visible GPUs for a 2-rank RCCL group (this box shows {torch.cuda.device_count()})")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "rccl_two_ranks.py")
+        with open(path, "w") as fh:
+            fh.write(_TWO_RANK_SCRIPT % ROOT)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), path]
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0 and "RCCL2_OK 2" in res.stdout, (res.stdout[-2000:], res.stderr[-4000:])
+
+
+def test_two_rank_script_is_valid_python_and_names_the_product_entry_points():
+    """(CPU) the script of the 2-GPU test above cannot rot unnoticed on 1-GPU boxes: it compiles, and every audio_amd.distributed
+    name it uses exists."""
+    src = _TWO_RANK_SCRIPT % ROOT
+    compile(src, "rccl_two_ranks.py", "exec")
+    for name in ("init_from_env", "shard_range", "ShardedTransform", "scatter_batch", "gather_batch"):
+        assert name in src and hasattr(D, name), name

@@ -231,7 +231,7 @@ def test_fuzz_fftconvolve_vs_fft(seed):
         with _lib.kernel_policy(_lib.POLICY_FFTCONV_FDL), torch.no_grad():
             fdl = F.fftconvolve(x.cuda(), y.cuda(), mode)
         assert peak_rel_err(fdl.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (xs, ys, mode, "delay line")
-        with _lib.kernel_policy(_lib.POLICY_FFTCONV_NO_FDL), torch.no_grad():     # (the default above ran plan 3 up to 24576 taps)
+        with _lib.kernel_policy(_lib.POLICY_FFTCONV_NO_FDL), torch.no_grad():     # (the default above ran plan 3 up to 32768 taps)
             rec = F.fftconvolve(x.cuda(), y.cuda(), mode)
         assert peak_rel_err(rec.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (xs, ys, mode, "recompute")
 

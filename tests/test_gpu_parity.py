@@ -397,8 +397,8 @@ def test_fftconvolve_delay_line_plan_against_oracle(case):
     assert cplan in (1, 2) and torch.equal(cown, fdl if cplan == 2 else rec)
     own = F.fftconvolve(xd, yd, mode)
     plan = _lib.lib().aamd_fftconvolve_plan(rows, xs[-1], ys[-1], exp.shape[-1])
-    # default: the real-block delay line of round 4 (plan 3) serves 8193 .. 24576 taps, the complex plans the rest
-    assert plan == (3 if 192 < ys[-1] <= 24576 else cplan)
+    # default: the real-block kernel (plan 3) serves 193 .. 32768 taps (round 5: a third delayed spectrum in registers)
+    assert plan == (3 if 192 < ys[-1] <= 32768 else cplan)
     assert fdl.shape == exp.shape == own.shape
     assert peak_rel_err(fdl.cpu().numpy(), exp) <= 1e-5
     assert peak_rel_err(rec.cpu().numpy(), exp) <= 1e-5
@@ -411,7 +411,9 @@ def test_fftconvolve_delay_line_plan_against_oracle(case):
                                   ((6, 20001), (1, 4001), "full"),
                                   ((3, 50001), (1, 8193), "full"), ((2, 3, 33333), (2, 3, 12345), "same"),
                                   ((5, 70001), (5, 24576), "valid"), ((1, 200000), (1, 17000), "full"),
-                                  ((7, 16385), (1, 16384), "full"), ((2, 9000), (2, 8500), "full")])
+                                  ((7, 16385), (1, 16384), "full"), ((2, 9000), (2, 8500), "full"),
+                                  ((3, 90001), (1, 24577), "full"), ((2, 2, 70000), (2, 1, 32768), "same"),
+                                  ((260, 40000), (1, 30001), "valid")])
 def test_fftconvolve_real_block_delay_line_edges(case):
     """Plan 3 (csrc/fftconv_fdr.h) at its edges: the smallest / largest tap counts it serves, odd row lengths (rows on odd
     float offsets take the scalar load / store paths), outputs that end inside a block, a single row cut into segments, taps
@@ -866,6 +868,44 @@ def test_resample_binary16_split_kernel_against_fp32_kernel_and_oracle(gain):
     q = got[1, :, 12000:].cpu().numpy(), exp[1, :, 12000:]                       # the quiet part, against ITS peak
     assert float(np.abs(q[0] - q[1]).max()) <= 2e-5 * float(np.abs(q[1]).max())
     assert float(got[2, 1, 7400:].abs().max()) == 0.0                             # silence stays silence
+
+
+def test_resample_click_and_minus_100_db_tone_in_one_chunk():
+    """the block-floating scaling of the binary16-split resampler is weakest where ONE chunk (64
+    output groups = 28 224 input samples at 441 : 160) holds a full-scale click AND a passage 100 dB below it: the chunk's
+    power-of-two scale is set by the click, the quiet samples land near the bottom of binary16's normal range and their low
+    parts in its subnormals.  Element-wise against the float64 oracle with a floor of 1e-6 of the peak, beside the fp32-MFMA
+    kernel on the same input; and the tone alone (no click in its chunk) as the control."""
+    import audio_amd.transforms as T
+    from audio_amd import _lib
+    from oracle import dsp_oracle as O
+    kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=64, rolloff=0.9475937167399596,
+              beta=14.769656459379492)
+    r = T.Resample(44100, 16000, **kw).cuda()
+    n = 3 * 28224 + 777
+    t = np.arange(n) / 44100.0
+    tone = (1e-5 * np.sin(2 * np.pi * 997.0 * t)).astype(np.float32)
+    x = np.stack([tone.copy(), tone.copy(), tone.copy()])
+    x[0, 28224 + 5000] = 1.0                 # click in the middle of the second chunk, tone all around it
+    x[1, 28224 + 5000] = -1.0
+    x[1, 28224 + 5003] = 0.75
+    xt = torch.from_numpy(x)
+    with torch.no_grad():
+        got = r(xt.cuda()).cpu().numpy()
+        with _lib.kernel_policy(_lib.POLICY_RESAMPLE_FP32):
+            ref32 = r(xt.cuda()).cpu().numpy()
+    exp = O.resample(x.astype(np.float64), 44100, 16000, **kw)
+    assert got.shape == exp.shape
+    e16 = [floor_rel_err(got[i], exp[i], floor=1e-6) for i in range(3)]
+    e32 = [floor_rel_err(ref32[i], exp[i], floor=1e-6) for i in range(3)]
+    # rows with the click: every sample -- the ringing of the click AND the tone 100 dB under it -- within 2e-5 of its own size
+    # (floor: 1e-6 of the peak); the binary16 split may not be worse than 2 x the exact-fp32 kernel + 1e-5
+    assert max(e16) <= 2e-5, (e16, e32)
+    assert all(a <= 2.0 * b + 1e-5 for a, b in zip(e16, e32)), (e16, e32)
+    # the tone in the chunks around the click's chunk, against ITS OWN peak (1e-5 of the click)
+    q = slice(2 * 10240 + 200, None)
+    assert float(np.abs(got[0, q] - exp[0, q]).max()) <= 2e-5 * float(np.abs(exp[0, q]).max())
+    assert float(np.abs(got[2] - exp[2]).max()) <= 1e-5 * float(np.abs(exp[2]).max())          # the control row: no click at all
 
 
 @pytest.mark.parametrize("hop", [100, 200])

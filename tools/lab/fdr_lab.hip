@@ -43,7 +43,7 @@ extern "C" int lab_fdr(const float* x, const float* y, float* out, int64_t rows,
                          (const int64_t*)nullptr, ymap, out);                                                             \
     } while (0)
     if (tap_rows == 1) ymap = reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(workspace) + lab_fdr_workspace(1, ny));
-    if (g.n_part == 1) LAB_FDR(1); else if (g.n_part == 2) LAB_FDR(2); else LAB_FDR(3);
+    if (g.n_part == 1) LAB_FDR(1); else if (g.n_part == 2) LAB_FDR(2); else if (g.n_part == 3) LAB_FDR(3); else LAB_FDR(4);
 #undef LAB_FDR
   }
   return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -1,36 +1,122 @@
 #!/usr/bin/env python
-"""Condense a rocprofv3 `--kernel-trace --stats --output-format csv` run into a short text table
-(kernel names truncated) for profiles/.   python tools/prof_summary.py <dir> [prefix]"""
+"""Condense a rocprofv3 `--kernel-trace --stats --output-format csv` run into a short text table for profiles/.
+
+  python tools/prof_summary.py <dir>
+
+Round 5: a reader must be able to map every row to a BASELINE config without knowing the launch structure.
+  * kernel names keep their TEMPLATE ARGUMENTS (three rows used to read `aamd::m400::melspec400_kernel`), and known
+    instantiations get the `configs[].id` of tools/bench_configs.py they belong to in the last column;
+  * the table is built from the kernel TRACE (one row per dispatch), not from rocprof's own stats: launches of one name whose
+    durations fall into two clusters (the MFCC kernel is launched twice per call -- pass 0 and the near-empty fix-up launch --
+    under one name) are split into two rows;
+  * `avg_us` counts every launch; `steady_us` drops the first 25 ms of each row's launches (the chip's clock ramp after an
+    idle or a change of workload, profiles/r04_t_clock_ramp_configs.txt) -- the un-profiled bench times its configs after a
+    60 ms ramp, so `steady_us` is the figure to compare with `configs[].ms` (rocprof itself adds 1-4 % on top)."""
 import csv
 import glob
 import os
+import re
 import sys
 
+EPI = {0: "EPI400_MEL", 1: "EPI400_MEL_DB", 2: "EPI400_SPEC", 3: "EPI400_MEL_NORM", 4: "EPI400_MFCC"}
 
-def short(name: str, n: int = 72) -> str:
-    name = name.split("(")[0] if not name.startswith("void ") else name[5:].split("<")[0]
-    return name[:n]
+
+def clean(name: str) -> str:
+    """`void ns::kernel<args>(params) [clone .kd]` -> `ns::kernel<args>`"""
+    n = name.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    depth, end = 0, len(n)
+    for i, ch in enumerate(n):                      # cut the parameter list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and not n[:i].endswith("anonymous namespace") and n[i:i + 11] != "(anonymous ":
+            end = i
+            break
+    n = n[:end].strip()
+    n = re.sub(r"\s+", " ", n).replace(", ", ",")
+    return n
+
+
+def config_of(name: str, cluster: str) -> str:
+    m = re.match(r"aamd::m400::melspec400_kernel<(\d+),(\d+),(\d+),([^,]+),(\d+),(\d+)>", name)
+    if m:
+        epi = int(m.group(2))
+        tag = EPI.get(epi, "EPI?")
+        if epi == 0:
+            return "cfg2 (bench.py headline)" + ("" if int(m.group(6)) else " [generic filterbank instantiation]")
+        if epi == 2:
+            return "spec"
+        if epi == 4:
+            return "cfg4 / cfg4_per_item: " + ("fix-up launch" if cluster == "short" else "pass 0" if cluster == "long" else tag)
+        return tag
+    if name.startswith("aamd::rsm::resample_f16_kernel"):
+        return "cfg3"
+    if name.startswith("aamd::lfw::lfilter_wave_mover_kernel"):
+        return "cfg5a"
+    if name.startswith("aamd::fdr::delay_line_kernel"):
+        return "cfg5b"
+    if name.startswith("aamd::fdr::spectrum_kernel") or name.startswith("aamd::fco::twiddle_kernel"):
+        return "cfg5b: preparation (first call with a tap tensor only)"
+    if name.startswith("aamd::mfcc_dct") or name.startswith("aamd::mel_tab") or name.startswith("aamd::mfcc_frag"):
+        return "set-up (once per module)"
+    if name.startswith("at::") or name.startswith("(anonymous") or "elementwise" in name or "distribution" in name:
+        return "torch (input generation / clock ramp filler)"
+    return ""
 
 
 def main():
     d = sys.argv[1]
     out = []
-    for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)):
-        out.append(f"# {os.path.basename(f)}")
-        out.append(f"{'kernel':72s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}")
-        for r in csv.DictReader(open(f)):
-            out.append(f"{short(r['Name']):72s} {r['Calls']:>6s} {float(r['AverageNs']) / 1e3:10.2f} "
-                       f"{float(r['MinNs']) / 1e3:10.2f} {float(r['MaxNs']) / 1e3:10.2f} {float(r['Percentage']):7.2f}")
     for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
-        seen = {}
+        rows = {}
+        meta = {}
         for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
-            if k not in seen:
-                seen[k] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"],
-                           r["Workgroup_Size_X"], r["Grid_Size_X"])
-        out.append(f"# {os.path.basename(f)}: kernel  vgpr agpr sgpr lds_bytes wg grid")
-        for k, v in seen.items():
-            out.append(f"{k:72s} " + " ".join(v))
+            k = clean(r["Kernel_Name"])
+            s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            rows.setdefault(k, []).append((s, e - s))
+            if k not in meta:
+                meta[k] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size_X"],
+                           r["Grid_Size_X"])
+        total = sum(dur for v in rows.values() for _, dur in v) or 1
+        table = []
+        for k, v in rows.items():
+            v.sort()
+            durs = [dur for _, dur in v]
+            lo, hi = min(durs), max(durs)
+            groups = [("", v)]
+            if len(v) >= 8 and hi > 4 * lo:                  # two launch kinds under one name: split at the geometric mean
+                cut = (lo * hi) ** 0.5
+                a, b = [x for x in v if x[1] < cut], [x for x in v if x[1] >= cut]
+                if len(a) >= 3 and len(b) >= 3:
+                    groups = [("short", a), ("long", b)]
+            for tag, g in groups:
+                t0 = g[0][0]
+                steady = [dur for s, dur in g if s - t0 > 25_000_000] or [dur for _, dur in g]
+                dd = [dur for _, dur in g]
+                table.append((sum(dd), k, tag, len(dd), sum(dd) / len(dd) / 1e3, sum(steady) / len(steady) / 1e3, len(steady),
+                              min(dd) / 1e3, max(dd) / 1e3))
+        table.sort(reverse=True)
+        out.append(f"# {os.path.basename(f)} -- one row per kernel instantiation (and per duration cluster); avg over all launches, "
+                   "steady = launches later than 25 ms after the row's first (behind the clock ramp)")
+        out.append(f"{'kernel<template arguments>':96s} {'calls':>6s} {'avg_us':>9s} {'steady_us':>9s} {'(n)':>6s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s}  config")
+        for tot, k, tag, n, avg, st, ns, mn, mx in table:
+            nm = (k if len(k) <= 92 else k[:89] + "...") + (f" [{tag}]" if tag else "")
+            out.append(f"{nm:96s} {n:6d} {avg:9.2f} {st:9.2f} {ns:6d} {mn:9.2f} {mx:9.2f} {100.0 * tot / total:6.2f}  {config_of(k, tag)}")
+        out.append(f"# kernel  vgpr agpr sgpr lds_bytes wg grid")
+        for k, v in meta.items():
+            if k.startswith("aamd::"):
+                out.append(f"{(k if len(k) <= 96 else k[:93] + '...'):96s} " + " ".join(v))
+    if not out:                                             # no trace: fall back to rocprof's own stats, names un-truncated
+        for f in sorted(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)):
+            out.append(f"# {os.path.basename(f)}")
+            out.append(f"{'kernel':96s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>7s}")
+            for r in csv.DictReader(open(f)):
+                k = clean(r["Name"])
+                out.append(f"{k[:96]:96s} {r['Calls']:>6s} {float(r['AverageNs']) / 1e3:10.2f} {float(r['MinNs']) / 1e3:10.2f} "
+                           f"{float(r['MaxNs']) / 1e3:10.2f} {float(r['Percentage']):7.2f}  {config_of(k, '')}")
     print("\n".join(out))
 
 
