@@ -114,3 +114,53 @@ def floor_rel_err(a, b, floor=1e-6):
     m = np.max(np.abs(b)) if b.size else 0.0
     den = np.maximum(np.abs(b), floor * m)
     return float(np.max(np.abs(a - b) / den)) if b.size else 0.0
+
+
+def windowed_rel_err(a, b, win=32, floor=1e-6):
+    """max over windows of `win` consecutive samples (last axis) of  max|a - b| / max(max|b| in the window, floor * max|b|):
+    the error of every passage against ITS OWN local amplitude.  An element-wise ratio is the wrong yardstick for an
+    oscillating signal -- at a zero crossing |b| is arbitrarily small while any fp32 evaluation (the reference's conv1d
+    included) carries an error proportional to the local envelope."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    n = b.shape[-1] // win * win
+    if n == 0:
+        return 0.0
+    e = np.abs(a[..., :n] - b[..., :n]).reshape(b.shape[:-1] + (-1, win)).max(-1)
+    m = np.abs(b[..., :n]).reshape(b.shape[:-1] + (-1, win)).max(-1)
+    return float((e / np.maximum(m, floor * np.abs(b).max())).max())
+
+
+def click_and_quiet_tone():
+    """Three rows of 3 x 28 224 + 777 samples at 44.1 kHz: a 997 Hz tone at 1e-5 of full scale (- 100 dB); rows 0 and 1 carry
+    a full-scale click (row 1: two samples of opposite sign) in the middle, row 2 is the control.  A chunk of the f16
+    resampler is 32 output groups = 14 112 input samples at 441 : 160, so the click's chunk holds ~ 14 000 samples of the tone."""
+    n = 3 * 28224 + 777
+    t = np.arange(n) / 44100.0
+    tone = (1e-5 * np.sin(2 * np.pi * 997.0 * t)).astype(np.float32)
+    x = np.stack([tone.copy(), tone.copy(), tone.copy()])
+    x[0, 28224 + 5000] = 1.0
+    x[1, 28224 + 5000] = -1.0
+    x[1, 28224 + 5003] = 0.75
+    return x
+
+
+def check_click_and_quiet_tone(got, ref32, exp):
+    """The assertions of the click case, shared by the GPU test and the CPU replay (tests/test_cpu_sim.py).  Every passage is
+    judged against ITS OWN local amplitude (32-sample windows, floor 1e-6 of the row's peak): the ringing of the click, the
+    tone 100 dB under it inside the same chunk, and the tone in the chunks around it."""
+    assert got.shape == exp.shape and ref32.shape == exp.shape
+    for i in range(3):
+        e16, e32 = windowed_rel_err(got[i], exp[i]), windowed_rel_err(ref32[i], exp[i])
+        # against the float64 oracle: 1.05e-5 for BOTH kernels where the ringing meets the tone (the float32 tap table the
+        # reference builds against the oracle's float64 taps), 2e-6 on the control row
+        assert e16 <= 3e-5 and e32 <= 3e-5, (i, e16, e32)
+        assert e16 <= 1.25 * e32 + 2e-6, (i, e16, e32)
+        # binary16 split (chunk scale set by the click) against exact-fp32 MFMA on the same float32 taps: measured 2.2e-6,
+        # and the worst window lies in a chunk WITHOUT the click
+        assert windowed_rel_err(got[i], ref32[i]) <= 6e-6, i
+    # the tone in the chunk behind the click's, against ITS OWN peak (1e-5 of the click)
+    q = slice(2 * 10240 + 200, None)
+    assert float(np.abs(got[0, q] - exp[0, q]).max()) <= 2e-5 * float(np.abs(exp[0, q]).max())
+    assert float(np.abs(got[2] - exp[2]).max()) <= 1e-5 * float(np.abs(exp[2]).max())          # the control row: no click at all

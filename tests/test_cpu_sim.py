@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from audio_amd import _host
-from conftest import peak_rel_err, ref_runs
+from conftest import check_click_and_quiet_tone, click_and_quiet_tone, peak_rel_err, ref_runs
 from oracle import dsp_oracle as O
 import oracle_dispatch as OD
 import sim_util as S
@@ -140,6 +140,21 @@ def test_sim_resample(case):
         assert rc == 0
         assert not np.isnan(got3).any()          # every output written exactly by some lane
         assert peak_rel_err(got3.reshape(exp.shape), exp) <= 1e-5
+
+
+def test_sim_resample_click_and_minus_100_db_tone_in_one_chunk():
+    """The click case of tests/test_gpu_parity.py through the CPU replay of both matrix-core resamplers (binary16 split with the
+    chunk's power-of-two scale set by the click; exact fp32 MFMA) against the float64 oracle: same assertions as on the GPU."""
+    import math
+    kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=64, rolloff=0.9475937167399596,
+              beta=14.769656459379492)
+    x = click_and_quiet_tone()
+    k, width = _host.sinc_resample_kernel(44100, 16000, math.gcd(44100, 16000), **kw)
+    rc16, got = S.sim_resample_mfma(x, k.numpy(), 441, 160, width, 1, 1)
+    rc32, ref32 = S.sim_resample_mfma(x, k.numpy(), 441, 160, width, 1, 0)
+    assert rc16 == 0 and rc32 == 0
+    exp = O.resample(x.astype(np.float64), 44100, 16000, **kw)
+    check_click_and_quiet_tone(got, ref32, exp)
 
 
 @pytest.mark.parametrize("case", ref_runs().select("lfilter"), ids=lambda c: f"{c['id']}-{c.get('tag')}")

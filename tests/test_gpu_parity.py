@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import floor_rel_err, peak_rel_err, ref_runs
+from conftest import (check_click_and_quiet_tone, click_and_quiet_tone, floor_rel_err, peak_rel_err, ref_runs,
+                      windowed_rel_err)
 import oracle_dispatch as OD
 import product_dispatch as PD
 
@@ -871,41 +872,25 @@ def test_resample_binary16_split_kernel_against_fp32_kernel_and_oracle(gain):
 
 
 def test_resample_click_and_minus_100_db_tone_in_one_chunk():
-    """the block-floating scaling of the binary16-split resampler is weakest where ONE chunk (64
-    output groups = 28 224 input samples at 441 : 160) holds a full-scale click AND a passage 100 dB below it: the chunk's
-    power-of-two scale is set by the click, the quiet samples land near the bottom of binary16's normal range and their low
-    parts in its subnormals.  Element-wise against the float64 oracle with a floor of 1e-6 of the peak, beside the fp32-MFMA
-    kernel on the same input; and the tone alone (no click in its chunk) as the control."""
+    """the block-floating scaling of the binary16-split resampler is weakest where ONE chunk holds a
+    full-scale click AND a passage 100 dB below it: the chunk's power-of-two scale is set by the click, the quiet samples land
+    near the bottom of binary16's normal range and their low parts in its subnormals.  Against the float64 oracle and against
+    the fp32-MFMA kernel on the same input (`check_click_and_quiet_tone`); the same case runs through the CPU replay of both
+    kernels in tests/test_cpu_sim.py."""
     import audio_amd.transforms as T
     from audio_amd import _lib
     from oracle import dsp_oracle as O
     kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=64, rolloff=0.9475937167399596,
               beta=14.769656459379492)
     r = T.Resample(44100, 16000, **kw).cuda()
-    n = 3 * 28224 + 777
-    t = np.arange(n) / 44100.0
-    tone = (1e-5 * np.sin(2 * np.pi * 997.0 * t)).astype(np.float32)
-    x = np.stack([tone.copy(), tone.copy(), tone.copy()])
-    x[0, 28224 + 5000] = 1.0                 # click in the middle of the second chunk, tone all around it
-    x[1, 28224 + 5000] = -1.0
-    x[1, 28224 + 5003] = 0.75
+    x = click_and_quiet_tone()
     xt = torch.from_numpy(x)
     with torch.no_grad():
         got = r(xt.cuda()).cpu().numpy()
         with _lib.kernel_policy(_lib.POLICY_RESAMPLE_FP32):
             ref32 = r(xt.cuda()).cpu().numpy()
     exp = O.resample(x.astype(np.float64), 44100, 16000, **kw)
-    assert got.shape == exp.shape
-    e16 = [floor_rel_err(got[i], exp[i], floor=1e-6) for i in range(3)]
-    e32 = [floor_rel_err(ref32[i], exp[i], floor=1e-6) for i in range(3)]
-    # rows with the click: every sample -- the ringing of the click AND the tone 100 dB under it -- within 2e-5 of its own size
-    # (floor: 1e-6 of the peak); the binary16 split may not be worse than 2 x the exact-fp32 kernel + 1e-5
-    assert max(e16) <= 2e-5, (e16, e32)
-    assert all(a <= 2.0 * b + 1e-5 for a, b in zip(e16, e32)), (e16, e32)
-    # the tone in the chunks around the click's chunk, against ITS OWN peak (1e-5 of the click)
-    q = slice(2 * 10240 + 200, None)
-    assert float(np.abs(got[0, q] - exp[0, q]).max()) <= 2e-5 * float(np.abs(exp[0, q]).max())
-    assert float(np.abs(got[2] - exp[2]).max()) <= 1e-5 * float(np.abs(exp[2]).max())          # the control row: no click at all
+    check_click_and_quiet_tone(got, ref32, exp)
 
 
 @pytest.mark.parametrize("hop", [100, 200])
