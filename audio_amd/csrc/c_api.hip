@@ -72,6 +72,7 @@ int policy() {
     if (std::getenv("AAMD_RESAMPLE_FP32") != nullptr) p |= AAMD_POLICY_RESAMPLE_FP32;
     if (std::getenv("AAMD_FFTCONV_NO_FDL") != nullptr) p |= AAMD_POLICY_FFTCONV_NO_FDL;
     if (std::getenv("AAMD_FFTCONV_FDL") != nullptr) p |= AAMD_POLICY_FFTCONV_FDL;
+    if (std::getenv("AAMD_RESAMPLE_B32") != nullptr) p |= AAMD_POLICY_RESAMPLE_B32;
     int expected = -1;
     g_policy.compare_exchange_strong(expected, p);
     p = g_policy.load(std::memory_order_relaxed);
@@ -355,7 +356,7 @@ int aamd_set_kernel_policy(int flags) {
   const int prev = policy();
   if (flags >= 0) g_policy.store(flags & (AAMD_POLICY_FORCE_GENERIC | AAMD_POLICY_MEL400_WIDE | AAMD_POLICY_ISTFT_ATOMIC |
                                           AAMD_POLICY_RESAMPLE_FP32 | AAMD_POLICY_FFTCONV_NO_FDL | AAMD_POLICY_FFTCONV_FDL |
-                                          AAMD_POLICY_FFTCONV_COMPLEX));
+                                          AAMD_POLICY_FFTCONV_COMPLEX | AAMD_POLICY_RESAMPLE_B32));
   return prev;
 }
 
@@ -1243,6 +1244,7 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
       if (g.tap_lo[t] > max_lo) max_lo = g.tap_lo[t];
     }
     const bool f16 = (policy() & AAMD_POLICY_RESAMPLE_FP32) == 0;
+    const bool rd64 = f16 && rsm::b64_ok(ks, orig) && (policy() & AAMD_POLICY_RESAMPLE_B32) == 0;
     if (!rsm::plan_chunk(g, ks, f16, nq, max_lo, lds_cap))   // a single q-group does not fit (huge orig): scalar kernel
       return aamd_resample_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, stream);
     const int qg = g.qg;
@@ -1267,6 +1269,8 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
     auto kern = !f16 ? rsm::resample_mfma_kernel<KS>                                                  \
                 : g.lab == 0 ? rsm::resample_f16_kernel<KS, 0>                                         \
                 : g.lab == 64 ? rsm::resample_f16_kernel<KS, 1> : rsm::resample_f16_kernel<KS, 2>;    \
+    /* 8-byte operand reads: odd orig, KS = 80 / 112 (resample_mfma.h, b64_rot) */                    \
+    if (f16 && rd64) kern = g.lab == 64 ? rsm::kernel_rd64<KS, 1>() : rsm::kernel_rd64<KS, 0>();      \
     if (lds > 48 * 1024)                                                                              \
       AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \

@@ -143,6 +143,47 @@ AAMD_HD void store_c(const Geom& g, float* out_row, int64_t qc0, int qt, int pt,
     if (p0 + i < g.new_ && oi + i < g.out_len) out_row[oi + i] = c[i];
 }
 
+// store_c for an explicit output group q (the 8-byte operand-read layout below deals q to tiles by parity)
+AAMD_HD void store_c_at(const Geom& g, float* out_row, int64_t q, int pt, int lane, float c0, float c1, float c2, float c3) {
+  const int p0 = 16 * pt + 4 * (lane >> 4);
+  const int64_t oi = q * g.new_ + p0;
+  if (g.vec_out && p0 + 4 <= g.new_ && oi + 4 <= g.out_len) {
+    *reinterpret_cast<F4*>(out_row + oi) = F4{c0, c1, c2, c3};
+    return;
+  }
+  const float c[4] = {c0, c1, c2, c3};
+  for (int i = 0; i < 4; ++i)
+    if (p0 + i < g.new_ && oi + i < g.out_len) out_row[oi + i] = c[i];
+}
+
+// ---- 8-byte operand reads (round 5; f16 kernel, odd `orig`, KS = 80 / 112) -------------------------------------------------
+// The f16 kernel's MFMA loop is bound by its LDS operand reads: a compute wave issues 8 ds_read_b32 per operand tile (a lane
+// needs 8 consecutive dwords, and q orig + tap is odd for every second q), 2 240 of them per chunk and CU = 4 480 LDS cycles
+// against 1 680 cycles of matrix pipe per SIMD.  ds_read_b64 moves twice the bytes per LDS cycle (MI355X_MICROARCH.md, LDS
+// table) but wants 8-byte aligned addresses and is served in groups of 32 lanes.  So, for odd `orig`:
+//   * the 32 output groups of a q-group are dealt to the two MFMA tiles BY PARITY -- tile h holds q = 2 n + h (n = lane & 15):
+//     the dword address (32 grp + 2 n + h) orig + tap_lo + KS g + shift + 8 s then has the same parity in all 64 lanes, and
+//     exactly one of the two tiles is 8-byte aligned, wave-uniformly: h = (tap_lo + shift) & 1.  That tile reads 4 pairs per
+//     step; the other one reads the 5 aligned pairs that start one dword earlier and regroups from dword 1 on (the
+//     v_perm_b32 of the hi / lo regrouping takes any two registers: no extra instruction);
+//   * bank model: lanes n of one group are 2 orig dwords apart -- 2 (orig n mod 32) mod 64, sixteen distinct EVEN banks whose
+//     complement among the even banks is the same set + 32; lane group g + 1 sits KS = 16 (mod 32) dwords further, so the odd
+//     lane groups walk the contraction steps ROTATED by r steps with KS + 8 r = 32 (mod 64) (r = 6 for KS = 112, 2 for 80;
+//     none exists for 16 / 48): step s of an odd group multiplies taps tap_lo + KS g + 8 ((s + r) mod NS) + e.  The 32 lanes a
+//     ds_read_b64 is served with then cover 32 even banks + their odd neighbours: conflict-free (the sum over the contraction
+//     does not care about the order; A fragments are loaded in the same rotated order).
+AAMD_HD constexpr int b64_rot(int ks) { return ks == 112 ? 6 : ks == 80 ? 2 : 0; }
+AAMD_HD bool b64_ok(int ks, int orig) { return (orig & 1) != 0 && b64_rot(ks) != 0; }
+// tap-table step that lane group `grp4` (= lane >> 4) multiplies at loop step s
+AAMD_HD int b64_step(int ks, int s, int grp4) {
+  const int t = s + ((grp4 & 1) ? b64_rot(ks) : 0), ns = ks / 8;
+  return t >= ns ? t - ns : t;
+}
+// LDS dword index of the B fragment of lane l, tile h (q = 2 n + h) of 32-q group `grp`, table step 0
+AAMD_HD int b_base64(const Geom& g, int grp, int h, int tap_lo, int ks, int shift, int lane) {
+  return (32 * grp + 2 * (lane & 15) + h) * g.orig + tap_lo + ks * (lane >> 4) + shift;
+}
+
 // ---- the f16 matrix-pipe variant: fp32-class accuracy from three f16 MFMAs per product --------------------------------
 // v_mfma_f32_16x16x4_f32 runs at 1/16 of the f16 rate of the matrix cores (157 against 2 500 TFLOP/s), and cfg3 is bound by
 // exactly that.  Every operand is therefore split into two binary16 numbers, v = hi + lo with hi = f16(v), lo = f16(v - hi)
@@ -226,9 +267,14 @@ AAMD_HD void chunk_scale(uint32_t max_bits, float& scale, float& inv) {
   std::memcpy(&inv, &iu, 4);
 }
 // A operand dword d (elements 2 d, 2 d + 1) of step s: the hi parts and the lo parts
+// (a_pack16_at: the same for an explicit tap index `tap` of element 2 d)
+AAMD_HD void a_pack16_at(const Geom& g, const float* kern, int pt, int tap, int lane, uint32_t& hi, uint32_t& lo);
 AAMD_HD void a_pack16(const Geom& g, const float* kern, int pt, int tap_lo, int ks, int s, int d, int lane,
                       uint32_t& hi, uint32_t& lo) {
-  const int p = 16 * pt + (lane & 15), tap = tap_lo + ks * (lane >> 4) + 8 * s + 2 * d;
+  a_pack16_at(g, kern, pt, tap_lo + ks * (lane >> 4) + 8 * s + 2 * d, lane, hi, lo);
+}
+AAMD_HD void a_pack16_at(const Geom& g, const float* kern, int pt, int tap, int lane, uint32_t& hi, uint32_t& lo) {
+  const int p = 16 * pt + (lane & 15);
   // unconditional loads from clamped indices, zeroed by select: the 2 x 112 loads of a lane are then issued back to back
   // (behind a branch each they were serialised: 0.08 ms per launch on the cfg3 shard)
   const float* row = kern + (int64_t)(p < g.new_ ? p : 0) * g.taps;
@@ -342,9 +388,11 @@ __device__ long long g_rsm_census[16 * 32 * 8];
 // LABM: the tools-only switches live in instantiations of their own -- 1 = the time stamps (AAMD_RSM_LAB=64), 2 = every lab
 // switch (their branches inside the MFMA loop cut it into basic blocks the scheduler cannot move the LDS reads across:
 // the product kernel carried them until the round-2 census, profiles/r02_v)
-template <int KS, int LABM>
+// RD: 0 = ds_read_b32 operand reads (any geometry); 1 = the 8-byte operand reads described above b64_rot (odd orig, KS >= 80)
+template <int KS, int LABM, int RD = 0>
 __global__ void __launch_bounds__(KS >= 80 ? 768 : 1024)
 resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restrict__ kern, float* __restrict__ out) {
+  static_assert(RD == 0 || b64_rot(KS) != 0, "8-byte operand reads need a conflict-free rotation (KS = 80 / 112)");
   const int lab = LABM ? g.lab : 0;
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   using h8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -398,6 +446,9 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (!loader) { AAMD_RSM_STAMP(k - 1, 3) }
     if (lab & 1) return;
+#if defined(AAMD_RSM_PRIO_CONV)
+    __builtin_amdgcn_s_setprio(AAMD_RSM_PRIO_CONV);     // lab: the conversion yields its issue slots to the MFMA loops still running
+#endif
     float scale, inv;
     chunk_scale(__atomic_load_n(&mx[k % 3], __ATOMIC_RELAXED), scale, inv);
     float* buf = smem_rsm + (k & 1) * g.buf_floats;
@@ -414,6 +465,9 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       for (int i = 0; i < kGrab; ++i)
         if (j0 + 64 * i < pieces) *reinterpret_cast<u32x4*>(buf + 4 * (j0 + 64 * i)) = pack4(t[i], scale);
     }
+#if defined(AAMD_RSM_PRIO_CONV)
+    if (loader) __builtin_amdgcn_s_setprio(3);
+#endif
   };
   if (loader) {
     __builtin_amdgcn_s_setprio(3);                  // the producers: first pick of the issue slots of their SIMDs
@@ -514,16 +568,48 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   }
 
   uint32_t ah[NS * 4], al[NS * 4];
+  if constexpr (RD == 1) {
+    // odd lane groups hold the steps rotated (b64_step): one per-lane tap offset, the wrap a compile-time choice per step.
+    // The per-lane base goes through an opaque move every AAMD_RSM_PRO_BATCH steps: left alone, the 224 tap indices are all
+    // formed up front, and with the 8-byte loop's registers on top the fragment loads were spilled one by one behind vmcnt(0)
+#ifndef AAMD_RSM_PRO_BATCH
+#define AAMD_RSM_PRO_BATCH 2
+#endif
+    int tap_base = tap_lo + KS * (lane >> 4) + ((lane & 16) ? 8 * b64_rot(KS) : 0);
 #pragma unroll
-  for (int i = 0; i < NS * 4; ++i) {
-    ah[i] = 0x3c003c00u; al[i] = 0x1c001c00u + i;
-    if (!(lab & 16)) a_pack16(g, kern, pt, tap_lo, KS, i >> 2, i & 3, lane, ah[i], al[i]);
+    for (int s_ = 0; s_ < NS; ++s_) {
+      if (s_ % AAMD_RSM_PRO_BATCH == 0) asm volatile("" : "+v"(tap_base));
+      if (s_ == NS - b64_rot(KS)) tap_base -= (lane & 16) * (KS / 16);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int i = 4 * s_ + d;
+        ah[i] = 0x3c003c00u; al[i] = 0x1c001c00u + i;
+        if (!(lab & 16)) a_pack16_at(g, kern, pt, tap_base + 8 * s_ + 2 * d, lane, ah[i], al[i]);
+      }
+      // the packed fragments of the step exist HERE: the split arithmetic was otherwise sunk behind convert(0)'s wait loop and
+      // the barrier, with all 224 raw taps alive across both
+      asm volatile("" : "+v"(ah[4 * s_]), "+v"(ah[4 * s_ + 1]), "+v"(ah[4 * s_ + 2]), "+v"(ah[4 * s_ + 3]),
+                        "+v"(al[4 * s_]), "+v"(al[4 * s_ + 1]), "+v"(al[4 * s_ + 2]), "+v"(al[4 * s_ + 3]));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < NS * 4; ++i) {
+      ah[i] = 0x3c003c00u; al[i] = 0x1c001c00u + i;
+      if (!(lab & 16)) a_pack16(g, kern, pt, tap_lo, KS, i >> 2, i & 3, lane, ah[i], al[i]);
+    }
   }
   if (first < end) convert(0);
   __syncthreads();                                       // A0
   for (int64_t cid = first; cid < end; ++cid) {
     const int k = (int)(cid - first);
     AAMD_RSM_STAMP(k, 0)
+#if defined(AAMD_RSM_PRIO_LOOP)
+#if AAMD_RSM_PRIO_LOOP == 9                              /* lab: the younger wave of a SIMD first */
+    if ((wave >> 2) == 0) __builtin_amdgcn_s_setprio(1); else if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+#else
+    __builtin_amdgcn_s_setprio(AAMD_RSM_PRIO_LOOP);
+#endif
+#endif
     const uint32_t* buf = reinterpret_cast<const uint32_t*>(smem_rsm + (k & 1) * g.buf_floats);
     float scale, inv;
     chunk_scale(mx[k % 3], scale, inv);
@@ -533,6 +619,121 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     float* out_row = out + row * g.out_len;
 #pragma unroll 1
     for (int r = 0; r < g.rounds; ++r) {                 // (indentation of the body kept: one more level would not fit the lines)
+    if constexpr (RD == 1) {
+      // 8-byte operand reads (see b64_rot): tile A = the parity of q whose addresses are 8-byte aligned for this wave and chunk,
+      // tile B the other parity, read from one dword earlier; odd lane groups walk the steps rotated by ROT
+      using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+      constexpr int ROT = b64_rot(KS);
+      const int grp = qgi + g.qg * r;
+      int ln = lane;                                        // lane-derived addresses are formed per round: hoisted out of the chunk loop they were spilled
+      asm volatile("" : "+v"(ln));
+      const int hA = (tap_lo + shift) & 1, hB = hA ^ 1;
+      const int odd_g = (ln >> 4) & 1;
+      const uint32_t* pa = buf + b_base64(g, grp, hA, tap_lo, KS, shift, ln) + (odd_g ? 8 * ROT : 0);
+      const uint32_t* pb = buf + b_base64(g, grp, hB, tap_lo, KS, shift, ln) - 1 + (odd_g ? 8 * ROT : 0);
+      // steps s >= NS - ROT of the odd lane groups read table step s + ROT - NS: both pointers step back KS dwords there
+      // (once per tile and round, formed from the lane number: nothing more to hold across the loop)
+      f32x4 accA = {0.0f, 0.0f, 0.0f, 0.0f}, accB = {0.0f, 0.0f, 0.0f, 0.0f};
+      // single ds_read_b64 each: left alone, hipcc pairs two of them into a ds_read2_b64 (8 LDS cycles instead of 2 x 2; fftconv_fdr.h)
+#define AAMD_RSM_PAIRS(P, N, R)                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < (N); ++j) {                                                            \
+        const u32x2 t_ = *reinterpret_cast<const u32x2*>((P) + 2 * j);                                             \
+        asm volatile("" ::: "memory");                                                                             \
+        R[2 * j] = t_.x; R[2 * j + 1] = t_.y;                                                                      \
+      }
+#define AAMD_RSM_READ_A(S, R) { if ((S) == NS - ROT) pa -= (ln & 16) * (KS / 16); AAMD_RSM_PAIRS(pa + 8 * (S), 4, R) }
+      // tile B: its dwords 0 .. 7 of a step are (carry, pairs (1, 2) (3, 4) (5, 6), first half of (7, 8)) and the second half of
+      // (7, 8) is dword 0 of the NEXT table step: four pairs per step, every register used (five pairs with two half-used
+      // ones were narrowed to ds_read_b32 by the compiler: two-way bank conflicts in this layout).  Dword 0 is read on its own
+      // where a run of table steps starts: step 0, and step NS - ROT where the odd lane groups wrap to table step 0
+#define AAMD_RSM_READ_B(S, R)                                                                                      \
+      {                                                                                                            \
+        if ((S) == NS - ROT) pb -= (ln & 16) * (KS / 16);                                                          \
+        if ((S) == 0 || (S) == NS - ROT) { cf = pb[8 * (S) + 1]; asm volatile("" ::: "memory"); }                  \
+        AAMD_RSM_PAIRS(pb + 8 * (S) + 2, 4, R)                                                                     \
+      }
+#define AAMD_RSM_MFMA3(ACC, HV, LV)                                                                                \
+      ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, __builtin_bit_cast(h8, HV), ACC, 0, 0, 0);                 \
+      ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, LV), ACC, 0, 0, 0);                 \
+      ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, HV), ACC, 0, 0, 0);
+      // operand tiles one after the other as in the 4-byte loop (A(s), B(s), A(s + 1), ...), the reads of the tile after the
+      // next in flight: 3 x 8 registers + the carry
+      uint32_t ra[2][8], rb[2][8], cf = 0u;
+      AAMD_RSM_READ_A(0, ra[0])
+      AAMD_RSM_READ_B(0, rb[0])
+      __builtin_amdgcn_sched_barrier(0);
+#if defined(AAMD_RSM_B64_INTERLEAVE)
+      // lab: both tiles of a step regrouped first, their six MFMAs interleaved (no MFMA waits for its predecessor's accumulator)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const h8 ahv = __builtin_bit_cast(h8, u32x4{ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]});
+        const h8 alv = __builtin_bit_cast(h8, u32x4{al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]});
+        const uint32_t d0 = (s == 0 || s == NS - ROT) ? cf : rb[(s + 1) & 1][7];
+        u32x4 hv, lv, hw, lw;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          hv[d] = __builtin_amdgcn_perm(ra[s & 1][2 * d + 1], ra[s & 1][2 * d], 0x05040100u);
+          lv[d] = __builtin_amdgcn_perm(ra[s & 1][2 * d + 1], ra[s & 1][2 * d], 0x07060302u);
+        }
+        hw[0] = __builtin_amdgcn_perm(rb[s & 1][0], d0, 0x05040100u);
+        lw[0] = __builtin_amdgcn_perm(rb[s & 1][0], d0, 0x07060302u);
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+          hw[d] = __builtin_amdgcn_perm(rb[s & 1][2 * d], rb[s & 1][2 * d - 1], 0x05040100u);
+          lw[d] = __builtin_amdgcn_perm(rb[s & 1][2 * d], rb[s & 1][2 * d - 1], 0x07060302u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < NS) { AAMD_RSM_READ_A(s + 1, ra[(s + 1) & 1]) AAMD_RSM_READ_B(s + 1, rb[(s + 1) & 1]) }
+        __builtin_amdgcn_sched_barrier(0);
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, __builtin_bit_cast(h8, hv), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, __builtin_bit_cast(h8, hw), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, lv), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, lw), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, hv), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, hw), accB, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const h8 ahv = __builtin_bit_cast(h8, u32x4{ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]});
+        const h8 alv = __builtin_bit_cast(h8, u32x4{al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]});
+        if (s + 1 < NS) AAMD_RSM_READ_A(s + 1, ra[(s + 1) & 1])
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 hv, lv;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          hv[d] = __builtin_amdgcn_perm(ra[s & 1][2 * d + 1], ra[s & 1][2 * d], 0x05040100u);
+          lv[d] = __builtin_amdgcn_perm(ra[s & 1][2 * d + 1], ra[s & 1][2 * d], 0x07060302u);
+        }
+        AAMD_RSM_MFMA3(accA, hv, lv)
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t d0 = (s == 0 || s == NS - ROT) ? cf : rb[(s + 1) & 1][7];     // (before the next reads land there)
+        if (s + 1 < NS) AAMD_RSM_READ_B(s + 1, rb[(s + 1) & 1])
+        __builtin_amdgcn_sched_barrier(0);
+        hv[0] = __builtin_amdgcn_perm(rb[s & 1][0], d0, 0x05040100u);
+        lv[0] = __builtin_amdgcn_perm(rb[s & 1][0], d0, 0x07060302u);
+#pragma unroll
+        for (int d = 1; d < 4; ++d) {
+          hv[d] = __builtin_amdgcn_perm(rb[s & 1][2 * d], rb[s & 1][2 * d - 1], 0x05040100u);
+          lv[d] = __builtin_amdgcn_perm(rb[s & 1][2 * d], rb[s & 1][2 * d - 1], 0x07060302u);
+        }
+        AAMD_RSM_MFMA3(accB, hv, lv)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
+#undef AAMD_RSM_MFMA3
+#undef AAMD_RSM_READ_A
+#undef AAMD_RSM_READ_B
+#undef AAMD_RSM_PAIRS
+      asm volatile("" : "+v"(accA), "+v"(accB));
+      if (!(lab & 32) || accA[0] == 12345.0f) {
+        const int64_t q0 = qc0 + 32 * grp + 2 * (ln & 15);
+        store_c_at(g, out_row, q0 + hA, pt, ln, accA[0] * inv, accA[1] * inv, accA[2] * inv, accA[3] * inv);
+        store_c_at(g, out_row, q0 + hB, pt, ln, accB[0] * inv, accB[1] * inv, accB[2] * inv, accB[3] * inv);
+      }
+      continue;
+    }
     const int qt0 = 2 * (qgi + g.qg * r), qt1 = qt0 + 1;
     const uint32_t* b0 = buf + b_base(g, qt0, tap_lo, KS, shift, lane);
     const uint32_t* b1 = buf + b_base(g, qt1, tap_lo, KS, shift, lane);
@@ -585,12 +786,22 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     }
     AAMD_RSM_STAMP(k, 1)                                 // (the MFMA loops and the stores of all rounds)
     AAMD_RSM_STAMP(k, 2)
+#if defined(AAMD_RSM_CONV_SIMD23)                         /* lab: the waves of SIMDs 0 / 1 (three MFMA loops each) leave the conversion to the others */
+    if (cid + 1 < end && (wave & 3) >= 2) convert(k + 1);
+#else
     if (cid + 1 < end) convert(k + 1);                   // (stamp 3 inside: both loaders have arrived)
+#endif
     AAMD_RSM_STAMP(k, 4)
     __syncthreads();                                     // A(cid): chunk cid is consumed, chunk cid + 1 is in LDS
     AAMD_RSM_STAMP(k, 5)
     if (threadIdx.x == 0) { mx[k % 3] = 0u; grab[k % 3] = 0u; }                // read by everybody before A(cid); next written behind A(cid + 1)
   }
+}
+// the instantiation with 8-byte operand reads where one exists (the launcher asks for it only for those KS)
+template <int KS, int LABM>
+inline auto kernel_rd64() {
+  if constexpr (b64_rot(KS) != 0) return resample_f16_kernel<KS, LABM, 1>;
+  else return resample_f16_kernel<KS, LABM, 0>;
 }
 #endif  // __HIPCC__
 

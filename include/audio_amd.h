@@ -117,7 +117,7 @@ int aamd_mel400_table_build(const aamd_mel_bands* bands, float* table_out, void*
 
 /* Kernel-selection switches for tests and A/B measurements (never needed in production): a process-wide bit mask,
  * initialised once from the environment variables AAMD_FORCE_GENERIC / AAMD_MEL400_WIDE / AAMD_ISTFT_ATOMIC /
- * AAMD_RESAMPLE_FP32 / AAMD_FFTCONV_NO_FDL / AAMD_FFTCONV_FDL.
+ * AAMD_RESAMPLE_FP32 / AAMD_FFTCONV_NO_FDL / AAMD_FFTCONV_FDL / AAMD_RESAMPLE_B32.
  * aamd_set_kernel_policy returns the previous mask; a negative argument only queries.  Results do not depend on the mask, only which kernel computes them. */
 enum {
   AAMD_POLICY_FORCE_GENERIC = 1,  /* skip the shape-specialised kernels (radix-20x20, wave FFT, MFMA paths) */
@@ -126,10 +126,12 @@ enum {
   AAMD_POLICY_RESAMPLE_FP32 = 8,  /* banded resampling on v_mfma_f32_16x16x4_f32 instead of the f16 hi/lo-split MFMAs (16 x slower pipe) */
   AAMD_POLICY_FFTCONV_NO_FDL = 16, /* overlap-save: never the frequency-domain delay-line plan */
   AAMD_POLICY_FFTCONV_FDL   = 32, /* overlap-save: the COMPLEX-block delay-line plan (2) whenever the tap count allows it (cost model ignored) */
-  AAMD_POLICY_FFTCONV_COMPLEX = 64 /* overlap-save: only the complex-block kernels of rounds 1-3 (plans 1 / 2), never the
+  AAMD_POLICY_FFTCONV_COMPLEX = 64, /* overlap-save: only the complex-block kernels of rounds 1-3 (plans 1 / 2), never the
                                       real-block kernel of round 4 (plan 3).  NOTE: ANY of the three FFTCONV bits selects the
                                       complex-block kernels for ALL tap counts -- also for <= 8192 taps, where plan 3 is plain
                                       overlap-save on real blocks and no delay line is involved */
+  AAMD_POLICY_RESAMPLE_B32 = 128  /* f16 resampler: 4-byte LDS operand reads also where the 8-byte layout of round 5 applies
+                                      (odd reduced `orig`, bands of 257 .. 448 taps: kaiser_best 44.1k -> 16k) */
 };
 int         aamd_set_kernel_policy(int flags);
 

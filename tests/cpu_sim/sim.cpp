@@ -794,13 +794,18 @@ int sim_resample_sparse(const float* wav, const float* hb, const int32_t* lo, fl
 // C: lane n + 16 (m / 4), element m % 4) applied to a_frag / b_base / store_c.
 // f16 = 1: replay of rsm::resample_f16_kernel (chunk maximum -> power-of-two scale, samples and taps split into two
 // binary16 numbers, hi*hi + hi*lo + lo*hi with the 16x16x32 fragment maps); f16 = 0: rsm::resample_mfma_kernel
+// f16 = 2: the same kernel with the 8-byte operand reads (template argument RD = 1: tiles dealt by the parity of q, odd lane
+// groups rotated through the contraction steps -- b64_rot / b64_step / b_base64 / store_c_at), including the alignment and
+// buffer-bound claims the pair reads rest on (-4 / -5 when one does not hold); -6 when the geometry is not served by it
 int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t rows, int64_t length,
                       int64_t row_stride, int orig, int new_, int width, int64_t out_len,
                       const int32_t* tap_lo, int tap_span, int vec_ok, int f16) {
+  const bool rd64 = f16 == 2;
   using namespace rsm;
   const int n_tiles = (new_ + 15) / 16;
   const int ks = pick_ks(tap_span);
   if (ks == 0) return -2;
+  if (rd64 && !b64_ok(ks, orig)) return -6;
   Geom g{};
   g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
   g.orig = orig; g.new_ = new_; g.width = width; g.taps = 2 * width + orig;
@@ -843,6 +848,41 @@ int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t r
         for (int half = 0; half < 2; ++half) {
           const int qt = 2 * qgi + half;
           float Cm[16][16] = {};
+          if (rd64) {
+            // tile `half` holds q = 32 qgi + 2 n + half; the kernel calls the 8-byte aligned one tile A (half = (lo + shift) & 1)
+            const bool aligned = half == ((lo + shift) & 1);
+            for (int sidx = 0; sidx < ks / 8; ++sidx)
+              for (int k4 = 0; k4 < 4; ++k4) {
+                const int sig = b64_step(ks, sidx, k4);
+                for (int n = 0; n < 16; ++n) {
+                  const int b0 = b_base64(g, qgi, half, lo, ks, shift, n + 16 * k4) + 8 * sig;
+                  if (((b0 & 1) == 0) != aligned) return -4;                 // every lane of a tile has the tile's parity
+                  // the pair reads: [b0, b0 + 8) for the aligned tile, [b0 - 1, b0 + 9) for the other one
+                  if (b0 - (aligned ? 0 : 1) < 0 || b0 + (aligned ? 7 : 8) >= g.buf_floats) return -5;
+                }
+              }
+            for (int sidx = 0; sidx < ks / 8; ++sidx)
+              for (int term = 0; term < 3; ++term)
+                for (int m = 0; m < 16; ++m)
+                  for (int n = 0; n < 16; ++n)
+                    for (int k4 = 0; k4 < 4; ++k4)
+                      for (int e = 0; e < 8; ++e) {
+                        const int sig = b64_step(ks, sidx, k4);
+                        uint32_t ahi, alo;
+                        a_pack16_at(g, kern, pt, lo + ks * k4 + 8 * sig + 2 * (e >> 1), m + 16 * k4, ahi, alo);
+                        const uint16_t a_h = (uint16_t)(ahi >> (16 * (e & 1))), a_l = (uint16_t)(alo >> (16 * (e & 1)));
+                        const int bidx = b_base64(g, qgi, half, lo, ks, shift, n + 16 * k4) + 8 * sig + e;
+                        const uint16_t b_h = (uint16_t)(pk[bidx] & 0xffffu), b_l = (uint16_t)(pk[bidx] >> 16);
+                        const float a = f16_value(term == 0 ? a_l : a_h), b = f16_value(term == 1 ? b_l : b_h);
+                        Cm[m][n] += a * b;
+                      }
+            for (int lane = 0; lane < 64; ++lane) {
+              const int n = lane & 15, gq = lane >> 4;
+              store_c_at(g, out + row * out_len, qc0 + 32 * qgi + 2 * n + half, pt, lane, Cm[4 * gq][n] * inv,
+                         Cm[4 * gq + 1][n] * inv, Cm[4 * gq + 2][n] * inv, Cm[4 * gq + 3][n] * inv);
+            }
+            continue;
+          }
           if (f16) {
             // lane (row m / column n, group k4): A elements 8 s + e of its group, B the 8 consecutive samples
             for (int sidx = 0; sidx < ks / 8; ++sidx)

@@ -133,10 +133,11 @@ def test_sim_resample(case):
     got2 = S.sim_resample(x2, k.numpy(), o // g, n // g, width, qt=3, use_lds=0).reshape(exp.shape)
     assert peak_rel_err(got2, exp) <= 1e-5
     # matrix-core kernel (banded taps, permuted contraction order, double-buffered chunks)
-    for vec_ok, f16 in ((1, 0), (0, 0), (1, 1), (0, 1)):      # f16: the hi / lo-split binary16 MFMA variant (the default)
+    # f16 = 1: the hi / lo-split binary16 MFMA variant (the default); 2: its 8-byte operand-read layout (odd orig, KS >= 80)
+    for vec_ok, f16 in ((1, 0), (0, 0), (1, 1), (0, 1), (1, 2), (0, 2)):
         rc, got3 = S.sim_resample_mfma(x2, k.numpy(), o // g, n // g, width, vec_ok, f16)
-        if rc == -2:
-            continue          # band wider than 448 taps: the scalar kernel serves it
+        if rc == -2 or (f16 == 2 and rc == -6):
+            continue          # band wider than 448 taps: the scalar kernel serves it; -6: not a geometry of the 8-byte layout
         assert rc == 0
         assert not np.isnan(got3).any()          # every output written exactly by some lane
         assert peak_rel_err(got3.reshape(exp.shape), exp) <= 1e-5
@@ -150,11 +151,13 @@ def test_sim_resample_click_and_minus_100_db_tone_in_one_chunk():
               beta=14.769656459379492)
     x = click_and_quiet_tone()
     k, width = _host.sinc_resample_kernel(44100, 16000, math.gcd(44100, 16000), **kw)
-    rc16, got = S.sim_resample_mfma(x, k.numpy(), 441, 160, width, 1, 1)
     rc32, ref32 = S.sim_resample_mfma(x, k.numpy(), 441, 160, width, 1, 0)
-    assert rc16 == 0 and rc32 == 0
     exp = O.resample(x.astype(np.float64), 44100, 16000, **kw)
-    check_click_and_quiet_tone(got, ref32, exp)
+    for layout in (2, 1):       # 2: the 8-byte operand-read layout cfg3 runs (tiles by parity of q, rotated steps); 1: the 4-byte one
+        rc16, got = S.sim_resample_mfma(x, k.numpy(), 441, 160, width, 1, layout)
+        assert rc16 == 0 and rc32 == 0
+        assert not np.isnan(got).any()
+        check_click_and_quiet_tone(got, ref32, exp)
 
 
 @pytest.mark.parametrize("case", ref_runs().select("lfilter"), ids=lambda c: f"{c['id']}-{c.get('tag')}")
