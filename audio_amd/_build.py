@@ -74,7 +74,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + _tmp_suffix()]
+    # AAMD_EXTRA_HIPCC_FLAGS: experiment builds only (e.g. -DAAMD_M400_POOLS=1 for tools/bench_pool_ab.py); never set by the product
+    extra = os.environ.get("AAMD_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + _tmp_suffix()]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

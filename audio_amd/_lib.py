@@ -156,7 +156,7 @@ def lib():
 
 POLICY_FORCE_GENERIC, POLICY_MEL400_WIDE, POLICY_ISTFT_ATOMIC, POLICY_RESAMPLE_FP32 = 1, 2, 4, 8
 POLICY_FFTCONV_NO_FDL, POLICY_FFTCONV_FDL, POLICY_FFTCONV_COMPLEX = 16, 32, 64
-POLICY_RESAMPLE_B32 = 128
+POLICY_RESAMPLE_B32, POLICY_MEL400_NO_POOL = 128, 256
 
 
 class kernel_policy:

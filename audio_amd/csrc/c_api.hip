@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <utility>
 #include <string>
 
 #include "../../include/audio_amd.h"
@@ -73,6 +75,7 @@ int policy() {
     if (std::getenv("AAMD_FFTCONV_NO_FDL") != nullptr) p |= AAMD_POLICY_FFTCONV_NO_FDL;
     if (std::getenv("AAMD_FFTCONV_FDL") != nullptr) p |= AAMD_POLICY_FFTCONV_FDL;
     if (std::getenv("AAMD_RESAMPLE_B32") != nullptr) p |= AAMD_POLICY_RESAMPLE_B32;
+    if (std::getenv("AAMD_MEL400_NO_POOL") != nullptr) p |= AAMD_POLICY_MEL400_NO_POOL;
     int expected = -1;
     g_policy.compare_exchange_strong(expected, p);
     p = g_policy.load(std::memory_order_relaxed);
@@ -267,6 +270,35 @@ int launch_fft400_h(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, co
   return launch_fft400_nr<EPI, H, TIn, m400::kMelMaxRounds>(g, mb, wav, window, twiddle, out, epi, s);
 }
 
+// (Only in builds with -DAAMD_M400_POOLS=1: the product is built without the pools, DESIGN 4.1 "Round 5".)
+// Ticket counters of the n_fft = 400 kernel's tail pools (csrc/melspec400.h, pool_tile): one zeroed 64 KB block per (device,
+// stream), allocated on the stream's first eligible launch and never freed (at most 256 of them, 16 MB).  The kernel leaves
+// every counter at zero, and launches on one stream run one after the other, so the block needs no memset between launches.
+// Under stream capture nothing is handed out (no allocation inside a capture, and a captured launch may be replayed on
+// another stream beside eager launches of this one): such launches run their static tile runs, as every launch of the
+// product does.  In such a build this is the library's only mutable state besides the thread-local error string.
+#if AAMD_M400_POOLS
+unsigned* mel400_pool_block(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (st != hipStreamCaptureStatusNone) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, unsigned*> blocks;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = blocks.find({dev, s});
+  if (it != blocks.end()) return it->second;
+  if (blocks.size() >= 256) return nullptr;
+  constexpr size_t kBytes = 64 * 1024;
+  void* p = nullptr;
+  if (hipMalloc(&p, kBytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemsetAsync(p, 0, kBytes, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }   // ordered in front of the launch
+  blocks[{dev, s}] = static_cast<unsigned*>(p);
+  return static_cast<unsigned*>(p);
+}
+#endif
+
 template <int EPI, int H, typename TIn, int NR, int SIG>
 int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, const float* window,
                      const float* twiddle, float* out, const m400::Epi400& epi_in, hipStream_t s) {
@@ -297,6 +329,22 @@ int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, c
   if (blocks >= 8) blocks -= blocks % 8;  // XCD remap wants a multiple of 8
   if (blocks < 1) blocks = 1;
   const int tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
+  // tail pools: the last P tiles of every workgroup's run are shared with the workgroups of the other XCDs (melspec400.h, pool_tile)
+  epi.pool = nullptr;
+  epi.pool_p = 0;
+#if AAMD_M400_POOLS
+  {
+    static const int lab_p = [] { const char* e = std::getenv("AAMD_MEL400_POOL_P"); return e ? std::atoi(e) : -1; }();   // tools only
+    int P = lab_p >= 0 ? lab_p : m400::pool_share(tiles_per_block);
+    if (P > tiles_per_block) P = tiles_per_block;
+    const bool fixup_pass = (EPI == m400::EPI400_MFCC) && epi.fixup != 0;
+    if (P > 0 && !fixup_pass && epi.lab == 0 && (policy() & AAMD_POLICY_MEL400_NO_POOL) == 0 &&
+        (size_t)m400::pool_count((int)blocks) * m400::kPoolStride * sizeof(unsigned) <= 64 * 1024) {
+      epi.pool = mel400_pool_block(s);
+      epi.pool_p = epi.pool ? P : 0;
+    }
+  }
+#endif
   // 16-B paths: LDS-DMA staging of the waveform, dwordx4 stores of the output rows
   const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (g.row_stride % (16 / (int)sizeof(TIn)) == 0);
   // mel rows leave as 4-byte stores straight from the accumulators: the LDS pipe is this kernel's
@@ -356,7 +404,7 @@ int aamd_set_kernel_policy(int flags) {
   const int prev = policy();
   if (flags >= 0) g_policy.store(flags & (AAMD_POLICY_FORCE_GENERIC | AAMD_POLICY_MEL400_WIDE | AAMD_POLICY_ISTFT_ATOMIC |
                                           AAMD_POLICY_RESAMPLE_FP32 | AAMD_POLICY_FFTCONV_NO_FDL | AAMD_POLICY_FFTCONV_FDL |
-                                          AAMD_POLICY_FFTCONV_COMPLEX | AAMD_POLICY_RESAMPLE_B32));
+                                          AAMD_POLICY_FFTCONV_COMPLEX | AAMD_POLICY_RESAMPLE_B32 | AAMD_POLICY_MEL400_NO_POOL));
   return prev;
 }
 

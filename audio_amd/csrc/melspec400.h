@@ -170,8 +170,44 @@ struct Epi400 {
   int frag_in_lds;                  // MFCC: the workgroup's LDS has room for the fragment table (hop 100 / 160; not hop 200)
   int fixup;                        // MFCC: 0 = first pass, 1 = fix-up pass
   int lab;                          // MFCC (tools only): 1 no fragment loads, 2 no MFMA, 4 no tile minimum, 8 no stores
+  unsigned* pool;                   // tail pools (round 5; null = static runs only): one ticket counter per pool, kPoolStride dwords apart
+  int pool_p;                       // tiles every workgroup leaves in its pool (0 < pool_p <= tiles_per_block when pool != null)
 };
 constexpr int kSpecBins = 201;
+
+// ---- tail pools (round 5) ----------------------------------------------------------------------------------------------
+// A workgroup owns a contiguous run of tiles_per_block tiles and its waves claim them from an LDS queue; the launch ends when
+// the SLOWEST workgroup has finished its run (round 3: workgroups finish 63.9 .. 71.4 us, the XCDs differ by up to 7 % and
+// which one is slow changes from box to box).  So every workgroup leaves the last P tiles of its run in a POOL that it shares
+// with the workgroups of the other XCDs (pool p = workgroups p, p + NP, p + 2 NP, ...: with the XCD-aware numbering one per
+// XCD): a wave that finds its workgroup's queue empty takes tickets from the pool's counter in memory (one device-scope
+// atomic per tile, requested a phase ahead) until a ticket lies past the pool's tiles.  Every wave of every member ends with
+// exactly ONE such ticket, so a launch draws exactly members * (P + waves) tickets from a pool: the wave that draws the last one
+// puts the counter back to zero for the next launch on the stream (no memset, no second counter; the host hands out one
+// counter block per stream).  Which wave computes a tile never changes the tile's result: outputs are bit-identical.
+#ifndef AAMD_M400_POOLS
+#define AAMD_M400_POOLS 0      /* built, verified bit-identical, measured - 0.8 % on the headline batch (profiles/r05_i_mel400_pool_sweep.txt): the
+                                  tile loop's part is compiled out of the product; -DAAMD_M400_POOLS=1 builds it */
+#endif
+constexpr int kPoolStride = 64;                               // dwords between two pools' counters (256 B)
+constexpr unsigned kNoTile = 0xffffffffu;
+AAMD_HD int pool_count(int nb) { return nb >= 8 ? nb / 8 : 1; }                       // NP
+AAMD_HD int pool_members(int nb, int np, int p) { return p < nb ? (nb - p + np - 1) / np : 0; }
+// tiles a workgroup hands to its pool; 0 = no pools for this launch
+// (measured on the cfg2 / Spectrogram / cfg4 batches, profiles/r05_i_mel400_pool_sweep.txt: 2, 4 and 8 tiles per workgroup all
+// give - 0.5 .. - 1.3 us per launch, 24 nothing, 40 costs 0.8 us: the tickets are device-scope atomics)
+AAMD_HD int pool_share(int tiles_per_block) { const int p = tiles_per_block / 20; return tiles_per_block < 48 ? 0 : p > 8 ? 8 : p; }
+// ticket -> global tile; kNoTile with exhausted = true behind the pool's last tile, kNoTile with exhausted = false for a slot
+// of the last workgroup's run that lies past the end of the batch (the caller draws again)
+AAMD_HD unsigned pool_tile(int np, int P, int tiles_per_block, unsigned n_tiles, int p, int members, unsigned ticket,
+                           bool& exhausted) {
+  exhausted = ticket >= (unsigned)(members * P);
+  if (exhausted) return kNoTile;
+  const unsigned m = ticket / (unsigned)P, off = ticket - m * (unsigned)P;
+  const unsigned long long t = (unsigned long long)(m * (unsigned)np + (unsigned)p) * (unsigned)tiles_per_block +
+                               (unsigned)(tiles_per_block - P) + off;
+  return t < n_tiles ? (unsigned)t : kNoTile;
+}
 static_assert(kFramesPerWave * kSpecBins + 3 <= kSOff && 3 * 2 * kSpecBins + 3 <= kSOff, "SPEC rows must fit below the staging area");
 
 // column held by the lane at position pi of a 20-lane group (pass 2), and its inverse:
@@ -1182,6 +1218,44 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     if (lane == 0) v = __hip_atomic_fetch_add(queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return (unsigned)__builtin_amdgcn_readfirstlane(v);
   };
+#if AAMD_M400_POOLS
+  // tail pools (see pool_tile): with a pool, blk_count shrinks to the workgroup's OWN tiles; every later queue index is a ticket of
+  // the pool.  Everything else about the pool is formed where a ticket is drawn (once or twice per wave and launch) from an opaque
+  // copy of the workgroup number: held across the tile loop, those ten scalars cost the MFCC instantiation 45 more spilled SGPRs.
+#define AAMD_M400_POOLED (AAMD_M400_POOLS && (LAB == 0) && epi.pool != nullptr && !(EPI == EPI400_MFCC && epi.fixup != 0))   /* (not held in a register pair) */
+  if (AAMD_M400_POOLED && blk_count > (unsigned)(tiles_per_block - epi.pool_p)) blk_count = (unsigned)(tiles_per_block - epi.pool_p);
+  unsigned pool_ticket = 0;      // lane 0: the ticket in flight
+  auto pool_request = [&]() {
+    int lbo = (int)(blk_first / (unsigned)tiles_per_block);    // = lb (not kept across the loop)
+    asm volatile("" : "+s"(lbo));
+    unsigned* const ctr = epi.pool + (lbo % pool_count(nb)) * kPoolStride;
+    if (lane == 0) pool_ticket = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // the ticket requested earlier -> queue index of its tile (global tile - blk_first, modulo 2^32) and whether there is one
+  auto pool_take = [&]() {
+    int lbo = (int)(blk_first / (unsigned)tiles_per_block);
+    asm volatile("" : "+s"(lbo));
+    const int np = pool_count(nb), pid = lbo % np, mem = pool_members(nb, np, pid);
+    for (;;) {
+      const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)pool_ticket);
+      if (v + 1u == (unsigned)(mem * (epi.pool_p + kWavesPerBlock)) && lane == 0)      // the launch's last ticket of this pool
+        __hip_atomic_store(epi.pool + pid * kPoolStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool exhausted;
+      const unsigned t = pool_tile(np, epi.pool_p, tiles_per_block, (unsigned)n_tiles, pid, mem, v, exhausted);
+      if (t != kNoTile) return t - blk_first;
+      if (exhausted) return 0x80000000u;          // (= kBadIdx below)
+      pool_request();            // a slot past the end of the batch (last workgroup's run only): draw again
+    }
+  };
+  // queue indices: idx < blk_count = the workgroup's own tiles; a pool tile t travels as t - blk_first (modulo 2^32); kBadIdx = no
+  // tile, kPendIdx = a pool ticket is to be drawn -- neither can be a difference of two tile numbers (n_tiles < 2^31)
+  constexpr unsigned kBadIdx = 0x80000000u, kPendIdx = 0x80000001u;
+#define AAMD_M400_IDX_OK(I) ((((I) ^ 0x80000000u)) > 1u)
+#define AAMD_M400_LOCAL(I) ((I) < blk_count ? (I) : kBadIdx)
+#else
+#define AAMD_M400_IDX_OK(I) ((I) < blk_count)
+#define AAMD_M400_LOCAL(I) (I)
+#endif
   // lab bit 17: chip-wide queue.  A wave owns a chunk of kLabChunk consecutive tiles; the ticket of its NEXT chunk is
   // requested when a chunk starts and read when it ends (the atomic's round trip hides behind kLabChunk tiles).
   constexpr unsigned kLabChunk = 8;
@@ -1213,7 +1287,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     const unsigned row = t / (unsigned)tiles_per_row;
     ti.row = row;
     ti.t0 = (int64_t)(t - row * (unsigned)tiles_per_row) * kFramesPerWave;
-    ti.staged = idx < blk_count && in_aligned && (ti.t0 * kHop - kPad >= 0) &&
+    ti.staged = AAMD_M400_IDX_OK(idx) && in_aligned && (ti.t0 * kHop - kPad >= 0) &&
                 ((ti.t0 + kFramesPerWave - 1) * kHop + (kN - kPad) <= length) &&
                 (ti.t0 + kFramesPerWave <= n_frames);
     return ti;
@@ -1249,7 +1323,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       for (unsigned i = 0; i < n_mine + D; ++i) {
         const unsigned t = i * (unsigned)kNio + (unsigned)(wave - (kWavesPerBlock - kNio));
         if (i < n_mine) {
-          const TileInfo ti = tile_info(t);
+          const TileInfo ti = tile_info(AAMD_M400_LOCAL(t));
           const unsigned dst = (unsigned)(uintptr_t)(smem400 + (t % (unsigned)kWavesPerBlock) * HC::lds_dwords + kSOff);
           if (ti.staged) {
             const TIn* src = wav + (ti.row / InTraits<TIn>::chans) * row_stride + (ti.t0 * kHop - kPad);
@@ -1263,7 +1337,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
           } else {
             asm volatile("s_waitcnt vmcnt(56)" ::: "memory");   // 7 D younger operations: the pieces of the tile D back have landed
             const unsigned told = t - D * (unsigned)kNio;
-            const TileInfo to = tile_info(told);
+            const TileInfo to = tile_info(AAMD_M400_LOCAL(told));
             const float* stg = smem400 + (told % (unsigned)kWavesPerBlock) * HC::lds_dwords;
             store_wide(lane, mt, stg, out + to.row * (int64_t)n_frames * (int64_t)mb.n_mels, to.t0, n_frames);
           }
@@ -1273,6 +1347,13 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     blk_count = 0;                                         // (this wave's copy: it runs no tile)
   }
   unsigned cur_idx = (LAB & 131072) ? g_base : (unsigned)wave;
+#if AAMD_M400_POOLS
+  if (cur_idx >= blk_count) cur_idx = kBadIdx;
+  if (AAMD_M400_POOLED && cur_idx == kBadIdx) {       // fewer own tiles than waves (the last workgroups of a launch): straight to the pool
+    pool_request();
+    cur_idx = pool_take();
+  }
+#endif
   TileInfo cur = tile_info(cur_idx);
   if (LAB & 128) {   // lab: stagger the waves of a SIMD by thirds of a tile time.  Interleaved A/B runs
     // (tools/ubench/mel400_lab) put it within noise of the lock-step start (74-78 us either way): off.
@@ -1311,12 +1392,17 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     ph_acc[K] += now_ - ph_t;                               \
     ph_t = now_;                                            \
   }
-  while (cur_idx < blk_count) {
+  while (AAMD_M400_IDX_OK(cur_idx)) {
     if (LAB & 8388608) { ph_t = (long long)clock64(); ++ph_tiles; }
     // claim the tile after this one now: it is prefetched while this one is in its second half
     // (issuing the LDS atomic here and reading its ticket behind the column reads' wait moved 70 cycles from phase A to
     // phase B and nothing else: profiles/r03_zz_mel400_phase_census.txt)
+#if AAMD_M400_POOLS
+    unsigned nxt_idx = (LAB & 131072) ? g_next() : claim();
+    if (nxt_idx >= blk_count) nxt_idx = AAMD_M400_POOLED ? kPendIdx : kBadIdx;   // (the queue is empty: with pools, a ticket is drawn below)
+#else
     const unsigned nxt_idx = (LAB & 131072) ? g_next() : claim();
+#endif
     TileInfo nxt = tile_info(nxt_idx);
     float fix_cut = -INFINITY;
     if (fix) {
@@ -1342,6 +1428,10 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       gather_global<H, TIn>(c, wav + (cur.row / InTraits<TIn>::chans) * row_stride, length, cur.t0, n_frames, X,
                             (int)(cur.row % InTraits<TIn>::chans));
     }
+#if AAMD_M400_POOLS
+    // (behind stage_wait's vmcnt(0): the atomic flies during phase A and the column reads and is read in front of the next DMA)
+    if (nxt_idx == kPendIdx) pool_request();
+#endif
     phase_a<H, kWinRegs, kTwRegBatches>(c, X, lds, winr, twr);
     if ((LAB & 32768) && nxt.staged) gload(nxt);        // X is dead: the next tile's samples fly during phases B and C
     wave_lds_fence();
@@ -1352,6 +1442,12 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       // every transposition row has been read: the staging area (it aliases rows) is free again
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       AAMD_M400_STAMP(1)   // column reads
+#if AAMD_M400_POOLS
+      if (nxt_idx == kPendIdx) {
+        nxt_idx = pool_take();
+        nxt = tile_info(nxt_idx);
+      }
+#endif
       if (nxt.staged && !(LAB & 8) && !fix) stage_issue(nxt);
     }
     if (LAB & 16) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }

@@ -117,7 +117,7 @@ int aamd_mel400_table_build(const aamd_mel_bands* bands, float* table_out, void*
 
 /* Kernel-selection switches for tests and A/B measurements (never needed in production): a process-wide bit mask,
  * initialised once from the environment variables AAMD_FORCE_GENERIC / AAMD_MEL400_WIDE / AAMD_ISTFT_ATOMIC /
- * AAMD_RESAMPLE_FP32 / AAMD_FFTCONV_NO_FDL / AAMD_FFTCONV_FDL / AAMD_RESAMPLE_B32.
+ * AAMD_RESAMPLE_FP32 / AAMD_FFTCONV_NO_FDL / AAMD_FFTCONV_FDL / AAMD_RESAMPLE_B32 / AAMD_MEL400_NO_POOL.
  * aamd_set_kernel_policy returns the previous mask; a negative argument only queries.  Results do not depend on the mask, only which kernel computes them. */
 enum {
   AAMD_POLICY_FORCE_GENERIC = 1,  /* skip the shape-specialised kernels (radix-20x20, wave FFT, MFMA paths) */
@@ -130,8 +130,11 @@ enum {
                                       real-block kernel of round 4 (plan 3).  NOTE: ANY of the three FFTCONV bits selects the
                                       complex-block kernels for ALL tap counts -- also for <= 8192 taps, where plan 3 is plain
                                       overlap-save on real blocks and no delay line is involved */
-  AAMD_POLICY_RESAMPLE_B32 = 128  /* f16 resampler: 4-byte LDS operand reads also where the 8-byte layout of round 5 applies
+  AAMD_POLICY_RESAMPLE_B32 = 128, /* f16 resampler: 4-byte LDS operand reads also where the 8-byte layout of round 5 applies
                                       (odd reduced `orig`, bands of 257 .. 448 taps: kaiser_best 44.1k -> 16k) */
+  AAMD_POLICY_MEL400_NO_POOL = 256 /* n_fft = 400 kernels, builds with -DAAMD_M400_POOLS=1 only (round 5 experiment: the last tiles of
+                                      every workgroup's run shared between the XCDs; bit-identical results, - 0.8 %, compiled out
+                                      of the product): static tile runs per workgroup, as the product always does */
 };
 int         aamd_set_kernel_policy(int flags);
 

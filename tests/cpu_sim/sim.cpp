@@ -1110,6 +1110,97 @@ int sim_lfilter(const float* x, const float* a, const float* b, float* y, int64_
   return -1;
 }
 
+// The tile hand-out of the n_fft = 400 kernel with tail pools (m400::pool_tile and the claim logic of melspec400_kernel):
+// nb workgroups of `waves` waves, each wave a state machine that is advanced one atomic operation at a time in a seeded random
+// order -- LDS queue claim, pool ticket request, pool ticket read (with the reset by the launch's last ticket).  `launches`
+// launches in a row on the same counters.  visits[t] counts how often tile t was run.  Returns 0, or: -1 a counter was not
+// back at zero after a launch, -2 a wave drew a ticket after the reset, -3 the launch did not terminate.
+// P < 0: the launcher's own share (pool_share); P = 0: no pools.  xcd_remap as in the kernel (lb from blockIdx).
+int sim_mel400_pool(int nb, int tiles_per_block, int64_t n_tiles, int P, int waves, int launches, uint32_t seed, int32_t* visits) {
+  using namespace m400;
+  if (P < 0) P = pool_share(tiles_per_block);
+  if (P > tiles_per_block) P = tiles_per_block;
+  const bool pooled = P > 0;
+  const int np = pool_count(nb);
+  std::vector<uint32_t> ctr((size_t)np, 0u);
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
+  struct Wave { int wg, state; unsigned cur_idx, nxt_idx, ticket; bool cur_ok, nxt_ok, nxt_pool, first; };
+  for (int l = 0; l < launches; ++l) {
+    std::vector<unsigned> queue((size_t)nb, (unsigned)waves);
+    std::vector<Wave> ws;
+    for (int b = 0; b < nb; ++b)
+      for (int w = 0; w < waves; ++w) ws.push_back(Wave{b, 0, (unsigned)w, 0u, 0u, false, false, false, true});
+    std::vector<char> reset_done((size_t)np, 0);
+    size_t alive = ws.size();
+    for (int64_t step = 0; alive > 0; ++step) {
+      if (step > (int64_t)40 * (n_tiles + (int64_t)nb * waves) + 1000) return -3;
+      Wave& w = ws[rnd() % ws.size()];
+      if (w.state == 9) continue;
+      const int lb = ((nb & 7) == 0) ? (w.wg & 7) * (nb >> 3) + (w.wg >> 3) : w.wg;
+      const unsigned blk_first = (unsigned)lb * (unsigned)tiles_per_block;
+      unsigned blk_count = 0;
+      if (blk_first < (unsigned)n_tiles) {
+        blk_count = (unsigned)n_tiles - blk_first;
+        if (blk_count > (unsigned)tiles_per_block) blk_count = (unsigned)tiles_per_block;
+      }
+      unsigned n_static = blk_count;
+      if (pooled && n_static > (unsigned)(tiles_per_block - P)) n_static = (unsigned)(tiles_per_block - P);
+      const int pid = lb % np, mem = pool_members(nb, np, pid);
+      auto request = [&]() {
+        if (reset_done[pid]) return false;                      // a ticket drawn behind the reset: the protocol is broken
+        w.ticket = ctr[pid]++;
+        return true;
+      };
+      auto take = [&](unsigned& idx, bool& ok, bool& again) {   // pool_take of the kernel, one draw
+        again = false;
+        if (w.ticket + 1u == (unsigned)(mem * (P + waves))) { ctr[pid] = 0u; reset_done[pid] = 1; }
+        bool ex;
+        const unsigned t = pool_tile(np, P, tiles_per_block, (unsigned)n_tiles, pid, mem, w.ticket, ex);
+        ok = t != kNoTile;
+        idx = t - blk_first;
+        if (!ok && !ex) again = true;
+      };
+      switch (w.state) {
+        case 0:      // before the tile loop
+          w.cur_ok = w.cur_idx < (pooled ? n_static : blk_count);
+          if (pooled && !w.cur_ok) { if (!request()) return -2; w.state = 1; } else w.state = 2;
+          break;
+        case 1: {    // pool_take for the first tile
+          bool again;
+          take(w.cur_idx, w.cur_ok, again);
+          if (again) { if (!request()) return -2; } else w.state = 2;
+          break;
+        }
+        case 2:      // loop head: claim the next tile from the LDS queue
+          if (!w.cur_ok) { w.state = 9; --alive; break; }
+          w.nxt_idx = queue[w.wg]++;
+          w.nxt_ok = w.nxt_idx < (pooled ? n_static : blk_count);
+          w.nxt_pool = pooled && !w.nxt_ok;
+          w.state = w.nxt_pool ? 3 : 5;
+          break;
+        case 3:      // pool_request behind the gather
+          if (!request()) return -2;
+          w.state = 4;
+          break;
+        case 4: {    // pool_take in front of the next tile's DMA
+          bool again;
+          take(w.nxt_idx, w.nxt_ok, again);
+          if (again) { if (!request()) return -2; } else w.state = 5;
+          break;
+        }
+        case 5:      // the rest of the tile: it is computed and stored
+          ++visits[blk_first + w.cur_idx];
+          w.cur_idx = w.nxt_idx; w.cur_ok = w.nxt_ok;
+          w.state = 2;
+          break;
+      }
+    }
+    for (int p_ = 0; p_ < np; ++p_)
+      if (ctr[p_] != 0u) return -1;
+  }
+  return 0;
+}
+
 // The launcher's chunk geometry of the banded resampler for one set of phase tiles (rsm::plan_chunk), for property tests:
 // out = {qg, rounds, n_loaders, buf_floats, waves, chunk_q}; returns 0 when even one q-group does not fit.
 int sim_rsm_plan(int orig, int new_, int width, int tap_span, int max_lo, int64_t nq, int f16, int64_t lds_cap, int* out) {

@@ -871,3 +871,28 @@ def test_sim_lfilter_wave_slowly_decaying_poles_across_waves(r, theta):
         rc, got = S.sim_lfilter_wave(x, a[None, None], b[None, None], False, waves)
         ref = O.lfilter(x[0, 0].astype(np.float64), a, b, False)
         assert rc == 0 and peak_rel_err(got[0, 0], ref) <= 4e-5, (r, theta, waves)
+
+
+@pytest.mark.parametrize("nb,tpb,n_tiles,P", [
+    (256, 167, 256 * 167, -1),          # the headline launch: 42 752 tiles, 13 per workgroup pooled
+    (256, 167, 256 * 167 - 91, -1),     # a last run cut short by the end of the batch (slots past the end are drawn and skipped)
+    (256, 167, 256 * 166 + 5, 16),      # the last workgroup owns 5 tiles: fewer than its waves, fewer than the pool share
+    (256, 334, 512 * 167, -1),          # cfg4
+    (248, 60, 248 * 60 - 7, 5),         # a grid that is a multiple of 8 but not of the CU count
+    (7, 100, 650, 8),                   # fewer than 8 workgroups: one pool, no XCD numbering
+    (20, 64, 1270, 6),                  # not a multiple of 8: no XCD numbering, two pools
+    (256, 40, 256 * 40, -1),            # short runs: the launcher's share is 0, static runs only
+    (64, 48, 64 * 48, 48),              # everything pooled
+])
+def test_mel400_tail_pools_hand_out_every_tile_once(nb, tpb, n_tiles, P):
+    """The tile hand-out of the n_fft = 400 kernel with tail pools (csrc/melspec400.h, pool_tile): under randomly interleaved
+    waves every tile is run exactly once, every wave ends with exactly one ticket behind its pool's last tile (so that the
+    launch's last ticket can put the counter back to zero), and three launches in a row on the same counters behave alike."""
+    import ctypes as C
+    f = S.sim().sim_mel400_pool
+    f.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p]
+    for seed in (1, 2, 3):
+        visits = np.zeros(nb * tpb + 64, dtype=np.int32)
+        rc = f(nb, tpb, n_tiles, P, 12, 3, seed, visits.ctypes.data_as(C.c_void_p))
+        assert rc == 0, rc
+        assert (visits[:n_tiles] == 3).all() and (visits[n_tiles:] == 0).all()

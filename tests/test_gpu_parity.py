@@ -1444,3 +1444,46 @@ def test_rnnt_features_from_interleaved_pcm(hop):
     assert torch.equal(got3, want3)
     with pytest.raises(ValueError):
         fe.features(torch.zeros(2, 4800, 2).cuda(), channels_first=False)          # float input is not PCM
+
+
+def test_mel400_tail_pools_are_bit_identical_to_static_runs_and_reset_themselves():
+    """Round 5 experiment (compiled in with -DAAMD_M400_POOLS=1 only; in the product build both arms run the static hand-out and the
+    test checks repeated launches on two streams): the last tiles of every workgroup's run of the n_fft = 400 kernel are shared between
+    the XCDs through ticket counters in memory (csrc/melspec400.h, pool_tile).  Which wave computes a tile must not matter: every epilogue (mel, dB,
+    spectrogram, MFCC pass 0 + fix-up) gives the bits of the static hand-out (AAMD_POLICY_MEL400_NO_POOL), repeated launches
+    find their counters back at zero (the launch's last ticket resets them), two streams use separate counter blocks, and a
+    batch whose last run is cut short draws the slots past its end without running them."""
+    import audio_amd.transforms as T
+    from audio_amd import _lib
+    g = torch.Generator().manual_seed(77)
+    mods = [T.MelSpectrogram(16000, n_fft=400, hop_length=160, n_mels=80).cuda(),
+            T.MelSpectrogram(16000, n_fft=400, hop_length=200, n_mels=128).cuda(),
+            T.Spectrogram(n_fft=400, hop_length=160).cuda(),
+            torch.nn.Sequential(T.MelSpectrogram(16000, n_fft=400, hop_length=160, n_mels=80), T.AmplitudeToDB(top_db=80.0)).cuda(),
+            T.MFCC(16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).cuda()]
+    # 256 x 10 s: 167 tiles per workgroup, 13 of them pooled; 301 x 7.77 s: the last run is cut short; 40 x 3 s: short runs, no pools
+    for rows, n in ((256, 160000), (301, 124321), (40, 48000)):
+        x = (0.5 * torch.randn(rows, n, generator=g)).clamp_(-1, 1).cuda()
+        x[rows // 3, n // 2:] = 0.0                                    # (MFCC: tiles under the cut-off, redone by the fix-up launch)
+        for m in mods:
+            with torch.no_grad():
+                with _lib.kernel_policy(_lib.POLICY_MEL400_NO_POOL):
+                    ref = m(x)
+                for _ in range(4):                                     # the fourth launch must find the counters the first one left
+                    got = m(x)
+                    assert torch.equal(got, ref), (type(m).__name__, rows, n)
+    # two streams at once: one counter block per stream
+    m = mods[0]
+    x = (0.5 * torch.randn(256, 160000, generator=g)).clamp_(-1, 1).cuda()
+    with torch.no_grad():
+        with _lib.kernel_policy(_lib.POLICY_MEL400_NO_POOL):
+            ref = m(x)
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for _ in range(6):
+            for st in (s1, s2):
+                with torch.cuda.stream(st):
+                    outs.append(m(x))
+        torch.cuda.synchronize()
+        assert all(torch.equal(o, ref) for o in outs)

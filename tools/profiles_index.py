@@ -13,6 +13,8 @@ DESC = [
     (r'r0\d_.*pmc_.*', 'rocprofv3 --pmc counter summaries (separate passes; FETCH x2 per the guide)', 'traffic = 1.002 x algorithmic bytes; VALU / LDS instruction counts, LDS-active and conflict cycles (DESIGN 4.x)'),
     (r'r0\d_.*gpu_pytest.*|r0\d_.*pytest_gpu.*', '`pytest -m gpu` log on an MI355X (full suite unless the name says otherwise; _reverse / _serialize: reversed order, AMD_SERIALIZE_KERNEL=3)', 'parity green on the GPU at that commit'),
     (r'r0\d_.*smoke.*', '__graft_entry__.smoke() log', 'smoke, stage by stage'),
+    (r'r0\d_.*mel400_pool.*', 'tools/bench_pool_ab.py: tail pools of the n_fft = 400 kernel vs static tile runs, through the product API (a -DAAMD_M400_POOLS=1 build)', 'DESIGN 4.1 round 5: built, bit-identical, - 0.8 %, compiled out'),
+    (r'r0\d_.*rsm_lab.*', 'tools/rsm_lab.py: A/B of resampler variants (csrc/resample_mfma.h compiled alone per -D variant)', 'DESIGN 4.3 round 5: 8-byte operand reads, priorities, conversion placement'),
     (r'r0\d_.*mel400.*', 'tools/mel400_lab.py A/B runs of headline-kernel variants (interleaved, rotating buffers)', 'DESIGN 4.1 / HISTORY: what moved the headline kernel and what did not'),
     (r'r0\d_.*lfilter.*', 'lfilter kernels: ISA notes, lab ablations, shape sweeps, general-order scans', 'DESIGN 4.4'),
     (r'r0\d_.*mfcc.*', 'MFCC paths: one-kernel vs two-kernel timings, epilogue ablation', 'DESIGN 4.2'),
