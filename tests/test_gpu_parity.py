@@ -871,6 +871,43 @@ def test_resample_binary16_split_kernel_against_fp32_kernel_and_oracle(gain):
     assert float(got[2, 1, 7400:].abs().max()) == 0.0                             # silence stays silence
 
 
+def test_resample_8_byte_operand_layout_against_the_4_byte_one():
+    """Round 5: for odd reduced `orig` and bands of 257 .. 448 taps (cfg3: 441 : 160, kaiser_best) the binary16-split resampler
+    deals the output groups to its two MFMA tiles by parity and walks the contraction steps rotated in the odd lane groups, so
+    that its LDS operand reads are conflict-free ds_read_b64 (csrc/resample_mfma.h, b64_rot).  Same products, another summation
+    order: against the 4-byte layout (AAMD_POLICY_RESAMPLE_B32) <= 2e-6 of the peak, both <= 1e-5 of the float64 oracle; ragged
+    lengths, unaligned views (the 16-byte phase of a chunk changes which tile is the aligned one), a row that falls silent; and
+    a rate pair outside the layout (even orig) is bit-identical under the switch."""
+    import audio_amd.transforms as T
+    from audio_amd import _lib
+    from oracle import dsp_oracle as O
+    kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=64, rolloff=0.9475937167399596,
+              beta=14.769656459379492)
+    r = T.Resample(44100, 16000, **kw).cuda()
+    g = torch.Generator().manual_seed(29)
+    base = (0.5 * torch.randn(5, 90017, generator=g)).clamp_(-1, 1)
+    base[3, 40000:] = 0.0
+    base = base.cuda()
+    for view in (base, base[:, 1:], base[:, 2:70001], base[1:, 3:], base[:, :14113], base[:, :500]):
+        with torch.no_grad():
+            got = r(view)
+            with _lib.kernel_policy(_lib.POLICY_RESAMPLE_B32):
+                ref = r(view)
+        exp = O.resample(view.cpu().numpy().astype(np.float64), 44100, 16000, **kw)
+        assert got.shape == exp.shape == ref.shape
+        peak = float(np.abs(exp).max())
+        assert float((got - ref).abs().max()) <= 2e-6 * peak
+        assert peak_rel_err(got.cpu().numpy(), exp) <= 1e-5 and peak_rel_err(ref.cpu().numpy(), exp) <= 1e-5
+    assert float(r(base)[3, 14600:].abs().max()) == 0.0                  # silence stays silence
+    r2 = T.Resample(48000, 44100, **kw).cuda()                             # 160 : 147, even orig: the 4-byte layout either way
+    x = base[:, :50000]
+    with torch.no_grad():
+        a = r2(x)
+        with _lib.kernel_policy(_lib.POLICY_RESAMPLE_B32):
+            b = r2(x)
+    assert torch.equal(a, b)
+
+
 def test_resample_click_and_minus_100_db_tone_in_one_chunk():
     """the block-floating scaling of the binary16-split resampler is weakest where ONE chunk holds a
     full-scale click AND a passage 100 dB below it: the chunk's power-of-two scale is set by the click, the quiet samples land

@@ -17,6 +17,13 @@ DT = {"f16": torch.float16, "bf16": torch.bfloat16}
 EPS = {"f16": 2.0 ** -11, "bf16": 2.0 ** -8}          # half an ulp, relative
 
 
+def _within_one_rounding(got, want32, tag):
+    """`got` (reduced precision) against the float32 result it was narrowed from: the two calls may differ by the FMA contraction
+    of their kernel instantiations (1e-7 of the peak), which moves a few values across a rounding boundary of the output dtype."""
+    d = (got.float() - want32).abs()
+    return bool((d <= 2.0 * EPS[tag] * want32.abs() + 2e-6 * float(want32.abs().max())).all())
+
+
 def _gold():
     return np.load(os.path.join(HERE, "golden", "lowp_goldens.npz"))
 
@@ -96,8 +103,10 @@ def test_melspectrogram_reads_reduced_precision_waveforms_directly(tag, hop):
     assert got.dtype == dt and got.shape == want32.shape
     if hop in (160, 200):
         direct = F._melspectrogram_lowp(x, 0, mel.spectrogram.window, mel.mel_scale.fb, 400, hop, 400, 2.0, False, True, "reflect")
-        assert direct is not None and torch.equal(direct.transpose(-1, -2), want32)     # same arithmetic, conversion in the load
-    assert torch.equal(got, want32.to(dt))
+        # same arithmetic, conversion in the load -- up to the FMA contraction: the float32 call of an 80-mel HTK / Slaney bank runs
+        # the instantiation compiled for that bank (DESIGN 4.1, 9e-8 of the peak from the table-driven one the half types use)
+        assert direct is not None and float((direct.transpose(-1, -2) - want32).abs().max()) <= 1e-6 * float(want32.abs().max())
+    assert _within_one_rounding(got, want32, tag)
     # a view with a row stride and an odd start: the unstaged gather of the same kernel
     big = torch.zeros(5, 16000 + 37 + 11, dtype=dt, device="cuda")
     big[:, 3:3 + x.shape[1]] = x
@@ -110,7 +119,7 @@ def test_melspectrogram_reads_reduced_precision_waveforms_directly(tag, hop):
                 T.Spectrogram(n_fft=400, hop_length=hop).cuda(), T.Spectrogram(n_fft=512, hop_length=128, power=1.0).cuda()):
         w32 = mod(x.float())
         y = mod(x)
-        assert y.dtype == dt and torch.equal(y, w32.to(dt)), type(mod).__name__
+        assert y.dtype == dt and _within_one_rounding(y, w32, tag), type(mod).__name__
     if tag == "f16":                                   # complex: ComplexHalf, as aten::stft returns for half input
         z = T.Spectrogram(n_fft=400, hop_length=hop, power=None).cuda()(x)
         assert z.dtype == torch.complex32
