@@ -87,7 +87,7 @@ def _features(waveform: Tensor, window_shift: int, window_size: int, padded: int
               snip_edges: bool, raw_energy: bool, energy_floor: float, dither: float, remove_dc_offset: bool,
               preemphasis_coefficient: float, bands, use_power: bool, use_log: bool, energy_col: int, first_col: int,
               n_cols: int) -> Tensor:
-    if padded > 8192:
+    if padded > 8192:       # (~5 750 .. 8 192 run the generic kernel's layout without an LDS twiddle table; beyond that nothing fits the LDS)
         raise NotImplementedError(f"audio_amd: padded windows above 8192 samples are not supported, got {padded}")
     if not waveform.is_cuda:
         raise RuntimeError(f"audio_amd: waveform must be on an MI355X (ROCm) device, got {waveform.device}. "

@@ -221,9 +221,14 @@ int launch_generic(const StftGeom& g, const MelBandsDev& mb, const float* wav, c
   const int bpr = (pairs_per_row + pb - 1) / pb;
   const int64_t blocks = g.rows * bpr;
   AAMD_CHECK_ARG(blocks < (1ll << 31), "too many frames for one launch");
-  const size_t lds = gen_lds_floats(g.n_fft, g.n_freq, pb) * sizeof(float);
-  if (lds > dev_props().lds_per_block_optin) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft too large for the LDS");
+  size_t lds = gen_lds_floats(g.n_fft, g.n_freq, pb) * sizeof(float);
   auto kern = stft_generic_kernel<float, EPI>;
+  if (lds > dev_props().lds_per_block_optin) {
+    // long windows (n_fft ~5 750 .. 8 192): the layout without the LDS twiddle table (stft_generic.h, gen_lds_floats_long)
+    lds = gen_lds_floats_long(g.n_fft, pb) * sizeof(float);
+    kern = stft_generic_kernel<float, EPI, 1>;
+    if (lds > dev_props().lds_per_block_optin) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft too large for the LDS");
+  }
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -793,7 +798,9 @@ int aamd_kaldi_features_f32(const float* wav, const float* window, const float* 
     if (plan.n_stages < 0 || d->n_fft > 8192)
       return fail(AAMD_EUNSUPPORTED, "audio_amd: padded window too long / too many prime factors for the Kaldi front-end");
     const int pb = kgen::pairs_per_block(d->n_fft);
-    const size_t lds = kgen::lds_floats(d->n_fft, pb) * sizeof(float);
+    size_t lds = kgen::lds_floats(d->n_fft, pb) * sizeof(float);
+    const bool long_win = lds > dev_props().lds_per_block_optin;     // ~5 750 .. 8 192: the layout without the LDS twiddle table
+    if (long_win) lds = kgen::lds_floats_long(d->n_fft, pb) * sizeof(float);
     if (lds > dev_props().lds_per_block_optin)
       return fail(AAMD_EUNSUPPORTED, "audio_amd: padded window too long for the LDS");
     const int64_t bpu = (d->n_frames + 2 * pb - 1) / (2 * pb);
@@ -801,13 +808,13 @@ int aamd_kaldi_features_f32(const float* wav, const float* window, const float* 
     AAMD_CHECK_ARG(nblk < (1ll << 31), "too many frames for one launch");
     const auto* twg = reinterpret_cast<const cplx<float>*>(twiddle);
     if (bands == nullptr) {
-      auto kk = kgen::kaldi_generic_kernel<0>;
+      auto kk = long_win ? kgen::kaldi_generic_kernel<0, 1> : kgen::kaldi_generic_kernel<0>;
       if (lds > 48 * 1024)
         AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kk, dim3((unsigned)nblk), dim3(kgen::kThreads), lds, (hipStream_t)stream, kg, plan, pb, (int)bpu, wav,
                          window, twg, mb, out);
     } else {
-      auto kk = kgen::kaldi_generic_kernel<1>;
+      auto kk = long_win ? kgen::kaldi_generic_kernel<1, 1> : kgen::kaldi_generic_kernel<1>;
       if (lds > 48 * 1024)
         AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(kk, dim3((unsigned)nblk), dim3(kgen::kThreads), lds, (hipStream_t)stream, kg, plan, pb, (int)bpu, wav,
@@ -931,9 +938,13 @@ int aamd_istft_f32(const float* spec, const float* window, const float* twiddle,
   const int bpr = (pairs_per_row + pb - 1) / pb;
   const int64_t blocks = g.rows * bpr;
   AAMD_CHECK_ARG(blocks < (1ll << 31), "too many frames for one launch");
-  const size_t lds = ((size_t)2 * g.n_fft + (size_t)4 * pb * gen_seq_len(g.n_fft)) * sizeof(float);
-  if (lds > dev_props().lds_per_block_optin) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft too large for the LDS");
+  size_t lds = ((size_t)2 * g.n_fft + (size_t)4 * pb * gen_seq_len(g.n_fft)) * sizeof(float);
   auto kern = ola_kernel<float>;
+  if (lds > dev_props().lds_per_block_optin) {     // long windows: twiddles from memory (stft_generic.h, gen_lds_floats_long)
+    lds = gen_lds_floats_long(g.n_fft, pb) * sizeof(float);
+    kern = ola_kernel<float, 1>;
+    if (lds > dev_props().lds_per_block_optin) return fail(AAMD_EUNSUPPORTED, "audio_amd: n_fft too large for the LDS");
+  }
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -81,21 +81,23 @@ AAMD_HD T ola_gather(const OlaGeom& og, const cplx<T>* X, const T* window, int p
 }
 
 #if defined(__HIPCC__)
-template <typename T>
+template <typename T, int LONG = 0>       // LONG = 1: twiddles from memory (stft_generic.h, gen_lds_floats_long)
 __global__ void __launch_bounds__(kGenThreads)
 ola_kernel(OlaGeom og, const T* __restrict__ spec, const T* __restrict__ window, const cplx<T>* __restrict__ tw,
            const T* __restrict__ inv_env, T* __restrict__ out, int pairs_per_block, int blocks_per_row) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_ola[];
   const StftGeom& g = og.g;
   const int N = g.n_fft, pb = pairs_per_block, SL = gen_seq_len(N);
-  cplx<T>* twl = reinterpret_cast<cplx<T>*>(smem_ola);
-  cplx<T>* bufA = twl + N;
+  cplx<T>* twl_lds = reinterpret_cast<cplx<T>*>(smem_ola);
+  cplx<T>* bufA = LONG ? twl_lds : twl_lds + N;
   cplx<T>* bufB = bufA + pb * SL;
+  const cplx<T>* twl = LONG ? tw : twl_lds;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int64_t row = blockIdx.x / blocks_per_row;
   const int chunk = blockIdx.x - (int)row * blocks_per_row;
   const int64_t t0 = (int64_t)chunk * 2 * pb;
-  for (int i = tid; i < N; i += nthr) twl[i] = tw[i];
+  if (!LONG)
+    for (int i = tid; i < N; i += nthr) twl_lds[i] = tw[i];
   ola_load<T>(tid, nthr, og, spec + row * g.n_frames * 2 * (int64_t)g.n_freq, t0, pb, bufA);
   __syncthreads();
   cplx<T>* x = bufA;

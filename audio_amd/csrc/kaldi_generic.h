@@ -45,6 +45,20 @@ AAMD_HD Lds carve(float* base, int N, int pb) {
   l.stat = l.red + kThreads;
   return l;
 }
+// the long-window layout (round 5, stft_generic.h gen_lds_floats_long): no twiddle table (read from memory), the power rows take the
+// ping-pong buffer the last stage left free (`P` is set by the kernel)
+AAMD_HD size_t lds_floats_long(int n_fft, int pb) { return (size_t)4 * pb * gen_seq_len(n_fft) + kThreads + 4 * 2 * pb; }
+AAMD_HD Lds carve_long(float* base, int N, int pb) {
+  Lds l;
+  const int SL = gen_seq_len(N);
+  l.twl = nullptr;
+  l.bufA = reinterpret_cast<cplx<float>*>(base);
+  l.bufB = l.bufA + pb * SL;
+  l.P = nullptr;
+  l.red = reinterpret_cast<float*>(l.bufB + pb * SL);
+  l.stat = l.red + kThreads;
+  return l;
+}
 
 // thread tid works on frame f = tid / tpf with its tpf-strided share of the samples
 struct Who {
@@ -185,21 +199,23 @@ struct Plan {
 
 #if defined(__HIPCC__)
 // MODE 0: kaldi.spectrogram rows [N/2 + 1]; MODE 1: kaldi.fbank rows [n_cols]
-template <int MODE>
+template <int MODE, int LONG = 0>
 __global__ void __launch_bounds__(kThreads)
 kaldi_generic_kernel(KaldiGeom kg, Plan plan, int pb, int blocks_per_utt, const float* wav,
                      const float* __restrict__ window /* [N], 0 past win */, const cplx<float>* __restrict__ tw,
                      MelBandsDev mb, float* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_kg[];
   const int N = plan.n_fft, nf = 2 * pb;
-  const Lds l = carve(reinterpret_cast<float*>(smem_kg), N, pb);
+  Lds l = LONG ? carve_long(reinterpret_cast<float*>(smem_kg), N, pb) : carve(reinterpret_cast<float*>(smem_kg), N, pb);
+  const cplx<float>* twl = LONG ? tw : l.twl;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int64_t utt = blockIdx.x / blocks_per_utt;            // batch extension: one utterance per group of workgroups
   const int64_t t0 = (int64_t)(blockIdx.x - utt * blocks_per_utt) * nf;
   wav += utt * kg.utt_stride;
   out += utt * kg.n_frames * (MODE == 0 ? (int64_t)(N / 2 + 1) : (int64_t)kg.n_cols);
   if (kg.noise != nullptr) kg.noise += utt * kg.n_frames * kg.win;
-  for (int i = tid; i < N; i += nthr) l.twl[i] = tw[i];
+  if (!LONG)
+    for (int i = tid; i < N; i += nthr) l.twl[i] = tw[i];
   pass_sum(tid, nthr, nf, kg, wav, t0, l.red);
   __syncthreads();
   fold_mean(tid, nthr, nf, kg, l.red, l.stat);
@@ -221,7 +237,7 @@ kaldi_generic_kernel(KaldiGeom kg, Plan plan, int pb, int blocks_per_utt, const 
   int s = 1;
   for (int st = 0; st < plan.n_stages; ++st) {
     const int r = plan.radix[st];
-    gen_stage<float>(tid, nthr, N, r, s, pb, x, y, l.twl);
+    gen_stage<float>(tid, nthr, N, r, s, pb, x, y, twl);
     __syncthreads();
     s *= r;
     cplx<float>* tmp = x; x = y; y = tmp;
@@ -229,6 +245,7 @@ kaldi_generic_kernel(KaldiGeom kg, Plan plan, int pb, int blocks_per_utt, const 
   if (MODE == 0) {
     store_spec(tid, nthr, nf, N, kg, x, t0, l.stat, out);
   } else {
+    if (LONG) l.P = reinterpret_cast<float*>(y);      // 2 pb (N / 2 + 2) floats into a buffer of 2 pb SL
     power_rows(tid, nthr, nf, N, kg, x, l.P);
     __syncthreads();
     fbank_rows(tid, nthr, nf, N, kg, mb, l.P, t0, l.stat, out);

@@ -56,6 +56,11 @@ AAMD_HD int gen_seq_len(int n_fft) { return gen_pad(n_fft - 1) + 1; }
 AAMD_HD size_t gen_lds_floats(int n_fft, int n_freq, int pb) {
   return (size_t)2 * n_fft + (size_t)4 * pb * gen_seq_len(n_fft) + (size_t)2 * pb * n_freq;
 }
+// The long-window layout (round 5; n_fft of about 5 750 .. 8 192 in float32: 0.36 .. 0.51 s windows at 16 kHz, n_fft = 8192 at 44.1 / 48 kHz):
+// only the two ping-pong buffers -- the twiddles are read from the table in memory (64 KB: L2-resident) and the power rows of the
+// mel epilogue take the ping-pong buffer that the last stage left free.  Slower per stage than the LDS table; used only when the
+// full layout does not fit.
+AAMD_HD size_t gen_lds_floats_long(int n_fft, int pb) { return (size_t)4 * pb * gen_seq_len(n_fft); }
 
 template <typename T>
 AAMD_HD T stft_sample(const StftGeom& g, const T* wav_row, int64_t t, int n) {
@@ -277,24 +282,27 @@ AAMD_HD void gen_mel(int tid, int nthr, const StftGeom& g, const MelBandsDev& mb
 #if defined(__HIPCC__)
 enum { EPI_SPEC = 0, EPI_MEL = 1 };
 
-template <typename T, int EPI>
+// LONG = 1: the long-window layout (gen_lds_floats_long): twiddles from memory, power rows in the free ping-pong buffer
+template <typename T, int EPI, int LONG = 0>
 __global__ void __launch_bounds__(kGenThreads)
 stft_generic_kernel(StftGeom g, const T* __restrict__ wav, const T* __restrict__ window,
                     const cplx<T>* __restrict__ tw, MelBandsDev mb, T* __restrict__ out,
                     int pairs_per_block, int blocks_per_row) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = g.n_fft, pb = pairs_per_block, SL = gen_seq_len(N);
-  cplx<T>* twl = reinterpret_cast<cplx<T>*>(smem);
-  cplx<T>* bufA = twl + N;
+  cplx<T>* twl_lds = reinterpret_cast<cplx<T>*>(smem);
+  cplx<T>* bufA = LONG ? twl_lds : twl_lds + N;
   cplx<T>* bufB = bufA + pb * SL;
   T* P = reinterpret_cast<T*>(bufB + pb * SL);
+  const cplx<T>* twl = LONG ? tw : twl_lds;
 
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int64_t row = blockIdx.x / blocks_per_row;
   const int chunk = blockIdx.x - (int)row * blocks_per_row;
   const int64_t t0 = (int64_t)chunk * 2 * pb;
   const T* wav_row = wav + row * g.row_stride;
-  for (int i = tid; i < N; i += nthr) twl[i] = tw[i];
+  if (!LONG)
+    for (int i = tid; i < N; i += nthr) twl_lds[i] = tw[i];
   gen_load<T>(tid, nthr, g, wav_row, window, t0, pb, bufA);
   __syncthreads();
   cplx<T>* x = bufA;
@@ -311,6 +319,7 @@ stft_generic_kernel(StftGeom g, const T* __restrict__ wav, const T* __restrict__
     const int opf = g.power <= 0.0f ? 2 * g.n_freq : g.n_freq;
     gen_store_spec<T>(tid, nthr, g, x, pb, t0, out + row * g.n_frames * (int64_t)opf);
   } else {
+    if (LONG) P = reinterpret_cast<T*>(y);            // (2 pb n_freq floats into a buffer of 2 pb SL: the other one holds the spectra)
     gen_power_rows<T>(tid, nthr, g, x, pb, P);
     __syncthreads();
     gen_mel<T>(tid, nthr, g, mb, P, pb, t0, out + row * g.n_frames * (int64_t)mb.n_mels);

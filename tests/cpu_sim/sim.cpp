@@ -1201,6 +1201,14 @@ int sim_mel400_pool(int nb, int tiles_per_block, int64_t n_tiles, int P, int wav
   return 0;
 }
 
+// LDS bytes of the generic STFT / Kaldi kernels: layout 0 = full (twiddle table in LDS), 1 = long windows (stft_generic.h,
+// gen_lds_floats_long), 2 = the Kaldi front-end's long layout
+int64_t sim_gen_lds_bytes(int n_fft, int pb, int layout) {
+  if (layout == 0) return (int64_t)(gen_lds_floats(n_fft, n_fft / 2 + 1, pb) * sizeof(float));
+  if (layout == 1) return (int64_t)(gen_lds_floats_long(n_fft, pb) * sizeof(float));
+  return (int64_t)(kgen::lds_floats_long(n_fft, pb) * sizeof(float));
+}
+
 // The launcher's chunk geometry of the banded resampler for one set of phase tiles (rsm::plan_chunk), for property tests:
 // out = {qg, rounds, n_loaders, buf_floats, waves, chunk_q}; returns 0 when even one q-group does not fit.
 int sim_rsm_plan(int orig, int new_, int width, int tap_span, int max_lo, int64_t nq, int f16, int64_t lds_cap, int* out) {
