@@ -10,6 +10,12 @@ using namespace aamd;
 #ifndef LAB_RSM_RD
 #define LAB_RSM_RD 0
 #endif
+#ifndef LAB_RSM_LABM              /* 2: the instantiation that honours the timing-only switches of Geom::lab (wrong results) */
+#define LAB_RSM_LABM 0
+#endif
+#ifndef LAB_RSM_BITS              /* Geom::lab of this variant: 1 no conversion, 2 no MFMA, 4 no LDS operand reads, 8 no global loads, 16 no tap fragments, 32 no stores */
+#define LAB_RSM_BITS 0
+#endif
 
 extern "C" int lab_rsm_rd() { return LAB_RSM_RD; }
 
@@ -20,7 +26,7 @@ extern "C" int lab_rsm(const float* wav, const float* kernel, float* out, int64_
   const int ks = rsm::pick_ks(tap_span);
   if (ks == 0) return -2;
   rsm::Geom g{};
-  g.lab = lab;
+  g.lab = LAB_RSM_BITS ? LAB_RSM_BITS : lab;
   g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
   g.orig = orig; g.new_ = new_; g.width = width; g.taps = 2 * width + orig;
   g.vec_in = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (row_stride % 4 == 0);
@@ -52,7 +58,7 @@ extern "C" int lab_rsm(const float* wav, const float* kernel, float* out, int64_
     if (ks != 112) return -4;                               // the lab serves the cfg3 instantiation
     constexpr int RD = LAB_RSM_RD;
     if (RD && !rsm::b64_ok(ks, orig)) return -5;
-    auto kern = rsm::resample_f16_kernel<112, 0, RD>;
+    auto kern = rsm::resample_f16_kernel<112, LAB_RSM_LABM, RD>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -6;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wg_waves), lds, (hipStream_t)stream, g, wav, kernel, out);
