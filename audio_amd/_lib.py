@@ -109,6 +109,10 @@ _SIGS = {
                                     C.c_int32, C.c_int64, _P]),
     "aamd_resample_banded_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int64, C.POINTER(ResampleBands), _P]),
+    "aamd_resample_frag_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.POINTER(ResampleBands)]),
+    "aamd_resample_frag_build_f32": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ResampleBands), _P, _P]),
+    "aamd_resample_prepared_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int64, C.POINTER(ResampleBands), _P, _P]),
     "aamd_resample_sparse_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, C.c_int64, _P]),
     "aamd_lfilter_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
@@ -148,7 +152,7 @@ def lib():
                 fn = getattr(h, name)   # AttributeError if the ABI symbol is missing
                 fn.restype = res
                 fn.argtypes = args
-            if h.aamd_abi_version() != 6:
+            if h.aamd_abi_version() != 7:
                 raise RuntimeError("audio_amd: ABI version mismatch between _lib.py and libaudio_amd.so")
             _lib = h
     return _lib

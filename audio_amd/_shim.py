@@ -26,8 +26,9 @@ OPS = ("spectrogram", "mel_spectrogram", "mel_spectrogram_db", "mfcc_dct", "resa
        "mel_spectrogram_lognorm", "mfcc_frag_build", "mfcc_fused", "istft", "istft_f64", "spectrogram_f64", "phase_vocoder",
        "griffinlim_update", "mel_scale", "amplitude_to_db", "amplitude_to_db_clamped", "db_clamp", "spectrogram_grad",
        "mel_spectrogram_grad", "resample_sparse", "kaldi_features", "lfilter_f64", "resample_f64", "fftconvolve_f64",
-       # round 5: the staged form of fftconvolve (prepared tap spectra for a repeated impulse response)
-       "fftconvolve_staged")
+       # round 5: the staged form of fftconvolve (prepared tap spectra for a repeated impulse response), the prepared tap
+       # fragments of the matrix-core resampler
+       "fftconvolve_staged", "resample_frag_build")
 
 _lock = threading.Lock()
 _handle = None
@@ -48,7 +49,7 @@ def load():
             torch.ops.load_library(SHIM_PATH)
             h = C.CDLL(SHIM_PATH)
             h.aamd_torch_shim_abi.restype = C.c_int
-            if h.aamd_torch_shim_abi() != 6:
+            if h.aamd_torch_shim_abi() != 7:
                 raise RuntimeError("audio_amd: ABI version mismatch between the torch shim and include/audio_amd.h")
             _register_fakes()
             _handle = h
@@ -81,8 +82,14 @@ def _register_fakes() -> None:
         return mel.new_empty((mel.shape[0], dct_mat.shape[1]))
 
     @reg("aamd::resample")
-    def _(wav, kernel, orig, new, width, out_len, band_tap_lo, tap_span):
+    def _(wav, kernel, orig, new, width, out_len, band_tap_lo, tap_span, frag):
         return wav.new_empty((wav.shape[0], out_len))
+
+    @reg("aamd::resample_frag_build")
+    def _(kernel, orig, new, width, band_tap_lo, tap_span):
+        from . import _host
+        ks = _host._rs_pick_ks(int(tap_span))             # rsm::frag_bytes: tiles x (KS / 8) steps x (hi, lo) x 64 lanes x 16 B
+        return kernel.new_empty((len(band_tap_lo) * (ks // 8) * 2 * 64 * 4,))
 
     @reg("aamd::lfilter")
     def _(waveform, a_coeffs, b_coeffs, n_stages, clamp):

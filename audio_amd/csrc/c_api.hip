@@ -1269,6 +1269,45 @@ extern "C" __attribute__((visibility("default"))) int aamd_debug_rsm_census(long
 int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, int64_t rows,
                              int64_t length, int64_t row_stride, int32_t orig, int32_t new_, int32_t width,
                              int64_t out_len, const aamd_resample_bands* bands, void* stream) {
+  return aamd_resample_prepared_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, bands, nullptr, stream);
+}
+
+int64_t aamd_resample_frag_bytes(int32_t orig, int32_t new_, const aamd_resample_bands* bands) {
+  (void)orig;
+  if (bands == nullptr || new_ < 1 || bands->n_tiles != (new_ + 15) / 16) return 0;
+  const int ks = rsm::pick_ks(bands->tap_span);
+  return ks == 0 ? 0 : rsm::frag_bytes(bands->n_tiles, ks);
+}
+
+int aamd_resample_frag_build_f32(const float* kernel, int32_t orig, int32_t new_, int32_t width,
+                                 const aamd_resample_bands* bands, void* frag, void* stream) {
+  DeviceScope dev_scope_(kernel);
+  AAMD_CHECK_ARG(kernel && frag && bands, "null buffer");
+  AAMD_CHECK_ARG(orig >= 1 && new_ >= 1 && width >= 0, "bad sizes");
+  const int n_tiles = (new_ + 15) / 16;
+  AAMD_CHECK_ARG(bands->n_tiles == n_tiles && bands->tap_lo != nullptr && bands->tap_span >= 1, "band table must have ceil(new/16) tiles");
+  const int ks = rsm::pick_ks(bands->tap_span);
+  if (ks == 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: band wider than 448 taps: no matrix-core kernel, no prepared fragments");
+  AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(frag) % 16 == 0, "fragment table must be 16-byte aligned");
+  const int taps = 2 * width + orig;
+  for (int t = 0; t < n_tiles; ++t)
+    AAMD_CHECK_ARG(bands->tap_lo[t] >= 0 && bands->tap_lo[t] < taps, "tap_lo outside the tap table");
+  rsm::Geom g{};
+  g.orig = orig; g.new_ = new_; g.width = width; g.taps = taps;
+  for (int pt0 = 0; pt0 < n_tiles; pt0 += rsm::kMaxPhaseTiles) {          // (the band starts ride in the kernel arguments, 14 tiles a launch)
+    g.pt0 = pt0;
+    g.n_pt = n_tiles - pt0 < rsm::kMaxPhaseTiles ? n_tiles - pt0 : rsm::kMaxPhaseTiles;
+    for (int t = 0; t < g.n_pt; ++t) g.tap_lo[t] = bands->tap_lo[pt0 + t];
+    const int n = g.n_pt * (ks / 8) * 64;
+    hipLaunchKernelGGL(rsm::frag_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, ks, kernel,
+                       static_cast<uint32_t*>(frag));
+  }
+  return launch_check();
+}
+
+int aamd_resample_prepared_f32(const float* wav, const float* kernel, float* out, int64_t rows,
+                               int64_t length, int64_t row_stride, int32_t orig, int32_t new_, int32_t width,
+                               int64_t out_len, const aamd_resample_bands* bands, const void* frag, void* stream) {
   DeviceScope dev_scope_(wav);
   const int n_tiles = (new_ + 15) / 16;
   const int ks = bands ? rsm::pick_ks(bands->tap_span) : 0;
@@ -1287,6 +1326,8 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
   rsm::Geom g{};
   static const int rsm_lab = [] { const char* e = std::getenv("AAMD_RSM_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
   g.lab = rsm_lab;
+  g.frag = static_cast<const uint32_t*>(frag);       // (read by the f16 kernels only)
+  AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(frag) % 16 == 0, "fragment table must be 16-byte aligned");
   g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
   g.orig = orig; g.new_ = new_; g.width = width; g.taps = taps;
   g.vec_in = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (row_stride % 4 == 0);

@@ -46,6 +46,8 @@ struct Geom {
   int vec_in, vec_out;       // 16-B global loads / stores are legal
   int tap_lo[kMaxPhaseTiles];
   int lab;                   // tools only (AAMD_RSM_LAB): 1 no conversion, 2 no MFMA, 4 no LDS operand reads, 8 no global loads, 16 no tap fragments, 32 no stores
+  const uint32_t* frag;      // f16 kernel: the packed tap fragments prepared once per filter (frag_piece), or null: every compute wave
+                             // splits its 224 taps itself (224 scattered loads + 448 binary16 conversions per lane and launch)
 };
 
 // k-steps needed for a band of `span` taps, from the supported set (all = 16 mod 32); 0 = too wide
@@ -183,6 +185,16 @@ AAMD_HD int b64_step(int ks, int s, int grp4) {
 AAMD_HD int b_base64(const Geom& g, int grp, int h, int tap_lo, int ks, int shift, int lane) {
   return (32 * grp + 2 * (lane & 15) + h) * g.orig + tap_lo + ks * (lane >> 4) + shift;
 }
+
+// ---- prepared tap fragments (round 5) --------------------------------------------------------------------------------------
+// The f16 kernel's A operand of (phase tile pt, table step s, lane) is 8 binary16 hi parts + 8 lo parts of the taps
+// tap_lo[pt] + KS (lane >> 4) + 8 s + e of phase 16 pt + (lane & 15), scaled by 2^15: constants of the filter.  Every compute wave of
+// every workgroup used to form them in its prologue -- 224 scattered loads and 448 conversions per lane; the lab switch that skips
+// them says 0.557 -> 0.485 ms on the cfg3 shard (profiles/r05_m_rsm_lab_ablation.txt), 13 % of the launch.  Prepared ONCE per filter
+// (frag_build_kernel, the host keeps the table with the tap tensor) they are 2 NS coalesced 16-byte loads per lane.  The table is in
+// natural step order; the 8-byte operand layout's rotated lane groups (b64_step) pick their rows from it.
+AAMD_HD int64_t frag_piece(int pt, int ns, int s, int hl, int lane) { return (((int64_t)pt * ns + s) * 2 + hl) * 64 + lane; }   // 16-B pieces
+AAMD_HD int64_t frag_bytes(int n_tiles, int ks) { return (int64_t)n_tiles * (ks / 8) * 2 * 64 * 16; }
 
 // ---- the f16 matrix-pipe variant: fp32-class accuracy from three f16 MFMAs per product --------------------------------
 // v_mfma_f32_16x16x4_f32 runs at 1/16 of the f16 rate of the matrix cores (157 against 2 500 TFLOP/s), and cfg3 is bound by
@@ -568,7 +580,18 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   }
 
   uint32_t ah[NS * 4], al[NS * 4];
-  if constexpr (RD == 1) {
+  if (g.frag != nullptr && !(lab & 16)) {
+    // prepared fragments: 2 NS coalesced 16-byte loads per lane (natural step order in the table; the rotated lane groups of the
+    // 8-byte layout take the row of THEIR table step)
+    const u32x4* ft = reinterpret_cast<const u32x4*>(g.frag);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const int sig = RD ? b64_step(KS, s_, lane >> 4) : s_;
+      const u32x4 h = ft[frag_piece(pt, NS, sig, 0, lane)], l = ft[frag_piece(pt, NS, sig, 1, lane)];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) { ah[4 * s_ + d] = h[d]; al[4 * s_ + d] = l[d]; }
+    }
+  } else if constexpr (RD == 1) {
     // odd lane groups hold the steps rotated (b64_step): one per-lane tap offset, the wrap a compile-time choice per step.
     // The per-lane base goes through an opaque move every AAMD_RSM_PRO_BATCH steps: left alone, the 224 tap indices are all
     // formed up front, and with the 8-byte loop's registers on top the fragment loads were spilled one by one behind vmcnt(0)
@@ -797,6 +820,26 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     if (threadIdx.x == 0) { mx[k % 3] = 0u; grab[k % 3] = 0u; }                // read by everybody before A(cid); next written behind A(cid + 1)
   }
 }
+// the prepared tap fragments of the phase tiles [g.pt0, g.pt0 + g.n_pt) of one filter: one thread per (tile, step, lane)
+__global__ void __launch_bounds__(256)
+frag_build_kernel(Geom g, int ks, const float* __restrict__ kern, uint32_t* __restrict__ frag) {
+  using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+  const int ns = ks / 8;
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= g.n_pt * ns * 64) return;
+  const int lane = i & 63, s = (i >> 6) % ns, pt_l = (i >> 6) / ns, pt = g.pt0 + pt_l;
+  u32x4 h, l;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    uint32_t hi, lo;
+    a_pack16(g, kern, pt, g.tap_lo[pt_l], ks, s, d, lane, hi, lo);
+    h[d] = hi; l[d] = lo;
+  }
+  u32x4* ft = reinterpret_cast<u32x4*>(frag);
+  ft[frag_piece(pt, ns, s, 0, lane)] = h;
+  ft[frag_piece(pt, ns, s, 1, lane)] = l;
+}
+
 // the instantiation with 8-byte operand reads where one exists (the launcher asks for it only for those KS)
 template <int KS, int LABM>
 inline auto kernel_rd64() {

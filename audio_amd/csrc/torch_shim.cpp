@@ -211,11 +211,13 @@ Tensor mfcc_dct(Tensor mel, Tensor dct, int64_t log_mode, std::optional<Tensor> 
 }
 
 // ---- aamd::resample  (functional/functional.py:1421-1428) ----------------------------------------------------------
+// `frag`: the prepared tap fragments of aamd::resample_frag_build for the same kernel values and band table (ABI 7), or none
 Tensor resample(Tensor wav, Tensor kernel, int64_t orig, int64_t new_, int64_t width, int64_t out_len,
-                std::optional<std::vector<int64_t>> band_tap_lo, int64_t tap_span) {
+                std::optional<std::vector<int64_t>> band_tap_lo, int64_t tap_span, std::optional<Tensor> frag) {
   want_f32(wav, "waveform", 2);
   want_f32(kernel, "kernel", 2);
   same_device(wav, kernel);
+  if (frag.has_value()) same_device(wav, *frag);
   STD_TORCH_CHECK(kernel.size(0) == new_ && kernel.size(1) == 2 * width + orig,
                   "audio_amd: resample kernel shape does not match (new, 2*width+orig)");
   const torch::stable::accelerator::DeviceGuard guard(wav.get_device_index());
@@ -225,13 +227,36 @@ Tensor resample(Tensor wav, Tensor kernel, int64_t orig, int64_t new_, int64_t w
     if (band_tap_lo.has_value()) {
       std::vector<int32_t> lo(band_tap_lo->begin(), band_tap_lo->end());
       aamd_resample_bands bands{(int32_t)lo.size(), (int32_t)tap_span, lo.data()};
-      check(aamd_resample_banded_f32(fp(wav), fp(kernel), fpm(out), wav.size(0), length, length > 0 ? length : 1,
-                                     (int32_t)orig, (int32_t)new_, (int32_t)width, out_len, &bands, current_stream(wav)));
+      const void* fr = nullptr;
+      if (frag.has_value()) {
+        STD_TORCH_CHECK(frag->is_contiguous() && (int64_t)(frag->numel() * frag->element_size()) >=
+                            aamd_resample_frag_bytes((int32_t)orig, (int32_t)new_, &bands),
+                        "audio_amd: prepared tap fragments too small for this band table");
+        fr = frag->data_ptr();
+      }
+      check(aamd_resample_prepared_f32(fp(wav), fp(kernel), fpm(out), wav.size(0), length, length > 0 ? length : 1,
+                                       (int32_t)orig, (int32_t)new_, (int32_t)width, out_len, &bands, fr, current_stream(wav)));
     } else {
       check(aamd_resample_f32(fp(wav), fp(kernel), fpm(out), wav.size(0), length, length > 0 ? length : 1, (int32_t)orig,
                               (int32_t)new_, (int32_t)width, out_len, current_stream(wav)));
     }
   }
+  return out;
+}
+
+// ---- aamd::resample_frag_build: the packed binary16 tap fragments of a resampling kernel, once per filter (ABI 7) -------------
+Tensor resample_frag_build(Tensor kernel, int64_t orig, int64_t new_, int64_t width, std::vector<int64_t> band_tap_lo, int64_t tap_span) {
+  want_f32(kernel, "kernel", 2);
+  STD_TORCH_CHECK(kernel.size(0) == new_ && kernel.size(1) == 2 * width + orig,
+                  "audio_amd: resample kernel shape does not match (new, 2*width+orig)");
+  const torch::stable::accelerator::DeviceGuard guard(kernel.get_device_index());
+  std::vector<int32_t> lo(band_tap_lo.begin(), band_tap_lo.end());
+  aamd_resample_bands bands{(int32_t)lo.size(), (int32_t)tap_span, lo.data()};
+  const int64_t bytes = aamd_resample_frag_bytes((int32_t)orig, (int32_t)new_, &bands);
+  STD_TORCH_CHECK(bytes > 0, "audio_amd: no matrix-core resampling kernel serves this band table (no fragments to prepare)");
+  Tensor out = torch::stable::new_empty(kernel, {bytes / 4});          // float32 storage holding the packed dwords
+  check(aamd_resample_frag_build_f32(fp(kernel), (int32_t)orig, (int32_t)new_, (int32_t)width, &bands, out.data_ptr(),
+                                     current_stream(kernel)));
   return out;
 }
 
@@ -759,7 +784,8 @@ STABLE_TORCH_LIBRARY(aamd, m) {
         "int rows_per_group, int table_sig) -> Tensor");
   m.def("mfcc_dct(Tensor mel, Tensor dct_mat, int log_mode, Tensor? group_max, int vec_per_group, float top_db) -> Tensor");
   m.def("resample(Tensor wav, Tensor kernel, int orig, int new, int width, int out_len, int[]? band_tap_lo, "
-        "int tap_span) -> Tensor");
+        "int tap_span, Tensor? frag) -> Tensor");
+  m.def("resample_frag_build(Tensor kernel, int orig, int new, int width, int[] band_tap_lo, int tap_span) -> Tensor");
   m.def("lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, int n_stages, int clamp) -> Tensor");
   m.def("fftconvolve(Tensor x, Tensor y, Tensor? x_row_of, Tensor? y_row_of, int rows, int start, int out_len) -> Tensor");
   m.def("fftconvolve_staged(Tensor x, Tensor y, Tensor? x_row_of, Tensor? y_row_of, int rows, int start, int out_len, "
@@ -802,6 +828,7 @@ STABLE_TORCH_LIBRARY_IMPL(aamd, CUDA, m) {
   m.impl("mel_spectrogram_db", TORCH_BOX(&mel_spectrogram_db));
   m.impl("mfcc_dct", TORCH_BOX(&mfcc_dct));
   m.impl("resample", TORCH_BOX(&resample));
+  m.impl("resample_frag_build", TORCH_BOX(&resample_frag_build));
   m.impl("lfilter", TORCH_BOX(&lfilter));
   m.impl("fftconvolve", TORCH_BOX(&fftconvolve));
   m.impl("fftconvolve_staged", TORCH_BOX(&fftconvolve_staged));

@@ -1370,18 +1370,39 @@ def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new
     tap_lo, span = _tensor_cached(key_tensor, ("rs_bands", key, new),
                                   lambda: _host.resample_band_table(kern.cpu().numpy()))
     ops = _ops()
+    lo_list = _tensor_cached(key_tensor, ("rs_bands_list", key, new), lambda: [int(v) for v in tap_lo])
+    # prepared tap fragments of the binary16-split matrix-core kernel (C ABI 7): the packed (hi, lo) operands of the filter, built
+    # once per kernel tensor instead of in every workgroup's prologue (13 % of a BASELINE config-3 launch).  Built on the current
+    # stream and synchronised once, so that any later stream may read them; not under graph capture (memory of a capture's
+    # private pool must not outlive the graph): such a call forms the fragments in the kernel, with identical results
+    frag = None
+    if _host._rs_pick_ks(int(span)) != 0 and not torch.cuda.is_current_stream_capturing():
+        def _frag():
+            L = _lib.lib()
+            bands = _lib.ResampleBands(tap_lo.shape[0], span, tap_lo.ctypes.data_as(C.POINTER(C.c_int32)))
+            with torch.cuda.device(x2.device):
+                if ops is not None:
+                    t = ops.resample_frag_build(kern, orig, new, width, lo_list, int(span))
+                else:
+                    nb = int(L.aamd_resample_frag_bytes(orig, new, C.byref(bands)))
+                    t = torch.empty((nb // 4,), dtype=torch.float32, device=x2.device)
+                    _lib.check(L.aamd_resample_frag_build_f32(kern.data_ptr(), orig, new, width, C.byref(bands), t.data_ptr(),
+                                                              _lib.current_stream(x2.device)))
+                torch.cuda.current_stream(x2.device).synchronize()
+            return t
+        frag = _tensor_cached(key_tensor, ("rs_frag", key, orig, new, width, str(x2.device)), _frag)
     if ops is not None:
         if x2.stride(0) != length and rows > 1:
             x2 = x2.contiguous()
-        lo_list = _tensor_cached(key_tensor, ("rs_bands_list", key, new), lambda: [int(v) for v in tap_lo])
-        return ops.resample(x2, kern, orig, new, width, out_len, lo_list, int(span))
+        return ops.resample(x2, kern, orig, new, width, out_len, lo_list, int(span), frag)
     out = torch.empty((rows, out_len), dtype=torch.float32, device=x2.device)
     if out.numel():
         L = _lib.lib()
         bands = _lib.ResampleBands(tap_lo.shape[0], span, tap_lo.ctypes.data_as(C.POINTER(C.c_int32)))
-        _lib.check(L.aamd_resample_banded_f32(x2.data_ptr(), kern.data_ptr(), out.data_ptr(), rows, length,
-                                              x2.stride(0) if rows > 1 else max(length, 1), orig, new, width,
-                                              out_len, C.byref(bands), _lib.current_stream(x2.device)))
+        _lib.check(L.aamd_resample_prepared_f32(x2.data_ptr(), kern.data_ptr(), out.data_ptr(), rows, length,
+                                                x2.stride(0) if rows > 1 else max(length, 1), orig, new, width,
+                                                out_len, C.byref(bands), None if frag is None else frag.data_ptr(),
+                                                _lib.current_stream(x2.device)))
     return out
 
 

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define AAMD_ABI_VERSION 6
+#define AAMD_ABI_VERSION 7
 
 enum {
   AAMD_OK = 0,
@@ -383,6 +383,23 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
                              int64_t length, int64_t row_stride, int32_t orig, int32_t new_,
                              int32_t width, int64_t out_len, const aamd_resample_bands* bands,
                              void* stream);
+
+/* Prepared tap fragments (ABI 7, round 5).  The binary16-split matrix-core kernels multiply with the filter's taps as packed
+ * (hi, lo) binary16 fragments; formed by every workgroup in its prologue they cost 13 % of a BASELINE config-3 launch.  A filter
+ * that is applied many times (T.Resample holds its `kernel` buffer, transforms/_transforms.py:966-980) prepares them once:
+ *   aamd_resample_frag_bytes      size of the table for this band table (0: no matrix-core kernel serves it)
+ *   aamd_resample_frag_build_f32  fills `frag` (device, 16-byte aligned, that many bytes) from the tap table, on `stream`
+ *   aamd_resample_prepared_f32    = aamd_resample_banded_f32 reading `frag` (NULL: forms the fragments itself; bit-identical results)
+ * `frag` must come from a build with the same kernel values, orig, new, width and band table, stream-ordered before the call
+ * (or synchronised); it is read-only while calls run and independent of the kernel policy (the fp32-MFMA and scalar kernels
+ * ignore it). */
+int64_t aamd_resample_frag_bytes(int32_t orig, int32_t new_, const aamd_resample_bands* bands);
+int     aamd_resample_frag_build_f32(const float* kernel, int32_t orig, int32_t new_, int32_t width,
+                                     const aamd_resample_bands* bands, void* frag, void* stream);
+int     aamd_resample_prepared_f32(const float* wav, const float* kernel, float* out, int64_t rows,
+                                   int64_t length, int64_t row_stride, int32_t orig, int32_t new_,
+                                   int32_t width, int64_t out_len, const aamd_resample_bands* bands,
+                                   const void* frag, void* stream);
 
 /* Sparse evaluation for ratios whose REDUCED rates are huge (F.pitch_shift / T.PitchShift: 20158 -> 16000 Hz is
  * 10079 : 8000, a tap table of 8000 x 10095 with ~36 non-negligible taps per phase; functional/functional.py:1790-1840):

@@ -908,6 +908,55 @@ def test_resample_8_byte_operand_layout_against_the_4_byte_one():
     assert torch.equal(a, b)
 
 
+def test_resample_prepared_tap_fragments_are_bit_identical_to_the_in_kernel_split():
+    """Round 5 (C ABI 7): the packed binary16 (hi, lo) tap fragments of the matrix-core resampler are prepared once per kernel
+    tensor (aamd_resample_frag_build_f32; 13 % of a BASELINE config-3 launch when every workgroup forms them itself) and read by
+    both operand layouts.  Same values, same arithmetic: bit-identical to the call without them (C entry with frag = NULL), on
+    cfg3's filter (8-byte layout), under AAMD_POLICY_RESAMPLE_B32 (4-byte layout), on a default-quality pair with filled phase
+    tiles (48 k -> 16 k), on a pair with more than 14 phase tiles (several build launches), and after the kernel tensor was
+    changed in place (the cache key holds its version)."""
+    import ctypes as C
+    import audio_amd.transforms as T
+    from audio_amd import _host, _lib
+    g = torch.Generator().manual_seed(31)
+    x = (0.5 * torch.randn(3, 60011, generator=g)).clamp_(-1, 1).cuda()
+
+    def unprepared(r, orig, new, xin):           # the C entry without fragments, on the tensors the module holds
+        kern = r.kernel.reshape(r.kernel.shape[0], -1).contiguous()
+        lo, span = _host.resample_band_table(kern.cpu().numpy())
+        lo = np.ascontiguousarray(lo, dtype=np.int32)
+        bands = _lib.ResampleBands(lo.shape[0], span, lo.ctypes.data_as(C.POINTER(C.c_int32)))
+        out_len = -(-new * xin.shape[1] // orig)
+        out = torch.empty(xin.shape[0], out_len, device="cuda")
+        _lib.check(_lib.lib().aamd_resample_prepared_f32(xin.data_ptr(), kern.data_ptr(), out.data_ptr(), xin.shape[0], xin.shape[1],
+                                                         xin.shape[1], orig, new, r.width, out_len, C.byref(bands), None,
+                                                         _lib.current_stream(xin.device)))
+        return out
+
+    kw = dict(resampling_method="sinc_interp_kaiser", lowpass_filter_width=64, rolloff=0.9475937167399596, beta=14.769656459379492)
+    r = T.Resample(44100, 16000, **kw).cuda()
+    with torch.no_grad():
+        got = r(x)
+        assert torch.equal(got, unprepared(r, 441, 160, x))
+        with _lib.kernel_policy(_lib.POLICY_RESAMPLE_B32):
+            assert torch.equal(r(x), unprepared(r, 441, 160, x))
+        r.kernel.mul_(0.5)                                        # in place: a new version, new fragments
+        assert torch.equal(r(x), unprepared(r, 441, 160, x))
+        assert float((r(x) - 0.5 * got).abs().max()) <= 1e-6 * float(got.abs().max())
+        r3 = T.Resample(44100, 48000, **kw).cuda()                # 147 : 160 -> 160 phases = 10 tiles; and a long table:
+        assert torch.equal(r3(x), unprepared(r3, 147, 160, x))
+        r4 = T.Resample(16000, 22050).cuda()                      # 320 : 441 -> 28 phase tiles: two build launches
+        assert torch.equal(r4(x), unprepared(r4, 320, 441, x))
+        with _lib.kernel_policy(_lib.POLICY_RESAMPLE_FP32):
+            y4f = r4(x)
+        assert float((r4(x) - y4f).abs().max()) <= 2e-6 * float(y4f.abs().max())
+        r2 = T.Resample(48000, 16000).cuda()                      # one phase: the host fills the 16-phase tile (3 : 1 -> 48 : 16)
+        y2 = r2(x)
+        with _lib.kernel_policy(_lib.POLICY_RESAMPLE_FP32):       # the exact-fp32 MFMA kernel ignores the fragments
+            y2f = r2(x)
+        assert float((y2 - y2f).abs().max()) <= 2e-6 * float(y2f.abs().max())
+
+
 def test_resample_click_and_minus_100_db_tone_in_one_chunk():
     """the block-floating scaling of the binary16-split resampler is weakest where ONE chunk holds a
     full-scale click AND a passage 100 dB below it: the chunk's power-of-two scale is set by the click, the quiet samples land

@@ -86,7 +86,7 @@ def test_abi_header_symbols_exported():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name)
-    assert L.aamd_abi_version() == 6
+    assert L.aamd_abi_version() == 7
 
 
 def test_mfcc_fixup_shares_partition_the_tiles():

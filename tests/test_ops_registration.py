@@ -105,7 +105,10 @@ def test_compiled_aamd_ops_have_fake_kernels():
         assert torch.ops.aamd.mel_spectrogram_db(w, win, tw, lo, wd, wt, None, None, 400, 160, 0, True, 0, 101, 1.0, 2.0, 10.0,
                                                  1e-10, 0.0, None, 1, 0).shape == (4, 101, 80)
         assert torch.ops.aamd.mfcc_dct(torch.empty(404, 80, device=dev), torch.empty(80, 40, device=dev), 2, None, 1, 80.0).shape == (404, 40)
-        assert torch.ops.aamd.resample(w, torch.empty(160, 815, device=dev), 441, 160, 187, 5805, None, 0).shape == (4, 5805)
+        assert torch.ops.aamd.resample(w, torch.empty(160, 815, device=dev), 441, 160, 187, 5805, None, 0, None).shape == (4, 5805)
+        fr = torch.ops.aamd.resample_frag_build(torch.empty(160, 815, device=dev), 441, 160, 187, [0] * 10, 448)    # 10 tiles x 14 steps x 2 x 1 KB
+        assert fr.shape == (10 * 14 * 2 * 64 * 4,)
+        assert torch.ops.aamd.resample(w, torch.empty(160, 815, device=dev), 441, 160, 187, 5805, [0] * 10, 448, fr).shape == (4, 5805)
         x3 = torch.empty(2, 3, 100, device=dev)
         assert torch.ops.aamd.lfilter(x3, torch.empty(1, 3, 3, device=dev), torch.empty(1, 3, 3, device=dev), 1, 1).shape == x3.shape
         assert torch.ops.aamd.fftconvolve(torch.empty(6, 100, device=dev), torch.empty(6, 7, device=dev), None, None, 6, 0, 106).shape == (6, 106)

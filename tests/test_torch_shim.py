@@ -21,7 +21,7 @@ SCHEMAS = {
     "mfcc_dct": "aamd::mfcc_dct(Tensor mel, Tensor dct_mat, int log_mode, Tensor? group_max, int vec_per_group, "
                 "float top_db) -> Tensor",
     "resample": "aamd::resample(Tensor wav, Tensor kernel, int orig, int new, int width, int out_len, int[]? band_tap_lo, "
-                "int tap_span) -> Tensor",
+                "int tap_span, Tensor? frag) -> Tensor",
     "lfilter": "aamd::lfilter(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, int n_stages, int clamp) -> Tensor",
     "fftconvolve": "aamd::fftconvolve(Tensor x, Tensor y, Tensor? x_row_of, Tensor? y_row_of, int rows, int start, "
                    "int out_len) -> Tensor",

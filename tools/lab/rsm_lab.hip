@@ -31,6 +31,24 @@ extern "C" int lab_rsm(const float* wav, const float* kernel, float* out, int64_
   g.orig = orig; g.new_ = new_; g.width = width; g.taps = 2 * width + orig;
   g.vec_in = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (row_stride % 4 == 0);
   g.vec_out = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (out_len % 4 == 0) && (new_ % 4 == 0);
+#if defined(LAB_RSM_FRAG)          /* prepared tap fragments (built once per process: the lab runs one filter) */
+  {
+    static uint32_t* frag = nullptr;
+    if (frag == nullptr) {
+      if (hipMalloc(reinterpret_cast<void**>(&frag), (size_t)rsm::frag_bytes(n_tiles, ks)) != hipSuccess) return -7;
+      rsm::Geom b = g;
+      for (int pt0 = 0; pt0 < n_tiles; pt0 += rsm::kMaxPhaseTiles) {
+        b.pt0 = pt0;
+        b.n_pt = n_tiles - pt0 < rsm::kMaxPhaseTiles ? n_tiles - pt0 : rsm::kMaxPhaseTiles;
+        for (int t = 0; t < b.n_pt; ++t) b.tap_lo[t] = tap_lo[pt0 + t];
+        const int n = b.n_pt * (ks / 8) * 64;
+        hipLaunchKernelGGL(rsm::frag_build_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, b, ks, kernel, frag);
+      }
+      if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -8;
+    }
+    g.frag = frag;
+  }
+#endif
   const int64_t nq = (out_len + new_ - 1) / new_;
   const int max_cw = rsm::max_compute_waves(ks);
   const size_t lds_cap = 160 * 1024;
