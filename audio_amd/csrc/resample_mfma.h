@@ -190,7 +190,7 @@ AAMD_HD int b_base64(const Geom& g, int grp, int h, int tap_lo, int ks, int shif
 // The f16 kernel's A operand of (phase tile pt, table step s, lane) is 8 binary16 hi parts + 8 lo parts of the taps
 // tap_lo[pt] + KS (lane >> 4) + 8 s + e of phase 16 pt + (lane & 15), scaled by 2^15: constants of the filter.  Every compute wave of
 // every workgroup used to form them in its prologue -- 224 scattered loads and 448 conversions per lane; the lab switch that skips
-// them says 0.557 -> 0.485 ms on the cfg3 shard (profiles/r05_m_rsm_lab_ablation.txt), 13 % of the launch.  Prepared ONCE per filter
+// them says 0.557 -> 0.485 ms on the cfg3 shard (profiles/r05_n_rsm_lab_ablation_prepared_fragments.txt), 13 % of the launch.  Prepared ONCE per filter
 // (frag_build_kernel, the host keeps the table with the tap tensor) they are 2 NS coalesced 16-byte loads per lane.  The table is in
 // natural step order; the 8-byte operand layout's rotated lane groups (b64_step) pick their rows from it.
 AAMD_HD int64_t frag_piece(int pt, int ns, int s, int hl, int lane) { return (((int64_t)pt * ns + s) * 2 + hl) * 64 + lane; }   // 16-B pieces
