@@ -269,6 +269,28 @@ AAMD_HD uint32_t pack_hl(float xs) {
   const uint16_t lo = f16_bits(xs - f16_value(hi));
   return (uint32_t)hi | ((uint32_t)lo << 16);
 }
+// The SAMPLES' split (round 5; the taps keep pack_hl): hi = the value with its mantissa CUT to binary16's 10 bits (one v_and_b32,
+// exact in binary16), lo = the remainder rounded to nearest -- so that ONE v_cvt_pk_f16_f32 (hi, lo) of gfx950 forms the packed dword:
+// 4 operations per sample (scale, and, subtract, convert-and-pack) instead of 6 (scale, convert, convert back, subtract, convert,
+// pack); the conversion is 16 % of a BASELINE config-3 launch.  The pair carries 2^-21 of the sample instead of 2^-22 (a cut hi leaves
+// a remainder twice as large), unbiased.  (The first build used v_cvt_pkrtz_f16_f32: a lo rounded towards zero is a BIAS that the
+// filter's DC gain adds up coherently -- one reference fixture failed its element-wise bound, 1.25e-7 of the peak.)
+AAMD_HD uint32_t pack_hl_cut(float xs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+  typedef float f2_ __attribute__((ext_vector_type(2)));
+  const float hi = __uint_as_float(__float_as_uint(xs) & 0xffffe000u);
+  const f2_ v = {hi, xs - hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2_));
+#else
+  uint32_t u;
+  std::memcpy(&u, &xs, 4);
+  u &= 0xffffe000u;
+  float hi;
+  std::memcpy(&hi, &u, 4);
+  return (uint32_t)f16_bits(hi) | ((uint32_t)f16_bits(xs - hi) << 16);
+#endif
+}
 constexpr int kTapShift = 15;                       // taps are scaled by 2^15
 // scale of a chunk from the bits of its largest |sample|: the largest scaled sample lies in [2^14, 2^15)
 AAMD_HD void chunk_scale(uint32_t max_bits, float& scale, float& inv) {
@@ -443,7 +465,11 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   unsigned* cnt = mx + 3;                              // [3]: loader waves whose raw samples and maximum are in LDS, monotonic
   auto pack4 = [](const F4& t, float scale) {
     u32x4 o;
+#if defined(AAMD_RSM_RNE_SAMPLES)    /* lab: the round-to-nearest split of the samples (6 operations each; the taps always use it) */
     o.x = pack_hl(t.x * scale); o.y = pack_hl(t.y * scale); o.z = pack_hl(t.z * scale); o.w = pack_hl(t.w * scale);
+#else
+    o.x = pack_hl_cut(t.x * scale); o.y = pack_hl_cut(t.y * scale); o.z = pack_hl_cut(t.z * scale); o.w = pack_hl_cut(t.w * scale);
+#endif
     return o;
   };
   // convert(k): raw image of chunk k -> packed dwords, in batches of kGrab x 64 pieces handed out by an LDS counter to whichever

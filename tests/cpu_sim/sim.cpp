@@ -841,7 +841,7 @@ int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t r
         for (float v : buf) { uint32_t u; std::memcpy(&u, &v, 4); u &= 0x7fffffffu; if (u > mxb) mxb = u; }
         chunk_scale(mxb, sc, inv);
         pk.resize(buf.size());
-        for (size_t i = 0; i < buf.size(); ++i) pk[i] = pack_hl(buf[i] * sc);
+        for (size_t i = 0; i < buf.size(); ++i) pk[i] = pack_hl_cut(buf[i] * sc);      // (the samples' 4-operation split; the taps: pack_hl)
       }
       for (int w = 0; w < g.n_pt * qg * g.rounds; ++w) {      // (rounds: the same wave, its next q-group)
         const int pt_l = w % g.n_pt, qgi = w / g.n_pt, pt = pt0 + pt_l, lo = g.tap_lo[pt_l];
