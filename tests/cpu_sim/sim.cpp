@@ -462,7 +462,7 @@ int sim_istft(const float* spec, const float* window, const float* tw, const flo
       for (int j = 0; j < span; ++j) {
         const int64_t i = ola_target(g, t0 * g.hop + j);
         if (i < 0) continue;
-        float v = ola_gather<float>(og, x, window, pb, j);
+        float v = ola_gather<float>(og, x, window, (int)nf, j);
         if (inv_env) v *= inv_env[i];
         out[row * g.length + i] += v;
       }

@@ -896,3 +896,26 @@ def test_mel400_tail_pools_hand_out_every_tile_once(nb, tpb, n_tiles, P):
         rc = f(nb, tpb, n_tiles, P, 12, 3, seed, visits.ctypes.data_as(C.c_void_p))
         assert rc == 0, rc
         assert (visits[:n_tiles] == 3).all() and (visits[n_tiles:] == 0).all()
+
+
+def test_sim_istft_odd_frame_count_does_not_leak_the_missing_partner_frame():
+    """Fuzz campaign seed 311 (round 5): n_fft = 200, hop = 100, 13 frames, length 1296.  The generic inverse packs two frames per
+    complex transform; behind an odd number of frames the last pair's partner is an all-zero spectrum, and its "samples" -- the
+    transform's rounding cross-talk from the real frame -- were overlap-added at full window weight into the last hop of the
+    row, where a hann window at hop = n_fft / 2 leaves an envelope of ~4e-5: 4e-4 of the peak on the row's last samples
+    (torch.istft: 3e-6).  The sum now stops at the last existing frame."""
+    n_fft, hop, L = 200, 100, 1296
+    g = torch.Generator().manual_seed(311)
+    x = (0.5 * torch.randn(3, L, generator=g)).double()
+    w = torch.hann_window(n_fft, dtype=torch.float64)
+    X = torch.stft(x, n_fft, hop, n_fft, w, center=True, pad_mode="reflect", return_complex=True)
+    T_ = X.shape[-1]
+    assert T_ % 2 == 1
+    ref = torch.istft(X, n_fft, hop, n_fft, w, True, False, True, L, False).numpy()
+    env = torch.nn.functional.conv_transpose1d(torch.ones(1, 1, T_, dtype=torch.float64), w.pow(2).view(1, 1, n_fft),
+                                               stride=hop).view(-1)[n_fft // 2: n_fft // 2 + L]
+    assert float(env.min()) < 1e-4                                    # the ill-conditioned tail is what this test is about
+    fm = X.transpose(-1, -2).contiguous().numpy().astype(np.complex64)
+    got = S.sim_istft(fm, w.float().numpy(), L, n_fft, hop, center=True, pad_mode="constant", scale=1.0,
+                      inv_env=(1.0 / env).float().numpy())
+    assert peak_rel_err(got, ref) <= 1e-5                             # (the complex64 spectrum itself limits it to ~3e-6)

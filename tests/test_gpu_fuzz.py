@@ -122,18 +122,31 @@ def test_fuzz_inverse_spectrogram_vs_aten_istft(seed):
     x = (0.5 * torch.randn(3, L, generator=g)).cuda()
     s = T.Spectrogram(n_fft=n_fft, win_length=win_length, hop_length=hop, power=None, normalized=normalized).cuda()
     inv = T.InverseSpectrogram(n_fft=n_fft, win_length=win_length, hop_length=hop, normalized=normalized).cuda()
+    w = torch.hann_window(win_length, dtype=torch.float64).cuda()
     with torch.no_grad():
         X = s(x)
-        got = inv(X, L if use_length else None)
-    w = torch.hann_window(win_length, dtype=torch.float64).cuda()
-    Xs = X.to(torch.complex128)
-    if normalized == "window":
-        Xs = Xs * w.pow(2).sum().sqrt()
-    elif normalized == "frame_length":
-        Xs = Xs * math.sqrt(n_fft)
+        Xs = X.to(torch.complex128)
+        if normalized == "window":
+            Xs = Xs * w.pow(2).sum().sqrt()
+        elif normalized == "frame_length":
+            Xs = Xs * math.sqrt(n_fft)
+        try:
+            got = inv(X, L if use_length else None)
+        except RuntimeError as e:
+            # a window / hop pair whose envelope has a zero inside the row (hop = n_fft // 3 with a 0.75 n_fft window): aten::istft
+            # refuses it with the same message (SpectralOps.cpp: "window overlap add min: 1"), and so must the call on its own input
+            assert "window overlap add min" in str(e)
+            with pytest.raises(RuntimeError, match="window overlap add min"):
+                torch.istft(Xs, n_fft, hop, win_length, w, True, False, True, L if use_length else None, False)
+            return
     ref = torch.istft(Xs, n_fft, hop, win_length, w, True, False, True, L if use_length else None, False)
     assert got.shape == ref.shape
-    assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= 2e-5, (n_fft, hop, win_length, normalized, L, use_length)
+    # yardstick: the float64 result; where a row ENDS inside the last frame's taper the envelope sum_t w^2 is tiny there (1e-7 for a
+    # zero-padded window) and ANY float32 evaluation is amplified by 1 / w -- aten's own float32 istft on the same spectrum sets the
+    # bar for those samples (fuzz campaign seeds 311 / 429, round 5)
+    ref32 = torch.istft(Xs.to(torch.complex64), n_fft, hop, win_length, w.float(), True, False, True, L if use_length else None, False)
+    bar = max(2e-5, 4.0 * peak_rel_err(ref32.double().cpu().numpy(), ref.cpu().numpy()))
+    assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= bar, (n_fft, hop, win_length, normalized, L, use_length, bar)
 
 
 @pytest.mark.parametrize("seed", range(16))

@@ -1573,3 +1573,27 @@ def test_mel400_tail_pools_are_bit_identical_to_static_runs_and_reset_themselves
                     outs.append(m(x))
         torch.cuda.synchronize()
         assert all(torch.equal(o, ref) for o in outs)
+
+
+def test_inverse_spectrogram_odd_frame_count_low_envelope_tail():
+    """Fuzz campaign seed 311 (round 5; the CPU replay of the same case is in tests/test_cpu_sim.py): behind an odd number of frames
+    the generic inverse STFT overlap-added the rounding cross-talk of the last pair's missing partner frame at full window weight;
+    where the envelope is ~4e-5 (hann, hop = n_fft / 2, a length that ends inside the last frame's taper) that was 2e-4 of the
+    peak against 5e-6 for torch.istft.  Every size family of the inverse (generic 200 / 96 / 600, wave FFT 256 / 1024, n_fft = 400)."""
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(311)
+    for n_fft in (200, 96, 600, 256, 1024, 400):
+        hop = n_fft // 2
+        L = 11 * hop + int(round(0.975 * n_fft)) + 1          # 13 frames; the row ends where the last frame's window is ~6e-3
+        x = (0.5 * torch.randn(3, L, generator=g)).cuda()
+        s = T.Spectrogram(n_fft=n_fft, hop_length=hop, power=None).cuda()
+        inv = T.InverseSpectrogram(n_fft=n_fft, hop_length=hop).cuda()
+        with torch.no_grad():
+            X = s(x)
+            got = inv(X, L)
+        assert X.shape[-1] % 2 == 1, (n_fft, X.shape)
+        w = torch.hann_window(n_fft, dtype=torch.float64).cuda()
+        ref = torch.istft(X.to(torch.complex128), n_fft, hop, n_fft, w, True, False, True, L, False)
+        ref32 = torch.istft(X, n_fft, hop, n_fft, w.float(), True, False, True, L, False)      # aten's float32 path: the yardstick
+        bar = max(2e-5, 4.0 * peak_rel_err(ref32.double().cpu().numpy(), ref.cpu().numpy()))
+        assert peak_rel_err(got.cpu().numpy(), ref.cpu().numpy()) <= bar, (n_fft, bar)
