@@ -71,6 +71,53 @@ def test_fuzz_spectrogram_family_vs_aten_stft(seed):
     assert e <= 2e-5, (cfg, e)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_long_window_spectrogram_and_inverse_vs_aten(seed):
+    """Round 5: windows of 4 096 .. 8 192 samples -- the generic kernels' full LDS layout up to ~5 740, their long-window layout
+    (twiddles from memory, csrc/stft_generic.h gen_lds_floats_long) beyond, the register FFT at 4 096 is not involved (its sizes
+    end at 2 048) -- forward against aten::stft in float64, inverse against aten::istft (its float32 path as the yardstick where
+    a row ends inside a taper)."""
+    import audio_amd.transforms as T
+    r = _rng(7000 + seed)
+    n_fft = int(r.choice([4096, 5000, 5740, 5742, 6000, 6400, 7000, 7200, 8192, 8192, 8190]))
+    win_length = n_fft if r.random() < 0.6 else int(r.integers(n_fft // 2, n_fft + 1))
+    hop = int(r.choice([n_fft // 4, n_fft // 2, n_fft // 3, int(r.integers(1, n_fft + 1))]))
+    center = bool(r.random() < 0.8)
+    pad_mode = str(r.choice(["reflect", "reflect", "constant", "replicate", "circular"]))
+    power = [2.0, 1.0, None, None][int(r.integers(0, 4))]
+    normalized = [False, True, "window", "frame_length"][int(r.integers(0, 4))]
+    L = int(r.integers(n_fft + 1, 5 * n_fft))
+    g = torch.Generator().manual_seed(seed)
+    xc = (0.5 * torch.randn(2, L, generator=g)).clamp_(-1, 1).cuda()
+    w = torch.hann_window(win_length, dtype=torch.float64).cuda()
+    wfn = (lambda n, _w=w: _w.float().cpu())
+    t = T.Spectrogram(n_fft=n_fft, win_length=win_length, hop_length=hop, power=power, normalized=normalized, center=center,
+                      pad_mode=pad_mode, window_fn=wfn).cuda()
+    with torch.no_grad():
+        got = t(xc)
+    ref = torch.stft(xc.double(), n_fft, hop, win_length, w, center, pad_mode, False, True, return_complex=True)
+    if normalized is True or normalized == "window":
+        ref = ref / w.pow(2).sum().sqrt()
+    elif normalized == "frame_length":
+        ref = ref / math.sqrt(n_fft)
+    cfg = dict(n_fft=n_fft, wl=win_length, hop=hop, center=center, pad_mode=pad_mode, power=power, norm=normalized, L=L)
+    assert got.shape == ref.shape, cfg
+    if power is None:
+        e = peak_rel_err(torch.view_as_real(got).cpu().numpy(), torch.view_as_real(ref).cpu().numpy())
+    else:
+        e = peak_rel_err(got.double().pow(2.0 / power).cpu().numpy(), ref.abs().pow(2.0).cpu().numpy())
+    assert e <= 2e-5, (cfg, e)
+    if power is None and center and hop <= win_length // 2:          # a complex spectrogram the inverse can take (NOLA holds)
+        inv = T.InverseSpectrogram(n_fft=n_fft, win_length=win_length, hop_length=hop, normalized=normalized, window_fn=wfn).cuda()
+        with torch.no_grad():
+            back = inv(got, L)
+        refc = ref * (w.pow(2).sum().sqrt() if normalized in (True, "window") else math.sqrt(n_fft) if normalized == "frame_length" else 1.0)
+        want = torch.istft(refc, n_fft, hop, win_length, w, True, False, True, L, False)
+        want32 = torch.istft(refc.to(torch.complex64), n_fft, hop, win_length, w.float(), True, False, True, L, False)
+        bar = max(2e-5, 4.0 * peak_rel_err(want32.double().cpu().numpy(), want.cpu().numpy()))
+        assert peak_rel_err(back.cpu().numpy(), want.cpu().numpy()) <= bar, (cfg, bar)
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_fuzz_melspectrogram_and_mfcc_vs_aten(seed):
     import audio_amd.transforms as T
