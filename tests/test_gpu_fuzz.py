@@ -251,6 +251,10 @@ def test_fuzz_lfilter_vs_oracle(seed):
         A = np.stack([a * (1 + 0.01 * i) for i in range(nf)])
         B = np.stack([b * (1 - 0.02 * i) for i in range(nf)])
         A[:, 0] = a[0]
+        # (scaling a[1:] moves the poles: at order 8 a 2 % change can push one outside the unit circle -- campaign seed 704 drew a row
+        # with a pole at radius 1.07, whose float64 output reaches 1e151: nothing to compare.  Such draws keep the unperturbed a.)
+        if max(float(np.abs(np.roots(np.asarray(row, dtype=np.float32).astype(np.float64))).max()) for row in A) >= 0.97:
+            A = np.stack([a for _ in range(nf)])
     else:
         A, B = a, b
     with torch.no_grad():
