@@ -6,9 +6,10 @@ Runs only in the build container (the GPU box has no /root/reference); needs no 
     python tools/cpu_fuzz_vs_reference.py istft 0 400      # generic / wave-FFT / run-based / n_fft = 400 inverse STFT vs torch.istft (float64)
     python tools/cpu_fuzz_vs_reference.py kaldi 0 150      # kaldi.{spectrogram, fbank, mfcc} replay vs torchaudio.compliance.kaldi
     python tools/cpu_fuzz_vs_reference.py resample 0 60    # matrix-core resampler replay (4-byte and 8-byte layouts) vs F.resample
+    python tools/cpu_fuzz_vs_reference.py lfilter 0 150    # scan and wave-per-sequence IIR replays (orders 1 .. 8, cascades) vs the float64 oracle
 
 Round 5 (after the GPU fuzz campaign had found the odd-frame-count bug of the generic inverse, profiles/r05_w_fuzz_campaign.txt):
-istft 399 cases, kaldi 145 cases, resample 71 cases (both layouts) -- 0 failures (the resampler within 1.3e-5 of the reference's
+istft 399 cases, kaldi 145 cases, resample 71 cases (both layouts), lfilter 304 cases -- 0 failures (the resampler within 1.3e-5 of the reference's
 float32 result, which is itself 2e-5 from its own float64 result: F.resample evaluates its kernel in the waveform's dtype; the
 script's 1e-5 line flags those, they are not failures)."""
 import math
@@ -167,5 +168,58 @@ def fuzz_resample(first, last):
     for b in bad[:15]: print(b)
 
 
+def fuzz_lfilter(first, last):
+    import sim_util as S
+    from oracle import dsp_oracle as O
+    bad = []; n = 0
+    t0 = time.time()
+    for seed in range(first, last):
+        r = np.random.default_rng(30000 + seed)
+        order = int(r.choice([1, 2, 2, 2, 3, 4, 6, 8]))
+        stages = int(r.choice([1, 1, 2, 4])) if order <= 2 else 1
+        ch = int(r.choice([1, 2, 3]))
+        rows = ch if r.random() < 0.5 else 1
+        A = np.zeros((stages, rows, order + 1)); B = np.zeros((stages, rows, order + 1))
+        for s in range(stages):
+            for c in range(rows):
+                poles = []
+                while len(poles) < order:
+                    if order - len(poles) >= 2 and r.random() < 0.7:
+                        rad, th = r.uniform(0.2, 0.93), r.uniform(0.05, 3.1)
+                        poles += [rad * np.exp(1j * th), rad * np.exp(-1j * th)]
+                    else:
+                        poles.append(r.uniform(-0.9, 0.9))
+                a0 = r.uniform(0.5, 2.0)
+                A[s, c] = np.real(np.poly(poles)) * a0
+                B[s, c] = r.uniform(-0.5, 0.5, size=order + 1) * a0
+        clamp = bool(r.random() < 0.5)
+        batch = int(r.choice([1, 2, 3]))
+        L = int(r.choice([17, 100, 2047, 2048, 2049, 5000, 8193, 20000, 33000]))
+        x = (r.uniform(0.05, 0.6) * r.standard_normal((batch, ch, L))).astype(np.float32)
+        A32, B32 = A.astype(np.float32), B.astype(np.float32)
+        # float64 oracle, stage by stage with the float32-rounded coefficients
+        ref = x.astype(np.float64)
+        for s in range(stages):
+            ref = np.stack([O.lfilter(ref[:, c], A32[s, c if rows > 1 else 0].astype(np.float64), B32[s, c if rows > 1 else 0].astype(np.float64), clamp=clamp) for c in range(ch)], axis=1)
+        # (a clamped output is judged against the UNCLAMPED peak: a filter with gain 200 leaves, between its clipped stretches, samples whose
+        # float32 rounding is 1e-7 of 200, not of 1)
+        ref_u = x.astype(np.float64)
+        for s in range(stages):
+            ref_u = np.stack([O.lfilter(ref_u[:, c], A32[s, c if rows > 1 else 0].astype(np.float64), B32[s, c if rows > 1 else 0].astype(np.float64), clamp=False) for c in range(ch)], axis=1)
+        pk = max(float(np.abs(ref).max()), float(np.abs(ref_u).max()) if stages == 1 else 0.0, 1e-30)
+        tol = 1e-4 if order <= 2 else 5e-4
+        got = S.sim_lfilter(x, A32, B32, clamp)
+        e = float(np.abs(got - ref).max()) / pk; n += 1
+        if not np.isfinite(got).all() or e > tol: bad.append((seed, "scan", order, stages, rows, ch, clamp, batch, L, e))
+        if order <= 2:
+            for waves in (1, int(r.choice([2, 4, 16]))):
+                rc, gw = S.sim_lfilter_wave(x, A32, B32, clamp, waves)
+                if rc != 0: continue
+                e = float(np.abs(gw - ref).max()) / pk; n += 1
+                if np.isnan(gw).any() or e > tol: bad.append((seed, "wave%d" % waves, order, stages, rows, ch, clamp, batch, L, e))
+    print("cases", n, "bad", len(bad), "time %.0f s" % (time.time() - t0))
+    for b in bad[:15]: print(b)
+
+
 if __name__ == "__main__":
-    {"istft": fuzz_istft, "kaldi": fuzz_kaldi, "resample": fuzz_resample}[sys.argv[1]](int(sys.argv[2]), int(sys.argv[3]))
+    {"istft": fuzz_istft, "kaldi": fuzz_kaldi, "resample": fuzz_resample, "lfilter": fuzz_lfilter}[sys.argv[1]](int(sys.argv[2]), int(sys.argv[3]))
