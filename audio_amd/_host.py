@@ -88,7 +88,7 @@ def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sampl
     falling = (-1.0 * dist[:, :-2]) / gaps[:-1]
     rising = dist[:, 2:] / gaps[1:]
     fb = torch.max(torch.zeros(1), torch.min(falling, rising))
-    if norm == "slaney":
+    if norm is not None and norm == "slaney":       # (written with the refinement TorchScript needs for an Optional[str])
         fb *= (2.0 / (edges_hz[2:n_mels + 2] - edges_hz[:n_mels])).unsqueeze(0)
     if (fb.max(dim=0).values == 0.0).any():
         warnings.warn(

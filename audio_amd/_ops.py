@@ -40,11 +40,48 @@ _DEF.define("fftconvolve(Tensor x, Tensor y, str mode) -> Tensor")
 _DEF.define("phase_vocoder(Tensor complex_specgrams, float rate, Tensor phase_advance) -> Tensor")
 _DEF.define("griffinlim(Tensor specgram, Tensor window, int n_fft, int hop_length, int win_length, float power, int n_iter, "
             "float momentum, int? length, bool rand_init) -> Tensor")
+# round 6: the rest of the public surface, so that every scripted front of functional.py / transforms.py is one operator
+_DEF.define("mel_scale(Tensor specgram, Tensor fb) -> Tensor")
+_DEF.define("resample(Tensor waveform, int orig_freq, int new_freq, int lowpass_filter_width, float rolloff, "
+            "str resampling_method, float? beta) -> Tensor")
+_DEF.define("pitch_shift(Tensor waveform, int sample_rate, int n_steps, int bins_per_octave, int n_fft, int? win_length, "
+            "int? hop_length, Tensor? window) -> Tensor")
+_DEF.define("biquad(Tensor waveform, float b0, float b1, float b2, float a0, float a1, float a2) -> Tensor")
+_DEF.define("filtfilt(Tensor waveform, Tensor a_coeffs, Tensor b_coeffs, bool clamp) -> Tensor")
+_DEF.define("designed_biquad(Tensor waveform, str kind, int sample_rate, float[] params, bool flag) -> Tensor")
+_DEF.define("mfcc_module(Tensor waveform, Tensor window, Tensor fb, Tensor dct_mat, int pad, int n_fft, int hop_length, "
+            "int win_length, float power, int norm_mode, bool center, str pad_mode, bool log_mels, float top_db, "
+            "float multiplier, float amin, float db_multiplier, int fused, int state) -> Tensor")
 _DEF.define("rnnt_features(Tensor waveform, Tensor window, Tensor fb, int n_fft, int hop_length, float gain, Tensor mean, "
             "Tensor invstddev, int right_padding) -> Tensor")
 
 _CUDA = torch.library.Library("audio_amd", "IMPL", "CUDA")
 _META = torch.library.Library("audio_amd", "IMPL", "Meta")
+_AUTOGRAD = torch.library.Library("audio_amd", "IMPL", "AutogradCUDA")
+
+
+def _plain_tensor_wants_grad(a) -> bool:
+    # (`type(a) is Tensor`: fake / functional tensors of a tracer never take the Python implementation -- they go on to the
+    # Meta kernel exactly as before the autograd route existed)
+    return type(a) is Tensor and a.requires_grad
+
+
+def _register(name: str, fn) -> None:
+    """CUDA-key kernel = the eager implementation.  The AutogradCUDA kernel makes a SCRIPTED call differentiable the way the
+    eager call is (the reference's scripted modules are: they are aten compositions): when autograd is recording and an
+    argument asks for a gradient the implementation runs right there, at the autograd level, and its own autograd Functions
+    (F._SpectrogramFunction, _LFilterFunction, ...) record the graph; every other call goes below autograd to the CUDA /
+    Meta kernel."""
+    _CUDA.impl(name, fn)
+    op = getattr(torch.ops.audio_amd, name).default
+
+    def at_autograd_level(*args):
+        if torch.is_grad_enabled() and any(_plain_tensor_wants_grad(a) for a in args):
+            return fn(*args)
+        with torch._C._AutoDispatchBelowAutograd():
+            return op(*args)
+
+    _AUTOGRAD.impl(name, at_autograd_level)
 
 
 def _spectrogram(waveform, window, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode, onesided):
@@ -70,17 +107,38 @@ def _inverse_spectrogram(spectrogram, length, window, pad, n_fft, hop_length, wi
                                  center, pad_mode, onesided)
 
 
-_CUDA.impl("spectrogram", _spectrogram)
-_CUDA.impl("inverse_spectrogram", _inverse_spectrogram)
-_CUDA.impl("mel_spectrogram", _mel_spectrogram)
-_CUDA.impl("mfcc", _mfcc)
-_CUDA.impl("amplitude_to_DB", F.amplitude_to_DB)
-_CUDA.impl("resample_apply", F._apply_sinc_resample_kernel)
-_CUDA.impl("lfilter", F.lfilter)
-_CUDA.impl("lfilter_cascade", F.biquad_cascade)
-_CUDA.impl("fftconvolve", F.fftconvolve)
-_CUDA.impl("phase_vocoder", F.phase_vocoder)
-_CUDA.impl("griffinlim", F.griffinlim)
+def _mel_spectrogram_module(waveform, window, fb, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode):
+    return F._melspectrogram_module(waveform, window, fb, pad, n_fft, hop_length, win_length, power, _NORM[norm_mode], center,
+                                    pad_mode)
+
+
+def _mfcc_module(waveform, window, fb, dct_mat, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode,
+                 log_mels, top_db, multiplier, amin, db_multiplier, fused, state):
+    return F._mfcc_module(waveform, window, fb, dct_mat, pad, n_fft, hop_length, win_length, power, _NORM[norm_mode], center,
+                          pad_mode, log_mels, top_db, (multiplier, amin, db_multiplier), fused,
+                          F._mfcc_state_of(state) if fused else None)
+
+
+_register("spectrogram", _spectrogram)
+_register("inverse_spectrogram", _inverse_spectrogram)
+_register("mel_spectrogram", _mel_spectrogram_module)
+_register("mfcc", _mfcc)
+_register("amplitude_to_DB", F.amplitude_to_DB)
+_register("resample_apply", F._apply_sinc_resample_kernel)
+_register("lfilter", F.lfilter)
+_register("lfilter_cascade", F.biquad_cascade)
+_register("fftconvolve", F.fftconvolve)
+_register("phase_vocoder", F.phase_vocoder)
+_register("griffinlim", F.griffinlim)
+
+
+_register("mfcc_module", _mfcc_module)
+_register("mel_scale", F.mel_scale)
+_register("resample", F.resample)
+_register("pitch_shift", F.pitch_shift)
+_register("biquad", F.biquad)
+_register("filtfilt", F.filtfilt)
+_register("designed_biquad", F._designed_biquad)
 
 
 def _rnnt_features(waveform, window, fb, n_fft, hop_length, gain, mean, invstddev, right_padding):
@@ -88,7 +146,7 @@ def _rnnt_features(waveform, window, fb, n_fft, hop_length, gain, mean, invstdde
     return out.view(tuple(waveform.shape[:-1]) + out.shape[-2:])
 
 
-_CUDA.impl("rnnt_features", _rnnt_features)
+_register("rnnt_features", _rnnt_features)
 
 
 # ---- Meta implementations: shapes / strides only ---------------------------------------------
@@ -175,6 +233,31 @@ def _rnnt_features_meta(waveform, window, fb, n_fft, hop_length, gain, mean, inv
     return waveform.new_empty(tuple(waveform.shape[:-1]) + (T + right_padding, fb.shape[1]), dtype=torch.float32)
 
 
+def _mfcc_module_meta(waveform, window, fb, dct_mat, pad, n_fft, hop_length, win_length, power, norm_mode, center, pad_mode,
+                      log_mels, top_db, multiplier, amin, db_multiplier, fused, state):
+    return _frame_major_view(waveform, dct_mat.shape[1], _stft_frames(waveform.shape[-1], pad, n_fft, hop_length, center))
+
+
+def _mel_scale_meta(specgram, fb):
+    lead, T = tuple(specgram.shape[:-2]), specgram.shape[-1]
+    return specgram.new_empty(lead + (T, fb.shape[1])).transpose(-1, -2)
+
+
+def _resample_full_meta(waveform, orig_freq, new_freq, lowpass_filter_width, rolloff, resampling_method, beta):
+    if orig_freq == new_freq:
+        return waveform
+    g = math.gcd(int(orig_freq), int(new_freq))
+    return _resample_meta(waveform, None, orig_freq, new_freq, g, 0)
+
+
+_same_as_waveform = lambda waveform, *rest: torch.empty_like(waveform)        # noqa: E731
+_META.impl("mfcc_module", _mfcc_module_meta)
+_META.impl("mel_scale", _mel_scale_meta)
+_META.impl("resample", _resample_full_meta)
+_META.impl("pitch_shift", _same_as_waveform)
+_META.impl("biquad", _same_as_waveform)
+_META.impl("filtfilt", _same_as_waveform)
+_META.impl("designed_biquad", _same_as_waveform)
 _META.impl("inverse_spectrogram", _inverse_spectrogram_meta)
 _META.impl("phase_vocoder", _phase_vocoder_meta)
 _META.impl("griffinlim", _griffinlim_meta)
