@@ -124,7 +124,13 @@ _register("inverse_spectrogram", _inverse_spectrogram)
 _register("mel_spectrogram", _mel_spectrogram_module)
 _register("mfcc", _mfcc)
 _register("amplitude_to_DB", F.amplitude_to_DB)
-_register("resample_apply", F._apply_sinc_resample_kernel)
+def _resample_apply(waveform, kernel, orig_freq, new_freq, gcd, width):
+    # (the schema puts the tap table second; until round 6 the function itself was registered and received the arguments in the
+    # wrong order -- found by the first scripted Resample that ran on a device, tests/test_torchscript.py)
+    return F._apply_sinc_resample_kernel(waveform, orig_freq, new_freq, gcd, kernel, width)
+
+
+_register("resample_apply", _resample_apply)
 _register("lfilter", F.lfilter)
 _register("lfilter_cascade", F.biquad_cascade)
 _register("fftconvolve", F.fftconvolve)

@@ -362,8 +362,21 @@ AAMD_HD void mid_mac(int tid, const C32 (&h)[8], const C32 (&z)[8], C32 (&acc)[8
     }
   }
 }
-// tap spectra in the thread-owned layout: complex index ((p * 8 + i) * 1024 + tid) of a y row's table
-AAMD_HD int64_t h_index(int p, int i, int tid) { return ((int64_t)p * 8 + i) * kThreads + tid; }
+// tap spectra in the thread-owned layout.  AAMD_FDR_H16 = 0: complex index ((p * 8 + i) * 1024 + tid) of a y row's table -- eight
+// coalesced 8-byte loads per partition and thread; 1 (round 6): bins i and i + 1 of a thread lie side by side,
+// ((p * 4 + i / 2) * 1024 + tid) * 2 + (i & 1) -- four 16-byte loads: the 192 KB of tap spectra a step reads are a throughput cost
+// of the vector-memory path (the kernel without them ran 13 % faster, profiles/r05_c_fdr_lab_barriers_hloads.txt), and an 8-byte
+// access moves bytes at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH.md)
+#ifndef AAMD_FDR_H16
+#define AAMD_FDR_H16 1
+#endif
+AAMD_HD int64_t h_index(int p, int i, int tid) {
+#if AAMD_FDR_H16
+  return (((int64_t)p * 4 + (i >> 1)) * kThreads + tid) * 2 + (i & 1);
+#else
+  return ((int64_t)p * 8 + i) * kThreads + tid;
+#endif
+}
 constexpr int64_t kHPerPart = 8 * kThreads;            // complex numbers per partition (= 8192)
 
 // ---- geometry --------------------------------------------------------------------------------------------------------
@@ -634,6 +647,17 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
         // ONE scalar base (the row's table) + a 32-bit vector byte offset per load: global_load_dwordx2 v, v_off, s[base].
         // Left to itself the compiler forms eight 64-bit vector addresses per partition (16 registers and 16 carry chains)
         // or, with per-load scalar bases, hoists 24 base pairs out of the step loop and spills scalar registers.
+#if AAMD_FDR_H16
+        const unsigned off = (unsigned)fco::opaque(tid) * 16u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned o = off + (unsigned)((p * 4 + i) * kThreads * 16);
+          asm volatile("" : "+v"(o));
+          const F4 q = *reinterpret_cast<const F4*>(reinterpret_cast<const char*>(Hr) + o);
+          h0[2 * i] = C32{q.x, q.y};
+          h0[2 * i + 1] = C32{q.z, q.w};
+        }
+#else
         const unsigned off = (unsigned)fco::opaque(tid) * (unsigned)sizeof(C32);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -641,6 +665,7 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
           asm volatile("" : "+v"(o));
           h0[i] = *reinterpret_cast<const C32*>(reinterpret_cast<const char*>(Hr) + o);
         }
+#endif
 #ifdef AAMD_FDR_LAB_NOH
 #pragma unroll
         for (int i = 0; i < 8; ++i) h0[i] = C32{1.0f + (float)i, 0.5f};

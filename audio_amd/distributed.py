@@ -60,6 +60,24 @@ def shard_range(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
+_PRIMED_GROUPS: set = set()
+
+
+def _prime_group(device, group=None) -> None:
+    """The first operation of a process group on RCCL must be entered by EVERY rank of the group (the communicator is built
+    inside it); a ragged split leaves ranks with an empty shard out of the batched point-to-point exchange below, which is
+    undefined as a group's first operation.  One 4-byte all-reduce per group, once, builds the communicator with
+    everybody present; gloo needs nothing."""
+    if dist.get_backend(group) != "nccl":
+        return
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    key = (id(pg), pg.size(), pg.rank())         # (a re-initialised default group is another object)
+    if key in _PRIMED_GROUPS:
+        return
+    dist.all_reduce(torch.zeros(1, dtype=torch.float32, device=device), group=group)
+    _PRIMED_GROUPS.add(key)
+
+
 def scatter_batch(batch: Optional[Tensor], shape: Tuple[int, ...], device, root: int = 0, group=None,
                   dtype=torch.float32) -> Tensor:
     """Rank ``root`` holds ``batch`` of ``shape`` (leading dim = rows to shard); every rank returns its
@@ -68,6 +86,7 @@ def scatter_batch(batch: Optional[Tensor], shape: Tuple[int, ...], device, root:
     lo, hi = shard_range(shape[0], world, rank)
     if world == 1:
         return batch.to(device)
+    _prime_group(device, group)
     local = torch.empty((hi - lo,) + tuple(shape[1:]), dtype=dtype, device=device)
     # ONE batch of point-to-point operations per rank (dist.batch_isend_irecv = one ncclGroupStart / End on RCCL): the root's
     # sends to its world - 1 peers leave over their own xGMI links concurrently instead of one isend after the other on the
@@ -94,6 +113,7 @@ def gather_batch(local: Tensor, n_rows: int, root: int = 0, group=None) -> Optio
     if world == 1:
         return local
     local = local.contiguous()
+    _prime_group(local.device, group)
     if rank == root:
         out = torch.empty((n_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         ops = []

@@ -86,6 +86,10 @@ def _reduced_precision_io(fn):
 
         def widen(a):
             if isinstance(a, Tensor) and (a.dtype in LOW_PRECISION):
+                if a is not first and not a.requires_grad:
+                    # a constant of a module cast with .half() (window, filterbank, tap table): widened ONCE per tensor, so that
+                    # what is derived from it (band tables, prepared tap fragments) is found again on the next call
+                    return _tensor_cached(a, "widened_f32", lambda: a.float())
                 return a.float()
             if isinstance(a, Tensor) and a.dtype == torch.complex32:
                 return a.to(torch.complex64)
@@ -157,6 +161,16 @@ def _cached(key, make):
     return v
 
 
+def _drop_dead_slot(tid: int, ref) -> None:
+    """Weak-reference callback of `_tensor_cached`: the tensor object is gone, so is everything derived from it (the
+    slots of dead tensors -- prepared fftconvolve workspaces of up to 64 MiB among them -- used to wait for their id to be
+    reused or for the dictionary to pass 512 entries)."""
+    with _CACHE_LOCK:
+        slot = _TENSOR_CACHE.get(tid)
+        if slot is not None and slot[0] is ref:
+            del _TENSOR_CACHE[tid]
+
+
 def _tensor_cached(t: Tensor, key, make, replace: bool = False):
     """Cache a constant derived from tensor `t` (window / fb buffers).  The slot is found by
     object id but is only trusted while its weak reference still resolves to `t` itself, so a
@@ -172,7 +186,7 @@ def _tensor_cached(t: Tensor, key, make, replace: bool = False):
             if len(_TENSOR_CACHE) > 512:
                 for kk in [kk for kk, sl in _TENSOR_CACHE.items() if sl[0]() is None]:
                     del _TENSOR_CACHE[kk]
-            slot = (weakref.ref(t), {})
+            slot = (weakref.ref(t, lambda r, tid=tid: _drop_dead_slot(tid, r)), {})
             _TENSOR_CACHE[tid] = slot
         v = None if replace else slot[1].get(k)
         if v is not None:
@@ -1489,7 +1503,9 @@ def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new
     # stream and synchronised once, so that any later stream may read them; not under graph capture (memory of a capture's
     # private pool must not outlive the graph): such a call forms the fragments in the kernel, with identical results
     frag = None
-    if _host._rs_pick_ks(int(span)) != 0 and not torch.cuda.is_current_stream_capturing():
+    with torch.cuda.device(x2.device):               # (the capture status is per device: ask the one the data lives on)
+        capturing = torch.cuda.is_current_stream_capturing()
+    if _host._rs_pick_ks(int(span)) != 0 and not capturing:
         def _frag():
             L = _lib.lib()
             bands = _lib.ResampleBands(tap_lo.shape[0], span, tap_lo.ctypes.data_as(C.POINTER(C.c_int32)))
@@ -1501,9 +1517,18 @@ def _polyphase(x2: Tensor, kern: Tensor, key_tensor: Tensor, key, orig: int, new
                     t = torch.empty((nb // 4,), dtype=torch.float32, device=x2.device)
                     _lib.check(L.aamd_resample_frag_build_f32(kern.data_ptr(), orig, new, width, C.byref(bands), t.data_ptr(),
                                                               _lib.current_stream(x2.device)))
-                torch.cuda.current_stream(x2.device).synchronize()
-            return t
-        frag = _tensor_cached(key_tensor, ("rs_frag", key, orig, new, width, str(x2.device)), _frag)
+                # later calls may run on other streams: they wait for this event (device-side) until it has completed -- the host
+                # is not blocked (a blocking synchronize here cost a pipeline bubble per new tap table)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(x2.device))
+            return [t, ev, _lib.current_stream(x2.device)]
+        ent = _tensor_cached(key_tensor, ("rs_frag", key, orig, new, width, str(x2.device)), _frag)
+        frag = ent[0]
+        if ent[1] is not None:
+            if ent[1].query():
+                ent[1] = None                       # built long ago: nothing to order any more
+            elif _lib.current_stream(x2.device) != ent[2]:
+                torch.cuda.current_stream(x2.device).wait_event(ent[1])
     if ops is not None:
         if x2.stride(0) != length and rows > 1:
             x2 = x2.contiguous()
@@ -1998,11 +2023,26 @@ def _check_convolve_mode(mode: str) -> None:
 
 
 _FFTCONV_HELD_BYTES = 64 << 20       # largest workspace kept with a tap tensor (cfg5: 0.5 MiB per tap row)
+_FFTCONV_HELD_TOTAL = 512 << 20      # ... and of all kept workspaces together, per process
+_HELD_LIVE: list = []                # weak references to the live _HeldTaps (their bytes are summed when one more is asked for)
+
+
+def _held_taps_or_none(ws_bytes: int, dev):
+    """A workspace to keep with a tap tensor, or None when the process already keeps `_FFTCONV_HELD_TOTAL` bytes of them."""
+    with _CACHE_LOCK:
+        live = [r for r in _HELD_LIVE if r() is not None]
+        _HELD_LIVE[:] = live
+        if sum(r().ws.numel() * 4 for r in live) + ws_bytes > _FFTCONV_HELD_TOTAL:
+            return None
+    held = _HeldTaps(torch.empty((ws_bytes // 4 + 2,), dtype=torch.float32, device=dev))
+    with _CACHE_LOCK:
+        _HELD_LIVE.append(weakref.ref(held))
+    return held
 
 
 class _HeldTaps:
     """The prepared workspace of one (tap tensor, plan, stream): twiddles + tap spectra, read-only once `ready`."""
-    __slots__ = ("ws", "ready", "_claimed", "_lock")
+    __slots__ = ("ws", "ready", "_claimed", "_lock", "__weakref__")
 
     def __init__(self, ws: Tensor):
         self.ws, self.ready, self._claimed, self._lock = ws, False, False, threading.Lock()
@@ -2024,7 +2064,7 @@ def fftconvolve_held_taps(y: Tensor) -> int:
         return sum(1 for k, v in slot[1].items() if isinstance(v, _HeldTaps) and v.ready and k[1] == y._version)
 
 
-def _conv_slice(x: Tensor, y: Tensor, start: int, out_len: int) -> Tensor:
+def _conv_slice(x: Tensor, y: Tensor, start: int, out_len: int, hold: bool = True) -> Tensor:
     """out[..., i] = (x * y)[start + i], i in [0, out_len): a slice of the full linear convolution of the
     last dims, leading dims broadcast (forward-only launcher of aamd_fftconvolve_f32)."""
     nx, ny = x.size(-1), y.size(-1)
@@ -2069,17 +2109,25 @@ def _conv_slice(x: Tensor, y: Tensor, start: int, out_len: int) -> Tensor:
         # after the first skips the two preparation launches (aamd_fftconvolve_staged_f32; ~16 us of the config-5 shard's 0.79 ms).
         # Only where the workspace is read-only while the plan runs (plans 1 and 3), the taps are y (ny <= nx), nothing is being
         # captured (a replayed graph must not depend on host-side version checks) and the workspace is small.
+        # A workspace is kept only for a tap tensor that has SHOWN it is reused -- from the second call with the same
+        # (tensor object, version) on: a fresh RIR batch per step must not leave 64 MiB behind per step --, never for
+        # the flipped temporaries of the autograd backward (`hold=False`), and only while the process keeps less than
+        # `_FFTCONV_HELD_TOTAL` bytes of them; the slot goes when the tap tensor dies (`_drop_dead_slot`).
         held, stages = None, 3
-        if ws_bytes and ny <= nx and ws_bytes <= _FFTCONV_HELD_BYTES and not torch.cuda.is_current_stream_capturing():
+        if hold and ws_bytes and ny <= nx and ws_bytes <= _FFTCONV_HELD_BYTES and not torch.cuda.is_current_stream_capturing():
             plan = int(L.aamd_fftconvolve_plan(rows, nx, ny, out_len))
             if plan in (1, 3):
                 key = ("fftconv_ws", plan, ny, yr.shape[0], int(ws_bytes), _lib.current_stream(dev),
                        int(L.aamd_set_kernel_policy(-1)))
-                held = _tensor_cached(y, key, lambda: _HeldTaps(torch.empty((ws_bytes // 4 + 2,), dtype=torch.float32, device=dev)))
-                if held.ready:
-                    stages = 2
-                elif not held.claim():          # another thread is preparing this very workspace right now: use a private one
-                    held = None
+                seen = _tensor_cached(y, ("fftconv_seen",) + key[1:], lambda: [0])
+                seen[0] += 1
+                if seen[0] >= 2:
+                    held = _tensor_cached(y, key, lambda: _held_taps_or_none(int(ws_bytes), dev) or False) or None
+                if held is not None:
+                    if held.ready:
+                        stages = 2
+                    elif not held.claim():      # another thread is preparing this very workspace right now: use a private one
+                        held = None
         ws = held.ws if held is not None else torch.empty((ws_bytes // 4 + 2,), dtype=torch.float32, device=dev)
         if ops is not None:
             out = ops.fftconvolve_staged(xr, yr, xmap, ymap, rows, start, out_len, ws, stages)
@@ -2113,7 +2161,8 @@ class _FFTConvolveFunction(torch.autograd.Function):
         nx, ny = x.size(-1), y.size(-1)
         full = torch.nn.functional.pad(dz, (ctx.start, nx + ny - 1 - ctx.start - ctx.out_len))   # dz at offset `start`
         # create_graph=True: both adjoints are convolutions again -- apply them through this Function
-        conv = _FFTConvolveFunction.apply if torch.is_grad_enabled() else _conv_slice
+        # (the flipped operands are temporaries: nothing is kept with them)
+        conv = _FFTConvolveFunction.apply if torch.is_grad_enabled() else (lambda a, b, st, n: _conv_slice(a, b, st, n, hold=False))
         dx = dy = None
         if ctx.needs_input_grad[0]:
             dx = conv(full, y.flip(-1), ny - 1, nx).sum_to_size(x.shape)

@@ -307,10 +307,11 @@ def test_staged_fftconvolve_schema():
 @pytest.mark.parametrize("route", ["shim", "ctypes"])
 @pytest.mark.parametrize("taps", [700, 9000, 24000, 30000])
 def test_repeated_impulse_response_skips_the_preparation_and_stays_bit_identical(route, taps):
-    """The second call with the SAME tap tensor runs on the workspace the first call prepared (no twiddle / tap-spectrum
-    launches); its result is bit-identical to a call that prepares afresh (a clone of the taps), an in-place update of the
-    taps invalidates the held workspace; a workspace is held only for plans 1 and 3 (plan 2 keeps its delay-line ring there)
-    and only up to 64 MiB (30 000 taps: the workspace formula still reserves the complex-block rings)."""
+    """A tap tensor that is used AGAIN gets a workspace of its own on that second call (round 6: a tensor used once leaves
+    nothing behind), and from the third call on the transform runs on it without the twiddle / tap-spectrum launches; the results
+    are bit-identical to a call that prepares afresh (a clone of the taps), an in-place update of the taps invalidates the held
+    workspace; a workspace is held only for plans 1 and 3 (plan 2 keeps its delay-line ring there) and only up to 64 MiB
+    (30 000 taps: the workspace formula still reserves the complex-block rings)."""
     import audio_amd.functional as F
     from audio_amd import _lib
     g = torch.Generator().manual_seed(taps)
@@ -321,12 +322,14 @@ def test_repeated_impulse_response_skips_the_preparation_and_stays_bit_identical
         F._force_route(route)
         plan = _lib.lib().aamd_fftconvolve_plan(6, 70000, taps, 70000 + taps - 1)
         y1 = F.fftconvolve(x1, h)
+        assert F.fftconvolve_held_taps(h) == 0          # used once: nothing is kept
+        y2 = F.fftconvolve(x2, h)                       # used again: prepared into a workspace that stays with `h`
         held = F.fftconvolve_held_taps(h)
         ws_bytes = _lib.lib().aamd_fftconvolve_workspace(6, 6, 1, 70000, taps)
         assert held == (1 if plan in (1, 3) and ws_bytes <= F._FFTCONV_HELD_BYTES else 0)
-        y2 = F.fftconvolve(x2, h)                       # run-only on the held workspace
+        y2_run_only = F.fftconvolve(x2, h)              # run-only on the held workspace
         y2_fresh = F.fftconvolve(x2, h.clone())         # prepares again
-        assert torch.equal(y2, y2_fresh)
+        assert torch.equal(y2, y2_fresh) and torch.equal(y2_run_only, y2_fresh)
         y1_again = F.fftconvolve(x1, h)
         assert torch.equal(y1, y1_again)
         # against the float64 direct evaluation at a few output samples
@@ -351,10 +354,12 @@ def test_held_taps_are_per_stream_and_not_used_under_capture():
     x = (torch.rand(4, 50000, generator=g) - 0.5).cuda()
     h = (torch.randn(1, 12000, generator=g) * 0.02).cuda()
     y0 = F.fftconvolve(x, h)
+    y0 = F.fftconvolve(x, h)                            # (a workspace is kept from the second use on)
     assert F.fftconvolve_held_taps(h) == 1
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
+        y1 = F.fftconvolve(x, h)
         y1 = F.fftconvolve(x, h)                        # another stream: its own prepared workspace
     s.synchronize()
     assert F.fftconvolve_held_taps(h) == 2
@@ -374,3 +379,46 @@ def test_held_taps_are_per_stream_and_not_used_under_capture():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.allclose(yg, 0.5 * y0, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_tap_tensors_used_once_and_backward_temporaries_leave_no_workspace_behind():
+    """a fresh impulse-response batch per step, and the flipped operands of the autograd backward, must not
+    pin a prepared workspace each; the total kept per process is bounded."""
+    import gc
+    import audio_amd.functional as F
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(4, 60000, generator=g) - 0.5).cuda()
+    gc.collect()
+    live0 = sum(1 for r in F._HELD_LIVE if r() is not None)
+    for i in range(12):                                 # an augmentation loop: new taps every step
+        h = (torch.randn(1, 12000, generator=g) * 0.02).cuda()
+        F.fftconvolve(x, h)
+        assert F.fftconvolve_held_taps(h) == 0
+    xg = x.clone().requires_grad_(True)
+    hg = (torch.randn(1, 12000, generator=g) * 0.02).cuda().requires_grad_(True)
+    for _ in range(3):                                  # the same leaves every step: forward may keep, backward never does
+        F.fftconvolve(xg, hg).square().sum().backward()
+    del h
+    gc.collect()
+    live = sum(1 for r in F._HELD_LIVE if r() is not None)
+    assert live - live0 <= 1, (live0, live)             # at most the one workspace of the reused leaf `hg`
+    # the bound: with the total set below one workspace nothing more is kept
+    keep = F._FFTCONV_HELD_TOTAL
+    try:
+        F._FFTCONV_HELD_TOTAL = 0
+        h2 = (torch.randn(1, 12000, generator=g) * 0.02).cuda()
+        a = F.fftconvolve(x, h2)
+        b = F.fftconvolve(x, h2)
+        assert F.fftconvolve_held_taps(h2) == 0 and torch.equal(a, b)
+    finally:
+        F._FFTCONV_HELD_TOTAL = keep
+    # a dead tap tensor takes its slot (and its workspace) with it
+    h3 = (torch.randn(1, 12000, generator=g) * 0.02).cuda()
+    F.fftconvolve(x, h3)
+    F.fftconvolve(x, h3)
+    assert F.fftconvolve_held_taps(h3) == 1
+    tid = id(h3)
+    del h3
+    gc.collect()
+    assert tid not in F._TENSOR_CACHE
