@@ -12,6 +12,10 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaudio_amd.so")
+if os.environ.get("AAMD_USE_LAB_LIB"):
+    # tools/ only: the library with the tools-only kernel instantiations and their environment switches
+    # (python -m audio_amd._build --lab; see audio_amd/_build.py).  The product never sets this.
+    LIB_PATH = os.path.join(_HERE, "lib", "libaudio_amd_lab.so")
 
 AAMD_OK = 0
 PAD_MODES = {"reflect": 0, "constant": 1, "replicate": 2, "circular": 3}

@@ -322,7 +322,9 @@ int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, c
   if (lds > dev_props().lds_per_block_optin)
     return fail(AAMD_EUNSUPPORTED, "audio_amd: mel filterbank too large for the LDS of this device");
   auto kern = m400::melspec400_kernel<0, EPI, H, TIn, NR, SIG>;
+#ifdef AAMD_LAB    // tools-only instantiations are compiled into the lab library only (python -m audio_amd._build --lab)
   if (EPI == m400::EPI400_MFCC && epi.lab != 0) kern = m400::melspec400_kernel<(EPI == m400::EPI400_MFCC ? 524288 : 0), EPI, H, TIn, NR, SIG>;
+#endif
   if (lds > 48 * 1024)
     AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -339,7 +341,11 @@ int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, c
   epi.pool_p = 0;
 #if AAMD_M400_POOLS
   {
+#ifdef AAMD_LAB
     static const int lab_p = [] { const char* e = std::getenv("AAMD_MEL400_POOL_P"); return e ? std::atoi(e) : -1; }();   // tools only
+#else
+    constexpr int lab_p = -1;
+#endif
     int P = lab_p >= 0 ? lab_p : m400::pool_share(tiles_per_block);
     if (P > tiles_per_block) P = tiles_per_block;
     const bool fixup_pass = (EPI == m400::EPI400_MFCC) && epi.fixup != 0;
@@ -572,8 +578,10 @@ int aamd_mfcc_fused_f32(const float* wav, const float* window, const float* twid
   // (pass 1: every workgroup of the fix-up launch finds the flagged tiles among its own strided share of the tile minima --
   // no list kernel between the passes; fix_count was reset by pass 0 of this call and collects what the workgroups redo)
   if (f->pass == 1) AAMD_CHECK_ARG(f->fix_count && f->tile_list, "pass 1 of the fused MFCC needs fix_count and tile_list");
+#ifdef AAMD_LAB
   static const int mfcc_lab = [] { const char* e = std::getenv("AAMD_MFCC_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
   epi.lab = mfcc_lab;
+#endif
   hipStream_t s = (hipStream_t)stream;
   switch (g.hop) {
     case 100: return launch_fft400_nr<m400::EPI400_MFCC, 5, float, 4>(g, mb, wav, window, twiddle, out, epi, s);
@@ -1324,8 +1332,10 @@ int aamd_resample_prepared_f32(const float* wav, const float* kernel, float* out
   for (int t = 0; t < n_tiles; ++t)
     AAMD_CHECK_ARG(bands->tap_lo[t] >= 0 && bands->tap_lo[t] < taps, "tap_lo outside the tap table");
   rsm::Geom g{};
+#ifdef AAMD_LAB
   static const int rsm_lab = [] { const char* e = std::getenv("AAMD_RSM_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
   g.lab = rsm_lab;
+#endif
   g.frag = static_cast<const uint32_t*>(frag);       // (read by the f16 kernels only)
   AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(frag) % 16 == 0, "fragment table must be 16-byte aligned");
   g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
@@ -1364,13 +1374,18 @@ int aamd_resample_prepared_f32(const float* wav, const float* kernel, float* out
     g.chunks_per_block = (int)((g.n_chunks + blocks - 1) / blocks);
     blocks = (g.n_chunks + g.chunks_per_block - 1) / g.chunks_per_block;
     const int threads = 64 * wg_waves;
+#ifdef AAMD_LAB
+#define AAMD_RSM_F16(KS) (g.lab == 0 ? rsm::resample_f16_kernel<KS, 0> : g.lab == 64 ? rsm::resample_f16_kernel<KS, 1> : rsm::resample_f16_kernel<KS, 2>)
+#define AAMD_RSM_RD64(KS) (g.lab == 64 ? rsm::kernel_rd64<KS, 1>() : rsm::kernel_rd64<KS, 0>())
+#else
+#define AAMD_RSM_F16(KS) (rsm::resample_f16_kernel<KS, 0>)
+#define AAMD_RSM_RD64(KS) (rsm::kernel_rd64<KS, 0>())
+#endif
 #define AAMD_RSM(KS)                                                                                  \
   do {                                                                                                \
-    auto kern = !f16 ? rsm::resample_mfma_kernel<KS>                                                  \
-                : g.lab == 0 ? rsm::resample_f16_kernel<KS, 0>                                         \
-                : g.lab == 64 ? rsm::resample_f16_kernel<KS, 1> : rsm::resample_f16_kernel<KS, 2>;    \
+    auto kern = !f16 ? rsm::resample_mfma_kernel<KS> : AAMD_RSM_F16(KS);                              \
     /* 8-byte operand reads: odd orig, KS = 80 / 112 (resample_mfma.h, b64_rot) */                    \
-    if (f16 && rd64) kern = g.lab == 64 ? rsm::kernel_rd64<KS, 1>() : rsm::kernel_rd64<KS, 0>();      \
+    if (f16 && rd64) kern = AAMD_RSM_RD64(KS);                                                        \
     if (lds > 48 * 1024)                                                                              \
       AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
@@ -1384,6 +1399,8 @@ int aamd_resample_prepared_f32(const float* wav, const float* kernel, float* out
       default: AAMD_RSM(112); break;
     }
 #undef AAMD_RSM
+#undef AAMD_RSM_F16
+#undef AAMD_RSM_RD64
     int rc = launch_check();
     if (rc != AAMD_OK) return rc;
   }
@@ -1424,13 +1441,19 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
     int W = 1;
     while (W < lfw::kMaxWaves && n_seq * (2 * W) <= 8192 && (int64_t)W * lfw::kWaveBlock < length) W *= 2;
     const size_t cap = dev_props().lds_per_block_optin ? dev_props().lds_per_block_optin : 64 * 1024;
+#ifdef AAMD_LAB
     static const int lab_w = [] { const char* e = std::getenv("AAMD_LFW_W"); return e ? std::atoi(e) : 0; }();    // tools only
     if (lab_w >= 1 && lab_w <= lfw::kMaxWaves && (lab_w & (lab_w - 1)) == 0) W = lab_w;
+#endif
     while (W > 1 && lfw::lds_bytes(W, n_stages) > cap) W /= 2;
     const size_t lds = lfw::lds_bytes(W, n_stages);
     if (lds <= cap) {
       const int blocks = grid_for(n_seq, 1, dev_props().cu_count * 8);
+#ifdef AAMD_LAB
       static const int lab = [] { const char* e = std::getenv("AAMD_LFW_LAB"); return e ? std::atoi(e) : 0; }();   // tools only
+#else
+      constexpr int lab = 0;
+#endif
       const int vec_ok = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(y) % 16 == 0) &&
                          (length % 4 == 0) && lab != 64;      // lab 64: the dword copies also for aligned rows
 #define AAMD_LFW(LL, MW, VV)                                                                                       \
@@ -1440,6 +1463,10 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
         hipLaunchKernelGGL((lfw::lfilter_wave_kernel<LL, MW, VV>), dim3(blocks), dim3(64 * W), lds, s, x, a, b, y, \
                            n_seq, channels, length, n_order, n_coeff_rows, n_stages, clamp);                       \
       }
+#ifndef AAMD_LAB
+#define AAMD_LFW_LABS(MW)                                                                                          \
+      { if (vec_ok) AAMD_LFW(0, MW, true) else AAMD_LFW(0, MW, false) }
+#else
 #define AAMD_LFW_LABS(MW)                                                                                          \
       switch (vec_ok ? lab : 0) {                                                                                  \
         case 1: AAMD_LFW(1, MW, true) break;                                                                       \
@@ -1457,7 +1484,12 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
         default:                                                                                                   \
           if (vec_ok) AAMD_LFW(0, MW, true) else AAMD_LFW(0, MW, false)                                            \
       }
+#endif
+#ifdef AAMD_LAB
       static const int lab_pipe = [] { const char* e = std::getenv("AAMD_LFW_PIPE"); return e ? std::atoi(e) : -1; }();   // tools only
+#else
+      constexpr int lab_pipe = -1;
+#endif
       const bool pipe = vec_ok && W >= 8 && lab_pipe != 0 && lfw::pipe_lds_bytes(8, n_stages) <= cap;
       if (pipe && n_stages >= 3 && lab_pipe != 1) {   // + 4 mover waves that own the copies and the stores
         const size_t plds = lfw::pipe_lds_bytes(8, n_stages);
@@ -1468,6 +1500,7 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
           hipLaunchKernelGGL((lfw::lfilter_wave_mover_kernel<LL>), dim3(blocks), dim3(64 * (8 + lfw::kMovers)),    \
                              plds, s, x, a, b, y, n_seq, channels, length, n_order, n_coeff_rows, n_stages, clamp);\
         }
+#ifdef AAMD_LAB
         switch (lab) {
           case 1: AAMD_LFWM(1) break;
           case 16: AAMD_LFWM(16) break;
@@ -1475,6 +1508,9 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
           case 48: AAMD_LFWM(48) break;
           default: AAMD_LFWM(0)
         }
+#else
+        AAMD_LFWM(0)
+#endif
 #undef AAMD_LFWM
       } else if (pipe) {        // two tiles per wave, copies and stores spread over the stages (8 waves)
         W = 8;
@@ -1486,6 +1522,7 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
           hipLaunchKernelGGL((lfw::lfilter_wave_pipe_kernel<LL>), dim3(blocks), dim3(512), plds, s, x, a, b, y,    \
                              n_seq, channels, length, n_order, n_coeff_rows, n_stages, clamp);                     \
         }
+#ifdef AAMD_LAB
         switch (lab) {
           case 1: AAMD_LFWP(1) break;
           case 15: AAMD_LFWP(15) break;
@@ -1498,6 +1535,9 @@ int aamd_lfilter_f32(const float* x, const float* a, const float* b, float* y, i
           case 63: AAMD_LFWP(63) break;
           default: AAMD_LFWP(0)
         }
+#else
+        AAMD_LFWP(0)
+#endif
 #undef AAMD_LFWP
       } else if (W <= 8) {      // 512 threads: the 256-register instantiation
         AAMD_LFW_LABS(8)

@@ -678,8 +678,8 @@ def main():
             sweep = torch_cpu_ref.sweep_mel_baseline(batch, SECONDS, SR, N_FFT, HOP, N_MELS)
             best = max(sweep, key=lambda r: r["audio_sec_per_sec"])
             proto = torch_cpu_ref.protocol_set_num_threads(batch, SECONDS, SR, N_FFT, HOP, N_MELS)
-            out["cpu_baseline"] = {"value": best["audio_sec_per_sec"], "unit": "audio-sec/sec", "cores": os.cpu_count(),
-                                   "threads_best": best["threads"], "cpu_model": cpu_model(),
+            out["cpu_baseline"] = {"value": best["audio_sec_per_sec"], "unit": "audio-sec/sec", "cores": best["threads"],
+                                   "host_cores": os.cpu_count(), "threads_best": best["threads"], "cpu_model": cpu_model(),
                                    "kind": "port", "sweep": sweep,
                                    "protocol_set_num_threads": proto,
                                    "protocol_note": "BASELINE.md section 4 as written -- ONE call over the whole batch under "
@@ -692,6 +692,21 @@ def main():
                                              "1 / 8 / 16 / 32 / 64 / all, ~3 s each, the best reported; a port, not "
                                              "torchaudio itself (the GPU box has no /root/reference): the same ATen ops "
                                              "torchaudio's CPU path issues (torch.stft + abs().pow(2) + matmul)"}
+            # ... and one CPU figure per BASELINE config of `configs`: ports of the reference's CPU compositions
+            # on bounded samples, rows dealt to host threads, ~2.5 s per thread count (oracle/cpu_baselines.py; for lfilter the
+            # core loop is the reference's own lfilter.cpp where oracle/_ref travelled with the tree)
+            if configs is not None and not any("error" in c for c in configs):
+                try:
+                    from oracle import cpu_baselines
+                    per_cfg = cpu_baselines.measure(budget_s=2.5)
+                    for c in configs:
+                        key = "cfg4" if c.get("id") == "cfg4_per_item" else c.get("id")
+                        if key in per_cfg:
+                            c["cpu_baseline"] = per_cfg[key]
+                        elif key == "cfg2":
+                            c["cpu_baseline"] = "the line's `cpu_baseline`"
+                except Exception as e:                        # never lose the line to a side measurement
+                    out["configs_cpu_baseline_error"] = f"{type(e).__name__}: {e}"[:300]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

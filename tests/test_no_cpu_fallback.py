@@ -43,7 +43,7 @@ def test_cpu_tensors_are_refused(call):
 
 def test_product_never_imports_the_oracle():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audio_amd")
-    pat = re.compile(r"^\s*(from|import)\s+oracle\b|\boracle\.(dsp_oracle|torch_cpu_ref|build_ref)\b")
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|\boracle\.(dsp_oracle|torch_cpu_ref|build_ref|cpu_baselines)\b")
     for d, _, files in os.walk(root):
         for f in files:
             if f.endswith(".py"):

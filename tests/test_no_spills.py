@@ -18,11 +18,9 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # shapes; orders 3 .. 8 run as second-order sections), the 2048-point Kaldi kernel, the one-tile biquad kernel's table builder
 ALLOW = [(r"aamd14lfilter_kernelILi(8|12|16)E", 4200), (r"aamd2p217kaldi_pow2_kernelILi32E", 128),
          (r"aamd3lfw19lfilter_wave_kernel", 96), (r"aamd3lfw24lfilter_wave_pipe_kernel", 32),
-         # lab instantiations of the one-tile biquad kernel (tools only: AAMD_LFW_LAB copy-order / non-temporal variants)
-         (r"aamd3lfw19lfilter_wave_kernelILi(128|896)ELi16E", 128),
          (r"aamd3lfw25lfilter_wave_mover_kernel", 32), (r"aamd4m40015istft400_kernel", 16),
-         # lab instantiations of the f16 resampler (tools only: AAMD_RSM_LAB), never the product one (<KS, 0>)
-         (r"aamd3rsm19resample_f16_kernelILi\d+ELi[12]E", 64),
+         # (round 6: the tools-only instantiations -- AAMD_LFW_LAB, AAMD_RSM_LAB, AAMD_MFCC_LAB -- are compiled into
+         # libaudio_amd_lab.so only; test_the_product_library_holds_no_lab_instantiation below)
          # round 5, 24 577 .. 32 768 taps: three delayed spectra in registers; one item-loop constant (a 64-bit bound) is parked in
          # scratch OUTSIDE the block-step loop (test_real_block_delay_line_steps_do_not_touch_scratch covers the loop)
          (r"aamd3fdr17delay_line_kernelILi4E", 16)]
@@ -110,3 +108,37 @@ def test_real_block_delay_line_steps_do_not_touch_scratch():
         # pass: the stores that follow the last barrier belong to it
         inside = [l for l in body[bars[1]:] if "scratch_" in l]
         assert not inside, (np_, inside[:3])
+
+
+def test_the_product_library_holds_no_lab_instantiation():
+    """the tools-only kernel variants (first template argument != 0 of the biquad kernels, variants 1 / 2
+    of the f16 resampler, the MFCC epilogue's lab instantiation) live in libaudio_amd_lab.so (-DAAMD_LAB), not in the product."""
+    ks = _kernels()
+    lab = [k for k in ks if re.search(r"aamd3lfw19lfilter_wave_kernelILi[1-9]", k)
+           or re.search(r"aamd3lfw2[45]lfilter_wave_(pipe|mover)_kernelILi[1-9]", k)
+           or re.search(r"aamd3rsm19resample_f16_kernelILi\d+ELi[12]E", k)
+           or re.search(r"aamd4m40017melspec400_kernelILi524288E", k)]
+    assert not lab, lab
+
+
+def test_build_staleness_is_decided_by_content_not_by_modification_time():
+    """touching a source must not rebuild, changing the flags must."""
+    from audio_amd import _build
+    if not os.path.exists(_build.OUT) or _build.stale():
+        pytest.skip("libaudio_amd.so is not built from the current sources")
+    src = os.path.join(_build.CSRC, "hd.h")
+    st = os.stat(src)
+    try:
+        os.utime(src, None)                         # a newer mtime, the same bytes
+        assert not _build.stale()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    keep = os.environ.get("AAMD_EXTRA_HIPCC_FLAGS")
+    try:
+        os.environ["AAMD_EXTRA_HIPCC_FLAGS"] = "-DSOMETHING_ELSE=1"
+        assert _build.stale()
+    finally:
+        if keep is None:
+            del os.environ["AAMD_EXTRA_HIPCC_FLAGS"]
+        else:
+            os.environ["AAMD_EXTRA_HIPCC_FLAGS"] = keep

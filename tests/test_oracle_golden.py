@@ -3,6 +3,7 @@
      tests/golden/make_golden.py; index<->parameter map in SURVEY.md appendix B), and
  (ii) outputs of the reference implementation itself run in the build container.
 CPU-only; no GPU, no /root/reference at run time."""
+import os
 import numpy as np
 import pytest
 
@@ -133,3 +134,65 @@ def test_oracle_vs_reference_runs(case):
     if case["op"] == "lfilter" and case.get("tag") in ("order4", "order8"):
         tol = 2e-4   # fp32 recursion in the reference drifts for higher orders
     assert peak_rel_err(got, exp) <= tol, peak_rel_err(got, exp)
+
+
+# ---- round 6: the CPU baselines of the other BASELINE configs (oracle/cpu_baselines.py) against the float64 oracle --------------
+
+
+def _cpu_baselines():
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_build", "liboracle_lfilter.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle")])
+    from oracle import cpu_baselines
+    return cpu_baselines
+
+
+def test_c_lfilter_core_equals_the_reference_binary():
+    """oracle/lfilter_core.c restates /root/reference/src/libtorchaudio/lfilter.cpp:17-48; where the reference's own compiled loop
+    is available (oracle/_ref, built from the reference sources by oracle/build_ref.py) the two agree bit for bit, and both agree
+    with the float64 recursion within float32 rounding."""
+    import torch
+    cb = _cpu_baselines()
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, 4, 5000, generator=g) - 0.5
+    a = torch.tensor([[1.0, -1.2, 0.5], [1.0, -0.3, 0.2], [1.0, 0.4, -0.1], [1.0, -1.7, 0.8]])
+    a_flip = a.flip(1).contiguous()
+    fn, kind = cb.lfilter_core()
+    y_port = torch.zeros(3, 4, 5002)
+    fn(x, a_flip, y_port, 0, 12)
+    want = np.zeros((3, 4, 5002))
+    xd, ad = x.double().numpy(), a_flip.double().numpy()
+    for n in range(5000):
+        want[:, :, n + 2] = xd[:, :, n] - (want[:, :, n:n + 3] * ad[None]).sum(-1)
+    assert peak_rel_err(y_port.numpy(), want) < 2e-5
+    ref_core = cb.reference_lfilter_core()
+    if ref_core is None:
+        pytest.skip("oracle/_ref (the reference's compiled lfilter core) is not present here")
+    y_ref = torch.zeros(3, 4, 5002)
+    ref_core(x, a_flip, y_ref)
+    assert torch.equal(y_ref, y_port)
+
+
+def test_cpu_baseline_ports_match_the_oracle():
+    import torch
+    cb = _cpu_baselines()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 3, 4000, generator=g) - 0.5
+    a4 = torch.tensor([[1.3, -1.0, 0.4], [1.1, -0.3, 0.2]])
+    b4 = torch.tensor([[0.3, 0.2, 0.1], [0.5, 0.1, 0.0]])
+    got = cb.biquad_cascade(x, a4, b4).numpy()
+    want = x.double().numpy()
+    for s in range(2):
+        want = O.lfilter(want, a4[s].double().numpy(), b4[s].double().numpy(), clamp=True)
+    assert peak_rel_err(got, want) < 1e-5
+    xc, yc = torch.rand(3, 700, generator=g) - 0.5, torch.rand(1, 90, generator=g) - 0.5
+    assert peak_rel_err(cb.fftconvolve(xc, yc).numpy(), O.fftconvolve(xc.double().numpy(), yc.double().numpy())) < 1e-5
+
+
+def test_cpu_baseline_records_carry_value_cores_kind_and_sample():
+    cb = _cpu_baselines()
+    rec = cb.time_cfg5b(budget_s=0.2, rows=8, seconds=0.5, taps=2000)
+    assert rec["value"] > 0 and rec["cores"] >= 1 and rec["kind"] == "port" and "rows" in rec["sample"]
+    rec = cb.time_cfg5a(budget_s=0.2, batch=2, channels=2, seconds=0.5)
+    assert rec["value"] > 0 and "core_loop" in rec

@@ -3,6 +3,9 @@
 4 no tile minimum, 8 no stores; read once per process): us per call.  Run once per value:
     for v in 0 1 2 4 8 15; do AAMD_MFCC_LAB=$v python tools/bench_mfcc_lab.py; done"""
 import json, os, sys
+# the tools-only kernel variants live in libaudio_amd_lab.so (python -m audio_amd._build --lab), reached through ctypes
+os.environ.setdefault("AAMD_USE_LAB_LIB", "1")
+os.environ.setdefault("AAMD_NO_TORCH_SHIM", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import audio_amd.transforms as T

@@ -10,6 +10,9 @@ the experiment with  AAMD_EXTRA_HIPCC_FLAGS=-DAAMD_M400_POOLS=1 python -m audio_
 arms of this A/B run the same static hand-out."""
 import json
 import os
+# the tools-only kernel variants live in libaudio_amd_lab.so (python -m audio_amd._build --lab), reached through ctypes
+os.environ.setdefault("AAMD_USE_LAB_LIB", "1")
+os.environ.setdefault("AAMD_NO_TORCH_SHIM", "1")
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -2,6 +2,9 @@
 """Barrier / phase ablation of the fused 4-biquad cascade (cfg5a shard): AAMD_LFW_LAB selects variants of
 lfilter_wave_kernel (wrong results by design).  One variant per process:  AAMD_LFW_LAB=N python tools/lfw_lab.py"""
 import math, os, sys
+# the tools-only kernel variants live in libaudio_amd_lab.so (python -m audio_amd._build --lab), reached through ctypes
+os.environ.setdefault("AAMD_USE_LAB_LIB", "1")
+os.environ.setdefault("AAMD_NO_TORCH_SHIM", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import audio_amd.functional as F

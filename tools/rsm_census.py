@@ -1,6 +1,9 @@
 #!/usr/bin/env python
 """Per-phase time stamps of the f16 resampler's workgroup 0 (AAMD_RSM_LAB=64 must be set): where a chunk period goes."""
 import ctypes as C, os, sys
+# the tools-only kernel variants live in libaudio_amd_lab.so (python -m audio_amd._build --lab), reached through ctypes
+os.environ.setdefault("AAMD_USE_LAB_LIB", "1")
+os.environ.setdefault("AAMD_NO_TORCH_SHIM", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import audio_amd.transforms as T
