@@ -227,14 +227,28 @@ AAMD_HD void pass_m2_fwd_a(int tid, const C32* lds, const C32* tl, C32 (&o)[8]) 
   const C32* tab = tl + kTw4 + j;
   mul_table8<false, 2>(o, tab);
 }
-AAMD_HD void pass_m2_fwd_b(int tid, const C32 (&o)[8], const C32 (&nb)[8], C32* lds) {
+// Round 6: the radix-2 is ONE instruction per float on the device -- v_fmac_f32_dpp own, dpp(own), s = own + s nb, s = +1 in lane
+// j = 0 and -1 in lane j = 1 -- so lane 1 holds o1 - o0: the NEGATED value.  The sign is carried, not repaired: every ODD
+// position of the digit-reversed spectrum in LDS (the bins k + 4096 and 8192 - k of a quad) holds minus its bin.  The middle step
+// reads and writes the pairs with that sign (free: other add / sub operands), and the inverse radix-2 -- own + s' nb with
+// s' = -s -- turns (x0, -x1) into the true x0 + x1 and x0 - x1.  Rounds 3-5: v_mov (initialise) + v_mov_b32_dpp + add + sub +
+// v_cndmask per float; the step is VALU-issue bound (profiles/r06_e_fdr_lab_radix32.txt).
+AAMD_HD float radix2_sign(int tid) { return (tid & 1) ? -1.0f : 1.0f; }
+AAMD_HD void radix2_level(C32 (&own)[8], const C32 (&nb)[8], float s) {      // the CPU replay's form of the DPP level
+#pragma unroll
+  for (int r = 0; r < 8; ++r) own[r] = C32{own[r].x + s * nb[r].x, own[r].y + s * nb[r].y};
+}
+AAMD_HD void pass_m2_fwd_store(int tid, const C32 (&w)[8], C32* lds) {
   tid = fco::opaque(tid);
-  const int blk = m2_block(tid), j = tid & 1;
-  C32* cell = lds + pad(16 * blk + j);
+  C32* cell = lds + pad(16 * m2_block(tid) + (tid & 1));
+  lds_write8<AAMD_FDR_STRIDE(2)>(cell, w);
+}
+AAMD_HD void pass_m2_fwd_b(int tid, const C32 (&o)[8], const C32 (&nb)[8], C32* lds) {
   C32 w[8];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) w[r] = j ? csub(nb[r], o[r]) : cadd(o[r], nb[r]);
-  lds_write8<AAMD_FDR_STRIDE(2)>(cell, w);
+  for (int r = 0; r < 8; ++r) w[r] = o[r];
+  radix2_level(w, nb, radix2_sign(tid));
+  pass_m2_fwd_store(tid, w, lds);
 }
 // inverse: x = the values at 16 blk + j + 2 r; lane 0 forms x0 + x1, lane 1 x0 - x1, then the inverse radix-8 pass
 AAMD_HD void pass_m2_inv_a(int tid, const C32* lds, C32 (&x)[8]) {
@@ -242,17 +256,22 @@ AAMD_HD void pass_m2_inv_a(int tid, const C32* lds, C32 (&x)[8]) {
   const C32* cell = lds + pad(16 * m2_block(tid) + (tid & 1));
   lds_read8<AAMD_FDR_STRIDE(2)>(cell, x);
 }
-AAMD_HD void pass_m2_inv_b(int tid, const C32 (&x)[8], const C32 (&nb)[8], C32* lds, const C32* tl) {
+// inverse: the stored (x0, -x1) -> x0 + x1 in lane 0 (own - nb), x0 - x1 in lane 1 (own + nb): true values again
+AAMD_HD void pass_m2_inv_finish(int tid, C32 (&v)[8], C32* lds, const C32* tl) {
   tid = fco::opaque(tid);
   const int blk = m2_block(tid), j = tid & 1;
-  C32 v[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] = j ? csub(nb[r], x[r]) : cadd(x[r], nb[r]);
   const C32* tab = tl + kTw4 + j;
   mul_table8<true, 2>(v, tab);
   dft8<true>(v);
   C32* cell = lds + pad(16 * blk + j);
   lds_write8<AAMD_FDR_STRIDE(2)>(cell, v);
+}
+AAMD_HD void pass_m2_inv_b(int tid, const C32 (&x)[8], const C32 (&nb)[8], C32* lds, const C32* tl) {
+  C32 v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = x[r];
+  radix2_level(v, nb, -radix2_sign(tid));
+  pass_m2_inv_finish(tid, v, lds, tl);
 }
 
 // ---- the middle step: split, delay line, merge ------------------------------------------------------------------------
@@ -316,12 +335,16 @@ AAMD_HD void merge_pair(C32 yk, C32 ym, C32 w, C32& ck, C32& cm) {
 // the thread's 8 spectrum bins of the block in LDS -> z[0 .. 7] (twice the real block's spectrum):
 //   z[4 s + 0] = Z[k], + 1: Z[k + 4096], + 2: Z[4096 - k], + 3: Z[8192 - k]
 //   thread 0, s = 0: z[0] = (Z[0], Z[8192]) (both real), z[1] = Z[4096], z[2] = Z[2048], z[3] = Z[6144]
+// (the ODD cell of every pair read here holds MINUS its bin -- see radix2_level: c1 and c3 are negated on the way in, which the
+// compiler folds into the operands of the first additions)
+AAMD_HD C32 cneg(C32 a) { return C32{-a.x, -a.y}; }
 AAMD_HD void mid_split(int tid, const C32* lds, const MidConst& mc, C32 (&z)[8]) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     C32 c0, c1, c2, c3;
     lds_read_pair(lds + mc.a0s(s), c0, c1);
     lds_read_pair(lds + mc.a1[s], c2, c3);
+    c1 = cneg(c1); c3 = cneg(c3);
     if (tid == 0 && s == 0) {
       z[0] = C32{2.0f * (c0.x + c0.y), 2.0f * (c0.x - c0.y)};
       z[1] = C32{2.0f * c1.x, -2.0f * c1.y};
@@ -346,7 +369,8 @@ AAMD_HD void mid_merge(int tid, const C32 (&y)[8], const MidConst& mc, C32* lds)
       merge_pair(y[4 * s], y[4 * s + 3], w, c0, c3);
       merge_pair(y[4 * s + 1], y[4 * s + 2], C32{w.y, -w.x}, c1, c2);
     }
-    lds[mc.a0s(s)] = c0; lds[mc.a0s(s) + 1] = c1; lds[mc.a1[s]] = c2; lds[mc.a1[s] + 1] = c3;
+    // (the odd cells are stored negated: what the inverse radix-2 expects)
+    lds[mc.a0s(s)] = c0; lds[mc.a0s(s) + 1] = cneg(c1); lds[mc.a1[s]] = c2; lds[mc.a1[s] + 1] = cneg(c3);
   }
 }
 // acc += h * z bin by bin (complex), except thread 0's slot 0 = two REAL bins packed into one complex number
@@ -505,13 +529,24 @@ __device__ __forceinline__ void pair_sync(unsigned* flags, unsigned gen) {
     else __syncthreads();                                                                 \
   } while (0)
 #define AAMD_FDR_BARRIER(BIT) do { if (AAMD_FDR_LAB_NOBAR & (BIT)) fco::wave_sync(); else __syncthreads(); } while (0)
-// neighbour exchange (lane ^ 1) of 8 complex registers: DPP quad_perm [1, 0, 3, 2]
-__device__ __forceinline__ void swap_neighbour(const C32 (&o)[8], C32 (&nb)[8]) {
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    nb[r].x = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o[r].x), 0xB1, 0xf, 0xf, false));
-    nb[r].y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(o[r].y), 0xB1, 0xf, 0xf, false));
-  }
+// the radix-2 between neighbouring lanes (lane ^ 1: DPP quad_perm [1, 0, 3, 2]) on all 16 floats of a thread, in place:
+// u += s * dpp(u), one v_fmac_f32_dpp each (radix2_level).  One asm block: the s_nop in front covers the two wait states a DPP read
+// needs behind a VALU write of the same register; inside the block every instruction touches its own register.
+__device__ __forceinline__ void radix2_dpp(C32 (&u)[8], float s) {
+#define AAMD_FDR_QP " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+  asm("s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %0, %16" AAMD_FDR_QP "v_fmac_f32_dpp %1, %1, %16" AAMD_FDR_QP
+      "v_fmac_f32_dpp %2, %2, %16" AAMD_FDR_QP "v_fmac_f32_dpp %3, %3, %16" AAMD_FDR_QP
+      "v_fmac_f32_dpp %4, %4, %16" AAMD_FDR_QP "v_fmac_f32_dpp %5, %5, %16" AAMD_FDR_QP
+      "v_fmac_f32_dpp %6, %6, %16" AAMD_FDR_QP "v_fmac_f32_dpp %7, %7, %16" AAMD_FDR_QP
+      "v_fmac_f32_dpp %8, %8, %16" AAMD_FDR_QP "v_fmac_f32_dpp %9, %9, %16" AAMD_FDR_QP
+      "v_fmac_f32_dpp %10, %10, %16" AAMD_FDR_QP "v_fmac_f32_dpp %11, %11, %16" AAMD_FDR_QP
+      "v_fmac_f32_dpp %12, %12, %16" AAMD_FDR_QP "v_fmac_f32_dpp %13, %13, %16" AAMD_FDR_QP
+      "v_fmac_f32_dpp %14, %14, %16" AAMD_FDR_QP "v_fmac_f32_dpp %15, %15, %16 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "+v"(u[0].x), "+v"(u[0].y), "+v"(u[1].x), "+v"(u[1].y), "+v"(u[2].x), "+v"(u[2].y), "+v"(u[3].x), "+v"(u[3].y),
+        "+v"(u[4].x), "+v"(u[4].y), "+v"(u[5].x), "+v"(u[5].y), "+v"(u[6].x), "+v"(u[6].y), "+v"(u[7].x), "+v"(u[7].y)
+      : "v"(s));
+#undef AAMD_FDR_QP
 }
 // forward transform of the block in v (registers) to the digit-reversed spectrum in LDS; ends with a workgroup barrier
 // how many of the 7 twiddles of the length-128 pass live in registers, by partition count (the 3-partition kernel holds two
@@ -534,10 +569,10 @@ __device__ __forceinline__ void forward_block(int tid, C32 (&v)[8], C32* lds, co
   AAMD_FDR_BARRIER(1);
   if (NR > 0) pass_m16_regtw<false, NR>(tid, lds, tl, tw3); else pass_m16<false>(tid, lds, tl);
   fco::wave_sync();
-  C32 o[8], nb[8];
+  C32 o[8];
   pass_m2_fwd_a(tid, lds, tl, o);
-  swap_neighbour(o, nb);
-  pass_m2_fwd_b(tid, o, nb, lds);
+  radix2_dpp(o, radix2_sign(tid));
+  pass_m2_fwd_store(tid, o, lds);
   AAMD_FDR_BARRIER(2);
 }
 // ... and back: LDS spectrum (digit-reversed) -> the block's samples in v.  The first half (inverse radix-2 + length-16 and
@@ -598,6 +633,7 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
   constexpr int kTw3 = Tw3Regs<NP>::n;
   C32 tw3[7];
   load_tw3<kTw3>(tid, tl, tw3);
+  const float r2s = radix2_sign(tid);
 #ifdef AAMD_FDR_PRIO
   // lab (tools/fdr_lab.py): static issue priority per wave -- the four waves of a SIMD (w, w + 4, w + 8, w + 12) get distinct
   // priorities so that they leave a pass one after the other instead of together
@@ -689,10 +725,10 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
       if (kTw3 > 0) pass_m16_regtw<false, kTw3>(tid, lds, tl, tw3); else pass_m16<false>(tid, lds, tl);
       fco::wave_sync();
       {
-        C32 o[8], nb[8];
+        C32 o[8];
         pass_m2_fwd_a(tid, lds, tl, o);
-        swap_neighbour(o, nb);
-        pass_m2_fwd_b(tid, o, nb, lds);
+        radix2_dpp(o, r2s);
+        pass_m2_fwd_store(tid, o, lds);
       }
       AAMD_FDR_BARRIER(2);
       if (produce) h_load(0);              // H_0: requested before the split reads LDS (an L2 round trip)
@@ -712,10 +748,10 @@ delay_line_kernel(Geom g, const float* __restrict__ x, const C32* __restrict__ t
       // step the thread holds three spectra, the accumulators and a partition of tap spectra -- with these 16 registers on top
       // the 128-register budget of four waves per SIMD spilled)
       if (produce) {                       // inverse_block_a with the pair rendezvous in place of its closing barrier
-        C32 xq[8], nb[8];
+        C32 xq[8];
         pass_m2_inv_a(tid, lds, xq);
-        swap_neighbour(xq, nb);
-        pass_m2_inv_b(tid, xq, nb, lds, tl);
+        radix2_dpp(xq, -r2s);
+        pass_m2_inv_finish(tid, xq, lds, tl);
         fco::wave_sync();
         if (kTw3 > 0) pass_m16_regtw<true, kTw3>(tid, lds, tl, tw3); else pass_m16<true>(tid, lds, tl);
         AAMD_FDR_PAIR(1);
