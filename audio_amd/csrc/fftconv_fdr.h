@@ -511,16 +511,20 @@ constexpr float kSpectrumScale = 1.0f / (8.0f * (float)kM);      // un-halved sp
 #define AAMD_FDR_WAR_BARRIER 0
 #endif
 __device__ __forceinline__ void pair_sync(unsigned* flags, unsigned gen) {
+  // (release / acquire spelled out instead of relying on `volatile` and in-order LDS.  The fences name the LDS address
+  // space only -- "local" -- so they lower to s_waitcnt lgkmcnt(0): a plain workgroup-scope release would also wait for the
+  // vector-memory loads in flight, the next block's samples and the tap spectra, which have nothing to do with this hand-over.
+  // The flag itself is a relaxed workgroup-scope atomic: never cached in a register, never torn.)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  volatile unsigned* vf = flags;
-  if ((threadIdx.x & 63) == 0) vf[wave] = gen;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_store(flags + wave, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   for (;;) {
-    const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane((int)vf[wave ^ 1]);
+    const unsigned f = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)__hip_atomic_load(flags + (wave ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     if ((int)(f - gen) >= 0) break;
     __builtin_amdgcn_s_sleep(1);
   }
-  asm volatile("" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 #define AAMD_FDR_PAIR(BIT)                                                                \
   do {                                                                                    \

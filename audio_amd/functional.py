@@ -165,10 +165,13 @@ def _drop_dead_slot(tid: int, ref) -> None:
     """Weak-reference callback of `_tensor_cached`: the tensor object is gone, so is everything derived from it (the
     slots of dead tensors -- prepared fftconvolve workspaces of up to 64 MiB among them -- used to wait for their id to be
     reused or for the dictionary to pass 512 entries)."""
-    with _CACHE_LOCK:
-        slot = _TENSOR_CACHE.get(tid)
+    cache, lock = _TENSOR_CACHE, _CACHE_LOCK
+    if cache is None or lock is None:          # interpreter shutdown: the module's globals are already gone
+        return
+    with lock:
+        slot = cache.get(tid)
         if slot is not None and slot[0] is ref:
-            del _TENSOR_CACHE[tid]
+            del cache[tid]
 
 
 def _tensor_cached(t: Tensor, key, make, replace: bool = False):

@@ -52,3 +52,25 @@ with torch.no_grad():
     print(json.dumps({"path": "F.fftconvolve again", "ms": timed(lambda: F.fftconvolve(x, rir))}), flush=True)
     fresh = lambda: F.fftconvolve(x, rir.clone())
     print(json.dumps({"path": "F.fftconvolve with a NEW tap tensor per call (prepares every call)", "ms": timed(fresh)}), flush=True)
+    # the lab build of the same header (tools/fdr_lab.py build NAME), in this process on this box
+    for name in sys.argv[1:]:
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab", "_build", "libfdr_%s.so" % name)
+        if not os.path.exists(so):
+            continue
+        LL = C.CDLL(so)
+        LL.lab_fdr_workspace.restype = C.c_int64
+        LL.lab_fdr_workspace.argtypes = [C.c_int64, C.c_int64]
+        LL.lab_fdr.argtypes = [C.c_void_p] * 3 + [C.c_int64] * 4 + [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        nbl = LL.lab_fdr_workspace(1, 24000)
+        wsl = torch.zeros((nbl + 8 * 256) // 4 + 2, dtype=torch.float32, device=dev)
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+        def lab_call(stages):
+            rc = LL.lab_fdr(xr.data_ptr(), yr.data_ptr(), out.data_ptr(), 256, 1, 480000, 24000, wsl.data_ptr(), stages, cus, st)
+            assert rc == 0, rc
+        lab_call(1)
+        print(json.dumps({"path": "lab build '%s', RUN only, the same buffers" % name, "ms": timed(lambda: lab_call(2))}), flush=True)
+        ref = F.fftconvolve(x, rir).reshape(256, -1)
+        lab_call(2)
+        torch.cuda.synchronize()
+        print(json.dumps({"lab_vs_product_bit_equal": bool(torch.equal(out, ref))}), flush=True)
