@@ -750,16 +750,26 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         if (s + 1 < NS) AAMD_RSM_READ_A(s + 1, ra[(s + 1) & 1])
         __builtin_amdgcn_sched_barrier(0);
         u32x4 hv, lv;
+#if defined(AAMD_RSM_LAB_NOPERM)   /* lab, timing only (wrong results): what the 16 v_perm_b32 per step cost */
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { hv[d] = ra[s & 1][2 * d]; lv[d] = ra[s & 1][2 * d + 1]; }
+#else
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           hv[d] = __builtin_amdgcn_perm(ra[s & 1][2 * d + 1], ra[s & 1][2 * d], 0x05040100u);
           lv[d] = __builtin_amdgcn_perm(ra[s & 1][2 * d + 1], ra[s & 1][2 * d], 0x07060302u);
         }
+#endif
         AAMD_RSM_MFMA3(accA, hv, lv)
         __builtin_amdgcn_sched_barrier(0);
         const uint32_t d0 = (s == 0 || s == NS - ROT) ? cf : rb[(s + 1) & 1][7];     // (before the next reads land there)
         if (s + 1 < NS) AAMD_RSM_READ_B(s + 1, rb[(s + 1) & 1])
         __builtin_amdgcn_sched_barrier(0);
+#if defined(AAMD_RSM_LAB_NOPERM)
+        hv[0] = d0; lv[0] = rb[s & 1][0];
+#pragma unroll
+        for (int d = 1; d < 4; ++d) { hv[d] = rb[s & 1][2 * d - 1]; lv[d] = rb[s & 1][2 * d]; }
+#else
         hv[0] = __builtin_amdgcn_perm(rb[s & 1][0], d0, 0x05040100u);
         lv[0] = __builtin_amdgcn_perm(rb[s & 1][0], d0, 0x07060302u);
 #pragma unroll
@@ -767,6 +777,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
           hv[d] = __builtin_amdgcn_perm(rb[s & 1][2 * d], rb[s & 1][2 * d - 1], 0x05040100u);
           lv[d] = __builtin_amdgcn_perm(rb[s & 1][2 * d], rb[s & 1][2 * d - 1], 0x07060302u);
         }
+#endif
         AAMD_RSM_MFMA3(accB, hv, lv)
         __builtin_amdgcn_sched_barrier(0);
       }
