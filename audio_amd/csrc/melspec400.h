@@ -1030,7 +1030,15 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // private run of the scratch list and leaves when there are none (the common case), before any table is built.  (Rounds
   // 3-4 compacted ONE chip-wide list in a kernel of its own between the passes; un-profiled that launch cost 3-5 us per call,
   // profiles/r04_p_mfcc_one_launch.txt.)
+  // (Round 6 measured what this launch costs on the cfg4 noise batch, 7 us per call, and where: the bare launch of the grid is
+  // ~1 us -- a build that returns here at once --, reading the minima in coalesced blocks of 16 instead of one cache line per
+  // lane changes nothing, and the batch is not "nothing flagged": 2 of its 85 504 tiles lie under the cut-off, so two workgroups
+  // build their tables and redo one tile each -- a wave-tile's latency.  The launch costs what redoing ONE tile costs.
+  // profiles/r06_n_mfcc_fixup_floor.txt)
   unsigned fix_base = 0, fix_cnt = 0;
+#if defined(AAMD_LAB) && defined(AAMD_MFCC_FIXUP_RETURNS)      /* lab, timing only: what the bare launch of the fix-up grid costs */
+  if (EPI == EPI400_MFCC && epi.fixup != 0) return;
+#endif
   if (EPI == EPI400_MFCC && epi.fixup != 0) {
     int* const cnt = reinterpret_cast<int*>(smem400);     // (wave 0's region: nothing lives there yet)
     if (threadIdx.x == 0) *cnt = 0;
