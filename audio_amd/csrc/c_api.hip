@@ -315,8 +315,10 @@ int launch_fft400_nr(const StftGeom& g, const MelBandsDev& mb, const TIn* wav, c
   const int wdw = m400::Hop<H>::lds_dwords;
   size_t lds = (EPI == m400::EPI400_SPEC) ? m400::lds_bytes(0, 1, wdw) : m400::lds_bytes(mb.n_mels, mb.max_width, wdw);
   m400::Epi400 epi = epi_in;
-  if (EPI == m400::EPI400_MFCC && m400::lds_bytes(mb.n_mels, mb.max_width, wdw, true) <= dev_props().lds_per_block_optin) {
-    lds = m400::lds_bytes(mb.n_mels, mb.max_width, wdw, true);      // room for the DCT fragments next to the band table
+  if (EPI == m400::EPI400_MFCC && H != 10) {
+    // hop 100 / 160: the DCT fragments sit next to the band table in LDS (the kernel's choice per instantiation, melspec400.h
+    // kFragLds; mfcc_fused_ok has checked that they fit); hop 200: read from the cache-resident table
+    lds = m400::lds_bytes(mb.n_mels, mb.max_width, wdw, true);
     epi.frag_in_lds = 1;
   }
   if (lds > dev_props().lds_per_block_optin)
@@ -523,8 +525,11 @@ int aamd_melspectrogram_f32(const float* wav, const float* window, const float* 
 // ---- MFCC in one kernel (+ a fix-up launch for clamped tiles) --------------------------------------------------------
 namespace {
 bool mfcc_fused_ok(const StftGeom& g, const MelBandsDev& mb, int n_mfcc) {
-  return mel400_eligible(g, mb) && mb.n_mels == m400::kMfccMels && n_mfcc >= 4 && n_mfcc <= 16 * m400::kMfccMT &&
-         n_mfcc % 4 == 0;
+  if (!(mel400_eligible(g, mb) && mb.n_mels == m400::kMfccMels && n_mfcc >= 4 && n_mfcc <= 16 * m400::kMfccMT && n_mfcc % 4 == 0))
+    return false;
+  // hop 100 / 160 keep the DCT fragments in LDS: a band table too wide to leave them room takes the two-kernel path
+  const int wdw = g.hop == 100 ? m400::Hop<5>::lds_dwords : g.hop == 200 ? m400::Hop<10>::lds_dwords : m400::Hop<8>::lds_dwords;
+  return g.hop == 200 || m400::lds_bytes(mb.n_mels, mb.max_width, wdw, true) <= dev_props().lds_per_block_optin;
 }
 }  // namespace
 

@@ -227,12 +227,17 @@ AAMD_HD constexpr int pos_of_col(int c) {
 //   than two kernels.  Now (round 3) every operand is v = hi + lo, hi = f16(v), lo = f16(v - hi) (22 significant bits), and
 //   a product of sums is hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 / 16x16x16_f16 with fp32 accumulation (the
 //   dropped lo*lo is 2^-22 of the product): 80 mels = two K = 32 steps + one K = 16 step, 3 coefficient tiles, 3 terms =
-//   27 instructions of 8-16 cycles on a pipe the rest of the kernel does not use.  Ranges: dB values (|y| < 256 after the
-//   cut-off) are scaled by 2^-8, DCT weights (|d| <= 0.16 for "ortho", <= 2 unnormalised) by 2^-1; the result by 2^9: exact
-//   powers of two.  Absolute error of a dB value 256 * 2^-22 * |y / 256| <= 2.4e-5 dB, below the fused epilogue's log2.
-//   n_mels = 80 exactly (every K slot is a real mel), n_mfcc <= 48.
+//   27 instructions of 8-16 cycles on a pipe the rest of the kernel does not use.
+//   Round 6: 18 instructions -- the six live frames fill 6 of the 16 B columns, so the hi plane of the dB rows goes to
+//   columns 0 .. 5 and the lo plane to columns 8 .. 13 of ONE operand; A_lo x B and A_hi x B leave (A_hi + A_lo) B_hi in lane j
+//   and (A_hi + A_lo) B_lo in lane j + 8 of every row of 16 lanes (all four terms) and one DPP add per accumulator register
+//   joins them.  Ranges: dB values are scaled by 2^-4 (|y| < 770 for any float32 power and multiplier <= 20 -> < 48; the lo
+//   part of a typical 50 dB value is a NORMAL binary16 number -- the 2^-8 of rounds 3-5 left it subnormal, 2.4e-5 dB of
+//   absolute error, now ~4e-6), DCT weights (|d| <= 0.16 for "ortho", <= 2 unnormalised) by 2^4 (their lo parts normal as
+//   well): the product needs no scaling on the way out.  n_mels = 80 exactly (every K slot is a real mel), n_mfcc <= 48.
 constexpr int kMfccMT = 3, kMfccMels = 80, kMfccSteps = 3;
-constexpr float kMfccYScale = 1.0f / 256.0f, kMfccDScale = 0.5f, kMfccOutScale = 512.0f;
+constexpr float kMfccYScale = 1.0f / 16.0f, kMfccDScale = 16.0f;
+static_assert(kMfccYScale * kMfccDScale == 1.0f, "the accumulators leave the matrix pipe unscaled");
 // fragment table: [t][s][hi / lo][lane][8 halves] as 16-byte pieces -> floats
 constexpr int kMfccFragFloats = kMfccMT * kMfccSteps * 2 * 64 * 4;      // 4608 floats = 18 432 B
 AAMD_HD int mfcc_frag_piece(int t, int s, int hl, int lane) { return ((t * kMfccSteps + s) * 2 + hl) * 64 + lane; }   // 16-B pieces
@@ -245,10 +250,14 @@ AAMD_HD float mfcc_frag_value(const float* dct, int n_mels, int n_mfcc, int t, i
   const int mel = mfcc_slot_mel(s, lane, j), coef = 16 * t + (lane & 15);
   return (mel >= 0 && mel < n_mels && coef < n_mfcc) ? dct[mel * n_mfcc + coef] * kMfccDScale : 0.0f;
 }
-// index (in halves) of the lane's B values of step s in the staged binary16 rows (frames >= 6: any live row)
+// index (in halves) of the lane's B values of step s in the staged binary16 planes.  Column n = lane & 15 of the B operand:
+// n = 0 .. 5 the hi plane of frame n, n = 8 .. 13 the lo plane of frame n - 8 (columns 6, 7, 14, 15: any live row; their
+// products are never stored).  The lo plane starts kMfccPlaneHalves behind the hi plane.
+AAMD_HD int mfcc_b_col_frame(int lane) { const int j = lane & 7; return j < kFramesPerWave ? j : kFramesPerWave - 1; }
+AAMD_HD int mfcc_b_col_plane(int lane) { return (lane >> 3) & 1; }
 AAMD_HD int mfcc_b_index(int lane, int s) {
-  const int j = (lane & 15) < kFramesPerWave ? (lane & 15) : kFramesPerWave - 1;
-  return j * kMfccMels + (s < 2 ? 32 * s + 8 * (lane >> 4) : 64 + 4 * (lane >> 4));
+  return mfcc_b_col_plane(lane) * (kFramesPerWave * kMfccMels) + mfcc_b_col_frame(lane) * kMfccMels +
+         (s < 2 ? 32 * s + 8 * (lane >> 4) : 64 + 4 * (lane >> 4));
 }
 constexpr int kMfccPlaneHalves = kFramesPerWave * kMfccMels;     // 480: the lo plane starts here (960 B, 16-B aligned)
 
@@ -827,7 +836,7 @@ AAMD_HD void mel_regs_load(const LaneConst& c, const MelTab& mt, MelRegs<NR>& h)
 AAMD_HD constexpr int sig_chunks(int sig, int r) { return (sig >> (4 * r)) & 15; }
 constexpr int kSigHtk80 = 0x4221, kSigSlaney80 = 0x4211;      // melscale_fbanks(201, 0, 8000, 80, 16000): htk / slaney
 
-template <int NR = kMelMaxRounds, int SIG = 0>
+template <int NR = kMelMaxRounds, int SIG = 0, bool FENCED = false>
 AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
                      float (&acc_a)[NR], float (&acc_b)[NR], const MelRegs<NR>* h = nullptr) {
   const float* Pp = lds + kPPair * c.p;
@@ -835,6 +844,11 @@ AAMD_HD void phase_c(const LaneConst& c, const MelTab& mt, const float* lds,
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     float sa = 0.0f, sb = 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // FENCED: the straight-line rounds of a signature instantiation one after the other (the scheduler otherwise puts the reads
+    // of all four rounds in flight together: up to 108 registers, which the MFCC instantiation does not have)
+    if (FENCED && SIG != 0 && r > 0 && (r & 1) == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
     if (SIG != 0 || r < mt.n_rounds) {
       const float* wt = wt0 + r * kMelSlots * mt.ws;
       const float* P = Pp + (h ? h->poff(r) : 2 * mt.lo2[r * kMelSlots + c.pi]);
@@ -917,6 +931,30 @@ AAMD_HD void store_wide(int lane, const MelTab& mt, const float* lds, float* out
 }
 
 #if defined(__HIPCC__)
+// v_max_f32 / v_min_f32 on operands the caller knows to be canonical (results of arithmetic): fmaxf / fminf compile to
+// llvm.maxnum / minnum, which under the IEEE mode of compute kernels get a quieting `v_max_f32 x, x, x` per operand whose
+// producer the compiler cannot see.  (The instruction itself quiets a signalling NaN and returns the other operand for a quiet
+// one, as fmaxf does.)
+__device__ __forceinline__ float vmax_raw(float x, float y) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ float vmin_raw(float x, float y) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ float vmax3_raw(float x, float y, float z) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
+__device__ __forceinline__ float vmin3_raw(float x, float y, float z) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
 __device__ __forceinline__ void wave_lds_fence() {
   // Hand-off between lanes of ONE wave through LDS.  The hardware executes a wave's LDS
   // instructions in order, so no s_waitcnt is needed between the writes and the dependent
@@ -1121,7 +1159,12 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // loads per lane whose registers (prefetch) pushed the kernel into scratch, and a scratch reload waits for the LDS-DMA in
   // flight (one in-order vmcnt)
   float* frag_lds = const_tab + kConstDwords + tab_dwords + 4;
-  if (EPI == EPI400_MFCC && epi.frag_in_lds)
+  // MFCC: the DCT fragments live in LDS for hop 100 / 160 and are read from the cache-resident table for hop 200 (whose wave
+  // regions leave no room) -- decided by the INSTANTIATION, not at run time: with both paths in one kernel the compiler kept the
+  // twelve 64-bit piece addresses of the global path in registers for the whole launch (24 VGPRs of a 168-register budget)
+  constexpr bool kFragLds = (H != 10);
+  if (EPI == EPI400_MFCC && (epi.frag_in_lds != 0) != kFragLds) __builtin_trap();      // (a launcher bug)
+  if (EPI == EPI400_MFCC && kFragLds)
     for (int i = threadIdx.x; i < kMfccFragFloats; i += blockDim.x) frag_lds[i] = epi.dct_frag[i];
   if (EPI != EPI400_SPEC && mb.table400 != nullptr) {
     // the band table was laid out once per filterbank (mel_tab_build_kernel): one round of independent loads here
@@ -1144,8 +1187,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // The 20 window taps of this lane live in registers for the whole launch (round 2: -5 us on the headline batch once
   // the buffers rotate over more than the 256 MiB Infinity Cache; 5 b128 LDS reads per tile less).  Lab bit 8192 forces
   // it on, bit 262144 forces the LDS table; the twiddles (38 more registers) stay in LDS (bit 16384: spills at 3 waves/SIMD).
-  // (the MFCC epilogue's MFMA operands need the 20 registers more than the window does: its taps stay in the LDS table)
-  constexpr bool kWinRegs = (EPI != EPI400_MFCC) && (((LAB & 8192) != 0) || !(LAB & 262144));
+  // (the MFCC instantiation kept its window taps in the LDS table until round 6: its 163 registers were 30 too many because both
+  // fragment paths lived in one kernel -- kFragLds above; now 162 with the window and two twiddle batches in registers)
+  constexpr bool kWinRegs = ((LAB & 8192) != 0) || !(LAB & 262144);
   float winr[20], twr[40];
   if (kWinRegs) {
 #pragma unroll
@@ -1162,13 +1206,17 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
 #ifndef AAMD_M400_TWREG_DB
 #define AAMD_M400_TWREG_DB 1
 #endif
+#ifndef AAMD_M400_TWREG_MFCC
+#define AAMD_M400_TWREG_MFCC 2
+#endif
   constexpr bool kPlain = H == 8 && std::is_same<TIn, float>::value && LAB == 0;
   constexpr int kTwRegBatches = (LAB & 16384) ? 4
                                 : (SIG != 0 && EPI == EPI400_MEL) ? AAMD_M400_TWREG
                                 : !kPlain ? 0
                                 : EPI == EPI400_SPEC ? 2
                                 : (EPI == EPI400_MEL && SIG == 0) ? (NR <= 4 ? 1 : 3)
-                                : ((EPI == EPI400_MEL_DB || EPI == EPI400_MFCC) && NR <= 4) ? AAMD_M400_TWREG_DB : 0;
+                                : (EPI == EPI400_MFCC && NR <= 4) ? AAMD_M400_TWREG_MFCC
+                                : (EPI == EPI400_MEL_DB && NR <= 4) ? AAMD_M400_TWREG_DB : 0;
   if (kTwRegBatches > 0) {
 #pragma unroll
     for (int q = 0; q < 10 * kTwRegBatches; ++q) twr[q] = c.tw[q];
@@ -1188,6 +1236,9 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     const int sig_rt = mregs.nc[0] | (mregs.nc[1 % NR] << 4) | (mregs.nc[2 % NR] << 8) | (mregs.nc[3 % NR] << 12);
     if (mt.n_rounds != NR || mt.n_mels != kMelSlots * NR || sig_rt != SIG) __builtin_trap();
   }
+  // the one-kernel MFCC serves 80 mels = exactly NR rounds of 20 table rows, each holding a mel (c_api: mfcc_fused_ok); its
+  // epilogue is written for that
+  if (EPI == EPI400_MFCC && (mt.n_rounds != NR || mt.n_mels != kMelSlots * NR)) __builtin_trap();
   float nrm_mean[NR], nrm_inv[NR];   // MEL_NORM: statistics of this lane's mels
   if (EPI == EPI400_MEL_NORM) {
 #pragma unroll
@@ -1400,6 +1451,33 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     ph_acc[K] += now_ - ph_t;                               \
     ph_t = now_;                                            \
   }
+  // MFCC: accumulators of the DCT product (C row 4 (l >> 4) + r = coefficient, column l & 15 = frame / plane)
+  using mfcc_f32x4 = __attribute__((ext_vector_type(4))) float;
+  mfcc_f32x4 cf[kMfccMT];
+  const int mfcc_elab = (LAB & 524288) ? epi.lab : 0;
+  auto mfcc_finish = [&](int64_t row, int64_t t0) {
+#pragma unroll
+    for (int t = 0; t < kMfccMT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {     // lane j += lane j + 8 of its row (row_ror:8)
+        cf[t][i] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(cf[t][i]), 0x128, 0xf, 0xf, true));
+        asm volatile("" : "+v"(cf[t][i]));     // keeps the add beside its DPP move (one v_add_f32_dpp): without it the add sinks
+                                               // into the EXEC-masked store blocks and the move stays behind as an instruction
+      }
+    // stores: lane (j = l & 15 < 6, g = l >> 4) holds coefficients 16 t + 4 g .. + 3 of frame j.  One wave-uniform tile
+    // pointer + a 32-bit lane offset that does not change from tile to tile (no per-lane 64-bit pointer arithmetic).
+    const int64_t left64 = n_frames - t0;
+    const int left = left64 < kFramesPerWave ? (int)left64 : kFramesPerWave;     // live frames of this tile (wave-uniform)
+    if (!(LAB & 2) && !(mfcc_elab & 8) && (lane & 15) < left) {
+      float* otile = out + (row * (int64_t)n_frames + t0) * (int64_t)epi.n_mfcc;       // wave-uniform
+      const unsigned ooff = (unsigned)(lane & 15) * (unsigned)epi.n_mfcc + 4u * (unsigned)(lane >> 4);
+#pragma unroll
+      for (int t = 0; t < kMfccMT; ++t) {
+        const int k0 = 16 * t + 4 * (lane >> 4);
+        if (k0 < epi.n_mfcc) *reinterpret_cast<F4*>(otile + (ooff + 16u * (unsigned)t)) = F4{cf[t][0], cf[t][1], cf[t][2], cf[t][3]};
+      }
+    }
+  };
   while (AAMD_M400_IDX_OK(cur_idx)) {
     if (LAB & 8388608) { ph_t = (long long)clock64(); ++ph_tiles; }
     // claim the tile after this one now: it is prefetched while this one is in its second half
@@ -1494,7 +1572,7 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     AAMD_M400_STAMP(3)     // power, P rows
     float acc_a[NR], acc_b[NR];
     if (LAB & 4) { wave_lds_fence(); cur = nxt; cur_idx = nxt_idx; continue; }
-    phase_c<NR, SIG>(c, mt, lds, acc_a, acc_b, mh);
+    phase_c<NR, SIG, EPI == EPI400_MFCC>(c, mt, lds, acc_a, acc_b, mh);
     if (LAB & 8388608) { asm volatile("" : "+v"(acc_a[0]), "+v"(acc_b[NR - 1])); }
     AAMD_M400_STAMP(4)     // band reduction
     if (kDb) {
@@ -1509,27 +1587,61 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       // frames past the end of the clip hold garbage (phase_a): keep them out of the maximum
       const bool va_ok = cur.t0 + 2 * c.p < n_frames, vb_ok = cur.t0 + 2 * c.p + 1 < n_frames;
       float tmin = INFINITY;
+      if (EPI == EPI400_MFCC) {
+        // 80 mels are exactly NR = 4 rounds in which every table row holds a mel (mfcc_fused_ok, checked at kernel entry):
+        // no `round exists` / `row holds a mel` tests; the accumulators are sums of products (canonical), so the amin clamp
+        // is a bare v_max_f32 (fmaxf puts a v_max x, x, x in front of each: the compiler cannot see through phase C's switch);
+        // y = (multiplier log10 2) log2 x - db_sub in one fma (epi_db multiplies twice: <= 1 ulp of y apart, 8e-6 dB at 100 dB)
+        const float db_c1 = epi.multiplier * 0.30102999566398120f;
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        if (r < mt.n_rounds) {
-          acc_a[r] = epi_db(acc_a[r], epi);
-          acc_b[r] = epi_db(acc_b[r], epi);
-          wmax = fmaxf(wmax, fmaxf(va_ok ? acc_a[r] : -INFINITY, vb_ok ? acc_b[r] : -INFINITY));
-          if (EPI == EPI400_MFCC) {
-            const bool real = (mh ? mh->mel(r) : mt.row_mel[r * kMelSlots + c.pi]) >= 0;
-            tmin = fminf(tmin, fminf(va_ok && real ? acc_a[r] : INFINITY, vb_ok && real ? acc_b[r] : INFINITY));
-            acc_a[r] = fmaxf(acc_a[r], fix_cut);       // first pass: fix_cut = -inf
-            acc_b[r] = fmaxf(acc_b[r], fix_cut);
+        for (int r = 0; r < NR; ++r) {
+          acc_a[r] = __builtin_fmaf(__log2f(vmax_raw(acc_a[r], epi.amin)), db_c1, -epi.db_sub);
+          acc_b[r] = __builtin_fmaf(__log2f(vmax_raw(acc_b[r], epi.amin)), db_c1, -epi.db_sub);
+        }
+        if (cur.t0 + kFramesPerWave <= n_frames) {       // interior tile (wave-uniform; 166 of a 10 s clip's 167): six live frames
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            wmax = vmax3_raw(wmax, acc_a[r], acc_b[r]);
+            tmin = vmin3_raw(tmin, acc_a[r], acc_b[r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            wmax = fmaxf(wmax, fmaxf(va_ok ? acc_a[r] : -INFINITY, vb_ok ? acc_b[r] : -INFINITY));
+            tmin = fminf(tmin, fminf(va_ok ? acc_a[r] : INFINITY, vb_ok ? acc_b[r] : INFINITY));
+          }
+        }
+        if (fix) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            acc_a[r] = vmax_raw(acc_a[r], fix_cut);
+            acc_b[r] = vmax_raw(acc_b[r], fix_cut);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          if (r < mt.n_rounds) {
+            acc_a[r] = epi_db(acc_a[r], epi);
+            acc_b[r] = epi_db(acc_b[r], epi);
+            wmax = fmaxf(wmax, fmaxf(va_ok ? acc_a[r] : -INFINITY, vb_ok ? acc_b[r] : -INFINITY));
           }
         }
       }
       if (EPI == EPI400_MFCC && !fix && !(elab & 4)) {
-        // min-scan by DPP moves (VALU; a butterfly of __shfl_xor would be 6 LDS round trips): lane 63 ends with the minimum
-#define AAMD_MIN_STEP(CTRL, ROWS)                                                                                  \
-        tmin = fminf(tmin, __int_as_float(__builtin_amdgcn_update_dpp(0x7f800000, __float_as_int(tmin), CTRL, ROWS, 0xf, false)));
-        AAMD_MIN_STEP(0x111, 0xf) AAMD_MIN_STEP(0x112, 0xf) AAMD_MIN_STEP(0x114, 0xf) AAMD_MIN_STEP(0x118, 0xf)
-        AAMD_MIN_STEP(0x142, 0xa) AAMD_MIN_STEP(0x143, 0xc)
-#undef AAMD_MIN_STEP
+        // min-scan on DPP operands (VALU; a butterfly of __shfl_xor would be 6 LDS round trips): lane 63 ends with the minimum.
+        // One v_min_f32_dpp per step: a lane without a source keeps its value (bound_ctrl off), and the values are results of
+        // arithmetic (canonical), so none of the v_mov / v_max x, x, x the compiler wraps around fminf(update_dpp(..)) is needed;
+        // s_nop 1 = the two wait states between a VALU write and a DPP read of the same register.
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+            : "+v"(tmin));
         if (lane == 63) epi.tile_min[blk_first + cur_idx] = tmin;
       }
     }
@@ -1541,93 +1653,73 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
       using h4 = __attribute__((ext_vector_type(4))) _Float16;
       using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
       using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
-      const u32x4* ftab = reinterpret_cast<const u32x4*>(epi.frag_in_lds ? frag_lds : epi.dct_frag);
-      auto frag_load = [&](int sidx, u32x4 (&a)[kMfccMT][2]) {      // step sidx: 3 coefficient tiles x (hi, lo), 16 B each (LDS)
-#pragma unroll
-        for (int t = 0; t < kMfccMT; ++t)
-#pragma unroll
-          for (int hl = 0; hl < 2; ++hl) {
-            a[t][hl] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-            if (!(elab & 1)) a[t][hl] = ftab[mfcc_frag_piece(t, sidx, hl, lane)];
-          }
-      };
-      u32x4 a0[kMfccMT][2];
       wave_lds_fence();
-      {   // stage: v = y * 2^-8 = hi + lo
+      {   // stage: v = y / 16 = hi + lo.  (Lanes 60 .. 63 shadow lanes 40 .. 43: the same halves to the same addresses.)
         uint16_t* hs = reinterpret_cast<uint16_t*>(lds);
         uint16_t* ls = hs + kMfccPlaneHalves;
-        if (c.active) {
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            if (r < mt.n_rounds) {
-              const int m = mh ? mh->mel(r) : mt.row_mel[r * kMelSlots + c.pi];
-              if (m >= 0) {
-                const float va = acc_a[r] * kMfccYScale, vb = acc_b[r] * kMfccYScale;
-                const _Float16 ha = (_Float16)va, hb = (_Float16)vb;
-                const _Float16 la = (_Float16)(va - (float)ha), lb = (_Float16)(vb - (float)hb);
-                hs[2 * c.p * kMfccMels + m] = __builtin_bit_cast(uint16_t, ha);
-                ls[2 * c.p * kMfccMels + m] = __builtin_bit_cast(uint16_t, la);
-                hs[(2 * c.p + 1) * kMfccMels + m] = __builtin_bit_cast(uint16_t, hb);
-                ls[(2 * c.p + 1) * kMfccMels + m] = __builtin_bit_cast(uint16_t, lb);
-              }
-            }
-          }
+        for (int r = 0; r < NR; ++r) {
+          const int m = mh ? mh->mel(r) : mt.row_mel[r * kMelSlots + c.pi];
+          const float va = acc_a[r] * kMfccYScale, vb = acc_b[r] * kMfccYScale;
+          const _Float16 ha = (_Float16)va, hb = (_Float16)vb;
+          const _Float16 la = (_Float16)(va - (float)ha), lb = (_Float16)(vb - (float)hb);
+          hs[2 * c.p * kMfccMels + m] = __builtin_bit_cast(uint16_t, ha);
+          ls[2 * c.p * kMfccMels + m] = __builtin_bit_cast(uint16_t, la);
+          hs[(2 * c.p + 1) * kMfccMels + m] = __builtin_bit_cast(uint16_t, hb);
+          ls[(2 * c.p + 1) * kMfccMels + m] = __builtin_bit_cast(uint16_t, lb);
         }
       }
       wave_lds_fence();
-      f32x4 cf[kMfccMT];
 #pragma unroll
       for (int t = 0; t < kMfccMT; ++t) cf[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (!(elab & 2)) {
+      // The product (round 6: 18 matrix instructions instead of 27).  The six live frames fill 6 of the 16 B columns, so the
+      // hi plane goes to columns 0 .. 5 and the lo plane to columns 8 .. 13 of ONE operand: A_lo x B and A_hi x B then leave
+      // (A_hi + A_lo) B_hi in lane j and (A_hi + A_lo) B_lo in lane j + 8 of every row of 16 lanes (all four terms; the
+      // three-term form dropped lo x lo), and one DPP add per accumulator register joins them.  One B read per step instead of two.
+      // The fragment table is read through a pointer of its own address space (kFragLds, per instantiation: a pointer selected
+      // at run time made every one of the 18 reads a flat_load).
+      auto product = [&](const u32x4* __restrict__ ftab) {
         const uint16_t* hs = reinterpret_cast<const uint16_t*>(lds);
+        u32x4 a0[kMfccMT][2];
+        auto frag_load = [&](int sidx) {      // step sidx: 3 coefficient tiles x (hi, lo), 16 B each
+#pragma unroll
+          for (int t = 0; t < kMfccMT; ++t)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+              a0[t][hl] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+              if (!(elab & 1)) a0[t][hl] = ftab[mfcc_frag_piece(t, sidx, hl, lane)];
+            }
+        };
         // consecutive MFMAs go to different accumulators (a dependent one would wait out the passes of its predecessor)
-#define AAMD_MFCC_K32(A)                                                                                           \
-        {                                                                                                          \
-          _Pragma("unroll") for (int t = 0; t < kMfccMT; ++t)                                                      \
-            cf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, A[t][1]), bh, cf[t], 0, 0, 0);  \
-          _Pragma("unroll") for (int t = 0; t < kMfccMT; ++t)                                                      \
-            cf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, A[t][0]), bl, cf[t], 0, 0, 0);  \
-          _Pragma("unroll") for (int t = 0; t < kMfccMT; ++t)                                                      \
-            cf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, A[t][0]), bh, cf[t], 0, 0, 0);  \
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          const h8 bb = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(hs + mfcc_b_index(lane, sidx)));
+          frag_load(sidx);
+#pragma unroll
+          for (int t = 0; t < kMfccMT; ++t)
+            cf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a0[t][1]), bb, cf[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < kMfccMT; ++t)
+            cf[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a0[t][0]), bb, cf[t], 0, 0, 0);
         }
-        {
-          const h8 bh = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(hs + mfcc_b_index(lane, 0)));
-          const h8 bl = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(hs + kMfccPlaneHalves + mfcc_b_index(lane, 0)));
-          frag_load(0, a0);
-          AAMD_MFCC_K32(a0)
-        }
-        {
-          const h8 bh = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(hs + mfcc_b_index(lane, 1)));
-          const h8 bl = __builtin_bit_cast(h8, *reinterpret_cast<const u32x4*>(hs + kMfccPlaneHalves + mfcc_b_index(lane, 1)));
-          frag_load(1, a0);
-          AAMD_MFCC_K32(a0)
-        }
-#undef AAMD_MFCC_K32
         {   // mels 64 .. 79: K = 16 (4 halves per lane: the low 8 bytes of the fragment pieces)
-          frag_load(2, a0);
-          const h4 bh = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(hs + mfcc_b_index(lane, 2)));
-          const h4 bl = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(hs + kMfccPlaneHalves + mfcc_b_index(lane, 2)));
+          frag_load(2);
+          const h4 bb = __builtin_bit_cast(h4, *reinterpret_cast<const u32x2*>(hs + mfcc_b_index(lane, 2)));
 #define AAMD_A4(T, HL) __builtin_bit_cast(h4, u32x2{a0[T][HL][0], a0[T][HL][1]})
 #pragma unroll
-          for (int t = 0; t < kMfccMT; ++t) cf[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(AAMD_A4(t, 1), bh, cf[t], 0, 0, 0);
+          for (int t = 0; t < kMfccMT; ++t) cf[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(AAMD_A4(t, 1), bb, cf[t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < kMfccMT; ++t) cf[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(AAMD_A4(t, 0), bl, cf[t], 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < kMfccMT; ++t) cf[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(AAMD_A4(t, 0), bh, cf[t], 0, 0, 0);
+          for (int t = 0; t < kMfccMT; ++t) cf[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(AAMD_A4(t, 0), bb, cf[t], 0, 0, 0);
 #undef AAMD_A4
         }
+      };
+      if (!(elab & 2)) {
+        if (kFragLds) product(reinterpret_cast<const u32x4*>(frag_lds));
+        else product(reinterpret_cast<const u32x4*>(epi.dct_frag));
       }
-      const int j = lane & 15;
-      if (!(LAB & 2) && !(elab & 8) && cur.t0 + j < n_frames && j < kFramesPerWave) {
-        float* orow = out + (cur.row * (int64_t)n_frames + cur.t0 + j) * (int64_t)epi.n_mfcc;
-#pragma unroll
-        for (int t = 0; t < kMfccMT; ++t) {
-          const int k0 = 16 * t + 4 * (lane >> 4);
-          if (k0 < epi.n_mfcc)
-            *reinterpret_cast<F4*>(orow + k0) = F4{cf[t][0] * kMfccOutScale, cf[t][1] * kMfccOutScale,
-                                                   cf[t][2] * kMfccOutScale, cf[t][3] * kMfccOutScale};
-        }
-      }
+      // (Round 6 also deferred this join + store behind the NEXT tile's claim and gather, so that the wave does not sit out its
+      // dependent chain of matrix instructions: no gain, 179.8 against 177.3 us -- profiles/r06_v_mfcc_lab_defer.txt.)
+      if (!(elab & 2)) mfcc_finish(cur.row, cur.t0);
       wave_lds_fence();
       cur = nxt;
       cur_idx = nxt_idx;

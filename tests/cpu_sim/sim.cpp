@@ -616,14 +616,14 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
     }
     if (epi_mode == EPI400_MFCC) {
       // the staged binary16 planes + the fragment maps of v_mfma_f32_16x16x32_f16 / 16x16x16_f16 (A[l & 15][8 (l >> 4) + j],
-      // B[8 (l >> 4) + j][l & 15], C row 4 (l >> 4) + r): hi*hi + hi*lo + lo*hi in fp32
+      // B[8 (l >> 4) + j][l & 15], C row 4 (l >> 4) + r).  Column n of B: n = 0 .. 5 the hi plane of frame n, n = 8 .. 13 the lo
+      // plane of frame n - 8 (mfcc_b_index); A_lo B, then A_hi B; lane j += lane j + 8 of its row of 16 (the DPP row_ror:8 add)
       uint16_t* hs = reinterpret_cast<uint16_t*>(lds);
       uint16_t* ls = hs + kMfccPlaneHalves;
       for (int l = 0; l < 64; ++l) {
-        if (!c[l].active) continue;
         for (int r = 0; r < mt.n_rounds; ++r) {
           const int m = mt.row_mel[r * kMelSlots + c[l].pi];
-          if (m < 0) continue;
+          if (m < 0) return -7;                 // (the kernel traps: 80 mels = 4 full rounds)
           const float va = acc_a[l][r] * kMfccYScale, vb = acc_b[l][r] * kMfccYScale;
           const uint16_t ha = rsm::f16_bits(va), hb = rsm::f16_bits(vb);
           hs[2 * c[l].p * kMfccMels + m] = ha;
@@ -636,18 +636,17 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
       std::memset(C3, 0, sizeof(C3));
       const uint16_t* fh = reinterpret_cast<const uint16_t*>(g_mfcc.frag.data());
       for (int sidx = 0; sidx < kMfccSteps; ++sidx)
-        for (int t = 0; t < kMfccMT; ++t)
-          for (int i = 0; i < 16; ++i)
-            for (int j = 0; j < 16; ++j)
-              for (int g4 = 0; g4 < 4; ++g4)
-                for (int e = 0; e < (sidx < 2 ? 8 : 4); ++e) {
-                  const int la = i + 16 * g4, lb = j + 16 * g4;
-                  const float ah = rsm::f16_value(fh[mfcc_frag_piece(t, sidx, 0, la) * 8 + e]);
-                  const float al = rsm::f16_value(fh[mfcc_frag_piece(t, sidx, 1, la) * 8 + e]);
-                  const float bh = rsm::f16_value(hs[mfcc_b_index(lb, sidx) + e]);
-                  const float bl = rsm::f16_value(ls[mfcc_b_index(lb, sidx) + e]);
-                  C3[t][i][j] += al * bh + ah * bl + ah * bh;
-                }
+        for (int hl = 1; hl >= 0; --hl)
+          for (int t = 0; t < kMfccMT; ++t)
+            for (int i = 0; i < 16; ++i)
+              for (int j = 0; j < 16; ++j)
+                for (int g4 = 0; g4 < 4; ++g4)
+                  for (int e = 0; e < (sidx < 2 ? 8 : 4); ++e) {
+                    const int la = i + 16 * g4, lb = j + 16 * g4;
+                    const float av = rsm::f16_value(fh[mfcc_frag_piece(t, sidx, hl, la) * 8 + e]);
+                    const float bv = rsm::f16_value(hs[mfcc_b_index(lb, sidx) + e]);
+                    C3[t][i][j] += av * bv;
+                  }
       for (int l = 0; l < 64; ++l) {
         const int j = l & 15;
         if (j >= kFramesPerWave || t0 + j >= n_frames) continue;
@@ -655,7 +654,7 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
         for (int t = 0; t < kMfccMT; ++t)
           for (int r = 0; r < 4; ++r) {
             const int k0 = 16 * t + 4 * (l >> 4);
-            if (k0 < g_mfcc.n_mfcc) orow[k0 + r] = C3[t][4 * (l >> 4) + r][j] * kMfccOutScale;
+            if (k0 < g_mfcc.n_mfcc) orow[k0 + r] = C3[t][4 * (l >> 4) + r][j] + C3[t][4 * (l >> 4) + r][(j + 8) & 15];
           }
       }
       cur_staged = nxt_staged;

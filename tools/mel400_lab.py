@@ -3,6 +3,7 @@
 
   build (here, no GPU):   python tools/mel400_lab.py build NAME[:-DFLAG[,-DFLAG...]] ...
   run (GPU box):          python tools/mel400_lab.py run NAME NAME ... [--launches 300] [--rounds 4]
+  MFCC epilogue:          python tools/mel400_lab.py mfcc NAME NAME ... [--launches 200] [--rounds 4]   (cfg4 batch, both passes)
 
 Every variant is tools/lab/mel400_lab.hip (= csrc/melspec400.h alone) compiled into tools/lab/_build/libm400_NAME.so with
 its -D switches.  `run` launches the cfg2 batch (256 x 160 000) with buffers rotating over > 256 MiB, variants interleaved
@@ -162,6 +163,110 @@ def run(names, launches, rounds, rows=256, seconds=10.0, wide=0, blocks=0):
                           "mean": round(sum(v) / len(v), 2), "frac_hbm": round(245841920 / (min(v) * 1e-6) / 8e12, 4)}))
 
 
+def run_mfcc(names, launches, rounds, rows=512, seconds=10.0):
+    """The one-kernel MFCC (lab_mfcc400: pass 0 + fix-up launch, as F._mfcc_fused issues them) on the cfg4 batch: every variant
+    against the product's two-kernel result (max |diff| in dB-weighted coefficient units) and against the first variant, then
+    interleaved timings of the two launches together."""
+    import torch
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    from audio_amd import _lib
+    dev = torch.device("cuda")
+    length = int(16000 * seconds)
+    m = T.MFCC(sample_rate=16000, n_mfcc=40, melkwargs=dict(n_fft=400, hop_length=160, n_mels=80)).to(dev)
+    m.fused = False
+    mel = m.MelSpectrogram
+    bands = F._mel_bands(mel.mel_scale.fb, dev)
+    window = F._padded_window(mel.spectrogram.window, 400)
+    tw = F._twiddles(400, dev)
+    dct = m.dct_mat.detach().to(torch.float32).contiguous()
+    n_frames = 1 + length // 160
+    n_tiles = rows * ((n_frames + 5) // 6)
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    xs = [(0.5 * torch.randn(rows, length, device=dev, generator=g)).clamp_(-1, 1) for _ in range(3)]
+    outs = [torch.empty(rows, n_frames, 40, device=dev) for _ in range(3)]
+    tile_min = torch.empty(n_tiles, device=dev)
+    tile_list = torch.empty(n_tiles, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    gpool = torch.full((1 << 16,), float("-inf"), device=dev)
+    gi = [0]
+    stream = _lib.current_stream(dev)
+    libs, frags, labsw = {}, {}, {}
+    for n in names:
+        base_name, _, sw = n.partition("@")      # NAME@K: library NAME with the epilogue's lab switch K (needs -DLAB_MFCC_BITS=524288)
+        labsw[n] = int(sw or 0)
+        L = C.CDLL(so_path(base_name))
+        L.lab_mfcc400.argtypes = [C.c_void_p] * 5 + [C.c_int64] * 3 + [C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+        L.lab_mfcc_frag_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        fr = torch.empty(L.lab_mfcc_frag_floats(), device=dev)
+        assert L.lab_mfcc_frag_build(dct.data_ptr(), 80, 40, fr.data_ptr(), stream) == 0
+        libs[n], frags[n] = L, fr
+
+    def launch(n, i, passes=(0, 1)):
+        L = libs[n]
+        x, o = xs[i % 3], outs[i % 3]
+        gm = gpool[gi[0]:gi[0] + 1]
+        gi[0] = (gi[0] + 1) % gpool.numel()
+        f = _lib.MfccFused(frags[n].data_ptr(), 40, 0, 10.0, 1e-10, 0.0, 80.0, gm.data_ptr(), rows, tile_min.data_ptr(),
+                           count.data_ptr(), tile_list.data_ptr())
+        for ps in passes:
+            f.pass_ = ps
+            rc = L.lab_mfcc400(x.data_ptr(), window.data_ptr(), tw.data_ptr(), C.byref(bands.struct), o.data_ptr(), rows, length,
+                               length, n_frames, 1.0, C.byref(f), labsw[n], stream)
+            assert rc == 0, rc
+        return o
+
+    ref = m(xs[0]).transpose(-1, -2).contiguous()       # the exact two-kernel path
+    torch.cuda.synchronize()
+    first = None
+    for n in names:
+        o = launch(n, 0).clone()
+        torch.cuda.synchronize()
+        rec = {"check": n, "max_abs_vs_two_kernel": float((o - ref).abs().max()), "redone_tiles": int(count.item())}
+        if first is None:
+            first = o
+        else:
+            rec["max_abs_vs_first"] = float((o - first).abs().max())
+            rec["bit_equal_first"] = bool(torch.equal(o, first))
+        print(json.dumps(rec), flush=True)
+    # a batch that clamps: the last 20 % of every clip silent -> the fix-up pass redoes a fifth of the tiles
+    xz = xs[0].clone()
+    xz[:, int(0.8 * length):] = 0.0
+    keep = xs[0]
+    xs[0] = xz
+    refz = m(xz).transpose(-1, -2).contiguous()
+    for n in names:
+        o = launch(n, 0)
+        torch.cuda.synchronize()
+        print(json.dumps({"check_clamped": n, "max_abs_vs_two_kernel": float((o - refz).abs().max()),
+                          "redone_tiles": int(count.item())}), flush=True)
+    xs[0] = keep
+    gpool.fill_(float("-inf"))
+    for i in range(200):
+        launch(names[0], i)
+    torch.cuda.synchronize()
+    res = {n: [] for n in names}
+    res0 = {n: [] for n in names}
+    for r in range(rounds):
+        for passes, acc in (((0, 1), res), ((0,), res0)):
+            for n in names:
+                gpool.fill_(float("-inf"))
+                for i in range(20):
+                    launch(n, i, passes)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(launches):
+                    launch(n, i, passes)
+                e1.record()
+                torch.cuda.synchronize()
+                acc[n].append(e0.elapsed_time(e1) / launches * 1e3)
+    for n in names:
+        v, v0 = res[n], res0[n]
+        print(json.dumps({"variant": n, "us_per_call_both_passes": [round(t, 1) for t in v], "best": round(min(v), 1),
+                          "pass0_only": [round(t, 1) for t in v0], "best_pass0": round(min(v0), 1),
+                          "frac_hbm": round(409661440 / (min(v) * 1e-6) / 8e12, 4)}), flush=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2:])
@@ -181,4 +286,7 @@ if __name__ == "__main__":
                 blocks = int(args[i + 1]); i += 2
             else:
                 names.append(args[i]); i += 1
-        run(names, launches, rounds, wide=wide, blocks=blocks)
+        if sys.argv[1] == "mfcc":
+            run_mfcc(names, launches, rounds)
+        else:
+            run(names, launches, rounds, wide=wide, blocks=blocks)
