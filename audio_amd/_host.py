@@ -217,11 +217,12 @@ def resample_band_table(kernel: np.ndarray, rel_threshold: float = 2.0 ** -40):
     return lo, span
 
 
-def _rs_pick_ks(span: int) -> int:
-    """rsm::pick_ks (csrc/resample_mfma.h): k-steps of the narrowest kernel instantiation that covers a band of `span` taps."""
+def _rs_pick_ks(span: int, orig: int = 0) -> int:
+    """rsm::pick_ks (csrc/resample_mfma.h): k-steps of the narrowest kernel instantiation that covers a band of `span` taps
+    (104 exists for odd `orig` only: the 8-byte operand layout)."""
     need = (span + 3) // 4
-    for ks in (16, 48, 80, 112):
-        if need <= ks:
+    for ks in (16, 48, 80, 104, 112):
+        if need <= ks and (ks != 104 or (orig & 1)):
             return ks
     return 0
 
@@ -247,7 +248,7 @@ def resample_fill_phase_tiles(kernel: np.ndarray, orig: int, new: int, width: in
             for j in range(m):
                 kp[j * new:(j + 1) * new, j * orig:j * orig + taps] = kernel
         _, span = resample_band_table(kp)
-        ks = _rs_pick_ks(span)
+        ks = _rs_pick_ks(span, m * orig)
         if ks == 0:
             if m == 1:
                 return kernel, 1

@@ -88,7 +88,7 @@ def _register_fakes() -> None:
     @reg("aamd::resample_frag_build")
     def _(kernel, orig, new, width, band_tap_lo, tap_span):
         from . import _host
-        ks = _host._rs_pick_ks(int(tap_span))             # rsm::frag_bytes: tiles x (KS / 8) steps x (hi, lo) x 64 lanes x 16 B
+        ks = _host._rs_pick_ks(int(tap_span), int(orig))  # rsm::frag_bytes: tiles x (KS / 8) steps x (hi, lo) x 64 lanes x 16 B
         return kernel.new_empty((len(band_tap_lo) * (ks // 8) * 2 * 64 * 4,))
 
     @reg("aamd::lfilter")

@@ -1286,9 +1286,8 @@ int aamd_resample_banded_f32(const float* wav, const float* kernel, float* out, 
 }
 
 int64_t aamd_resample_frag_bytes(int32_t orig, int32_t new_, const aamd_resample_bands* bands) {
-  (void)orig;
   if (bands == nullptr || new_ < 1 || bands->n_tiles != (new_ + 15) / 16) return 0;
-  const int ks = rsm::pick_ks(bands->tap_span);
+  const int ks = rsm::pick_ks(bands->tap_span, orig);
   return ks == 0 ? 0 : rsm::frag_bytes(bands->n_tiles, ks);
 }
 
@@ -1299,7 +1298,7 @@ int aamd_resample_frag_build_f32(const float* kernel, int32_t orig, int32_t new_
   AAMD_CHECK_ARG(orig >= 1 && new_ >= 1 && width >= 0, "bad sizes");
   const int n_tiles = (new_ + 15) / 16;
   AAMD_CHECK_ARG(bands->n_tiles == n_tiles && bands->tap_lo != nullptr && bands->tap_span >= 1, "band table must have ceil(new/16) tiles");
-  const int ks = rsm::pick_ks(bands->tap_span);
+  const int ks = rsm::pick_ks(bands->tap_span, orig);
   if (ks == 0) return fail(AAMD_EUNSUPPORTED, "audio_amd: band wider than 448 taps: no matrix-core kernel, no prepared fragments");
   AAMD_CHECK_ARG(reinterpret_cast<uintptr_t>(frag) % 16 == 0, "fragment table must be 16-byte aligned");
   const int taps = 2 * width + orig;
@@ -1323,7 +1322,7 @@ int aamd_resample_prepared_f32(const float* wav, const float* kernel, float* out
                                int64_t out_len, const aamd_resample_bands* bands, const void* frag, void* stream) {
   DeviceScope dev_scope_(wav);
   const int n_tiles = (new_ + 15) / 16;
-  const int ks = bands ? rsm::pick_ks(bands->tap_span) : 0;
+  const int ks = bands ? rsm::pick_ks(bands->tap_span, orig) : 0;
   if (bands == nullptr || ks == 0 || force_generic())
     return aamd_resample_f32(wav, kernel, out, rows, length, row_stride, orig, new_, width, out_len, stream);
   AAMD_CHECK_ARG(wav && kernel && out, "null buffer");
@@ -1389,7 +1388,7 @@ int aamd_resample_prepared_f32(const float* wav, const float* kernel, float* out
 #define AAMD_RSM(KS)                                                                                  \
   do {                                                                                                \
     auto kern = !f16 ? rsm::resample_mfma_kernel<KS> : AAMD_RSM_F16(KS);                              \
-    /* 8-byte operand reads: odd orig, KS = 80 / 112 (resample_mfma.h, b64_rot) */                    \
+    /* 8-byte operand reads: odd orig, KS = 80 / 104 / 112 (resample_mfma.h, b64_rot) */              \
     if (f16 && rd64) kern = AAMD_RSM_RD64(KS);                                                        \
     if (lds > 48 * 1024)                                                                              \
       AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \
@@ -1401,6 +1400,7 @@ int aamd_resample_prepared_f32(const float* wav, const float* kernel, float* out
       case 16: AAMD_RSM(16); break;
       case 48: AAMD_RSM(48); break;
       case 80: AAMD_RSM(80); break;
+      case 104: AAMD_RSM(104); break;      // (odd orig only: pick_ks)
       default: AAMD_RSM(112); break;
     }
 #undef AAMD_RSM

@@ -738,6 +738,47 @@ AAMD_HD void store_spec(int lane, const float* lds, float* out, int64_t a0, int 
   }
 }
 
+// The same copy for a FULL tile (6 x 201 floats; 166 of a 10 s clip's 167): the five 16-byte pieces of a lane are read
+// together and stored from registers; only the run's first and last piece can be ragged (phase != 0, (phase + 1206) % 4 != 0)
+// and their two lanes finish with single floats out of the registers they already hold.  (The loop above reads, waits and
+// stores piece by piece and walks four guarded single-float blocks, each with an LDS read of its own, in its first and last
+// iteration.)
+#ifndef AAMD_M400_SPEC_FULL
+#define AAMD_M400_SPEC_FULL 1
+#endif
+AAMD_HD void store_spec_full(int lane, const float* lds, float* out, int64_t a0) {
+  constexpr int kN = kFramesPerWave * kSpecBins;          // 1206
+  const int phase = (int)(a0 & 3);
+  float* base = out + (a0 - phase);
+  const int n_pieces = (phase + kN + 3) >> 2;             // 302 or 303
+  F4 v[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int j = lane + 64 * u;
+    if (u < 4 || j < n_pieces) v[u] = *reinterpret_cast<const F4*>(lds + 4 * j);
+  }
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int j = lane + 64 * u, i0 = 4 * j;
+    const bool full = i0 >= phase && i0 + 4 <= phase + kN;
+    if ((u < 4 || j < n_pieces) && full) *reinterpret_cast<F4*>(base + i0) = v[u];
+  }
+  // the ragged ends: piece 0 (lane 0 of u = 0) and piece n_pieces - 1 (u = 4)
+  if (lane == 0 && phase != 0) {
+    const float e[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (k >= phase) base[k] = e[k];
+  }
+  const int jl = n_pieces - 1, il = 4 * jl;               // (jl >= 256: a lane of u = 4)
+  if (lane + 256 == jl && il + 4 > phase + kN) {
+    const float e[4] = {v[4].x, v[4].y, v[4].z, v[4].w};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (il + k < phase + kN) base[il + k] = e[k];
+  }
+}
+
 // amplitude_to_DB of one value (functional.py:390-391); log10 through the hardware log2
 // (v_log_f32, ~1 ulp of log2 x => < 2e-5 dB absolute)
 AAMD_HD float fast_log10(float x) {
@@ -1007,6 +1048,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_dst) : "memory", "m0");
 }
 
+// the same with the source as wave-uniform base (SGPR pair) + 32-bit lane offset in bytes: no per-lane 64-bit address
+#ifndef AAMD_M400_DMA_SADDR
+#define AAMD_M400_DMA_SADDR 1
+#endif
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff_bytes, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
 __device__ __forceinline__ void stage_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 struct TileInfo {
@@ -1189,7 +1237,8 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
   // it on, bit 262144 forces the LDS table; the twiddles (38 more registers) stay in LDS (bit 16384: spills at 3 waves/SIMD).
   // (the MFCC instantiation kept its window taps in the LDS table until round 6: its 163 registers were 30 too many because both
   // fragment paths lived in one kernel -- kFragLds above; now 162 with the window and two twiddle batches in registers)
-  constexpr bool kWinRegs = ((LAB & 8192) != 0) || !(LAB & 262144);
+  // (the hop-200 MFCC instantiation reads its fragments from global memory and holds their addresses: window in the LDS table there)
+  constexpr bool kWinRegs = (EPI != EPI400_MFCC || H != 10) && (((LAB & 8192) != 0) || !(LAB & 262144));
   float winr[20], twr[40];
   if (kWinRegs) {
 #pragma unroll
@@ -1356,7 +1405,13 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
     if (LAB & 32) src = wav + 6 * kHop;                 // lab: always the same (cache-resident) tile
 #pragma unroll
     for (int k = 0; k < SG::ndma; ++k)
-      if (!(LAB & 64) || k == 0) glds16(src + spiece[k], s_addr + 1024 * k);   // lab bit 6: one piece only
+      if (!(LAB & 64) || k == 0) {                      // lab bit 6: one piece only
+#if AAMD_M400_DMA_SADDR
+        glds16s(src, (unsigned)spiece[k] * (unsigned)sizeof(TIn), s_addr + 1024 * k);
+#else
+        glds16(src + spiece[k], s_addr + 1024 * k);
+#endif
+      }
   };
 
   // MEL_DB: running maximum of this wave's dB values, flushed whenever the cut-off group changes
@@ -1549,7 +1604,10 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
         const int64_t a0 = (cur.row * n_frames + cur.t0) * (int64_t)kSpecBins;
         phase_b2_spec(c, zr, zi, qr, qi, epi.power, (int)(a0 & 3), lds);
         wave_lds_fence();
-        if (!(LAB & 2)) store_spec(lane, lds, out, a0, n_valid * kSpecBins);
+        if (!(LAB & 2)) {
+          if (AAMD_M400_SPEC_FULL && n_valid == kFramesPerWave) store_spec_full(lane, lds, out, a0);
+          else store_spec(lane, lds, out, a0, n_valid * kSpecBins);
+        }
         wave_lds_fence();
       } else {   // complex output, two halves of 3 frames
 #pragma unroll
@@ -1619,12 +1677,16 @@ melspec400_kernel(const TIn* __restrict__ wav, const float* __restrict__ window,
           }
         }
       } else {
+        // MEL_DB: the same two savings (round 6) -- a bare v_max_f32 for the amin clamp (epi_db's arithmetic otherwise), and no
+        // "frame exists" selects in interior tiles
+        const bool interior = cur.t0 + kFramesPerWave <= n_frames;       // wave-uniform
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           if (r < mt.n_rounds) {
-            acc_a[r] = epi_db(acc_a[r], epi);
-            acc_b[r] = epi_db(acc_b[r], epi);
-            wmax = fmaxf(wmax, fmaxf(va_ok ? acc_a[r] : -INFINITY, vb_ok ? acc_b[r] : -INFINITY));
+            acc_a[r] = epi.multiplier * fast_log10(vmax_raw(acc_a[r], epi.amin)) - epi.db_sub;
+            acc_b[r] = epi.multiplier * fast_log10(vmax_raw(acc_b[r], epi.amin)) - epi.db_sub;
+            if (interior) wmax = vmax3_raw(wmax, acc_a[r], acc_b[r]);
+            else wmax = fmaxf(wmax, fmaxf(va_ok ? acc_a[r] : -INFINITY, vb_ok ? acc_b[r] : -INFINITY));
           }
         }
       }

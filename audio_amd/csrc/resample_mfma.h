@@ -50,12 +50,16 @@ struct Geom {
                              // splits its 224 taps itself (224 scattered loads + 448 binary16 conversions per lane and launch)
 };
 
-// k-steps needed for a band of `span` taps, from the supported set (all = 16 mod 32); 0 = too wide
-AAMD_HD int pick_ks(int span) {
+// k-steps needed for a band of `span` taps, from the supported set; 0 = too wide.  16 / 48 / 80 / 112 are = 16 mod 32 (the
+// 4-byte operand reads are conflict-free for them).  104 (round 6) exists for the 8-byte operand layout only, i.e. for odd
+// `orig`: its odd lane groups rotate by 7 steps (b64_rot) -- and it is exactly what BASELINE config 3 needs: the 16-phase
+// tiles of kaiser_best 441 : 160 span 414 taps = 104 k-steps, so 112 multiplied 7 % of zeros.
+AAMD_HD int pick_ks(int span, int orig = 0) {
   const int need = (span + 3) / 4;
   if (need <= 16) return 16;
   if (need <= 48) return 48;
   if (need <= 80) return 80;
+  if (need <= 104 && (orig & 1)) return 104;
   if (need <= 112) return 112;
   return 0;
 }
@@ -170,11 +174,13 @@ AAMD_HD void store_c_at(const Geom& g, float* out_row, int64_t q, int pt, int la
 //     v_perm_b32 of the hi / lo regrouping takes any two registers: no extra instruction);
 //   * bank model: lanes n of one group are 2 orig dwords apart -- 2 (orig n mod 32) mod 64, sixteen distinct EVEN banks whose
 //     complement among the even banks is the same set + 32; lane group g + 1 sits KS = 16 (mod 32) dwords further, so the odd
-//     lane groups walk the contraction steps ROTATED by r steps with KS + 8 r = 32 (mod 64) (r = 6 for KS = 112, 2 for 80;
+//     lane groups walk the contraction steps ROTATED by r steps with KS + 8 r = 32 (mod 64) (r = 6 for KS = 112, 7 for 104, 2 for 80;
 //     none exists for 16 / 48): step s of an odd group multiplies taps tap_lo + KS g + 8 ((s + r) mod NS) + e.  The 32 lanes a
 //     ds_read_b64 is served with then cover 32 even banks + their odd neighbours: conflict-free (the sum over the contraction
 //     does not care about the order; A fragments are loaded in the same rotated order).
-AAMD_HD constexpr int b64_rot(int ks) { return ks == 112 ? 6 : ks == 80 ? 2 : 0; }
+AAMD_HD constexpr int b64_rot(int ks) { return ks == 112 ? 6 : ks == 104 ? 7 : ks == 80 ? 2 : 0; }
+static_assert((112 + 8 * b64_rot(112)) % 64 == 32 && (104 + 8 * b64_rot(104)) % 64 == 32 && (80 + 8 * b64_rot(80)) % 64 == 32,
+              "odd lane groups must land 32 banks from the even ones");
 AAMD_HD bool b64_ok(int ks, int orig) { return (orig & 1) != 0 && b64_rot(ks) != 0; }
 // tap-table step that lane group `grp4` (= lane >> 4) multiplies at loop step s
 AAMD_HD int b64_step(int ks, int s, int grp4) {
@@ -426,7 +432,7 @@ __device__ long long g_rsm_census[16 * 32 * 8];
 template <int KS, int LABM, int RD = 0>
 __global__ void __launch_bounds__(KS >= 80 ? 768 : 1024)
 resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restrict__ kern, float* __restrict__ out) {
-  static_assert(RD == 0 || b64_rot(KS) != 0, "8-byte operand reads need a conflict-free rotation (KS = 80 / 112)");
+  static_assert(RD == 0 || b64_rot(KS) != 0, "8-byte operand reads need a conflict-free rotation (KS = 80 / 104 / 112)");
   const int lab = LABM ? g.lab : 0;
   using f32x4 = __attribute__((ext_vector_type(4))) float;
   using h8 = __attribute__((ext_vector_type(8))) _Float16;
@@ -628,7 +634,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
       if (s_ % AAMD_RSM_PRO_BATCH == 0) asm volatile("" : "+v"(tap_base));
-      if (s_ == NS - b64_rot(KS)) tap_base -= (lane & 16) * (KS / 16);
+      if (s_ == NS - b64_rot(KS)) tap_base -= ((lane >> 4) & 1) * KS;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int i = 4 * s_ + d;
@@ -690,14 +696,14 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         asm volatile("" ::: "memory");                                                                             \
         R[2 * j] = t_.x; R[2 * j + 1] = t_.y;                                                                      \
       }
-#define AAMD_RSM_READ_A(S, R) { if ((S) == NS - ROT) pa -= (ln & 16) * (KS / 16); AAMD_RSM_PAIRS(pa + 8 * (S), 4, R) }
+#define AAMD_RSM_READ_A(S, R) { if ((S) == NS - ROT) pa -= ((ln >> 4) & 1) * KS; AAMD_RSM_PAIRS(pa + 8 * (S), 4, R) }
       // tile B: its dwords 0 .. 7 of a step are (carry, pairs (1, 2) (3, 4) (5, 6), first half of (7, 8)) and the second half of
       // (7, 8) is dword 0 of the NEXT table step: four pairs per step, every register used (five pairs with two half-used
       // ones were narrowed to ds_read_b32 by the compiler: two-way bank conflicts in this layout).  Dword 0 is read on its own
       // where a run of table steps starts: step 0, and step NS - ROT where the odd lane groups wrap to table step 0
 #define AAMD_RSM_READ_B(S, R)                                                                                      \
       {                                                                                                            \
-        if ((S) == NS - ROT) pb -= (ln & 16) * (KS / 16);                                                          \
+        if ((S) == NS - ROT) pb -= ((ln >> 4) & 1) * KS;                                                          \
         if ((S) == 0 || (S) == NS - ROT) { cf = pb[8 * (S) + 1]; asm volatile("" ::: "memory"); }                  \
         AAMD_RSM_PAIRS(pb + 8 * (S) + 2, 4, R)                                                                     \
       }

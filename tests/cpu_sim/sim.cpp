@@ -585,7 +585,10 @@ static int sim_melspec400_h(const TIn* wav, const float* window, const float* tw
         const int64_t a0 = (row * n_frames + t0) * (int64_t)kSpecBins;
         for (int l = 0; l < 64; ++l)
           phase_b2_spec(c[l], zr[l], zi[l], xr[l], xi[l], epi.power, (int)(a0 & 3), lds);
-        for (int l = 0; l < 64; ++l) store_spec(l, lds, out, a0, n_valid * kSpecBins);
+        for (int l = 0; l < 64; ++l) {
+          if (n_valid == kFramesPerWave) store_spec_full(l, lds, out, a0);     // (the kernel's choice for full tiles)
+          else store_spec(l, lds, out, a0, n_valid * kSpecBins);
+        }
       } else {
         for (int half = 0; half < 2; ++half) {
           const int64_t a0 = (row * n_frames + t0 + 3 * half) * (int64_t)(2 * kSpecBins);
@@ -802,7 +805,7 @@ int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t r
   const bool rd64 = f16 == 2;
   using namespace rsm;
   const int n_tiles = (new_ + 15) / 16;
-  const int ks = pick_ks(tap_span);
+  const int ks = pick_ks(tap_span, orig);
   if (ks == 0) return -2;
   if (rd64 && !b64_ok(ks, orig)) return -6;
   Geom g{};
@@ -1212,7 +1215,7 @@ int64_t sim_gen_lds_bytes(int n_fft, int pb, int layout) {
 // out = {qg, rounds, n_loaders, buf_floats, waves, chunk_q}; returns 0 when even one q-group does not fit.
 int sim_rsm_plan(int orig, int new_, int width, int tap_span, int max_lo, int64_t nq, int f16, int64_t lds_cap, int* out) {
   using namespace rsm;
-  const int ks = pick_ks(tap_span);
+  const int ks = pick_ks(tap_span, orig);
   if (ks == 0) return -2;
   Geom g{};
   g.orig = orig; g.new_ = new_; g.width = width; g.taps = 2 * width + orig;

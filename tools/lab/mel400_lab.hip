@@ -108,3 +108,32 @@ extern "C" int lab_mfcc400(const float* wav, const float* window, const float* t
                      row_stride, n_frames, scale, tiles_per_row, n_tiles, tiles_per_block, in_aligned, 0, epi);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ---- the Spectrogram epilogue (EPI400_SPEC, power 2): what launch_fft400_nr does for hop 160 ---------------------------------------
+#ifndef LAB_SPEC_BITS
+#define LAB_SPEC_BITS 0
+#endif
+extern "C" int lab_spec400(const float* wav, const float* window, const float* tw, float* out, int64_t rows, int64_t length,
+                           int64_t row_stride, int n_frames, float scale, float power, void* stream) {
+  MelBandsDev mb{};
+  const int tiles_per_row = (n_frames + m400::kFramesPerWave - 1) / m400::kFramesPerWave;
+  const int64_t n_tiles = rows * tiles_per_row;
+  const int wpb = m400::kWavesPerBlock;
+  const size_t lds = m400::lds_bytes(0, 1, m400::Hop<8>::lds_dwords);
+  m400::Epi400 epi{};
+  epi.power = power;
+  auto kern = m400::melspec400_kernel<LAB_SPEC_BITS, m400::EPI400_SPEC, 8, float, m400::kMelMaxRounds, 0>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
+  static int cus = 0;
+  if (!cus) { hipDeviceProp_t dp; int dev = 0; (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&dp, dev); cus = dp.multiProcessorCount; }
+  int64_t blocks = cus;
+  const int64_t need = (n_tiles + wpb - 1) / wpb;
+  if (blocks > need) blocks = need;
+  if (blocks >= 8) blocks -= blocks % 8;
+  if (blocks < 1) blocks = 1;
+  const int tiles_per_block = (int)((n_tiles + blocks - 1) / blocks);
+  const int in_aligned = (reinterpret_cast<uintptr_t>(wav) % 16 == 0) && (row_stride % 4 == 0);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, (hipStream_t)stream, wav, window, tw, mb, out, rows, length,
+                     row_stride, n_frames, scale, tiles_per_row, n_tiles, tiles_per_block, in_aligned, 1, epi);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

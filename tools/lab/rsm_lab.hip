@@ -23,8 +23,11 @@ extern "C" int lab_rsm(const float* wav, const float* kernel, float* out, int64_
                        int orig, int new_, int width, int64_t out_len, const int32_t* tap_lo, int tap_span, int lab,
                        int cu_count, void* stream) {
   const int n_tiles = (new_ + 15) / 16;
-  const int ks = rsm::pick_ks(tap_span);
-  if (ks == 0) return -2;
+#ifndef LAB_RSM_KS                 /* the k-step count of this variant: 112 (rounds 2-5) or 104 (round 6: the cfg3 band is 414 taps) */
+#define LAB_RSM_KS 112
+#endif
+  const int ks = LAB_RSM_KS;
+  if (rsm::pick_ks(tap_span, orig) == 0 || rsm::pick_ks(tap_span, orig) > ks) return -2;
   rsm::Geom g{};
   g.lab = LAB_RSM_BITS ? LAB_RSM_BITS : lab;
   g.rows = rows; g.length = length; g.row_stride = row_stride; g.out_len = out_len;
@@ -73,10 +76,9 @@ extern "C" int lab_rsm(const float* wav, const float* kernel, float* out, int64_
     if (blocks > g.n_chunks) blocks = g.n_chunks;
     g.chunks_per_block = (int)((g.n_chunks + blocks - 1) / blocks);
     blocks = (g.n_chunks + g.chunks_per_block - 1) / g.chunks_per_block;
-    if (ks != 112) return -4;                               // the lab serves the cfg3 instantiation
     constexpr int RD = LAB_RSM_RD;
     if (RD && !rsm::b64_ok(ks, orig)) return -5;
-    auto kern = rsm::resample_f16_kernel<112, LAB_RSM_LABM, RD>;
+    auto kern = rsm::resample_f16_kernel<LAB_RSM_KS, LAB_RSM_LABM, RD>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -6;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wg_waves), lds, (hipStream_t)stream, g, wav, kernel, out);

@@ -267,6 +267,62 @@ def run_mfcc(names, launches, rounds, rows=512, seconds=10.0):
                           "frac_hbm": round(409661440 / (min(v) * 1e-6) / 8e12, 4)}), flush=True)
 
 
+def run_spec(names, launches, rounds, rows=256, seconds=10.0):
+    """The Spectrogram epilogue (lab_spec400, power 2) on the cfg2 batch: variants against the product, interleaved timings."""
+    import torch
+    import audio_amd.functional as F
+    import audio_amd.transforms as T
+    from audio_amd import _lib
+    dev = torch.device("cuda")
+    length = int(16000 * seconds)
+    sp = T.Spectrogram(n_fft=400, hop_length=160).to(dev)
+    window = F._padded_window(sp.window, 400)
+    tw = F._twiddles(400, dev)
+    n_frames = 1 + length // 160
+    g = torch.Generator(device="cuda").manual_seed(0)
+    xs = [(torch.rand(rows, length, device=dev, generator=g) - 0.5) for _ in range(4)]
+    outs = [torch.empty(rows, n_frames, 201, device=dev) for _ in range(3)]
+    stream = _lib.current_stream(dev)
+    libs = {}
+    for n in names:
+        L = C.CDLL(so_path(n))
+        L.lab_spec400.argtypes = [C.c_void_p] * 4 + [C.c_int64] * 3 + [C.c_int, C.c_float, C.c_float, C.c_void_p]
+        libs[n] = L
+
+    def launch(n, i):
+        x, o = xs[i % 4], outs[i % 3]
+        rc = libs[n].lab_spec400(x.data_ptr(), window.data_ptr(), tw.data_ptr(), o.data_ptr(), rows, length, length, n_frames, 1.0, 2.0, stream)
+        assert rc == 0, rc
+        return o
+
+    ref = sp(xs[0]).transpose(-1, -2)
+    peak = float(ref.abs().max())
+    for n in names:
+        o = launch(n, 0)
+        torch.cuda.synchronize()
+        print(json.dumps({"check": n, "vs_product_peak_rel": float((o - ref).abs().max()) / peak, "bit_equal": bool(torch.equal(o, ref))}), flush=True)
+    for i in range(400):
+        launch(names[0], i)
+    torch.cuda.synchronize()
+    res = {n: [] for n in names}
+    for r in range(rounds):
+        for n in names:
+            for i in range(20):
+                launch(n, i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(launches):
+                launch(n, i)
+            e1.record()
+            torch.cuda.synchronize()
+            res[n].append(e0.elapsed_time(e1) / launches * 1e3)
+    algo = rows * length * 4 + rows * n_frames * 201 * 4
+    for n in names:
+        v = res[n]
+        print(json.dumps({"variant": n, "us_per_launch": [round(t, 2) for t in v], "best": round(min(v), 2),
+                          "frac_hbm": round(algo / (min(v) * 1e-6) / 8e12, 4)}), flush=True)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2:])
@@ -288,5 +344,7 @@ if __name__ == "__main__":
                 names.append(args[i]); i += 1
         if sys.argv[1] == "mfcc":
             run_mfcc(names, launches, rounds)
+        elif sys.argv[1] == "spec":
+            run_spec(names, launches, rounds)
         else:
             run(names, launches, rounds, wide=wide, blocks=blocks)
