@@ -1380,15 +1380,16 @@ int aamd_resample_prepared_f32(const float* wav, const float* kernel, float* out
     const int threads = 64 * wg_waves;
 #ifdef AAMD_LAB
 #define AAMD_RSM_F16(KS) (g.lab == 0 ? rsm::resample_f16_kernel<KS, 0> : g.lab == 64 ? rsm::resample_f16_kernel<KS, 1> : rsm::resample_f16_kernel<KS, 2>)
-#define AAMD_RSM_RD64(KS) (g.lab == 64 ? rsm::kernel_rd64<KS, 1>() : rsm::kernel_rd64<KS, 0>())
+#define AAMD_RSM_RD64(KS) (g.lab == 64 ? (full ? rsm::kernel_rd64<KS, 1, 1>() : rsm::kernel_rd64<KS, 1>()) : (full ? rsm::kernel_rd64<KS, 0, 1>() : rsm::kernel_rd64<KS, 0>()))
 #else
 #define AAMD_RSM_F16(KS) (rsm::resample_f16_kernel<KS, 0>)
-#define AAMD_RSM_RD64(KS) (rsm::kernel_rd64<KS, 0>())
+#define AAMD_RSM_RD64(KS) (full ? rsm::kernel_rd64<KS, 0, 1>() : rsm::kernel_rd64<KS, 0>())
 #endif
 #define AAMD_RSM(KS)                                                                                  \
   do {                                                                                                \
     auto kern = !f16 ? rsm::resample_mfma_kernel<KS> : AAMD_RSM_F16(KS);                              \
     /* 8-byte operand reads: odd orig, KS = 80 / 104 / 112 (resample_mfma.h, b64_rot) */              \
+    const bool full = rd64 && rsm::chunk_is_full(g, KS);   /* padded chunk: the branch-free loader instantiation */ \
     if (f16 && rd64) kern = AAMD_RSM_RD64(KS);                                                        \
     if (lds > 48 * 1024)                                                                              \
       AAMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                               \

@@ -100,6 +100,14 @@ AAMD_HD bool plan_chunk(Geom& g, int ks, bool f16, int64_t nq, int max_lo, size_
     while (g.rounds < 8 && (int64_t)kQPerGroup * qg * g.rounds < nq && fits(qg * (g.rounds + 1))) ++g.rounds;
   g.qg = qg;
   g.buf_floats = buf_floats_needed(chunk_q(g), g.orig, g.taps, max_lo, ks);
+  // Round 6: on long rows the chunk buffer of the wide f16 instantiations is padded to EXACTLY what the two loader waves hold in
+  // registers (64 x 2 x 30 pieces of 16 bytes): every lane then owns a whole piece in every one of its 30 slots -- no index clamp
+  // in front of the loads and the LDS writes, immediate offsets (the few samples fetched beyond the chunk's reach are the next
+  // chunk's, i.e. L2 hits; they take part in the chunk maximum, which any scale >= the needed one tolerates)
+  if (f16 && ks >= 80 && g.n_loaders == kLoaderWaves) {
+    const int64_t full = 4ll * 64 * kLoaderWaves * loader_pieces_per_lane(ks);
+    if (g.buf_floats <= full && nq * g.orig >= 8 * full && 2 * (size_t)full * sizeof(float) + 48 <= lds_cap) g.buf_floats = (int)full;
+  }
   return 2 * (size_t)g.buf_floats * sizeof(float) + (f16 ? 48 : 0) <= lds_cap;
 }
 
@@ -429,7 +437,9 @@ __device__ long long g_rsm_census[16 * 32 * 8];
 // switch (their branches inside the MFMA loop cut it into basic blocks the scheduler cannot move the LDS reads across:
 // the product kernel carried them until the round-2 census, profiles/r02_v)
 // RD: 0 = ds_read_b32 operand reads (any geometry); 1 = the 8-byte operand reads described above b64_rot (odd orig, KS >= 80)
-template <int KS, int LABM, int RD = 0>
+// FULL: 1 = the chunk buffer is plan_chunk's padded one (64 x 2 x U pieces: every lane of the two loader waves owns a whole piece in
+// every slot) -- an instantiation of its own, because both addressing schemes in one kernel spilled
+template <int KS, int LABM, int RD = 0, int FULL = 0>
 __global__ void __launch_bounds__(KS >= 80 ? 768 : 1024)
 resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restrict__ kern, float* __restrict__ out) {
   static_assert(RD == 0 || b64_rot(KS) != 0, "8-byte operand reads need a conflict-free rotation (KS = 80 / 104 / 112)");
@@ -533,11 +543,32 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       a0 = chunk_a0(g, qc0);
       interior = g.vec_in && a0 >= 0 && a0 + g.buf_floats <= g.length && pieces <= 64 * nld * U && !(lab & 8);
     };
+    constexpr bool full = FULL != 0;   // (the launcher: pieces == 64 * kLoaderWaves * U, two loader waves)
+    // largest |sample| so far, as the bits of a non-negative float (ordered like unsigned integers): two v_max3_f32 with |.| source
+    // modifiers per piece (rounds 2-6: four v_and_b32 + three integer maxima).  A NaN sample no longer forces the unit scale -- the
+    // maximum skips it; the outputs it reaches are NaN either way
     auto absmax = [](unsigned m, const F4& t) {
+#if defined(AAMD_RSM_INT_ABSMAX)
       const unsigned a = __float_as_uint(t.x) & 0x7fffffffu, bb = __float_as_uint(t.y) & 0x7fffffffu;
       const unsigned cc = __float_as_uint(t.z) & 0x7fffffffu, d = __float_as_uint(t.w) & 0x7fffffffu;
       return max(max(m, max(a, bb)), max(cc, d));
+#else
+      asm("v_max3_f32 %0, |%1|, |%2|, %0\n\tv_max3_f32 %0, |%3|, |%4|, %0" : "+v"(m) : "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));   // (one statement: hipcc pads between two)
+      return m;
+#endif
     };
+    // five pieces per statement (hipcc pads an s_nop between two asm statements; U = 20 / 30)
+    auto absmax5 = [](unsigned m, const F4& a, const F4& b, const F4& c, const F4& d, const F4& e) {
+      asm("v_max3_f32 %0, |%1|, |%2|, %0\n\tv_max3_f32 %0, |%3|, |%4|, %0\n\t"
+          "v_max3_f32 %0, |%5|, |%6|, %0\n\tv_max3_f32 %0, |%7|, |%8|, %0\n\t"
+          "v_max3_f32 %0, |%9|, |%10|, %0\n\tv_max3_f32 %0, |%11|, |%12|, %0\n\t"
+          "v_max3_f32 %0, |%13|, |%14|, %0\n\tv_max3_f32 %0, |%15|, |%16|, %0\n\t"
+          "v_max3_f32 %0, |%17|, |%18|, %0\n\tv_max3_f32 %0, |%19|, |%20|, %0"
+          : "+v"(m) : "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w), "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w),
+                      "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w), "v"(e.x), "v"(e.y), "v"(e.z), "v"(e.w));
+      return m;
+    };
+    static_assert(U % 5 == 0, "absmax5 takes the loader's pieces five at a time");
     // the wave's maximum by DPP moves, ONE LDS atomic per wave (64 same-address LDS atomics per wave cost 3.4 us per chunk),
     // then -- behind the wave's own LDS writes, which the LDS executes in order -- the arrival count
     auto publish = [&](int k, unsigned m) {
@@ -558,12 +589,24 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         const F4* base4 = reinterpret_cast<const F4*>(wrow + a0);                                                  \
         int lt_ = lt;                                                                                              \
         asm volatile("" : "+v"(lt_));   /* offsets recomputed here: hoisted out of the chunk loop they get spilled */ \
-        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                            \
-          const int j = lt_ + 64 * nld * u;                                                               \
-          v[u] = base4[(unsigned)(j < pieces ? j : pieces - 1)];                                                   \
+        if (full) {   /* the base in SGPRs (said so: the compiler formed thirty 64-bit lane addresses and spilled) */  \
+          const uint64_t b_ = reinterpret_cast<uint64_t>(base4);                                                   \
+          const uint32_t blo_ = __builtin_amdgcn_readfirstlane((uint32_t)b_);                                      \
+          const uint32_t bhi_ = __builtin_amdgcn_readfirstlane((uint32_t)(b_ >> 32));                              \
+          const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                                    \
+              reinterpret_cast<void*>(((uint64_t)bhi_ << 32) | blo_), 0, 64 * kLoaderWaves * U * 16, 0x00020000);  \
+          const int vo_ = lt_ * 16;   /* buffer loads: descriptor + ONE lane offset + a constant per load */        \
+          _Pragma("unroll") for (int u = 0; u < U; ++u)                                                            \
+            v[u] = __builtin_bit_cast(F4, __builtin_amdgcn_raw_buffer_load_b128(rs_, vo_, 64 * kLoaderWaves * 16 * u, 0)); \
+        } else {                                                                                                   \
+          _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                          \
+            const int j = lt_ + 64 * nld * u;                                                                      \
+            v[u] = base4[(unsigned)(j < pieces ? j : pieces - 1)];                                                 \
+          }                                                                                                        \
         }                                                                                                          \
       }                                                                                                            \
     }
+#if defined(AAMD_RSM_SHARED_CONV)   /* lab: rounds 2-6 -- raw floats staged, every free wave converts them in place (convert()) */
 #define AAMD_RSM_STAGE(CID)                                                                                        \
     {                                                                                                              \
       const int k_ = (int)((CID) - first);                                                                         \
@@ -590,18 +633,81 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       publish(k_, m_);                                                                                             \
       AAMD_RSM_STAMP(k_, 2)                                                                                        \
     }
+#else
+    // Round 6: the loader waves convert THEIR pieces from the registers the fetch left them in -- largest |sample| of the wave
+    // (DPP) -> LDS atomic max + arrival count -> wait for the other loader wave(s) -> the chunk's power-of-two scale -> split
+    // and pack in the registers -> ONE 16-byte LDS write per piece.  (Rounds 2-6 staged the raw floats, and every wave of the
+    // workgroup that found itself free converted batches of them in place: a write, a read and a write per piece, a batch
+    // counter, and the compute waves' matrix loops could not start before the last batch.)  Same maximum, same scale, same
+    // arithmetic per sample: bit-identical results.  Edge chunks (zero padding by index) and chunks longer than the loaders'
+    // registers go through LDS: raw pieces written, then -- behind the same rendezvous -- converted in place by the lane that
+    // wrote them (the LDS executes one wave's accesses in order).
+#define AAMD_RSM_STAGE(CID)                                                                                        \
+    {                                                                                                              \
+      const int k_ = (int)((CID) - first);                                                                         \
+      float* buf_ = smem_rsm + (k_ & 1) * g.buf_floats;                                                            \
+      unsigned m_ = 0u;                                                                                            \
+      AAMD_RSM_STAMP(k_, 0)                                                                                        \
+      if (interior) {   /* ONE wait: the pieces were requested a chunk period ago (left alone: a vmcnt(N) per piece) */ \
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        _Pragma("unroll") for (int u = 0; u < U; u += 5) m_ = absmax5(m_, v[u], v[u + 1], v[u + 2], v[u + 3], v[u + 4]); \
+      } else if (!(lab & 8)) {   /* edge chunks, very long chunks */                                               \
+        _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * nld) {                                          \
+          const F4 t = load_piece(g, wrow, a0, j);                                                                 \
+          *reinterpret_cast<F4*>(buf_ + 4 * j) = t;                                                                \
+          m_ = absmax(m_, t);                                                                                      \
+        }                                                                                                          \
+      }                                                                                                            \
+      AAMD_RSM_STAMP(k_, 1)                                                                                        \
+      publish(k_, m_);                                                                                             \
+      {                                                                                                            \
+        const unsigned want_ = (unsigned)nld * (unsigned)(k_ / 3 + 1);                                             \
+        while (__atomic_load_n(&cnt[k_ % 3], __ATOMIC_RELAXED) < want_) __builtin_amdgcn_s_sleep(1);               \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                     \
+      }                                                                                                            \
+      AAMD_RSM_STAMP(k_, 2)                                                                                        \
+      if (!(lab & 1)) {                                                                                            \
+        float scale_, inv_;                                                                                        \
+        chunk_scale(__atomic_load_n(&mx[k_ % 3], __ATOMIC_RELAXED), scale_, inv_);                                 \
+        if (interior) {   /* a lane past the end holds a copy of the last piece and rewrites it */                 \
+          int lt_ = lt;                                                                                            \
+          asm volatile("" : "+v"(lt_));   /* as in FETCH: nothing of this hoisted out of the chunk loop */          \
+          u32x4* dst_ = reinterpret_cast<u32x4*>(buf_);                                                            \
+          if (full) {   /* one address register, immediate offsets */                                              \
+            u32x4* dl_ = dst_ + lt_;                                                                               \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) dl_[64 * kLoaderWaves * u] = pack4(v[u], scale_);        \
+          } else {                                                                                                 \
+            _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                        \
+              const int j = lt_ + 64 * nld * u;                                                                    \
+              dst_[j < pieces ? j : pieces - 1] = pack4(v[u], scale_);                                             \
+            }                                                                                                      \
+          }                                                                                                        \
+        } else if (!(lab & 8)) {                                                                                   \
+          _Pragma("unroll 4") for (int j = lt; j < pieces; j += 64 * nld) {                                        \
+            const F4 t = *reinterpret_cast<const F4*>(buf_ + 4 * j);                                               \
+            *reinterpret_cast<u32x4*>(buf_ + 4 * j) = pack4(t, scale_);                                            \
+          }                                                                                                        \
+        }                                                                                                          \
+      }                                                                                                            \
+    }
+#endif
     if (first < end) {
       AAMD_RSM_FETCH(first)
       AAMD_RSM_STAGE(first)
     }
     if (first + 1 < end) AAMD_RSM_FETCH(first + 1)
+#if defined(AAMD_RSM_SHARED_CONV)
     if (first < end) convert(0);
+#endif
     __syncthreads();                                     // A0
     for (int64_t cid = first; cid < end; ++cid) {
       if (cid + 1 < end) AAMD_RSM_STAGE(cid + 1)          // fetched a whole chunk period ago; its buffer is free since A(cid - 1)
-      if (cid + 2 < end) AAMD_RSM_FETCH(cid + 2)          // stays in registers until the next round
       AAMD_RSM_STAMP((int)(cid + 1 - first), 3)
+      if (cid + 2 < end) AAMD_RSM_FETCH(cid + 2)          // stays in registers until the next round
+#if defined(AAMD_RSM_SHARED_CONV)
       if (cid + 1 < end) convert((int)(cid + 1 - first));
+#endif
       AAMD_RSM_STAMP((int)(cid + 1 - first), 4)
       __syncthreads();                                   // A(cid)
       AAMD_RSM_STAMP((int)(cid + 1 - first), 5)
@@ -653,7 +759,9 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       if (!(lab & 16)) a_pack16(g, kern, pt, tap_lo, KS, i >> 2, i & 3, lane, ah[i], al[i]);
     }
   }
+#if defined(AAMD_RSM_SHARED_CONV)
   if (first < end) convert(0);
+#endif
   __syncthreads();                                       // A0
   for (int64_t cid = first; cid < end; ++cid) {
     const int k = (int)(cid - first);
@@ -707,10 +815,34 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         if ((S) == 0 || (S) == NS - ROT) { cf = pb[8 * (S) + 1]; asm volatile("" ::: "memory"); }                  \
         AAMD_RSM_PAIRS(pb + 8 * (S) + 2, 4, R)                                                                     \
       }
+#if defined(AAMD_RSM_LAB_NOMFMA)   /* lab, timing only (wrong results): the loop without its matrix instructions (operands kept alive) */
+#define AAMD_RSM_MFMA3(ACC, HV, LV) asm volatile("" :: "v"(HV), "v"(LV), "v"(ahv), "v"(alv));
+#else
 #define AAMD_RSM_MFMA3(ACC, HV, LV)                                                                                \
+      if (!((AAMD_RSM_LAB_T1MASK >> s) & 1)) {                                                                     \
       ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(alv, __builtin_bit_cast(h8, HV), ACC, 0, 0, 0);                 \
       ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, LV), ACC, 0, 0, 0);                 \
+      }                                                                                                            \
       ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahv, __builtin_bit_cast(h8, HV), ACC, 0, 0, 0);
+#endif
+#ifndef AAMD_RSM_LAB_T1MASK      /* lab, timing only (wrong results): steps that issue hi x hi alone */
+#define AAMD_RSM_LAB_T1MASK 0
+#endif
+#ifndef AAMD_RSM_ONE_WAIT
+#define AAMD_RSM_ONE_WAIT 1
+#endif
+      // the eight regrouping instructions of a tile in front of its three matrix instructions (the scheduler put two of them behind
+      // the first MFMA and paid an s_nop for the hazard in front of the second)
+#if defined(AAMD_RSM_NO_ORDER) || defined(AAMD_RSM_LAB_NOPERM) || defined(AAMD_RSM_LAB_NOMFMA)
+#define AAMD_RSM_ORDER_PERM_MFMA
+#else
+#define AAMD_RSM_ORDER_PERM_MFMA if (!((AAMD_RSM_LAB_T1MASK >> s) & 1)) { __builtin_amdgcn_sched_group_barrier(0x002, 8, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); }
+#endif
+#if defined(AAMD_RSM_LAB_NOREAD)   /* lab, timing only (wrong results): operand tiles read once per round, re-used (opaquely) by every step */
+      constexpr bool kNoRead = true;
+#else
+      constexpr bool kNoRead = false;
+#endif
       // operand tiles one after the other as in the 4-byte loop (A(s), B(s), A(s + 1), ...), the reads of the tile after the
       // next in flight: 3 x 8 registers + the carry
       uint32_t ra[2][8], rb[2][8], cf = 0u;
@@ -751,44 +883,57 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #else
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
+        const int cur = kNoRead ? 0 : (s & 1);
         const h8 ahv = __builtin_bit_cast(h8, u32x4{ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]});
         const h8 alv = __builtin_bit_cast(h8, u32x4{al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]});
-        if (s + 1 < NS) AAMD_RSM_READ_A(s + 1, ra[(s + 1) & 1])
+        if (s + 1 < NS && !kNoRead) AAMD_RSM_READ_A(s + 1, ra[(s + 1) & 1])
+        if (kNoRead) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { asm volatile("" : "+v"(ra[0][j])); asm volatile("" : "+v"(rb[0][j])); }
+        }
         __builtin_amdgcn_sched_barrier(0);
+        // ONE wait for the four pairs of the tile (left alone, hipcc waits in front of each regrouping instruction: lgkmcnt(11),
+        // (10), (9), (8) -- four issue slots of a loop that is bound by its issue slots: 19.5 instructions around 3 MFMAs of 4 slots
+        // each, profiles/r06_zd); where the carried dword's read is among the outstanding ones the compiler's own waits stand
+        if (AAMD_RSM_ONE_WAIT && s >= 1 && s + 1 < NS && s != NS - ROT) { __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8)); __builtin_amdgcn_sched_barrier(0); }
         u32x4 hv, lv;
 #if defined(AAMD_RSM_LAB_NOPERM)   /* lab, timing only (wrong results): what the 16 v_perm_b32 per step cost */
 #pragma unroll
-        for (int d = 0; d < 4; ++d) { hv[d] = ra[s & 1][2 * d]; lv[d] = ra[s & 1][2 * d + 1]; }
+        for (int d = 0; d < 4; ++d) { hv[d] = ra[cur][2 * d]; lv[d] = ra[cur][2 * d + 1]; }
 #else
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          hv[d] = __builtin_amdgcn_perm(ra[s & 1][2 * d + 1], ra[s & 1][2 * d], 0x05040100u);
-          lv[d] = __builtin_amdgcn_perm(ra[s & 1][2 * d + 1], ra[s & 1][2 * d], 0x07060302u);
+          hv[d] = __builtin_amdgcn_perm(ra[cur][2 * d + 1], ra[cur][2 * d], 0x05040100u);
+          lv[d] = __builtin_amdgcn_perm(ra[cur][2 * d + 1], ra[cur][2 * d], 0x07060302u);
         }
 #endif
         AAMD_RSM_MFMA3(accA, hv, lv)
+        AAMD_RSM_ORDER_PERM_MFMA
         __builtin_amdgcn_sched_barrier(0);
-        const uint32_t d0 = (s == 0 || s == NS - ROT) ? cf : rb[(s + 1) & 1][7];     // (before the next reads land there)
-        if (s + 1 < NS) AAMD_RSM_READ_B(s + 1, rb[(s + 1) & 1])
+        const uint32_t d0 = (s == 0 || s == NS - ROT) ? cf : rb[kNoRead ? 0 : ((s + 1) & 1)][7];     // (before the next reads land there)
+        if (s + 1 < NS && !kNoRead) AAMD_RSM_READ_B(s + 1, rb[(s + 1) & 1])
         __builtin_amdgcn_sched_barrier(0);
+        if (AAMD_RSM_ONE_WAIT && s >= 1 && s + 1 < NS && s != NS - ROT && s + 1 != NS - ROT) { __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8)); __builtin_amdgcn_sched_barrier(0); }
 #if defined(AAMD_RSM_LAB_NOPERM)
-        hv[0] = d0; lv[0] = rb[s & 1][0];
+        hv[0] = d0; lv[0] = rb[cur][0];
 #pragma unroll
-        for (int d = 1; d < 4; ++d) { hv[d] = rb[s & 1][2 * d - 1]; lv[d] = rb[s & 1][2 * d]; }
+        for (int d = 1; d < 4; ++d) { hv[d] = rb[cur][2 * d - 1]; lv[d] = rb[cur][2 * d]; }
 #else
-        hv[0] = __builtin_amdgcn_perm(rb[s & 1][0], d0, 0x05040100u);
-        lv[0] = __builtin_amdgcn_perm(rb[s & 1][0], d0, 0x07060302u);
+        hv[0] = __builtin_amdgcn_perm(rb[cur][0], d0, 0x05040100u);
+        lv[0] = __builtin_amdgcn_perm(rb[cur][0], d0, 0x07060302u);
 #pragma unroll
         for (int d = 1; d < 4; ++d) {
-          hv[d] = __builtin_amdgcn_perm(rb[s & 1][2 * d], rb[s & 1][2 * d - 1], 0x05040100u);
-          lv[d] = __builtin_amdgcn_perm(rb[s & 1][2 * d], rb[s & 1][2 * d - 1], 0x07060302u);
+          hv[d] = __builtin_amdgcn_perm(rb[cur][2 * d], rb[cur][2 * d - 1], 0x05040100u);
+          lv[d] = __builtin_amdgcn_perm(rb[cur][2 * d], rb[cur][2 * d - 1], 0x07060302u);
         }
 #endif
         AAMD_RSM_MFMA3(accB, hv, lv)
+        AAMD_RSM_ORDER_PERM_MFMA
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
 #undef AAMD_RSM_MFMA3
+#undef AAMD_RSM_ORDER_PERM_MFMA
 #undef AAMD_RSM_READ_A
 #undef AAMD_RSM_READ_B
 #undef AAMD_RSM_PAIRS
@@ -852,10 +997,14 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     }
     AAMD_RSM_STAMP(k, 1)                                 // (the MFMA loops and the stores of all rounds)
     AAMD_RSM_STAMP(k, 2)
+#if defined(AAMD_RSM_SHARED_CONV)
 #if defined(AAMD_RSM_CONV_SIMD23)                         /* lab: the waves of SIMDs 0 / 1 (three MFMA loops each) leave the conversion to the others */
     if (cid + 1 < end && (wave & 3) >= 2) convert(k + 1);
 #else
     if (cid + 1 < end) convert(k + 1);                   // (stamp 3 inside: both loaders have arrived)
+#endif
+#else
+    AAMD_RSM_STAMP(k, 3)
 #endif
     AAMD_RSM_STAMP(k, 4)
     __syncthreads();                                     // A(cid): chunk cid is consumed, chunk cid + 1 is in LDS
@@ -884,10 +1033,14 @@ frag_build_kernel(Geom g, int ks, const float* __restrict__ kern, uint32_t* __re
 }
 
 // the instantiation with 8-byte operand reads where one exists (the launcher asks for it only for those KS)
-template <int KS, int LABM>
+template <int KS, int LABM, int FULL = 0>
 inline auto kernel_rd64() {
-  if constexpr (b64_rot(KS) != 0) return resample_f16_kernel<KS, LABM, 1>;
-  else return resample_f16_kernel<KS, LABM, 0>;
+  if constexpr (b64_rot(KS) != 0) return resample_f16_kernel<KS, LABM, 1, FULL>;
+  else return resample_f16_kernel<KS, LABM, 0, 0>;
+}
+// does the launch's chunk qualify for the FULL instantiations? (plan_chunk pads exactly then)
+AAMD_HD bool chunk_is_full(const Geom& g, int ks) {
+  return ks >= 80 && g.n_loaders == kLoaderWaves && g.buf_floats == 4 * 64 * kLoaderWaves * loader_pieces_per_lane(ks);
 }
 #endif  // __HIPCC__
 

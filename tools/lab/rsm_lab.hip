@@ -78,7 +78,8 @@ extern "C" int lab_rsm(const float* wav, const float* kernel, float* out, int64_
     blocks = (g.n_chunks + g.chunks_per_block - 1) / g.chunks_per_block;
     constexpr int RD = LAB_RSM_RD;
     if (RD && !rsm::b64_ok(ks, orig)) return -5;
-    auto kern = rsm::resample_f16_kernel<LAB_RSM_KS, LAB_RSM_LABM, RD>;
+    const bool full = RD && rsm::chunk_is_full(g, ks);
+    auto kern = full ? rsm::resample_f16_kernel<LAB_RSM_KS, LAB_RSM_LABM, RD, RD ? 1 : 0> : rsm::resample_f16_kernel<LAB_RSM_KS, LAB_RSM_LABM, RD, 0>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -6;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wg_waves), lds, (hipStream_t)stream, g, wav, kernel, out);

@@ -29,9 +29,9 @@ for w in range(10):
     a = t[w]
     d = [(a[:, i + 1] - a[:, i]).mean() for i in range(5)]
     print("  wave %2d: loop %5.2f  stores %5.2f  wait %5.2f  convert %5.2f  barrier %5.2f" % (w, *d))
-print("loader waves (10, 11): data wait + raw LDS stores + max = s1 - s0, publish = s2 - s1, fetch issue = s3 - s2, convert = s4 - s3, barrier = s5 - s4")
+print("loader waves (10, 11), round 6: data wait + max = s1 - s0, publish + wait for the other loader = s2 - s1, convert + LDS writes = s3 - s2, fetch issue = s4 - s3, barrier = s5 - s4")
 for w in (10, 11):
     a = t[w]
     d = [(a[:, i + 1] - a[:, i]).mean() for i in range(5)]
-    print("  wave %2d: stage %5.2f  publish %5.2f  fetch %5.2f  convert %5.2f  barrier %5.2f   | s0 relative to compute wave 0's chunk start: %5.2f" % (
+    print("  wave %2d: data+max %5.2f  publish %5.2f  convert+write %5.2f  fetch %5.2f  barrier %5.2f   | s0 relative to compute wave 0's chunk start: %5.2f" % (
         w, *d, (a[:, 0] - t[0, :, 0]).mean()))
