@@ -186,15 +186,44 @@ AAMD_HD void store_c_at(const Geom& g, float* out_row, int64_t q, int pt, int la
 //     none exists for 16 / 48): step s of an odd group multiplies taps tap_lo + KS g + 8 ((s + r) mod NS) + e.  The 32 lanes a
 //     ds_read_b64 is served with then cover 32 even banks + their odd neighbours: conflict-free (the sum over the contraction
 //     does not care about the order; A fragments are loaded in the same rotated order).
-AAMD_HD constexpr int b64_rot(int ks) { return ks == 112 ? 6 : ks == 104 ? 7 : ks == 80 ? 2 : 0; }
-static_assert((112 + 8 * b64_rot(112)) % 64 == 32 && (104 + 8 * b64_rot(104)) % 64 == 32 && (80 + 8 * b64_rot(80)) % 64 == 32,
-              "odd lane groups must land 32 banks from the even ones");
+// Round 6: the rotation WITH WRAP of round 5 kept that promise only in front of the wrap -- behind it the odd groups sat 8 r dwords
+// from the even ones, not 32 (mod 64): SQ_LDS_BANK_CONFLICT was 31 % of the kernel's LDS cycles (profiles/r06_zl_pmc_resample.txt;
+// the bank model below reproduces the count: 7 of the 13 steps of KS = 104 two-way).  What is needed is a PERMUTATION sigma of the
+// steps with  KS + 8 (sigma(s) - s) = 32 (mod 64)  for as many s as possible, in runs of consecutive steps (tile B carries a
+// dword from step to step inside a run).  The congruence fixes sigma(s) - s modulo 8, and a perfect permutation does not exist
+// for these KS; the tables leave ONE step of 13 (KS = 104) and TWO of 14 / 10 (112 / 80) two-way conflicted:
+//   104: sigma - s = 7 (mod 8): s = 1 .. 4 -> 0 .. 3, s = 5 -> 12, s = 6 .. 12 -> 5 .. 11, and step 0 takes the block left (4)
+//   112: sigma - s = 6 (mod 8): s = 2 .. 5 -> 0 .. 3, s = 6, 7 -> 12, 13, s = 8 .. 13 -> 6 .. 11, steps 0, 1 take 4, 5
+//    80: sigma - s = 2 (mod 8): the rotation by 2 of round 5 (its last two steps are the conflicted ones)
+AAMD_HD constexpr int b64_rot(int ks) { return ks == 112 ? 6 : ks == 104 ? 7 : ks == 80 ? 2 : 0; }   // != 0: the layout exists for this KS
+AAMD_HD constexpr int b64_sigma(int ks, int s) {
+  if (ks == 104) return s == 0 ? 4 : s <= 4 ? s - 1 : s == 5 ? 12 : s - 1;
+  if (ks == 112) return s <= 1 ? s + 4 : s <= 5 ? s - 2 : s <= 7 ? s + 6 : s - 2;
+  if (ks == 80) return s < 8 ? s + 2 : s - 8;
+  return s;
+}
+// a step where the odd groups' run of consecutive table steps starts (tile B reads its carried dword there)
+AAMD_HD constexpr bool b64_run_start(int ks, int s) { return s == 0 || b64_sigma(ks, s) != b64_sigma(ks, s - 1) + 1; }
+// what the odd groups' operand pointer moves by in front of step s, beyond the 8 dwords every step advances
+AAMD_HD constexpr int b64_jump(int ks, int s) {
+  return 8 * ((b64_sigma(ks, s) - s) - (s == 0 ? 0 : b64_sigma(ks, s - 1) - (s - 1)));
+}
+AAMD_HD constexpr bool b64_sigma_is_permutation(int ks) {
+  unsigned seen = 0;
+  for (int s = 0; s < ks / 8; ++s) seen |= 1u << b64_sigma(ks, s);
+  return seen == (1u << (ks / 8)) - 1u;
+}
+AAMD_HD constexpr int b64_conflicted_steps(int ks) {
+  int n = 0;
+  for (int s = 0; s < ks / 8; ++s) n += ((ks + 8 * (b64_sigma(ks, s) - s)) % 64 + 64) % 64 != 32;
+  return n;
+}
+static_assert(b64_sigma_is_permutation(80) && b64_sigma_is_permutation(104) && b64_sigma_is_permutation(112), "every table step once");
+static_assert(b64_conflicted_steps(104) == 1 && b64_conflicted_steps(112) == 2 && b64_conflicted_steps(80) == 2,
+              "odd lane groups must land 32 banks from the even ones in all but these steps");
 AAMD_HD bool b64_ok(int ks, int orig) { return (orig & 1) != 0 && b64_rot(ks) != 0; }
 // tap-table step that lane group `grp4` (= lane >> 4) multiplies at loop step s
-AAMD_HD int b64_step(int ks, int s, int grp4) {
-  const int t = s + ((grp4 & 1) ? b64_rot(ks) : 0), ns = ks / 8;
-  return t >= ns ? t - ns : t;
-}
+AAMD_HD int b64_step(int ks, int s, int grp4) { return (grp4 & 1) ? b64_sigma(ks, s) : s; }
 // LDS dword index of the B fragment of lane l, tile h (q = 2 n + h) of 32-q group `grp`, table step 0
 AAMD_HD int b_base64(const Geom& g, int grp, int h, int tap_lo, int ks, int shift, int lane) {
   return (32 * grp + 2 * (lane & 15) + h) * g.orig + tap_lo + ks * (lane >> 4) + shift;
@@ -736,11 +765,11 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #ifndef AAMD_RSM_PRO_BATCH
 #define AAMD_RSM_PRO_BATCH 2
 #endif
-    int tap_base = tap_lo + KS * (lane >> 4) + ((lane & 16) ? 8 * b64_rot(KS) : 0);
+    int tap_base = tap_lo + KS * (lane >> 4);
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
       if (s_ % AAMD_RSM_PRO_BATCH == 0) asm volatile("" : "+v"(tap_base));
-      if (s_ == NS - b64_rot(KS)) tap_base -= ((lane >> 4) & 1) * KS;
+      if (b64_jump(KS, s_) != 0) tap_base += ((lane >> 4) & 1) * b64_jump(KS, s_);
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int i = 4 * s_ + d;
@@ -792,8 +821,8 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       asm volatile("" : "+v"(ln));
       const int hA = (tap_lo + shift) & 1, hB = hA ^ 1;
       const int odd_g = (ln >> 4) & 1;
-      const uint32_t* pa = buf + b_base64(g, grp, hA, tap_lo, KS, shift, ln) + (odd_g ? 8 * ROT : 0);
-      const uint32_t* pb = buf + b_base64(g, grp, hB, tap_lo, KS, shift, ln) - 1 + (odd_g ? 8 * ROT : 0);
+      const uint32_t* pa = buf + b_base64(g, grp, hA, tap_lo, KS, shift, ln);
+      const uint32_t* pb = buf + b_base64(g, grp, hB, tap_lo, KS, shift, ln) - 1;
       // steps s >= NS - ROT of the odd lane groups read table step s + ROT - NS: both pointers step back KS dwords there
       // (once per tile and round, formed from the lane number: nothing more to hold across the loop)
       f32x4 accA = {0.0f, 0.0f, 0.0f, 0.0f}, accB = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -804,15 +833,15 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         asm volatile("" ::: "memory");                                                                             \
         R[2 * j] = t_.x; R[2 * j + 1] = t_.y;                                                                      \
       }
-#define AAMD_RSM_READ_A(S, R) { if ((S) == NS - ROT) pa -= ((ln >> 4) & 1) * KS; AAMD_RSM_PAIRS(pa + 8 * (S), 4, R) }
+#define AAMD_RSM_READ_A(S, R) { if (b64_jump(KS, S) != 0) pa += odd_g * b64_jump(KS, S); AAMD_RSM_PAIRS(pa + 8 * (S), 4, R) }
       // tile B: its dwords 0 .. 7 of a step are (carry, pairs (1, 2) (3, 4) (5, 6), first half of (7, 8)) and the second half of
       // (7, 8) is dword 0 of the NEXT table step: four pairs per step, every register used (five pairs with two half-used
       // ones were narrowed to ds_read_b32 by the compiler: two-way bank conflicts in this layout).  Dword 0 is read on its own
       // where a run of table steps starts: step 0, and step NS - ROT where the odd lane groups wrap to table step 0
 #define AAMD_RSM_READ_B(S, R)                                                                                      \
       {                                                                                                            \
-        if ((S) == NS - ROT) pb -= ((ln >> 4) & 1) * KS;                                                          \
-        if ((S) == 0 || (S) == NS - ROT) { cf = pb[8 * (S) + 1]; asm volatile("" ::: "memory"); }                  \
+        if (b64_jump(KS, S) != 0) pb += odd_g * b64_jump(KS, S);                                                   \
+        if (b64_run_start(KS, S)) { cf = pb[8 * (S) + 1]; asm volatile("" ::: "memory"); }                         \
         AAMD_RSM_PAIRS(pb + 8 * (S) + 2, 4, R)                                                                     \
       }
 #if defined(AAMD_RSM_LAB_NOMFMA)   /* lab, timing only (wrong results): the loop without its matrix instructions (operands kept alive) */
@@ -855,7 +884,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       for (int s = 0; s < NS; ++s) {
         const h8 ahv = __builtin_bit_cast(h8, u32x4{ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]});
         const h8 alv = __builtin_bit_cast(h8, u32x4{al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]});
-        const uint32_t d0 = (s == 0 || s == NS - ROT) ? cf : rb[(s + 1) & 1][7];
+        const uint32_t d0 = b64_run_start(KS, s) ? cf : rb[(s + 1) & 1][7];
         u32x4 hv, lv, hw, lw;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -895,7 +924,11 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         // ONE wait for the four pairs of the tile (left alone, hipcc waits in front of each regrouping instruction: lgkmcnt(11),
         // (10), (9), (8) -- four issue slots of a loop that is bound by its issue slots: 19.5 instructions around 3 MFMAs of 4 slots
         // each, profiles/r06_zd); where the carried dword's read is among the outstanding ones the compiler's own waits stand
-        if (AAMD_RSM_ONE_WAIT && s >= 1 && s + 1 < NS && s != NS - ROT) { __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8)); __builtin_amdgcn_sched_barrier(0); }
+        // (outstanding behind tile A(s): B(s) -- with its carried dword where a run starts -- and A(s + 1))
+        if (AAMD_RSM_ONE_WAIT && s + 1 < NS) {
+          if (b64_run_start(KS, s)) __builtin_amdgcn_s_waitcnt(0xC07F | (9 << 8)); else __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8));
+          __builtin_amdgcn_sched_barrier(0);
+        }
         u32x4 hv, lv;
 #if defined(AAMD_RSM_LAB_NOPERM)   /* lab, timing only (wrong results): what the 16 v_perm_b32 per step cost */
 #pragma unroll
@@ -910,10 +943,14 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         AAMD_RSM_MFMA3(accA, hv, lv)
         AAMD_RSM_ORDER_PERM_MFMA
         __builtin_amdgcn_sched_barrier(0);
-        const uint32_t d0 = (s == 0 || s == NS - ROT) ? cf : rb[kNoRead ? 0 : ((s + 1) & 1)][7];     // (before the next reads land there)
+        const uint32_t d0 = b64_run_start(KS, s) ? cf : rb[kNoRead ? 0 : ((s + 1) & 1)][7];     // (before the next reads land there)
         if (s + 1 < NS && !kNoRead) AAMD_RSM_READ_B(s + 1, rb[(s + 1) & 1])
         __builtin_amdgcn_sched_barrier(0);
-        if (AAMD_RSM_ONE_WAIT && s >= 1 && s + 1 < NS && s != NS - ROT && s + 1 != NS - ROT) { __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8)); __builtin_amdgcn_sched_barrier(0); }
+        // (behind tile B(s): A(s + 1) and B(s + 1))
+        if (AAMD_RSM_ONE_WAIT && s + 1 < NS) {
+          if (b64_run_start(KS, s + 1)) __builtin_amdgcn_s_waitcnt(0xC07F | (9 << 8)); else __builtin_amdgcn_s_waitcnt(0xC07F | (8 << 8));
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #if defined(AAMD_RSM_LAB_NOPERM)
         hv[0] = d0; lv[0] = rb[cur][0];
 #pragma unroll

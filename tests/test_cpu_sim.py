@@ -856,6 +856,22 @@ def test_resampler_chunk_plan_respects_the_hardware_limits():
     assert seen_rounds > 20 and seen_four > 20          # both mechanisms are exercised by the grid
 
 
+def test_resampler_8_byte_operand_reads_bank_model():
+    """The odd lane groups of the 8-byte operand layout walk the contraction steps in the order rsm::b64_sigma so that they sit 32
+    banks from the even groups: under the LDS bank model (ds_read_b64: two groups of 32 lanes over 64 dword banks) ONE step of 13
+    is two-way conflicted for KS = 104 and two of 14 / 10 for KS = 112 / 80, for every phase tile and chunk phase -- round 5's
+    rotation with wrap conflicted in 7 of 13 (SQ_LDS_BANK_CONFLICT = 31 % of the LDS cycles, profiles/r06_zl_pmc_resample.txt)."""
+    import ctypes as C
+    f = S.sim().sim_rsm_b64_conflicted_steps
+    f.argtypes = [C.c_int] * 4
+    for ks, span, expect in ((80, 318, 2), (104, 414, 1), (112, 446, 2)):
+        for orig in (441, 147, 3, 4411):
+            for tap_lo in (0, 1, 45, 90, 134, 398):
+                for shift in range(4):
+                    assert f(ks, orig, tap_lo, shift) <= expect, (ks, orig, tap_lo, shift)
+    assert f(104, 441, 1, 0) == 1 and f(104, 440, 1, 0) == -1        # (even orig: no 8-byte layout)
+
+
 @pytest.mark.parametrize("r,theta", [(0.9995, 0.3), (0.999, 1.2), (0.99, 0.05), (0.9999, 2.0)])
 def test_sim_lfilter_wave_slowly_decaying_poles_across_waves(r, theta):
     """Resonators whose impulse response outlives a wave's 2048 samples (|pole|^2048 = 0.36 at 0.9995, 0.81 at 0.9999): the
