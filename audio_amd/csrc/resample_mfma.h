@@ -792,6 +792,28 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   if (first < end) convert(0);
 #endif
   __syncthreads();                                       // A0
+  // The scalars of a chunk -- its row, first output group, 16-byte phase, output row, and the scale that undoes the chunk's
+  // power-of-two (from the loaders' maximum) -- are ~75 dependent scalar instructions and an LDS round trip.  Round 6: they are
+  // worked out for chunk k + 1 IN FRONT of barrier A(k), where eleven of the twelve waves wait anyway; behind the barrier every wave
+  // of the workgroup did them at the same moment and no matrix instruction issued for ~0.3 us of a 5.3 us chunk period.  The maximum
+  // of chunk k + 1 is final once all loader waves have counted themselves in (cnt: it is, long before; checked, with the
+  // acquire fence the barrier used to supply).
+  struct ChunkHeader { float inv; int shift; int64_t qc0; float* out_row; };
+  auto chunk_header = [&](int64_t cid_) {
+    ChunkHeader h;
+    const int k_ = (int)(cid_ - first);
+    const unsigned want_ = (unsigned)nld * (unsigned)(k_ / 3 + 1);
+    while (__atomic_load_n(&cnt[k_ % 3], __ATOMIC_RELAXED) < want_) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float scale_;
+    chunk_scale(__atomic_load_n(&mx[k_ % 3], __ATOMIC_RELAXED), scale_, h.inv);
+    const int64_t row_ = (int64_t)((uint32_t)cid_ / (uint32_t)g.chunks_per_row);   // n_chunks < 2^31 (checked by the launcher)
+    h.qc0 = (cid_ - row_ * g.chunks_per_row) * qc;
+    h.shift = (int)((h.qc0 * g.orig - g.width) - chunk_a0(g, h.qc0));
+    h.out_row = out + row_ * g.out_len;
+    return h;
+  };
+  ChunkHeader hdr{};
   for (int64_t cid = first; cid < end; ++cid) {
     const int k = (int)(cid - first);
     AAMD_RSM_STAMP(k, 0)
@@ -803,12 +825,15 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #endif
 #endif
     const uint32_t* buf = reinterpret_cast<const uint32_t*>(smem_rsm + (k & 1) * g.buf_floats);
-    float scale, inv;
-    chunk_scale(mx[k % 3], scale, inv);
-    const int64_t row = (int64_t)((uint32_t)cid / (uint32_t)g.chunks_per_row);   // n_chunks < 2^31 (checked by the launcher)
-    const int64_t qc0 = (cid - row * g.chunks_per_row) * qc;
-    const int shift = (int)((qc0 * g.orig - g.width) - chunk_a0(g, qc0));
-    float* out_row = out + row * g.out_len;
+#if defined(AAMD_RSM_HEADER_BEHIND_BARRIER)   /* lab: rounds 2-6 -- every wave works out the chunk's scalars right behind the barrier */
+    if (true) hdr = chunk_header(cid);
+#else
+    if (k == 0) hdr = chunk_header(cid);
+#endif
+    const float inv = hdr.inv;
+    const int64_t qc0 = hdr.qc0;
+    const int shift = hdr.shift;
+    float* out_row = hdr.out_row;
 #pragma unroll 1
     for (int r = 0; r < g.rounds; ++r) {                 // (indentation of the body kept: one more level would not fit the lines)
     if constexpr (RD == 1) {
@@ -875,7 +900,14 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       // operand tiles one after the other as in the 4-byte loop (A(s), B(s), A(s + 1), ...), the reads of the tile after the
       // next in flight: 3 x 8 registers + the carry
       uint32_t ra[2][8], rb[2][8], cf = 0u;
+#if defined(AAMD_RSM_DEEP_A)
+      uint32_t ra3[3][8];
+#define AAMD_RSM_RA_CUR ra3[s % 3]
+      AAMD_RSM_READ_A(0, ra3[0])
+#else
+#define AAMD_RSM_RA_CUR ra[cur]
       AAMD_RSM_READ_A(0, ra[0])
+#endif
       AAMD_RSM_READ_B(0, rb[0])
       __builtin_amdgcn_sched_barrier(0);
 #if defined(AAMD_RSM_B64_INTERLEAVE)
@@ -915,7 +947,12 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         const int cur = kNoRead ? 0 : (s & 1);
         const h8 ahv = __builtin_bit_cast(h8, u32x4{ah[4 * s], ah[4 * s + 1], ah[4 * s + 2], ah[4 * s + 3]});
         const h8 alv = __builtin_bit_cast(h8, u32x4{al[4 * s], al[4 * s + 1], al[4 * s + 2], al[4 * s + 3]});
+#if defined(AAMD_RSM_DEEP_A)   /* lab: tile A's pairs requested two steps ahead (three register sets) */
+        if (s == 0 && NS > 1) AAMD_RSM_READ_A(1, ra3[1])
+        if (s + 2 < NS) AAMD_RSM_READ_A(s + 2, ra3[(s + 2) % 3])
+#else
         if (s + 1 < NS && !kNoRead) AAMD_RSM_READ_A(s + 1, ra[(s + 1) & 1])
+#endif
         if (kNoRead) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { asm volatile("" : "+v"(ra[0][j])); asm volatile("" : "+v"(rb[0][j])); }
@@ -932,12 +969,12 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
         u32x4 hv, lv;
 #if defined(AAMD_RSM_LAB_NOPERM)   /* lab, timing only (wrong results): what the 16 v_perm_b32 per step cost */
 #pragma unroll
-        for (int d = 0; d < 4; ++d) { hv[d] = ra[cur][2 * d]; lv[d] = ra[cur][2 * d + 1]; }
+        for (int d = 0; d < 4; ++d) { hv[d] = AAMD_RSM_RA_CUR[2 * d]; lv[d] = AAMD_RSM_RA_CUR[2 * d + 1]; }
 #else
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          hv[d] = __builtin_amdgcn_perm(ra[cur][2 * d + 1], ra[cur][2 * d], 0x05040100u);
-          lv[d] = __builtin_amdgcn_perm(ra[cur][2 * d + 1], ra[cur][2 * d], 0x07060302u);
+          hv[d] = __builtin_amdgcn_perm(AAMD_RSM_RA_CUR[2 * d + 1], AAMD_RSM_RA_CUR[2 * d], 0x05040100u);
+          lv[d] = __builtin_amdgcn_perm(AAMD_RSM_RA_CUR[2 * d + 1], AAMD_RSM_RA_CUR[2 * d], 0x07060302u);
         }
 #endif
         AAMD_RSM_MFMA3(accA, hv, lv)
@@ -970,6 +1007,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       }
 #endif
 #undef AAMD_RSM_MFMA3
+#undef AAMD_RSM_RA_CUR
 #undef AAMD_RSM_ORDER_PERM_MFMA
 #undef AAMD_RSM_READ_A
 #undef AAMD_RSM_READ_B
@@ -1044,6 +1082,9 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     AAMD_RSM_STAMP(k, 3)
 #endif
     AAMD_RSM_STAMP(k, 4)
+#if !defined(AAMD_RSM_HEADER_BEHIND_BARRIER)
+    if (cid + 1 < end) hdr = chunk_header(cid + 1);
+#endif
     __syncthreads();                                     // A(cid): chunk cid is consumed, chunk cid + 1 is in LDS
     AAMD_RSM_STAMP(k, 5)
     if (threadIdx.x == 0) { mx[k % 3] = 0u; grab[k % 3] = 0u; }                // read by everybody before A(cid); next written behind A(cid + 1)
