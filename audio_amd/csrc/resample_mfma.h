@@ -478,7 +478,20 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
   constexpr int NS = KS / 8;                       // MFMA steps: 8 taps per lane group and step
   extern __shared__ __attribute__((aligned(16))) float smem_rsm[];
-  unsigned* mx = reinterpret_cast<unsigned*>(smem_rsm + 2 * g.buf_floats);     // [3]: largest |sample| bits, chunk k -> slot k % 3
+#ifndef AAMD_RSM_FLAGS
+#define AAMD_RSM_FLAGS 0
+#endif
+  // AAMD_RSM_FLAGS = 1 (round 6): no workgroup barrier in the chunk loop.  The two LDS buffers are handed over by counters -- `fullc[b]`:
+  // loader waves that have written their packed pieces of a chunk into buffer b; `donec[b]`: compute waves that have finished reading
+  // it -- so a wave that is done with chunk k goes on to chunk k + 1 as soon as the loaders have it, instead of idling at the barrier
+  // until the slowest wave of the workgroup arrives (the oldest wave of a SIMD finishes its matrix loop 2 us before the youngest of a
+  // 5.3 us period, profiles/r06_zi).  Every wave of the workgroup is resident: the waits are bounded.  Four maximum slots instead of
+  // three; a slot is zeroed by the first loader wave one chunk before its next use (see publish).
+  constexpr int kSlots = AAMD_RSM_FLAGS ? 4 : 3;
+#if AAMD_RSM_FLAGS && defined(AAMD_RSM_SHARED_CONV)
+#error "the flag hand-over needs the loader-side conversion (the batch counters of AAMD_RSM_SHARED_CONV share its LDS words)"
+#endif
+  unsigned* mx = reinterpret_cast<unsigned*>(smem_rsm + 2 * g.buf_floats);     // [kSlots]: largest |sample| bits, chunk k -> slot k % kSlots
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ncw = g.n_pt * g.qg;
@@ -494,7 +507,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   const int64_t first = (int64_t)blockIdx.x * g.chunks_per_block;
   int64_t end = first + g.chunks_per_block;
   if (end > g.n_chunks) end = g.n_chunks;
-  if (threadIdx.x < 9) mx[threadIdx.x] = 0u;          // 3 maxima + 3 arrival counters + 3 batch counters
+  if (threadIdx.x < 12) mx[threadIdx.x] = 0u;         // maxima + arrival counters + (3 batch counters | 2 + 2 hand-over counters): 48 bytes
   __syncthreads();
 
   // Timeline (one barrier per chunk):
@@ -507,7 +520,10 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   // (compute waves behind their MFMA loops, loaders behind their fetches), once all loaders have arrived, takes batches of
   // the raw image from an LDS counter and turns them into packed (lo << 16 | hi) dwords in place.  Round-2 census (profiles/r02_v): with the conversion in the two loader waves they were the critical
   // path of every chunk (6.8 of 7.5 us) while the ten compute waves idled 2.3 - 3.9 us at the barrier.
-  unsigned* cnt = mx + 3;                              // [3]: loader waves whose raw samples and maximum are in LDS, monotonic
+  unsigned* cnt = mx + kSlots;                         // [kSlots]: loader waves whose maximum is in LDS, monotonic
+  unsigned* fullc = mx + 8;                            // [2] (AAMD_RSM_FLAGS): loader waves that have filled buffer b, monotonic
+  unsigned* donec = mx + 10;                           // [2] (AAMD_RSM_FLAGS): compute waves that have consumed buffer b, monotonic
+  (void)fullc; (void)donec;
   auto pack4 = [](const F4& t, float scale) {
     u32x4 o;
 #if defined(AAMD_RSM_RNE_SAMPLES)    /* lab: the round-to-nearest split of the samples (6 operations each; the taps always use it) */
@@ -521,11 +537,11 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   // wave is free (the early finishers of the MFMA loop and the loaders behind their fetches take most of them; the last
   // compute waves of a period find nothing left), once all loader waves have counted themselves in (slot k % 3 is used for
   // the (k / 3 + 1)-th time; every wave of the workgroup is resident, so the wait is bounded)
-  unsigned* grab = cnt + 3;                            // [3]: batches handed out
+  unsigned* grab = cnt + 3;                            // [3]: batches handed out (AAMD_RSM_SHARED_CONV builds only)
   constexpr int kGrab = 3;
   auto convert = [&](int k) {
-    const unsigned want = (unsigned)nld * (unsigned)(k / 3 + 1);
-    while (__atomic_load_n(&cnt[k % 3], __ATOMIC_RELAXED) < want) __builtin_amdgcn_s_sleep(1);
+    const unsigned want = (unsigned)nld * (unsigned)(k / kSlots + 1);
+    while (__atomic_load_n(&cnt[k % kSlots], __ATOMIC_RELAXED) < want) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (!loader) { AAMD_RSM_STAMP(k - 1, 3) }
     if (lab & 1) return;
@@ -533,7 +549,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
     __builtin_amdgcn_s_setprio(AAMD_RSM_PRIO_CONV);     // lab: the conversion yields its issue slots to the MFMA loops still running
 #endif
     float scale, inv;
-    chunk_scale(__atomic_load_n(&mx[k % 3], __ATOMIC_RELAXED), scale, inv);
+    chunk_scale(__atomic_load_n(&mx[k % kSlots], __ATOMIC_RELAXED), scale, inv);
     float* buf = smem_rsm + (k & 1) * g.buf_floats;
     for (;;) {
       unsigned b = 0u;
@@ -607,8 +623,12 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #undef AAMD_RSM_MAX_STEP
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 63) {
-        atomicMax(&mx[k % 3], m);
-        atomicAdd(&cnt[k % 3], 1u);
+        atomicMax(&mx[k % kSlots], m);
+        // (flags: the slot of chunk k + 1 was last used by chunk k - 3, whose readers -- the compute waves' headers -- ran before
+        // their loops of chunk k - 3, and this wave has waited for the end of those loops in its stage of chunk k - 1; the other
+        // loader waves publish into it only behind this chunk's rendezvous, i.e. behind the atomicAdd below)
+        if (AAMD_RSM_FLAGS && wave == ncw) __atomic_store_n(&mx[(k + 1) % kSlots], 0u, __ATOMIC_RELAXED);
+        atomicAdd(&cnt[k % kSlots], 1u);
       }
     };
 #define AAMD_RSM_FETCH(CID)                                                                                        \
@@ -691,14 +711,19 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       AAMD_RSM_STAMP(k_, 1)                                                                                        \
       publish(k_, m_);                                                                                             \
       {                                                                                                            \
-        const unsigned want_ = (unsigned)nld * (unsigned)(k_ / 3 + 1);                                             \
-        while (__atomic_load_n(&cnt[k_ % 3], __ATOMIC_RELAXED) < want_) __builtin_amdgcn_s_sleep(1);               \
+        const unsigned want_ = (unsigned)nld * (unsigned)(k_ / kSlots + 1);                                             \
+        while (__atomic_load_n(&cnt[k_ % kSlots], __ATOMIC_RELAXED) < want_) __builtin_amdgcn_s_sleep(1);               \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                     \
       }                                                                                                            \
       AAMD_RSM_STAMP(k_, 2)                                                                                        \
+      if (AAMD_RSM_FLAGS) {   /* the buffer's previous chunk (k - 2) consumed by every compute wave */              \
+        const unsigned wd_ = (unsigned)ncw * (unsigned)(k_ / 2);                                                   \
+        while (__atomic_load_n(&donec[k_ & 1], __ATOMIC_RELAXED) < wd_) __builtin_amdgcn_s_sleep(1);               \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                                     \
+      }                                                                                                            \
       if (!(lab & 1)) {                                                                                            \
         float scale_, inv_;                                                                                        \
-        chunk_scale(__atomic_load_n(&mx[k_ % 3], __ATOMIC_RELAXED), scale_, inv_);                                 \
+        chunk_scale(__atomic_load_n(&mx[k_ % kSlots], __ATOMIC_RELAXED), scale_, inv_);                                 \
         if (interior) {   /* a lane past the end holds a copy of the last piece and rewrites it */                 \
           int lt_ = lt;                                                                                            \
           asm volatile("" : "+v"(lt_));   /* as in FETCH: nothing of this hoisted out of the chunk loop */          \
@@ -719,6 +744,10 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
           }                                                                                                        \
         }                                                                                                          \
       }                                                                                                            \
+      if (AAMD_RSM_FLAGS) {   /* behind the wave's own LDS writes (the LDS executes a wave's accesses in order) */   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                                     \
+        if (lane == 63) atomicAdd(&fullc[k_ & 1], 1u);                                                             \
+      }                                                                                                            \
     }
 #endif
     if (first < end) {
@@ -729,7 +758,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #if defined(AAMD_RSM_SHARED_CONV)
     if (first < end) convert(0);
 #endif
-    __syncthreads();                                     // A0
+    if (!AAMD_RSM_FLAGS) __syncthreads();                // A0
     for (int64_t cid = first; cid < end; ++cid) {
       if (cid + 1 < end) AAMD_RSM_STAGE(cid + 1)          // fetched a whole chunk period ago; its buffer is free since A(cid - 1)
       AAMD_RSM_STAMP((int)(cid + 1 - first), 3)
@@ -738,7 +767,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       if (cid + 1 < end) convert((int)(cid + 1 - first));
 #endif
       AAMD_RSM_STAMP((int)(cid + 1 - first), 4)
-      __syncthreads();                                   // A(cid)
+      if (!AAMD_RSM_FLAGS) __syncthreads();              // A(cid)
       AAMD_RSM_STAMP((int)(cid + 1 - first), 5)
     }
 #undef AAMD_RSM_FETCH
@@ -791,7 +820,7 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #if defined(AAMD_RSM_SHARED_CONV)
   if (first < end) convert(0);
 #endif
-  __syncthreads();                                       // A0
+  if (!AAMD_RSM_FLAGS) __syncthreads();                  // A0
   // The scalars of a chunk -- its row, first output group, 16-byte phase, output row, and the scale that undoes the chunk's
   // power-of-two (from the loaders' maximum) -- are ~75 dependent scalar instructions and an LDS round trip.  Round 6: they are
   // worked out for chunk k + 1 IN FRONT of barrier A(k), where eleven of the twelve waves wait anyway; behind the barrier every wave
@@ -802,11 +831,11 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   auto chunk_header = [&](int64_t cid_) {
     ChunkHeader h;
     const int k_ = (int)(cid_ - first);
-    const unsigned want_ = (unsigned)nld * (unsigned)(k_ / 3 + 1);
-    while (__atomic_load_n(&cnt[k_ % 3], __ATOMIC_RELAXED) < want_) __builtin_amdgcn_s_sleep(1);
+    const unsigned want_ = (unsigned)nld * (unsigned)(k_ / kSlots + 1);
+    while (__atomic_load_n(&cnt[k_ % kSlots], __ATOMIC_RELAXED) < want_) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     float scale_;
-    chunk_scale(__atomic_load_n(&mx[k_ % 3], __ATOMIC_RELAXED), scale_, h.inv);
+    chunk_scale(__atomic_load_n(&mx[k_ % kSlots], __ATOMIC_RELAXED), scale_, h.inv);
     const int64_t row_ = (int64_t)((uint32_t)cid_ / (uint32_t)g.chunks_per_row);   // n_chunks < 2^31 (checked by the launcher)
     h.qc0 = (cid_ - row_ * g.chunks_per_row) * qc;
     h.shift = (int)((h.qc0 * g.orig - g.width) - chunk_a0(g, h.qc0));
@@ -830,6 +859,11 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #else
     if (k == 0) hdr = chunk_header(cid);
 #endif
+    if (AAMD_RSM_FLAGS) {   // the chunk is in its buffer: every loader wave has written its pieces
+      const unsigned wf = (unsigned)nld * (unsigned)(k / 2 + 1);
+      while (__atomic_load_n(&fullc[k & 1], __ATOMIC_RELAXED) < wf) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     const float inv = hdr.inv;
     const int64_t qc0 = hdr.qc0;
     const int shift = hdr.shift;
@@ -1070,6 +1104,10 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
       store_c(g, out_row, qc0, qt1, pt, lane, acc1[0] * inv, acc1[1] * inv, acc1[2] * inv, acc1[3] * inv);
     }
     }
+    if (AAMD_RSM_FLAGS) {   // this wave's operand reads of the chunk have all returned (the matrix instructions used them)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) atomicAdd(&donec[k & 1], 1u);
+    }
     AAMD_RSM_STAMP(k, 1)                                 // (the MFMA loops and the stores of all rounds)
     AAMD_RSM_STAMP(k, 2)
 #if defined(AAMD_RSM_SHARED_CONV)
@@ -1085,9 +1123,9 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
 #if !defined(AAMD_RSM_HEADER_BEHIND_BARRIER)
     if (cid + 1 < end) hdr = chunk_header(cid + 1);
 #endif
-    __syncthreads();                                     // A(cid): chunk cid is consumed, chunk cid + 1 is in LDS
+    if (!AAMD_RSM_FLAGS) __syncthreads();                // A(cid): chunk cid is consumed, chunk cid + 1 is in LDS
     AAMD_RSM_STAMP(k, 5)
-    if (threadIdx.x == 0) { mx[k % 3] = 0u; grab[k % 3] = 0u; }                // read by everybody before A(cid); next written behind A(cid + 1)
+    if (!AAMD_RSM_FLAGS && threadIdx.x == 0) { mx[k % kSlots] = 0u; grab[k % 3] = 0u; }   // read by everybody before A(cid); next written behind A(cid + 1)
   }
 }
 // the prepared tap fragments of the phase tiles [g.pt0, g.pt0 + g.n_pt) of one filter: one thread per (tile, step, lane)
