@@ -510,16 +510,17 @@ resample_f16_kernel(Geom g, const float* __restrict__ wav, const float* __restri
   if (threadIdx.x < 12) mx[threadIdx.x] = 0u;         // maxima + arrival counters + (3 batch counters | 2 + 2 hand-over counters): 48 bytes
   __syncthreads();
 
-  // Timeline (one barrier per chunk):
-  //   loaders   fetch(f) stage(f) fetch(f+1) convert(f)   A0 | stage(f+1) fetch(f+2) convert(f+1)       A(f) | stage(f+2) ...
-  //   the rest  tap fragments, convert(f)                 A0 | compute(f) (all rounds), stores, convert(f+1) A(f) | compute(f+1) ...
+  // Timeline (one barrier per chunk; round 6):
+  //   loaders   fetch(f) stage(f) fetch(f+1)   A0 | stage(f+1) fetch(f+2)                  A(f) | stage(f+2) ...
+  //   the rest  tap fragments                  A0 | compute(f) (all rounds), stores, header(f+1) A(f) | compute(f+1) ...
   // fetch = the chunk's global loads into registers: issued a whole chunk period before the LDS buffer they go to is free
   // (two chunks in LDS + one in the loaders' registers = the HBM latency of a 60 KB burst per CU is off the critical path);
-  // stage = wait for the data, publish the wave's largest |sample| (DPP reduction + one LDS atomic max), write the RAW
-  // floats to the free buffer, count the wave as arrived (LDS counter, after its writes).  convert = every wave that is free
-  // (compute waves behind their MFMA loops, loaders behind their fetches), once all loaders have arrived, takes batches of
-  // the raw image from an LDS counter and turns them into packed (lo << 16 | hi) dwords in place.  Round-2 census (profiles/r02_v): with the conversion in the two loader waves they were the critical
-  // path of every chunk (6.8 of 7.5 us) while the ten compute waves idled 2.3 - 3.9 us at the barrier.
+  // stage = wait for the data, publish the wave's largest |sample| (max3 chain + DPP reduction + one LDS atomic max), count the
+  // wave in, wait for the other loader wave(s), then split the pieces IN THE REGISTERS with the chunk's scale and write the
+  // packed (lo << 16 | hi) dwords to the free buffer.  (Rounds 2-5, kept as -DAAMD_RSM_SHARED_CONV for A/Bs: the loaders staged
+  // the raw floats and every wave that found itself free converted batches of them in place -- `convert` below; with the
+  // 6-operation split and the staged path of round 2 the two loader waves were the critical path, profiles/r02_v.  With the
+  // 4-operation split, buffer loads and immediate offsets a loader wave's chunk is ~650 instructions, profiles/r06_zi.)
   unsigned* cnt = mx + kSlots;                         // [kSlots]: loader waves whose maximum is in LDS, monotonic
   unsigned* fullc = mx + 8;                            // [2] (AAMD_RSM_FLAGS): loader waves that have filled buffer b, monotonic
   unsigned* donec = mx + 10;                           // [2] (AAMD_RSM_FLAGS): compute waves that have consumed buffer b, monotonic

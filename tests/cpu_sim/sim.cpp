@@ -797,7 +797,7 @@ int sim_resample_sparse(const float* wav, const float* hb, const int32_t* lo, fl
 // f16 = 1: replay of rsm::resample_f16_kernel (chunk maximum -> power-of-two scale, samples and taps split into two
 // binary16 numbers, hi*hi + hi*lo + lo*hi with the 16x16x32 fragment maps); f16 = 0: rsm::resample_mfma_kernel
 // f16 = 2: the same kernel with the 8-byte operand reads (template argument RD = 1: tiles dealt by the parity of q, odd lane
-// groups rotated through the contraction steps -- b64_rot / b64_step / b_base64 / store_c_at), including the alignment and
+// groups walking the contraction steps in the order b64_sigma -- b64_step / b_base64 / store_c_at), including the alignment and
 // buffer-bound claims the pair reads rest on (-4 / -5 when one does not hold); -6 when the geometry is not served by it
 int sim_resample_mfma(const float* wav, const float* kern, float* out, int64_t rows, int64_t length,
                       int64_t row_stride, int orig, int new_, int width, int64_t out_len,

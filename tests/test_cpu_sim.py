@@ -153,7 +153,7 @@ def test_sim_resample_click_and_minus_100_db_tone_in_one_chunk():
     k, width = _host.sinc_resample_kernel(44100, 16000, math.gcd(44100, 16000), **kw)
     rc32, ref32 = S.sim_resample_mfma(x, k.numpy(), 441, 160, width, 1, 0)
     exp = O.resample(x.astype(np.float64), 44100, 16000, **kw)
-    for layout in (2, 1):       # 2: the 8-byte operand-read layout cfg3 runs (tiles by parity of q, rotated steps); 1: the 4-byte one
+    for layout in (2, 1):       # 2: the 8-byte operand-read layout cfg3 runs (tiles by parity of q, permuted steps in the odd lane groups); 1: the 4-byte one
         rc16, got = S.sim_resample_mfma(x, k.numpy(), 441, 160, width, 1, layout)
         assert rc16 == 0 and rc32 == 0
         assert not np.isnan(got).any()

@@ -882,8 +882,8 @@ def test_resample_binary16_split_kernel_against_fp32_kernel_and_oracle(gain):
 
 def test_resample_8_byte_operand_layout_against_the_4_byte_one():
     """Round 5: for odd reduced `orig` and bands of 257 .. 448 taps (cfg3: 441 : 160, kaiser_best) the binary16-split resampler
-    deals the output groups to its two MFMA tiles by parity and walks the contraction steps rotated in the odd lane groups, so
-    that its LDS operand reads are conflict-free ds_read_b64 (csrc/resample_mfma.h, b64_rot).  Same products, another summation
+    deals the output groups to its two MFMA tiles by parity and walks the contraction steps in a permuted order in the odd lane groups, so
+    that its LDS operand reads are 8-byte aligned ds_read_b64 with one two-way conflicted step of 13 (csrc/resample_mfma.h, b64_sigma).  Same products, another summation
     order: against the 4-byte layout (AAMD_POLICY_RESAMPLE_B32) <= 2e-6 of the peak, both <= 1e-5 of the float64 oracle; ragged
     lengths, unaligned views (the 16-byte phase of a chunk changes which tile is the aligned one), a row that falls silent; and
     a rate pair outside the layout (even orig) is bit-identical under the switch."""

@@ -50,14 +50,14 @@ def build(specs):
             print(txt[-3000:])
 
 
-def run(names, launches, rounds, rows=(128, 2), n=1323000):
+def run(names, launches, rounds, rows=(128, 2), n=1323000, nbuf=3):
     import numpy as np
     import torch
     import audio_amd.transforms as T
     from audio_amd import _host, _lib
     dev = torch.device("cuda")
     g = torch.Generator(device="cuda").manual_seed(0)
-    xs = [(0.5 * torch.randn(*rows, n, device=dev, generator=g)).clamp_(-1, 1) for _ in range(3)]
+    xs = [(0.5 * torch.randn(*rows, n, device=dev, generator=g)).clamp_(-1, 1) for _ in range(nbuf)]
     rs = T.Resample(44100, 16000, resampling_method="sinc_interp_kaiser", lowpass_filter_width=64,
                     rolloff=0.9475937167399596, beta=14.769656459379492).to(dev)
     kern = rs.kernel.reshape(160, -1).contiguous()
@@ -66,7 +66,7 @@ def run(names, launches, rounds, rows=(128, 2), n=1323000):
     lo = np.ascontiguousarray(lo, dtype=np.int32)
     n_rows = rows[0] * rows[1]
     out_len = -(-160 * n // 441)
-    outs = [torch.empty(n_rows, out_len, device=dev) for _ in range(3)]
+    outs = [torch.empty(n_rows, out_len, device=dev) for _ in range(nbuf)]
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     stream = _lib.current_stream(dev)
     libs = {}
@@ -76,7 +76,7 @@ def run(names, launches, rounds, rows=(128, 2), n=1323000):
         libs[nm] = L
 
     def launch(nm, i):
-        x, o = xs[i % 3], outs[i % 3]
+        x, o = xs[i % nbuf], outs[i % nbuf]
         rc = libs[nm].lab_rsm(x.data_ptr(), kern.data_ptr(), o.data_ptr(), n_rows, n, n, 441, 160, width, out_len,
                               lo.ctypes.data_as(C.c_void_p), span, 0, cus, stream)
         assert rc == 0, (nm, rc)
@@ -137,6 +137,7 @@ if __name__ == "__main__":
     else:
         args = sys.argv[2:]
         launches, rounds = 20, 4
+        rows, nbuf = (128, 2), 3            # --rows R: R x stereo rows; --nbuf 1: one input / output buffer (cache-resident when it fits the 256 MiB L3)
         names = []
         i = 0
         while i < len(args):
@@ -144,6 +145,10 @@ if __name__ == "__main__":
                 launches = int(args[i + 1]); i += 2
             elif args[i] == "--rounds":
                 rounds = int(args[i + 1]); i += 2
+            elif args[i] == "--rows":
+                rows = (int(args[i + 1]), 2); i += 2
+            elif args[i] == "--nbuf":
+                nbuf = int(args[i + 1]); i += 2
             else:
                 names.append(args[i]); i += 1
-        run(names, launches, rounds)
+        run(names, launches, rounds, rows=rows, nbuf=nbuf)
