@@ -47,7 +47,15 @@ constexpr int kMaxWaves = 16;
 //                           Mc^(64 w), w = 0..15 [16][4]
 constexpr int kPow2 = 10;
 constexpr int kTabAB = 0, kTabM = 8, kTabPow = kTabM + 4 * kPow2, kTabPowW = kTabPow + 4 * 64;
-constexpr int kTabFloats = kTabPowW + 4 * kMaxWaves;           // 368
+// AAMD_LFW_HTAB: the homogeneous responses to the states (1, 0) and (0, 1), h0[j], h1[j], j = 0 .. 31, behind the matrices
+// ({h0[j], h1[j]} interleaved: one broadcast b128 read serves two samples) -- the correction y[j] = z[j] + h0[j] t0 + h1[j] t1
+// is then two independent FMAs per sample instead of a 2-term recurrence (mul + fma, a dependent chain) and an add
+#ifndef AAMD_LFW_HTAB
+#define AAMD_LFW_HTAB 0
+#endif
+constexpr bool kHTab = AAMD_LFW_HTAB != 0;
+constexpr int kTabH = kTabPowW + 4 * kMaxWaves;                                   // 368
+constexpr int kTabFloats = kTabH + (kHTab ? 2 * kCh : 0);                         // 368 / 432
 // exchange area (floats): S[2 buffers][W][2] | carry[2 parity][stages][2]
 AAMD_HD int xch_S(int W, int buf, int w) { return (buf * W + w) * 2; }
 AAMD_HD int xch_carry(int W, int n_stages, int parity, int st) { return 4 * W + (parity * n_stages + st) * 2; }
@@ -100,6 +108,7 @@ AAMD_HD void build_stage(const float* a_row, const float* b_row, int n_order, fl
       const double y = -(double)ah[1] * h0 - (double)ah[2] * h1;
       h1 = h0;
       h0 = y;
+      if (kHTab) tab[kTabH + 2 * j + d] = tab_sat(y);
     }
     M[0][d] = h0;   // y[31]
     M[1][d] = h1;   // y[30]
@@ -130,8 +139,44 @@ struct StageCoef { float a1, a2, b0, b1, b2; };
 AAMD_HD StageCoef stage_coef(const float* tab) {
   return StageCoef{tab[kTabAB + 1], tab[kTabAB + 2], tab[kTabAB + 3], tab[kTabAB + 4], tab[kTabAB + 5]};
 }
+// AAMD_LFW_SPLIT (round 6): the two passes of a stage issue the SAME operations in an order that leaves one instruction of every
+// sample on the dependent chain instead of five / four (0 = the sample-by-sample order of rounds 2 - 5, tools/lfw_ab.py)
+#ifndef AAMD_LFW_SPLIT
+#define AAMD_LFW_SPLIT 1
+#endif
 AAMD_HD void chunk_pass(const StageCoef& cf, float (&x)[kCh], float hu0, float hu1, float& s0, float& s1) {
   float hz0 = 0.0f, hz1 = 0.0f;
+  if (AAMD_LFW_SPLIT) {
+    // the same operations in another order: the feed-forward sums of all 32 samples first (in place, last sample first -- 96
+    // independent instructions), then the recursion (one instruction of every sample on the chain, one beside it)
+    auto in = [&](int j) { return j >= 0 ? x[j] : (j == -1 ? hu0 : hu1); };
+#pragma unroll
+    for (int j = kCh - 4; j >= 0; j -= 4) {          // samples j .. j + 3, four independent sums side by side
+      float w0 = cf.b2 * in(j - 2), w1 = cf.b2 * in(j - 1), w2 = cf.b2 * in(j), w3 = cf.b2 * in(j + 1);
+      w0 += cf.b1 * in(j - 1); w1 += cf.b1 * in(j); w2 += cf.b1 * in(j + 1); w3 += cf.b1 * in(j + 2);
+      w0 += cf.b0 * in(j); w1 += cf.b0 * in(j + 1); w2 += cf.b0 * in(j + 2); w3 += cf.b0 * in(j + 3);
+      x[j] = w0; x[j + 1] = w1; x[j + 2] = w2; x[j + 3] = w3;
+#if defined(__HIPCC__)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    // the recursion: t = w[j + 1] - a2 y[j - 1] is worked out beside the chain instruction y[j] = t' - a1 y[j - 1]
+    float t = x[0];
+#pragma unroll
+    for (int j = 0; j < kCh; ++j) {
+      float y = t;
+      if (j >= 1) y -= cf.a1 * hz0;
+      if (j + 1 < kCh) {
+        t = x[j + 1];
+        if (j >= 1) t -= cf.a2 * hz0;      // hz0 = y[j - 1] here
+      }
+      hz1 = hz0; hz0 = y;
+      x[j] = y;
+    }
+    s0 = hz0;
+    s1 = hz1;
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < kCh; ++j) {
     const float u = x[j];
@@ -200,6 +245,36 @@ AAMD_HD void fold_finish(const float* tab, int w, float i0, float i1, float c0, 
 template <bool CLAMP>
 AAMD_HD void correct_clamp_t(const StageCoef& cf, float t0, float t1, float (&z)[kCh]) {
   float c0 = t0, c1 = t1;
+  if (AAMD_LFW_SPLIT) {
+    // the same operations, software-pipelined: beside the chain instruction of sample j (c[j] = m - a1 c[j - 1]) stand the
+    // product of sample j + 1 (- a2 c[j - 1]), the sum of sample j - 1 and the clamp of sample j - 2
+    float m = -(cf.a2 * c1);
+#if defined(__HIPCC__)
+    asm volatile("" : "+v"(m));
+#endif
+    float cp = 0.0f, yp = 0.0f;        // c[j - 1], y[j - 1] (not clamped yet)
+#pragma unroll
+    for (int j = 0; j <= kCh + 1; ++j) {
+      float c = 0.0f;
+      if (j < kCh) c = m - cf.a1 * c0;
+      if (j + 1 < kCh) {
+        m = -(cf.a2 * c0);
+#if defined(__HIPCC__)
+        asm volatile("" : "+v"(m));     // a product of its own: contracted into the chain instruction it would put two on the chain
+#endif
+      }
+      float y = 0.0f;
+      if (j >= 1 && j <= kCh) y = z[j - 1] + cp;
+      if (j >= 2) z[j - 2] = CLAMP ? fmin(fmax(yp, -1.0f), 1.0f) : yp;
+      yp = y;
+      cp = c;
+      c0 = c;
+#if defined(__HIPCC__)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < kCh; ++j) {
     float c = -(cf.a2 * c1);
@@ -209,6 +284,21 @@ AAMD_HD void correct_clamp_t(const StageCoef& cf, float t0, float t1, float (&z)
     float y = z[j] + c;
     if (CLAMP) y = fmin(fmax(y, -1.0f), 1.0f);
     z[j] = y;
+  }
+}
+// the same from the table of responses (kHTab): no chain
+template <bool CLAMP>
+AAMD_HD void correct_clamp_h(const float* tab, float t0, float t1, float (&z)[kCh]) {
+#pragma unroll
+  for (int j = 0; j < kCh; j += 2) {
+    const F4 h = *reinterpret_cast<const F4*>(tab + kTabH + 2 * j);
+    float y0 = z[j] + h.x * t0;
+    float y1 = z[j + 1] + h.z * t0;
+    y0 += h.y * t1;
+    y1 += h.w * t1;
+    if (CLAMP) { y0 = fmin(fmax(y0, -1.0f), 1.0f); y1 = fmin(fmax(y1, -1.0f), 1.0f); }
+    z[j] = y0;
+    z[j + 1] = y1;
   }
 }
 AAMD_HD void correct_clamp(const StageCoef& cf, float t0, float t1, int clamp, float (&z)[kCh]) {
@@ -338,7 +428,8 @@ __device__ __forceinline__ void stage_step(const float* tab, float* xch, int W, 
     float t0 = wave_shr1(s0), t1 = wave_shr1(s1);
     if (lane == 0) { t0 = e0; t1 = e1; }
     __builtin_amdgcn_sched_barrier(0);
-    if (PRE) correct_clamp(cf, t0, t1, clamp, v);
+    if (kHTab) { if (clamp) correct_clamp_h<true>(tab, t0, t1, v); else correct_clamp_h<false>(tab, t0, t1, v); }
+    else if (PRE) correct_clamp(cf, t0, t1, clamp, v);
     else correct_clamp(tab, t0, t1, clamp, v);             // (a1, a2 re-read: the 128-register instantiations have no room to keep them)
   }
   if (lane == 63 && wave == W - 1)   // true (unclamped) state leaving the block -> next block's carry
@@ -692,20 +783,30 @@ lfilter_wave_pipe_kernel(const float* __restrict__ x, const float* __restrict__ 
 // vector-memory instruction inside the block loop at all: four extra waves of the workgroup own the traffic.  They take part
 // in the stages' barriers, which is also what orders their LDS accesses with the filter waves':
 //   slot (i, st) = what a mover does between barrier (i, st - 1) and barrier (i, st) of block i;
-//   slot (i, 0): nothing -- the filter waves wrote block i - 1 into the OUT tiles and took block i out of the IN tiles after
-//                barrier (i - 1, n - 1), only barrier (i, 0) orders that with the movers;
-//   slots (i, 1 .. n - 1): the stores of block i - 1 from the OUT tiles, an even share per slot;
-//   slots (i, 1 .. n - 2): the copies of block i + 1 into the IN tiles; slot (i, n - 1) starts with vmcnt(0), so the copies have
+//   round 6 (kSlot0): one more barrier per block, X(i), right behind the filter waves' exchange (block i - 1 -> OUT tiles, block
+//                i + 1 <- IN tiles, after barrier (i - 1, n - 1)) orders the exchange with the movers, so that slot (i, 0) -- the
+//                longest one: it holds a whole stage -- carries traffic too (cfg5a shard 238.7 -> 231.4 us, bit-identical);
+//   slots (i, 0 .. n - 1): the stores of block i - 1 from the OUT tiles, an even share per slot;
+//   slots (i, 0 .. n - 2): the copies of block i + 1 into the IN tiles; slot (i, n - 1) starts with vmcnt(0), so the copies have
 //                landed when the filter waves pass barrier (i, n - 1) and read them.
+//   (rounds 2 - 5, AAMD_LFW_SLOT0 = 0: no X(i), slot (i, 0) empty -- only barrier (i, 0) ordered the exchange with the movers --
+//   stores in slots 1 .. n - 1, copies in slots 1 .. n - 2.)
 constexpr int kMovers = 4;
 #ifndef AAMD_LFW_PREFETCH
 #define AAMD_LFW_PREFETCH 1
 #endif
 constexpr bool kMoverPrefetch = AAMD_LFW_PREFETCH != 0;
+#ifndef AAMD_LFW_SLOT0
+#define AAMD_LFW_SLOT0 1
+#endif
+constexpr bool kSlot0 = AAMD_LFW_SLOT0 != 0;
 
 #if defined(__HIPCC__)
 template <int LAB = 0>
-__global__ void __launch_bounds__(64 * (8 + kMovers))
+#ifndef AAMD_LFW_W12TEST
+#define AAMD_LFW_W12TEST 0     // lab, arithmetic-only runs: 12 filter waves whose tiles alias those of waves 0 .. 7 (wrong results)
+#endif
+__global__ void __launch_bounds__(64 * ((AAMD_LFW_W12TEST ? 12 : 8) + kMovers))
 lfilter_wave_mover_kernel(const float* __restrict__ x, const float* __restrict__ a, const float* __restrict__ b,
                           float* __restrict__ y, int64_t n_seq, int channels, int64_t length, int n_order,
                           int n_coeff_rows, int n_stages, int clamp) {
@@ -725,7 +826,7 @@ lfilter_wave_mover_kernel(const float* __restrict__ x, const float* __restrict__
     const int k_ = mode == 0 ? (b_ & 7) : mode == 1 ? ((b_ >> 3) & 7) : ((b_ * 5 + (b_ >> 3)) & 7);
     for (int i = 0; i < k_; ++i) __builtin_amdgcn_s_sleep(AAMD_LFW_STAGGER & 127);
   }
-  float* tabs = smem_lfw + W * kPipeTile;
+  float* tabs = smem_lfw + (AAMD_LFW_W12TEST ? 8 : W) * kPipeTile;
   float* xch = tabs + n_stages * kTabFloats;
   const int64_t block_len = (int64_t)W * kWaveBlock;
   auto piece = [](int l, int odd) { return 32 * (l >> 3) + 4 * ((l & 7) ^ (4 * odd + (l >> 4))); };
@@ -792,20 +893,25 @@ lfilter_wave_mover_kernel(const float* __restrict__ x, const float* __restrict__
       // (measured and dropped: two movers that only copy + two that only store, the stores issued BEHIND the slot's barrier
       // from registers -- 300 us against 290 us for this form)
       const int m = wave - W;
-      const int sslots = n_stages - 1, cslots = n_stages - 2;          // slots with stores / with copies
+      // kSlot0: one more barrier per block, right behind the filter waves' exchange (block i - 1 -> OUT tiles, block i + 1 <- IN
+      // tiles), orders it with the movers, so slot (i, 0) -- the longest one -- carries traffic too: stores in n slots, copies in n - 1
+      const int s0 = kSlot0 ? 0 : 1;
+      // (measured beside it, profiles/r06_zw_*: copies in one slot fewer +- 0, movers at a raised issue priority + 1.5 %)
+      const int sslots = n_stages - s0, cslots = n_stages - 1 - s0;    // slots with stores / with copies
       for (int64_t n0 = 0; n0 < length; n0 += block_len) {
         const bool has_next = n0 + block_len < length;
+        if (kSlot0 && !(LAB & 2)) lds_barrier();
         for (int st = 0; st < n_stages; ++st) {
-          if (st >= 1) {
+          if (st >= s0) {
             if (st == n_stages - 1 && !(LAB & 1)) vm_wait();          // the copies of block i + 1 have landed
             for (int t = m; t < W; t += kMovers) {
               const int64_t nw = n0 + (int64_t)t * kWaveBlock;
-              if (n0 > 0) store_pieces(t, nw - block_len, 8 * (st - 1) / sslots, 8 * st / sslots);
+              if (n0 > 0) store_pieces(t, nw - block_len, 8 * (st - s0) / sslots, 8 * (st - s0 + 1) / sslots);
               if (has_next) {
                 const int64_t nxt = nw + block_len;
                 if (nxt + kWaveBlock <= length) {
-                  if (st <= cslots) copy_pieces(t, nxt, 9 * (st - 1) / cslots, 9 * st / cslots);
-                } else if (st == 1) {
+                  if (st - s0 < cslots) copy_pieces(t, nxt, 9 * (st - s0) / cslots, 9 * (st - s0 + 1) / cslots);
+                } else if (st == s0) {
                   fill_ragged(t, nxt);
                 }
               }
@@ -818,7 +924,7 @@ lfilter_wave_mover_kernel(const float* __restrict__ x, const float* __restrict__
     }
 
     // ------------------------------------------------------------------ a filter wave
-    float* tile = smem_lfw + wave * kPipeTile;
+    float* tile = smem_lfw + (AAMD_LFW_W12TEST ? (wave & 7) : wave) * kPipeTile;
     float* otile = tile + kTile;
     float* own_in = tile + kHist + kCh * lane;
     float* own_out = otile + kCh * lane;
@@ -850,6 +956,7 @@ lfilter_wave_mover_kernel(const float* __restrict__ x, const float* __restrict__
     for (int64_t n0 = 0; n0 < length; n0 += block_len, parity ^= 1) {
       const int64_t nw = n0 + (int64_t)wave * kWaveBlock;
       nw_last = nw;
+      if (kSlot0 && !(LAB & 2)) lds_barrier();
       for (int st = 0; st < n_stages; ++st, sbuf ^= 1)
         stage_step<LAB, kMoverPrefetch>(tabs + st * kTabFloats, xch, W, n_stages, parity, st, sbuf, wave, lane, stage_clamp(clamp, st, n_stages), v, hin0, hin1);
       // behind barrier (i, n - 1): the movers have read block i - 1 out of the OUT tile and block i + 1 has landed in the IN tile

@@ -374,6 +374,11 @@ def main():
                     help="mel = BASELINE configs[1] (the headline metric, default); mfcc = configs[3], the one op with a collective")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="also time scatter_batch / gather_batch of a root-born batch (outside the K steps)")
+    ap.add_argument("--launch", choices=["graph", "eager"], default="eager",
+                    help="how the K timed steps are launched: 'eager' (default) = one Python call per step; 'graph' = the K steps "
+                         "captured ONCE, before the timed region, in a HIP graph (K kernel nodes over the rotating batches) and "
+                         "replayed inside it.  Measured in round 6 (profiles/r06_zv_launch_modes.txt): the graph's kernel nodes "
+                         "run 83-90 us apart where eager launches run 70-71 us apart -- not the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the other BASELINE configs (cfg3 / cfg4 / cfg5a / cfg5b shards, measured after the timed K steps "
@@ -486,14 +491,31 @@ def main():
         for i in range(args.warmup):
             step(i)
         torch.cuda.synchronize()
+        # --launch graph: the K timed steps as ONE HIP graph (captured here, outside the timed region, and replayed once untimed so
+        # that it is instantiated and uploaded): K kernel nodes over the same rotating batches, nothing skipped or cached.  With one
+        # Python call per step the host needs 30-50 us before the FIRST kernel of the timed region is enqueued (3 % of a 20-step
+        # region on the host clock) -- but the graph's nodes are dispatched 83-90 us apart against 70-71 us for eager launches of
+        # this 66 us kernel (profiles/r06_zv_launch_modes.txt), so eager stays the default.
+        use_graph = args.launch == "graph" and 0 < args.steps <= 256 and args.op == "mel"
+        graph = None
+        if use_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for i in range(args.steps):
+                    step(i)
+            graph.replay()
+            torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         e0.record()                      # the kernels are launched on torch's current stream
-        for i in range(args.steps):
-            step(i)
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(args.steps):
+                step(i)
         e1.record()
         torch.cuda.synchronize()
         my_wall = time.perf_counter() - t0                   # this rank's own K steps
@@ -501,6 +523,16 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / args.steps
+    eager_ms = None
+    if graph is not None:
+        # the same K steps with one Python call per step (rounds 1-5's timed region), host clock, outside the timed region
+        with torch.no_grad():
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            torch.cuda.synchronize()
+            eager_ms = (time.perf_counter() - te) / args.steps * 1e3
     y = ys[(args.steps - 1) % ring] if args.steps else run(xs[0])
     steady = None
     if args.steps < 500:
@@ -637,6 +669,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "clock_ramp_launches": args.clock_ramp,
+            "launch": ({"mode": "hip_graph", "note": "the K timed steps are K kernel nodes of one HIP graph, captured and replayed once "
+                        "before the timed region; same rotating batches, nothing skipped", "eager_ms_per_step_same_K": eager_ms}
+                       if graph is not None else {"mode": "eager", "note": "one Python call per step"}),
             "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",

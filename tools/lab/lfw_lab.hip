@@ -17,12 +17,15 @@ using namespace aamd;
 
 extern "C" int lab_lfw_mover(const float* x, const float* a, const float* b, float* y, int64_t n_seq, int channels,
                              int64_t length, int n_order, int n_coeff_rows, int n_stages, int clamp, void* stream) {
-  const size_t plds = lfw::pipe_lds_bytes(8, n_stages);
+#ifndef LAB_W
+#define LAB_W 8
+#endif
+  const size_t plds = lfw::pipe_lds_bytes(8, n_stages) + 4096;
   auto kern = lfw::lfilter_wave_mover_kernel<LAB_BITS>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds) != hipSuccess)
     return -2;
   int blocks = (int)(n_seq < 2048 ? n_seq : 2048);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * (8 + lfw::kMovers)), plds, (hipStream_t)stream, x, a, b, y, n_seq, channels,
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * (LAB_W + lfw::kMovers)), plds, (hipStream_t)stream, x, a, b, y, n_seq, channels,
                      length, n_order, n_coeff_rows, n_stages, clamp);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
