@@ -160,6 +160,10 @@ def measure_issue(kernel_ms, timeout_s=150):
     res = {"valu_issue_frac": vals["SQ_INSTS_VALU"] * 2.0 / (cus * 4 * cycles),
            "valu_issue_frac_at_measured_2.78_cycles_per_instr": vals["SQ_INSTS_VALU"] * 2.78 / (cus * 4 * cycles),
            "shader_clock_GHz_assumed": clock / 1e9,
+           # round 6, by the WALL clock (tools/lab/valu_wall.hip, profiles/r06_zy_valu_issue_wall_clock.txt): whatever the occupancy
+           # and the parallelism inside a wave, a SIMD of this chip sustains one wave64 fp32 instruction per 1.05-1.25 ns (the
+           # cycle counter slows down as the vector ALUs fill up) -- the share of that rate this launch uses, priced at 1.15 ns
+           "valu_issue_frac_of_sustained_wall_clock_rate": vals["SQ_INSTS_VALU"] / (cus * 4) * 1.15e-9 / (kernel_ms * 1e-3),
            "SQ_INSTS_VALU": vals["SQ_INSTS_VALU"], "SQ_INSTS_LDS": vals.get("SQ_INSTS_LDS"),
            "limited_by": "VALU issue + LDS pipe + in-order issue behind vector-memory instructions, at the 1.9-2.0 GHz the "
                          "chip sustains under this kernel's HBM traffic (profiles/r03_b_mel400_lab_io_clock_ab.txt); `bound` "
