@@ -651,11 +651,13 @@ def test_lfilter_wave_kernel_shape_edges():
     assert peak_rel_err(got.cpu().numpy(), exp) <= 1e-4
 
 
-@pytest.mark.parametrize("n_stages,length", [(1, 70004), (2, 40964), (3, 16384 + 8), (4, 65536), (8, 20000)])
+@pytest.mark.parametrize("n_stages,length", [(1, 70004), (2, 40964), (3, 16384 + 8), (4, 65536), (8, 20000),
+                                              (5, 2 * 16384 + 6148), (6, 49156), (7, 3 * 16384 - 4), (3, 5 * 16384)])
 def test_lfilter_pipelined_kernel_against_oracle(n_stages, length):
     """Long, 16-byte aligned rows take the two-tile kernel (copies and stores issued a few pieces per stage): whole blocks,
     a ragged last block (waves partly / wholly past the end), a length that is an exact multiple of the block, every
-    piece-per-stage split (1, 2, 3, 4, 8 stages) -- against the sequential float64 cascade, clamped per stage."""
+    piece-per-stage split (1 .. 8 stages; from 3 stages on the mover kernel, whose stores run in n and copies in n - 1 slots per
+    block since round 6) -- against the sequential float64 cascade, clamped per stage."""
     import audio_amd.functional as F
     from oracle import dsp_oracle as O
     g = torch.Generator().manual_seed(100 + n_stages)
