@@ -156,7 +156,7 @@ AAMD_HD void chunk_pass(const StageCoef& cf, float (&x)[kCh], float hu0, float h
       w0 += cf.b1 * in(j - 1); w1 += cf.b1 * in(j); w2 += cf.b1 * in(j + 1); w3 += cf.b1 * in(j + 2);
       w0 += cf.b0 * in(j); w1 += cf.b0 * in(j + 1); w2 += cf.b0 * in(j + 2); w3 += cf.b0 * in(j + 3);
       x[j] = w0; x[j + 1] = w1; x[j + 2] = w2; x[j + 3] = w3;
-#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)
       __builtin_amdgcn_sched_barrier(0);
 #endif
     }
@@ -249,7 +249,7 @@ AAMD_HD void correct_clamp_t(const StageCoef& cf, float t0, float t1, float (&z)
     // the same operations, software-pipelined: beside the chain instruction of sample j (c[j] = m - a1 c[j - 1]) stand the
     // product of sample j + 1 (- a2 c[j - 1]), the sum of sample j - 1 and the clamp of sample j - 2
     float m = -(cf.a2 * c1);
-#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(m));
 #endif
     float cp = 0.0f, yp = 0.0f;        // c[j - 1], y[j - 1] (not clamped yet)
@@ -259,7 +259,7 @@ AAMD_HD void correct_clamp_t(const StageCoef& cf, float t0, float t1, float (&z)
       if (j < kCh) c = m - cf.a1 * c0;
       if (j + 1 < kCh) {
         m = -(cf.a2 * c0);
-#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)
         asm volatile("" : "+v"(m));     // a product of its own: contracted into the chain instruction it would put two on the chain
 #endif
       }
@@ -269,7 +269,7 @@ AAMD_HD void correct_clamp_t(const StageCoef& cf, float t0, float t1, float (&z)
       yp = y;
       cp = c;
       c0 = c;
-#if defined(__HIPCC__)
+#if defined(__HIP_DEVICE_COMPILE__)
       __builtin_amdgcn_sched_barrier(0);
 #endif
     }
