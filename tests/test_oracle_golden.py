@@ -196,3 +196,38 @@ def test_cpu_baseline_records_carry_value_cores_kind_and_sample():
     assert rec["value"] > 0 and rec["cores"] >= 1 and rec["kind"] == "port" and "rows" in rec["sample"]
     rec = cb.time_cfg5a(budget_s=0.2, batch=2, channels=2, seconds=0.5)
     assert rec["value"] > 0 and "core_loop" in rec
+
+
+# ---- the Kaldi-compatible front-end: oracle/kaldi_oracle.py against the reference's own runs ----------------
+def _kaldi_fixture_cases():
+    import json
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kaldi_goldens.npz"))
+    return g, json.loads(bytes(g["meta"]).decode())
+
+
+@pytest.mark.parametrize("name", sorted(_kaldi_fixture_cases()[1]))
+def test_kaldi_oracle_vs_reference_fixtures(name):
+    """The float64 restatement of compliance/kaldi.py against the 21 reference runs of tests/golden/make_kaldi_golden.py (every
+    window type, snip_edges, raw / windowed energy, VTLN, HTK order, non-power-of-two windows, the three dither cases on the
+    recorded draw): the difference is the float32 rounding of the reference."""
+    from oracle import kaldi_oracle as KO
+    import kaldi_fuzz_cases as C
+    g, meta = _kaldi_fixture_cases()
+    fn, kw = meta[name]["fn"], dict(meta[name]["kw"])
+    x = g["wav"][max(kw.pop("channel", -1), 0)]
+    if "noise" in meta[name]:
+        kw["noise"] = g[meta[name]["noise"]]
+    C.judge(getattr(KO, fn)(x, **kw), g[name], fn, kw)
+
+
+def test_kaldi_oracle_vs_reference_on_the_fuzz_generator():
+    """... and against the reference's runs of the random configurations the device fuzz family draws (suite seeds;
+    tests/golden/make_kaldi_fuzz_golden.py): the oracle is what the campaign seeds are judged by."""
+    from oracle import kaldi_oracle as KO
+    import kaldi_fuzz_cases as C
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kaldi_fuzz_goldens.npz"))
+    for seed in C.SUITE_SEEDS:
+        fn, wav, kw = C.case(seed)
+        kw = dict(kw)
+        x = wav[kw.pop("channel")]
+        C.judge(getattr(KO, fn)(x, **kw), g[f"seed{seed}"], fn, kw)

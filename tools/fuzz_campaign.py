@@ -19,10 +19,12 @@ def main():
     ap.add_argument("--first", type=int, default=100)
     ap.add_argument("--count", type=int, default=150)
     ap.add_argument("--budget-s", type=float, default=240.0)
+    ap.add_argument("--only", default="", help="substring of the family names to run")
     args = ap.parse_args()
     import torch
     import test_gpu_fuzz as tf
-    families = [n for n in dir(tf) if n.startswith("test_fuzz_") and "seed" in getattr(tf, n).__code__.co_varnames[:1]]
+    families = [n for n in dir(tf) if n.startswith("test_fuzz_") and "seed" in getattr(tf, n).__code__.co_varnames[:1]
+                and args.only in n]
     print(f"# {torch.cuda.get_device_name(0)}; seeds {args.first} .. {args.first + args.count - 1} per family; families: {len(families)}")
     t_start = time.time()
     total = fails = 0

@@ -16,6 +16,7 @@ DESC = [
     (r'r0\d_.*mel400_pool.*', 'tools/bench_pool_ab.py: tail pools of the n_fft = 400 kernel vs static tile runs, through the product API (a -DAAMD_M400_POOLS=1 build)', 'DESIGN 4.1 round 5: built, bit-identical, - 0.8 %, compiled out'),
     (r'r0\d_.*rsm_lab.*', 'tools/rsm_lab.py: A/B of resampler variants (csrc/resample_mfma.h compiled alone per -D variant)', 'DESIGN 4.3 round 5: 8-byte operand reads, priorities, conversion placement'),
     (r'r0\d_.*mel400.*', 'tools/mel400_lab.py A/B runs of headline-kernel variants (interleaved, rotating buffers)', 'DESIGN 4.1 / HISTORY: what moved the headline kernel and what did not'),
+    (r'r0\d_.*fuzz_kaldi.*', 'tools/fuzz_campaign.py --only kaldi_front: the device against oracle/kaldi_oracle.py on random Kaldi configurations', 'DESIGN 2: 1 500 seeds, 0 failed; the oracle against the reference itself on the same seeds'),
     (r'r0\d_.*launch_modes.*', 'bench.py --launch graph | eager on one box', 'DESIGN 5: the K steps as a HIP graph run 83-90 us apart, eager launches 70-71: eager stays the default'),
     (r'r0\d_.*lfw_lab.*', 'tools/lfw_ab.py: A/B of biquad-cascade variants (csrc/lfilter_wave.h compiled alone per -D variant)', 'DESIGN 4.4 round 6: slot 0, split passes; response table / 12 filter waves / mover priority left off'),
     (r'r0\d_.*valu_vgpr_banks.*', 'tools/lab/valu_bank.hip: fp32 VALU rate against the register banks of the sources', 'DESIGN 4.4: no difference'),
