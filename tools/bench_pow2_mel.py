@@ -14,6 +14,9 @@ CASES = [(400, 160, 80), (512, 160, 80), (512, 128, 64), (1024, 256, 80), (1024,
 
 
 def main():
+    global CASES
+    if os.environ.get("P2_ONLY"):                      # e.g. P2_ONLY=512,160,80 (PMC runs)
+        CASES = [tuple(int(v) for v in os.environ["P2_ONLY"].split(","))]
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(3)
     xs = [(0.5 * torch.randn(256, 160000, device=dev, generator=g)).clamp_(-1, 1) for _ in range(3)]
