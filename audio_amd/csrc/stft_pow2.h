@@ -317,9 +317,9 @@ AAMD_HD void mel_stage(int tid, int nthr, const MelBandsDev& mb, float* tab) {
 // neighbouring mels: similar band widths, and the two output rows leave as coalesced stores)
 template <int E>
 AAMD_HD void mel_rows(int lane, const StftGeom& g, const MelBandsDev& mb, const float* tab /* LDS table or null */,
-                      const F2* P, int64_t ta, float* out_row) {
+                      const F2* P, int64_t ta, float* out_row, int m_end) {
   const bool vb = ta + 1 < g.n_frames;
-  for (int m = lane; m < mb.n_mels; m += 64) {
+  for (int m = lane; m < m_end; m += 64) {
     float acc_a = 0.0f, acc_b = 0.0f;
     if (tab) {
       const int ms = mel_stride(mb.max_width);
@@ -344,6 +344,47 @@ AAMD_HD void mel_rows(int lane, const StftGeom& g, const MelBandsDev& mb, const 
     out_row[ta * (int64_t)mb.n_mels + m] = acc_a;
     if (vb) out_row[(ta + 1) * (int64_t)mb.n_mels + m] = acc_b;
   }
+}
+
+// Round 6: the LAST round of the walk holds the widest bands on the fewest lanes (80 mels: 16 lanes walk 13 two-tap steps for
+// n_fft = 512, 26 for 1024, while 48 lanes are masked off -- and an LDS instruction costs its passes whatever the mask).  Its
+// R = n_mels - 64 floor((n_mels - 1) / 64) mels get G = 2 / 4 / 8 lanes each (the largest power of two with G R <= 64): lane ->
+// (mel m0 + lane / G, part lane % G), part p walks the taps [p tl, (p + 1) tl) of the band (tl = ceil(w / G), even), the G partial
+// sums meet in the part-0 lane through row_shl adds.  mel_tail_src names the source lane of a reduction step (-1: none) -- the
+// kernel's DPP controls and the CPU replay's array reads are the same map.
+AAMD_HD int mel_tail_lanes(int n_mels) {
+  const int r = n_mels - 64 * ((n_mels - 1) / 64);
+  int G = 1;
+  while (G < 8 && 2 * G * r <= 64) G *= 2;
+  return G;
+}
+AAMD_HD int mel_tail_first(int n_mels) { return 64 * ((n_mels - 1) / 64); }
+AAMD_HD int mel_tail_src(int step /* 1, 2, 4 */, int lane) { return (lane & 15) + step < 16 ? lane + step : -1; }
+AAMD_HD void mel_tail_partial(int lane, const MelBandsDev& mb, const float* tab, const F2* P, int G, float& pa, float& pb) {
+  pa = 0.0f;
+  pb = 0.0f;
+  const int m = mel_tail_first(mb.n_mels) + lane / G, part = lane % G;
+  if (m >= mb.n_mels) return;
+  const int ms = mel_stride(mb.max_width);
+  const int* lo_tab = reinterpret_cast<const int*>(tab + mb.n_mels * ms);
+  const int lo = lo_tab[m], w = lo_tab[mb.n_mels + m];
+  const int tl = ((w + G - 1) / G + 1) & ~1;
+  const int i0 = part * tl, i1 = i0 + tl < w ? i0 + tl : w;
+  const float* wt = tab + m * ms;
+  const F2* Pf = P + lo;
+  for (int i = i0; i < i1; i += 2) {                 // (an odd end reads one zero-padded tap, as the one-lane walk does)
+    const F2 p0 = Pf[i], p1 = Pf[i + 1];
+    const float w0 = wt[i], w1 = wt[i + 1];
+    pa += w0 * p0.x; pb += w0 * p0.y;
+    pa += w1 * p1.x; pb += w1 * p1.y;
+  }
+}
+AAMD_HD void mel_tail_store(int lane, const StftGeom& g, const MelBandsDev& mb, int G, float pa, float pb, int64_t ta,
+                            float* out_row) {
+  const int m = mel_tail_first(mb.n_mels) + lane / G;
+  if (lane % G != 0 || m >= mb.n_mels) return;
+  out_row[ta * (int64_t)mb.n_mels + m] = pa;
+  if (ta + 1 < g.n_frames) out_row[(ta + 1) * (int64_t)mb.n_mels + m] = pb;
 }
 
 // ---- inverse: frames -> waveform (torch.istft numerator / envelope, or the adjoint of the onesided STFT) ------
@@ -615,6 +656,12 @@ AAMD_D void wave_lds_sync() {     // program order within the wave is the only o
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// lane l <- lane l + N of its row of 16 (zeros past the row's end)
+template <int N>
+AAMD_D float row_shl0(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + N, 0xf, 0xf, true));
+}
+
 template <int E, int EPI>
 __global__ void __launch_bounds__(64 * kWaves)
 stft_pow2_kernel(StftGeom g, const float* __restrict__ wav, const float* __restrict__ window,
@@ -632,6 +679,7 @@ stft_pow2_kernel(StftGeom g, const float* __restrict__ wav, const float* __restr
     __syncthreads();                       // the only workgroup barrier: before the persistent loop
     mel_tab = tab;
   }
+  const int tail_G = (EPI == EPI_MEL && mel_tab != nullptr) ? mel_tail_lanes(mb.n_mels) : 1;      // lanes per mel in the last round
   LaneTab<E> lt;
   lane_tab<E>(lane, window, tw, g.scale, lt);
   const int64_t n_waves = (int64_t)gridDim.x * kWaves;
@@ -683,7 +731,20 @@ stft_pow2_kernel(StftGeom g, const float* __restrict__ wav, const float* __restr
       F2* P = reinterpret_cast<F2*>(lds);
       power_rows<E>(lane, g, A, B, P);
       wave_lds_sync();
-      mel_rows<E>(lane, g, mb, mel_tab, P, ta, out_row);
+      mel_rows<E>(lane, g, mb, mel_tab, P, ta, out_row, tail_G > 1 ? mel_tail_first(mb.n_mels) : mb.n_mels);
+      if (tail_G > 1) {
+        // (an opaque copy of the lane number: the tail's lane-derived addresses hoisted out of the persistent loop cost E = 8 its
+        // fourth wave per SIMD -- 134 registers)
+        int tl_lane = lane;
+        asm volatile("" : "+v"(tl_lane));
+        float pa, pb;
+        mel_tail_partial(tl_lane, mb, mel_tab, P, tail_G, pa, pb);
+        // (all lanes take part: the row_shl moves read zeros past the row's end; a group never crosses a row of 16)
+        pa += row_shl0<1>(pa); pb += row_shl0<1>(pb);
+        if (tail_G > 2) { pa += row_shl0<2>(pa); pb += row_shl0<2>(pb); }
+        if (tail_G > 4) { pa += row_shl0<4>(pa); pb += row_shl0<4>(pb); }
+        mel_tail_store(tl_lane, g, mb, tail_G, pa, pb, ta, out_row);
+      }
     }
   }
 }

@@ -77,7 +77,17 @@ static int sim_pow2_e(const float* wav, const float* window, const float* tw, co
     } else {
       F2* P = reinterpret_cast<F2*>(lds.data());
       for (int l = 0; l < 64; ++l) power_rows<E>(l, g, A[l].data(), B[l].data(), P);
-      for (int l = 0; l < 64; ++l) mel_rows<E>(l, g, mb, mel_tab, P, ta, out_row);
+      const int tail_G = mel_tab ? mel_tail_lanes(mb.n_mels) : 1;
+      for (int l = 0; l < 64; ++l) mel_rows<E>(l, g, mb, mel_tab, P, ta, out_row, tail_G > 1 ? mel_tail_first(mb.n_mels) : mb.n_mels);
+      if (tail_G > 1) {
+        float pa[64], pb[64], ta_[64], tb_[64];
+        for (int l = 0; l < 64; ++l) mel_tail_partial(l, mb, mel_tab, P, tail_G, pa[l], pb[l]);
+        for (int step = 1; step < tail_G; step *= 2) {
+          for (int l = 0; l < 64; ++l) { const int sl = mel_tail_src(step, l); ta_[l] = sl >= 0 ? pa[sl] : 0.0f; tb_[l] = sl >= 0 ? pb[sl] : 0.0f; }
+          for (int l = 0; l < 64; ++l) { pa[l] += ta_[l]; pb[l] += tb_[l]; }
+        }
+        for (int l = 0; l < 64; ++l) mel_tail_store(l, g, mb, tail_G, pa[l], pb[l], ta, out_row);
+      }
     }
   }
   return 0;

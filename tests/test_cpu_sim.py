@@ -576,7 +576,8 @@ def test_sim_stft_pow2_vs_torch_stft(cfg):
     assert peak_rel_err(got, ref.numpy()) <= 2e-6
 
 
-@pytest.mark.parametrize("n_fft,hop,n_mels", [(256, 80, 40), (512, 160, 80), (1024, 256, 128), (2048, 512, 40)])
+@pytest.mark.parametrize("n_fft,hop,n_mels", [(256, 80, 40), (512, 160, 80), (1024, 256, 128), (2048, 512, 40),
+                                               (512, 128, 96), (1024, 256, 72), (512, 160, 65)])   # last round on 2 / 8 / 8 lanes per mel
 def test_sim_mel_pow2_vs_reference_composition(n_fft, hop, n_mels):
     from oracle import torch_cpu_ref as R
     g = torch.Generator().manual_seed(n_fft)
