@@ -577,7 +577,8 @@ def test_sim_stft_pow2_vs_torch_stft(cfg):
 
 
 @pytest.mark.parametrize("n_fft,hop,n_mels", [(256, 80, 40), (512, 160, 80), (1024, 256, 128), (2048, 512, 40),
-                                               (512, 128, 96), (1024, 256, 72), (512, 160, 65)])   # last round on 2 / 8 / 8 lanes per mel
+                                               (512, 128, 96), (1024, 256, 72), (512, 160, 65),      # last round on 2 / 8 / 8 lanes per mel
+                                               (512, 160, 20), (256, 64, 8), (1024, 256, 33)])     # ... the ONLY round on 2 / 8 / 1
 def test_sim_mel_pow2_vs_reference_composition(n_fft, hop, n_mels):
     from oracle import torch_cpu_ref as R
     g = torch.Generator().manual_seed(n_fft)

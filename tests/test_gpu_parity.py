@@ -6,6 +6,7 @@ Tolerances: integer work (shapes, strides, frame indexing) exact; floating point
 import math
 import os
 
+import warnings
 import numpy as np
 import pytest
 import torch
@@ -1418,6 +1419,28 @@ def test_pow2_wave_fft_equals_generic_and_torch_stft(n_fft, hop):
     m = T.MelSpectrogram(sample_rate=48000, n_fft=n_fft, hop_length=hop, n_mels=24, f_min=20.0).cuda()
     x = torch.randn(2, 4 * n_fft, generator=g).clamp_(-1, 1).cuda()
     assert peak_rel_err(m(x).cpu().numpy(), _force_generic(lambda: m(x)).cpu().numpy()) <= 3e-6
+
+
+@pytest.mark.parametrize("n_fft,hop", [(256, 64), (512, 160), (1024, 256), (2048, 512)])
+def test_pow2_mel_band_walk_lanes_per_mel(n_fft, hop):
+    """Round 6: the last round of the power-of-two kernel's band walk runs on G = 1 / 2 / 4 / 8 lanes per mel, G from
+    n_mels alone (mel_tail_lanes): every G, the last round being the only one (n_mels <= 64), full rounds (64, 128), a ragged
+    last frame pair -- against the generic kernel and the float64 composition of torch.stft with the module's own filterbank."""
+    import audio_amd.transforms as T
+    g = torch.Generator().manual_seed(n_fft)
+    x = torch.randn(3, 7 * n_fft + 33, generator=g).clamp_(-1, 1)
+    w64 = torch.hann_window(n_fft, dtype=torch.float64)
+    ref = torch.stft(x.double(), n_fft, hop, n_fft, w64, True, "reflect", False, True, return_complex=True).abs().pow(2)
+    for n_mels in (1, 8, 20, 33, 40, 64, 65, 72, 80, 96, 100, 128, 136):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")          # (narrow filters at the low end have no bin at small n_fft: the reference warns too)
+            m = T.MelSpectrogram(sample_rate=16000, n_fft=n_fft, hop_length=hop, n_mels=n_mels).cuda()
+        fast = m(x.cuda())
+        gen = _force_generic(lambda: m(x.cuda()))
+        exp = torch.matmul(ref.transpose(-1, -2), m.mel_scale.fb.cpu().double()).transpose(-1, -2)
+        assert fast.shape == gen.shape == exp.shape and fast.stride() == gen.stride()
+        assert peak_rel_err(fast.cpu().numpy(), gen.cpu().numpy()) <= 3e-6, n_mels
+        assert peak_rel_err(fast.cpu().numpy(), exp.numpy()) <= 1e-5, n_mels
 
 
 def _assert_rnnt_features_close(got, ref, x_cpu, fe):
